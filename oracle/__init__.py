@@ -1,0 +1,300 @@
+"""ctypes front end of the CPU oracle (oracle/gvrs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from gridfour_amd/.  See gvrs_oracle.h for
+how the restatement is pinned against the reference's fixtures.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgvrs_oracle.so")
+
+OK, DECLINED = 0, 1
+ERR_FORMAT, ERR_BOUNDS, ERR_CAPACITY, ERR_ARG = -1, -2, -3, -4
+INT4_NULL = -(2 ** 31)
+PM_DIFFERENCING, PM_LINEAR, PM_TRIANGLE, PM_DIFFERENCING_NULLS = 1, 2, 3, 4
+
+
+def build(force=False):
+    """Compile libgvrs_oracle.so with gcc (seconds)."""
+    src = os.path.join(_HERE, "gvrs_oracle.c")
+    hdr = os.path.join(_HERE, "gvrs_oracle.h")
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libgvrs_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        try:
+            build()
+        except Exception:
+            if not os.path.exists(_SO):
+                raise
+        L = C.CDLL(_SO)
+        u8p, i32p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+        szp, ip = C.POINTER(C.c_size_t), C.POINTER(C.c_int)
+        L.gvo_m32_encode.argtypes = [C.c_int32, u8p]
+        L.gvo_m32_decode.argtypes = [u8p, szp]
+        L.gvo_m32_decode.restype = C.c_int32
+        L.gvo_predictor_encode.argtypes = [C.c_int, C.c_int, C.c_int, i32p, u8p, i32p]
+        L.gvo_predictor_decode.argtypes = [C.c_int, C.c_int32, C.c_int, C.c_int, u8p, C.c_size_t, i32p]
+        L.gvo_huffman_encode.argtypes = [u8p, C.c_size_t, szp, u8p, C.c_size_t, u8p, szp]
+        L.gvo_huffman_decode.argtypes = [u8p, C.c_size_t, szp, u8p, C.c_size_t]
+        L.gvo_codec_huffman_encode.argtypes = [C.c_int, C.c_int, C.c_int, i32p, u8p, C.c_size_t,
+                                               szp, C.c_int, ip]
+        L.gvo_codec_huffman_decode.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, i32p]
+        L.gvo_codec_huffman_bound.argtypes = [C.c_size_t]
+        L.gvo_codec_huffman_bound.restype = C.c_size_t
+        L.gvo_codec_deflate_encode.argtypes = [C.c_int, C.c_int, C.c_int, i32p, u8p, C.c_size_t, szp, ip]
+        L.gvo_codec_deflate_decode.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, i32p]
+        L.gvo_float_planes_encode.argtypes = [C.c_int, C.c_int, u32p, u8p]
+        L.gvo_float_planes_decode.argtypes = [C.c_int, C.c_int, u8p, u32p]
+        L.gvo_codec_float_encode.argtypes = [C.c_int, C.c_int, C.c_int, u32p, C.c_int, u8p,
+                                             C.c_size_t, szp]
+        L.gvo_codec_float_decode.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, u32p]
+        L.gvo_batch_huffman_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, i32p, u8p,
+                                               C.c_size_t, u32p, u8p]
+        L.gvo_batch_huffman_decode.argtypes = [C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t,
+                                               u32p, i32p]
+        L.gvo_splitmix64.argtypes = [C.c_uint64]
+        L.gvo_splitmix64.restype = C.c_uint64
+        L.gvo_dem_value.argtypes = [C.c_uint64, C.c_int64, C.c_int64]
+        L.gvo_dem_value.restype = C.c_int32
+        L.gvo_dem_fill_tiles.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                         C.c_int64, i32p]
+        L.gvo_dem_fill_tiles.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    if isinstance(a, (bytes, bytearray)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+# ---- M32 ----
+def m32_encode(value):
+    out = np.zeros(8, np.uint8)
+    n = lib().gvo_m32_encode(int(value), _p(out, C.c_uint8))
+    return bytes(out[:n])
+
+
+def m32_encode_seq(values):
+    return b"".join(m32_encode(v) for v in values)
+
+
+def m32_decode_seq(data, count):
+    buf = _u8(data)
+    buf = np.concatenate([buf, np.zeros(8, np.uint8)])
+    pos = C.c_size_t(0)
+    out = []
+    for _ in range(count):
+        out.append(lib().gvo_m32_decode(_p(buf, C.c_uint8), C.byref(pos)))
+    return out, pos.value
+
+
+# ---- predictors ----
+def predictor_encode(model, n_rows, n_cols, values):
+    v = _i32(values).ravel()
+    out = np.zeros(6 * v.size + 8, np.uint8)
+    seed = C.c_int32(0)
+    n = lib().gvo_predictor_encode(model, n_rows, n_cols, _p(v, C.c_int32), _p(out, C.c_uint8),
+                                   C.byref(seed))
+    if n < 0:
+        return None, 0
+    return bytes(out[:n]), seed.value
+
+
+def predictor_decode(model, seed, n_rows, n_cols, m32):
+    m = np.concatenate([_u8(m32), np.zeros(6 * n_rows * n_cols + 8, np.uint8)])
+    out = np.zeros(n_rows * n_cols, np.int32)
+    rc = lib().gvo_predictor_decode(model, seed, n_rows, n_cols, _p(m, C.c_uint8), len(m32),
+                                    _p(out, C.c_int32))
+    if rc != OK:
+        raise ValueError("predictor_decode rc=%d" % rc)
+    return out
+
+
+# ---- Huffman over a bit buffer ----
+def huffman_encode(symbols, bit_pos=0, prefix=b""):
+    """Returns (bytes, end_bit_pos, code_lengths[256], tree_bits)."""
+    s = _u8(symbols)
+    cap = len(prefix) + 400 + 32 * s.size + 64
+    buf = np.zeros(cap, np.uint8)
+    buf[:len(prefix)] = np.frombuffer(prefix, np.uint8) if prefix else []
+    pos = C.c_size_t(bit_pos)
+    cl = np.zeros(256, np.uint8)
+    tb = C.c_size_t(0)
+    rc = lib().gvo_huffman_encode(_p(buf, C.c_uint8), cap * 8, C.byref(pos), _p(s, C.c_uint8),
+                                  s.size, _p(cl, C.c_uint8), C.byref(tb))
+    if rc != OK:
+        raise ValueError("huffman_encode rc=%d" % rc)
+    return bytes(buf[:(pos.value + 7) // 8]), pos.value, cl, tb.value
+
+
+def huffman_decode(data, n_symbols, bit_pos=0):
+    b = _u8(data)
+    out = np.zeros(max(n_symbols, 1), np.uint8)
+    pos = C.c_size_t(bit_pos)
+    rc = lib().gvo_huffman_decode(_p(b, C.c_uint8), b.size * 8, C.byref(pos), _p(out, C.c_uint8),
+                                  n_symbols)
+    if rc != OK:
+        raise ValueError("huffman_decode rc=%d" % rc)
+    return bytes(out[:n_symbols]), pos.value
+
+
+# ---- CodecHuffman ----
+def codec_huffman_encode(codec_index, n_rows, n_cols, values, predictor_mask=0xF):
+    """Returns (packing bytes | None, predictor_used)."""
+    v = _i32(values).ravel()
+    assert v.size == n_rows * n_cols
+    cap = 4 * v.size + 4096
+    while True:
+        out = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        used = C.c_int(0)
+        rc = lib().gvo_codec_huffman_encode(codec_index, n_rows, n_cols, _p(v, C.c_int32),
+                                            _p(out, C.c_uint8), cap, C.byref(n), predictor_mask,
+                                            C.byref(used))
+        if rc == ERR_CAPACITY:
+            cap = n.value + 16
+            continue
+        break
+    if rc == DECLINED:
+        return None, 0
+    if rc != OK:
+        raise ValueError("codec_huffman_encode rc=%d" % rc)
+    return bytes(out[:n.value]), used.value
+
+
+def codec_huffman_decode(n_rows, n_cols, packing):
+    p = _u8(packing)
+    out = np.zeros(n_rows * n_cols, np.int32)
+    rc = lib().gvo_codec_huffman_decode(n_rows, n_cols, _p(p, C.c_uint8), p.size, _p(out, C.c_int32))
+    if rc != OK:
+        raise IOError("codec_huffman_decode rc=%d" % rc)
+    return out
+
+
+# ---- CodecDeflate ----
+def codec_deflate_encode(codec_index, n_rows, n_cols, values):
+    v = _i32(values).ravel()
+    cap = 6 * v.size + 256
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    used = C.c_int(0)
+    rc = lib().gvo_codec_deflate_encode(codec_index, n_rows, n_cols, _p(v, C.c_int32),
+                                        _p(out, C.c_uint8), cap, C.byref(n), C.byref(used))
+    if rc == DECLINED:
+        return None, 0
+    if rc != OK:
+        raise ValueError("codec_deflate_encode rc=%d" % rc)
+    return bytes(out[:n.value]), used.value
+
+
+def codec_deflate_decode(n_rows, n_cols, packing):
+    p = _u8(packing)
+    out = np.zeros(n_rows * n_cols, np.int32)
+    rc = lib().gvo_codec_deflate_decode(n_rows, n_cols, _p(p, C.c_uint8), p.size, _p(out, C.c_int32))
+    if rc != OK:
+        raise IOError("codec_deflate_decode rc=%d" % rc)
+    return out
+
+
+# ---- CodecFloat ----
+def float_planes_encode(n_rows, n_cols, raw_bits):
+    c = np.ascontiguousarray(raw_bits, dtype=np.uint32).ravel()
+    n = c.size
+    planes = np.zeros((n + 7) // 8 + 4 * n, np.uint8)
+    lib().gvo_float_planes_encode(n_rows, n_cols, _p(c, C.c_uint32), _p(planes, C.c_uint8))
+    return planes
+
+
+def float_planes_decode(n_rows, n_cols, planes):
+    p = _u8(planes)
+    out = np.zeros(n_rows * n_cols, np.uint32)
+    lib().gvo_float_planes_decode(n_rows, n_cols, _p(p, C.c_uint8), _p(out, C.c_uint32))
+    return out
+
+
+def codec_float_encode(codec_index, n_rows, n_cols, raw_bits, level=9):
+    c = np.ascontiguousarray(raw_bits, dtype=np.uint32).ravel()
+    cap = 5 * c.size + 1024
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().gvo_codec_float_encode(codec_index, n_rows, n_cols, _p(c, C.c_uint32), level,
+                                      _p(out, C.c_uint8), cap, C.byref(n))
+    if rc != OK:
+        raise ValueError("codec_float_encode rc=%d" % rc)
+    return bytes(out[:n.value])
+
+
+def codec_float_decode(n_rows, n_cols, packing):
+    p = _u8(packing)
+    out = np.zeros(n_rows * n_cols, np.uint32)
+    rc = lib().gvo_codec_float_decode(n_rows, n_cols, _p(p, C.c_uint8), p.size, _p(out, C.c_uint32))
+    if rc != OK:
+        raise IOError("codec_float_decode rc=%d" % rc)
+    return out
+
+
+# ---- batch (CPU baseline) ----
+def batch_huffman_encode(codec_index, n_rows, n_cols, tiles, stride=None):
+    """tiles: int32 [n_tiles, n_rows*n_cols].  Returns (out[n_tiles, stride], lengths, predictors)."""
+    v = _i32(tiles).reshape(-1, n_rows * n_cols)
+    nt = v.shape[0]
+    if stride is None:
+        stride = 4 * n_rows * n_cols + 4096
+    out = np.zeros((nt, stride), np.uint8)
+    lengths = np.zeros(nt, np.uint32)
+    preds = np.zeros(nt, np.uint8)
+    rc = lib().gvo_batch_huffman_encode(codec_index, n_rows, n_cols, nt, _p(v, C.c_int32),
+                                        _p(out, C.c_uint8), stride, _p(lengths, C.c_uint32),
+                                        _p(preds, C.c_uint8))
+    if rc != OK:
+        raise ValueError("batch_huffman_encode rc=%d" % rc)
+    return out, lengths, preds
+
+
+def batch_huffman_decode(n_rows, n_cols, packings, lengths):
+    p = _u8(packings)
+    nt, stride = p.shape
+    ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+    out = np.zeros((nt, n_rows * n_cols), np.int32)
+    rc = lib().gvo_batch_huffman_decode(n_rows, n_cols, nt, _p(p, C.c_uint8), stride,
+                                        _p(ln, C.c_uint32), _p(out, C.c_int32))
+    if rc != OK:
+        raise IOError("batch_huffman_decode rc=%d" % rc)
+    return out
+
+
+# ---- synthetic DEM ----
+DEM_SEED = 0x9E3779B97F4A7C15
+
+
+def dem_tiles(seed, n_rows, n_cols, tiles_per_row, tile0, n_tiles):
+    out = np.zeros((n_tiles, n_rows * n_cols), np.int32)
+    lib().gvo_dem_fill_tiles(seed & (2 ** 64 - 1), n_rows, n_cols, tiles_per_row, tile0, n_tiles,
+                             _p(out, C.c_int32))
+    return out

@@ -1,0 +1,126 @@
+/*
+ * gvrs_oracle.h -- CPU restatement ("oracle") of the Gridfour GVRS tile-codec
+ * hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  It is the parity checker for the HIP codec and
+ * the `cpu_baseline` leg of bench.py.  Nothing in the product path
+ * (gridfour_amd/, include/) may call, link or import it.
+ *
+ * Parity pinning: the restatement is checked in tests/test_oracle_golden.py
+ * against the reference's own binary fixtures
+ *   core/src/test/resources/org/gridfour/gvrs/SampleFiles/Sample05_IntComp.gvrs
+ *   .../Sample06_FltComp.gvrs, .../Sample14_LSOP.gvrs
+ * (copied as data under tests/golden/ref_samples/), the M32 known-answer table
+ * of core/src/test/java/org/gridfour/compress/CodecM32Test.java:95-112 and the
+ * byte examples of CodecM32.java:82-89.  What no reference fixture pins is
+ * listed in DESIGN.md ("unpinned").
+ *
+ * Each function cites the reference file:line it follows.  Paths are relative
+ * to core/src/main/java/org/gridfour/ in the reference repository.
+ */
+#ifndef GVRS_ORACLE_H
+#define GVRS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVO_OK 0
+#define GVO_DECLINED 1        /* Java encoder would return null            */
+#define GVO_ERR_FORMAT (-1)   /* Java decoder would throw IOException      */
+#define GVO_ERR_BOUNDS (-2)   /* Java would throw ArrayIndexOutOfBounds    */
+#define GVO_ERR_CAPACITY (-3) /* caller's output buffer too small          */
+#define GVO_ERR_ARG (-4)
+
+#define GVO_INT4_NULL ((int32_t)0x80000000) /* util/GridfourConstants.java:61 */
+
+/* predictor codes, compress/PredictorModelType.java:46-63 */
+enum { GVO_PM_NONE = 0, GVO_PM_DIFFERENCING = 1, GVO_PM_LINEAR = 2,
+       GVO_PM_TRIANGLE = 3, GVO_PM_DIFFERENCING_NULLS = 4 };
+
+/* ---- CodecM32 (compress/CodecM32.java:257-311, 327-356) ---- */
+/* appends the M32 form of value at out, returns the number of bytes (1..6) */
+int gvo_m32_encode(int32_t value, uint8_t *out);
+/* decodes one value at buf[*pos], advances *pos; no bounds checks (as the reference) */
+int32_t gvo_m32_decode(const uint8_t *buf, size_t *pos);
+
+/* ---- predictors (compress/PredictorModel*.java) ----
+ * encode: returns number of M32 bytes written to out (capacity 6*nRows*nCols),
+ *         -1 when the model declines (Triangle with <2 rows/cols), seed in *seed.
+ * decode: fills values[nRows*nCols] from the M32 bytes.                     */
+int gvo_predictor_encode(int model, int nRows, int nCols, const int32_t *values,
+                         uint8_t *out, int32_t *seed);
+int gvo_predictor_decode(int model, int32_t seed, int nRows, int nCols,
+                         const uint8_t *m32, size_t nM32, int32_t *values);
+
+/* ---- legacy Huffman (compress/HuffmanEncoder.java:124-305,
+ *      compress/HuffmanDecoder.java:65-187) over a bit store
+ *      (io/BitOutputStore.java, io/BitInputStore.java: LSB-first) ---- */
+/* Appends tree+text to a zeroed bit buffer `bits` starting at *bitPos.
+ * capBits = capacity in bits. Returns GVO_OK or GVO_ERR_CAPACITY.
+ * codeLen256/treeBits are optional diagnostics (may be NULL).               */
+int gvo_huffman_encode(uint8_t *bits, size_t capBits, size_t *bitPos,
+                       const uint8_t *symbols, size_t nSymbols,
+                       uint8_t *codeLen256, size_t *treeBits);
+/* Decodes nSymbols starting at *bitPos from a buffer of nBitsTotal bits.    */
+int gvo_huffman_decode(const uint8_t *bits, size_t nBitsTotal, size_t *bitPos,
+                       uint8_t *symbols, size_t nSymbols);
+
+/* ---- CodecHuffman (compress/CodecHuffman.java:70-153) ---- */
+/* predictorMask: bit (model-1) set = model may be tried; 0xF = reference
+ * behaviour (all registered models).  *predictorUsed receives the model of
+ * the returned packing.  Returns GVO_OK, GVO_DECLINED (null), or error.     */
+int gvo_codec_huffman_encode(int codecIndex, int nRows, int nCols,
+                             const int32_t *values, uint8_t *out, size_t outCap,
+                             size_t *outLen, int predictorMask, int *predictorUsed);
+int gvo_codec_huffman_decode(int nRows, int nCols, const uint8_t *packing,
+                             size_t len, int32_t *values);
+/* worst-case packing size for a tile with nCells cells */
+size_t gvo_codec_huffman_bound(size_t nCells);
+
+/* ---- CodecDeflate (compress/CodecDeflate.java:108-228), zlib level 6 ---- */
+int gvo_codec_deflate_encode(int codecIndex, int nRows, int nCols,
+                             const int32_t *values, uint8_t *out, size_t outCap,
+                             size_t *outLen, int *predictorUsed);
+int gvo_codec_deflate_decode(int nRows, int nCols, const uint8_t *packing,
+                             size_t len, int32_t *values);
+
+/* ---- CodecFloat (compress/CodecFloat.java:300-458) ---- */
+/* the five byte planes before Deflate: sign bits (ceil(n/8)), exponent (n),
+ * delta-coded mantissa hi/mid/lo (n each).  planes must hold ceil(n/8)+4n.  */
+int gvo_float_planes_encode(int nRows, int nCols, const uint32_t *rawBits,
+                            uint8_t *planes);
+int gvo_float_planes_decode(int nRows, int nCols, const uint8_t *planes,
+                            uint32_t *rawBits);
+/* full codec; level = zlib level (reference source: 9; sample files: 6)     */
+int gvo_codec_float_encode(int codecIndex, int nRows, int nCols,
+                           const uint32_t *rawBits, int level, uint8_t *out,
+                           size_t outCap, size_t *outLen);
+int gvo_codec_float_decode(int nRows, int nCols, const uint8_t *packing,
+                           size_t len, uint32_t *rawBits);
+
+/* ---- batch helpers used by the CPU baseline (plain loops over tiles) ---- */
+/* tiles are contiguous, nRows*nCols each.  out slots have `stride` bytes.   */
+int gvo_batch_huffman_encode(int codecIndex, int nRows, int nCols, size_t nTiles,
+                             const int32_t *values, uint8_t *out, size_t stride,
+                             uint32_t *lengths, uint8_t *predictors);
+int gvo_batch_huffman_decode(int nRows, int nCols, size_t nTiles,
+                             const uint8_t *packings, size_t stride,
+                             const uint32_t *lengths, int32_t *values);
+
+/* ---- deterministic synthetic DEM, integer only ---- */
+uint64_t gvo_splitmix64(uint64_t x);
+/* value of the synthetic elevation field at grid cell (gx, gy)              */
+int32_t gvo_dem_value(uint64_t seed, int64_t gx, int64_t gy);
+/* fills nTiles tiles (tile t = tile row t / tilesPerRow, col t % tilesPerRow
+ * of a grid cut into nRows x nCols tiles), starting at tile index tile0.     */
+void gvo_dem_fill_tiles(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                        int64_t tile0, int64_t nTiles, int32_t *values);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
