@@ -1,0 +1,92 @@
+"""ctypes binding of libgvrs_hip.so (the C ABI in include/gvrs_hip_codec.h).
+
+There is deliberately no fallback: if the library cannot be loaded the import fails, and
+if no HIP device is present every compute call fails with GF_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK, DECLINED, OVERFLOW = 0, 1, 2
+ERR_FORMAT, ERR_BOUNDS, ERR_CAPACITY, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+PM_ALL = 0xF
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); this table is also what tests/test_abi_symbols.py checks
+# against include/gvrs_hip_codec.h
+SIGNATURES = {
+    "gf_version": (C.c_char_p, []),
+    "gf_status_string": (C.c_char_p, [C.c_int]),
+    "gf_last_error": (C.c_char_p, []),
+    "gf_device_count": (C.c_int, []),
+    "gf_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "gf_context_destroy": (None, [_vp]),
+    "gf_context_reserve": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t]),
+    "gf_context_stream": (_vp, [_vp]),
+    "gf_context_synchronize": (C.c_int, [_vp]),
+    "gf_huffman_default_stride": (C.c_size_t, [C.c_int, C.c_int]),
+    "gf_huffman_max_packing": (C.c_size_t, [C.c_int, C.c_int]),
+    "gf_huffman_encode_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gf_huffman_decode_i32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
+    "gf_huffman_encode_batch_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t,
+                                              _vp, _vp, _vp]),
+    "gf_huffman_decode_batch_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_huffman_encode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp,
+                                                  C.c_size_t, _vp, _vp, _vp, C.c_int]),
+    "gf_huffman_decode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp,
+                                                  C.c_size_t, _vp, _vp, _vp]),
+    "gf_compact_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t]),
+    "gf_synth_dem_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_size_t, _vp]),
+    "gf_dev_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "gf_dev_free": (C.c_int, [_vp, _vp]),
+    "gf_dev_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    "gf_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "gf_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "gf_timer_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "gf_timer_destroy": (None, [_vp]),
+    "gf_timer_start": (C.c_int, [_vp, _vp]),
+    "gf_timer_stop": (C.c_int, [_vp, _vp]),
+    "gf_timer_elapsed_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class GvrsHipError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = lib().gf_status_string(status).decode()
+        detail = lib().gf_last_error().decode()
+        super().__init__("%s: %s%s" % (where, msg, (" [" + detail + "]") if detail else ""))
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """Loads libgvrs_hip.so (building it first if the sources are newer).  Raises if it
+    cannot be built or loaded -- the HIP library is the only implementation."""
+    global _lib
+    if _lib is None:
+        if _build.needs_build():
+            _build.build()
+        L = C.CDLL(_build.LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)           # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, where=""):
+    if status < 0:
+        raise GvrsHipError(status, where)
+    return status

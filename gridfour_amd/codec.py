@@ -1,0 +1,283 @@
+"""Host-side mirror of the reference plug-in interface for the HIP codec.
+
+`CodecHuffmanHip` carries the method names, argument meaning and error behaviour of the
+reference's `ICompressionEncoder` / `ICompressionDecoder` as implemented by `CodecHuffman`
+(core/src/main/java/org/gridfour/compress/ICompressionEncoder.java:61-91,
+ICompressionDecoder.java:62-105, CodecHuffman.java:70-153):
+
+  encode(codecIndex, nRows, nCols, values) -> bytes | None      (None = Java null)
+  decode(nRows, nColumns, packing) -> int32 array, raises IOError (= IOException)
+  encodeFloats / decodeFloats -> None, implementsIntegerEncoding() -> True, ...
+
+plus the batched forms the GPU needs (one launch per batch of tiles, not per tile).
+All compute happens in libgvrs_hip.so; nothing here has a CPU implementation.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+INT4_NULL_CODE = -(2 ** 31)   # util/GridfourConstants.java:61
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class GvrsHipContext:
+    """One device context (stream + workspace); one per process and GPU."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().gf_context_create(int(device), C.byref(self._h)), "gf_context_create")
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self):
+        return lib().gf_context_stream(self._h)
+
+    def synchronize(self):
+        check(lib().gf_context_synchronize(self._h), "gf_context_synchronize")
+
+    def reserve(self, n_rows, n_cols, n_tiles):
+        check(lib().gf_context_reserve(self._h, n_rows, n_cols, n_tiles), "gf_context_reserve")
+
+    def close(self):
+        if self._h:
+            lib().gf_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CodecHuffmanHip:
+    """Drop-in for org.gridfour.compress.CodecHuffman, computed on the MI355X."""
+
+    def __init__(self, context=None, device=0):
+        self.ctx = context if context is not None else GvrsHipContext(device)
+
+    # ---- ICompressionEncoder ----
+    def encode(self, codecIndex, nRows, nCols, values):
+        v = np.ascontiguousarray(values, dtype=np.int32).ravel()
+        if v.size != nRows * nCols:
+            raise ValueError("values.length != nRows*nCols")
+        cap = int(lib().gf_huffman_max_packing(nRows, nCols))
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        st = lib().gf_huffman_encode_i32(self.ctx.handle, codecIndex, nRows, nCols, _ptr(v), _ptr(out), cap,
+                                         C.byref(n))
+        if st == _lib.DECLINED:
+            return None
+        if st == _lib.ERR_BOUNDS:
+            raise IndexError("ArrayIndexOutOfBoundsException in the reference for these dimensions")
+        check(st, "gf_huffman_encode_i32")
+        return bytes(out[:n.value])
+
+    def encodeFloats(self, codecIndex, nRows, nCols, values):
+        return None                                  # CodecHuffman.java:237-239
+
+    def implementsFloatingPointEncoding(self):
+        return False
+
+    def implementsIntegerEncoding(self):
+        return True
+
+    # ---- ICompressionDecoder ----
+    def decode(self, nRows, nColumns, packing):
+        p = np.frombuffer(bytes(packing), dtype=np.uint8)
+        out = np.empty(nRows * nColumns, np.int32)
+        st = lib().gf_huffman_decode_i32(self.ctx.handle, nRows, nColumns, _ptr(p), p.size, _ptr(out))
+        if st in (_lib.ERR_FORMAT, _lib.ERR_BOUNDS):
+            raise IOError(lib().gf_status_string(st).decode())
+        check(st, "gf_huffman_decode_i32")
+        return out
+
+    def decodeFloats(self, nRows, nColumns, packing):
+        return None                                  # CodecHuffman.java:242-244
+
+    # ---- batched forms (host memory) ----
+    def encode_batch(self, codecIndex, nRows, nCols, tiles):
+        """tiles: int32 [nTiles, nRows*nCols].  Returns (packings: list[bytes|None], predictors, status)."""
+        v = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        cap = nt * int(lib().gf_huffman_default_stride(nRows, nCols))
+        offsets = np.zeros(nt + 1, np.uint64)
+        preds = np.zeros(nt, np.uint8)
+        status = np.zeros(nt, np.int32)
+        while True:
+            blob = np.empty(max(cap, 16), np.uint8)
+            st = lib().gf_huffman_encode_batch_i32(self.ctx.handle, codecIndex, nRows, nCols, nt, _ptr(v),
+                                                   _ptr(blob), cap, _ptr(offsets), _ptr(preds), _ptr(status))
+            if st == _lib.ERR_CAPACITY:
+                cap = int(offsets[nt]) + 16
+                continue
+            check(st, "gf_huffman_encode_batch_i32")
+            break
+        packs = []
+        for t in range(nt):
+            if status[t] == _lib.OK:
+                packs.append(bytes(blob[int(offsets[t]):int(offsets[t + 1])]))
+            else:
+                packs.append(None)
+        return packs, preds, status
+
+    def decode_batch(self, nRows, nCols, packings):
+        """packings: list of bytes.  Returns (values int32 [nTiles, cells], status)."""
+        nt = len(packings)
+        offsets = np.zeros(nt + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(p) for p in packings])
+        blob = np.frombuffer(b"".join(packings) + b"\0" * 16, dtype=np.uint8)
+        out = np.empty((nt, nRows * nCols), np.int32)
+        status = np.zeros(nt, np.int32)
+        check(lib().gf_huffman_decode_batch_i32(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets),
+                                                _ptr(out), _ptr(status)), "gf_huffman_decode_batch_i32")
+        return out, status
+
+
+class DeviceBuffer:
+    """A raw device allocation owned through the C ABI (no torch needed)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().gf_dev_malloc(ctx.handle, max(self.nbytes, 16), C.byref(p)), "gf_dev_malloc")
+        self.ptr = p
+
+    def upload(self, array, byte_offset=0):
+        a = np.ascontiguousarray(array)
+        assert byte_offset + a.nbytes <= max(self.nbytes, 16)
+        check(lib().gf_dev_upload(self.ctx.handle, C.c_void_p(self.ptr.value + byte_offset), _ptr(a), a.nbytes),
+              "gf_dev_upload")
+        return self
+
+    def download(self, dtype, count, byte_offset=0):
+        out = np.empty(count, dtype)
+        assert byte_offset + out.nbytes <= max(self.nbytes, 16)
+        check(lib().gf_dev_download(self.ctx.handle, _ptr(out), C.c_void_p(self.ptr.value + byte_offset),
+                                    out.nbytes), "gf_dev_download")
+        return out
+
+    def fill(self, value=0):
+        check(lib().gf_dev_memset(self.ctx.handle, self.ptr, value, self.nbytes), "gf_dev_memset")
+        return self
+
+    def free(self):
+        if self.ptr:
+            lib().gf_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceTileBatch:
+    """Device-resident batch of tiles and their packings: the measured hot path.
+
+    encode(): values -> slots/lengths/predictors/status   (gf_huffman_encode_batch_i32_dev)
+    decode(): slots/lengths -> decoded/status              (gf_huffman_decode_batch_i32_dev)
+    Nothing synchronises unless asked; everything is enqueued on `stream` (default: the
+    context's stream).
+    """
+
+    def __init__(self, ctx, n_rows, n_cols, n_tiles, slot_stride=None):
+        self.ctx, self.n_rows, self.n_cols, self.n_tiles = ctx, int(n_rows), int(n_cols), int(n_tiles)
+        self.cells = self.n_rows * self.n_cols
+        self.stride = int(slot_stride or lib().gf_huffman_default_stride(n_rows, n_cols))
+        assert self.stride % 16 == 0
+        nt = self.n_tiles
+        self.values = DeviceBuffer(ctx, nt * self.cells * 4)
+        self.decoded = DeviceBuffer(ctx, nt * self.cells * 4)
+        self.slots = DeviceBuffer(ctx, nt * self.stride + 16)
+        self.lengths = DeviceBuffer(ctx, nt * 4)
+        self.predictors = DeviceBuffer(ctx, nt)
+        self.enc_status = DeviceBuffer(ctx, nt * 4)
+        self.dec_status = DeviceBuffer(ctx, nt * 4)
+        ctx.reserve(n_rows, n_cols, nt)
+
+    def synth_dem(self, seed, tiles_per_row, tile0=0, stream=None):
+        check(lib().gf_synth_dem_dev(self.ctx.handle, stream, seed & (2 ** 64 - 1), self.n_rows, self.n_cols,
+                                     tiles_per_row, tile0, self.n_tiles, self.values.ptr), "gf_synth_dem_dev")
+
+    def encode(self, codec_index=0, predictor_mask=_lib.PM_ALL, stream=None):
+        check(lib().gf_huffman_encode_batch_i32_dev(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols,
+                                                    self.n_tiles, self.values.ptr, self.slots.ptr, self.stride,
+                                                    self.lengths.ptr, self.predictors.ptr, self.enc_status.ptr,
+                                                    predictor_mask), "gf_huffman_encode_batch_i32_dev")
+
+    def decode(self, stream=None):
+        check(lib().gf_huffman_decode_batch_i32_dev(self.ctx.handle, stream, self.n_rows, self.n_cols, self.n_tiles,
+                                                    self.slots.ptr, self.n_tiles * self.stride, None, self.stride,
+                                                    self.lengths.ptr, self.decoded.ptr, self.dec_status.ptr),
+              "gf_huffman_decode_batch_i32_dev")
+
+    # host views (synchronising copies)
+    def get_lengths(self):
+        return self.lengths.download(np.uint32, self.n_tiles)
+
+    def get_predictors(self):
+        return self.predictors.download(np.uint8, self.n_tiles)
+
+    def get_enc_status(self):
+        return self.enc_status.download(np.int32, self.n_tiles)
+
+    def get_dec_status(self):
+        return self.dec_status.download(np.int32, self.n_tiles)
+
+    def get_packing(self, t, length=None):
+        if length is None:
+            length = int(self.lengths.download(np.uint32, 1, 4 * t)[0])
+        return bytes(self.slots.download(np.uint8, length, t * self.stride))
+
+    def get_values(self, t0=0, n=None):
+        n = self.n_tiles - t0 if n is None else n
+        return self.values.download(np.int32, n * self.cells, t0 * self.cells * 4).reshape(n, self.cells)
+
+    def get_decoded(self, t0=0, n=None):
+        n = self.n_tiles - t0 if n is None else n
+        return self.decoded.download(np.int32, n * self.cells, t0 * self.cells * 4).reshape(n, self.cells)
+
+    def free(self):
+        for b in (self.values, self.decoded, self.slots, self.lengths, self.predictors, self.enc_status,
+                  self.dec_status):
+            b.free()
+
+
+class GpuTimer:
+    """HIP-event timer on the stream the kernels are launched on (gf_timer_*)."""
+
+    def __init__(self, ctx):
+        self._h = C.c_void_p()
+        check(lib().gf_timer_create(ctx.handle, C.byref(self._h)), "gf_timer_create")
+
+    def start(self, stream=None):
+        check(lib().gf_timer_start(self._h, stream), "gf_timer_start")
+
+    def stop(self, stream=None):
+        check(lib().gf_timer_stop(self._h, stream), "gf_timer_stop")
+
+    def elapsed_ms(self):
+        ms = C.c_float(0)
+        check(lib().gf_timer_elapsed_ms(self._h, C.byref(ms)), "gf_timer_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gf_timer_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass

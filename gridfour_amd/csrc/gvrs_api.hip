@@ -1,0 +1,495 @@
+// gvrs_api.hip -- the C ABI of include/gvrs_hip_codec.h: context, device-resident batch
+// entry points (what bench.py measures) and the host-memory entry points a JNI / FFI
+// binding of ICompressionEncoder / ICompressionDecoder calls.  No CPU fallback anywhere:
+// every compute call needs a HIP device.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gvrs_hip_codec.h"
+#include "gvrs_kernels.h"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+gf_status hipFail(hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    g_lastError = buf;
+    return GF_ERR_HIP;
+}
+
+#define GF_HIP(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return hipFail(e_, #call); \
+    } while (0)
+
+size_t roundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    gf_status ensure(size_t need)
+    {
+        if (need <= bytes) return GF_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        need = roundUp(need + need / 8, 1 << 20);
+        GF_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return GF_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct gf_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf workspace;      // decode spill: grid * 6*cells
+    // staging for the host-memory entry points
+    DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
+};
+
+struct gf_timer {
+    gf_context *ctx;
+    hipEvent_t start, stop;
+};
+
+extern "C" {
+
+const char *gf_version(void) { return "gvrs-hip-codec 0.1 (gfx950)"; }
+
+const char *gf_status_string(int s)
+{
+    switch (s) {
+    case GF_OK: return "ok";
+    case GF_DECLINED: return "declined (encoder returns null)";
+    case GF_OVERFLOW: return "packing larger than the output slot";
+    case GF_ERR_FORMAT: return "format error (IOException in the reference)";
+    case GF_ERR_BOUNDS: return "out of bounds (ArrayIndexOutOfBounds in the reference)";
+    case GF_ERR_CAPACITY: return "output buffer too small";
+    case GF_ERR_ARG: return "bad argument";
+    case GF_ERR_NO_DEVICE: return "no HIP device";
+    case GF_ERR_HIP: return "HIP runtime error";
+    case GF_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+const char *gf_last_error(void) { return g_lastError.c_str(); }
+
+int gf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+gf_status gf_context_create(int device, gf_context **out)
+{
+    if (!out) return GF_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_lastError = "no HIP device visible";
+        return GF_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return GF_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return GF_ERR_NO_DEVICE;
+    gf_context *c = new (std::nothrow) gf_context();
+    if (!c) return GF_ERR_ARG;
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        hipFail(e, "hipStreamCreate");
+        return GF_ERR_NO_DEVICE;
+    }
+    *out = c;
+    return GF_OK;
+}
+
+void gf_context_destroy(gf_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->workspace.release();
+    c->dValues.release();
+    c->dSlots.release();
+    c->dBlob.release();
+    c->dLengths.release();
+    c->dPred.release();
+    c->dStatus.release();
+    c->dOffsets.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *gf_context_stream(gf_context *c) { return c ? (void *)c->stream : nullptr; }
+
+gf_status gf_context_synchronize(gf_context *c)
+{
+    if (!c) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    return GF_OK;
+}
+
+static size_t decodeWorkspaceStride(int nRows, int nCols)
+{
+    return roundUp((size_t)6 * (size_t)nRows * (size_t)nCols + 16, 16);
+}
+
+gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
+{
+    if (!c || nRows < 1 || nCols < 1) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const unsigned grid = gf_huffman_decode_grid(nTiles);
+    return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
+}
+
+size_t gf_huffman_default_stride(int nRows, int nCols)
+{
+    return roundUp((size_t)4 * (size_t)nRows * (size_t)nCols + 1024, 16);
+}
+
+size_t gf_huffman_max_packing(int nRows, int nCols)
+{
+    // 80 header bits + tree (8 + 10*256 - 1) + 6 M32 bytes per cell at <= 46 bits per code
+    // (depth d needs Fib(d+2) symbols; nM32 < 2^31 bounds d by 44)
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const size_t bits = 80 + 8 + 2559 + cells * 6 * 46;
+    return roundUp((bits + 7) / 8 + 16, 16);
+}
+
+// ------------------------------------------------------------------ device-resident
+
+gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
+                                          size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
+                                          uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus,
+                                          int predictorMask)
+{
+    if (!c || nRows < 1 || nCols < 1 || !dValues || !dOut || !dLengths || !dStatus) return GF_ERR_ARG;
+    if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
+    if (slotStride % 16 != 0 || ((uintptr_t)dOut & 15) != 0 || slotStride < 16) return GF_ERR_ARG;
+    GfEncodeArgs a;
+    a.values = dValues;
+    a.out = dOut;
+    a.lengths = dLengths;
+    a.predictors = dPredictors;
+    a.status = dStatus;
+    a.nTiles = nTiles;
+    a.slotStride = slotStride;
+    a.nRows = nRows;
+    a.nCols = nCols;
+    a.codecIndex = codecIndex;
+    a.predictorMask = predictorMask & GF_PM_ALL;
+    GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
+    return GF_OK;
+}
+
+gf_status gf_huffman_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
+                                          const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets,
+                                          size_t slotStride, const uint32_t *dLengths, int32_t *dValues,
+                                          int32_t *dStatus)
+{
+    if (!c || nRows < 1 || nCols < 1 || !dBlob || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
+    if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
+    if (((uintptr_t)dBlob & 3) != 0) return GF_ERR_ARG;
+    const unsigned grid = gf_huffman_decode_grid(nTiles);
+    const size_t wsStride = decodeWorkspaceStride(nRows, nCols);
+    if (c->workspace.bytes < (size_t)grid * wsStride) {
+        // not capture-safe: callers that capture graphs call gf_context_reserve first
+        GF_HIP(hipSetDevice(c->device));
+        gf_status s = c->workspace.ensure((size_t)grid * wsStride);
+        if (s != GF_OK) return s;
+    }
+    GfDecodeArgs a;
+    a.blob = dBlob;
+    a.blobBytes = blobBytes;
+    a.offsets = dOffsets;
+    a.slotStride = slotStride;
+    a.lengths = dLengths;
+    a.values = dValues;
+    a.status = dStatus;
+    a.workspace = (uint8_t *)c->workspace.p;
+    a.workspaceStride = wsStride;
+    a.nTiles = nTiles;
+    a.nRows = nRows;
+    a.nCols = nCols;
+    a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
+    GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
+    return GF_OK;
+}
+
+gf_status gf_compact_dev(gf_context *c, void *stream, size_t nTiles, const uint8_t *dSlots, size_t slotStride,
+                         const uint32_t *dLengths, uint64_t *dOffsets, uint8_t *dBlob, size_t blobCap)
+{
+    if (!c || !dSlots || !dLengths || !dOffsets || !dBlob) return GF_ERR_ARG;
+    if (((uintptr_t)dSlots & 15) != 0 || slotStride % 16 != 0) return GF_ERR_ARG;
+    GF_HIP(gf_launch_compact(nTiles, dSlots, slotStride, dLengths, dOffsets, dBlob, blobCap,
+                             stream ? (hipStream_t)stream : c->stream));
+    return GF_OK;
+}
+
+gf_status gf_synth_dem_dev(gf_context *c, void *stream, uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                           int64_t tile0, size_t nTiles, int32_t *dValues)
+{
+    if (!c || nRows < 1 || nCols < 1 || tilesPerRow < 1 || !dValues) return GF_ERR_ARG;
+    GF_HIP(gf_launch_synth_dem(seed, nRows, nCols, tilesPerRow, tile0, nTiles, dValues,
+                               stream ? (hipStream_t)stream : c->stream));
+    return GF_OK;
+}
+
+// ------------------------------------------------------------------ device memory helpers
+
+gf_status gf_dev_malloc(gf_context *c, size_t bytes, void **p)
+{
+    if (!c || !p) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    GF_HIP(hipMalloc(p, bytes ? bytes : 16));
+    return GF_OK;
+}
+
+gf_status gf_dev_free(gf_context *c, void *p)
+{
+    if (!c) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    GF_HIP(hipFree(p));
+    return GF_OK;
+}
+
+gf_status gf_dev_memset(gf_context *c, void *p, int value, size_t bytes)
+{
+    if (!c) return GF_ERR_ARG;
+    GF_HIP(hipMemsetAsync(p, value, bytes, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    return GF_OK;
+}
+
+gf_status gf_dev_upload(gf_context *c, void *d, const void *h, size_t bytes)
+{
+    if (!c) return GF_ERR_ARG;
+    GF_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    return GF_OK;
+}
+
+gf_status gf_dev_download(gf_context *c, void *h, const void *d, size_t bytes)
+{
+    if (!c) return GF_ERR_ARG;
+    GF_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    return GF_OK;
+}
+
+// ------------------------------------------------------------------ timers
+
+gf_status gf_timer_create(gf_context *c, gf_timer **out)
+{
+    if (!c || !out) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    gf_timer *t = new (std::nothrow) gf_timer();
+    if (!t) return GF_ERR_ARG;
+    t->ctx = c;
+    GF_HIP(hipEventCreate(&t->start));
+    GF_HIP(hipEventCreate(&t->stop));
+    *out = t;
+    return GF_OK;
+}
+
+void gf_timer_destroy(gf_timer *t)
+{
+    if (!t) return;
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+}
+
+gf_status gf_timer_start(gf_timer *t, void *stream)
+{
+    if (!t) return GF_ERR_ARG;
+    GF_HIP(hipEventRecord(t->start, stream ? (hipStream_t)stream : t->ctx->stream));
+    return GF_OK;
+}
+
+gf_status gf_timer_stop(gf_timer *t, void *stream)
+{
+    if (!t) return GF_ERR_ARG;
+    GF_HIP(hipEventRecord(t->stop, stream ? (hipStream_t)stream : t->ctx->stream));
+    return GF_OK;
+}
+
+gf_status gf_timer_elapsed_ms(gf_timer *t, float *ms)
+{
+    if (!t || !ms) return GF_ERR_ARG;
+    GF_HIP(hipEventSynchronize(t->stop));
+    GF_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+    return GF_OK;
+}
+
+// ------------------------------------------------------------------ host-memory entry points
+
+gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                      const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
+                                      uint8_t *predictors, int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const size_t stride = gf_huffman_default_stride(nRows, nCols);
+    gf_status s;
+    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dSlots.ensure(nTiles * stride + 16)) != GF_OK) return s;
+    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dPred.ensure(nTiles + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
+    s = gf_huffman_encode_batch_i32_dev(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
+                                        (uint8_t *)c->dSlots.p, stride, (uint32_t *)c->dLengths.p,
+                                        (uint8_t *)c->dPred.p, (int32_t *)c->dStatus.p, GF_PM_ALL);
+    if (s != GF_OK) return s;
+    std::vector<uint32_t> lengths(nTiles);
+    std::vector<int32_t> st(nTiles);
+    GF_HIP(hipMemcpyAsync(lengths.data(), c->dLengths.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    if (predictors) GF_HIP(hipMemcpyAsync(predictors, c->dPred.p, nTiles, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+
+    // tiles whose packing did not fit the default slot (longer than the raw tile): redo them one by
+    // one into a worst-case slot so that the bytes are still exactly the reference's
+    std::vector<std::vector<uint8_t>> big(nTiles);
+    bool anyBig = false;
+    for (size_t t = 0; t < nTiles; t++) {
+        if (st[t] != GF_OVERFLOW) continue;
+        anyBig = true;
+        const size_t maxp = gf_huffman_max_packing(nRows, nCols);
+        DevBuf slot, meta;
+        if ((s = slot.ensure(maxp)) != GF_OK) return s;
+        if ((s = meta.ensure(64)) != GF_OK) { slot.release(); return s; }
+        uint32_t *dLen = (uint32_t *)meta.p;
+        int32_t *dSt = (int32_t *)((uint8_t *)meta.p + 16);
+        s = gf_huffman_encode_batch_i32_dev(c, c->stream, codecIndex, nRows, nCols, 1,
+                                            (const int32_t *)c->dValues.p + t * cells, (uint8_t *)slot.p, maxp, dLen,
+                                            nullptr, dSt, GF_PM_ALL);
+        if (s == GF_OK) {
+            uint32_t l = 0;
+            int32_t tst = 0;
+            hipMemcpyAsync(&l, dLen, 4, hipMemcpyDeviceToHost, c->stream);
+            hipMemcpyAsync(&tst, dSt, 4, hipMemcpyDeviceToHost, c->stream);
+            hipStreamSynchronize(c->stream);
+            big[t].resize(l);
+            hipMemcpy(big[t].data(), slot.p, l, hipMemcpyDeviceToHost);
+            lengths[t] = l;
+            st[t] = tst;
+        }
+        slot.release();
+        meta.release();
+        if (s != GF_OK) return s;
+    }
+
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        offsets[t] = total;
+        total += (st[t] == GF_OK) ? lengths[t] : 0;
+    }
+    offsets[nTiles] = total;
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    if (total > blobCap) return GF_ERR_CAPACITY;
+
+    if (!anyBig) {
+        // contiguous blob built on the device, one D2H copy
+        if ((s = c->dBlob.ensure(total + 16)) != GF_OK) return s;
+        // lengths of failed tiles must be zero for the scan
+        bool patched = false;
+        for (size_t t = 0; t < nTiles; t++)
+            if (st[t] != GF_OK && lengths[t]) { lengths[t] = 0; patched = true; }
+        if (patched) GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
+        s = gf_compact_dev(c, c->stream, nTiles, (const uint8_t *)c->dSlots.p, stride, (const uint32_t *)c->dLengths.p,
+                           (uint64_t *)c->dOffsets.p, (uint8_t *)c->dBlob.p, c->dBlob.bytes);
+        if (s != GF_OK) return s;
+        if (total) GF_HIP(hipMemcpyAsync(blob, c->dBlob.p, total, hipMemcpyDeviceToHost, c->stream));
+        GF_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        for (size_t t = 0; t < nTiles; t++) {
+            if (st[t] != GF_OK || lengths[t] == 0) continue;
+            if (!big[t].empty()) memcpy(blob + offsets[t], big[t].data(), lengths[t]);
+            else GF_HIP(hipMemcpy(blob + offsets[t], (const uint8_t *)c->dSlots.p + t * stride, lengths[t],
+                                  hipMemcpyDeviceToHost));
+        }
+    }
+    return GF_OK;
+}
+
+gf_status gf_huffman_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                      const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const uint64_t total = offsets[nTiles];
+    gf_status s;
+    if ((s = c->dBlob.ensure(total + 32)) != GF_OK) return s;
+    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
+    std::vector<uint32_t> lengths(nTiles);
+    for (size_t t = 0; t < nTiles; t++) {
+        if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
+        lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
+    }
+    GF_HIP(hipMemcpyAsync(c->dBlob.p, blob, total, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dOffsets.p, offsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
+    s = gf_huffman_decode_batch_i32_dev(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total,
+                                        (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p,
+                                        (int32_t *)c->dValues.p, (int32_t *)c->dStatus.p);
+    if (s != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> st(nTiles);
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    return GF_OK;
+}
+
+gf_status gf_huffman_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values,
+                                uint8_t *out, size_t outCap, size_t *outLen)
+{
+    if (!outLen) return GF_ERR_ARG;
+    uint64_t offsets[2] = {0, 0};
+    int32_t st = 0;
+    gf_status s = gf_huffman_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, out, outCap, offsets, nullptr, &st);
+    *outLen = (size_t)offsets[1];
+    if (s != GF_OK) return s;
+    return (gf_status)st;
+}
+
+gf_status gf_huffman_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len,
+                                int32_t *values)
+{
+    uint64_t offsets[2] = {0, (uint64_t)len};
+    int32_t st = 0;
+    gf_status s = gf_huffman_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
+    if (s != GF_OK) return s;
+    return (gf_status)st;
+}
+
+}  // extern "C"

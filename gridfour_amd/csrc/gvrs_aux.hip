@@ -1,0 +1,147 @@
+// gvrs_aux.hip -- small helper kernels: packing compaction and the synthetic DEM generator.
+
+#include <hip/hip_runtime.h>
+
+#include "gvrs_kernels.h"
+
+namespace {
+
+// ---- compaction: exclusive scan of the lengths (one workgroup), then one workgroup per tile copies ----
+__global__ __launch_bounds__(1024) void k_scan_lengths(size_t nTiles, const uint32_t *__restrict__ lengths,
+                                                       uint64_t *__restrict__ offsets)
+{
+    __shared__ unsigned long long waveSum[16];
+    __shared__ unsigned long long carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < nTiles; base += 1024) {
+        const size_t i = base + tid;
+        const unsigned long long v = i < nTiles ? lengths[i] : 0ull;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) waveSum[wave] = incl;
+        __syncthreads();
+        unsigned long long pre = carry, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) pre += waveSum[w];
+            tot += waveSum[w];
+        }
+        if (i < nTiles) offsets[i] = pre + incl - v;
+        __syncthreads();
+        if (tid == 0) carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[nTiles] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_gather(size_t nTiles, const uint8_t *__restrict__ slots, size_t slotStride,
+                                                const uint32_t *__restrict__ lengths,
+                                                const uint64_t *__restrict__ offsets, uint8_t *__restrict__ blob,
+                                                size_t blobCap)
+{
+    for (size_t t = blockIdx.x; t < nTiles; t += gridDim.x) {
+        const uint8_t *src = slots + t * slotStride;
+        const uint64_t off = offsets[t];
+        const uint32_t len = lengths[t];
+        if (off + len > blobCap) continue;
+        uint8_t *dst = blob + off;
+        // head bytes up to 4-byte alignment of dst, then dwords assembled from the (aligned) slot
+        const uint32_t mis = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
+        const uint32_t head = mis < len ? mis : len;
+        for (uint32_t i = threadIdx.x; i < head; i += blockDim.x) dst[i] = src[i];
+        const uint32_t nw = (len - head) >> 2;
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);   // slots are 16-byte aligned
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+        for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
+            const uint32_t b = head + 4 * w;                             // source byte offset
+            const uint32_t lo = s32[b >> 2], hi = s32[(b >> 2) + 1];
+            const uint32_t sh = (b & 3) * 8;
+            d32[w] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+        }
+        for (uint32_t i = head + 4 * nw + threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// ---- synthetic DEM: integer value noise, same integer recipe as the test-side CPU generator ----
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ int32_t dem_lattice(uint64_t seed, int o, int64_t i, int64_t j)
+{
+    const uint64_t h = splitmix64(seed ^ ((uint64_t)o << 56) ^ (((uint64_t)j & 0xFFFFFFFULL) << 28) ^
+                                  ((uint64_t)i & 0xFFFFFFFULL));
+    const int32_t amp = 4096 >> o;
+    return (int32_t)((((h >> 32) & 0xFFFF) * (uint64_t)(2 * amp)) >> 16) - amp;
+}
+
+__device__ int32_t dem_value(uint64_t seed, int64_t gx, int64_t gy)
+{
+    int64_t sum = 0;
+    for (int o = 0; o < 6; o++) {
+        const int sh = 8 - o;
+        const int64_t s = (int64_t)1 << sh;
+        const int64_t i = gx >> sh, j = gy >> sh;
+        const int64_t fx = gx & (s - 1), fy = gy & (s - 1);
+        const int64_t l00 = dem_lattice(seed, o, i, j), l10 = dem_lattice(seed, o, i + 1, j);
+        const int64_t l01 = dem_lattice(seed, o, i, j + 1), l11 = dem_lattice(seed, o, i + 1, j + 1);
+        const int64_t top = l00 * (s - fx) + l10 * fx;
+        const int64_t bot = l01 * (s - fx) + l11 * fx;
+        sum += (top * (s - fy) + bot * fy) >> (2 * sh);
+    }
+    const uint64_t h = splitmix64(seed ^ 0x7700000000000000ULL ^ (((uint64_t)gy & 0xFFFFFFFULL) << 28) ^
+                                  ((uint64_t)gx & 0xFFFFFFFULL));
+    sum += (int64_t)((h >> 40) % 5) - 2;
+    sum -= 2000;
+    if (sum < -11000) sum = -11000;
+    if (sum > 8848) sum = 8848;
+    return (int32_t)sum;
+}
+
+__global__ __launch_bounds__(256) void k_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                                                   int64_t tile0, size_t nTiles, int32_t *__restrict__ values)
+{
+    const size_t nCells = (size_t)nRows * (size_t)nCols;
+    const size_t total = nTiles * nCells;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = g / nCells;
+        const uint32_t k = (uint32_t)(g - t * nCells);
+        const int r = (int)(k / (uint32_t)nCols), c = (int)(k - (uint32_t)r * (uint32_t)nCols);
+        const int64_t tile = tile0 + (int64_t)t;
+        const int64_t tr = tile / tilesPerRow, tc = tile % tilesPerRow;
+        values[g] = dem_value(seed, tc * nCols + c, tr * nRows + r);
+    }
+}
+
+}  // namespace
+
+hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStride, const uint32_t *lengths,
+                             uint64_t *offsets, uint8_t *blob, size_t blobCap, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_scan_lengths, dim3(1), dim3(1024), 0, stream, nTiles, lengths, offsets);
+    if (nTiles) {
+        const unsigned grid = (unsigned)(nTiles < 8192 ? nTiles : 8192);
+        hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, stream, nTiles, slots, slotStride, lengths, offsets,
+                           blob, blobCap);
+    }
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow, int64_t tile0,
+                               size_t nTiles, int32_t *values, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth_dem, dim3(4096), dim3(256), 0, stream, seed, nRows, nCols, tilesPerRow, tile0, nTiles,
+                       values);
+    return hipGetLastError();
+}

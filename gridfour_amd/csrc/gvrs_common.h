@@ -1,0 +1,103 @@
+// gvrs_common.h -- shared host/device helpers of the HIP GVRS codec.
+//
+// Everything here is integer arithmetic on uint32_t (Java int wrap-around).
+// Reference paths are relative to core/src/main/java/org/gridfour/.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GF_HD __host__ __device__ __forceinline__
+#else
+#define GF_HD inline
+#endif
+
+#define GF_NULL_CODE 0x80000000u
+
+// ---- CodecM32 (compress/CodecM32.java:257-311) -------------------------
+// Number of M32 bytes of a residual (1..6).  Thresholds :105-111.
+GF_HD int gf_m32_len(uint32_t x)
+{
+    if (x == GF_NULL_CODE) return 1;
+    uint32_t a = ((int32_t)x < 0) ? (0u - x) : x;
+    if (a <= 126u) return 1;
+    if (a <= 254u) return 2;
+    if (a <= 16638u) return 3;
+    if (a <= 2113790u) return 4;
+    if (a <= 270549246u) return 5;
+    return 6;
+}
+
+// Byte k (0-based) of the n-byte M32 form of x.
+//   n == 1 : the value itself (two's complement byte; 0x80 for the null code)
+//   n  > 1 : byte 0 = introducer 0x7f / 0x81, then (abs - base[n-2]) in
+//            big-endian 7-bit groups, continuation bit 0x80 on all but the last
+GF_HD uint32_t gf_m32_byte(uint32_t x, int n, int k)
+{
+    if (n == 1) return x == GF_NULL_CODE ? 0x80u : (x & 0xffu);
+    bool neg = (int32_t)x < 0;
+    if (k == 0) return neg ? 0x81u : 0x7fu;
+    uint32_t a = neg ? (0u - x) : x;
+    uint32_t base = n == 2 ? 127u : n == 3 ? 255u : n == 4 ? 16639u : n == 5 ? 2113791u : 270549247u;
+    uint32_t d = a - base;
+    int shift = 7 * (n - 1 - k);              // k = n-1 -> 0
+    uint32_t b = (d >> shift) & 0x7fu;
+    return (k == n - 1) ? b : (b | 0x80u);
+}
+
+// ---- predictor residuals (compress/PredictorModel*.java) ---------------
+// v = cell, W = (r,c-1), WW = (r,c-2), N = (r-1,c), NW = (r-1,c-1); callers pass
+// any value for neighbours that do not exist.  Cell (0,0) has no residual.
+GF_HD uint32_t gf_res_differencing(int r, int c, uint32_t v, uint32_t W, uint32_t N)
+{
+    (void)r;
+    return c > 0 ? v - W : v - N;             // PredictorModelDifferencing.java:120-137
+}
+GF_HD uint32_t gf_res_linear(int r, int c, uint32_t v, uint32_t W, uint32_t WW, uint32_t N)
+{
+    (void)r;
+    if (c >= 2) return v - (2u * W - WW);     // PredictorModelLinear.java:128-141
+    return c == 1 ? v - W : v - N;            // :113-126
+}
+GF_HD uint32_t gf_res_triangle(int r, int c, uint32_t v, uint32_t W, uint32_t N, uint32_t NW)
+{
+    if (r == 0) return v - W;                 // PredictorModelTriangle.java:114-119
+    if (c == 0) return v - N;                 // :121-127
+    return v - (W + N - NW);                  // :130-142
+}
+
+// ---- stream order <-> cell (the order the reference emits residuals) ---
+// number of residuals in the stream of a model
+GF_HD uint32_t gf_stream_len(int model, uint32_t nR, uint32_t nC)
+{
+    return model == 4 ? nR * nC : nR * nC - 1u;
+}
+
+// cell index (row-major) of stream element s
+GF_HD uint32_t gf_stream_cell(int model, uint32_t nR, uint32_t nC, uint32_t s)
+{
+    switch (model) {
+    case 1: return s + 1u;
+    case 2: {
+        if (s == 0) return 1u;
+        uint32_t seedLen = 2u * nR - 1u;      // 1 + 2*(nR-1)
+        if (s < seedLen) {
+            uint32_t t = s - 1u;
+            return (1u + (t >> 1)) * nC + (t & 1u);
+        }
+        uint32_t t = s - seedLen, w = nC - 2u;
+        uint32_t r = t / w;
+        return r * nC + 2u + (t - r * w);
+    }
+    case 3: {
+        if (s < nC - 1u) return s + 1u;
+        uint32_t t = s - (nC - 1u);
+        if (t < nR - 1u) return (t + 1u) * nC;
+        t -= nR - 1u;
+        uint32_t w = nC - 1u;
+        uint32_t r = t / w;
+        return (r + 1u) * nC + 1u + (t - r * w);
+    }
+    default: return s;
+    }
+}

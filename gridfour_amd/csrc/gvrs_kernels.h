@@ -1,0 +1,53 @@
+// gvrs_kernels.h -- launch interface between the C ABI (gvrs_api.hip) and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// per-tile status values written by the kernels; identical to gf_status in
+// include/gvrs_hip_codec.h
+#define GF_K_OK 0
+#define GF_K_DECLINED 1
+#define GF_K_OVERFLOW 2
+#define GF_K_ERR_FORMAT (-1)
+#define GF_K_ERR_BOUNDS (-2)
+
+struct GfEncodeArgs {
+    const int32_t *values;     // nTiles * nRows*nCols
+    uint8_t *out;              // nTiles slots of slotStride bytes
+    uint32_t *lengths;
+    uint8_t *predictors;       // may be null
+    int32_t *status;
+    size_t nTiles;
+    size_t slotStride;
+    int nRows, nCols;
+    int codecIndex;
+    int predictorMask;
+};
+
+struct GfDecodeArgs {
+    const uint8_t *blob;       // 4-byte aligned
+    size_t blobBytes;
+    const uint64_t *offsets;   // may be null -> t * slotStride
+    size_t slotStride;
+    const uint32_t *lengths;
+    int32_t *values;
+    int32_t *status;
+    uint8_t *workspace;        // gridDim.x * workspaceStride bytes (M32 spill)
+    size_t workspaceStride;
+    size_t nTiles;
+    int nRows, nCols;
+    uint32_t ldsM32Bytes;      // capacity of the in-LDS M32 buffer
+};
+
+hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
+hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
+unsigned gf_huffman_decode_grid(size_t nTiles);
+uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols);
+
+hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStride,
+                             const uint32_t *lengths, uint64_t *offsets, uint8_t *blob,
+                             size_t blobCap, hipStream_t stream);
+hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                               int64_t tile0, size_t nTiles, int32_t *values, hipStream_t stream);

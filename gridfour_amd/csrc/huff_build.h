@@ -1,0 +1,118 @@
+// huff_build.h -- Huffman tree construction that reproduces, node for node, the
+// tree compress/HuffmanEncoder.java:124-194 builds, without its linked list.
+//
+// Why a different algorithm gives the same tree
+//   The reference keeps ONE list sorted by count: leaves ordered (count asc,
+//   symbol asc) (:86-92,138), and every new branch is inserted before the first
+//   node whose count is >= its own (:175-193).  Successive branch counts never
+//   decrease, so the list is always the merge of
+//     - the leaf queue, and
+//     - the branch list: groups of equal count in creation order, and inside a
+//       group the NEWEST branch first (it was inserted in front of its equals),
+//   with branches ahead of leaves of equal count.  Popping "the two smallest"
+//   is therefore: compare the head of the leaf queue with the top of the oldest
+//   non-empty branch group (a stack), branch wins ties.  That is what
+//   gf_huff_merge does with two cursors; no list scan, O(1) per pop.
+//
+// Node numbering: leaves 0..n-1 in sorted order, branches n..2n-2 in creation
+// order; the root is node 2n-2.
+//
+// The functions are __host__ __device__ so that tests/ can compile this header
+// with g++ and check it against the oracle's literal linked-list restatement.
+#pragma once
+
+#include "gvrs_common.h"
+
+struct GfHuffTree {
+    uint32_t cnt[511];     // node counts
+    uint16_t parent[511];  // parent id, bit 15 set when the node is a RIGHT child (bit = 1)
+    uint16_t left[255];    // left child of branch b (index b - n)
+    uint16_t nl[511];      // leaves under the node
+    uint16_t bq[256];      // branch queue slots (node ids)
+    uint8_t sym[256];      // symbol of sorted leaf i
+    int n;                 // number of leaves (distinct symbols)
+};
+
+// Sequential merge.  Leaves (cnt[0..n), sym[0..n)) must already be sorted by
+// (count asc, symbol asc); nl[0..n) is set here.
+GF_HD void gf_huff_merge(GfHuffTree &T)
+{
+    const int n = T.n;
+    for (int i = 0; i < n; i++) T.nl[i] = 1;
+    int li = 0;                        // leaf queue head
+    int gs = 0, top = 0, ge = 0, m = 0;  // branch groups: front group slots [gs,top), next group at ge, end m
+    int next = n;
+    for (int step = 0; step < n - 1; step++) {
+        int pick[2];
+        for (int k = 0; k < 2; k++) {
+            bool haveB = top > gs;
+            bool haveL = li < n;
+            bool takeB = haveB && (!haveL || T.cnt[T.bq[top - 1]] <= T.cnt[li]);
+            if (takeB) {
+                pick[k] = T.bq[top - 1];
+                if (ge == m) { m--; ge--; }   // front group is also the last: drop the slot
+                top--;
+                if (top == gs) {              // front group exhausted: advance to the next group
+                    gs = ge;
+                    if (gs < m) {
+                        uint32_t c = T.cnt[T.bq[gs]];
+                        int e = gs + 1;
+                        while (e < m && T.cnt[T.bq[e]] == c) e++;
+                        ge = e;
+                        top = e;
+                    } else {
+                        gs = top = ge = m;
+                    }
+                }
+            } else {
+                pick[k] = li++;
+            }
+        }
+        const int a = pick[0], b = pick[1];
+        const int id = next++;
+        const uint32_t c = T.cnt[a] + T.cnt[b];
+        T.cnt[id] = c;
+        T.parent[a] = (uint16_t)id;                 // left, bit 0  (HuffmanEncoder.java:75-83)
+        T.parent[b] = (uint16_t)(id | 0x8000);      // right, bit 1
+        T.left[id - n] = (uint16_t)a;
+        T.nl[id] = (uint16_t)(T.nl[a] + T.nl[b]);
+        // push: joins the last group when the counts are equal, else opens a new group
+        bool nonEmpty = top > gs;
+        if (nonEmpty && T.cnt[T.bq[m - 1]] == c) {
+            bool frontIsLast = (ge == m);
+            T.bq[m++] = (uint16_t)id;
+            if (frontIsLast) { ge = m; top = m; }
+        } else {
+            T.bq[m++] = (uint16_t)id;
+            if (!nonEmpty) { gs = m - 1; top = m; ge = m; }
+        }
+    }
+    if (n >= 1) T.parent[2 * n - 2] = 0xFFFF;       // root
+}
+
+// Code of sorted leaf i: path bits root->leaf, first step in bit 0 (the order
+// HuffmanEncoder.java:198-213 appends them).  *pos = bit offset of the leaf's
+// "1 + 8-bit symbol" record inside the pre-order tree serialisation
+// (:221-294), counted from the root's bit.  Returns the code length.
+GF_HD int gf_huff_leaf_code(const GfHuffTree &T, int i, uint64_t *code, uint32_t *pos)
+{
+    const int n = T.n;
+    const int root = 2 * n - 2;
+    uint64_t c = 0;
+    uint32_t p = 0;
+    int len = 0;
+    int x = i;
+    while (x != root) {
+        uint32_t pr = T.parent[x];
+        uint32_t isR = pr >> 15;
+        pr &= 0x7fffu;
+        c = (c << 1) | isR;
+        // right child starts after the whole left subtree: 1 + (10*k - 1) bits for k leaves
+        p += isR ? 10u * T.nl[T.left[pr - n]] : 1u;
+        len++;
+        x = (int)pr;
+    }
+    *code = c;
+    *pos = p;
+    return len;
+}

@@ -1,0 +1,170 @@
+/*
+ * gvrs_hip_codec.h -- C ABI of the MI355X-native GVRS tile codec (libgvrs_hip.so).
+ *
+ * This is the drop-in boundary for the Gridfour compression plug-in interface.
+ * Reference paths are relative to core/src/main/java/org/gridfour/ of
+ * gwlucastrig/gridfour.  The entry points are what a JNI binding of
+ *     compress/ICompressionEncoder.java:61-91   (encode / encodeFloats)
+ *     compress/ICompressionDecoder.java:62-105  (decode / decodeFloats)
+ * would bind for the codec registered as "GvrsHuffman"
+ * (compress/CodecHuffman.java:70-153, registered the way
+ * gvrs/GvrsFileSpecification.java:1576-1631 addCompressionCodec does).
+ * INTEGRATION.md shows the Java adapter + JNI stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types.
+ *   - "host" entry points take host pointers and do their own H2D/D2H copies.
+ *   - "dev" entry points take device pointers plus a HIP stream (hipStream_t
+ *     passed as void*); they only enqueue work, never synchronise, never
+ *     allocate (gf_context_reserve first) -> safe for hipGraph capture.
+ *   - tiles are row-major int32[nRows*nCols], batches are contiguous tiles.
+ *   - every function returns a gf_status; per-tile outcomes of batch calls are
+ *     reported in a status array (int32 per tile).
+ *   - bit-exactness contract: for every tile, the bytes produced equal the
+ *     bytes CodecHuffman.encode returns for the same (codecIndex, nRows, nCols,
+ *     values), and decode inverts CodecHuffman.decode exactly.
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point returns GF_ERR_NO_DEVICE.
+ */
+#ifndef GVRS_HIP_CODEC_H
+#define GVRS_HIP_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gf_status {
+    GF_OK = 0,
+    GF_DECLINED = 1,          /* encoder result is Java `null` (all cells null): CodecHuffman.java:80-82 */
+    GF_OVERFLOW = 2,          /* packing longer than the slot/capacity handed in; length is still reported */
+    GF_ERR_FORMAT = -1,       /* decoder: Java would throw IOException (CodecHuffman.java:155-169)        */
+    GF_ERR_BOUNDS = -2,       /* Java would throw ArrayIndexOutOfBounds (short packing, nCols < 2, ...)   */
+    GF_ERR_CAPACITY = -3,     /* host output buffer too small                                             */
+    GF_ERR_ARG = -4,
+    GF_ERR_NO_DEVICE = -5,    /* no HIP device / HIP runtime error at context creation                    */
+    GF_ERR_HIP = -6,          /* a HIP call failed; gf_last_error() has the text                          */
+    GF_ERR_UNSUPPORTED = -7
+} gf_status;
+
+/* INT4_NULL_CODE, util/GridfourConstants.java:61 */
+#define GF_INT4_NULL ((int32_t)0x80000000)
+
+/* predictor codes, compress/PredictorModelType.java:46-63 */
+#define GF_PM_DIFFERENCING 1
+#define GF_PM_LINEAR 2
+#define GF_PM_TRIANGLE 3
+#define GF_PM_DIFFERENCING_NULLS 4
+/* predictor_mask bit for model m is 1 << (m-1); GF_PM_ALL = reference behaviour */
+#define GF_PM_ALL 0xF
+
+typedef struct gf_context gf_context;
+
+/* ---- library / device ---- */
+const char *gf_version(void);
+const char *gf_status_string(int status);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char *gf_last_error(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int gf_device_count(void);
+
+/* One context per (process, device): owns a stream and the scratch workspace.
+ * Calls on one context are serialised by the caller; different contexts are
+ * independent (this is how tile batches shard over the GPUs of a node).      */
+gf_status gf_context_create(int device, gf_context **ctx);
+void gf_context_destroy(gf_context *ctx);
+/* pre-allocates workspace for batches up to n_tiles tiles of n_rows x n_cols */
+gf_status gf_context_reserve(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles);
+/* the context's own stream (hipStream_t) */
+void *gf_context_stream(gf_context *ctx);
+gf_status gf_context_synchronize(gf_context *ctx);
+
+/* slot stride (bytes, multiple of 16) the batch encoders use by default:
+ * room for any packing the caller would keep (RasterTile keeps a packing only
+ * when shorter than 4*cells, gvrs/TileElementInt.java:198-204).              */
+size_t gf_huffman_default_stride(int n_rows, int n_cols);
+/* absolute worst-case packing size of CodecHuffman for a tile */
+size_t gf_huffman_max_packing(int n_rows, int n_cols);
+
+/* ---- single tile, host memory: replaces ICompressionEncoder.encode /
+ *      ICompressionDecoder.decode as implemented by CodecHuffman ----------- */
+/* returns GF_OK, GF_DECLINED (Java null), GF_ERR_CAPACITY (out_len = needed) */
+gf_status gf_huffman_encode_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols,
+                                const int32_t *values, uint8_t *out, size_t out_cap,
+                                size_t *out_len);
+/* returns GF_OK or GF_ERR_FORMAT / GF_ERR_BOUNDS (Java IOException / AIOOBE) */
+gf_status gf_huffman_decode_i32(gf_context *ctx, int n_rows, int n_cols,
+                                const uint8_t *packing, size_t packing_len, int32_t *values);
+
+/* ---- batches, host memory --------------------------------------------- */
+/* Encodes n_tiles tiles.  Packings are concatenated in tile order into blob;
+ * offsets[n_tiles+1] receives their byte offsets (offsets[t+1]-offsets[t] = length,
+ * 0 for a declined tile).  predictors[n_tiles] (optional) receives the predictor
+ * code chosen per tile, status[n_tiles] (optional) the per-tile gf_status.
+ * Returns GF_ERR_CAPACITY (offsets still filled) when blob_cap is too small.  */
+gf_status gf_huffman_encode_batch_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols,
+                                      size_t n_tiles, const int32_t *values, uint8_t *blob,
+                                      size_t blob_cap, uint64_t *offsets, uint8_t *predictors,
+                                      int32_t *status);
+gf_status gf_huffman_decode_batch_i32(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles,
+                                      const uint8_t *blob, const uint64_t *offsets,
+                                      int32_t *values, int32_t *status);
+
+/* ---- batches, device-resident (the measured hot path) ------------------ */
+/* d_values  : n_tiles * n_rows*n_cols int32
+ * d_out     : n_tiles slots of slot_stride bytes (16-byte aligned base, stride % 16 == 0);
+ *             tile t's packing starts at t*slot_stride
+ * d_lengths : packing length per tile (bytes; 0 = declined)
+ * d_predictors (optional, may be NULL), d_status: per tile
+ * predictor_mask: GF_PM_ALL for reference behaviour; a subset restricts the
+ *             models tried (test hook, mirrors the oracle)                   */
+gf_status gf_huffman_encode_batch_i32_dev(gf_context *ctx, void *stream, int codec_index,
+                                          int n_rows, int n_cols, size_t n_tiles,
+                                          const int32_t *d_values, uint8_t *d_out,
+                                          size_t slot_stride, uint32_t *d_lengths,
+                                          uint8_t *d_predictors, int32_t *d_status,
+                                          int predictor_mask);
+/* tile t's packing = d_blob[d_offsets[t] .. d_offsets[t]+d_lengths[t]).  When
+ * d_offsets is NULL the packings sit in slots: offset = t*slot_stride.
+ * d_blob must be 4-byte aligned; blob_bytes = readable size of d_blob.       */
+gf_status gf_huffman_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols,
+                                          size_t n_tiles, const uint8_t *d_blob,
+                                          size_t blob_bytes, const uint64_t *d_offsets,
+                                          size_t slot_stride, const uint32_t *d_lengths,
+                                          int32_t *d_values, int32_t *d_status);
+/* Gathers slot-strided packings into one contiguous blob (exclusive scan of the
+ * lengths + copy): d_offsets[n_tiles+1], d_blob capacity blob_cap bytes.      */
+gf_status gf_compact_dev(gf_context *ctx, void *stream, size_t n_tiles, const uint8_t *d_slots,
+                         size_t slot_stride, const uint32_t *d_lengths, uint64_t *d_offsets,
+                         uint8_t *d_blob, size_t blob_cap);
+
+/* ---- synthetic elevation tiles (bench / tests) ---- */
+/* fills n_tiles tiles of a seeded integer value-noise DEM cut into
+ * n_rows x n_cols tiles, tiles_per_row tiles across, starting at tile0.      */
+gf_status gf_synth_dem_dev(gf_context *ctx, void *stream, uint64_t seed, int n_rows, int n_cols,
+                           int64_t tiles_per_row, int64_t tile0, size_t n_tiles,
+                           int32_t *d_values);
+
+/* ---- thin device-memory helpers so that non-HIP hosts (JNI, ctypes) can
+ *      stage data without linking the HIP runtime themselves --------------- */
+gf_status gf_dev_malloc(gf_context *ctx, size_t bytes, void **d_ptr);
+gf_status gf_dev_free(gf_context *ctx, void *d_ptr);
+gf_status gf_dev_memset(gf_context *ctx, void *d_ptr, int value, size_t bytes);
+gf_status gf_dev_upload(gf_context *ctx, void *d_dst, const void *h_src, size_t bytes);
+gf_status gf_dev_download(gf_context *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- timing of the device entry points with HIP events on `stream` ------
+ * gf_timer_* bracket any sequence of *_dev calls; elapsed is in milliseconds. */
+typedef struct gf_timer gf_timer;
+gf_status gf_timer_create(gf_context *ctx, gf_timer **t);
+void gf_timer_destroy(gf_timer *t);
+gf_status gf_timer_start(gf_timer *t, void *stream);
+gf_status gf_timer_stop(gf_timer *t, void *stream);
+gf_status gf_timer_elapsed_ms(gf_timer *t, float *ms);   /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+"""GPU parity tests: the HIP codec (through the C ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle
+from tilegen import KINDS, NULL, add_nulls, make_tile
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(10, 10), (2, 2), (7, 9), (1, 2), (1, 37), (33, 65), (120, 150), (200, 200), (3, 2), (64, 64), (5, 300)]
+
+
+@pytest.fixture(scope="module")
+def codec():
+    import gridfour_amd
+    return gridfour_amd.CodecHuffmanHip()
+
+
+def _check_tiles(codec, n_rows, n_cols, tiles, codec_index=3):
+    packs, preds, status = codec.encode_batch(codec_index, n_rows, n_cols, tiles)
+    for t, v in enumerate(tiles):
+        ref, used = oracle.codec_huffman_encode(codec_index, n_rows, n_cols, v)
+        if ref is None:
+            assert packs[t] is None and status[t] == 1, (t, status[t])
+            continue
+        assert status[t] == 0, (t, status[t])
+        assert preds[t] == used, ("predictor", t, preds[t], used)
+        assert len(packs[t]) == len(ref), ("length", t, len(packs[t]), len(ref))
+        if packs[t] != ref:
+            first = next(i for i in range(len(ref)) if packs[t][i] != ref[i])
+            raise AssertionError("tile %d differs at byte %d of %d (model %d): got %s want %s" % (
+                t, first, len(ref), used, packs[t][first:first + 8].hex(), ref[first:first + 8].hex()))
+    good = [p for p in packs if p is not None]
+    vals, st = codec.decode_batch(n_rows, n_cols, good)
+    k = 0
+    for t, v in enumerate(tiles):
+        if packs[t] is None:
+            continue
+        assert st[k] == 0, (t, st[k])
+        if not np.array_equal(vals[k], v):
+            bad = np.nonzero(vals[k] != v)[0]
+            raise AssertionError("decode of tile %d (model %d) differs at %d cells, first %d: got %d want %d" % (
+                t, preds[t], bad.size, bad[0], vals[k][bad[0]], v[bad[0]]))
+        k += 1
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%d" % s)
+def test_encode_decode_parity_kinds(codec, shape):
+    n_rows, n_cols = shape
+    tiles = np.stack([make_tile(k, n_rows, n_cols) for k in KINDS])
+    _check_tiles(codec, n_rows, n_cols, tiles)
+
+
+@pytest.mark.parametrize("shape", [(10, 10), (6, 17), (1, 9), (9, 1), (120, 150), (50, 50)], ids=lambda s: "%dx%d" % s)
+def test_nulls_parity(codec, shape):
+    n_rows, n_cols = shape
+    tiles = []
+    for frac, blocks in ((0.02, False), (0.3, False), (0.9, False), (0.2, True)):
+        tiles.append(add_nulls(make_tile("smooth", n_rows, n_cols), n_rows, n_cols, frac, blocks=blocks))
+    v = make_tile("smooth", n_rows, n_cols)
+    v[0] = NULL
+    tiles.append(v)
+    v = make_tile("ramp", n_rows, n_cols)
+    v[::n_cols] = NULL                      # whole first column null: exercises the row-start rule
+    tiles.append(v)
+    tiles.append(np.full(n_rows * n_cols, NULL, np.int32))   # all null -> declined
+    _check_tiles(codec, n_rows, n_cols, np.stack(tiles))
+
+
+def test_single_tile_interface(codec):
+    v = make_tile("smooth", 120, 150)
+    ref, used = oracle.codec_huffman_encode(2, 120, 150, v)
+    got = codec.encode(2, 120, 150, v)
+    assert got == ref
+    assert np.array_equal(codec.decode(120, 150, got), v)
+    assert codec.encode(0, 4, 4, np.full(16, NULL, np.int32)) is None
+    assert codec.implementsIntegerEncoding() and not codec.implementsFloatingPointEncoding()
+    assert codec.encodeFloats(0, 2, 2, np.zeros(4, np.float32)) is None
+    with pytest.raises(IndexError):
+        codec.encode(0, 5, 1, np.arange(5, dtype=np.int32))       # reference: AIOOBE (nCols < 2)
+
+
+def test_decode_of_oracle_packings_and_errors(codec):
+    v = make_tile("smooth", 33, 65)
+    for mask in (1, 2, 4):
+        ref, used = oracle.codec_huffman_encode(1, 33, 65, v, predictor_mask=mask)
+        assert np.array_equal(codec.decode(33, 65, ref), v)
+    ref, _ = oracle.codec_huffman_encode(1, 33, 65, v)
+    bad = bytearray(ref)
+    bad[1] = 9
+    with pytest.raises(IOError):
+        codec.decode(33, 65, bytes(bad))
+    with pytest.raises(IOError):
+        codec.decode(33, 65, ref[:len(ref) // 2])
+    with pytest.raises(IOError):
+        codec.decode(33, 65, ref[:7])
+
+
+def test_each_predictor_alone(codec):
+    import gridfour_amd
+    from gridfour_amd import DeviceTileBatch
+    n_rows, n_cols = 40, 50
+    tiles = np.stack([make_tile(k, n_rows, n_cols, seed=3) for k in KINDS])
+    b = DeviceTileBatch(codec.ctx, n_rows, n_cols, len(tiles))
+    b.values.upload(tiles)
+    for model in (1, 2, 3):
+        b.encode(codec_index=7, predictor_mask=1 << (model - 1))
+        codec.ctx.synchronize()
+        lengths = b.get_lengths()
+        assert (b.get_enc_status() == 0).all()
+        assert (b.get_predictors() == model).all()
+        for t in range(len(tiles)):
+            ref, _ = oracle.codec_huffman_encode(7, n_rows, n_cols, tiles[t], predictor_mask=1 << (model - 1))
+            assert b.get_packing(t, int(lengths[t])) == ref, (model, t)
+        b.decode()
+        codec.ctx.synchronize()
+        assert (b.get_dec_status() == 0).all()
+        assert np.array_equal(b.get_decoded(), tiles)
+    b.free()
+
+
+def test_golden_oracle_vectors(codec, golden_dir):
+    import json
+    import os
+    vec = json.load(open(os.path.join(golden_dir, "oracle_vectors.json")))
+    for case in vec["cases"]:
+        v = np.array(case["values"], np.int32)
+        got = codec.encode(case["codec_index"], case["n_rows"], case["n_cols"], v)
+        want = bytes.fromhex(case["packing"]) if case["packing"] is not None else None
+        assert got == want, case["name"]
+        if want is not None:
+            assert np.array_equal(codec.decode(case["n_rows"], case["n_cols"], want), v), case["name"]
+
+
+def test_synth_dem_matches_oracle(codec):
+    from gridfour_amd import DeviceTileBatch
+    b = DeviceTileBatch(codec.ctx, 120, 150, 6)
+    b.synth_dem(oracle.DEM_SEED + 2, 144, tile0=141)
+    codec.ctx.synchronize()
+    assert np.array_equal(b.get_values(), oracle.dem_tiles(oracle.DEM_SEED + 2, 120, 150, 144, 141, 6))
+    b.free()
+
+
+def test_batch_dem_roundtrip_and_sampled_parity(codec):
+    """Config-2 shape at reduced count: 256 tiles of 200x200, all three predictors + Huffman."""
+    from gridfour_amd import DeviceTileBatch
+    n_rows, n_cols, nt = 200, 200, 256
+    b = DeviceTileBatch(codec.ctx, n_rows, n_cols, nt)
+    b.synth_dem(oracle.DEM_SEED + 1, 16)
+    b.encode(codec_index=0)
+    b.decode()
+    codec.ctx.synchronize()
+    assert (b.get_enc_status() == 0).all() and (b.get_dec_status() == 0).all()
+    vals = b.get_values()
+    assert np.array_equal(b.get_decoded(), vals)             # encode -> decode round trip, every tile
+    lengths = b.get_lengths()
+    preds = b.get_predictors()
+    for t in range(0, nt, 17):                               # sampled bit-exactness against the oracle
+        ref, used = oracle.codec_huffman_encode(0, n_rows, n_cols, vals[t])
+        assert preds[t] == used and b.get_packing(t, int(lengths[t])) == ref, t
+    b.free()
+
+
+def test_compact_blob_roundtrip(codec):
+    """Packings gathered into one contiguous blob (unaligned starts) decode identically."""
+    tiles = np.stack([make_tile(k, 31, 47, seed=9) for k in KINDS])
+    packs, preds, status = codec.encode_batch(1, 31, 47, tiles)
+    assert all(p is not None for p in packs)
+    vals, st = codec.decode_batch(31, 47, packs)
+    assert (st == 0).all() and np.array_equal(vals, tiles)
