@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode throughput of the HIP GVRS tile codec on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload etopo1|dem1024|gebco_shard]
+
+One "step" = one pass of the hot path over one batch of synthetic elevation tiles:
+CodecHuffman.encode of every tile (all predictors tried, shortest kept) followed by
+CodecHuffman.decode of every packing, inputs and outputs resident in HBM.
+
+Workloads (BASELINE.json configs)
+  etopo1      configs[2]: ETOPO1-shaped 10800x21600 int32 grid = 12,960 tiles of 120x150 per GPU
+              (default: the configuration north_star's target is quoted on)
+  dem1024     configs[1]: 1024 tiles of 200x200
+  gebco_shard configs[3]: one eighth of the GEBCO-shaped grid = 11,664 tiles of 200x200 per GPU
+
+Multi-GPU: tiles are independent, so every rank owns a contiguous tile range of the global
+grid and there is no data-path collective; per-GPU work is fixed (weak scaling).  The only
+collectives are the timing barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "encode+decode MB/s on int32 elevation tiles; bit-exact vs Java ref"
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    #  name         rows cols tiles/GPU tiles_per_row  description
+    "etopo1": (120, 150, 12960, 144, "ETOPO1-shaped 10800x21600 int32 grid, 120x150 tiles, full encode+decode roundtrip"),
+    "dem1024": (200, 200, 1024, 32, "1024-tile batch, 200x200 int32 synthetic DEM, all 3 predictors + Huffman"),
+    "gebco_shard": (200, 200, 11664, 432, "1/8 shard of the GEBCO_2023-shaped 43200x86400 int32 grid, 200x200 tiles"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="etopo1", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample-tiles", type=int, default=-1, help="tiles timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the bit-exactness checks")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the codec has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import gridfour_amd
+    from gridfour_amd import DeviceTileBatch, GpuTimer
+
+    n_rows, n_cols, n_tiles, tiles_per_row, descr = WORKLOADS[args.workload]
+    cells = n_rows * n_cols
+    ctx = gridfour_amd.GvrsHipContext(local_rank)
+    stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
+    batch = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride)
+    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3}[args.workload]
+    # rank r owns the contiguous tile range starting at r * n_tiles of the global grid
+    batch.synth_dem(seed, tiles_per_row, tile0=rank * n_tiles)
+    ctx.synchronize()
+
+    # one HIP-event pair per timed step and kernel, recorded on the stream the kernels run on and
+    # read only after the timed region (no host sync inside it)
+    t_enc = [GpuTimer(ctx) for _ in range(args.steps)]
+    t_dec = [GpuTimer(ctx) for _ in range(args.steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i=None):
+        if i is not None:
+            t_enc[i].start()
+        batch.encode(codec_index=0)
+        if i is not None:
+            t_enc[i].stop()
+            t_dec[i].start()
+        batch.decode()
+        if i is not None:
+            t_dec[i].stop()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    enc_ms = [t.elapsed_ms() for t in t_enc]
+    dec_ms = [t.elapsed_ms() for t in t_dec]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------- verification (outside the timed region) ----------------
+    lengths = batch.get_lengths()
+    enc_status = batch.get_enc_status()
+    dec_status = batch.get_dec_status()
+    packed_bytes = int(lengths.astype(np.int64).sum())
+    c_per_cell = packed_bytes / float(n_tiles * cells)
+    ok_status = bool((enc_status == 0).all() and (dec_status == 0).all())
+    bit_exact = None
+    cpu_baseline = None
+    if rank == 0 and not args.no_verify:
+        import oracle
+        vals = batch.get_values()
+        roundtrip_ok = bool(np.array_equal(batch.get_decoded(), vals))
+        preds = batch.get_predictors()
+        sample = list(range(0, n_tiles, max(1, n_tiles // 64)))[:64]
+        parity_ok = True
+        for t in sample:
+            ref, used = oracle.codec_huffman_encode(0, n_rows, n_cols, vals[t])
+            if ref != batch.get_packing(t, int(lengths[t])) or used != preds[t]:
+                parity_ok = False
+                break
+        bit_exact = bool(roundtrip_ok and parity_ok and ok_status)
+
+        # ---------------- CPU baseline: the oracle ("port"), 1 core, bounded sample ----------------
+        ns = args.cpu_sample_tiles
+        if ns < 0:
+            ns = min(n_tiles, max(64, int(300e6 / (4 * cells))))    # about 300 MB of tiles: ~10 s of CPU work
+        if ns > 0 and world == 1:
+            sub = vals[:ns]
+            c0 = time.perf_counter()
+            out, ln, _ = oracle.batch_huffman_encode(0, n_rows, n_cols, sub)
+            c1 = time.perf_counter()
+            dec = oracle.batch_huffman_decode(n_rows, n_cols, out, ln)
+            c2 = time.perf_counter()
+            assert np.array_equal(dec, sub)
+            mb = sub.nbytes / 1e6
+            cpu_baseline = {
+                "value": round(mb / (c2 - c0), 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                "sample": "first %d tiles of the same workload (%.0f MB), oracle C restatement of the Java "
+                          "algorithm, 1 thread; encode %.1f MB/s, decode %.1f MB/s" % (
+                              ns, mb, mb / (c1 - c0), mb / (c2 - c1)),
+            }
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    steps = args.steps
+    raw_mb = n_tiles * cells * 4 / 1e6
+    value = raw_mb * world * steps / elapsed
+    enc_avg, dec_avg = float(np.mean(enc_ms)), float(np.mean(dec_ms))
+    # algorithmic bytes per launch: encode reads 4 B/cell and writes c; decode reads c, writes 4
+    alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
+    dom_name, dom_ms = ("k_huffman_decode", dec_avg) if dec_avg >= enc_avg else ("k_huffman_encode", enc_avg)
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    out = {
+        "metric": METRIC,
+        "value": round(value, 1),
+        "unit": "MB/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, descr), "tile_rows": n_rows, "tile_cols": n_cols,
+                   "tiles_per_gpu": n_tiles, "codec": "CodecHuffman (Differencing/Linear/Triangle + M32 + Huffman)",
+                   "sharding": "contiguous tile ranges, no collective"},
+        "bit_exact": bit_exact,
+        "compressed_bytes_per_cell": round(c_per_cell, 4),
+        "encode_ms": round(enc_avg, 4),
+        "decode_ms": round(dec_avg, 4),
+        "encode_MBps": round(raw_mb / (enc_avg * 1e-3), 1),
+        "decode_MBps": round(raw_mb / (dec_avg * 1e-3), 1),
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "avg_launch_ms": round(dom_ms, 4),
+                     "roundtrip_frac": round((2 * alg_bytes) / ((enc_avg + dec_avg) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

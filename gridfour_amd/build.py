@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvrs_hip.so")
 SOURCES = ["gvrs_api.hip", "gvrs_encode.hip", "gvrs_decode.hip", "gvrs_aux.hip"]
-HEADERS = ["gvrs_common.h", "gvrs_kernels.h", "huff_build.h", os.path.join("..", "..", "include", "gvrs_hip_codec.h")]
+HEADERS = ["gvrs_common.h", "gvrs_kernels.h", "huff_build.h", "gvrs_encode_layout.h", os.path.join("..", "..", "include", "gvrs_hip_codec.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 

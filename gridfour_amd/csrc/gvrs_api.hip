@@ -13,10 +13,12 @@
 
 #include "../../include/gvrs_hip_codec.h"
 #include "gvrs_kernels.h"
+#include "gvrs_encode_layout.h"
 
 namespace {
 
 thread_local std::string g_lastError;
+uint32_t *g_encodeDebug = nullptr;   // diagnostic dump target of the next encode launches (tools only)
 
 gf_status hipFail(hipError_t e, const char *what)
 {
@@ -73,6 +75,11 @@ extern "C" {
 
 const char *gf_version(void) { return "gvrs-hip-codec 0.1 (gfx950)"; }
 
+// Not part of the public ABI: lets tools/ capture the encode kernel's on-chip tables
+// (gvrs_encode_layout.h).  d_words must hold gf_internal_encode_debug_words() uint32 per tile.
+void gf_internal_set_encode_debug(void *d_words) { g_encodeDebug = (uint32_t *)d_words; }
+size_t gf_internal_encode_debug_words(void);
+
 const char *gf_status_string(int s)
 {
     switch (s) {
@@ -89,6 +96,8 @@ const char *gf_status_string(int s)
     default: return "unknown status";
     }
 }
+
+size_t gf_internal_encode_debug_words(void) { return GF_ENC_DEBUG_WORDS; }
 
 const char *gf_last_error(void) { return g_lastError.c_str(); }
 
@@ -199,6 +208,7 @@ gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codec
     a.nCols = nCols;
     a.codecIndex = codecIndex;
     a.predictorMask = predictorMask & GF_PM_ALL;
+    a.debug = g_encodeDebug;
     GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
 }

@@ -28,7 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "gvrs_kernels.h"
-#include "gvrs_common.h"
+#include "huff_build.h"
 
 namespace {
 
@@ -49,7 +49,7 @@ struct DecShared {
     uint32_t qe[MAXQ];                         // subsequence end (start of the next one)
     uint32_t qn[MAXQ];                         // symbols in the subsequence, later exclusive prefix
     uint8_t qdirty[MAXQ];
-    uint32_t head[HEAD_BYTES / 4];
+    uint32_t head[HEAD_BYTES / 4 + 2];         // +2 words of slack for the 64-bit window reads
     uint32_t waveSum[DEC_WAVES];
     uint32_t textStart;                        // bit offset of the Huffman text in the packing
     int32_t parseStatus;
@@ -269,66 +269,81 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
 
-        if (tid == 0) {
-            // HuffmanDecoder.decodeTree, HuffmanDecoder.java:65-161
+        if (wave == 0) {
+            // HuffmanDecoder.decodeTree, HuffmanDecoder.java:65-161.  Executed wave-uniformly by all
+            // lanes of wave 0 (scalar loop, see GF_UNI in huff_build.h); lane 0 does the stores.
+            const bool writer = lane == 0;
             uint32_t bp = 80;
             const uint32_t totalBits = len * 8u;
-            auto getBit = [&]() -> uint32_t {
-                const uint32_t b = bp < HEAD_BYTES * 8u ? (hb[bp >> 3] >> (bp & 7u)) & 1u : 0u;
-                bp++;
-                return b;
-            };
-            auto getBits8 = [&]() -> uint32_t {
-                uint32_t v = 0;
-                for (int i = 0; i < 8; i++) v |= getBit() << i;
-                return v;
+            auto getBits = [&](uint32_t nb) -> uint32_t {       // nb <= 9
+                const uint32_t wi = bp >> 5, sh = bp & 31u;
+                uint64_t w = 0;
+                if (wi + 1 < HEAD_BYTES / 4 + 2) w = ((uint64_t)GF_UNI(S.head[wi + 1]) << 32) | GF_UNI(S.head[wi]);
+                bp += nb;
+                return (uint32_t)(w >> sh) & ((1u << nb) - 1u);
             };
             int32_t st = GF_K_OK;
-            S.uniformSym = -1;
-            const uint32_t nLeaves = getBits8() + 1;
-            const uint32_t rootBit = getBit();
+            int32_t uniformSym = -1;
+            const uint32_t nLeaves = getBits(8) + 1;
+            const uint32_t rootBit = getBits(1);
+            uint32_t nodes = 1;
             if (rootBit == 1) {
-                S.uniformSym = (int32_t)getBits8();
+                uniformSym = (int32_t)getBits(8);
             } else {
-                uint32_t nodes = 1, leaves = 0;
+                uint32_t leaves = 0;
                 int sp = 0;
-                S.stack[0] = 0;
-                S.childCount[0] = 0;
-                S.child0[0] = 0;
-                S.child1[0] = 0;
+                if (writer) {
+                    S.stack[0] = 0;
+                    S.childCount[0] = 0;
+                    S.child0[0] = 0;
+                    S.child1[0] = 0;
+                }
                 while (leaves < nLeaves) {
-                    const uint32_t parent = S.stack[sp];
-                    if (nodes >= 2 * nLeaves - 1 + 1 || nodes >= 511) { st = GF_K_ERR_BOUNDS; break; }
+                    const uint32_t parent = GF_UNI(S.stack[sp]);
+                    const uint32_t cc = GF_UNI(S.childCount[parent]);
+                    if (nodes >= 2 * nLeaves || nodes >= 511) { st = GF_K_ERR_BOUNDS; break; }
                     const uint32_t id = nodes++;
-                    if (S.childCount[parent] == 0) { S.child0[parent] = (uint16_t)id; S.childCount[parent] = 1; }
-                    else { S.child1[parent] = (uint16_t)id; S.childCount[parent] = 2; }
-                    if (getBit()) {
-                        S.leafSym[id] = (uint8_t)getBits8();
-                        S.child0[id] = 0xFFFFu;
-                        S.child1[id] = 0xFFFFu;
-                        S.childCount[id] = 2;
+                    if (writer) {
+                        if (cc == 0) S.child0[parent] = (uint16_t)id;
+                        else S.child1[parent] = (uint16_t)id;
+                        S.childCount[parent] = (uint8_t)(cc + 1);
+                    }
+                    if (getBits(1)) {
+                        const uint32_t sym = getBits(8);
+                        if (writer) {
+                            S.leafSym[id] = (uint8_t)sym;
+                            S.child0[id] = 0xFFFFu;
+                            S.child1[id] = 0xFFFFu;
+                            S.childCount[id] = 2;
+                        }
                         leaves++;
                         if (leaves == nLeaves) break;
-                        while (sp >= 0 && S.childCount[S.stack[sp]] == 2) sp--;
+                        while (sp >= 0 && GF_UNI(S.childCount[GF_UNI(S.stack[sp])]) == 2) sp--;
                         if (sp < 0) { st = GF_K_ERR_BOUNDS; break; }
                     } else {
-                        S.childCount[id] = 0;
-                        S.child0[id] = 0;
-                        S.child1[id] = 0;
                         sp++;
                         if (sp > (int)nLeaves || sp >= 259) { st = GF_K_ERR_BOUNDS; break; }
-                        S.stack[sp] = (uint16_t)id;
+                        if (writer) {
+                            S.childCount[id] = 0;
+                            S.child0[id] = 0;
+                            S.child1[id] = 0;
+                            S.stack[sp] = (uint16_t)id;
+                        }
                     }
                 }
                 if (st == GF_K_OK) {
                     // every branch must have both children, otherwise the reference walks garbage
-                    for (uint32_t k = 0; k < nodes; k++)
-                        if (S.childCount[k] != 2) { st = GF_K_ERR_FORMAT; break; }
+                    bool bad = false;
+                    for (uint32_t k = lane; k < nodes; k += 64) bad |= S.childCount[k] != 2;
+                    if (__ballot(bad) != 0ull) st = GF_K_ERR_FORMAT;
                 }
             }
             if (st == GF_K_OK && bp > totalBits) st = GF_K_ERR_BOUNDS;   // read past end of data
-            S.textStart = bp;
-            S.parseStatus = st;
+            if (writer) {
+                S.uniformSym = uniformSym;
+                S.textStart = bp;
+                S.parseStatus = st;
+            }
         }
         __syncthreads();
         if (S.parseStatus != GF_K_OK) {
@@ -470,18 +485,18 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
         } else {
             // PredictorModelDifferencingWithNulls.java:137-166: column 0 first (row starts depend on the
             // first cell of the previous row), then every row on its own
-            if (tid == 0) {
+            if (wave == 0) {
+                // wave-uniform scalar loop (all lanes hold the same state; lane 0 stores)
                 uint32_t prior = seed;
                 bool nullFlag = true;
                 for (uint32_t r = 0; r < nR; r++) {
-                    const uint32_t test = o[r * nC];
+                    const uint32_t test = GF_UNI(o[(size_t)r * nC]);
+                    uint32_t first = GF_NULL_CODE;
                     if (test != GF_NULL_CODE) {
-                        if (nullFlag) prior = seed;
-                        prior += test;
-                        o[r * nC] = prior;
+                        first = (nullFlag ? seed : prior) + test;
+                        if (lane == 0) o[(size_t)r * nC] = first;
                     }
                     // row start of the next row: prior = first cell of this row, flag by VALUE (:162-163)
-                    const uint32_t first = test == GF_NULL_CODE ? GF_NULL_CODE : prior;
                     prior = first;
                     nullFlag = first == GF_NULL_CODE;
                 }

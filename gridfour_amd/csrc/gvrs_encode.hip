@@ -22,33 +22,16 @@
 #include <hip/hip_runtime.h>
 
 #include "gvrs_kernels.h"
-#include "huff_build.h"
+#include "gvrs_encode_layout.h"
 
 namespace {
 
-constexpr int ENC_THREADS = 256;
-constexpr int ENC_WAVES = ENC_THREADS / 64;
+constexpr int ENC_THREADS = GF_ENC_THREADS;
+constexpr int ENC_WAVES = GF_ENC_WAVES;
 constexpr int HIST_R = 8;                       // histogram replicas
-constexpr int IMG_WORDS = 84;                   // 80 header bits + 8 + 2559 tree bits -> 83 words
+constexpr int IMG_WORDS = GF_IMG_WORDS;
 constexpr int WIN_WORDS = 2048;                 // bit-pack window (8 KB)
 constexpr int WIN_SLACK = 8;
-
-struct EncPersist {
-    uint32_t hist[3][256];                      // reduced histograms
-    uint64_t tab[3][256];                       // (len << 56) | code per symbol
-    uint32_t img[3][IMG_WORDS];                 // packing header + serialised tree
-    uint64_t totalBits[3];
-    uint32_t treeEndBit[3];                     // 80 + tree bits
-    uint32_t maxLen[3];
-    uint32_t maxN[3];
-    uint32_t nM32[3];
-    int32_t model[3];
-    uint32_t seed;
-    uint32_t flags;                             // bit0 any null, bit1 any valid
-    uint32_t waveSum[ENC_WAVES];
-    unsigned long long sumStart;                // nulls predictor seed
-    uint32_t nStart;
-};
 
 union EncScratch {
     uint32_t histR[3][256 * HIST_R];            // phase A
@@ -341,9 +324,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
             }
             __builtin_amdgcn_wave_barrier();
             uint32_t *img = P.img[p];
+            // the merge runs wave-uniformly on all lanes (scalar loop); lane 0 does the stores
+            if (n > 1) gf_huff_merge(T, n, lane == 0);
+            __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
                 T.n = n;
-                if (n > 1) gf_huff_merge(T);
                 // header, CodecHuffman.java:121-130 (LSB-first bit store == little-endian bytes)
                 const uint32_t seed = P.seed;
                 img[0] = ((uint32_t)a.codecIndex & 0xffu) | ((uint32_t)P.model[p] << 8) | (seed << 16);
@@ -388,6 +373,15 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
                 P.totalBits[p] = 80ull + treeBits + textBits;
                 P.maxLen[p] = maxLen;
             }
+        }
+        __syncthreads();
+        if (a.debug) {                           // diagnostic dump of the on-chip state (tests/tools only)
+            uint32_t *dbg = a.debug + t * (size_t)GF_ENC_DEBUG_WORDS;
+            const uint32_t *pw = reinterpret_cast<const uint32_t *>(&P);
+            const uint32_t *tw = reinterpret_cast<const uint32_t *>(&S.tree[0]);
+            for (uint32_t i = tid; i < sizeof(EncPersist) / 4; i += ENC_THREADS) dbg[i] = pw[i];
+            for (uint32_t i = tid; i < 3 * sizeof(GfHuffTree) / 4; i += ENC_THREADS)
+                dbg[sizeof(EncPersist) / 4 + i] = tw[i];
         }
         __syncthreads();                         // trees dead from here: S.win may be written
 

@@ -24,6 +24,7 @@ struct GfEncodeArgs {
     int nRows, nCols;
     int codecIndex;
     int predictorMask;
+    uint32_t *debug;           // optional diagnostic dump (GF_ENC_DEBUG_WORDS per tile), normally null
 };
 
 struct GfDecodeArgs {

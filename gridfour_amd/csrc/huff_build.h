@@ -33,61 +33,94 @@ struct GfHuffTree {
     int n;                 // number of leaves (distinct symbols)
 };
 
+// GF_UNI(x): on the device the merge is executed by EVERY lane of one wave with identical
+// (wave-uniform) state; readfirstlane tells the compiler so, which turns the whole loop
+// into scalar code with scalar branches (no exec-mask juggling; hipcc 7.2 miscompiles the
+// divergent single-lane form of this loop).  Stores are issued by the `writer` lane only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GF_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define GF_UNI(x) ((uint32_t)(x))
+#endif
+
 // Sequential merge.  Leaves (cnt[0..n), sym[0..n)) must already be sorted by
-// (count asc, symbol asc); nl[0..n) is set here.
-GF_HD void gf_huff_merge(GfHuffTree &T)
+// (count asc, symbol asc); nl[0..n) is set here.  `n` must be wave-uniform.
+GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer)
 {
-    const int n = T.n;
-    for (int i = 0; i < n; i++) T.nl[i] = 1;
-    int li = 0;                        // leaf queue head
-    int gs = 0, top = 0, ge = 0, m = 0;  // branch groups: front group slots [gs,top), next group at ge, end m
-    int next = n;
+    n = (int)GF_UNI(n);
+    if (writer) {
+        T.n = n;
+        for (int i = 0; i < n; i++) T.nl[i] = 1;
+    }
+    uint32_t li = 0;                              // leaf queue head
+    uint32_t gs = 0, top = 0, ge = 0, m = 0;      // branch groups: front group slots [gs,top), next group at ge, end m
+    uint32_t next = (uint32_t)n;
+    uint32_t leafCnt = n > 0 ? GF_UNI(T.cnt[0]) : 0u;      // count at the head of the leaf queue
+    uint32_t topId = 0, topCnt = 0;               // id and count of the branch on top of the front group
     for (int step = 0; step < n - 1; step++) {
-        int pick[2];
+        uint32_t pick[2], pickCnt[2], pickNl[2];
+#pragma unroll
         for (int k = 0; k < 2; k++) {
-            bool haveB = top > gs;
-            bool haveL = li < n;
-            bool takeB = haveB && (!haveL || T.cnt[T.bq[top - 1]] <= T.cnt[li]);
+            const bool haveB = top > gs;
+            const bool haveL = li < (uint32_t)n;
+            const bool takeB = haveB && (!haveL || topCnt <= leafCnt);
             if (takeB) {
-                pick[k] = T.bq[top - 1];
-                if (ge == m) { m--; ge--; }   // front group is also the last: drop the slot
+                pick[k] = topId;
+                pickCnt[k] = topCnt;
+                if (ge == m) { m--; ge--; }       // front group is also the last: drop the slot
                 top--;
-                if (top == gs) {              // front group exhausted: advance to the next group
+                if (top == gs) {                  // front group exhausted: advance to the next group
                     gs = ge;
                     if (gs < m) {
-                        uint32_t c = T.cnt[T.bq[gs]];
-                        int e = gs + 1;
-                        while (e < m && T.cnt[T.bq[e]] == c) e++;
+                        const uint32_t c = GF_UNI(T.cnt[GF_UNI(T.bq[gs])]);
+                        uint32_t e = gs + 1;
+                        while (e < m && GF_UNI(T.cnt[GF_UNI(T.bq[e])]) == c) e++;
                         ge = e;
                         top = e;
                     } else {
                         gs = top = ge = m;
                     }
                 }
+                if (top > gs) {
+                    topId = GF_UNI(T.bq[top - 1]);
+                    topCnt = GF_UNI(T.cnt[topId]);
+                }
             } else {
-                pick[k] = li++;
+                pick[k] = li;
+                pickCnt[k] = leafCnt;
+                li++;
+                if (li < (uint32_t)n) leafCnt = GF_UNI(T.cnt[li]);
             }
+            pickNl[k] = pick[k] < (uint32_t)n ? 1u : GF_UNI(T.nl[pick[k]]);
         }
-        const int a = pick[0], b = pick[1];
-        const int id = next++;
-        const uint32_t c = T.cnt[a] + T.cnt[b];
-        T.cnt[id] = c;
-        T.parent[a] = (uint16_t)id;                 // left, bit 0  (HuffmanEncoder.java:75-83)
-        T.parent[b] = (uint16_t)(id | 0x8000);      // right, bit 1
-        T.left[id - n] = (uint16_t)a;
-        T.nl[id] = (uint16_t)(T.nl[a] + T.nl[b]);
+        const uint32_t a = pick[0], b = pick[1];
+        const uint32_t id = next++;
+        const uint32_t c = pickCnt[0] + pickCnt[1];
         // push: joins the last group when the counts are equal, else opens a new group
-        bool nonEmpty = top > gs;
-        if (nonEmpty && T.cnt[T.bq[m - 1]] == c) {
-            bool frontIsLast = (ge == m);
-            T.bq[m++] = (uint16_t)id;
+        const bool nonEmpty = top > gs;
+        const uint32_t lastCnt = nonEmpty ? GF_UNI(T.cnt[GF_UNI(T.bq[m - 1])]) : 0u;
+        if (writer) {
+            T.cnt[id] = c;
+            T.parent[a] = (uint16_t)id;                 // left, bit 0  (HuffmanEncoder.java:75-83)
+            T.parent[b] = (uint16_t)(id | 0x8000u);     // right, bit 1
+            T.left[id - n] = (uint16_t)a;
+            T.nl[id] = (uint16_t)(pickNl[0] + pickNl[1]);
+            T.bq[m] = (uint16_t)id;
+        }
+        if (nonEmpty && lastCnt == c) {
+            const bool frontIsLast = (ge == m);
+            m++;
             if (frontIsLast) { ge = m; top = m; }
         } else {
-            T.bq[m++] = (uint16_t)id;
+            m++;
             if (!nonEmpty) { gs = m - 1; top = m; ge = m; }
         }
+        if (top == m) {                                 // the new branch is the top of the front group
+            topId = id;
+            topCnt = c;
+        }
     }
-    if (n >= 1) T.parent[2 * n - 2] = 0xFFFF;       // root
+    if (writer && n >= 1) T.parent[2 * n - 2] = 0xFFFF; // root
 }
 
 // Code of sorted leaf i: path bits root->leaf, first step in bit 0 (the order
@@ -102,7 +135,7 @@ GF_HD int gf_huff_leaf_code(const GfHuffTree &T, int i, uint64_t *code, uint32_t
     uint32_t p = 0;
     int len = 0;
     int x = i;
-    while (x != root) {
+    while (x != root && len < 256) {   // the bound only matters if the tables are corrupt
         uint32_t pr = T.parent[x];
         uint32_t isR = pr >> 15;
         pr &= 0x7fffu;

@@ -401,17 +401,22 @@ typedef struct {
     int overflow;
 } bitw_t;
 
-static inline void bw_bit(bitw_t *w, int bit)
-{
-    if (w->pos >= w->capBits) { w->overflow = 1; return; }
-    if (bit & 1) w->buf[w->pos >> 3] |= (uint8_t)(1u << (w->pos & 7));
-    w->pos++;
-}
-
 static inline void bw_bits(bitw_t *w, int n, uint32_t v)
 {
-    for (int i = 0; i < n; i++) bw_bit(w, (int)((v >> i) & 1));
+    /* appendBits(n, v): low n bits of v, LSB first (BitOutputStore.java:224-264); n <= 32.
+     * The buffer is zero beyond pos, so OR-ing whole bytes is equivalent to appending bits. */
+    if (w->pos + (size_t)n > w->capBits) { w->overflow = 1; return; }
+    uint64_t x = (uint64_t)(n < 32 ? (v & ((1u << n) - 1u)) : v) << (w->pos & 7);
+    size_t byte = w->pos >> 3;
+    int total = n + (int)(w->pos & 7);
+    for (int i = 0; i < total; i += 8) {
+        w->buf[byte++] |= (uint8_t)x;
+        x >>= 8;
+    }
+    w->pos += (size_t)n;
 }
+
+static inline void bw_bit(bitw_t *w, int bit) { bw_bits(w, 1, (uint32_t)(bit & 1)); }
 
 typedef struct {
     const uint8_t *buf;
@@ -580,9 +585,10 @@ int gvo_huffman_encode(uint8_t *bits, size_t capBits, size_t *bitPos,
     }
     for (size_t i = 0; i < nSymbols; i++) {                           /* :198-213 */
         const hnode_t *node = &nodes[symbols[i]];
-        for (int j = 0; j < node->nBitsInCode; j++) {
-            bw_bit(&w, (node->code[j >> 3] >> (j & 7)) & 1);
-        }
+        int nFull = node->nBitsInCode / 8;
+        for (int j = 0; j < nFull; j++) bw_bits(&w, 8, node->code[j]);
+        int rem = node->nBitsInCode - nFull * 8;
+        if (rem > 0) bw_bits(&w, rem, node->code[nFull]);
     }
     *bitPos = w.pos;
     free(nodes);

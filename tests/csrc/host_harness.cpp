@@ -38,7 +38,7 @@ int hh_huffman_encode(uint8_t *bits, size_t capBits, size_t *bitPos, const uint8
     static GfHuffTree T;
     T.n = n;
     for (int i = 0; i < n; i++) { T.cnt[i] = hist[order[i]]; T.sym[i] = (uint8_t)order[i]; }
-    gf_huff_merge(T);
+    gf_huff_merge(T, n, true);
     uint64_t code[256]; int len[256];
     size_t treeStart = pos;
     put((uint64_t)(n - 1), 8);
@@ -60,4 +60,53 @@ int hh_huffman_encode(uint8_t *bits, size_t capBits, size_t *bitPos, const uint8
 uint32_t hh_stream_cell(int model, uint32_t nR, uint32_t nC, uint32_t s) { return gf_stream_cell(model, nR, nC, s); }
 int hh_m32_len(uint32_t x) { return gf_m32_len(x); }
 uint32_t hh_m32_byte(uint32_t x, int n, int k) { return gf_m32_byte(x, n, k); }
+}
+
+// layout of the encode kernel's debug dump (gvrs_encode_layout.h)
+#include "../../gridfour_amd/csrc/gvrs_encode_layout.h"
+#include <cstddef>
+extern "C" {
+size_t hh_sizeof_persist() { return sizeof(EncPersist); }
+size_t hh_sizeof_tree() { return sizeof(GfHuffTree); }
+size_t hh_off_persist(int f)
+{
+    switch (f) {
+    case 0: return offsetof(EncPersist, hist);
+    case 1: return offsetof(EncPersist, tab);
+    case 2: return offsetof(EncPersist, img);
+    case 3: return offsetof(EncPersist, totalBits);
+    case 4: return offsetof(EncPersist, treeEndBit);
+    case 5: return offsetof(EncPersist, maxLen);
+    case 6: return offsetof(EncPersist, maxN);
+    case 7: return offsetof(EncPersist, nM32);
+    case 8: return offsetof(EncPersist, model);
+    case 9: return offsetof(EncPersist, seed);
+    default: return 0;
+    }
+}
+size_t hh_off_tree(int f)
+{
+    switch (f) {
+    case 0: return offsetof(GfHuffTree, cnt);
+    case 1: return offsetof(GfHuffTree, parent);
+    case 2: return offsetof(GfHuffTree, left);
+    case 3: return offsetof(GfHuffTree, nl);
+    case 4: return offsetof(GfHuffTree, bq);
+    case 5: return offsetof(GfHuffTree, sym);
+    case 6: return offsetof(GfHuffTree, n);
+    default: return 0;
+    }
+}
+// reference tables for a histogram: sorted leaves, parents, nl (same code path as the device)
+int hh_build_tree(const uint32_t *hist, GfHuffTree *T)
+{
+    std::vector<int> order;
+    for (int s = 0; s < 256; s++) if (hist[s]) order.push_back(s);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return hist[a] != hist[b] ? hist[a] < hist[b] : a < b; });
+    memset(T, 0, sizeof(*T));
+    T->n = (int)order.size();
+    for (int i = 0; i < T->n; i++) { T->cnt[i] = hist[order[i]]; T->sym[i] = (uint8_t)order[i]; }
+    if (T->n > 1) gf_huff_merge(*T, T->n, true);
+    return T->n;
+}
 }
