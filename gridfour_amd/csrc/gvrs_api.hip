@@ -18,6 +18,7 @@
 namespace {
 
 thread_local std::string g_lastError;
+int g_encPhaseLimit = 0, g_decPhaseLimit = 0;   // diagnostic phase ablation (tools only)
 uint32_t *g_encodeDebug = nullptr;   // diagnostic dump target of the next encode launches (tools only)
 
 gf_status hipFail(hipError_t e, const char *what)
@@ -78,6 +79,7 @@ const char *gf_version(void) { return "gvrs-hip-codec 0.1 (gfx950)"; }
 // Not part of the public ABI: lets tools/ capture the encode kernel's on-chip tables
 // (gvrs_encode_layout.h).  d_words must hold gf_internal_encode_debug_words() uint32 per tile.
 void gf_internal_set_encode_debug(void *d_words) { g_encodeDebug = (uint32_t *)d_words; }
+void gf_internal_set_phase_limits(int enc, int dec) { g_encPhaseLimit = enc; g_decPhaseLimit = dec; }
 size_t gf_internal_encode_debug_words(void);
 
 const char *gf_status_string(int s)
@@ -209,6 +211,7 @@ gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codec
     a.codecIndex = codecIndex;
     a.predictorMask = predictorMask & GF_PM_ALL;
     a.debug = g_encodeDebug;
+    a.phaseLimit = g_encPhaseLimit;
     GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
 }
@@ -243,6 +246,7 @@ gf_status gf_huffman_decode_batch_i32_dev(gf_context *c, void *stream, int nRows
     a.nRows = nRows;
     a.nCols = nCols;
     a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
+    a.phaseLimit = g_decPhaseLimit;
     GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     return GF_OK;
 }
@@ -401,11 +405,17 @@ gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, 
         if (s == GF_OK) {
             uint32_t l = 0;
             int32_t tst = 0;
-            hipMemcpyAsync(&l, dLen, 4, hipMemcpyDeviceToHost, c->stream);
-            hipMemcpyAsync(&tst, dSt, 4, hipMemcpyDeviceToHost, c->stream);
-            hipStreamSynchronize(c->stream);
+            hipError_t e1 = hipMemcpyAsync(&l, dLen, 4, hipMemcpyDeviceToHost, c->stream);
+            hipError_t e2 = hipMemcpyAsync(&tst, dSt, 4, hipMemcpyDeviceToHost, c->stream);
+            hipError_t e3 = hipStreamSynchronize(c->stream);
             big[t].resize(l);
-            hipMemcpy(big[t].data(), slot.p, l, hipMemcpyDeviceToHost);
+            hipError_t e4 = l ? hipMemcpy(big[t].data(), slot.p, l, hipMemcpyDeviceToHost) : hipSuccess;
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+                slot.release();
+                meta.release();
+                return hipFail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4,
+                               "overflow tile copy");
+            }
             lengths[t] = l;
             st[t] = tst;
         }

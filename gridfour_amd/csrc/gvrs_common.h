@@ -14,6 +14,11 @@
 
 #define GF_NULL_CODE 0x80000000u
 
+// 16-byte load from an address that is only 4-byte aligned (gfx950 global loads allow it)
+struct __attribute__((packed, aligned(4))) GfU4 {
+    uint32_t x, y, z, w;
+};
+
 // ---- CodecM32 (compress/CodecM32.java:257-311) -------------------------
 // Number of M32 bytes of a residual (1..6).  Thresholds :105-111.
 GF_HD int gf_m32_len(uint32_t x)

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
 
+        if (a.phaseLimit == 1) continue;
         uint8_t *m32 = nM32 <= a.ldsM32Bytes ? ldsM32 : a.workspace + (size_t)blockIdx.x * a.workspaceStride;
         int32_t tileStatus = GF_K_OK;
 
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
 
+        if (a.phaseLimit == 2) continue;
         // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
         {
             M32Step step{m32, nM32};
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
 
+        if (a.phaseLimit == 3) continue;
         // ---------------- phase 3: predictor inverse (wrap-around prefix sums) ----------------
         if (model != 4) {
             // Triangle: column sums of the interior residuals first (needs row 0 still as residuals)

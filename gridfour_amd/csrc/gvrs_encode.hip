@@ -95,6 +95,46 @@ __device__ __forceinline__ uint32_t cell_residual(int model, const uint32_t *__r
     }
 }
 
+// Bitonic sort of 256 32-bit keys held 4 per lane (element e = r*64 + lane), ascending.
+__device__ __forceinline__ void wave_bitonic_sort256(uint32_t (&k)[4], int lane)
+{
+#pragma unroll
+    for (int size = 2; size <= 256; size <<= 1) {
+#pragma unroll
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int rj = j >> 6;           // partner lives in another register of the same lane
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if ((r & rj) == 0) {
+                        const int r2 = r | rj;
+                        const bool asc = ((r * 64) & size) == 0;
+                        const uint32_t lo = min(k[r], k[r2]), hi = max(k[r], k[r2]);
+                        k[r] = asc ? lo : hi;
+                        k[r2] = asc ? hi : lo;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t other = (uint32_t)__shfl_xor((int)k[r], j, 64);
+                    const bool asc = (((r * 64) | lane) & size) == 0;
+                    const bool lower = (lane & j) == 0;
+                    k[r] = (lower == asc) ? min(k[r], other) : max(k[r], other);
+                }
+            }
+        }
+    }
+}
+
+// diagnostic: cycle stamps per phase (only when a debug buffer is attached)
+#define GF_STAMP(i)                                                                       \
+    do {                                                                                  \
+        if (a.debug && tid == 0)                                                          \
+            (a.debug + t * (size_t)GF_ENC_DEBUG_WORDS + GF_ENC_DEBUG_WORDS - 16)[i] =    \
+                (uint32_t)__builtin_amdgcn_s_memtime();                                   \
+    } while (0)
+
 struct BitSink {
     uint32_t *win;
     uint64_t acc;
@@ -153,6 +193,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
 
+        GF_STAMP(0);
         // ---------------- phase A: null scan + three histograms ----------------
         for (int i = tid; i < 3 * 256 * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
         if (tid == 0) { P.flags = 0; P.sumStart = 0; P.nStart = 0; }
@@ -163,31 +204,69 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
         const uint32_t rep = (uint32_t)lane & (HIST_R - 1);
         uint32_t myFlags = 0, maxN1 = 0, maxN2 = 0, maxN3 = 0;
         {
-            const uint32_t dq = ENC_THREADS / nC, dr = ENC_THREADS % nC;
-            uint32_t r = (uint32_t)tid / nC, c = (uint32_t)tid % nC;
-            for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
-                const uint32_t v = tile[idx];
-                myFlags |= (v == GF_NULL_CODE) ? 1u : 2u;
-                if (idx > 0) {
-                    const uint32_t W = c > 0 ? tile[idx - 1] : 0u;
-                    const uint32_t WW = c > 1 ? tile[idx - 2] : 0u;
-                    const uint32_t N = r > 0 ? tile[idx - nC] : 0u;
-                    const uint32_t NW = (r > 0 && c > 0) ? tile[idx - nC - 1] : 0u;
-                    const uint32_t d1 = gf_res_differencing(r, c, v, W, N);
-                    const uint32_t d2 = gf_res_linear(r, c, v, W, WW, N);
-                    const uint32_t d3 = gf_res_triangle(r, c, v, W, N, NW);
-                    const int n1 = gf_m32_len(d1), n2 = gf_m32_len(d2), n3 = gf_m32_len(d3);
-                    maxN1 = max(maxN1, (uint32_t)n1);
-                    maxN2 = max(maxN2, (uint32_t)n2);
-                    maxN3 = max(maxN3, (uint32_t)n3);
-                    for (int k = 0; k < n1; k++) atomicAdd(&S.histR[0][gf_m32_byte(d1, n1, k) * HIST_R + rep], 1u);
-                    for (int k = 0; k < n2; k++) atomicAdd(&S.histR[1][gf_m32_byte(d2, n2, k) * HIST_R + rep], 1u);
-                    if (triOk)
-                        for (int k = 0; k < n3; k++) atomicAdd(&S.histR[2][gf_m32_byte(d3, n3, k) * HIST_R + rep], 1u);
+            // Each thread takes quads of 4 consecutive cells (flat index), two quads per iteration, and
+            // issues every load of the iteration before using any of them: 16-byte loads of the cells and
+            // of the row above (4-byte aligned only), plus the three halo words.
+            auto addHist = [&](int p, uint32_t d) -> uint32_t {
+                const int n = gf_m32_len(d);
+                if (n == 1) {
+                    atomicAdd(&S.histR[p][gf_m32_byte(d, 1, 0) * HIST_R + rep], 1u);
+                } else {
+                    for (int k = 0; k < n; k++) atomicAdd(&S.histR[p][gf_m32_byte(d, n, k) * HIST_R + rep], 1u);
                 }
-                c += dr;
-                r += dq;
-                if (c >= nC) { c -= nC; r++; }
+                return (uint32_t)n;
+            };
+            struct Quad {
+                uint32_t cur[4], up[4], wm1, wm2, upm1;
+            };
+            auto loadQuad = [&](uint32_t i0, Quad &Q) {
+                if (i0 + 3 < nCells) {
+                    const GfU4 v = *reinterpret_cast<const GfU4 *>(tile + i0);
+                    Q.cur[0] = v.x; Q.cur[1] = v.y; Q.cur[2] = v.z; Q.cur[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) Q.cur[j] = i0 + j < nCells ? tile[i0 + j] : 0u;
+                }
+                Q.wm1 = i0 >= 1 ? tile[i0 - 1] : 0u;
+                Q.wm2 = i0 >= 2 ? tile[i0 - 2] : 0u;
+                if (i0 >= nC && i0 + 3 < nCells) {
+                    const GfU4 v = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC));
+                    Q.up[0] = v.x; Q.up[1] = v.y; Q.up[2] = v.z; Q.up[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) Q.up[j] = (i0 + j >= nC && i0 + j < nCells) ? tile[i0 + j - nC] : 0u;
+                }
+                Q.upm1 = i0 >= nC + 1 ? tile[i0 - nC - 1] : 0u;
+            };
+            auto doQuad = [&](uint32_t i0, const Quad &Q) {
+                uint32_t r = i0 / nC, c = i0 - r * nC;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t idx = i0 + j;
+                    if (idx < nCells) {
+                        const uint32_t v = Q.cur[j];
+                        myFlags |= (v == GF_NULL_CODE) ? 1u : 2u;
+                        if (idx > 0) {
+                            const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+                            const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
+                            const uint32_t N = Q.up[j];
+                            const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+                            maxN1 = max(maxN1, addHist(0, gf_res_differencing(r, c, v, W, N)));
+                            maxN2 = max(maxN2, addHist(1, gf_res_linear(r, c, v, W, WW, N)));
+                            if (triOk) maxN3 = max(maxN3, addHist(2, gf_res_triangle(r, c, v, W, N, NW)));
+                        }
+                    }
+                    if (++c >= nC) { c = 0; r++; }
+                }
+            };
+            const uint32_t nQuads = (nCells + 3) >> 2;
+            for (uint32_t q = tid; q < nQuads; q += 2 * ENC_THREADS) {
+                Quad Q0, Q1;
+                const uint32_t q1 = q + ENC_THREADS;
+                loadQuad(q << 2, Q0);
+                if (q1 < nQuads) loadQuad(q1 << 2, Q1);
+                doQuad(q << 2, Q0);
+                if (q1 < nQuads) doQuad(q1 << 2, Q1);
             }
         }
         if (myFlags) atomicOr(&P.flags, myFlags);
@@ -196,6 +275,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
         atomicMax(&P.maxN[2], maxN3);
         __syncthreads();
         const uint32_t flags = P.flags;
+        GF_STAMP(1);
+        if (a.phaseLimit == 1) { __syncthreads(); continue; }
         const bool anyNull = flags & 1u, anyValid = flags & 2u;
 
         if (!anyValid) {                         // CodecHuffman.java:80-82 -> null
@@ -279,62 +360,99 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
         for (int i = tid; i < 3 * IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
         __syncthreads();                         // histR dead from here: S.tree may be written
 
-        // ---------------- phase B: one Huffman tree per wave ----------------
+        GF_STAMP(2);
+        // ---------------- phase B: the three Huffman trees ----------------
+        // B1  waves 0..2: sort the used symbols of predictor p by (count asc, symbol asc)
         if (wave < 3 && P.model[wave] != 0) {
             const int p = wave;
             GfHuffTree &T = S.tree[p];
-            uint32_t *ccnt = &T.cnt[255];        // compacted counts (temp, branch area is free until the merge)
-            uint16_t *csym = T.bq;               // compacted symbols (temp)
             int n = 0;
             uint32_t nM32 = 0;
-            for (int j = 0; j < 4; j++) {
-                const int s = lane + 64 * j;
-                const uint32_t cnt = P.hist[p][s];
-                const unsigned long long m = __ballot(cnt != 0);
-                const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-                if (cnt != 0) { ccnt[pos] = cnt; csym[pos] = (uint16_t)s; }
-                n += __popcll(m);
-                nM32 += cnt;
+            if (6ull * nCells < (1ull << 24)) {
+                // counts < 2^24: one 32-bit key (count << 8 | symbol) per symbol, 256 keys in 4 registers
+                // per lane (element e = r*64 + lane), bitonic network: 36 compare-exchange steps
+                uint32_t key[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t cnt = P.hist[p][r * 64 + lane];
+                    key[r] = cnt ? ((cnt << 8) | (uint32_t)(r * 64 + lane)) : 0xFFFFFFFFu;
+                    n += __popcll(__ballot(cnt != 0));
+                    nM32 += cnt;
+                }
+                wave_bitonic_sort256(key, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int e = r * 64 + lane;
+                    if (e < n) { T.cnt[e] = key[r] >> 8; T.sym[e] = (uint8_t)(key[r] & 0xffu); }
+                }
+            } else {
+                // huge tiles: compaction + rank sort on full 32-bit counts
+                uint32_t *ccnt = &T.cnt[255];    // compacted counts (temp, branch area is free until the merge)
+                uint16_t *csym = T.bq;           // compacted symbols (temp)
+                for (int j = 0; j < 4; j++) {
+                    const int s = lane + 64 * j;
+                    const uint32_t cnt = P.hist[p][s];
+                    const unsigned long long m = __ballot(cnt != 0);
+                    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                    if (cnt != 0) { ccnt[pos] = cnt; csym[pos] = (uint16_t)s; }
+                    n += __popcll(m);
+                    nM32 += cnt;
+                }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t rk[4], myc[4];
+                uint16_t mys[4];
+                for (int j = 0; j < 4; j++) {
+                    const int i = lane + 64 * j;
+                    rk[j] = 0;
+                    if (i < n) {
+                        const uint32_t ci = ccnt[i];
+                        myc[j] = ci;
+                        mys[j] = csym[i];
+                        uint32_t rank = 0;
+                        for (int q = 0; q < n; q++) {
+                            const uint32_t cq = ccnt[q];
+                            rank += (cq < ci || (cq == ci && q < i)) ? 1u : 0u;
+                        }
+                        rk[j] = rank;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < 4; j++) {
+                    const int i = lane + 64 * j;
+                    if (i < n) { T.cnt[rk[j]] = myc[j]; T.sym[rk[j]] = (uint8_t)mys[j]; }
+                }
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) nM32 += __shfl_xor(nM32, d, 64);
-            __builtin_amdgcn_wave_barrier();
-            // rank sort by (count asc, symbol asc); symbols are already ascending in compact order
-            uint32_t rk[4], myc[4];
-            uint16_t mys[4];
-            for (int j = 0; j < 4; j++) {
-                const int i = lane + 64 * j;
-                rk[j] = 0;
-                if (i < n) {
-                    const uint32_t ci = ccnt[i];
-                    myc[j] = ci;
-                    mys[j] = csym[i];
-                    uint32_t rank = 0;
-                    for (int q = 0; q < n; q++) {
-                        const uint32_t cq = ccnt[q];
-                        rank += (cq < ci || (cq == ci && q < i)) ? 1u : 0u;
-                    }
-                    rk[j] = rank;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int j = 0; j < 4; j++) {
-                const int i = lane + 64 * j;
-                if (i < n) { T.cnt[rk[j]] = myc[j]; T.sym[rk[j]] = (uint8_t)mys[j]; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint32_t *img = P.img[p];
-            // the merge runs wave-uniformly on all lanes (scalar loop); lane 0 does the stores
-            if (n > 1) gf_huff_merge(T, n, lane == 0);
-            __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
                 T.n = n;
+                P.nM32[p] = nM32;
+            }
+        }
+        __syncthreads();
+        GF_STAMP(3);
+        // B2  SIMT over trees: lane p of wave 0 runs the sequential merge of predictor p (per-lane LDS
+        //     addressing); a scalar-unit formulation would be bound by the CU's single SALU
+        if (wave == 0 && lane < 3 && P.model[lane] != 0) {
+            GfHuffTree &T = S.tree[lane];
+            const int n = T.n;
+            if (n > 1) gf_huff_merge_t<false>(T, n, true);
+        }
+        __syncthreads();
+        GF_STAMP(4);
+        // B3  waves 0..2: header image, codes, serialised tree, exact bit totals
+        if (wave < 3 && P.model[wave] != 0) {
+            const int p = wave;
+            GfHuffTree &T = S.tree[p];
+            const int n = T.n;
+            const uint32_t nM32 = P.nM32[p];
+            uint32_t *img = P.img[p];
+            if (lane == 0) {
                 // header, CodecHuffman.java:121-130 (LSB-first bit store == little-endian bytes)
                 const uint32_t seed = P.seed;
                 img[0] = ((uint32_t)a.codecIndex & 0xffu) | ((uint32_t)P.model[p] << 8) | (seed << 16);
                 img[1] = (seed >> 16) | (nM32 << 16);
                 img[2] = (nM32 >> 16) | ((n > 1 ? (uint32_t)(n - 1) : 0u) << 16);
-                P.nM32[p] = nM32;
             }
             __builtin_amdgcn_wave_barrier();
             unsigned long long textBits = 0;
@@ -375,6 +493,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
             }
         }
         __syncthreads();
+        GF_STAMP(5);
         if (a.debug) {                           // diagnostic dump of the on-chip state (tests/tools only)
             uint32_t *dbg = a.debug + t * (size_t)GF_ENC_DEBUG_WORDS;
             const uint32_t *pw = reinterpret_cast<const uint32_t *>(&P);
@@ -384,6 +503,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
                 dbg[sizeof(EncPersist) / 4 + i] = tw[i];
         }
         __syncthreads();                         // trees dead from here: S.win may be written
+        if (a.phaseLimit == 2) continue;
 
         // ---------------- phase C: pick the shortest, pack it ----------------
         int best = -1;
@@ -441,6 +561,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
             wordBase += fullWords;
             __syncthreads();
         };
+        GF_STAMP(6);
         flush();                                 // header + tree image
         for (uint32_t chunk = 0; chunk < nStream; chunk += chunkElems) {
             // pass 1: residuals + their bit counts
@@ -485,6 +606,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
             bitBase += total;
             flush();
         }
+        GF_STAMP(7);
         // tail: whatever is left in the window (also covers nStream == 0 / uniform tiles)
         {
             const uint32_t remBits = bitBase - wordBase * 32u;

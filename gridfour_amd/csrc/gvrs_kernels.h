@@ -25,6 +25,7 @@ struct GfEncodeArgs {
     int codecIndex;
     int predictorMask;
     uint32_t *debug;           // optional diagnostic dump (GF_ENC_DEBUG_WORDS per tile), normally null
+    int phaseLimit;            // diagnostic: stop after phase A (1) / B (2); 0 = run everything
 };
 
 struct GfDecodeArgs {
@@ -40,6 +41,7 @@ struct GfDecodeArgs {
     size_t nTiles;
     int nRows, nCols;
     uint32_t ldsM32Bytes;      // capacity of the in-LDS M32 buffer
+    int phaseLimit;            // diagnostic: stop after phase 0/1/2 (value 1/2/3); 0 = run everything
 };
 
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);

@@ -44,10 +44,16 @@ struct GfHuffTree {
 #endif
 
 // Sequential merge.  Leaves (cnt[0..n), sym[0..n)) must already be sorted by
-// (count asc, symbol asc); nl[0..n) is set here.  `n` must be wave-uniform.
-GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer)
+// (count asc, symbol asc); nl[0..n) is set here.
+//   UNI = true : wave-uniform execution (all lanes, same tree, scalarised; `n` wave-uniform,
+//                `writer` = the one lane that stores)
+//   UNI = false: plain per-thread execution -- on the device each LANE builds its own tree
+//                (SIMT over trees), on the host this is the ordinary sequential code.
+template <bool UNI>
+GF_HD void gf_huff_merge_t(GfHuffTree &T, int n, bool writer)
 {
-    n = (int)GF_UNI(n);
+#define GF_U(x) (UNI ? GF_UNI(x) : (uint32_t)(x))
+    n = (int)GF_U(n);
     if (writer) {
         T.n = n;
         for (int i = 0; i < n; i++) T.nl[i] = 1;
@@ -55,8 +61,11 @@ GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer)
     uint32_t li = 0;                              // leaf queue head
     uint32_t gs = 0, top = 0, ge = 0, m = 0;      // branch groups: front group slots [gs,top), next group at ge, end m
     uint32_t next = (uint32_t)n;
-    uint32_t leafCnt = n > 0 ? GF_UNI(T.cnt[0]) : 0u;      // count at the head of the leaf queue
-    uint32_t topId = 0, topCnt = 0;               // id and count of the branch on top of the front group
+    uint32_t leafCnt = n > 0 ? GF_U(T.cnt[0]) : 0u;      // count at the head of the leaf queue
+    uint32_t topId = 0, topCnt = 0, topNl = 0;    // id, count, leaf count of the branch on top of the front group
+    uint32_t lastCnt = 0;                         // count of the newest branch == count of the LAST group while
+                                                  // the list is non-empty (the newest branch is popped first
+                                                  // inside its group, and nothing newer can have a smaller count)
     for (int step = 0; step < n - 1; step++) {
         uint32_t pick[2], pickCnt[2], pickNl[2];
 #pragma unroll
@@ -67,14 +76,15 @@ GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer)
             if (takeB) {
                 pick[k] = topId;
                 pickCnt[k] = topCnt;
+                pickNl[k] = topNl;
                 if (ge == m) { m--; ge--; }       // front group is also the last: drop the slot
                 top--;
                 if (top == gs) {                  // front group exhausted: advance to the next group
                     gs = ge;
                     if (gs < m) {
-                        const uint32_t c = GF_UNI(T.cnt[GF_UNI(T.bq[gs])]);
+                        const uint32_t c = GF_U(T.cnt[GF_U(T.bq[gs])]);
                         uint32_t e = gs + 1;
-                        while (e < m && GF_UNI(T.cnt[GF_UNI(T.bq[e])]) == c) e++;
+                        while (e < m && GF_U(T.cnt[GF_U(T.bq[e])]) == c) e++;
                         ge = e;
                         top = e;
                     } else {
@@ -82,29 +92,30 @@ GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer)
                     }
                 }
                 if (top > gs) {
-                    topId = GF_UNI(T.bq[top - 1]);
-                    topCnt = GF_UNI(T.cnt[topId]);
+                    topId = GF_U(T.bq[top - 1]);
+                    topCnt = GF_U(T.cnt[topId]);
+                    topNl = GF_U(T.nl[topId]);
                 }
             } else {
                 pick[k] = li;
                 pickCnt[k] = leafCnt;
+                pickNl[k] = 1u;
                 li++;
-                if (li < (uint32_t)n) leafCnt = GF_UNI(T.cnt[li]);
+                if (li < (uint32_t)n) leafCnt = GF_U(T.cnt[li]);
             }
-            pickNl[k] = pick[k] < (uint32_t)n ? 1u : GF_UNI(T.nl[pick[k]]);
         }
         const uint32_t a = pick[0], b = pick[1];
         const uint32_t id = next++;
         const uint32_t c = pickCnt[0] + pickCnt[1];
         // push: joins the last group when the counts are equal, else opens a new group
         const bool nonEmpty = top > gs;
-        const uint32_t lastCnt = nonEmpty ? GF_UNI(T.cnt[GF_UNI(T.bq[m - 1])]) : 0u;
+        const uint32_t nlSum = pickNl[0] + pickNl[1];
         if (writer) {
             T.cnt[id] = c;
             T.parent[a] = (uint16_t)id;                 // left, bit 0  (HuffmanEncoder.java:75-83)
             T.parent[b] = (uint16_t)(id | 0x8000u);     // right, bit 1
             T.left[id - n] = (uint16_t)a;
-            T.nl[id] = (uint16_t)(pickNl[0] + pickNl[1]);
+            T.nl[id] = (uint16_t)nlSum;
             T.bq[m] = (uint16_t)id;
         }
         if (nonEmpty && lastCnt == c) {
@@ -115,13 +126,18 @@ GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer)
             m++;
             if (!nonEmpty) { gs = m - 1; top = m; ge = m; }
         }
+        lastCnt = c;
         if (top == m) {                                 // the new branch is the top of the front group
             topId = id;
             topCnt = c;
+            topNl = nlSum;
         }
     }
     if (writer && n >= 1) T.parent[2 * n - 2] = 0xFFFF; // root
 }
+#undef GF_U
+
+GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer) { gf_huff_merge_t<true>(T, n, writer); }
 
 // Code of sorted leaf i: path bits root->leaf, first step in bit 0 (the order
 // HuffmanEncoder.java:198-213 appends them).  *pos = bit offset of the leaf's

@@ -195,3 +195,47 @@ def test_slot_overflow_is_reported_not_truncated(codec):
     b.free()
     packs, _, status = codec.encode_batch(0, n_rows, n_cols, tiles)
     assert list(status) == [0, 0] and packs[0] == ref0 and packs[1] == ref1
+
+
+def _tie_symbol_sets():
+    rng = np.random.default_rng(4321)
+    yield np.array([5, 9, 9], np.uint8)
+    yield np.tile(np.arange(250, dtype=np.uint8), 3)                    # all counts equal
+    yield np.tile(np.arange(7, dtype=np.uint8) * 31, 5)
+    yield np.repeat(np.arange(12, dtype=np.uint8), 2 ** np.arange(12))  # powers of two
+    yield np.repeat(np.arange(16, dtype=np.uint8) + 100,
+                    [1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987])   # Fibonacci: deepest tree
+    for _ in range(24):
+        n_sym = int(rng.integers(2, 251))
+        hi = int(rng.choice([1, 2, 3, 5, 20, 1000]))
+        counts = rng.integers(1, hi + 1, n_sym)
+        syms = rng.permutation(250)[:n_sym].astype(np.uint8)
+        data = np.repeat(syms, counts)
+        rng.shuffle(data)
+        yield data
+
+
+def test_tree_tie_breaking_on_device(codec):
+    """Histograms full of equal counts (leaf/leaf, leaf/branch and branch/branch ties): the packing
+    must still equal the reference's linked-list construction byte for byte.  The symbol stream is
+    forced by a 1-row tile under the Differencing predictor (residual k <-> M32 byte k)."""
+    import gridfour_amd
+    from gridfour_amd import DeviceTileBatch
+    # 250 usable single-byte residual values: -125..124 (avoids the introducer/null bytes 7f, 80, 81)
+    for data in _tie_symbol_sets():
+        res = data.astype(np.int64) - 125
+        v = np.concatenate([[1000], 1000 + np.cumsum(res)]).astype(np.int32)
+        n = v.size
+        stride = int(gridfour_amd.lib().gf_huffman_max_packing(1, n))
+        b = DeviceTileBatch(codec.ctx, 1, n, 1, slot_stride=stride)
+        b.values.upload(v)
+        b.encode(codec_index=0, predictor_mask=1)
+        codec.ctx.synchronize()
+        ref, _ = oracle.codec_huffman_encode(0, 1, n, v, predictor_mask=1)
+        assert b.get_enc_status()[0] == 0
+        got = b.get_packing(0)
+        assert got == ref, ("tree mismatch", len(set(data.tolist())), len(got), len(ref))
+        b.decode()
+        codec.ctx.synchronize()
+        assert b.get_dec_status()[0] == 0 and np.array_equal(b.get_decoded()[0], v)
+        b.free()
