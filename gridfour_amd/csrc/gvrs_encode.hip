@@ -8,16 +8,21 @@
 //   io/BitOutputStore.java:205-288             LSB-first bit order
 //
 // Phases of a workgroup (256 threads = 4 waves) on one tile
-//   A  one pass over the tile: residuals of all three predictors per cell, M32 byte
-//      lengths, three 256-bin histograms in LDS (replicated 8x to spread atomics)
-//   B  waves 0..2 build one Huffman tree each (rank sort of the used symbols, O(1)-pop
-//      merge of huff_build.h on lane 0, per-leaf code + pre-order position in parallel),
-//      giving code tables, the serialised header+tree image and the exact bit total
-//   C  the shortest candidate wins (ties: D, L, T order, CodecHuffman.java:107); its
-//      residuals are recomputed in stream order (tile re-read hits L2), code lengths are
-//      prefix-summed across the workgroup and each thread ORs its bits into an LDS window
-//      that is flushed to the tile's output slot with coalesced dword stores.
+//   A  one flat pass over the tile, 8 consecutive cells per thread (two 16-byte loads + the row
+//      above + 3 halo words, all issued before use): residuals of all three predictors, M32
+//      bytes, three 256-bin histograms in LDS (replicated to spread the atomics).  The common
+//      single-byte residual is straight-line code; multi-byte residuals take a masked side path.
+//   B  B1 waves 0..2 bitonic-sort the used symbols of one predictor each, B2 the sequential
+//      tree merges run SIMT (lane p of wave 0 = predictor p), B3 waves 0..2 derive codes, the
+//      serialised header+tree image and the exact bit total of their predictor
+//   C  the shortest candidate wins (ties: D, L, T order, CodecHuffman.java:107).  Its stream is
+//      [short border segment] + [flat scan of the cells with an emit mask], which is exactly
+//      the order the reference emits residuals in; code lengths are prefix-summed across the
+//      workgroup and each thread ORs its bits into an LDS window that is flushed to the
+//      tile's output slot with coalesced dword stores (tile re-read hits L2).
 // HBM traffic per cell: 4 B read + c B written; everything else stays on chip.
+// This integer pipeline is instruction-bound, not bandwidth-bound: the fast
+// paths are written branch-free to keep VALU and SALU (exec-mask) instruction counts down.
 
 #include <hip/hip_runtime.h>
 
@@ -28,10 +33,12 @@ namespace {
 
 constexpr int ENC_THREADS = GF_ENC_THREADS;
 constexpr int ENC_WAVES = GF_ENC_WAVES;
-constexpr int HIST_R = 8;                       // histogram replicas
+constexpr int HIST_R = 4;                       // histogram replicas
 constexpr int IMG_WORDS = GF_IMG_WORDS;
-constexpr int WIN_WORDS = 2048;                 // bit-pack window (8 KB)
+constexpr int WIN_WORDS = 4096;                 // bit-pack window (16 KB)
 constexpr int WIN_SLACK = 8;
+constexpr int CPT = 8;                          // cells per thread per step of the flat scans
+constexpr uint32_t STEP_CELLS = ENC_THREADS * CPT;
 
 union EncScratch {
     uint32_t histR[3][256 * HIST_R];            // phase A
@@ -68,7 +75,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *waveSu
     return base + incl - v;
 }
 
-// residual of one cell for a model; idx = r*nC + c
+// residual of one cell for a model (generic form, used by the border segments and fallbacks)
 __device__ __forceinline__ uint32_t cell_residual(int model, const uint32_t *__restrict__ tile, uint32_t nC,
                                                   uint32_t idx, uint32_t r, uint32_t c, uint32_t seed)
 {
@@ -95,17 +102,60 @@ __device__ __forceinline__ uint32_t cell_residual(int model, const uint32_t *__r
     }
 }
 
-// Bitonic sort of 256 32-bit keys held 4 per lane (element e = r*64 + lane), ascending.
-__device__ __forceinline__ void wave_bitonic_sort256(uint32_t (&k)[4], int lane)
+// 8 consecutive cells starting at flat index i0 plus what their predictors need
+struct Cells8 {
+    uint32_t cur[CPT], up[CPT], wm1, wm2, upm1;
+};
+
+__device__ __forceinline__ void load_cells8(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells,
+                                            uint32_t i0, Cells8 &Q)
+{
+    if (i0 >= nC + 2 && i0 + (CPT - 1) < nCells) {       // interior: every word exists
+        const GfU4 a = *reinterpret_cast<const GfU4 *>(tile + i0);
+        const GfU4 b = *reinterpret_cast<const GfU4 *>(tile + i0 + 4);
+        const GfU4 c = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC));
+        const GfU4 d = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC) + 4);
+        Q.wm1 = tile[i0 - 1];
+        Q.wm2 = tile[i0 - 2];
+        Q.upm1 = tile[i0 - nC - 1];
+        Q.cur[0] = a.x; Q.cur[1] = a.y; Q.cur[2] = a.z; Q.cur[3] = a.w;
+        Q.cur[4] = b.x; Q.cur[5] = b.y; Q.cur[6] = b.z; Q.cur[7] = b.w;
+        Q.up[0] = c.x; Q.up[1] = c.y; Q.up[2] = c.z; Q.up[3] = c.w;
+        Q.up[4] = d.x; Q.up[5] = d.y; Q.up[6] = d.z; Q.up[7] = d.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            Q.cur[j] = i0 + j < nCells ? tile[i0 + j] : 0u;
+            Q.up[j] = (i0 + j >= nC && i0 + j < nCells) ? tile[i0 + j - nC] : 0u;
+        }
+        Q.wm1 = (i0 >= 1 && i0 - 1 < nCells) ? tile[i0 - 1] : 0u;
+        Q.wm2 = (i0 >= 2 && i0 - 2 < nCells) ? tile[i0 - 2] : 0u;
+        Q.upm1 = (i0 >= nC + 1 && i0 - nC - 1 < nCells) ? tile[i0 - nC - 1] : 0u;
+    }
+}
+
+// first M32 byte of residual x and whether it is the whole encoding (CodecM32.java:257-283)
+__device__ __forceinline__ uint32_t m32_first_byte(uint32_t x, bool *single)
+{
+    const bool isNull = x == GF_NULL_CODE;
+    const bool one = (x + 126u) <= 252u || isNull;       // -126..126, or Integer.MIN_VALUE -> 0x80
+    *single = one;
+    const uint32_t intro = (int32_t)x < 0 ? 0x81u : 0x7fu;
+    return one ? (isNull ? 0x80u : (x & 0xffu)) : intro;
+}
+
+// Bitonic sort, ascending, of the 64*NREG 32-bit keys held in k[0..NREG) (element e = r*64 + lane).
+template <int NREG>
+__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[4], int lane)
 {
 #pragma unroll
-    for (int size = 2; size <= 256; size <<= 1) {
+    for (int size = 2; size <= 64 * NREG; size <<= 1) {
 #pragma unroll
         for (int j = size >> 1; j > 0; j >>= 1) {
             if (j >= 64) {
                 const int rj = j >> 6;           // partner lives in another register of the same lane
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < NREG; r++) {
                     if ((r & rj) == 0) {
                         const int r2 = r | rj;
                         const bool asc = ((r * 64) & size) == 0;
@@ -116,7 +166,7 @@ __device__ __forceinline__ void wave_bitonic_sort256(uint32_t (&k)[4], int lane)
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < NREG; r++) {
                     const uint32_t other = (uint32_t)__shfl_xor((int)k[r], j, 64);
                     const bool asc = (((r * 64) | lane) & size) == 0;
                     const bool lower = (lane & j) == 0;
@@ -125,6 +175,59 @@ __device__ __forceinline__ void wave_bitonic_sort256(uint32_t (&k)[4], int lane)
             }
         }
     }
+}
+
+// Huffman tree of one predictor by data-parallel rounds (one wave).  K holds the live nodes in
+// list order as keys (count << 9 | tie), 4 per lane, dead slots = 0xFFFFFFFF.  Each round pairs up
+// all nodes whose count is below x0 + x1 -- exactly the next merges of the sequential algorithm
+// of HuffmanEncoder.java:165-194, none of which can be affected by a branch created in the same
+// round -- then re-sorts.  tie: leaf = 256 + sorted index, branch k = 254 - k, so that newer
+// branches precede older ones and leaves of equal count (:175-193).  ~15 rounds instead of
+// ~150 dependent merges.  Writes T.parent / T.left / T.nl.  Needs total count < 2^23.
+__device__ __forceinline__ void wave_huff_rounds(GfHuffTree &T, uint32_t (&K)[4], int n, int lane)
+{
+    uint32_t L = (uint32_t)n, kbase = 0;
+    const uint32_t un = (uint32_t)n;
+    while (L > 1) {
+        const uint32_t s0 = ((uint32_t)__builtin_amdgcn_readlane((int)K[0], 0) >> 9) +
+                            ((uint32_t)__builtin_amdgcn_readlane((int)K[0], 1) >> 9);
+        uint32_t t = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) t += (uint32_t)__popcll(__ballot((K[r] >> 9) < s0));
+        const uint32_t P = t >> 1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if ((uint32_t)(r * 64) < 2u * P) {                      // wave-uniform
+                const uint32_t e = (uint32_t)(r * 64 + lane);
+                const bool inPair = e < 2u * P;
+                const uint32_t mine = K[r];
+                const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
+                const uint32_t tieM = mine & 511u, tieO = other & 511u;
+                const uint32_t idM = tieM >= 256u ? tieM - 256u : un + (254u - tieM);
+                const uint32_t idO = tieO >= 256u ? tieO - 256u : un + (254u - tieO);
+                const uint32_t k = kbase + (e >> 1);
+                const uint32_t parent = un + k;
+                const bool right = e & 1u;
+                if (inPair) {
+                    T.parent[idM] = (uint16_t)(parent | (right ? 0x8000u : 0u));
+                    if (!right) {
+                        const uint32_t nlL = idM < un ? 1u : T.nl[idM];
+                        const uint32_t nlR = idO < un ? 1u : T.nl[idO];
+                        T.left[k] = (uint16_t)idM;
+                        T.nl[parent] = (uint16_t)(nlL + nlR);
+                    }
+                    K[r] = right ? 0xFFFFFFFFu : ((((mine >> 9) + (other >> 9)) << 9) | (254u - k));
+                }
+            }
+        }
+        kbase += P;
+        const uint32_t Lold = L;
+        L -= P;
+        if (Lold > 128) wave_bitonic_sort<4>(K, lane);
+        else if (Lold > 64) wave_bitonic_sort<2>(K, lane);
+        else wave_bitonic_sort<1>(K, lane);
+    }
+    if (lane == 0 && n >= 1) T.parent[2 * n - 2] = 0xFFFF;         // root
 }
 
 // diagnostic: cycle stamps per phase (only when a debug buffer is attached)
@@ -159,7 +262,7 @@ struct BitSink {
         acc >>= 32;
         nacc -= 32;
     }
-    // len <= 32
+    // len <= 32; (code, len) = (0, 0) is a no-op
     __device__ __forceinline__ void put32(uint32_t code, uint32_t len)
     {
         acc |= (uint64_t)code << nacc;
@@ -181,6 +284,180 @@ struct BitSink {
     }
 };
 
+// residual and emit mask of cell j of a Cells8 block for one model (flat-scan form)
+template <int MODEL>
+__device__ __forceinline__ uint32_t flat_residual(const Cells8 &Q, int j, uint32_t idx, uint32_t c, uint32_t nC,
+                                                  uint32_t nCells, uint32_t seed, bool *emit)
+{
+    const uint32_t v = Q.cur[j];
+    const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+    if (MODEL == 1) {
+        *emit = idx >= 1 && idx < nCells;
+        return v - (c > 0 ? W : Q.up[j]);                               // PredictorModelDifferencing.java:120-137
+    } else if (MODEL == 2) {
+        const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
+        *emit = c >= 2 && idx < nCells;
+        return v - (2u * W - WW);                                       // PredictorModelLinear.java:128-141
+    } else if (MODEL == 3) {
+        const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+        *emit = idx >= nC && c >= 1 && idx < nCells;
+        return v - (W + Q.up[j] - NW);                                  // PredictorModelTriangle.java:130-142
+    } else {
+        *emit = idx < nCells;
+        uint32_t prior = c > 0 ? W : (idx >= nC ? Q.up[j] : GF_NULL_CODE);
+        if (prior == GF_NULL_CODE) prior = seed;                        // ...DifferencingWithNulls.java:109-131
+        return v == GF_NULL_CODE ? GF_NULL_CODE : v - prior;
+    }
+}
+
+struct PackState {
+    uint32_t bitBase;    // next free bit of the packing (absolute)
+    uint32_t wordBase;   // words already flushed to the output slot
+};
+
+// moves the completed words of the window to the output slot and slides the window
+// (call after a barrier that ends the emission into the window)
+__device__ __forceinline__ void window_flush(uint32_t *win, uint32_t *__restrict__ out32, PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t fullWords = (ps.bitBase >> 5) - ps.wordBase;
+    for (uint32_t j = tid; j < fullWords; j += ENC_THREADS) out32[ps.wordBase + j] = win[j];
+    const uint32_t partial = win[fullWords];
+    __syncthreads();
+    for (uint32_t j = tid; j <= fullWords; j += ENC_THREADS) win[j] = j == 0 ? partial : 0u;
+    ps.wordBase += fullWords;
+    __syncthreads();
+}
+
+// stream elements [sBegin, sEnd) of `model`, any residual size: the general (slow) packer
+__device__ void pack_generic(int model, const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
+                             const uint64_t *tab, uint32_t elemMaxBits, uint32_t sBegin, uint32_t sEnd,
+                             uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    // elements per chunk such that a chunk can never overflow the window
+    uint32_t E = 4;
+    while (E > 1 && (uint64_t)ENC_THREADS * E * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u) E >>= 1;
+    uint32_t active = ENC_THREADS;
+    if ((uint64_t)ENC_THREADS * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u)
+        active = max(1u, (uint32_t)(((uint64_t)(WIN_WORDS - 2) * 32u) / elemMaxBits));
+    const uint32_t chunkElems = active * E;
+    for (uint32_t chunk = sBegin; chunk < sEnd; chunk += chunkElems) {
+        uint32_t xs[4];
+        uint32_t myBits = 0;
+        const uint32_t s0 = chunk + tid * E;
+        const uint32_t cEnd = min(sEnd, chunk + chunkElems);
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++) {
+            xs[e] = 0;
+            const uint32_t s = s0 + e;
+            if (e < E && tid < active && s < cEnd) {
+                const uint32_t idx = gf_stream_cell(model, nR, nC, s);
+                const uint32_t r = idx / nC, c = idx - r * nC;
+                const uint32_t x = cell_residual(model, tile, nC, idx, r, c, seed);
+                xs[e] = x;
+                const int n = gf_m32_len(x);
+                for (int k = 0; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
+            }
+        }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
+        if (myBits) {
+            BitSink sink;
+            sink.init(win, ps.bitBase + excl - ps.wordBase * 32u);
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                const uint32_t s = s0 + e;
+                if (e < E && tid < active && s < cEnd) {
+                    const uint32_t x = xs[e];
+                    const int n = gf_m32_len(x);
+                    for (int k = 0; k < n; k++) {
+                        const uint64_t cl = tab[gf_m32_byte(x, n, k)];
+                        sink.put(cl & 0x00ffffffffffffffull, (uint32_t)(cl >> 56));
+                    }
+                }
+            }
+            sink.finish();
+        }
+        __syncthreads();
+        ps.bitBase += total;
+        window_flush(win, out32, ps);
+    }
+}
+
+// the main segment of a model's stream = flat scan over the cells with an emit mask; fast path
+// for residuals whose codes fit the window at CPT cells per thread
+template <int MODEL>
+__device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                          const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                          PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t c0 = (tid * CPT) % nC;
+    const uint32_t cStep = STEP_CELLS % nC;
+    for (uint32_t base = 0; base < nCells; base += STEP_CELLS) {
+        const uint32_t i0 = base + tid * CPT;
+        uint64_t cl[CPT];
+        uint32_t xs[CPT];
+        uint32_t myBits = 0, multi = 0;
+        if (i0 < nCells) {
+            Cells8 Q;
+            load_cells8(tile, nC, nCells, i0, Q);
+            uint32_t c = c0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                bool emit, single;
+                const uint32_t x = flat_residual<MODEL>(Q, j, i0 + j, c, nC, nCells, seed, &emit);
+                const uint32_t b0 = m32_first_byte(x, &single);
+                const uint64_t e = emit ? tab[b0] : 0ull;
+                cl[j] = e;
+                xs[j] = x;
+                myBits += (uint32_t)(e >> 56);
+                if (emit && !single) multi |= 1u << j;
+                if (++c == nC) c = 0;
+            }
+            if (multi) {                                              // continuation bytes (rare)
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    if ((multi >> j) & 1u) {
+                        const uint32_t x = xs[j];
+                        const int n = gf_m32_len(x);
+                        for (int k = 1; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) { cl[j] = 0; xs[j] = 0; }
+        }
+        c0 += cStep;
+        if (c0 >= nC) c0 -= nC;
+
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
+        if (myBits) {
+            BitSink sink;
+            sink.init(win, ps.bitBase + excl - ps.wordBase * 32u);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                sink.put(cl[j] & 0x00ffffffffffffffull, (uint32_t)(cl[j] >> 56));
+                if ((multi >> j) & 1u) {
+                    const uint32_t x = xs[j];
+                    const int n = gf_m32_len(x);
+                    for (int k = 1; k < n; k++) {
+                        const uint64_t e = tab[gf_m32_byte(x, n, k)];
+                        sink.put(e & 0x00ffffffffffffffull, (uint32_t)(e >> 56));
+                    }
+                }
+            }
+            sink.finish();
+        }
+        __syncthreads();
+        ps.bitBase += total;
+        window_flush(win, out32, ps);
+    }
+}
+
 __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
 {
     __shared__ EncPersist P;
@@ -197,87 +474,69 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
         // ---------------- phase A: null scan + three histograms ----------------
         for (int i = tid; i < 3 * 256 * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
         if (tid == 0) { P.flags = 0; P.sumStart = 0; P.nStart = 0; }
-        if (tid < 3) { P.maxN[tid] = 0; P.model[tid] = 0; P.nM32[tid] = 0; }
+        if (tid < 3) { P.maxN[tid] = 1; P.model[tid] = 0; P.nM32[tid] = 0; }
         __syncthreads();
 
         const bool triOk = nR >= 2 && nC >= 2;
         const uint32_t rep = (uint32_t)lane & (HIST_R - 1);
-        uint32_t myFlags = 0, maxN1 = 0, maxN2 = 0, maxN3 = 0;
+        uint32_t myFlags = 0, maxN1 = 1, maxN2 = 1, maxN3 = 1;
         {
-            // Each thread takes quads of 4 consecutive cells (flat index), two quads per iteration, and
-            // issues every load of the iteration before using any of them: 16-byte loads of the cells and
-            // of the row above (4-byte aligned only), plus the three halo words.
-            auto addHist = [&](int p, uint32_t d) -> uint32_t {
-                const int n = gf_m32_len(d);
-                if (n == 1) {
-                    atomicAdd(&S.histR[p][gf_m32_byte(d, 1, 0) * HIST_R + rep], 1u);
-                } else {
-                    for (int k = 0; k < n; k++) atomicAdd(&S.histR[p][gf_m32_byte(d, n, k) * HIST_R + rep], 1u);
+            uint32_t *const h0 = &S.histR[0][rep], *const h1 = &S.histR[1][rep], *const h2 = &S.histR[2][rep];
+            // all M32 bytes of residual x into histogram h; returns the byte count
+            auto addHist = [&](uint32_t *h, uint32_t x) -> uint32_t {
+                bool single;
+                const uint32_t b0 = m32_first_byte(x, &single);
+                atomicAdd(h + b0 * HIST_R, 1u);
+                uint32_t n = 1;
+                if (!single) {
+                    n = (uint32_t)gf_m32_len(x);
+                    for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
                 }
-                return (uint32_t)n;
+                return n;
             };
-            struct Quad {
-                uint32_t cur[4], up[4], wm1, wm2, upm1;
-            };
-            auto loadQuad = [&](uint32_t i0, Quad &Q) {
-                if (i0 + 3 < nCells) {
-                    const GfU4 v = *reinterpret_cast<const GfU4 *>(tile + i0);
-                    Q.cur[0] = v.x; Q.cur[1] = v.y; Q.cur[2] = v.z; Q.cur[3] = v.w;
-                } else {
+            uint32_t c0 = ((uint32_t)tid * CPT) % nC;
+            const uint32_t cStep = STEP_CELLS % nC;
+            for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
+                Cells8 Q;
+                load_cells8(tile, nC, nCells, i0, Q);
+                uint32_t c = c0;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) Q.cur[j] = i0 + j < nCells ? tile[i0 + j] : 0u;
-                }
-                Q.wm1 = i0 >= 1 ? tile[i0 - 1] : 0u;
-                Q.wm2 = i0 >= 2 ? tile[i0 - 2] : 0u;
-                if (i0 >= nC && i0 + 3 < nCells) {
-                    const GfU4 v = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC));
-                    Q.up[0] = v.x; Q.up[1] = v.y; Q.up[2] = v.z; Q.up[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) Q.up[j] = (i0 + j >= nC && i0 + j < nCells) ? tile[i0 + j - nC] : 0u;
-                }
-                Q.upm1 = i0 >= nC + 1 ? tile[i0 - nC - 1] : 0u;
-            };
-            auto doQuad = [&](uint32_t i0, const Quad &Q) {
-                uint32_t r = i0 / nC, c = i0 - r * nC;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < CPT; j++) {
                     const uint32_t idx = i0 + j;
-                    if (idx < nCells) {
-                        const uint32_t v = Q.cur[j];
-                        myFlags |= (v == GF_NULL_CODE) ? 1u : 2u;
-                        if (idx > 0) {
-                            const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
-                            const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
-                            const uint32_t N = Q.up[j];
-                            const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
-                            maxN1 = max(maxN1, addHist(0, gf_res_differencing(r, c, v, W, N)));
-                            maxN2 = max(maxN2, addHist(1, gf_res_linear(r, c, v, W, WW, N)));
-                            if (triOk) maxN3 = max(maxN3, addHist(2, gf_res_triangle(r, c, v, W, N, NW)));
-                        }
-                    }
-                    if (++c >= nC) { c = 0; r++; }
+                    const uint32_t v = Q.cur[j];
+                    const bool real = idx < nCells;
+                    myFlags |= real ? ((v == GF_NULL_CODE) ? 1u : 2u) : 0u;
+                    const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+                    const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
+                    const uint32_t N = Q.up[j];
+                    const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+                    // the seed cell and the padding behind the tile count as residual 0 in every
+                    // histogram; bin 0 is corrected after the reduction
+                    const bool counted = real && idx > 0;
+                    const uint32_t d = v - (c > 0 ? W : N);
+                    const uint32_t d1 = counted ? d : 0u;
+                    const uint32_t d2 = counted ? (c >= 2 ? v - (2u * W - WW) : d) : 0u;
+                    const uint32_t d3 = counted ? ((idx >= nC && c > 0) ? v - (W + N - NW) : d) : 0u;
+                    maxN1 = max(maxN1, addHist(h0, d1));
+                    maxN2 = max(maxN2, addHist(h1, d2));
+                    if (triOk) maxN3 = max(maxN3, addHist(h2, d3));
+                    if (++c == nC) c = 0;
                 }
-            };
-            const uint32_t nQuads = (nCells + 3) >> 2;
-            for (uint32_t q = tid; q < nQuads; q += 2 * ENC_THREADS) {
-                Quad Q0, Q1;
-                const uint32_t q1 = q + ENC_THREADS;
-                loadQuad(q << 2, Q0);
-                if (q1 < nQuads) loadQuad(q1 << 2, Q1);
-                doQuad(q << 2, Q0);
-                if (q1 < nQuads) doQuad(q1 << 2, Q1);
+                c0 += cStep;
+                if (c0 >= nC) c0 -= nC;
             }
         }
         if (myFlags) atomicOr(&P.flags, myFlags);
-        atomicMax(&P.maxN[0], maxN1);
-        atomicMax(&P.maxN[1], maxN2);
-        atomicMax(&P.maxN[2], maxN3);
+        if (maxN1 > 1) atomicMax(&P.maxN[0], maxN1);
+        if (maxN2 > 1) atomicMax(&P.maxN[1], maxN2);
+        if (maxN3 > 1) atomicMax(&P.maxN[2], maxN3);
         __syncthreads();
         const uint32_t flags = P.flags;
         GF_STAMP(1);
         if (a.phaseLimit == 1) { __syncthreads(); continue; }
         const bool anyNull = flags & 1u, anyValid = flags & 2u;
+        // cells that were counted as residual 0 above: the seed cell + the padding of the last step
+        uint32_t forcedZeros = ((nCells + CPT - 1) / CPT) * CPT - nCells + 1u;
 
         if (!anyValid) {                         // CodecHuffman.java:80-82 -> null
             if (tid == 0) {
@@ -299,7 +558,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
         }
 
         if (anyNull) {
-            // ---- nulls path: seed (PredictorModelDifferencingWithNulls.java:79-105), then one histogram ----
+            // ---- nulls path (rare): seed (PredictorModelDifferencingWithNulls.java:79-105), then one histogram ----
+            forcedZeros = 0;
             for (int i = tid; i < 3 * 256 * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
             long long mySum = 0;
             uint32_t myCnt = 0;
@@ -328,11 +588,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
                 P.model[0] = (a.predictorMask & 8) ? 4 : 0;
                 P.model[1] = 0;
                 P.model[2] = 0;
-                P.maxN[0] = 0;
+                P.maxN[0] = 1;
             }
             __syncthreads();
             const uint32_t seed = P.seed;
-            uint32_t maxN = 0;
+            uint32_t maxN = 1;
             for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
                 const uint32_t r = idx / nC, c = idx - r * nC;
                 const uint32_t x = cell_residual(4, tile, nC, idx, r, c, seed);
@@ -349,28 +609,29 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
             P.model[2] = ((a.predictorMask & 4) && triOk) ? 3 : 0;
         }
 
-        // reduce the replicas (registers first: hist aliases nothing, histR is read-only here)
+        // reduce the replicas
         for (int i = tid; i < 3 * 256; i += ENC_THREADS) {
             const uint32_t *h = &S.histR[0][0] + (size_t)i * HIST_R;
             uint32_t s = 0;
 #pragma unroll
             for (int k = 0; k < HIST_R; k++) s += h[k];
+            if ((i & 255) == 0 && s >= forcedZeros) s -= forcedZeros;
             P.hist[i >> 8][i & 255] = s;
         }
         for (int i = tid; i < 3 * IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
         __syncthreads();                         // histR dead from here: S.tree may be written
 
         GF_STAMP(2);
-        // ---------------- phase B: the three Huffman trees ----------------
-        // B1  waves 0..2: sort the used symbols of predictor p by (count asc, symbol asc)
+        // ---------------- phase B: the three Huffman trees, one wave each ----------------
         if (wave < 3 && P.model[wave] != 0) {
             const int p = wave;
             GfHuffTree &T = S.tree[p];
             int n = 0;
             uint32_t nM32 = 0;
-            if (6ull * nCells < (1ull << 24)) {
-                // counts < 2^24: one 32-bit key (count << 8 | symbol) per symbol, 256 keys in 4 registers
-                // per lane (element e = r*64 + lane), bitonic network: 36 compare-exchange steps
+            // B1  sort the used symbols by (count asc, symbol asc)
+            if (6ull * nCells < (1ull << 23)) {
+                // counts < 2^23: one 32-bit key (count << 8 | symbol) per symbol, 256 keys in 4 registers
+                // per lane (element e = r*64 + lane), bitonic network
                 uint32_t key[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -379,14 +640,25 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
                     n += __popcll(__ballot(cnt != 0));
                     nM32 += cnt;
                 }
-                wave_bitonic_sort256(key, lane);
+                wave_bitonic_sort<4>(key, lane);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int e = r * 64 + lane;
-                    if (e < n) { T.cnt[e] = key[r] >> 8; T.sym[e] = (uint8_t)(key[r] & 0xffu); }
+                    if (e < n) {
+                        T.cnt[e] = key[r] >> 8;
+                        T.sym[e] = (uint8_t)(key[r] & 0xffu);
+                        T.nl[e] = 1;
+                        key[r] = ((key[r] >> 8) << 9) | (uint32_t)(256 + e);
+                    } else {
+                        key[r] = 0xFFFFFFFFu;
+                    }
                 }
+                if (lane == 0) T.n = n;
+                GF_STAMP(3);
+                // B2  tree by data-parallel rounds
+                wave_huff_rounds(T, key, n, lane);
             } else {
-                // huge tiles: compaction + rank sort on full 32-bit counts
+                // huge tiles: compaction + rank sort on full 32-bit counts, sequential merge on one lane
                 uint32_t *ccnt = &T.cnt[255];    // compacted counts (temp, branch area is free until the merge)
                 uint16_t *csym = T.bq;           // compacted symbols (temp)
                 for (int j = 0; j < 4; j++) {
@@ -421,33 +693,18 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
                     const int i = lane + 64 * j;
                     if (i < n) { T.cnt[rk[j]] = myc[j]; T.sym[rk[j]] = (uint8_t)mys[j]; }
                 }
+                if (lane == 0) T.n = n;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0 && n > 1) gf_huff_merge_t<false>(T, n, true);
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) nM32 += __shfl_xor(nM32, d, 64);
-            if (lane == 0) {
-                T.n = n;
-                P.nM32[p] = nM32;
-            }
-        }
-        __syncthreads();
-        GF_STAMP(3);
-        // B2  SIMT over trees: lane p of wave 0 runs the sequential merge of predictor p (per-lane LDS
-        //     addressing); a scalar-unit formulation would be bound by the CU's single SALU
-        if (wave == 0 && lane < 3 && P.model[lane] != 0) {
-            GfHuffTree &T = S.tree[lane];
-            const int n = T.n;
-            if (n > 1) gf_huff_merge_t<false>(T, n, true);
-        }
-        __syncthreads();
-        GF_STAMP(4);
-        // B3  waves 0..2: header image, codes, serialised tree, exact bit totals
-        if (wave < 3 && P.model[wave] != 0) {
-            const int p = wave;
-            GfHuffTree &T = S.tree[p];
-            const int n = T.n;
-            const uint32_t nM32 = P.nM32[p];
+            __builtin_amdgcn_wave_barrier();
+            GF_STAMP(4);
+            // B3  header image, codes, serialised tree, exact bit totals
             uint32_t *img = P.img[p];
             if (lane == 0) {
+                P.nM32[p] = nM32;
                 // header, CodecHuffman.java:121-130 (LSB-first bit store == little-endian bytes)
                 const uint32_t seed = P.seed;
                 img[0] = ((uint32_t)a.codecIndex & 0xffu) | ((uint32_t)P.model[p] << 8) | (seed << 16);
@@ -501,8 +758,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
             for (uint32_t i = tid; i < sizeof(EncPersist) / 4; i += ENC_THREADS) dbg[i] = pw[i];
             for (uint32_t i = tid; i < 3 * sizeof(GfHuffTree) / 4; i += ENC_THREADS)
                 dbg[sizeof(EncPersist) / 4 + i] = tw[i];
+            __syncthreads();                     // trees dead from here: S.win may be written
         }
-        __syncthreads();                         // trees dead from here: S.win may be written
         if (a.phaseLimit == 2) continue;
 
         // ---------------- phase C: pick the shortest, pack it ----------------
@@ -537,83 +794,40 @@ __global__ __launch_bounds__(ENC_THREADS) void k_huffman_encode(GfEncodeArgs a)
 
         const uint32_t nStream = gf_stream_len(model, nR, nC);
         const uint32_t seed = P.seed;
-        const uint64_t *__restrict__ tab = P.tab[best];
-        // elements per chunk such that a chunk can never overflow the window
+        const uint64_t *tab = P.tab[best];
         const uint32_t elemMaxBits = max(1u, P.maxN[best] * P.maxLen[best]);
-        uint32_t E = 4;
-        while (E > 1 && (uint64_t)ENC_THREADS * E * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u) E >>= 1;
-        uint32_t active = ENC_THREADS;
-        if ((uint64_t)ENC_THREADS * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u)
-            active = max(1u, (uint32_t)(((uint64_t)(WIN_WORDS - 2) * 32u) / elemMaxBits));
-        const uint32_t chunkElems = active * E;
-
-        uint32_t bitBase = treeEnd;              // next free bit of the packing (absolute)
-        uint32_t wordBase = 0;                   // words already flushed to global
-        // moves the completed words of the window to the output slot and slides the window
-        auto flush = [&]() {
-            const uint32_t fullWords = (bitBase >> 5) - wordBase;
-            for (uint32_t j = tid; j < fullWords; j += ENC_THREADS) out32[wordBase + j] = S.win[j];
-            const uint32_t partial = S.win[fullWords];
-            __syncthreads();
-            for (uint32_t j = tid; j <= fullWords; j += ENC_THREADS) S.win[j] = 0;
-            __syncthreads();
-            if (tid == 0) S.win[0] = partial;
-            wordBase += fullWords;
-            __syncthreads();
-        };
+        PackState ps;
+        ps.bitBase = treeEnd;
+        ps.wordBase = 0;
         GF_STAMP(6);
-        flush();                                 // header + tree image
-        for (uint32_t chunk = 0; chunk < nStream; chunk += chunkElems) {
-            // pass 1: residuals + their bit counts
-            uint32_t xs[4];
-            uint32_t myBits = 0;
-            const uint32_t s0 = chunk + (uint32_t)tid * E;
-            const uint32_t sEnd = min(nStream, chunk + chunkElems);
-#pragma unroll
-            for (uint32_t e = 0; e < 4; e++) {
-                xs[e] = 0;
-                const uint32_t s = s0 + e;
-                if (e < E && (uint32_t)tid < active && s < sEnd) {
-                    const uint32_t idx = gf_stream_cell(model, nR, nC, s);
-                    const uint32_t r = idx / nC, c = idx - r * nC;
-                    const uint32_t x = cell_residual(model, tile, nC, idx, r, c, seed);
-                    xs[e] = x;
-                    const int n = gf_m32_len(x);
-                    for (int k = 0; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
-                }
+        window_flush(S.win, out32, ps);          // header + tree image
+        if (nStream > 0 && P.maxLen[best] > 0) {
+            // one step of the flat scan emits at most STEP_CELLS elements; it must fit the window
+            const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
+            if (!fast) {
+                pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, S.win, out32, P.waveSum, ps);
+            } else if (model == 1) {
+                pack_flat<1>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+            } else if (model == 2) {
+                // seed chain first: (0,1), then (r,0),(r,1) for r >= 1  (PredictorModelLinear.java:113-126)
+                pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, S.win, out32, P.waveSum, ps);
+                pack_flat<2>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+            } else if (model == 3) {
+                // row 0 and column 0 first  (PredictorModelTriangle.java:114-127)
+                pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, S.win, out32, P.waveSum, ps);
+                pack_flat<3>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+            } else {
+                pack_flat<4>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
             }
-            uint32_t total;
-            const uint32_t excl = block_excl_scan(myBits, P.waveSum, &total);
-            // pass 2: emit
-            if (myBits) {
-                BitSink sink;
-                sink.init(S.win, bitBase + excl - wordBase * 32u);
-#pragma unroll
-                for (uint32_t e = 0; e < 4; e++) {
-                    const uint32_t s = s0 + e;
-                    if (e < E && (uint32_t)tid < active && s < sEnd) {
-                        const uint32_t x = xs[e];
-                        const int n = gf_m32_len(x);
-                        for (int k = 0; k < n; k++) {
-                            const uint64_t cl = tab[gf_m32_byte(x, n, k)];
-                            sink.put(cl & 0x00ffffffffffffffull, (uint32_t)(cl >> 56));
-                        }
-                    }
-                }
-                sink.finish();
-            }
-            __syncthreads();
-            bitBase += total;
-            flush();
         }
         GF_STAMP(7);
-        // tail: whatever is left in the window (also covers nStream == 0 / uniform tiles)
+        // tail: whatever is left in the window (also covers uniform tiles)
         {
-            const uint32_t remBits = bitBase - wordBase * 32u;
+            const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
             const uint32_t remWords = (remBits + 31u) >> 5;
             const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
             for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
-                if (wordBase + j < slotWords) out32[wordBase + j] = S.win[j];
+                if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = S.win[j];
         }
         __syncthreads();
     }

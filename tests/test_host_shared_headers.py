@@ -22,6 +22,7 @@ def hh():
     L = C.CDLL(so)
     u8p = C.POINTER(C.c_uint8)
     L.hh_huffman_encode.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_size_t), u8p, C.c_size_t, u8p]
+    L.hh_huffman_encode_rounds.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_size_t), u8p, C.c_size_t, u8p]
     L.hh_stream_cell.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
     L.hh_stream_cell.restype = C.c_uint32
     L.hh_m32_len.argtypes = [C.c_uint32]
@@ -30,13 +31,13 @@ def hh():
     return L
 
 
-def _hh_encode(hh, symbols):
+def _hh_encode(hh, symbols, fn="hh_huffman_encode"):
     s = np.ascontiguousarray(symbols, np.uint8)
     cap = 400 + 40 * s.size
     buf = np.zeros(cap, np.uint8)
     pos = C.c_size_t(3)        # deliberately unaligned start
     cl = np.zeros(256, np.uint8)
-    rc = hh.hh_huffman_encode(buf.ctypes.data_as(C.POINTER(C.c_uint8)), cap * 8, C.byref(pos),
+    rc = getattr(hh, fn)(buf.ctypes.data_as(C.POINTER(C.c_uint8)), cap * 8, C.byref(pos),
                               s.ctypes.data_as(C.POINTER(C.c_uint8)), s.size,
                               cl.ctypes.data_as(C.POINTER(C.c_uint8)))
     assert rc == 0
@@ -75,6 +76,14 @@ def test_tree_matches_reference_algorithm(hh, name, data):
     assert got == ref
     back, _ = oracle.huffman_decode(got, len(data), 3)
     assert back == bytes(data)
+
+
+@pytest.mark.parametrize("name,data", list(_symbol_sets()), ids=lambda x: x if isinstance(x, str) else "")
+def test_rounds_construction_matches_reference(hh, name, data):
+    """The data-parallel 'rounds' construction (what the device runs) gives the reference tree."""
+    got, pos, cl = _hh_encode(hh, data, "hh_huffman_encode_rounds")
+    ref, rpos, rcl, _ = oracle.huffman_encode(data, bit_pos=3, prefix=b"\x00")
+    assert pos == rpos and np.array_equal(cl, rcl) and got == ref
 
 
 def test_m32_helpers(hh):
