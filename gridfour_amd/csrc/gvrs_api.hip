@@ -19,6 +19,7 @@ namespace {
 
 thread_local std::string g_lastError;
 int g_encPhaseLimit = 0, g_decPhaseLimit = 0;   // diagnostic phase ablation (tools only)
+uint32_t *g_decodeDebug = nullptr;   // 16 cycle stamps per tile (tools only)
 uint32_t *g_encodeDebug = nullptr;   // diagnostic dump target of the next encode launches (tools only)
 
 gf_status hipFail(hipError_t e, const char *what)
@@ -79,6 +80,7 @@ const char *gf_version(void) { return "gvrs-hip-codec 0.1 (gfx950)"; }
 // Not part of the public ABI: lets tools/ capture the encode kernel's on-chip tables
 // (gvrs_encode_layout.h).  d_words must hold gf_internal_encode_debug_words() uint32 per tile.
 void gf_internal_set_encode_debug(void *d_words) { g_encodeDebug = (uint32_t *)d_words; }
+void gf_internal_set_decode_debug(void *d_words) { g_decodeDebug = (uint32_t *)d_words; }
 void gf_internal_set_phase_limits(int enc, int dec) { g_encPhaseLimit = enc; g_decPhaseLimit = dec; }
 size_t gf_internal_encode_debug_words(void);
 
@@ -163,7 +165,9 @@ gf_status gf_context_synchronize(gf_context *c)
 
 static size_t decodeWorkspaceStride(int nRows, int nCols)
 {
-    return roundUp((size_t)6 * (size_t)nRows * (size_t)nCols + 16, 16);
+    // spill layout of the decode kernel: M32 bytes (6 per cell, rounded to 32), start bitmap, rank bases
+    const size_t cap = roundUp((size_t)6 * (size_t)nRows * (size_t)nCols, 32);
+    return roundUp(cap + 2 * ((cap >> 5) + 2) * 4 + 64, 16);
 }
 
 gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
@@ -246,7 +250,9 @@ gf_status gf_huffman_decode_batch_i32_dev(gf_context *c, void *stream, int nRows
     a.nRows = nRows;
     a.nCols = nCols;
     a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
+    a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
     a.phaseLimit = g_decPhaseLimit;
+    a.debug = g_decodeDebug;
     GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     return GF_OK;
 }

@@ -106,3 +106,23 @@ GF_HD uint32_t gf_stream_cell(int model, uint32_t nR, uint32_t nC, uint32_t s)
     default: return s;
     }
 }
+
+#if defined(__HIPCC__)
+// Wave64 inclusive prefix sum with DPP row shifts/broadcasts: 6 VALU steps, no LDS crossbar
+// (a __shfl_up ladder costs 6 dependent ds_bpermute round trips).
+__device__ __forceinline__ uint32_t gf_wave_incl_scan(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)x;
+#else
+    return v;                                                          // host pass of hipcc: never executed
+#endif
+}
+#endif

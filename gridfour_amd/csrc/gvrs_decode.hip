@@ -7,23 +7,26 @@
 //   compress/PredictorModel*.java decode      running sums
 //   io/BitInputStore.java:112-210             LSB-first bit order
 //
-// The format has no synchronisation points, so both variable-length layers (Huffman
-// codes over bits, M32 values over bytes) are parsed with the same self-synchronising
-// scheme: the stream is cut into fixed-size subsequences, every thread parses its
-// subsequence from a guessed start, then start positions are corrected from the
-// predecessor's end position until nothing changes (codes resynchronise after a few
-// symbols, so this takes 2-3 rounds; the worst case is still correct, just serial).
-// A prefix sum of the per-subsequence symbol counts then tells every thread where its
-// output goes.
+// The format has no synchronisation points, so both variable-length layers (Huffman codes
+// over bits, M32 values over bytes) are parsed with the same self-synchronising scheme: the
+// stream is cut into fixed-size subsequences, every thread parses its subsequence from a
+// guessed start, then start positions are corrected from the predecessor's end position
+// until nothing changes (codes resynchronise after a few symbols, so this takes 2-3 rounds;
+// the worst case is still correct, just serial).  A prefix sum of the per-subsequence symbol
+// counts then tells every thread where its output goes.
 //
 // Phases of a workgroup (256 threads) on one tile
-//   0  header + tree parse (thread 0, from an LDS copy of the first 344 bytes),
-//      11-bit decode LUT built by all threads
-//   1  Huffman text -> M32 bytes (LDS, or the per-workgroup global spill buffer for
-//      tiles whose M32 stream exceeds the LDS budget)
-//   2  M32 bytes -> residuals, scattered to their cells of the output tile
-//   3  predictor inverse in place: int32 wrap-around prefix sums (column 0 chain, then
-//      row scans; Linear = double scan, Triangle = column scans then row scans)
+//   0  header + tree: wave 0 walks the pre-order serialisation as a scalar loop (bits and the
+//      node stack live in registers, read with v_readlane), emitting per-leaf (code, length,
+//      symbol); then all threads fill the 11-bit decode LUT from the leaf table
+//   1  Huffman text -> M32 bytes in LDS (global spill buffer for oversized tiles); every thread
+//      keeps a 96-bit window of the text in registers and refills it one dword at a time
+//   2  M32 bytes -> residuals: value starts are marked in a bitmap, ranked by a popcount prefix
+//      sum, and decoded one byte position per thread so that stores to the output tile are
+//      coalesced (consecutive bytes are consecutive cells for single-byte values)
+//   3  predictor inverse in place (L2-resident): int32 wrap-around prefix sums -- column-0
+//      chain, then row scans (Linear = double scan, Triangle = column sums then row scans),
+//      with several independent loads in flight per thread
 
 #include <hip/hip_runtime.h>
 
@@ -36,183 +39,403 @@ constexpr int DEC_THREADS = 256;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int LUT_BITS = 11;
 constexpr int MAXQ = 512;                      // subsequences per chain
-constexpr int HEAD_BYTES = 344;                // 10 header + 1 + ceil(2559/8) tree bytes, rounded up
+constexpr int HEAD_WORDS = 88;                 // 10 header + 1 + ceil(2559/8) tree bytes = 332 -> 83 words, + slack
+constexpr int MAX_DEPTH = 63;                  // code length limit of the register tree parser
+
+constexpr int L2_MAX_BITS = 8;                 // second-level LUT: up to 8 more bits (codes of 12..19 bits)
+constexpr int L2_ENTRIES = 2048;               // shared by all second-level tables: 2048 >> l2bits tables of
+                                               // 2^l2bits entries, l2bits = min(8, longest code - 11) per tile
 
 struct DecShared {
-    uint16_t lut[1 << LUT_BITS];               // short: (len << 8) | sym ; long: 0x8000 | node
-    uint16_t child0[512];                      // 0xFFFF marks a leaf
-    uint16_t child1[512];
-    uint8_t leafSym[512];
-    uint8_t childCount[512];
-    uint16_t stack[260];
+    uint16_t lut[1 << LUT_BITS];               // (len << 8) | sym ; 0x8000 | sub-table ; 0xFFFF = search
+    uint16_t lut2[L2_ENTRIES];                 // (len << 8) | sym ; 0xFFFF = search the leaf table
+    unsigned long long leafCode[256];          // per leaf, in pre-order: path bits root->leaf, first step in bit 0
+    uint8_t leafLen[256];
+    uint8_t leafSym[256];
+    uint8_t shortLeaf[64];                     // leaves with code length <= 5 (filled cooperatively)
     uint32_t qs[MAXQ];                         // subsequence start
     uint32_t qe[MAXQ];                         // subsequence end (start of the next one)
     uint32_t qn[MAXQ];                         // symbols in the subsequence, later exclusive prefix
     uint8_t qdirty[MAXQ];
-    uint32_t head[HEAD_BYTES / 4 + 2];         // +2 words of slack for the 64-bit window reads
+    uint32_t head[HEAD_WORDS];
     uint32_t waveSum[DEC_WAVES];
+    uint32_t carry;
     uint32_t textStart;                        // bit offset of the Huffman text in the packing
     int32_t parseStatus;
     int32_t uniformSym;                        // >= 0: single-symbol encoding
+    uint32_t nLeaves, nShort, nSub, l2bits;
     uint32_t chainEnd;                         // position after the last needed symbol
     uint32_t chainTotal;
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
+    (void)lane;
+    return gf_wave_incl_scan(v);
 }
 
-// 64 bits of the blob starting at absolute bit position `bit` (LSB-first); reads beyond
-// the buffer return zeros
-__device__ __forceinline__ uint64_t peek64(const uint32_t *__restrict__ w32, uint64_t nWords, uint64_t bit)
+// exclusive scan over the workgroup (two barriers); *total = sum over all threads
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *waveSum, uint32_t *total)
 {
-    const uint64_t wi = bit >> 5;
-    const uint32_t sh = (uint32_t)bit & 31u;
-    const uint32_t w0 = wi < nWords ? w32[wi] : 0u;
-    const uint32_t w1 = wi + 1 < nWords ? w32[wi + 1] : 0u;
-    const uint32_t w2 = wi + 2 < nWords ? w32[wi + 2] : 0u;
-    uint64_t lo = ((uint64_t)w1 << 32) | w0;
-    lo >>= sh;
-    if (sh) lo |= (uint64_t)w2 << (64u - sh);
-    return lo;
-}
-
-struct HuffStep {
-    const uint32_t *w32;
-    uint64_t nWords;
-    uint64_t base;                 // absolute bit position of packing bit 0
-    const DecShared *S;
-    // decodes the symbol at packing bit `pos`; returns the position of the next symbol
-    __device__ __forceinline__ uint32_t operator()(uint32_t pos, uint32_t *sym) const
-    {
-        uint64_t w = peek64(w32, nWords, base + pos);
-        const uint32_t e = S->lut[(uint32_t)w & ((1u << LUT_BITS) - 1u)];
-        if (!(e & 0x8000u)) {
-            *sym = e & 0xffu;
-            return pos + (e >> 8);
-        }
-        uint32_t node = e & 0x7fffu;
-        uint32_t d = LUT_BITS;
-        uint32_t p = pos;
-        while (S->child0[node] != 0xFFFFu) {
-            const uint32_t bit = (uint32_t)(w >> d) & 1u;
-            node = bit ? S->child1[node] : S->child0[node];
-            if (++d == 64) {
-                p += 64;
-                d = 0;
-                w = peek64(w32, nWords, base + p);
-            }
-        }
-        *sym = S->leafSym[node];
-        return p + d;
-    }
-};
-
-struct M32Step {
-    const uint8_t *m;
-    uint32_t n;                    // bytes available
-    // length of the value at byte `pos` (CodecM32.java:327-356); returns next position
-    __device__ __forceinline__ uint32_t operator()(uint32_t pos, uint32_t *val) const
-    {
-        const uint32_t b0 = m[pos];
-        uint32_t p = pos + 1;
-        if (b0 != 0x7fu && b0 != 0x81u) {
-            *val = b0 == 0x80u ? GF_NULL_CODE : (uint32_t)(int32_t)(int8_t)b0;
-            return p;
-        }
-        uint32_t delta = 0;
-        const uint32_t base[5] = {127u, 255u, 16639u, 2113791u, 270549247u};
-        uint32_t v = 0;
-        bool done = false;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) waveSum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            if (!done) {
-                const uint32_t smp = p < n ? m[p] : 0u;
-                p++;
-                delta = (delta << 7) | (smp & 0x7fu);
-                if (!(smp & 0x80u)) {
-                    v = b0 == 0x81u ? (0u - delta - base[i]) : (delta + base[i]);
-                    done = true;
-                }
-            }
-        }
-        *val = done ? v : delta;
-        return p;
-    }
-};
-
-// Self-synchronising parse of [start, end) cut into Q subsequences of S units.  On return
-// qs[q] = true start of subsequence q, qn[q] = EXCLUSIVE prefix of the symbol counts,
-// S.chainTotal = number of symbols that start before `end`.
-template <class Step>
-__device__ void resolve_chain(DecShared &S, const Step &step, uint32_t start, uint32_t end, uint32_t unit, uint32_t Q)
-{
-    const int tid = threadIdx.x;
-    for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-        S.qs[q] = start + q * unit;
-        S.qdirty[q] = 1;
+    for (int w = 0; w < DEC_WAVES; w++) {
+        const uint32_t s = waveSum[w];
+        if (w < wave) base += s;
+        tot += s;
     }
     __syncthreads();
-    for (;;) {
-        for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-            if (S.qdirty[q]) {
-                uint32_t pos = S.qs[q], cnt = 0, dummy;
-                const uint32_t limit = min(end, start + (q + 1) * unit);
-                while (pos < limit) {
-                    pos = step(pos, &dummy);
-                    cnt++;
+    *total = tot;
+    return base + incl - v;
+}
+
+// ---- cursors: sequential readers of the two variable-length layers ----
+
+// Huffman symbols over the packing's bit stream.  The packing is staged in LDS once per tile
+// (coalesced copy); a cursor keeps three words of it in registers (w0..w2, bit offset sh into w0),
+// fetches one more word per 32 bits consumed -- a word ahead of its use -- and forms the 32-bit
+// decode window with one v_alignbit_b32.  Everything on the per-symbol path is 32-bit arithmetic
+// and the only waits are on LDS.  (Reading the text straight from global memory stalls a whole
+// wave on nearly every symbol: some lane is always refilling.)  prepare() / lookup() / advance()
+// are separate so that a thread can overlap the LDS lookups of two independent subsequences.
+// Packings that do not fit the LDS text buffer use the same code with a global pointer.
+template <class TextPtr>
+struct HuffCursorT {
+    TextPtr base32;                // word that holds packing bit 0 (LDS copy or global)
+    uint32_t nW;                   // words readable from base32
+    uint32_t sh0;                  // position of packing bit 0 inside base32[0]
+    const DecShared *S;
+    uint32_t pos;                  // packing-relative bit position of the next symbol
+    uint32_t sh;                   // (pos + sh0) & 31 : offset of the next symbol inside w0
+    uint32_t wi;                   // index of w0
+    uint32_t w0, w1, w2;
+
+    __device__ __forceinline__ uint32_t ld(uint32_t i) const { return i < nW ? base32[i] : 0u; }
+    __device__ __forceinline__ void seek(uint32_t p)
+    {
+        pos = p;
+        const uint32_t a = p + sh0;
+        wi = a >> 5;
+        sh = a & 31u;
+        w0 = ld(wi);
+        w1 = ld(wi + 1);
+        w2 = ld(wi + 2);
+    }
+    // 32 bits of the text starting at the next symbol
+    __device__ __forceinline__ uint32_t prepare() const { return __builtin_amdgcn_alignbit(w1, w0, sh); }
+    __device__ __forceinline__ uint32_t lookup(uint32_t w) const { return S->lut[w & ((1u << LUT_BITS) - 1u)]; }
+    __device__ __forceinline__ void advance(uint32_t len)
+    {
+        pos += len;
+        sh += len;
+        while (sh >= 32u) {                       // once per ~7 symbols per lane
+            sh -= 32u;
+            w0 = w1;
+            w1 = w2;
+            wi++;
+            w2 = ld(wi + 2);
+        }
+    }
+    // codes longer than 11 bits: second level, then (longer than 19 bits, or out of tables) the leaf table
+    __device__ __forceinline__ uint32_t resolve_long(uint32_t e, uint32_t w32v) const
+    {
+        const uint32_t l2 = S->l2bits, sub = e & 0x7fffu;
+        e = sub < ((uint32_t)L2_ENTRIES >> l2) ? S->lut2[(sub << l2) | ((w32v >> LUT_BITS) & ((1u << l2) - 1u))] : 0xFFFFu;
+        if (e == 0xFFFFu) {
+            // 64 bits of text for the leaf-table search (rare)
+            const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+            uint64_t w = lo >> sh;
+            if (sh) w |= (uint64_t)w2 << (64u - sh);
+            const uint32_t n = S->nLeaves;
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t cl = S->leafLen[i];
+                const uint64_t mask = cl >= 64 ? ~0ull : ((1ull << cl) - 1ull);
+                if (cl > LUT_BITS && (w & mask) == S->leafCode[i]) {
+                    e = (cl << 8) | S->leafSym[i];
+                    break;
                 }
-                S.qe[q] = pos;
-                S.qn[q] = cnt;
-                S.qdirty[q] = 0;
             }
+            if (e == 0xFFFFu) e = (1u << 8);       // cannot happen for a complete tree; keep moving
+        }
+        return e;
+    }
+    // decodes one symbol, advances
+    __device__ __forceinline__ uint32_t next()
+    {
+        const uint32_t w = prepare();
+        uint32_t e = lookup(w);
+        if (e & 0x8000u) e = resolve_long(e, w);
+        advance(e >> 8);
+        return e & 0xffu;
+    }
+};
+
+// M32 values over a byte buffer (CodecM32.java:327-356).  Two dwords of the buffer (the next 8
+// bytes, 4-byte aligned loads) are kept in registers; length detection is 32-bit bit twiddling.
+struct M32Cursor {
+    const uint8_t *m;              // 4-byte aligned, readable up to the next multiple of 4 beyond n
+    uint32_t n;                    // bytes available
+    uint32_t pos;
+    uint32_t base;                 // byte index of d0's first byte (multiple of 4)
+    uint32_t d0, d1, d2;           // bytes base .. base+11
+
+    __device__ __forceinline__ uint32_t ld4b(uint32_t i) const
+    {
+        if (i >= n) return 0u;
+        uint32_t v = *reinterpret_cast<const uint32_t *>(m + i);
+        if (i + 4 > n) v &= (1u << ((n - i) * 8u)) - 1u;          // bytes at or beyond n read as zero
+        return v;
+    }
+    __device__ __forceinline__ void seek(uint32_t p)
+    {
+        pos = p;
+        base = p & ~3u;
+        d0 = ld4b(base);
+        d1 = ld4b(base + 4);
+        d2 = ld4b(base + 8);
+    }
+    // bytes pos..pos+3 in *lo, pos+4..pos+7 in *hi
+    __device__ __forceinline__ void prepare(uint32_t *lo, uint32_t *hi)
+    {
+        while (pos >= base + 4) {
+            d0 = d1;
+            d1 = d2;
+            base += 4;
+            d2 = ld4b(base + 8);
+        }
+        const uint32_t bsh = (pos - base) * 8u;
+        *lo = __builtin_amdgcn_alignbit(d1, d0, bsh);
+        *hi = __builtin_amdgcn_alignbit(d2, d1, bsh);
+    }
+    // number of bytes of the value whose bytes 0..3 are lo and 4..7 are hi
+    __device__ static __forceinline__ uint32_t length(uint32_t lo, uint32_t hi)
+    {
+        const uint32_t b0 = lo & 0xffu;
+        if (b0 != 0x7fu && b0 != 0x81u) return 1u;
+        // introducer: payload bytes 1..5 carry a continuation bit, at most 5 of them (:335 loop bound)
+        const uint32_t stopLo = ~lo & 0x80808000u;               // payload bytes 1..3
+        if (stopLo) return 1u + ((uint32_t)__builtin_ctz(stopLo) >> 3);      // bit 15 -> 2, 23 -> 3, 31 -> 4
+        const uint32_t stopHi = ~hi & 0x00008080u;               // payload bytes 4..5
+        return stopHi ? 5u + ((uint32_t)__builtin_ctz(stopHi) >> 3) : 6u;    // bit 7 -> 5, 15 -> 6
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        uint32_t lo, hi;
+        prepare(&lo, &hi);
+        pos += length(lo, hi);
+        return 0;
+    }
+};
+
+// value encoded by bytes 0..3 (lo) and 4..7 (hi) (CodecM32.java:327-356); *len = its byte count
+__device__ __forceinline__ uint32_t m32_value(uint32_t lo, uint32_t hi, uint32_t *len)
+{
+    const uint32_t b0 = lo & 0xffu;
+    if (b0 != 0x7fu && b0 != 0x81u) {
+        *len = 1;
+        return b0 == 0x80u ? GF_NULL_CODE : (uint32_t)(int32_t)(int8_t)b0;
+    }
+    const uint32_t n = M32Cursor::length(lo, hi);
+    *len = n;
+    // payload bytes p1..p(n-1), big-endian 7-bit groups
+    const uint32_t p1 = (lo >> 8) & 0x7fu, p2 = (lo >> 16) & 0x7fu, p3 = (lo >> 24) & 0x7fu;
+    const uint32_t p4 = hi & 0x7fu, p5 = (hi >> 8) & 0x7fu;
+    uint32_t delta, base, last;
+    if (n == 2) { delta = p1; base = 127u; last = lo >> 8; }
+    else if (n == 3) { delta = (p1 << 7) | p2; base = 255u; last = lo >> 16; }
+    else if (n == 4) { delta = (p1 << 14) | (p2 << 7) | p3; base = 16639u; last = lo >> 24; }
+    else if (n == 5) { delta = (p1 << 21) | (p2 << 14) | (p3 << 7) | p4; base = 2113791u; last = hi; }
+    else { delta = (p1 << 28) | (p2 << 21) | (p3 << 14) | (p4 << 7) | p5; base = 270549247u; last = hi >> 8; }
+    if (last & 0x80u) return delta;                // five continuation bytes: the reference returns delta
+    return b0 == 0x81u ? (0u - delta - base) : (delta + base);
+}
+
+// advance two cursors of the same kind by one symbol each where active; the two table lookups
+// are issued back to back so that their latencies overlap
+template <class TextPtr>
+__device__ __forceinline__ void step2(HuffCursorT<TextPtr> &c0, bool r0, uint32_t *s0, HuffCursorT<TextPtr> &c1, bool r1,
+                                      uint32_t *s1)
+{
+    const uint32_t w0 = c0.prepare(), w1 = c1.prepare();
+    uint32_t e0 = c0.lookup(w0), e1 = c1.lookup(w1);
+    if ((e0 | e1) & 0x8000u) {
+        if (e0 & 0x8000u) e0 = c0.resolve_long(e0, w0);
+        if (e1 & 0x8000u) e1 = c1.resolve_long(e1, w1);
+    }
+    c0.advance(r0 ? (e0 >> 8) : 0u);
+    c1.advance(r1 ? (e1 >> 8) : 0u);
+    *s0 = e0 & 0xffu;
+    *s1 = e1 & 0xffu;
+}
+__device__ __forceinline__ void step2(M32Cursor &c0, bool r0, uint32_t *s0, M32Cursor &c1, bool r1, uint32_t *s1)
+{
+    uint32_t lo0, hi0, lo1, hi1;
+    c0.prepare(&lo0, &hi0);
+    c1.prepare(&lo1, &hi1);
+    c0.pos += r0 ? M32Cursor::length(lo0, hi0) : 0u;
+    c1.pos += r1 ? M32Cursor::length(lo1, hi1) : 0u;
+    *s0 = 0;
+    *s1 = 0;
+}
+
+// Self-synchronising parse of [start, end) cut into Q <= 2*DEC_THREADS subsequences of `unit`.  On
+// return qs[q] = true start of subsequence q, qn[q] = EXCLUSIVE prefix of the symbol counts,
+// S.chainTotal = number of symbols that start before `end`.
+//
+// Subsequence q > 0 first parses a warm-up stretch of `warm` units that ends at its boundary: the
+// codes resynchronise inside it with high probability, so the first position it reaches at or
+// beyond the boundary is already the true start, and its end and count are final after ONE pass.
+// Starts are then checked against the predecessor's end; only a mismatch (rare) marks a
+// subsequence dirty for another, barrier-synchronised, round.  Every thread owns subsequences
+// tid and tid + DEC_THREADS and advances them in lockstep (their lookups overlap).
+template <class Cursor>
+__device__ void resolve_chain(DecShared &S, Cursor cur, uint32_t start, uint32_t end, uint32_t unit, uint32_t Q,
+                              uint32_t warm, uint32_t *dbg = nullptr)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t rounds = 0;
+    const uint32_t tBegin = (uint32_t)__builtin_amdgcn_s_memtime();
+    const uint32_t q0 = tid, q1 = tid + DEC_THREADS;
+    bool first = true;
+    if (q0 < Q) S.qdirty[q0] = 1;
+    if (q1 < Q) S.qdirty[q1] = 1;
+    __syncthreads();
+    for (;;) {
+        {
+            Cursor c0 = cur, c1 = cur;
+            const bool d0 = q0 < Q && S.qdirty[q0], d1 = q1 < Q && S.qdirty[q1];
+            const uint32_t b0 = start + q0 * unit, b1 = start + q1 * unit;       // boundaries
+            const uint32_t lim0 = min(end, b0 + unit), lim1 = min(end, b1 + unit);
+            uint32_t cnt0 = 0, cnt1 = 0;
+            uint32_t s0 = first ? b0 : S.qs[q0], s1 = first ? b1 : S.qs[q1];
+            if (first) {
+                // warm-up: run from (boundary - warm) up to the boundary, keep only the landing position
+                const uint32_t w0 = (q0 > 0 && b0 - start >= warm) ? b0 - warm : (q0 > 0 ? start : b0);
+                const uint32_t w1 = b1 - start >= warm ? b1 - warm : start;
+                c0.seek(d0 ? w0 : end);
+                c1.seek(d1 ? w1 : end);
+                for (;;) {
+                    const bool r0 = d0 && c0.pos < min(b0, end), r1 = d1 && c1.pos < min(b1, end);
+                    if (!r0 && !r1) break;
+                    uint32_t u0, u1;
+                    step2(c0, r0, &u0, c1, r1, &u1);
+                }
+                s0 = c0.pos;
+                s1 = c1.pos;
+            } else {
+                c0.seek(d0 ? s0 : end);
+                c1.seek(d1 ? s1 : end);
+            }
+            for (;;) {
+                const bool r0 = d0 && c0.pos < lim0, r1 = d1 && c1.pos < lim1;
+                if (!r0 && !r1) break;
+                uint32_t u0, u1;
+                step2(c0, r0, &u0, c1, r1, &u1);
+                cnt0 += r0 ? 1u : 0u;
+                cnt1 += r1 ? 1u : 0u;
+            }
+            if (d0) { S.qs[q0] = s0; S.qe[q0] = c0.pos; S.qn[q0] = cnt0; S.qdirty[q0] = 0; }
+            if (d1) { S.qs[q1] = s1; S.qe[q1] = c1.pos; S.qn[q1] = cnt1; S.qdirty[q1] = 0; }
+            first = false;
         }
         __syncthreads();
+        rounds++;
+        if (dbg && tid == 0 && rounds == 1) dbg[1] = (uint32_t)__builtin_amdgcn_s_memtime() - tBegin;
         int changed = 0;
-        for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-            if (q > 0) {
-                const uint32_t ns = S.qe[q - 1];
-                if (ns != S.qs[q]) {
-                    S.qs[q] = ns;
-                    S.qdirty[q] = 1;
-                    changed = 1;
-                }
-            }
+        if (q0 > 0 && q0 < Q) {
+            const uint32_t ns = S.qe[q0 - 1];
+            if (ns != S.qs[q0]) { S.qs[q0] = ns; S.qdirty[q0] = 1; changed = 1; }
+        }
+        if (q1 < Q) {
+            const uint32_t ns = S.qe[q1 - 1];
+            if (ns != S.qs[q1]) { S.qs[q1] = ns; S.qdirty[q1] = 1; changed = 1; }
         }
         if (!__syncthreads_or(changed)) break;
     }
-    // exclusive prefix sum of qn over q (Q <= MAXQ = 2 per thread)
-    const uint32_t per = (Q + DEC_THREADS - 1) / DEC_THREADS;
-    uint32_t local[MAXQ / DEC_THREADS];
-    uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; j++) {
-        const uint32_t q = tid * per + j;
-        local[j] = q < Q ? S.qn[q] : 0u;
-        sum += local[j];
-    }
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t incl = wave_incl_scan(sum, lane);
-    if (lane == 63) S.waveSum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-    for (int w = 0; w < DEC_WAVES; w++) {
-        if (w < wave) base += S.waveSum[w];
-        tot += S.waveSum[w];
-    }
-    uint32_t run = base + incl - sum;
-    for (uint32_t j = 0; j < per; j++) {
-        const uint32_t q = tid * per + j;
-        if (q < Q) S.qn[q] = run;
-        run += local[j];
-    }
+    // exclusive prefix sum of qn in subsequence order: thread t sums q = 2t, 2t+1
+    const uint32_t qa = 2 * tid, qb = 2 * tid + 1;
+    const uint32_t na = qa < Q ? S.qn[qa] : 0u, nb = qb < Q ? S.qn[qb] : 0u;
+    uint32_t tot;
+    const uint32_t run = block_excl_scan(na + nb, S.waveSum, &tot);
+    if (qa < Q) S.qn[qa] = run;
+    if (qb < Q) S.qn[qb] = run + na;
     if (tid == 0) S.chainTotal = tot;
+    if (dbg && tid == 0) dbg[0] = rounds;
     __syncthreads();
+}
+
+// phase 1 body: Huffman text -> nM32 bytes at m32; returns GF_K_OK or the Java error it mirrors
+template <class TextPtr>
+__device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32_t textStart, uint32_t endBit,
+                                  uint32_t nM32, uint8_t *m32, uint32_t *dbg)
+{
+    const uint32_t tid = threadIdx.x;
+    int32_t status = GF_K_OK;
+    const uint32_t textBits = endBit - textStart;
+    uint32_t unit = (textBits + MAXQ - 1) / MAXQ;
+    unit = max(128u, (unit + 31u) & ~31u);
+    const uint32_t Q = max(1u, (textBits + unit - 1) / unit);
+    resolve_chain(S, cur, textStart, endBit, unit, Q, 128u, dbg);       // warm-up: 128 bits, about 25 symbols
+    if (dbg && tid == 0) dbg[-7] = (uint32_t)__builtin_amdgcn_s_memtime();      // stamp 4
+    if (S.chainTotal < nM32) status = GF_K_ERR_BOUNDS;                   // ran out of bits
+    if (tid == 0) S.chainEnd = 0;
+    __syncthreads();
+    {
+        const uint32_t q0 = tid, q1 = tid + DEC_THREADS;
+        HuffCursorT<TextPtr> c0 = cur, c1 = cur;
+        const bool d0 = q0 < Q, d1 = q1 < Q;
+        uint32_t k0 = d0 ? S.qn[q0] : nM32, k1 = d1 ? S.qn[q1] : nM32;
+        const uint32_t lim0 = min(endBit, textStart + (q0 + 1) * unit), lim1 = min(endBit, textStart + (q1 + 1) * unit);
+        c0.seek(d0 ? S.qs[q0] : endBit);
+        c1.seek(d1 ? S.qs[q1] : endBit);
+        for (;;) {
+            const bool r0 = d0 && c0.pos < lim0 && k0 < nM32, r1 = d1 && c1.pos < lim1 && k1 < nM32;
+            if (!r0 && !r1) break;
+            uint32_t u0, u1;
+            step2(c0, r0, &u0, c1, r1, &u1);
+            if (r0) { m32[k0++] = (uint8_t)u0; if (k0 == nM32) S.chainEnd = c0.pos; }
+            if (r1) { m32[k1++] = (uint8_t)u1; if (k1 == nM32) S.chainEnd = c1.pos; }
+        }
+    }
+    __syncthreads();
+    if (status == GF_K_OK && S.chainEnd > endBit) status = GF_K_ERR_BOUNDS;      // last code ran past the end
+    return status;
+}
+
+__device__ __forceinline__ uint32_t stream_cell_fast(int model, uint32_t nR, uint32_t nC, uint32_t k, uint32_t magic,
+                                                     bool useMagic)
+{
+    // cell of stream element k; the row/column split of the main segment uses a multiply-high
+    // reciprocal (exact while t * w < 2^32) instead of an integer division
+    uint32_t t, w, rowBase, colBase;
+    if (model == 1) return k + 1u;
+    if (model == 4) return k;
+    if (model == 2) {
+        if (k == 0) return 1u;
+        const uint32_t seedLen = 2u * nR - 1u;
+        if (k < seedLen) {
+            const uint32_t u = k - 1u;
+            return (1u + (u >> 1)) * nC + (u & 1u);
+        }
+        t = k - seedLen;
+        w = nC - 2u;
+        rowBase = 0u;
+        colBase = 2u;
+    } else {
+        if (k < nC - 1u) return k + 1u;
+        t = k - (nC - 1u);
+        if (t < nR - 1u) return (t + 1u) * nC;
+        t -= nR - 1u;
+        w = nC - 1u;
+        rowBase = 1u;
+        colBase = 1u;
+    }
+    const uint32_t r = useMagic ? __umulhi(t, magic) : t / w;
+    return (r + rowBase) * nC + colBase + (t - r * w);
 }
 
 // wave-wide inclusive scan of one row segment with carry; returns the new carry
@@ -223,10 +446,17 @@ __device__ __forceinline__ uint32_t row_scan_segment(uint32_t x, uint32_t carry,
     return __shfl(incl, 63, 64);
 }
 
+#define GF_DSTAMP(i)                                                                   \
+    do {                                                                               \
+        if (a.debug && tid == 0) (a.debug + t * 16)[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+constexpr int ROW_BATCH = 4;                    // rows a wave keeps in flight in the row scans
+
 __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
-    extern __shared__ __attribute__((aligned(16))) uint8_t ldsM32[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
@@ -245,11 +475,12 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
 
+        GF_DSTAMP(0);
         // ---------------- phase 0: header + tree ----------------
         {
             uint8_t *hb = reinterpret_cast<uint8_t *>(S.head);
-            const uint32_t nh = min(len, (uint32_t)HEAD_BYTES);
-            for (uint32_t i = tid; i < HEAD_BYTES; i += DEC_THREADS) hb[i] = i < nh ? pk[i] : 0;
+            const uint32_t nh = min(len, (uint32_t)(HEAD_WORDS * 4));
+            for (uint32_t i = tid; i < HEAD_WORDS * 4; i += DEC_THREADS) hb[i] = i < nh ? pk[i] : 0;
         }
         __syncthreads();
         const uint8_t *hb = reinterpret_cast<const uint8_t *>(S.head);
@@ -269,80 +500,103 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
 
+        GF_DSTAMP(1);
         if (wave == 0) {
-            // HuffmanDecoder.decodeTree, HuffmanDecoder.java:65-161.  Executed wave-uniformly by all
-            // lanes of wave 0 (scalar loop, see GF_UNI in huff_build.h); lane 0 does the stores.
-            const bool writer = lane == 0;
-            uint32_t bp = 80;
+            // HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161) as a wave-uniform scalar loop: the
+            // serialised tree (<= 83 dwords) and the node stack live in VGPRs and are read with
+            // v_readlane, so a node costs a few dozen scalar instructions and no LDS round trip.
+            const uint32_t hw0 = S.head[lane];
+            const uint32_t hw1 = lane < HEAD_WORDS - 64 ? S.head[64 + lane] : 0u;
             const uint32_t totalBits = len * 8u;
-            auto getBits = [&](uint32_t nb) -> uint32_t {       // nb <= 9
-                const uint32_t wi = bp >> 5, sh = bp & 31u;
-                uint64_t w = 0;
-                if (wi + 1 < HEAD_BYTES / 4 + 2) w = ((uint64_t)GF_UNI(S.head[wi + 1]) << 32) | GF_UNI(S.head[wi]);
-                bp += nb;
-                return (uint32_t)(w >> sh) & ((1u << nb) - 1u);
+            auto word = [&](uint32_t wi) -> uint32_t {
+                if (wi >= HEAD_WORDS) return 0u;
+                return (uint32_t)__builtin_amdgcn_readlane((int)(wi < 64 ? hw0 : hw1), (int)(wi & 63u));
             };
+            // scalar bit buffer: `buf` holds the next `have` bits of the serialised tree, LSB first
+            uint64_t buf = (((uint64_t)word(3) << 32) | word(2)) >> 16;      // packing bit 80 = bit 16 of word 2
+            uint32_t have = 48, wnext = 4, bp = 80;
+            auto refill = [&]() {
+                if (have <= 32) {
+                    buf |= (uint64_t)word(wnext) << have;
+                    have += 32;
+                    wnext++;
+                }
+            };
+            auto take = [&](uint32_t nb) -> uint32_t {          // nb <= 9, needs have >= nb
+                const uint32_t v = (uint32_t)buf & ((1u << nb) - 1u);
+                buf >>= nb;
+                have -= nb;
+                bp += nb;
+                return v;
+            };
+            const bool writer = lane == 0;
             int32_t st = GF_K_OK;
             int32_t uniformSym = -1;
-            const uint32_t nLeaves = getBits(8) + 1;
-            const uint32_t rootBit = getBits(1);
-            uint32_t nodes = 1;
+            const uint32_t nLeaves = take(8) + 1;
+            const uint32_t rootBit = take(1);
+            uint32_t nShort = 0, nSub = 0, maxLen = 1;
             if (rootBit == 1) {
-                uniformSym = (int32_t)getBits(8);
+                uniformSym = (int32_t)take(8);
             } else {
-                uint32_t leaves = 0;
-                int sp = 0;
-                if (writer) {
-                    S.stack[0] = 0;
-                    S.childCount[0] = 0;
-                    S.child0[0] = 0;
-                    S.child1[0] = 0;
-                }
+                // Pre-order walk without building nodes: `path` bit d = side (0 left, 1 right) of the child
+                // currently being read under the open branch at depth d; a leaf's code is path[0..depth].
+                // A run of z branch records (z zero bits) is consumed in one step: depth += z.
+                uint64_t path = 0;
+                uint32_t depth = 0;
+                uint32_t leaves = 0, records = 0;
                 while (leaves < nLeaves) {
-                    const uint32_t parent = GF_UNI(S.stack[sp]);
-                    const uint32_t cc = GF_UNI(S.childCount[parent]);
-                    if (nodes >= 2 * nLeaves || nodes >= 511) { st = GF_K_ERR_BOUNDS; break; }
-                    const uint32_t id = nodes++;
+                    refill();
+                    if (records > 511) { st = GF_K_ERR_BOUNDS; break; }
+                    if (!(buf & 1ull)) {
+                        uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
+                        z = min(z, have);
+                        if (depth + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }   // see DESIGN.md (unsupported depth)
+                        if (depth < LUT_BITS && depth + z >= LUT_BITS) {
+                            // the branch at depth 11 on this path: its 11-bit prefix continues into a second-level table
+                            if (writer) S.lut[(uint32_t)path & ((1u << LUT_BITS) - 1u)] = (uint16_t)(0x8000u | nSub);
+                            nSub++;
+                        }
+                        depth += z;
+                        records += z;
+                        buf >>= z;
+                        have -= z;
+                        bp += z;
+                        continue;
+                    }
+                    const uint32_t rec = take(9);
+                    const uint32_t sym = rec >> 1;
+                    const uint32_t clen = depth + 1u;
+                    records++;
                     if (writer) {
-                        if (cc == 0) S.child0[parent] = (uint16_t)id;
-                        else S.child1[parent] = (uint16_t)id;
-                        S.childCount[parent] = (uint8_t)(cc + 1);
+                        S.leafCode[leaves] = path;
+                        S.leafLen[leaves] = (uint8_t)clen;
+                        S.leafSym[leaves] = (uint8_t)sym;
+                        if (clen <= 5) S.shortLeaf[nShort & 63u] = (uint8_t)leaves;
                     }
-                    if (getBits(1)) {
-                        const uint32_t sym = getBits(8);
-                        if (writer) {
-                            S.leafSym[id] = (uint8_t)sym;
-                            S.child0[id] = 0xFFFFu;
-                            S.child1[id] = 0xFFFFu;
-                            S.childCount[id] = 2;
-                        }
-                        leaves++;
-                        if (leaves == nLeaves) break;
-                        while (sp >= 0 && GF_UNI(S.childCount[GF_UNI(S.stack[sp])]) == 2) sp--;
-                        if (sp < 0) { st = GF_K_ERR_BOUNDS; break; }
-                    } else {
-                        sp++;
-                        if (sp > (int)nLeaves || sp >= 259) { st = GF_K_ERR_BOUNDS; break; }
-                        if (writer) {
-                            S.childCount[id] = 0;
-                            S.child0[id] = 0;
-                            S.child1[id] = 0;
-                            S.stack[sp] = (uint16_t)id;
-                        }
-                    }
+                    if (clen <= 5) nShort++;
+                    maxLen = max(maxLen, clen);
+                    leaves++;
+                    if (leaves == nLeaves) break;
+                    // next record: right child of the deepest open branch that is still on its left child
+                    const uint64_t open = ~path & (depth >= 63 ? ~0ull : ((2ull << depth) - 1ull));
+                    if (open == 0) { st = GF_K_ERR_BOUNDS; break; }          // tree complete but leaves missing
+                    const uint32_t nd = 63u - (uint32_t)__builtin_clzll(open);
+                    path = (path & ((1ull << nd) - 1ull)) | (1ull << nd);
+                    depth = nd;
                 }
-                if (st == GF_K_OK) {
-                    // every branch must have both children, otherwise the reference walks garbage
-                    bool bad = false;
-                    for (uint32_t k = lane; k < nodes; k += 64) bad |= S.childCount[k] != 2;
-                    if (__ballot(bad) != 0ull) st = GF_K_ERR_FORMAT;
-                }
+                // all leaves read: the tree must be complete (every open branch is on its right child)
+                if (st == GF_K_OK && path != ((depth >= 63) ? ~0ull : ((2ull << depth) - 1ull))) st = GF_K_ERR_FORMAT;
             }
             if (st == GF_K_OK && bp > totalBits) st = GF_K_ERR_BOUNDS;   // read past end of data
             if (writer) {
                 S.uniformSym = uniformSym;
                 S.textStart = bp;
                 S.parseStatus = st;
+                S.nLeaves = nLeaves;
+                S.nShort = nShort;
+                const uint32_t l2 = maxLen > LUT_BITS ? min((uint32_t)L2_MAX_BITS, maxLen - LUT_BITS) : 1u;
+                S.l2bits = l2;
+                S.nSub = min(nSub, (uint32_t)L2_ENTRIES >> l2);
             }
         }
         __syncthreads();
@@ -351,9 +605,24 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             __syncthreads();
             continue;
         }
-
+        GF_DSTAMP(2);
         if (a.phaseLimit == 1) continue;
-        uint8_t *m32 = nM32 <= a.ldsM32Bytes ? ldsM32 : a.workspace + (size_t)blockIdx.x * a.workspaceStride;
+
+        // dynamic LDS / spill layout: [M32 bytes][start bitmap][bitmap rank base]
+        uint8_t *m32;
+        uint32_t *bm, *wb;
+        const uint32_t bmWords = (nM32 + 31u) >> 5;
+        if (nM32 <= a.ldsM32Bytes) {
+            m32 = ldsDyn;
+            bm = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes);
+            wb = bm + (a.ldsM32Bytes >> 5) + 1;
+        } else {
+            uint8_t *ws = a.workspace + (size_t)blockIdx.x * a.workspaceStride;
+            m32 = ws;
+            const size_t cap = ((size_t)6 * nCells + 31) & ~(size_t)31;
+            bm = reinterpret_cast<uint32_t *>(ws + cap);
+            wb = bm + (cap >> 5) + 1;
+        }
         int32_t tileStatus = GF_K_OK;
 
         // ---------------- phase 1: Huffman text -> M32 bytes ----------------
@@ -362,63 +631,165 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
             __syncthreads();
         } else {
-            // LUT: walk the tree with the low bits of every 11-bit index
-            for (uint32_t e = tid; e < (1u << LUT_BITS); e += DEC_THREADS) {
-                uint32_t node = 0, d = 0;
-                while (d < LUT_BITS && S.child0[node] != 0xFFFFu) {
-                    node = ((e >> d) & 1u) ? S.child1[node] : S.child0[node];
-                    d++;
+            // LUT from the leaf table: a leaf with a code of <= 11 bits owns 2^(11-len) first-level entries,
+            // one of 12..19 bits owns 2^(19-len) entries of its prefix's second-level table
+            {
+                const uint32_t nLeaves = S.nLeaves;
+                const uint32_t nSub = S.nSub;
+                const uint32_t l2 = S.l2bits;
+                for (uint32_t x = tid; x < (nSub << l2); x += DEC_THREADS) S.lut2[x] = 0xFFFFu;
+                if ((uint32_t)tid < nLeaves) {
+                    const uint32_t cl = S.leafLen[tid];
+                    if (cl > 5 && cl <= LUT_BITS) {
+                        const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
+                        for (uint32_t x = (uint32_t)S.leafCode[tid]; x < (1u << LUT_BITS); x += 1u << cl) S.lut[x] = e;
+                    }
                 }
-                S.lut[e] = S.child0[node] == 0xFFFFu ? (uint16_t)((d << 8) | S.leafSym[node]) : (uint16_t)(0x8000u | node);
+                const uint32_t nShort = min(S.nShort, 64u);
+                for (uint32_t j = 0; j < nShort; j++) {             // few, large fills: all threads together
+                    const uint32_t i = S.shortLeaf[j];
+                    const uint32_t cl = S.leafLen[i];
+                    const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[i]);
+                    for (uint32_t x = (uint32_t)S.leafCode[i] + ((uint32_t)tid << cl); x < (1u << LUT_BITS);
+                         x += (uint32_t)DEC_THREADS << cl)
+                        S.lut[x] = e;
+                }
+                __syncthreads();                                     // lut2 cleared, first level complete
+                if ((uint32_t)tid < nLeaves) {
+                    const uint32_t cl = S.leafLen[tid];
+                    if (cl > LUT_BITS && cl <= LUT_BITS + l2) {
+                        const uint64_t code = S.leafCode[tid];
+                        const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffu;
+                        if (subIdx < nSub) {
+                            uint16_t *sub = &S.lut2[subIdx << l2];
+                            const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
+                            for (uint32_t x = (uint32_t)(code >> LUT_BITS); x < (1u << l2); x += 1u << (cl - LUT_BITS))
+                                sub[x] = e;
+                        }
+                    }
+                }
             }
             __syncthreads();
+            GF_DSTAMP(3);
             const uint32_t textStart = S.textStart, endBit = len * 8u;
-            HuffStep step{w32, nWords, off * 8ull, &S};
-            const uint32_t textBits = endBit - textStart;
-            uint32_t unit = (textBits + MAXQ - 1) / MAXQ;
-            unit = max(128u, (unit + 31u) & ~31u);
-            const uint32_t Q = max(1u, (textBits + unit - 1) / unit);
-            resolve_chain(S, step, textStart, endBit, unit, Q);
-            if (S.chainTotal < nM32) tileStatus = GF_K_ERR_BOUNDS;       // ran out of bits
-            if (tid == 0) S.chainEnd = 0;
-            __syncthreads();
-            for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-                uint32_t pos = S.qs[q], k = S.qn[q], sym;
-                const uint32_t limit = min(endBit, textStart + (q + 1) * unit);
-                while (pos < limit && k < nM32) {
-                    pos = step(pos, &sym);
-                    m32[k++] = (uint8_t)sym;
-                    if (k == nM32) S.chainEnd = pos;
-                }
+            const uint64_t baseWord = (off * 8ull) >> 5;
+            const uint32_t sh0 = (uint32_t)(off * 8ull) & 31u;
+            const uint32_t pkWords = (sh0 + endBit + 31u) >> 5;          // words that hold the packing
+            uint32_t *dbg = a.debug ? a.debug + t * 16 + 11 : nullptr;
+            if (pkWords * 4u <= a.ldsTextBytes) {
+                // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
+                uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + 2 * (((size_t)a.ldsM32Bytes >> 5) + 2) * 4);
+                const uint64_t avail = nWords - baseWord;
+                for (uint32_t i = tid; i < pkWords; i += DEC_THREADS) txt[i] = i < avail ? w32[baseWord + i] : 0u;
+                __syncthreads();
+                HuffCursorT<const uint32_t *> cur;
+                cur.base32 = txt;
+                cur.nW = pkWords;
+                cur.sh0 = sh0;
+                cur.S = &S;
+                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg);
+            } else {
+                HuffCursorT<const uint32_t *> cur;
+                cur.base32 = w32 + baseWord;
+                cur.nW = (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord);
+                cur.sh0 = sh0;
+                cur.S = &S;
+                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg);
             }
-            __syncthreads();
-            if (tileStatus == GF_K_OK && S.chainEnd > endBit) tileStatus = GF_K_ERR_BOUNDS;  // last code ran past the end
         }
         if (tileStatus != GF_K_OK) {
             if (tid == 0) a.status[t] = tileStatus;
             __syncthreads();
             continue;
         }
-
+        GF_DSTAMP(5);
         if (a.phaseLimit == 2) continue;
+
         // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
         {
-            M32Step step{m32, nM32};
+            M32Cursor cur;
+            cur.m = m32;
+            cur.n = nM32;
+            cur.pos = 0;
+            cur.base = 0;
+            cur.d0 = cur.d1 = cur.d2 = 0;
             uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
             unit = max(16u, unit);
             const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
-            resolve_chain(S, step, 0u, nM32, unit, Q);
+            resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, a.debug ? a.debug + t * 16 + 13 : nullptr);   // warm-up: 8 bytes (a value is at most 6)
+            GF_DSTAMP(6);
+            if (S.chainTotal < nStream) tileStatus = GF_K_ERR_BOUNDS;    // predictor reads past codeM32s
+            // bitmap of the bytes that start a value
+            for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
             if (tid == 0) S.chainEnd = 0;
             __syncthreads();
-            if (S.chainTotal < nStream) tileStatus = GF_K_ERR_BOUNDS;    // predictor reads past codeM32s
             for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-                uint32_t pos = S.qs[q], k = S.qn[q], val;
                 const uint32_t limit = min(nM32, (q + 1) * unit);
-                while (pos < limit && k < nStream) {
-                    pos = step(pos, &val);
-                    o[gf_stream_cell(model, nR, nC, k)] = val;
-                    k++;
-                    if (k == nStream) S.chainEnd = pos;
+                cur.seek(S.qs[q]);
+                uint32_t word = cur.pos >> 5, mask = 0;
+                while (cur.pos < limit) {
+                    const uint32_t w = cur.pos >> 5;
+                    if (w != word) {
+                        if (mask) atomicOr(&bm[word], mask);
+                        word = w;
+                        mask = 0;
+                    }
+                    mask |= 1u << (cur.pos & 31u);
+                    cur.next();
+                }
+                if (mask) atomicOr(&bm[word], mask);
+            }
+            __syncthreads();
+            // rank base of every bitmap word (exclusive popcount prefix)
+            if (tid == 0) S.carry = 0;
+            __syncthreads();
+            for (uint32_t base = 0; base < bmWords; base += DEC_THREADS) {
+                const uint32_t w = base + tid;
+                const uint32_t pc = w < bmWords ? (uint32_t)__popc(bm[w]) : 0u;
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan(pc, S.waveSum, &tot);
+                if (w < bmWords) wb[w] = S.carry + ex;
+                __syncthreads();
+                if (tid == 0) S.carry += tot;
+                __syncthreads();
+            }
+            GF_DSTAMP(7);
+            // four byte positions per thread and step: consecutive bytes are (mostly) consecutive cells,
+            // so the stores of a wave are coalesced.  12 bytes of the buffer cover every value that
+            // starts in the thread's dword.
+            const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
+            const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
+            const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
+            const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
+            const uint32_t nDw = (nM32 + 3u) >> 2;
+            for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
+                const uint32_t i0 = dw << 2;
+                const uint32_t bits = (bm[i0 >> 5] >> (i0 & 31u)) & 0xfu;
+                if (bits) {
+                    const uint32_t word = bm[i0 >> 5];
+                    uint32_t k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
+                    // bytes i0 .. i0+11, zero beyond nM32
+                    uint32_t d0 = m32w[dw], d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
+                    if (i0 + 12 > nM32) {
+                        const uint32_t valid = nM32 - i0;            // 1..11 bytes
+                        if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
+                        if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
+                        d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if ((bits >> j) & 1u) {
+                            if (k < nStream) {
+                                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
+                                const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
+                                uint32_t vlen;
+                                const uint32_t val = m32_value(lo, hi, &vlen);
+                                o[stream_cell_fast(model, nR, nC, k, magic, useMagic && wMain > 1)] = val;
+                                if (k == nStream - 1) S.chainEnd = i0 + j + vlen;
+                            }
+                            k++;
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -429,17 +800,24 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             __syncthreads();
             continue;
         }
-
+        GF_DSTAMP(8);
         if (a.phaseLimit == 3) continue;
+
         // ---------------- phase 3: predictor inverse (wrap-around prefix sums) ----------------
         if (model != 4) {
             // Triangle: column sums of the interior residuals first (needs row 0 still as residuals)
             if (model == 3) {
                 for (uint32_t c = 1 + tid; c < nC; c += DEC_THREADS) {
                     uint32_t acc = o[c];
-                    for (uint32_t r = 1; r < nR; r++) {
-                        acc += o[r * nC + c];
-                        o[r * nC + c] = acc;
+                    for (uint32_t r = 1; r < nR; r += 8) {
+                        uint32_t x[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) x[j] = r + j < nR ? o[(size_t)(r + j) * nC + c] : 0u;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            acc += x[j];
+                            if (r + j < nR) o[(size_t)(r + j) * nC + c] = acc;
+                        }
                     }
                 }
             }
@@ -449,39 +827,55 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                 if (lane == 0) o[0] = seed;
                 for (uint32_t r0 = 1; r0 < nR; r0 += 64) {
                     const uint32_t r = r0 + lane;
-                    const uint32_t x = r < nR ? o[r * nC] : 0u;
+                    const uint32_t x = r < nR ? o[(size_t)r * nC] : 0u;
                     uint32_t v;
                     carry = row_scan_segment(x, carry, lane, &v);
-                    if (r < nR) o[r * nC] = v;
+                    if (r < nR) o[(size_t)r * nC] = v;
                 }
             }
             __syncthreads();
-            // rows
-            for (uint32_t r = wave; r < nR; r += DEC_WAVES) {
-                uint32_t *row = o + (size_t)r * nC;
-                if (model == 2) {
-                    // second column, then c[k] = 2b - a + res  <=>  first differences are a running sum
-                    uint32_t a0 = row[0];
-                    uint32_t b0 = row[1] + a0;                          // residual of (r,1) is relative to (r,0)
-                    uint32_t carryD = b0 - a0, carryV = b0;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) row[1] = b0;
-                    for (uint32_t c0 = 2; c0 < nC; c0 += 64) {
-                        const uint32_t c = c0 + lane;
-                        const uint32_t x = c < nC ? row[c] : 0u;
-                        uint32_t d, v;
-                        carryD = row_scan_segment(x, carryD, lane, &d);
-                        carryV = row_scan_segment(c < nC ? d : 0u, carryV, lane, &v);
-                        if (c < nC) row[c] = v;
+            GF_DSTAMP(9);
+            // rows: each wave keeps ROW_BATCH rows in flight
+            for (uint32_t rb = (uint32_t)wave * ROW_BATCH; rb < nR; rb += DEC_WAVES * ROW_BATCH) {
+                uint32_t carryV[ROW_BATCH], carryD[ROW_BATCH];
+                uint32_t cStart = 1;
+#pragma unroll
+                for (int b = 0; b < ROW_BATCH; b++) {
+                    const uint32_t r = rb + b;
+                    carryV[b] = 0;
+                    carryD[b] = 0;
+                    if (r < nR) {
+                        uint32_t *row = o + (size_t)r * nC;
+                        if (model == 2) {
+                            // second column, then c[k] = 2b - a + res  <=>  first differences are a running sum
+                            const uint32_t a0 = row[0];
+                            const uint32_t b0 = row[1] + a0;            // residual of (r,1) is relative to (r,0)
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane == 0) row[1] = b0;
+                            carryD[b] = b0 - a0;
+                            carryV[b] = b0;
+                        } else {
+                            carryV[b] = row[0];
+                        }
                     }
-                } else {
-                    uint32_t carry = row[0];
-                    for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
-                        const uint32_t c = c0 + lane;
-                        const uint32_t x = c < nC ? row[c] : 0u;
+                }
+                if (model == 2) cStart = 2;
+                for (uint32_t c0 = cStart; c0 < nC; c0 += 64) {
+                    const uint32_t c = c0 + lane;
+                    uint32_t x[ROW_BATCH];
+#pragma unroll
+                    for (int b = 0; b < ROW_BATCH; b++) x[b] = (rb + b < nR && c < nC) ? o[(size_t)(rb + b) * nC + c] : 0u;
+#pragma unroll
+                    for (int b = 0; b < ROW_BATCH; b++) {
                         uint32_t v;
-                        carry = row_scan_segment(x, carry, lane, &v);
-                        if (c < nC) row[c] = v;
+                        if (model == 2) {
+                            uint32_t d;
+                            carryD[b] = row_scan_segment(x[b], carryD[b], lane, &d);
+                            carryV[b] = row_scan_segment(c < nC ? d : 0u, carryV[b], lane, &v);
+                        } else {
+                            carryV[b] = row_scan_segment(x[b], carryV[b], lane, &v);
+                        }
+                        if (rb + b < nR && c < nC) o[(size_t)(rb + b) * nC + c] = v;
                     }
                 }
             }
@@ -508,12 +902,8 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             for (uint32_t r = tid; r < nR; r += DEC_THREADS) {
                 uint32_t *row = o + (size_t)r * nC;
                 uint32_t prior = row[0];
-                // inside a row the flag follows the residual just decoded, not the value
-                bool nullFlag;
-                {
-                    // (r,0) was null iff its residual was the null code; its final value is then the null code too
-                    nullFlag = prior == GF_NULL_CODE;
-                }
+                // inside a row the flag follows the residual just decoded; (r,0) was null iff its value is
+                bool nullFlag = prior == GF_NULL_CODE;
                 for (uint32_t c = 1; c < nC; c++) {
                     const uint32_t test = row[c];
                     if (test == GF_NULL_CODE) {
@@ -526,6 +916,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                 }
             }
         }
+        GF_DSTAMP(10);
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();
     }
@@ -537,10 +928,26 @@ uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
 {
     // typical M32 streams are ~1.0-1.1 bytes per cell; larger ones spill to the workspace
     size_t cells = (size_t)nRows * (size_t)nCols;
-    size_t want = cells + cells / 4 + 1024;
-    if (want < 16384) want = 16384;
-    if (want > 98304) want = 98304;
-    return (uint32_t)((want + 15) & ~(size_t)15);
+    size_t want = cells + cells / 8 + 512;
+    if (want < 8192) want = 8192;
+    if (want > 65536) want = 65536;             // with bitmap, rank bases, text and the static part: < 160 KB
+    return (uint32_t)((want + 31) & ~(size_t)31);
+}
+
+// dynamic LDS bytes for a given M32 capacity: bytes + start bitmap + rank bases
+static size_t decodeDynLds(uint32_t ldsM32Bytes, uint32_t ldsTextBytes)
+{
+    return (size_t)ldsM32Bytes + 2 * ((size_t)(ldsM32Bytes >> 5) + 2) * 4 + ldsTextBytes;
+}
+
+uint32_t gf_huffman_decode_lds_text(int nRows, int nCols)
+{
+    // LDS copy of the packing text: measured on MI355X (ETOPO1-shaped batch) the copy makes a decode
+    // pass ~25 % shorter but costs half the resident workgroups per CU, a net loss (5.3 vs 4.2 ms), so it
+    // is off by default; the code path stays for tiles/LDS budgets where it wins.
+    (void)nRows;
+    (void)nCols;
+    return 0;
 }
 
 unsigned gf_huffman_decode_grid(size_t nTiles)
@@ -552,6 +959,14 @@ unsigned gf_huffman_decode_grid(size_t nTiles)
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid)
 {
     if (a.nTiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_huffman_decode, dim3(grid), dim3(DEC_THREADS), a.ldsM32Bytes, stream, a);
+    const size_t dyn = decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
+    static size_t maxDynSet = 0;                   // dynamic LDS beyond the default limit must be opted into
+    if (dyn > maxDynSet) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_decode),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) return e;
+        maxDynSet = dyn;
+    }
+    hipLaunchKernelGGL(k_huffman_decode, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();
 }

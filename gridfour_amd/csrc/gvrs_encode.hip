@@ -48,12 +48,8 @@ union EncScratch {
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
+    (void)lane;
+    return gf_wave_incl_scan(v);
 }
 
 // exclusive scan over the workgroup; *total = sum over all threads

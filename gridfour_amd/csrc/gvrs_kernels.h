@@ -41,13 +41,16 @@ struct GfDecodeArgs {
     size_t nTiles;
     int nRows, nCols;
     uint32_t ldsM32Bytes;      // capacity of the in-LDS M32 buffer
+    uint32_t ldsTextBytes;     // capacity of the in-LDS copy of the packing (multiple of 16)
     int phaseLimit;            // diagnostic: stop after phase 0/1/2 (value 1/2/3); 0 = run everything
+    uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
 };
 
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 unsigned gf_huffman_decode_grid(size_t nTiles);
 uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols);
+uint32_t gf_huffman_decode_lds_text(int nRows, int nCols);
 
 hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStride,
                              const uint32_t *lengths, uint64_t *offsets, uint8_t *blob,

@@ -205,6 +205,10 @@ def _tie_symbol_sets():
     yield np.repeat(np.arange(12, dtype=np.uint8), 2 ** np.arange(12))  # powers of two
     yield np.repeat(np.arange(16, dtype=np.uint8) + 100,
                     [1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987])   # Fibonacci: deepest tree
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    yield np.repeat(np.arange(24, dtype=np.uint8) + 7, fib)              # depth 23: beyond both decode LUT levels
     for _ in range(24):
         n_sym = int(rng.integers(2, 251))
         hi = int(rng.choice([1, 2, 3, 5, 20, 1000]))
