@@ -1,0 +1,157 @@
+// gvrs_hip_codec.hpp -- C++ host-side mirror of Gridfour's compression plug-in interface for the
+// MI355X codec (header only; links against libgvrs_hip.so through include/gvrs_hip_codec.h).
+//
+// The reference is Java; there is no JDK in the build image, so the host side above the C ABI is
+// written in C++ with the reference's own names, argument meaning and error behaviour:
+//   org.gridfour.compress.ICompressionEncoder   core/src/main/java/org/gridfour/compress/ICompressionEncoder.java:46-92
+//   org.gridfour.compress.ICompressionDecoder   .../ICompressionDecoder.java:49-107
+//   org.gridfour.compress.CodecHuffman          .../CodecHuffman.java:50-260
+// Java `null` results are empty std::optional, Java IOException is gridfour::IOException.
+// The Java adapter that binds the same C ABI through JNI is in gridfour_amd/java/.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gvrs_hip_codec.h"
+
+namespace gridfour {
+
+struct IOException : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct ArrayIndexOutOfBoundsException : std::out_of_range {
+    using std::out_of_range::out_of_range;
+};
+
+/** An interface defining a coder for a Gridfour raster data compression implementation. */
+class ICompressionEncoder {
+public:
+    virtual ~ICompressionEncoder() = default;
+    /** Encodes the tile (row-major, nRows*nCols values); empty optional == Java null. */
+    virtual std::optional<std::vector<uint8_t>> encode(int codecIndex, int nRows, int nCols, const std::vector<int32_t> &values) = 0;
+    virtual std::optional<std::vector<uint8_t>> encodeFloats(int codecIndex, int nRows, int nCols, const std::vector<float> &values) = 0;
+    virtual bool implementsFloatingPointEncoding() const = 0;
+    virtual bool implementsIntegerEncoding() const = 0;
+};
+
+/** An interface defining a decoder for a Gridfour raster data compression implementation. */
+class ICompressionDecoder {
+public:
+    virtual ~ICompressionDecoder() = default;
+    /** Decodes the packing; throws IOException on an incompatible packing. */
+    virtual std::vector<int32_t> decode(int nRows, int nColumns, const std::vector<uint8_t> &packing) = 0;
+    virtual std::optional<std::vector<float>> decodeFloats(int nRows, int nColumns, const std::vector<uint8_t> &packing) = 0;
+    virtual void analyze(int nRows, int nColumns, const std::vector<uint8_t> &packing) = 0;
+    virtual void reportAnalysisData(std::FILE *ps, int nTilesInRaster) = 0;
+    virtual void clearAnalysisData() = 0;
+};
+
+/** Drop-in for org.gridfour.compress.CodecHuffman, computed on the GPU (no CPU fallback). */
+class CodecHuffmanHip : public ICompressionEncoder, public ICompressionDecoder {
+public:
+    explicit CodecHuffmanHip(int device = 0)
+    {
+        const gf_status s = gf_context_create(device, &ctx_);
+        if (s != GF_OK) throw std::runtime_error(std::string("CodecHuffmanHip: ") + gf_status_string(s) + " [" + gf_last_error() + "]");
+    }
+    ~CodecHuffmanHip() override { gf_context_destroy(ctx_); }
+    CodecHuffmanHip(const CodecHuffmanHip &) = delete;
+    CodecHuffmanHip &operator=(const CodecHuffmanHip &) = delete;
+
+    std::optional<std::vector<uint8_t>> encode(int codecIndex, int nRows, int nCols, const std::vector<int32_t> &values) override
+    {
+        if ((size_t)nRows * (size_t)nCols != values.size()) throw std::invalid_argument("values.length != nRows*nCols");
+        std::vector<uint8_t> out(gf_huffman_max_packing(nRows, nCols));
+        size_t n = 0;
+        const gf_status s = gf_huffman_encode_i32(ctx_, codecIndex, nRows, nCols, values.data(), out.data(), out.size(), &n);
+        if (s == GF_DECLINED) return std::nullopt;                       // CodecHuffman.java:80-82
+        if (s == GF_ERR_BOUNDS) throw ArrayIndexOutOfBoundsException("PredictorModelLinear needs nCols >= 2");
+        check(s, "gf_huffman_encode_i32");
+        out.resize(n);
+        return out;
+    }
+    std::optional<std::vector<uint8_t>> encodeFloats(int, int, int, const std::vector<float> &) override { return std::nullopt; }
+    bool implementsFloatingPointEncoding() const override { return false; }
+    bool implementsIntegerEncoding() const override { return true; }
+
+    std::vector<int32_t> decode(int nRows, int nColumns, const std::vector<uint8_t> &packing) override
+    {
+        std::vector<int32_t> out((size_t)nRows * (size_t)nColumns);
+        const gf_status s = gf_huffman_decode_i32(ctx_, nRows, nColumns, packing.data(), packing.size(), out.data());
+        if (s == GF_ERR_FORMAT || s == GF_ERR_BOUNDS) throw IOException(gf_status_string(s));   // CodecHuffman.java:155-169
+        check(s, "gf_huffman_decode_i32");
+        return out;
+    }
+    std::optional<std::vector<float>> decodeFloats(int, int, const std::vector<uint8_t> &) override { return std::nullopt; }
+
+    // statistics (CodecHuffman.java:172-234): kept on the host, fed by the packing headers only
+    void analyze(int, int, const std::vector<uint8_t> &packing) override
+    {
+        if (packing.size() < 10) throw IOException("short packing");
+        const unsigned p = packing[1];
+        if (p < 5) { tiles_[p]++; bytes_[p] += packing.size() - 10; }
+    }
+    void reportAnalysisData(std::FILE *ps, int nTilesInRaster) override
+    {
+        std::fprintf(ps, "Gridfour_Huffman (HIP)\n");
+        static const char *names[5] = {"None", "Differencing", "Linear", "Triangle", "DifferencingWithNulls"};
+        for (int p = 1; p < 5; p++)
+            std::fprintf(ps, "   %-22s %8ld (%4.1f %%)  %12.1f bytes/tile\n", names[p], tiles_[p],
+                         nTilesInRaster ? 100.0 * tiles_[p] / nTilesInRaster : 0.0, tiles_[p] ? (double)bytes_[p] / tiles_[p] : 0.0);
+    }
+    void clearAnalysisData() override { for (int p = 0; p < 5; p++) tiles_[p] = bytes_[p] = 0; }
+
+    // ---- batched forms: what the GPU is for (one launch per batch, not per tile) ----
+    struct Batch {
+        std::vector<uint8_t> blob;          // packings, concatenated in tile order
+        std::vector<uint64_t> offsets;      // nTiles + 1
+        std::vector<uint8_t> predictors;    // PredictorModelType code per tile
+        std::vector<int32_t> status;        // gf_status per tile (GF_DECLINED == Java null)
+    };
+    Batch encodeBatch(int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values)
+    {
+        Batch b;
+        b.offsets.resize(nTiles + 1);
+        b.predictors.resize(nTiles);
+        b.status.resize(nTiles);
+        b.blob.resize(nTiles * gf_huffman_default_stride(nRows, nCols));
+        gf_status s = gf_huffman_encode_batch_i32(ctx_, codecIndex, nRows, nCols, nTiles, values, b.blob.data(), b.blob.size(),
+                                                  b.offsets.data(), b.predictors.data(), b.status.data());
+        if (s == GF_ERR_CAPACITY) {
+            b.blob.resize(b.offsets[nTiles]);
+            s = gf_huffman_encode_batch_i32(ctx_, codecIndex, nRows, nCols, nTiles, values, b.blob.data(), b.blob.size(),
+                                            b.offsets.data(), b.predictors.data(), b.status.data());
+        }
+        check(s, "gf_huffman_encode_batch_i32");
+        b.blob.resize(b.offsets[nTiles]);
+        return b;
+    }
+    std::vector<int32_t> decodeBatch(int nRows, int nCols, const Batch &b, std::vector<int32_t> *status = nullptr)
+    {
+        const size_t nTiles = b.offsets.size() - 1;
+        std::vector<int32_t> out(nTiles * (size_t)nRows * (size_t)nCols), st(nTiles);
+        std::vector<uint8_t> padded(b.blob);
+        padded.resize(padded.size() + 16);
+        check(gf_huffman_decode_batch_i32(ctx_, nRows, nCols, nTiles, padded.data(), b.offsets.data(), out.data(), st.data()),
+              "gf_huffman_decode_batch_i32");
+        if (status) *status = st;
+        return out;
+    }
+    gf_context *context() { return ctx_; }
+
+private:
+    static void check(gf_status s, const char *where)
+    {
+        if (s < 0) throw std::runtime_error(std::string(where) + ": " + gf_status_string(s) + " [" + gf_last_error() + "]");
+    }
+    gf_context *ctx_ = nullptr;
+    long tiles_[5] = {0, 0, 0, 0, 0};
+    long bytes_[5] = {0, 0, 0, 0, 0};
+};
+
+}  // namespace gridfour

@@ -1,0 +1,104 @@
+// gvrs_hip_jni.cpp -- thin JNI shim between org.gridfour.hip.CodecHuffmanHip (Java adapter in this
+// directory) and the C ABI of libgvrs_hip.so (include/gvrs_hip_codec.h).
+//
+// Not compiled in the build image (no JDK, no jni.h).  Build on a host with a JDK:
+//   g++ -O2 -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I<repo>/include \
+//       gvrs_hip_jni.cpp -L<repo>/gridfour_amd/lib -lgvrs_hip -o libgvrs_hip_jni.so
+// One gf_context per adapter instance; CodecHolder creates one instance per codec
+// (gvrs/CodecHolder.java:208-234) and the decoder may be called from two threads
+// (gvrs/TileDecompressionAssistant.java:68-73), hence the mutex around context use.
+#include <jni.h>
+
+#include <mutex>
+
+#include "gvrs_hip_codec.h"
+
+namespace {
+struct Handle {
+    gf_context *ctx = nullptr;
+    std::mutex lock;
+};
+void throwIo(JNIEnv *env, const char *msg)
+{
+    jclass c = env->FindClass("java/io/IOException");
+    if (c) env->ThrowNew(c, msg);
+}
+}  // namespace
+
+extern "C" {
+
+JNIEXPORT jlong JNICALL Java_org_gridfour_hip_CodecHuffmanHip_createNative(JNIEnv *env, jclass, jint device)
+{
+    Handle *h = new Handle();
+    if (gf_context_create(device, &h->ctx) != GF_OK) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, gf_last_error());
+        delete h;
+        return 0;
+    }
+    return (jlong)(intptr_t)h;
+}
+
+JNIEXPORT void JNICALL Java_org_gridfour_hip_CodecHuffmanHip_destroyNative(JNIEnv *, jclass, jlong handle)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    if (!h) return;
+    gf_context_destroy(h->ctx);
+    delete h;
+}
+
+// byte[] encode(int codecIndex, int nRows, int nCols, int[] values)  -> null when declined
+JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_encodeNative(JNIEnv *env, jclass, jlong handle, jint codecIndex,
+                                                                               jint nRows, jint nCols, jintArray values)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    const size_t cap = gf_huffman_max_packing(nRows, nCols);
+    jbyte *out = new jbyte[cap];
+    size_t n = 0;
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        jint *v = (jint *)env->GetPrimitiveArrayCritical(values, nullptr);
+        s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
+        env->ReleasePrimitiveArrayCritical(values, v, JNI_ABORT);
+    }
+    jbyteArray result = nullptr;
+    if (s == GF_OK) {
+        result = env->NewByteArray((jsize)n);
+        if (result) env->SetByteArrayRegion(result, 0, (jsize)n, out);
+    } else if (s == GF_ERR_BOUNDS) {
+        jclass c = env->FindClass("java/lang/ArrayIndexOutOfBoundsException");
+        if (c) env->ThrowNew(c, "tile has fewer than 2 columns");
+    } else if (s != GF_DECLINED) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, gf_status_string(s));
+    }
+    delete[] out;
+    return result;   // null == Java null (CodecHuffman.java:80-82)
+}
+
+// int[] decode(int nRows, int nColumns, byte[] packing) throws IOException
+JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(JNIEnv *env, jclass, jlong handle, jint nRows,
+                                                                              jint nCols, jbyteArray packing)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    const jsize len = env->GetArrayLength(packing);
+    jintArray result = env->NewIntArray(nRows * nCols);
+    if (!result) return nullptr;
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        jbyte *p = (jbyte *)env->GetPrimitiveArrayCritical(packing, nullptr);
+        jint *o = (jint *)env->GetPrimitiveArrayCritical(result, nullptr);
+        s = gf_huffman_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
+        env->ReleasePrimitiveArrayCritical(result, o, 0);
+        env->ReleasePrimitiveArrayCritical(packing, p, JNI_ABORT);
+    }
+    if (s != GF_OK) {
+        throwIo(env, gf_status_string(s));
+        return nullptr;
+    }
+    return result;
+}
+
+}  // extern "C"
