@@ -42,6 +42,13 @@ SIGNATURES = {
     "gf_huffman_decode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp,
                                                   C.c_size_t, _vp, _vp, _vp]),
     "gf_compact_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t]),
+    "gf_float_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "gf_float_planes_encode_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t]),
+    "gf_float_planes_decode_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "gf_float_encode_batch_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "gf_float_decode_batch_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_float_encode_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gf_float_decode_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "gf_synth_dem_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_size_t, _vp]),
     "gf_dev_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "gf_dev_free": (C.c_int, [_vp, _vp]),

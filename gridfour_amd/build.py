@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvrs_hip.so")
-SOURCES = ["gvrs_api.hip", "gvrs_encode.hip", "gvrs_decode.hip", "gvrs_aux.hip"]
+SOURCES = ["gvrs_api.hip", "gvrs_encode.hip", "gvrs_decode.hip", "gvrs_aux.hip", "gvrs_float.hip"]
 HEADERS = ["gvrs_common.h", "gvrs_kernels.h", "huff_build.h", "gvrs_encode_layout.h", os.path.join("..", "..", "include", "gvrs_hip_codec.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -281,3 +281,71 @@ class GpuTimer:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+
+class CodecFloatHip:
+    """Drop-in for org.gridfour.compress.CodecFloat (CodecFloat.java:328-458): float32 tiles as five
+    byte planes (split/merged on the GPU) each compressed with zlib on the host.
+
+    `level` is the zlib level: 9 is what the current reference source passes to java.util.zip.Deflater,
+    6 is what the reference's sample files were written with."""
+
+    def __init__(self, context=None, device=0, level=9):
+        self.ctx = context if context is not None else GvrsHipContext(device)
+        self.level = int(level)
+
+    # ---- ICompressionEncoder ----
+    def encode(self, codecIndex, nRows, nCols, values):
+        return None                                  # CodecFloat.java: integer encoding not implemented
+
+    def encodeFloats(self, codecIndex, nRows, nCols, values):
+        v = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        if v.size != nRows * nCols:
+            raise ValueError("values.length != nRows*nCols")
+        cap = 5 * v.size + 4096
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        check(lib().gf_float_encode_f32(self.ctx.handle, codecIndex, nRows, nCols, _ptr(v), self.level, _ptr(out), cap,
+                                        C.byref(n)), "gf_float_encode_f32")
+        return bytes(out[:n.value])
+
+    def implementsFloatingPointEncoding(self):
+        return True
+
+    def implementsIntegerEncoding(self):
+        return False
+
+    # ---- ICompressionDecoder ----
+    def decode(self, nRows, nColumns, packing):
+        return None
+
+    def decodeFloats(self, nRows, nColumns, packing):
+        p = np.frombuffer(bytes(packing), dtype=np.uint8)
+        out = np.empty(nRows * nColumns, np.float32)
+        st = lib().gf_float_decode_f32(self.ctx.handle, nRows, nColumns, _ptr(p), p.size, _ptr(out))
+        if st in (_lib.ERR_FORMAT, _lib.ERR_BOUNDS):
+            raise IOError(lib().gf_status_string(st).decode())
+        check(st, "gf_float_decode_f32")
+        return out
+
+    # ---- batched, host memory ----
+    def encode_floats_batch(self, codecIndex, nRows, nCols, tiles):
+        v = np.ascontiguousarray(tiles, dtype=np.float32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        cap = nt * (5 * nRows * nCols + 4096)
+        blob = np.empty(cap, np.uint8)
+        offsets = np.zeros(nt + 1, np.uint64)
+        check(lib().gf_float_encode_batch_f32(self.ctx.handle, codecIndex, nRows, nCols, nt, _ptr(v), self.level, _ptr(blob),
+                                              cap, _ptr(offsets)), "gf_float_encode_batch_f32")
+        return [bytes(blob[int(offsets[t]):int(offsets[t + 1])]) for t in range(nt)]
+
+    def decode_floats_batch(self, nRows, nCols, packings):
+        nt = len(packings)
+        offsets = np.zeros(nt + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(p) for p in packings])
+        blob = np.frombuffer(b"".join(packings) + b"\0" * 16, dtype=np.uint8)
+        out = np.empty((nt, nRows * nCols), np.float32)
+        status = np.zeros(nt, np.int32)
+        check(lib().gf_float_decode_batch_f32(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets), _ptr(out),
+                                              _ptr(status)), "gf_float_decode_batch_f32")
+        return out, status

@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>
+
 #include "../../include/gvrs_hip_codec.h"
 #include "gvrs_kernels.h"
 #include "gvrs_encode_layout.h"
@@ -66,6 +68,7 @@ struct gf_context {
     DevBuf workspace;      // decode spill: grid * 6*cells
     // staging for the host-memory entry points
     DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
+    DevBuf dPlanes;        // CodecFloat plane staging
 };
 
 struct gf_timer {
@@ -149,6 +152,7 @@ void gf_context_destroy(gf_context *c)
     c->dPred.release();
     c->dStatus.release();
     c->dOffsets.release();
+    c->dPlanes.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -274,6 +278,148 @@ gf_status gf_synth_dem_dev(gf_context *c, void *stream, uint64_t seed, int nRows
     GF_HIP(gf_launch_synth_dem(seed, nRows, nCols, tilesPerRow, tile0, nTiles, dValues,
                                stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
+}
+
+
+// ------------------------------------------------------------------ CodecFloat
+
+size_t gf_float_planes_bytes(int nRows, int nCols)
+{
+    const size_t n = (size_t)nRows * (size_t)nCols;
+    return (n + 7) / 8 + 4 * n;
+}
+
+gf_status gf_float_planes_encode_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const float *dValues,
+                                     uint8_t *dPlanes, size_t planeStride)
+{
+    if (!c || nRows < 1 || nCols < 1 || !dValues || !dPlanes || planeStride < gf_float_planes_bytes(nRows, nCols)) return GF_ERR_ARG;
+    GF_HIP(gf_launch_float_planes_encode((const uint32_t *)dValues, dPlanes, planeStride, nTiles, nRows, nCols,
+                                         stream ? (hipStream_t)stream : c->stream));
+    return GF_OK;
+}
+
+gf_status gf_float_planes_decode_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const uint8_t *dPlanes,
+                                     size_t planeStride, float *dValues)
+{
+    if (!c || nRows < 1 || nCols < 1 || !dValues || !dPlanes || planeStride < gf_float_planes_bytes(nRows, nCols)) return GF_ERR_ARG;
+    GF_HIP(gf_launch_float_planes_decode(dPlanes, (uint32_t *)dValues, planeStride, nTiles, nRows, nCols,
+                                         stream ? (hipStream_t)stream : c->stream));
+    return GF_OK;
+}
+
+// java.util.zip.Deflater(level): setInput, finish, deflate(.., FULL_FLUSH) == one complete zlib stream
+static bool zDeflate(const uint8_t *in, size_t n, int level, std::vector<uint8_t> &out)
+{
+    uLongf cap = compressBound((uLong)n) + 64;
+    out.resize(cap);
+    if (compress2(out.data(), &cap, in, (uLong)n, level) != Z_OK) return false;
+    out.resize(cap);
+    return true;
+}
+
+gf_status gf_float_encode_batch_f32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles, const float *values,
+                                    int zlibLevel, uint8_t *blob, size_t blobCap, uint64_t *offsets)
+{
+    if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const size_t n = (size_t)nRows * (size_t)nCols, nSign = (n + 7) / 8;
+    const size_t stride = roundUp(gf_float_planes_bytes(nRows, nCols), 16);
+    gf_status s;
+    if ((s = c->dValues.ensure(nTiles * n * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dPlanes.ensure(nTiles * stride + 16)) != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * n * 4, hipMemcpyHostToDevice, c->stream));
+    s = gf_float_planes_encode_dev(c, c->stream, nRows, nCols, nTiles, (const float *)c->dValues.p, (uint8_t *)c->dPlanes.p, stride);
+    if (s != GF_OK) return s;
+    std::vector<uint8_t> planes(nTiles * stride);
+    GF_HIP(hipMemcpyAsync(planes.data(), c->dPlanes.p, nTiles * stride, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    // framing, CodecFloat.java:371-391: codecIndex, 0, then five [int32 LE length, zlib stream]
+    uint64_t total = 0;
+    bool fits = true;
+    std::vector<uint8_t> z;
+    for (size_t t = 0; t < nTiles; t++) {
+        offsets[t] = total;
+        const uint8_t *p = planes.data() + t * stride;
+        size_t off = total;
+        if (fits && off + 2 <= blobCap) { blob[off] = (uint8_t)codecIndex; blob[off + 1] = 0; } else fits = false;
+        off += 2;
+        size_t planeOff = 0;
+        for (int k = 0; k < 5; k++) {
+            const size_t pl = k == 0 ? nSign : n;
+            if (!zDeflate(p + planeOff, pl, zlibLevel, z)) return GF_ERR_ARG;
+            planeOff += pl;
+            if (fits && off + 4 + z.size() <= blobCap) {
+                const uint32_t zn = (uint32_t)z.size();
+                for (int b = 0; b < 4; b++) blob[off + b] = (uint8_t)(zn >> (8 * b));
+                memcpy(blob + off + 4, z.data(), z.size());
+            } else {
+                fits = false;
+            }
+            off += 4 + z.size();
+        }
+        total = off;
+    }
+    offsets[nTiles] = total;
+    return fits ? GF_OK : GF_ERR_CAPACITY;
+}
+
+gf_status gf_float_decode_batch_f32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                    const uint64_t *offsets, float *values, int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const size_t n = (size_t)nRows * (size_t)nCols, nSign = (n + 7) / 8;
+    const size_t stride = roundUp(gf_float_planes_bytes(nRows, nCols), 16);
+    std::vector<uint8_t> planes(nTiles * stride, 0);
+    gf_status overall = GF_OK;
+    for (size_t t = 0; t < nTiles; t++) {
+        const uint8_t *pk = blob + offsets[t];
+        const size_t len = (size_t)(offsets[t + 1] - offsets[t]);
+        int32_t st = GF_OK;
+        size_t off = 2, planeOff = 0;
+        for (int k = 0; k < 5 && st == GF_OK; k++) {
+            const size_t pl = k == 0 ? nSign : n;
+            if (off + 4 > len) { st = GF_ERR_BOUNDS; break; }
+            const uint32_t zn = (uint32_t)pk[off] | ((uint32_t)pk[off + 1] << 8) | ((uint32_t)pk[off + 2] << 16) | ((uint32_t)pk[off + 3] << 24);
+            off += 4;
+            if (off + zn > len) { st = GF_ERR_BOUNDS; break; }
+            uLongf got = (uLongf)pl;
+            const int zr = uncompress(planes.data() + t * stride + planeOff, &got, pk + off, zn);
+            if (zr != Z_OK && zr != Z_BUF_ERROR) st = GF_ERR_FORMAT;      // doInflate :285-298 -> RuntimeException
+            off += zn;
+            planeOff += pl;
+        }
+        if (status) status[t] = st;
+        if (st != GF_OK && overall == GF_OK) overall = (gf_status)st;
+    }
+    gf_status s;
+    if ((s = c->dValues.ensure(nTiles * n * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dPlanes.ensure(nTiles * stride + 16)) != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(c->dPlanes.p, planes.data(), nTiles * stride, hipMemcpyHostToDevice, c->stream));
+    s = gf_float_planes_decode_dev(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dPlanes.p, stride, (float *)c->dValues.p);
+    if (s != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * n * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    return status ? GF_OK : overall;
+}
+
+gf_status gf_float_encode_f32(gf_context *c, int codecIndex, int nRows, int nCols, const float *values, int zlibLevel,
+                              uint8_t *out, size_t outCap, size_t *outLen)
+{
+    if (!outLen) return GF_ERR_ARG;
+    uint64_t offsets[2] = {0, 0};
+    const gf_status s = gf_float_encode_batch_f32(c, codecIndex, nRows, nCols, 1, values, zlibLevel, out, outCap, offsets);
+    *outLen = (size_t)offsets[1];
+    return s;
+}
+
+gf_status gf_float_decode_f32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, float *values)
+{
+    uint64_t offsets[2] = {0, (uint64_t)len};
+    int32_t st = 0;
+    const gf_status s = gf_float_decode_batch_f32(c, nRows, nCols, 1, packing, offsets, values, &st);
+    if (s != GF_OK) return s;
+    return (gf_status)st;
 }
 
 // ------------------------------------------------------------------ device memory helpers

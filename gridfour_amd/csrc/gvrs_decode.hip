@@ -66,6 +66,7 @@ struct DecShared {
     uint32_t nLeaves, nShort, nSub, l2bits;
     uint32_t chainEnd;                         // position after the last needed symbol
     uint32_t chainTotal;
+    uint32_t dense;                            // M32 stream too dense in multi-byte values for local start resolution
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
@@ -713,33 +714,90 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             cur.pos = 0;
             cur.base = 0;
             cur.d0 = cur.d1 = cur.d2 = 0;
-            uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
-            unit = max(16u, unit);
-            const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
-            resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, a.debug ? a.debug + t * 16 + 13 : nullptr);   // warm-up: 8 bytes (a value is at most 6)
-            GF_DSTAMP(6);
-            if (S.chainTotal < nStream) tileStatus = GF_K_ERR_BOUNDS;    // predictor reads past codeM32s
+            const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
+            const uint32_t nDw = (nM32 + 3u) >> 2;
             // bitmap of the bytes that start a value
             for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
-            if (tid == 0) S.chainEnd = 0;
+            if (tid == 0) { S.chainEnd = 0; S.dense = 0; }
             __syncthreads();
-            for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-                const uint32_t limit = min(nM32, (q + 1) * unit);
-                cur.seek(S.qs[q]);
-                uint32_t word = cur.pos >> 5, mask = 0;
-                while (cur.pos < limit) {
-                    const uint32_t w = cur.pos >> 5;
-                    if (w != word) {
-                        if (mask) atomicOr(&bm[word], mask);
-                        word = w;
-                        mask = 0;
+            // Local resolution, one dword of the stream per thread and step: a byte is certainly a value
+            // start when none of the five bytes before it can be an introducer (0x7f / 0x81) -- no value
+            // is longer than 6 bytes.  Where introducer candidates are near, walk the few values from
+            // the nearest certain start ("anchor").  No chain, no rounds; only a stream that is dense in
+            // multi-byte values (no anchor within 11 bytes) falls back to the chain resolution.
+            {
+                // 0x80 in every byte that may be an introducer (false positives are harmless)
+                auto cand = [](uint32_t x) -> uint32_t {
+                    const uint32_t p = x ^ 0x7F7F7F7Fu, q = x ^ 0x81818181u;
+                    return (((p - 0x01010101u) & ~p) | ((q - 0x01010101u) & ~q)) & 0x80808080u;
+                };
+                auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits
+                    return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
+                };
+                for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
+                    const uint32_t i0 = dw << 2;
+                    uint32_t d0 = m32w[dw];
+                    if (i0 + 4 > nM32) d0 &= (1u << ((nM32 - i0) * 8u)) - 1u;
+                    const uint32_t dm1 = dw >= 1 ? m32w[dw - 1] : 0u, dm2 = dw >= 2 ? m32w[dw - 2] : 0u;
+                    const uint32_t c0 = cand(d0), cm1 = cand(dm1), cm2 = cand(dm2);
+                    const uint32_t validNib = i0 + 4 <= nM32 ? 0xFu : ((1u << (nM32 - i0)) - 1u);
+                    uint32_t nib;
+                    if (!((cm1 | (cm2 & 0x80000000u)) | c0)) {
+                        nib = validNib;                         // four single-byte values
+                    } else {
+                        const uint32_t dm3 = dw >= 3 ? m32w[dw - 3] : 0u, dm4 = dw >= 4 ? m32w[dw - 4] : 0u;
+                        // candidate bit b <-> byte i0 - 16 + b
+                        const uint32_t C = nib4(cand(dm4)) | (nib4(cand(dm3)) << 4) | (nib4(cm2) << 8) | (nib4(cm1) << 12) |
+                                           (nib4(c0) << 16);
+                        const uint32_t U = C | (C << 1) | (C << 2) | (C << 3) | (C << 4);   // bit m: a candidate in bytes m-4..m
+                        // position index j (byte i0-16+j) is a certain start iff U bit j-1 is clear; want the largest j <= 16
+                        const uint32_t safe = ~U & 0xFFF0u;                                  // j-1 in 4..15
+                        nib = 0;
+                        if (!safe) {
+                            S.dense = 1;
+                        } else {
+                            const uint32_t j = 32u - (uint32_t)__builtin_clz(safe);          // (j-1)+1
+                            const uint32_t anchor = i0 + j >= 16u ? i0 + j - 16u : 0u;
+                            M32Cursor c = cur;
+                            c.seek(anchor);
+                            const uint32_t stop = min(i0 + 4u, nM32);
+                            while (c.pos < stop) {
+                                if (c.pos >= i0) nib |= 1u << (c.pos - i0);
+                                c.next();
+                            }
+                        }
                     }
-                    mask |= 1u << (cur.pos & 31u);
-                    cur.next();
+                    if (nib) atomicOr(&bm[i0 >> 5], nib << (i0 & 31u));
                 }
-                if (mask) atomicOr(&bm[word], mask);
             }
             __syncthreads();
+            GF_DSTAMP(6);
+            if (S.dense) {
+                // chain resolution over the bytes (same scheme as the Huffman text), then mark the starts
+                for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
+                uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
+                unit = max(16u, unit);
+                const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
+                resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, a.debug ? a.debug + t * 16 + 13 : nullptr);   // warm-up: 8 bytes
+                for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
+                    const uint32_t limit = min(nM32, (q + 1) * unit);
+                    M32Cursor c = cur;
+                    c.seek(S.qs[q]);
+                    uint32_t word = c.pos >> 5, mask = 0;
+                    while (c.pos < limit) {
+                        const uint32_t w = c.pos >> 5;
+                        if (w != word) {
+                            if (mask) atomicOr(&bm[word], mask);
+                            word = w;
+                            mask = 0;
+                        }
+                        mask |= 1u << (c.pos & 31u);
+                        c.next();
+                    }
+                    if (mask) atomicOr(&bm[word], mask);
+                }
+                __syncthreads();
+            }
             // rank base of every bitmap word (exclusive popcount prefix)
             if (tid == 0) S.carry = 0;
             __syncthreads();
@@ -754,14 +812,13 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                 __syncthreads();
             }
             GF_DSTAMP(7);
+            if (S.carry < nStream) tileStatus = GF_K_ERR_BOUNDS;         // predictor reads past codeM32s
             // four byte positions per thread and step: consecutive bytes are (mostly) consecutive cells,
             // so the stores of a wave are coalesced.  12 bytes of the buffer cover every value that
             // starts in the thread's dword.
             const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
             const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
             const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
-            const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
-            const uint32_t nDw = (nM32 + 3u) >> 2;
             for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
                 const uint32_t i0 = dw << 2;
                 const uint32_t bits = (bm[i0 >> 5] >> (i0 & 31u)) & 0xfu;

@@ -1,0 +1,134 @@
+// gvrs_float.hip -- CodecFloat byte planes on the GPU.
+//
+// Replaces (reference, core/src/main/java/org/gridfour/compress/CodecFloat.java):
+//   encodeFloats :328-369   raw IEEE-754 bits -> sign-bit plane (LSB first), exponent plane, three
+//                           mantissa byte planes, each mantissa plane byte-delta coded (:300-313:
+//                           within a row b[k]-b[k-1]; the first cell of a row is relative to the
+//                           first cell of the previous row, row 0 to 0)
+//   decodeFloats :395-458   the inverse (decodeDeltas :315-325 = byte-wise running sums)
+// The Deflate stage of the five planes (doDeflate :268-283) stays on the host (libz) because its
+// bytes are only defined by zlib itself; see gvrs_api.hip gf_float_*.
+//
+// Plane buffer of a tile (same layout as the oracle): [sign: ceil(n/8)] [exponent: n] [m1: n]
+// [m2: n] [m3: n], tiles at a fixed stride.  Pure streaming: 4 B/cell in, 4.125 B/cell out.
+
+#include <hip/hip_runtime.h>
+
+#include "gvrs_kernels.h"
+#include "gvrs_common.h"
+
+namespace {
+
+constexpr int FLT_THREADS = 256;
+
+__global__ __launch_bounds__(FLT_THREADS) void k_float_planes_encode(const uint32_t *__restrict__ raw, uint8_t *__restrict__ planes,
+                                                                    size_t planeStride, size_t nTiles, int nRows, int nCols)
+{
+    const uint32_t nC = (uint32_t)nCols, n = (uint32_t)nRows * nC;
+    const uint32_t nSign = (n + 7u) >> 3;
+    const int lane = threadIdx.x & 63;
+    for (size_t t = blockIdx.x; t < nTiles; t += gridDim.x) {
+        const uint32_t *__restrict__ c = raw + t * (size_t)n;
+        uint8_t *pSign = planes + t * planeStride;
+        uint8_t *pExp = pSign + nSign, *pM1 = pExp + n, *pM2 = pM1 + n, *pM3 = pM2 + n;
+        // whole waves walk 64 consecutive cells so that one ballot yields 8 sign bytes
+        for (uint32_t base = (threadIdx.x >> 6) * 64u; base < n; base += FLT_THREADS) {
+            const uint32_t i = base + lane;
+            const bool in = i < n;
+            const uint32_t v = in ? c[i] : 0u;
+            const unsigned long long sb = __ballot(in && (v >> 31));
+            if (lane < 8 && base + 8u * lane < n) pSign[(base >> 3) + lane] = (uint8_t)(sb >> (8 * lane));
+            if (in) {
+                const uint32_t col = i % nC;
+                // prior cell of the delta rule: left neighbour, or the first cell of the previous row
+                const uint32_t p = col > 0 ? c[i - 1] : (i >= nC ? c[i - nC] : 0u);
+                pExp[i] = (uint8_t)(v >> 23);
+                pM1[i] = (uint8_t)(((v >> 16) & 0x7fu) - ((p >> 16) & 0x7fu));
+                pM2[i] = (uint8_t)((v >> 8) - (p >> 8));
+                pM3[i] = (uint8_t)(v - p);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(FLT_THREADS) void k_float_planes_decode(const uint8_t *__restrict__ planes, uint32_t *__restrict__ raw,
+                                                                    size_t planeStride, size_t nTiles, int nRows, int nCols)
+{
+    __shared__ uint32_t col0[3][1024];          // decoded first cells of the rows (three mantissa planes), by chunk
+    const uint32_t nR = (uint32_t)nRows, nC = (uint32_t)nCols, n = nR * nC;
+    const uint32_t nSign = (n + 7u) >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t t = blockIdx.x; t < nTiles; t += gridDim.x) {
+        const uint8_t *pSign = planes + t * planeStride;
+        const uint8_t *pExp = pSign + nSign, *pM1 = pExp + n, *pM2 = pM1 + n, *pM3 = pM2 + n;
+        uint32_t *o = raw + t * (size_t)n;
+        // rows are processed in chunks of 1024: column-0 chain of the chunk (wave 0, running sums mod 256), then
+        // every wave scans its rows
+        uint32_t carry1 = 0, carry2 = 0, carry3 = 0;            // first cell of the row before the chunk
+        for (uint32_t r0 = 0; r0 < nR; r0 += 1024) {
+            const uint32_t rows = min(1024u, nR - r0);
+            if (wave == 0) {
+                for (uint32_t rb = 0; rb < rows; rb += 64) {
+                    const uint32_t r = r0 + rb + lane;
+                    const bool in = rb + lane < rows;
+                    uint32_t a = in ? pM1[(size_t)r * nC] : 0u, b = in ? pM2[(size_t)r * nC] : 0u, d = in ? pM3[(size_t)r * nC] : 0u;
+                    a = gf_wave_incl_scan(a) + carry1;
+                    b = gf_wave_incl_scan(b) + carry2;
+                    d = gf_wave_incl_scan(d) + carry3;
+                    if (in) { col0[0][rb + lane] = a & 0xffu; col0[1][rb + lane] = b & 0xffu; col0[2][rb + lane] = d & 0xffu; }
+                    carry1 = __shfl(a, 63, 64) & 0xffu;
+                    carry2 = __shfl(b, 63, 64) & 0xffu;
+                    carry3 = __shfl(d, 63, 64) & 0xffu;
+                }
+            }
+            __syncthreads();
+            carry1 = col0[0][rows - 1];
+            carry2 = col0[1][rows - 1];
+            carry3 = col0[2][rows - 1];
+            for (uint32_t rr = wave; rr < rows; rr += FLT_THREADS / 64) {
+                const uint32_t r = r0 + rr;
+                const size_t rowOff = (size_t)r * nC;
+                uint32_t c1 = 0, c2 = 0, c3 = 0;                // running sums carried along the row
+                for (uint32_t cb = 0; cb < nC; cb += 64) {
+                    const uint32_t cc = cb + lane;
+                    const bool in = cc < nC;
+                    uint32_t a, b, d;
+                    if (cc == 0) { a = col0[0][rr]; b = col0[1][rr]; d = col0[2][rr]; }       // already decoded
+                    else { a = in ? pM1[rowOff + cc] : 0u; b = in ? pM2[rowOff + cc] : 0u; d = in ? pM3[rowOff + cc] : 0u; }
+                    a = gf_wave_incl_scan(a) + c1;
+                    b = gf_wave_incl_scan(b) + c2;
+                    d = gf_wave_incl_scan(d) + c3;
+                    c1 = __shfl(a, 63, 64);
+                    c2 = __shfl(b, 63, 64);
+                    c3 = __shfl(d, 63, 64);
+                    if (in) {
+                        const size_t i = rowOff + cc;
+                        const uint32_t s = (pSign[i >> 3] >> (i & 7)) & 1u;
+                        o[i] = (s << 31) | ((uint32_t)pExp[i] << 23) | ((a & 0x7fu) << 16) | ((b & 0xffu) << 8) | (d & 0xffu);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t gf_launch_float_planes_encode(const uint32_t *raw, uint8_t *planes, size_t planeStride, size_t nTiles, int nRows,
+                                         int nCols, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    const unsigned grid = (unsigned)(nTiles < 16384 ? nTiles : 16384);
+    hipLaunchKernelGGL(k_float_planes_encode, dim3(grid), dim3(FLT_THREADS), 0, stream, raw, planes, planeStride, nTiles, nRows, nCols);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_float_planes_decode(const uint8_t *planes, uint32_t *raw, size_t planeStride, size_t nTiles, int nRows,
+                                         int nCols, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    const unsigned grid = (unsigned)(nTiles < 16384 ? nTiles : 16384);
+    hipLaunchKernelGGL(k_float_planes_decode, dim3(grid), dim3(FLT_THREADS), 0, stream, planes, raw, planeStride, nTiles, nRows, nCols);
+    return hipGetLastError();
+}

@@ -57,3 +57,9 @@ hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStr
                              size_t blobCap, hipStream_t stream);
 hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                                int64_t tile0, size_t nTiles, int32_t *values, hipStream_t stream);
+
+// CodecFloat byte planes (gvrs_float.hip); plane buffer of a tile = ceil(n/8) + 4n bytes at planeStride
+hipError_t gf_launch_float_planes_encode(const uint32_t *raw, uint8_t *planes, size_t planeStride, size_t nTiles, int nRows,
+                                         int nCols, hipStream_t stream);
+hipError_t gf_launch_float_planes_decode(const uint8_t *planes, uint32_t *raw, size_t planeStride, size_t nTiles, int nRows,
+                                         int nCols, hipStream_t stream);

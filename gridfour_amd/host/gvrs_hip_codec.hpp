@@ -154,4 +154,47 @@ private:
     long bytes_[5] = {0, 0, 0, 0, 0};
 };
 
+/** Drop-in for org.gridfour.compress.CodecFloat (CodecFloat.java:328-458): byte planes on the GPU,
+ *  Deflate of the five planes on the host's zlib. */
+class CodecFloatHip : public ICompressionEncoder, public ICompressionDecoder {
+public:
+    explicit CodecFloatHip(int device = 0, int zlibLevel = 9) : level_(zlibLevel)
+    {
+        const gf_status s = gf_context_create(device, &ctx_);
+        if (s != GF_OK) throw std::runtime_error(std::string("CodecFloatHip: ") + gf_status_string(s) + " [" + gf_last_error() + "]");
+    }
+    ~CodecFloatHip() override { gf_context_destroy(ctx_); }
+    CodecFloatHip(const CodecFloatHip &) = delete;
+    CodecFloatHip &operator=(const CodecFloatHip &) = delete;
+
+    std::optional<std::vector<uint8_t>> encode(int, int, int, const std::vector<int32_t> &) override { return std::nullopt; }
+    std::optional<std::vector<uint8_t>> encodeFloats(int codecIndex, int nRows, int nCols, const std::vector<float> &values) override
+    {
+        std::vector<uint8_t> out(5 * values.size() + 4096);
+        size_t n = 0;
+        const gf_status s = gf_float_encode_f32(ctx_, codecIndex, nRows, nCols, values.data(), level_, out.data(), out.size(), &n);
+        if (s < 0) throw std::runtime_error(std::string("gf_float_encode_f32: ") + gf_status_string(s));
+        out.resize(n);
+        return out;
+    }
+    bool implementsFloatingPointEncoding() const override { return true; }
+    bool implementsIntegerEncoding() const override { return false; }
+    std::vector<int32_t> decode(int, int, const std::vector<uint8_t> &) override { return {}; }
+    std::optional<std::vector<float>> decodeFloats(int nRows, int nColumns, const std::vector<uint8_t> &packing) override
+    {
+        std::vector<float> out((size_t)nRows * (size_t)nColumns);
+        const gf_status s = gf_float_decode_f32(ctx_, nRows, nColumns, packing.data(), packing.size(), out.data());
+        if (s == GF_ERR_FORMAT || s == GF_ERR_BOUNDS) throw IOException(gf_status_string(s));
+        if (s < 0) throw std::runtime_error(std::string("gf_float_decode_f32: ") + gf_status_string(s));
+        return out;
+    }
+    void analyze(int, int, const std::vector<uint8_t> &) override {}
+    void reportAnalysisData(std::FILE *ps, int) override { std::fprintf(ps, "Gridfour_Float (HIP)\n"); }
+    void clearAnalysisData() override {}
+
+private:
+    gf_context *ctx_ = nullptr;
+    int level_;
+};
+
 }  // namespace gridfour

@@ -140,6 +140,29 @@ gf_status gf_compact_dev(gf_context *ctx, void *stream, size_t n_tiles, const ui
                          size_t slot_stride, const uint32_t *d_lengths, uint64_t *d_offsets,
                          uint8_t *d_blob, size_t blob_cap);
 
+/* ---- CodecFloat (compress/CodecFloat.java:328-458): float32 tiles ---------------------------
+ * The five byte planes (sign bits, exponent, three byte-delta coded mantissa bytes) are split and
+ * merged on the GPU; the Deflate stage of each plane runs on the host's zlib (its bytes are defined
+ * by zlib itself: the reference calls java.util.zip.Deflater(9), CodecFloat.java:268-283).
+ * plane buffer of a tile: [sign ceil(n/8)] [exponent n] [m1 n] [m2 n] [m3 n], n = n_rows*n_cols.   */
+size_t gf_float_planes_bytes(int n_rows, int n_cols);
+gf_status gf_float_planes_encode_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                     const float *d_values, uint8_t *d_planes, size_t plane_stride);
+gf_status gf_float_planes_decode_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                     const uint8_t *d_planes, size_t plane_stride, float *d_values);
+/* replaces ICompressionEncoder.encodeFloats / ICompressionDecoder.decodeFloats as implemented by
+ * CodecFloat, for one tile or a batch in host memory.  zlib_level: 9 = current reference source,
+ * 6 = what the reference's sample files were written with.  offsets[n_tiles+1] as for the int path. */
+gf_status gf_float_encode_batch_f32(gf_context *ctx, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                    const float *values, int zlib_level, uint8_t *blob, size_t blob_cap,
+                                    uint64_t *offsets);
+gf_status gf_float_decode_batch_f32(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                    const uint64_t *offsets, float *values, int32_t *status);
+gf_status gf_float_encode_f32(gf_context *ctx, int codec_index, int n_rows, int n_cols, const float *values,
+                              int zlib_level, uint8_t *out, size_t out_cap, size_t *out_len);
+gf_status gf_float_decode_f32(gf_context *ctx, int n_rows, int n_cols, const uint8_t *packing, size_t packing_len,
+                              float *values);
+
 /* ---- synthetic elevation tiles (bench / tests) ---- */
 /* fills n_tiles tiles of a seeded integer value-noise DEM cut into
  * n_rows x n_cols tiles, tiles_per_row tiles across, starting at tile0.      */
