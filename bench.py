@@ -53,6 +53,24 @@ def parse_args():
     return ap.parse_args()
 
 
+def _pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_hbm.sh writes
+    profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 corrections applied).
+    PMC collection cannot run inside the timed process, so the per-launch figure measured for this same
+    workload is read back; None when no measurement for the workload is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("workload") != workload:
+        return None
+    for name, d in rec.get("kernels", {}).items():
+        if kernel in name:
+            return int(d["traffic"])
+    return None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +195,7 @@ def main():
     alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
     dom_name, dom_ms = ("k_huffman_decode", dec_avg) if dec_avg >= enc_avg else ("k_huffman_encode", enc_avg)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = _pmc_traffic(args.workload, dom_name)
     out = {
         "metric": METRIC,
         "value": round(value, 1),
@@ -200,7 +219,7 @@ def main():
         "encode_MBps": round(raw_mb / (enc_avg * 1e-3), 1),
         "decode_MBps": round(raw_mb / (dec_avg * 1e-3), 1),
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "avg_launch_ms": round(dom_ms, 4),
                      "roundtrip_frac": round((2 * alg_bytes) / ((enc_avg + dec_avg) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
