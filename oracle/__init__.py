@@ -21,10 +21,9 @@ PM_DIFFERENCING, PM_LINEAR, PM_TRIANGLE, PM_DIFFERENCING_NULLS = 1, 2, 3, 4
 
 def build(force=False):
     """Compile libgvrs_oracle.so with gcc (seconds)."""
-    src = os.path.join(_HERE, "gvrs_oracle.c")
-    hdr = os.path.join(_HERE, "gvrs_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(f) for f in srcs)):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "libgvrs_oracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -75,6 +74,27 @@ def lib():
         L.gvo_dem_fill_tiles.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                          C.c_int64, i32p]
         L.gvo_dem_fill_tiles.restype = None
+        f32p = C.POINTER(C.c_float)
+        L.gvo_canon_encode.argtypes = [u8p, C.c_size_t, szp, i32p, C.c_size_t, u8p]
+        L.gvo_canon_decode.argtypes = [u8p, C.c_size_t, szp, i32p, C.c_size_t, szp]
+        L.gvo_predictor_encode_int.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p, i32p]
+        L.gvo_predictor_decode_int.argtypes = [C.c_int, C.c_int32, C.c_int, C.c_int, i32p, i32p]
+        L.gvo_codec_canon_encode.argtypes = [C.c_int, C.c_int, C.c_int, i32p, u8p, C.c_size_t, szp, C.c_int, ip]
+        L.gvo_codec_canon_decode.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, i32p]
+        L.gvo_codec_canon_bound.argtypes = [C.c_size_t]
+        L.gvo_codec_canon_bound.restype = C.c_size_t
+        L.gvo_batch_canon_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, i32p, u8p, C.c_size_t, u32p, u8p]
+        L.gvo_batch_canon_decode.argtypes = [C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, u32p, i32p]
+        L.gvo_lsop12_coefficients.argtypes = [C.c_int, C.c_int, i32p, f32p]
+        L.gvo_lsop12_residuals.argtypes = [C.c_int, C.c_int, i32p, i32p, f32p, i32p, i32p]
+        L.gvo_lsop12_encode.argtypes = [C.c_int, C.c_int, C.c_int, i32p, C.c_int, u8p, C.c_size_t, szp, ip]
+        L.gvo_lsop12_decode.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, i32p]
+        L.gvo_lsop12_encode_legacy_huffman.argtypes = [C.c_int, C.c_int, C.c_int, i32p, u8p, C.c_size_t, szp]
+        L.gvo_lsop12_bound.argtypes = [C.c_size_t]
+        L.gvo_lsop12_bound.restype = C.c_size_t
+        L.gvo_batch_lsop12_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, i32p, C.c_int, u8p, C.c_size_t,
+                                              u32p, u8p]
+        L.gvo_batch_lsop12_decode.argtypes = [C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, u32p, i32p]
         _lib = L
     return _lib
 
@@ -297,4 +317,162 @@ def dem_tiles(seed, n_rows, n_cols, tiles_per_row, tile0, n_tiles):
     out = np.zeros((n_tiles, n_rows * n_cols), np.int32)
     lib().gvo_dem_fill_tiles(seed & (2 ** 64 - 1), n_rows, n_cols, tiles_per_row, tile0, n_tiles,
                              _p(out, C.c_int32))
+    return out
+
+
+# ---- canonical Huffman / CodecCanonHuffman (parity unpinned: see gvrs_oracle_canon.c) ----
+def canon_encode(text, bit_pos=0, prefix=b""):
+    """CanonicalHuffman.encode appended at bit_pos; returns (bytes, end_bit_pos, code_lengths[260])."""
+    t = _i32(text).ravel()
+    cap = len(prefix) + 2048 + 11 * t.size + 64
+    buf = np.zeros(cap, np.uint8)
+    if prefix:
+        buf[:len(prefix)] = np.frombuffer(prefix, np.uint8)
+    pos = C.c_size_t(bit_pos)
+    cl = np.zeros(260, np.uint8)
+    rc = lib().gvo_canon_encode(_p(buf, C.c_uint8), cap * 8, C.byref(pos), _p(t, C.c_int32), t.size,
+                                _p(cl, C.c_uint8))
+    if rc != OK:
+        raise ValueError("canon_encode rc=%d" % rc)
+    return bytes(buf[:(pos.value + 7) // 8]), pos.value, cl
+
+
+def canon_decode(data, max_symbols, bit_pos=0):
+    b = _u8(data)
+    out = np.zeros(max(max_symbols, 1), np.int32)
+    pos = C.c_size_t(bit_pos)
+    nd = C.c_size_t(0)
+    rc = lib().gvo_canon_decode(_p(b, C.c_uint8), b.size * 8, C.byref(pos), _p(out, C.c_int32), max_symbols,
+                                C.byref(nd))
+    if rc != OK:
+        raise ValueError("canon_decode rc=%d" % rc)
+    return out[:nd.value].copy(), pos.value
+
+
+def predictor_encode_int(model, n_rows, n_cols, values):
+    v = _i32(values).ravel()
+    out = np.zeros(v.size + 8, np.int32)
+    seed = C.c_int32(0)
+    n = lib().gvo_predictor_encode_int(model, n_rows, n_cols, _p(v, C.c_int32), _p(out, C.c_int32), C.byref(seed))
+    if n < 0:
+        return None, 0
+    return out[:n].copy(), seed.value
+
+
+def predictor_decode_int(model, seed, n_rows, n_cols, residuals):
+    e = np.concatenate([_i32(residuals).ravel(), np.zeros(n_rows * n_cols + 8, np.int32)])
+    out = np.zeros(n_rows * n_cols, np.int32)
+    rc = lib().gvo_predictor_decode_int(model, seed, n_rows, n_cols, _p(e, C.c_int32), _p(out, C.c_int32))
+    if rc != OK:
+        raise ValueError("predictor_decode_int rc=%d" % rc)
+    return out
+
+
+def codec_canon_encode(codec_index, n_rows, n_cols, values, predictor_mask=0xF):
+    """CodecCanonHuffman.encode: (packing | None, predictor_used); ValueError where Java throws."""
+    v = _i32(values).ravel()
+    assert v.size == n_rows * n_cols
+    cap = int(lib().gvo_codec_canon_bound(v.size))
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    used = C.c_int(0)
+    rc = lib().gvo_codec_canon_encode(codec_index, n_rows, n_cols, _p(v, C.c_int32), _p(out, C.c_uint8), cap,
+                                      C.byref(n), predictor_mask, C.byref(used))
+    if rc == DECLINED:
+        return None, 0
+    if rc != OK:
+        raise ValueError("codec_canon_encode rc=%d" % rc)
+    return bytes(out[:n.value]), used.value
+
+
+def codec_canon_decode(n_rows, n_cols, packing):
+    p = _u8(packing)
+    out = np.zeros(n_rows * n_cols, np.int32)
+    rc = lib().gvo_codec_canon_decode(n_rows, n_cols, _p(p, C.c_uint8), p.size, _p(out, C.c_int32))
+    if rc != OK:
+        raise IOError("codec_canon_decode rc=%d" % rc)
+    return out
+
+
+def batch_canon_encode(codec_index, n_rows, n_cols, tiles, stride=None):
+    v = _i32(tiles).reshape(-1, n_rows * n_cols)
+    nt = v.shape[0]
+    stride = stride or int(lib().gvo_codec_canon_bound(n_rows * n_cols))
+    out = np.zeros(nt * stride, np.uint8)
+    ln = np.zeros(nt, np.uint32)
+    pr = np.zeros(nt, np.uint8)
+    rc = lib().gvo_batch_canon_encode(codec_index, n_rows, n_cols, nt, _p(v, C.c_int32), _p(out, C.c_uint8), stride,
+                                      _p(ln, C.c_uint32), _p(pr, C.c_uint8))
+    if rc != OK:
+        raise ValueError("batch_canon_encode rc=%d" % rc)
+    return out.reshape(nt, stride), ln, pr
+
+
+def batch_canon_decode(n_rows, n_cols, slots, lengths):
+    s = np.ascontiguousarray(slots, np.uint8)
+    nt, stride = s.shape
+    ln = np.ascontiguousarray(lengths, np.uint32)
+    out = np.zeros((nt, n_rows * n_cols), np.int32)
+    rc = lib().gvo_batch_canon_decode(n_rows, n_cols, nt, _p(s, C.c_uint8), stride, _p(ln, C.c_uint32),
+                                      _p(out, C.c_int32))
+    if rc != OK:
+        raise IOError("batch_canon_decode rc=%d" % rc)
+    return out
+
+
+# ---- LSOP12 ----
+def lsop12_coefficients(n_rows, n_cols, values):
+    v = _i32(values).ravel()
+    u = np.zeros(12, np.float32)
+    rc = lib().gvo_lsop12_coefficients(n_rows, n_cols, _p(v, C.c_int32), _p(u, C.c_float))
+    return None if rc != OK else u
+
+
+def lsop12_residuals(n_rows, n_cols, values):
+    v = _i32(values).ravel()
+    u = np.zeros(12, np.float32)
+    init = np.zeros(4 * n_rows + 2 * n_cols - 9, np.int32)
+    inter = np.zeros((n_rows - 2) * (n_cols - 4), np.int32)
+    seed = C.c_int32(0)
+    rc = lib().gvo_lsop12_residuals(n_rows, n_cols, _p(v, C.c_int32), C.byref(seed), _p(u, C.c_float),
+                                    _p(init, C.c_int32), _p(inter, C.c_int32))
+    if rc != OK:
+        return None
+    return seed.value, u, init, inter
+
+
+def lsop12_encode(codec_index, n_rows, n_cols, values, deflate_enabled=True):
+    """LsEncoder12.encode: (packing | None, container type)."""
+    v = _i32(values).ravel()
+    cap = int(lib().gvo_lsop12_bound(v.size))
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    typ = C.c_int(0)
+    rc = lib().gvo_lsop12_encode(codec_index, n_rows, n_cols, _p(v, C.c_int32), int(deflate_enabled), _p(out, C.c_uint8),
+                                 cap, C.byref(n), C.byref(typ))
+    if rc == DECLINED:
+        return None, 0
+    if rc != OK:
+        raise ValueError("lsop12_encode rc=%d" % rc)
+    return bytes(out[:n.value]), typ.value
+
+
+def lsop12_encode_legacy_huffman(codec_index, n_rows, n_cols, values):
+    v = _i32(values).ravel()
+    cap = 8 * v.size + 4096
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().gvo_lsop12_encode_legacy_huffman(codec_index, n_rows, n_cols, _p(v, C.c_int32), _p(out, C.c_uint8), cap,
+                                                C.byref(n))
+    if rc != OK:
+        raise ValueError("lsop12_encode_legacy_huffman rc=%d" % rc)
+    return bytes(out[:n.value])
+
+
+def lsop12_decode(n_rows, n_cols, packing):
+    p = _u8(packing)
+    out = np.zeros(n_rows * n_cols, np.int32)
+    rc = lib().gvo_lsop12_decode(n_rows, n_cols, _p(p, C.c_uint8), p.size, _p(out, C.c_int32))
+    if rc != OK:
+        raise IOError("lsop12_decode rc=%d" % rc)
     return out

@@ -102,6 +102,45 @@ int gvo_codec_float_encode(int codecIndex, int nRows, int nCols,
 int gvo_codec_float_decode(int nRows, int nCols, const uint8_t *packing,
                            size_t len, uint32_t *rawBits);
 
+/* ---- canonical Huffman (compress/canonicalHuffman/ *.java) -- PARITY UNPINNED, see gvrs_oracle_canon.c ---- */
+/* CanonicalHuffman.encode :177-283: appends code tables + text + end-of-text to a zeroed bit buffer at
+ * *bitPos.  codeLen260 (optional) receives the 260 code lengths.                                     */
+int gvo_canon_encode(uint8_t *bits, size_t capBits, size_t *bitPos, const int32_t *text, size_t nSymbols,
+                     uint8_t *codeLen260);
+/* CanonicalHuffman.decode :441-519: reads until the end-of-text symbol; text has room for nSymbolsInText */
+int gvo_canon_decode(const uint8_t *bits, size_t nBitsTotal, size_t *bitPos, int32_t *text,
+                     size_t nSymbolsInText, size_t *nDecoded);
+/* IPredictorModel.encodeInt / decodeInt: integer residual streams (no M32).  encode returns the
+ * number of residuals, -1 = model declines (Triangle), -2 = Java would index out of bounds.          */
+int gvo_predictor_encode_int(int model, int nRows, int nCols, const int32_t *values, int32_t *out, int32_t *seed);
+int gvo_predictor_decode_int(int model, int32_t seed, int nRows, int nCols, const int32_t *residuals,
+                             int32_t *values);
+/* CodecCanonHuffman.encode :70-160 / decode :163-195 (the default integer codec of current Gridfour)  */
+int gvo_codec_canon_encode(int codecIndex, int nRows, int nCols, const int32_t *values, uint8_t *out,
+                           size_t outCap, size_t *outLen, int predictorMask, int *predictorUsed);
+int gvo_codec_canon_decode(int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values);
+size_t gvo_codec_canon_bound(size_t nCells);
+int gvo_batch_canon_encode(int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                           uint8_t *out, size_t stride, uint32_t *lengths, uint8_t *predictors);
+int gvo_batch_canon_decode(int nRows, int nCols, size_t nTiles, const uint8_t *packings, size_t stride,
+                           const uint32_t *lengths, int32_t *values);
+
+/* ---- LSOP12 (lsop/LsOptimalPredictor12.java, LsEncoder12.java, LsDecoder12.java, LsHeader.java,
+ *      util/jama/LUDecomposition.java); see gvrs_oracle_lsop.c for what Sample14_LSOP.gvrs pins ---- */
+int gvo_lsop12_coefficients(int nRows, int nCols, const int32_t *values, float *u12);
+int gvo_lsop12_residuals(int nRows, int nCols, const int32_t *values, int32_t *seed, float *u12,
+                         int32_t *initInt, int32_t *interiorInt);
+int gvo_lsop12_encode(int codecIndex, int nRows, int nCols, const int32_t *values, int deflateEnabled,
+                      uint8_t *out, size_t outCap, size_t *outLen, int *containerType);
+int gvo_lsop12_decode(int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values);
+int gvo_lsop12_encode_legacy_huffman(int codecIndex, int nRows, int nCols, const int32_t *values,
+                                     uint8_t *out, size_t outCap, size_t *outLen);
+size_t gvo_lsop12_bound(size_t nCells);
+int gvo_batch_lsop12_encode(int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                            int deflateEnabled, uint8_t *out, size_t stride, uint32_t *lengths, uint8_t *types);
+int gvo_batch_lsop12_decode(int nRows, int nCols, size_t nTiles, const uint8_t *packings, size_t stride,
+                            const uint32_t *lengths, int32_t *values);
+
 /* ---- batch helpers used by the CPU baseline (plain loops over tiles) ---- */
 /* tiles are contiguous, nRows*nCols each.  out slots have `stride` bytes.   */
 int gvo_batch_huffman_encode(int codecIndex, int nRows, int nCols, size_t nTiles,
