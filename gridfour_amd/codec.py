@@ -63,24 +63,30 @@ class GvrsHipContext:
 class CodecHuffmanHip:
     """Drop-in for org.gridfour.compress.CodecHuffman, computed on the MI355X."""
 
+    _PREFIX = "gf_huffman"                       # entry-point family of the C ABI
+
     def __init__(self, context=None, device=0):
         self.ctx = context if context is not None else GvrsHipContext(device)
+
+    def _fn(self, name):
+        return getattr(lib(), "%s_%s" % (self._PREFIX, name))
 
     # ---- ICompressionEncoder ----
     def encode(self, codecIndex, nRows, nCols, values):
         v = np.ascontiguousarray(values, dtype=np.int32).ravel()
         if v.size != nRows * nCols:
             raise ValueError("values.length != nRows*nCols")
-        cap = int(lib().gf_huffman_max_packing(nRows, nCols))
+        cap = int(self._fn("max_packing")(nRows, nCols))
         out = np.empty(cap, np.uint8)
         n = C.c_size_t(0)
-        st = lib().gf_huffman_encode_i32(self.ctx.handle, codecIndex, nRows, nCols, _ptr(v), _ptr(out), cap,
-                                         C.byref(n))
+        st = self._fn("encode_i32")(self.ctx.handle, codecIndex, nRows, nCols, _ptr(v), _ptr(out), cap, C.byref(n))
         if st == _lib.DECLINED:
             return None
         if st == _lib.ERR_BOUNDS:
             raise IndexError("ArrayIndexOutOfBoundsException in the reference for these dimensions")
-        check(st, "gf_huffman_encode_i32")
+        if st == _lib.ERR_ARG and self._PREFIX == "gf_canon":
+            raise ValueError("IllegalArgumentException in the reference for these dimensions")
+        check(st, self._PREFIX + "_encode_i32")
         return bytes(out[:n.value])
 
     def encodeFloats(self, codecIndex, nRows, nCols, values):
@@ -96,10 +102,10 @@ class CodecHuffmanHip:
     def decode(self, nRows, nColumns, packing):
         p = np.frombuffer(bytes(packing), dtype=np.uint8)
         out = np.empty(nRows * nColumns, np.int32)
-        st = lib().gf_huffman_decode_i32(self.ctx.handle, nRows, nColumns, _ptr(p), p.size, _ptr(out))
+        st = self._fn("decode_i32")(self.ctx.handle, nRows, nColumns, _ptr(p), p.size, _ptr(out))
         if st in (_lib.ERR_FORMAT, _lib.ERR_BOUNDS):
             raise IOError(lib().gf_status_string(st).decode())
-        check(st, "gf_huffman_decode_i32")
+        check(st, self._PREFIX + "_decode_i32")
         return out
 
     def decodeFloats(self, nRows, nColumns, packing):
@@ -116,12 +122,12 @@ class CodecHuffmanHip:
         status = np.zeros(nt, np.int32)
         while True:
             blob = np.empty(max(cap, 16), np.uint8)
-            st = lib().gf_huffman_encode_batch_i32(self.ctx.handle, codecIndex, nRows, nCols, nt, _ptr(v),
-                                                   _ptr(blob), cap, _ptr(offsets), _ptr(preds), _ptr(status))
+            st = self._fn("encode_batch_i32")(self.ctx.handle, codecIndex, nRows, nCols, nt, _ptr(v), _ptr(blob), cap,
+                                              _ptr(offsets), _ptr(preds), _ptr(status))
             if st == _lib.ERR_CAPACITY:
                 cap = int(offsets[nt]) + 16
                 continue
-            check(st, "gf_huffman_encode_batch_i32")
+            check(st, self._PREFIX + "_encode_batch_i32")
             break
         packs = []
         for t in range(nt):
@@ -139,9 +145,16 @@ class CodecHuffmanHip:
         blob = np.frombuffer(b"".join(packings) + b"\0" * 16, dtype=np.uint8)
         out = np.empty((nt, nRows * nCols), np.int32)
         status = np.zeros(nt, np.int32)
-        check(lib().gf_huffman_decode_batch_i32(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets),
-                                                _ptr(out), _ptr(status)), "gf_huffman_decode_batch_i32")
+        check(self._fn("decode_batch_i32")(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets), _ptr(out),
+                                           _ptr(status)), self._PREFIX + "_decode_batch_i32")
         return out, status
+
+
+class CodecCanonHuffmanHip(CodecHuffmanHip):
+    """Drop-in for org.gridfour.compress.canonicalHuffman.CodecCanonHuffman (the default integer codec of
+    current Gridfour, GvrsFileSpecification.java:229), computed on the MI355X."""
+
+    _PREFIX = "gf_canon"
 
 
 class DeviceBuffer:
@@ -193,7 +206,9 @@ class DeviceTileBatch:
     context's stream).
     """
 
-    def __init__(self, ctx, n_rows, n_cols, n_tiles, slot_stride=None):
+    def __init__(self, ctx, n_rows, n_cols, n_tiles, slot_stride=None, codec="huffman"):
+        assert codec in ("huffman", "canon")
+        self.codec = codec
         self.ctx, self.n_rows, self.n_cols, self.n_tiles = ctx, int(n_rows), int(n_cols), int(n_tiles)
         self.cells = self.n_rows * self.n_cols
         self.stride = int(slot_stride or lib().gf_huffman_default_stride(n_rows, n_cols))
@@ -213,16 +228,16 @@ class DeviceTileBatch:
                                      tiles_per_row, tile0, self.n_tiles, self.values.ptr), "gf_synth_dem_dev")
 
     def encode(self, codec_index=0, predictor_mask=_lib.PM_ALL, stream=None):
-        check(lib().gf_huffman_encode_batch_i32_dev(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols,
-                                                    self.n_tiles, self.values.ptr, self.slots.ptr, self.stride,
-                                                    self.lengths.ptr, self.predictors.ptr, self.enc_status.ptr,
-                                                    predictor_mask), "gf_huffman_encode_batch_i32_dev")
+        fn = getattr(lib(), "gf_%s_encode_batch_i32_dev" % self.codec)
+        check(fn(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols, self.n_tiles, self.values.ptr,
+                 self.slots.ptr, self.stride, self.lengths.ptr, self.predictors.ptr, self.enc_status.ptr,
+                 predictor_mask), "gf_%s_encode_batch_i32_dev" % self.codec)
 
     def decode(self, stream=None):
-        check(lib().gf_huffman_decode_batch_i32_dev(self.ctx.handle, stream, self.n_rows, self.n_cols, self.n_tiles,
-                                                    self.slots.ptr, self.n_tiles * self.stride, None, self.stride,
-                                                    self.lengths.ptr, self.decoded.ptr, self.dec_status.ptr),
-              "gf_huffman_decode_batch_i32_dev")
+        fn = getattr(lib(), "gf_%s_decode_batch_i32_dev" % self.codec)
+        check(fn(self.ctx.handle, stream, self.n_rows, self.n_cols, self.n_tiles, self.slots.ptr,
+                 self.n_tiles * self.stride, None, self.stride, self.lengths.ptr, self.decoded.ptr,
+                 self.dec_status.ptr), "gf_%s_decode_batch_i32_dev" % self.codec)
 
     # host views (synchronising copies)
     def get_lengths(self):

@@ -198,10 +198,14 @@ size_t gf_huffman_max_packing(int nRows, int nCols)
 
 // ------------------------------------------------------------------ device-resident
 
-gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
-                                          size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
-                                          uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus,
-                                          int predictorMask)
+}  // extern "C"
+
+// codec kinds behind the shared batch plumbing
+enum { KIND_HUFFMAN = 0, KIND_CANON = 1 };
+
+static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
+                                size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
+                                uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus, int predictorMask)
 {
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dOut || !dLengths || !dStatus) return GF_ERR_ARG;
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
@@ -220,20 +224,20 @@ gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codec
     a.predictorMask = predictorMask & GF_PM_ALL;
     a.debug = g_encodeDebug;
     a.phaseLimit = g_encPhaseLimit;
-    GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
+    if (kind == KIND_CANON) GF_HIP(gf_launch_canon_encode(a, stream ? (hipStream_t)stream : c->stream));
+    else GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
 }
 
-gf_status gf_huffman_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
-                                          const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets,
-                                          size_t slotStride, const uint32_t *dLengths, int32_t *dValues,
-                                          int32_t *dStatus)
+static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
+                                const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets, size_t slotStride,
+                                const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus)
 {
     if (!c || nRows < 1 || nCols < 1 || !dBlob || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
     if (((uintptr_t)dBlob & 3) != 0) return GF_ERR_ARG;
     const unsigned grid = gf_huffman_decode_grid(nTiles);
-    const size_t wsStride = decodeWorkspaceStride(nRows, nCols);
+    const size_t wsStride = kind == KIND_CANON ? 0 : decodeWorkspaceStride(nRows, nCols);
     if (c->workspace.bytes < (size_t)grid * wsStride) {
         // not capture-safe: callers that capture graphs call gf_context_reserve first
         GF_HIP(hipSetDevice(c->device));
@@ -253,12 +257,61 @@ gf_status gf_huffman_decode_batch_i32_dev(gf_context *c, void *stream, int nRows
     a.nTiles = nTiles;
     a.nRows = nRows;
     a.nCols = nCols;
-    a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
-    a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
     a.phaseLimit = g_decPhaseLimit;
     a.debug = g_decodeDebug;
-    GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
+    if (kind == KIND_CANON) {
+        a.ldsM32Bytes = 0;
+        a.ldsTextBytes = gf_canon_decode_lds_text(nRows, nCols);
+        GF_HIP(gf_launch_canon_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
+    } else {
+        a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
+        a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
+        GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
+    }
     return GF_OK;
+}
+
+extern "C" {
+
+gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
+                                          size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
+                                          uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus,
+                                          int predictorMask)
+{
+    return encodeBatchDev(KIND_HUFFMAN, c, stream, codecIndex, nRows, nCols, nTiles, dValues, dOut, slotStride, dLengths,
+                          dPredictors, dStatus, predictorMask);
+}
+
+gf_status gf_huffman_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
+                                          const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets,
+                                          size_t slotStride, const uint32_t *dLengths, int32_t *dValues,
+                                          int32_t *dStatus)
+{
+    return decodeBatchDev(KIND_HUFFMAN, c, stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths,
+                          dValues, dStatus);
+}
+
+gf_status gf_canon_encode_batch_i32_dev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
+                                        size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
+                                        uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus, int predictorMask)
+{
+    return encodeBatchDev(KIND_CANON, c, stream, codecIndex, nRows, nCols, nTiles, dValues, dOut, slotStride, dLengths,
+                          dPredictors, dStatus, predictorMask);
+}
+
+gf_status gf_canon_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
+                                        const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets,
+                                        size_t slotStride, const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus)
+{
+    return decodeBatchDev(KIND_CANON, c, stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths,
+                          dValues, dStatus);
+}
+
+size_t gf_canon_max_packing(int nRows, int nCols)
+{
+    // 6 header bytes + code tables (< 750 bytes) + per value at most 4 symbols of 15 bits and 24 raw bits + end-of-text
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    return roundUp(6 + 768 + (cells * 84 + 15 + 7) / 8 + 16, 16);
 }
 
 gf_status gf_compact_dev(gf_context *c, void *stream, size_t nTiles, const uint8_t *dSlots, size_t slotStride,
@@ -511,9 +564,11 @@ gf_status gf_timer_elapsed_ms(gf_timer *t, float *ms)
 
 // ------------------------------------------------------------------ host-memory entry points
 
-gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles,
-                                      const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
-                                      uint8_t *predictors, int32_t *status)
+}  // extern "C"
+
+static gf_status encodeBatchHost(int kind, gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                 const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
+                                 uint8_t *predictors, int32_t *status)
 {
     if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
@@ -527,9 +582,9 @@ gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, 
     if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
     if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
     GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
-    s = gf_huffman_encode_batch_i32_dev(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
-                                        (uint8_t *)c->dSlots.p, stride, (uint32_t *)c->dLengths.p,
-                                        (uint8_t *)c->dPred.p, (int32_t *)c->dStatus.p, GF_PM_ALL);
+    s = encodeBatchDev(kind, c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
+                       (uint8_t *)c->dSlots.p, stride, (uint32_t *)c->dLengths.p, (uint8_t *)c->dPred.p,
+                       (int32_t *)c->dStatus.p, GF_PM_ALL);
     if (s != GF_OK) return s;
     std::vector<uint32_t> lengths(nTiles);
     std::vector<int32_t> st(nTiles);
@@ -545,15 +600,14 @@ gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, 
     for (size_t t = 0; t < nTiles; t++) {
         if (st[t] != GF_OVERFLOW) continue;
         anyBig = true;
-        const size_t maxp = gf_huffman_max_packing(nRows, nCols);
+        const size_t maxp = kind == KIND_CANON ? gf_canon_max_packing(nRows, nCols) : gf_huffman_max_packing(nRows, nCols);
         DevBuf slot, meta;
         if ((s = slot.ensure(maxp)) != GF_OK) return s;
         if ((s = meta.ensure(64)) != GF_OK) { slot.release(); return s; }
         uint32_t *dLen = (uint32_t *)meta.p;
         int32_t *dSt = (int32_t *)((uint8_t *)meta.p + 16);
-        s = gf_huffman_encode_batch_i32_dev(c, c->stream, codecIndex, nRows, nCols, 1,
-                                            (const int32_t *)c->dValues.p + t * cells, (uint8_t *)slot.p, maxp, dLen,
-                                            nullptr, dSt, GF_PM_ALL);
+        s = encodeBatchDev(kind, c, c->stream, codecIndex, nRows, nCols, 1, (const int32_t *)c->dValues.p + t * cells,
+                           (uint8_t *)slot.p, maxp, dLen, nullptr, dSt, GF_PM_ALL);
         if (s == GF_OK) {
             uint32_t l = 0;
             int32_t tst = 0;
@@ -609,8 +663,8 @@ gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, 
     return GF_OK;
 }
 
-gf_status gf_huffman_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
-                                      const uint64_t *offsets, int32_t *values, int32_t *status)
+static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                 const uint64_t *offsets, int32_t *values, int32_t *status)
 {
     if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
@@ -630,9 +684,9 @@ gf_status gf_huffman_decode_batch_i32(gf_context *c, int nRows, int nCols, size_
     GF_HIP(hipMemcpyAsync(c->dBlob.p, blob, total, hipMemcpyHostToDevice, c->stream));
     GF_HIP(hipMemcpyAsync(c->dOffsets.p, offsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
     GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
-    s = gf_huffman_decode_batch_i32_dev(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total,
-                                        (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p,
-                                        (int32_t *)c->dValues.p, (int32_t *)c->dStatus.p);
+    s = decodeBatchDev(kind, c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total,
+                       (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p, (int32_t *)c->dValues.p,
+                       (int32_t *)c->dStatus.p);
     if (s != GF_OK) return s;
     GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
     std::vector<int32_t> st(nTiles);
@@ -640,6 +694,55 @@ gf_status gf_huffman_decode_batch_i32(gf_context *c, int nRows, int nCols, size_
     GF_HIP(hipStreamSynchronize(c->stream));
     if (status) memcpy(status, st.data(), nTiles * 4);
     return GF_OK;
+}
+
+extern "C" {
+
+gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                      const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
+                                      uint8_t *predictors, int32_t *status)
+{
+    return encodeBatchHost(KIND_HUFFMAN, c, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, predictors, status);
+}
+
+gf_status gf_huffman_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                      const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    return decodeBatchHost(KIND_HUFFMAN, c, nRows, nCols, nTiles, blob, offsets, values, status);
+}
+
+gf_status gf_canon_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                    const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
+                                    uint8_t *predictors, int32_t *status)
+{
+    return encodeBatchHost(KIND_CANON, c, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, predictors, status);
+}
+
+gf_status gf_canon_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                    const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    return decodeBatchHost(KIND_CANON, c, nRows, nCols, nTiles, blob, offsets, values, status);
+}
+
+gf_status gf_canon_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, uint8_t *out,
+                              size_t outCap, size_t *outLen)
+{
+    if (!outLen) return GF_ERR_ARG;
+    uint64_t offsets[2] = {0, 0};
+    int32_t st = 0;
+    gf_status s = gf_canon_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, out, outCap, offsets, nullptr, &st);
+    *outLen = (size_t)offsets[1];
+    if (s != GF_OK) return s;
+    return (gf_status)st;
+}
+
+gf_status gf_canon_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values)
+{
+    uint64_t offsets[2] = {0, (uint64_t)len};
+    int32_t st = 0;
+    gf_status s = gf_canon_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
+    if (s != GF_OK) return s;
+    return (gf_status)st;
 }
 
 gf_status gf_huffman_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values,

@@ -1,0 +1,450 @@
+// gvrs_canon_encode.hip -- CodecCanonHuffman.encode (the default integer codec of current Gridfour) for a
+// batch of tiles on gfx950: one 256-thread workgroup per tile.
+//
+// Reference (core/src/main/java/org/gridfour/compress/canonicalHuffman/):
+//   CodecCanonHuffman.encode :70-143, compress :145-160  -- null / uniform shortcuts, predictors in the
+//       order Differencing, Linear, Triangle (DifferencingWithNulls alone when a null is present), the
+//       strictly shortest packing wins; 6-byte header codecIndex, predictor, seed LE
+//   CanonicalHuffman.encode :177-283, countSymbols :352-418, buildCodeLengthTree :285-343
+//   TreeBuilder, PackageMerge, LengthEncoder, HuffmanCodeBits (see gvrs_canon_common.h)
+//   the predictors' encodeInt (compress/PredictorModel*.java): same residual streams as their M32 forms
+//
+// Phases (same shape as gvrs_encode.hip):
+//   A  one flat pass over the tile, 8 cells per thread: residuals of the three predictors, their symbol
+//      classes, three 260-bin LDS histograms (4 replicas)
+//   B  one wave per predictor: cn_build() -> code table, serialised code tables, exact size
+//   C  the shortest candidate is packed: header + tables image, then the text -- per value its target
+//      symbol and, for values outside a byte, escape symbols with raw bits -- bit positions by a
+//      workgroup prefix sum, ORed into an LDS window that is flushed with coalesced stores
+
+#include <hip/hip_runtime.h>
+
+#include "gvrs_kernels.h"
+#include "gvrs_encode_layout.h"
+
+namespace {
+
+#include "gvrs_encode_common.h"
+#include "gvrs_canon_common.h"
+
+struct CanonPersist {
+    uint32_t hist[3][CN_HIST];
+    uint32_t tab[3][CN_HIST];
+    uint32_t img[3][CN_IMG_WORDS];
+    unsigned long long totalBits[3];
+    uint32_t imgBits[3];
+    uint32_t maxLen[3];
+    uint32_t maxKind[3];                        // largest escape kind seen (bounds the bits of one value)
+    uint32_t nGap[3];
+    int32_t model[3];
+    uint32_t seed;
+    uint32_t flags;                             // bit0 any null, bit1 any valid, bit2 some cell differs from cell 0
+    uint32_t waveSum[ENC_WAVES];
+    unsigned long long sumStart;
+    uint32_t nStart;
+};
+
+union CanonUnion {
+    uint32_t histR[3][CN_HIST * HIST_R];        // phase A
+    CanonScratch tree[3];                       // phase B
+    uint32_t win[WIN_WORDS + WIN_SLACK];        // phase C
+};
+
+// upper bound of the bits one value can take given the longest code and the largest escape kind
+__device__ __forceinline__ uint32_t cn_elem_max_bits(uint32_t maxLen, uint32_t maxKind)
+{
+    if (maxKind == 0u || maxKind == 7u) return maxLen;
+    if (maxKind <= 3u) return maxLen + maxKind * (maxLen + 2u);
+    return maxLen + 3u * (maxLen + 8u);
+}
+
+// stream elements [sBegin, sEnd) of `model`: the general packer (border segments, huge codes)
+__device__ void cpack_generic(int model, const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
+                              const uint32_t *tab, uint32_t elemMaxBits, uint32_t sBegin, uint32_t sEnd, uint32_t *win,
+                              uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t E = 4;
+    while (E > 1 && (uint64_t)ENC_THREADS * E * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u) E >>= 1;
+    uint32_t active = ENC_THREADS;
+    if ((uint64_t)ENC_THREADS * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u)
+        active = max(1u, (uint32_t)(((uint64_t)(WIN_WORDS - 2) * 32u) / elemMaxBits));
+    const uint32_t chunkElems = active * E;
+    for (uint32_t chunk = sBegin; chunk < sEnd; chunk += chunkElems) {
+        uint32_t xs[4];
+        uint32_t myBits = 0;
+        const uint32_t s0 = chunk + tid * E;
+        const uint32_t cEnd = min(sEnd, chunk + chunkElems);
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++) {
+            xs[e] = 0;
+            const uint32_t s = s0 + e;
+            if (e < E && tid < active && s < cEnd) {
+                const uint32_t idx = gf_stream_cell(model, nR, nC, s);
+                const uint32_t r = idx / nC, c = idx - r * nC;
+                xs[e] = cell_residual(model, tile, nC, idx, r, c, seed);
+                myBits += cn_value_bits(tab, xs[e]);
+            }
+        }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
+        if (myBits) {
+            BitSink sink;
+            sink.init(win, ps.bitBase + excl - ps.wordBase * 32u);
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                const uint32_t s = s0 + e;
+                if (e < E && tid < active && s < cEnd) cn_value_emit(sink, tab, xs[e]);
+            }
+            sink.finish();
+        }
+        __syncthreads();
+        ps.bitBase += total;
+        window_flush(win, out32, ps);
+    }
+}
+
+// the main segment of a model's stream = flat scan over the cells with an emit mask
+template <int MODEL>
+__device__ void cpack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                           const uint32_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                           PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t c0 = (tid * CPT) % nC;
+    const uint32_t cStep = STEP_CELLS % nC;
+    for (uint32_t base = 0; base < nCells; base += STEP_CELLS) {
+        const uint32_t i0 = base + tid * CPT;
+        uint32_t cl[CPT], xs[CPT];
+        uint32_t myBits = 0, wide = 0;
+        if (i0 < nCells) {
+            Cells8 Q;
+            load_cells8(tile, nC, nCells, i0, Q);
+            uint32_t c = c0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                bool emit;
+                const uint32_t x = flat_residual<MODEL>(Q, j, i0 + j, c, nC, nCells, seed, &emit);
+                const bool narrow = x + 128u < 256u;
+                const uint32_t e = emit ? (narrow ? tab[x + 128u] : 0u) : 0u;
+                cl[j] = e;
+                xs[j] = x;
+                myBits += e >> 16;
+                if (emit && !narrow) wide |= 1u << j;
+                if (++c == nC) c = 0;
+            }
+            if (wide) {                                               // values outside a byte (rare on terrain)
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if ((wide >> j) & 1u) myBits += cn_value_bits(tab, xs[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) { cl[j] = 0; xs[j] = 0; }
+        }
+        c0 += cStep;
+        if (c0 >= nC) c0 -= nC;
+
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
+        if (myBits) {
+            BitSink sink;
+            sink.init(win, ps.bitBase + excl - ps.wordBase * 32u);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                if ((wide >> j) & 1u) cn_value_emit(sink, tab, xs[j]);
+                else sink.put32(cl[j] & 0xffffu, cl[j] >> 16);
+            }
+            sink.finish();
+        }
+        __syncthreads();
+        ps.bitBase += total;
+        window_flush(win, out32, ps);
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_encode(GfEncodeArgs a)
+{
+    __shared__ CanonPersist P;
+    __shared__ CanonUnion S;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
+        uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
+
+        // ---------------- phase A: null / uniform scan + three histograms ----------------
+        for (int i = tid; i < 3 * CN_HIST * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
+        if (tid == 0) { P.flags = 0; P.sumStart = 0; P.nStart = 0; }
+        if (tid < 3) { P.maxKind[tid] = 0; P.model[tid] = 0; P.nGap[tid] = 0; }
+        __syncthreads();
+
+        const bool triOk = nR >= 2 && nC >= 2;
+        const uint32_t rep = (uint32_t)lane & (HIST_R - 1);
+        const uint32_t v0 = tile[0];
+        uint32_t myFlags = 0, mk1 = 0, mk2 = 0, mk3 = 0, gap1 = 0, gap2 = 0, gap3 = 0;
+        // all symbols of residual x into histogram h; returns the escape kind, counts the quirk values
+        auto addHist = [&](uint32_t *h, uint32_t x, uint32_t &gaps) -> uint32_t {
+            if (x + 128u < 256u) {
+                atomicAdd(h + (x + 128u) * HIST_R, 1u);
+                return 0u;
+            }
+            uint32_t kind;
+            const uint32_t target = cn_classify_count(x, &kind);
+            atomicAdd(h + target * HIST_R, 1u);
+            if (kind >= 1u && kind <= 3u) atomicAdd(h + CN_ESC2 * HIST_R, kind);
+            else if (kind >= 4u && kind <= 6u) atomicAdd(h + CN_ESC1 * HIST_R, kind - 3u);
+            if (cn_is_gap(x)) { gaps++; kind = 6u; }
+            return kind == 7u ? 0u : kind;
+        };
+        {
+            uint32_t *const h0 = &S.histR[0][rep], *const h1 = &S.histR[1][rep], *const h2 = &S.histR[2][rep];
+            uint32_t c0 = ((uint32_t)tid * CPT) % nC;
+            const uint32_t cStep = STEP_CELLS % nC;
+            for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
+                Cells8 Q;
+                load_cells8(tile, nC, nCells, i0, Q);
+                uint32_t c = c0;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint32_t idx = i0 + j;
+                    const uint32_t v = Q.cur[j];
+                    const bool real = idx < nCells;
+                    myFlags |= real ? (((v == GF_NULL_CODE) ? 1u : 2u) | (v != v0 ? 4u : 0u)) : 0u;
+                    const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+                    const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
+                    const uint32_t N = Q.up[j];
+                    const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+                    // the seed cell and the padding behind the tile count as residual 0; bin 128 is corrected below
+                    const bool counted = real && idx > 0;
+                    const uint32_t d = v - (c > 0 ? W : N);
+                    const uint32_t d1 = counted ? d : 0u;
+                    const uint32_t d2 = counted ? (c >= 2 ? v - (2u * W - WW) : d) : 0u;
+                    const uint32_t d3 = counted ? ((idx >= nC && c > 0) ? v - (W + N - NW) : d) : 0u;
+                    mk1 = max(mk1, addHist(h0, d1, gap1));
+                    mk2 = max(mk2, addHist(h1, d2, gap2));
+                    if (triOk) mk3 = max(mk3, addHist(h2, d3, gap3));
+                    if (++c == nC) c = 0;
+                }
+                c0 += cStep;
+                if (c0 >= nC) c0 -= nC;
+            }
+        }
+        if (myFlags) atomicOr(&P.flags, myFlags);
+        if (mk1) atomicMax(&P.maxKind[0], mk1);
+        if (mk2) atomicMax(&P.maxKind[1], mk2);
+        if (mk3) atomicMax(&P.maxKind[2], mk3);
+        if (gap1) atomicAdd(&P.nGap[0], gap1);
+        if (gap2) atomicAdd(&P.nGap[1], gap2);
+        if (gap3) atomicAdd(&P.nGap[2], gap3);
+        __syncthreads();
+        const uint32_t flags = P.flags;
+        const bool anyNull = flags & 1u, anyValid = flags & 2u, varied = flags & 4u;
+        uint32_t forcedZeros = ((nCells + CPT - 1) / CPT) * CPT - nCells + 1u;
+
+        int32_t early = 99;
+        if (!anyValid) early = GF_K_DECLINED;                                  // CodecCanonHuffman.java:85-87 -> null
+        else if (!varied) early = GF_K_OK;                                     // uniform shortcut :89-110
+        else if (4ull * nCells + 8ull >= (1ull << 22)) early = GF_K_ERR_UNSUPPORTED;   // 22-bit counts in the tree keys
+        else if (!anyNull && nC < 2 && (a.predictorMask & 2)) early = GF_K_ERR_BOUNDS;  // Linear: values[1] AIOOBE
+        else if (!anyNull && !triOk && (a.predictorMask & 4)) early = GF_K_ERR_ARG;     // Triangle -1 -> encode throws :183
+        if (early != 99) {
+            if (tid == 0) {
+                uint32_t n = 0;
+                if (early == GF_K_OK) {
+                    if (a.slotStride >= 8) {
+                        out32[0] = ((uint32_t)a.codecIndex & 0xffu) | (v0 << 16);
+                        out32[1] = v0 >> 16;
+                        n = 6;
+                    } else {
+                        early = GF_K_OVERFLOW;
+                        n = 6;
+                    }
+                }
+                a.lengths[t] = n;
+                a.status[t] = early;
+                if (a.predictors) a.predictors[t] = 0;
+            }
+            __syncthreads();
+            continue;
+        }
+
+        if (anyNull) {
+            // ---- nulls path: seed (PredictorModelDifferencingWithNulls.java:181-208), then one histogram ----
+            forcedZeros = 0;
+            for (int i = tid; i < 3 * CN_HIST * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
+            long long mySum = 0;
+            uint32_t myCnt = 0;
+            for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
+                const uint32_t v = tile[idx];
+                if (v == GF_NULL_CODE) continue;
+                const uint32_t r = idx / nC, c = idx - r * nC;
+                bool flag;
+                if (c > 0) flag = tile[idx - 1] == GF_NULL_CODE;
+                else flag = r == 0 ? true : tile[idx - nC] == GF_NULL_CODE;
+                if (flag) { mySum += (int32_t)v; myCnt++; }
+            }
+            if (myCnt) {
+                atomicAdd(&P.sumStart, (unsigned long long)mySum);
+                atomicAdd(&P.nStart, myCnt);
+            }
+            if (tid < 3) { P.maxKind[tid] = 0; P.nGap[tid] = 0; }
+            __syncthreads();
+            if (tid == 0) {
+                const double avg = (double)(long long)P.sumStart / (double)P.nStart;
+                double f = floor(avg + 0.5);
+                int32_t s;
+                if (f >= 2147483647.0) s = 2147483647;
+                else if (f <= -2147483648.0) s = (int32_t)0x80000000;
+                else s = (int32_t)f;
+                P.seed = (uint32_t)s;
+                P.model[0] = (a.predictorMask & 8) ? 4 : 0;
+                P.model[1] = 0;
+                P.model[2] = 0;
+            }
+            __syncthreads();
+            const uint32_t seed = P.seed;
+            uint32_t mk = 0, gaps = 0;
+            for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
+                const uint32_t r = idx / nC, c = idx - r * nC;
+                const uint32_t x = cell_residual(4, tile, nC, idx, r, c, seed);
+                mk = max(mk, addHist(&S.histR[0][rep], x, gaps));
+            }
+            if (mk) atomicMax(&P.maxKind[0], mk);
+            if (gaps) atomicAdd(&P.nGap[0], gaps);
+            __syncthreads();
+        } else if (tid == 0) {
+            P.seed = v0;
+            P.model[0] = (a.predictorMask & 1) ? 1 : 0;
+            P.model[1] = (a.predictorMask & 2) ? 2 : 0;
+            P.model[2] = ((a.predictorMask & 4) && triOk) ? 3 : 0;
+        }
+
+        // reduce the replicas; the end-of-text symbol counts 1 (CanonicalHuffman.java:355)
+        for (int i = tid; i < 3 * CN_HIST; i += ENC_THREADS) {
+            const int p = i / CN_HIST, s = i - p * CN_HIST;
+            const uint32_t *h = &S.histR[p][0] + (size_t)s * HIST_R;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < HIST_R; k++) sum += h[k];
+            if (s == 128 && sum >= forcedZeros) sum -= forcedZeros;
+            if (s == CN_EOT) sum = 1;
+            if (s >= CN_SYMS) sum = 0;
+            P.hist[p][s] = sum;
+        }
+        for (int i = tid; i < 3 * CN_IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
+        __syncthreads();                         // histR dead from here: S.tree may be written
+
+        // ---------------- phase B: code tables of the candidates, one wave each ----------------
+        if (wave < 3 && P.model[wave] != 0) {
+            const int p = wave;
+            const CanonBuilt B = cn_build(S.tree[p], P.hist[p], P.nGap[p], P.tab[p], P.img[p], lane);
+            if (lane == 0) {
+                P.imgBits[p] = B.imgBits;
+                P.maxLen[p] = B.maxLen;
+                P.totalBits[p] = 48ull + B.imgBits + B.textBits;
+            }
+        }
+        __syncthreads();                         // trees dead from here: S.win may be written
+
+        // ---------------- phase C: pick the shortest, pack it ----------------
+        int best = -1;
+        uint64_t bestBytes = ~0ull;
+        for (int p = 0; p < 3; p++) {
+            if (P.model[p] == 0) continue;
+            const uint64_t bytes = (P.totalBits[p] + 7) >> 3;
+            if (bytes < bestBytes) { bestBytes = bytes; best = p; }          // strict: CodecCanonHuffman.java:133
+        }
+        if (best < 0) {
+            if (tid == 0) {
+                a.lengths[t] = 0;
+                a.status[t] = GF_K_DECLINED;
+                if (a.predictors) a.predictors[t] = 0;
+            }
+            __syncthreads();
+            continue;
+        }
+        const int model = P.model[best];
+        if (tid == 0) {
+            a.lengths[t] = (uint32_t)min(bestBytes, (uint64_t)0xffffffffu);
+            a.status[t] = bestBytes > a.slotStride ? GF_K_OVERFLOW : GF_K_OK;
+            if (a.predictors) a.predictors[t] = (uint8_t)model;
+        }
+        if (bestBytes > a.slotStride) { __syncthreads(); continue; }
+
+        // header (6 bytes = 48 bits) + code tables image shifted behind it
+        const uint32_t seed = P.seed;
+        const uint32_t imgBits = P.imgBits[best];
+        const uint32_t headEnd = 48u + imgBits;
+        const uint32_t headWords = (headEnd + 31u) >> 5;
+        for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) {
+            uint32_t w = 0;
+            if (i < (int)headWords) {
+                // image bit b lives at packing bit 48 + b: word i takes image bits [32 i - 48, 32 i - 16)
+                const uint32_t *img = P.img[best];
+                if (i == 0) w = ((uint32_t)a.codecIndex & 0xffu) | ((uint32_t)model << 8) | (seed << 16);
+                else if (i == 1) w = (seed >> 16) | (img[0] << 16);
+                else {
+                    const uint32_t lo = img[i - 2], hi = i - 1 < CN_IMG_WORDS ? img[i - 1] : 0u;
+                    w = (lo >> 16) | (hi << 16);
+                }
+            }
+            S.win[i] = w;
+        }
+        __syncthreads();
+
+        const uint32_t nStream = gf_stream_len(model, nR, nC);
+        const uint32_t *tab = P.tab[best];
+        const uint32_t elemMaxBits = max(1u, cn_elem_max_bits(P.maxLen[best], P.maxKind[best]));
+        PackState ps;
+        ps.bitBase = headEnd;
+        ps.wordBase = 0;
+        window_flush(S.win, out32, ps);
+        if (nStream > 0) {
+            const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
+            if (!fast) {
+                cpack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, S.win, out32, P.waveSum, ps);
+            } else if (model == 1) {
+                cpack_flat<1>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+            } else if (model == 2) {
+                cpack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, S.win, out32, P.waveSum, ps);
+                cpack_flat<2>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+            } else if (model == 3) {
+                cpack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, S.win, out32, P.waveSum, ps);
+                cpack_flat<3>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+            } else {
+                cpack_flat<4>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+            }
+        }
+        // end-of-text symbol (CanonicalHuffman.java:278), then the tail of the window
+        if (tid == 0) {
+            const uint32_t e = tab[CN_EOT];
+            BitSink sink;
+            sink.init(S.win, ps.bitBase - ps.wordBase * 32u);
+            sink.put32(e & 0xffffu, e >> 16);
+            sink.finish();
+        }
+        ps.bitBase += tab[CN_EOT] >> 16;
+        __syncthreads();
+        {
+            const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
+            const uint32_t remWords = (remBits + 31u) >> 5;
+            const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
+            for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
+                if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = S.win[j];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream)
+{
+    if (a.nTiles == 0) return hipSuccess;
+    const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
+    hipLaunchKernelGGL(k_canon_encode, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    return hipGetLastError();
+}

@@ -69,30 +69,7 @@ struct DecShared {
     uint32_t dense;                            // M32 stream too dense in multi-byte values for local start resolution
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
-{
-    (void)lane;
-    return gf_wave_incl_scan(v);
-}
-
-// exclusive scan over the workgroup (two barriers); *total = sum over all threads
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *waveSum, uint32_t *total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t incl = wave_incl_scan(v, lane);
-    if (lane == 63) waveSum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < DEC_WAVES; w++) {
-        const uint32_t s = waveSum[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    __syncthreads();
-    *total = tot;
-    return base + incl - v;
-}
+#include "gvrs_decode_common.h"
 
 // ---- cursors: sequential readers of the two variable-length layers ----
 
@@ -407,52 +384,12 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
     return status;
 }
 
-__device__ __forceinline__ uint32_t stream_cell_fast(int model, uint32_t nR, uint32_t nC, uint32_t k, uint32_t magic,
-                                                     bool useMagic)
-{
-    // cell of stream element k; the row/column split of the main segment uses a multiply-high
-    // reciprocal (exact while t * w < 2^32) instead of an integer division
-    uint32_t t, w, rowBase, colBase;
-    if (model == 1) return k + 1u;
-    if (model == 4) return k;
-    if (model == 2) {
-        if (k == 0) return 1u;
-        const uint32_t seedLen = 2u * nR - 1u;
-        if (k < seedLen) {
-            const uint32_t u = k - 1u;
-            return (1u + (u >> 1)) * nC + (u & 1u);
-        }
-        t = k - seedLen;
-        w = nC - 2u;
-        rowBase = 0u;
-        colBase = 2u;
-    } else {
-        if (k < nC - 1u) return k + 1u;
-        t = k - (nC - 1u);
-        if (t < nR - 1u) return (t + 1u) * nC;
-        t -= nR - 1u;
-        w = nC - 1u;
-        rowBase = 1u;
-        colBase = 1u;
-    }
-    const uint32_t r = useMagic ? __umulhi(t, magic) : t / w;
-    return (r + rowBase) * nC + colBase + (t - r * w);
-}
-
-// wave-wide inclusive scan of one row segment with carry; returns the new carry
-__device__ __forceinline__ uint32_t row_scan_segment(uint32_t x, uint32_t carry, int lane, uint32_t *outv)
-{
-    const uint32_t incl = wave_incl_scan(x, lane) + carry;
-    *outv = incl;
-    return __shfl(incl, 63, 64);
-}
 
 #define GF_DSTAMP(i)                                                                   \
     do {                                                                               \
         if (a.debug && tid == 0) (a.debug + t * 16)[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
     } while (0)
 
-constexpr int ROW_BATCH = 4;                    // rows a wave keeps in flight in the row scans
 
 __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
 {
@@ -861,118 +798,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
         if (a.phaseLimit == 3) continue;
 
         // ---------------- phase 3: predictor inverse (wrap-around prefix sums) ----------------
-        if (model != 4) {
-            // Triangle: column sums of the interior residuals first (needs row 0 still as residuals)
-            if (model == 3) {
-                for (uint32_t c = 1 + tid; c < nC; c += DEC_THREADS) {
-                    uint32_t acc = o[c];
-                    for (uint32_t r = 1; r < nR; r += 8) {
-                        uint32_t x[8];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) x[j] = r + j < nR ? o[(size_t)(r + j) * nC + c] : 0u;
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            acc += x[j];
-                            if (r + j < nR) o[(size_t)(r + j) * nC + c] = acc;
-                        }
-                    }
-                }
-            }
-            // column 0 chain: o[r][0] = seed + sum of the column-0 residuals (all three models)
-            if (wave == 0) {
-                uint32_t carry = seed;
-                if (lane == 0) o[0] = seed;
-                for (uint32_t r0 = 1; r0 < nR; r0 += 64) {
-                    const uint32_t r = r0 + lane;
-                    const uint32_t x = r < nR ? o[(size_t)r * nC] : 0u;
-                    uint32_t v;
-                    carry = row_scan_segment(x, carry, lane, &v);
-                    if (r < nR) o[(size_t)r * nC] = v;
-                }
-            }
-            __syncthreads();
-            GF_DSTAMP(9);
-            // rows: each wave keeps ROW_BATCH rows in flight
-            for (uint32_t rb = (uint32_t)wave * ROW_BATCH; rb < nR; rb += DEC_WAVES * ROW_BATCH) {
-                uint32_t carryV[ROW_BATCH], carryD[ROW_BATCH];
-                uint32_t cStart = 1;
-#pragma unroll
-                for (int b = 0; b < ROW_BATCH; b++) {
-                    const uint32_t r = rb + b;
-                    carryV[b] = 0;
-                    carryD[b] = 0;
-                    if (r < nR) {
-                        uint32_t *row = o + (size_t)r * nC;
-                        if (model == 2) {
-                            // second column, then c[k] = 2b - a + res  <=>  first differences are a running sum
-                            const uint32_t a0 = row[0];
-                            const uint32_t b0 = row[1] + a0;            // residual of (r,1) is relative to (r,0)
-                            __builtin_amdgcn_wave_barrier();
-                            if (lane == 0) row[1] = b0;
-                            carryD[b] = b0 - a0;
-                            carryV[b] = b0;
-                        } else {
-                            carryV[b] = row[0];
-                        }
-                    }
-                }
-                if (model == 2) cStart = 2;
-                for (uint32_t c0 = cStart; c0 < nC; c0 += 64) {
-                    const uint32_t c = c0 + lane;
-                    uint32_t x[ROW_BATCH];
-#pragma unroll
-                    for (int b = 0; b < ROW_BATCH; b++) x[b] = (rb + b < nR && c < nC) ? o[(size_t)(rb + b) * nC + c] : 0u;
-#pragma unroll
-                    for (int b = 0; b < ROW_BATCH; b++) {
-                        uint32_t v;
-                        if (model == 2) {
-                            uint32_t d;
-                            carryD[b] = row_scan_segment(x[b], carryD[b], lane, &d);
-                            carryV[b] = row_scan_segment(c < nC ? d : 0u, carryV[b], lane, &v);
-                        } else {
-                            carryV[b] = row_scan_segment(x[b], carryV[b], lane, &v);
-                        }
-                        if (rb + b < nR && c < nC) o[(size_t)(rb + b) * nC + c] = v;
-                    }
-                }
-            }
-        } else {
-            // PredictorModelDifferencingWithNulls.java:137-166: column 0 first (row starts depend on the
-            // first cell of the previous row), then every row on its own
-            if (wave == 0) {
-                // wave-uniform scalar loop (all lanes hold the same state; lane 0 stores)
-                uint32_t prior = seed;
-                bool nullFlag = true;
-                for (uint32_t r = 0; r < nR; r++) {
-                    const uint32_t test = GF_UNI(o[(size_t)r * nC]);
-                    uint32_t first = GF_NULL_CODE;
-                    if (test != GF_NULL_CODE) {
-                        first = (nullFlag ? seed : prior) + test;
-                        if (lane == 0) o[(size_t)r * nC] = first;
-                    }
-                    // row start of the next row: prior = first cell of this row, flag by VALUE (:162-163)
-                    prior = first;
-                    nullFlag = first == GF_NULL_CODE;
-                }
-            }
-            __syncthreads();
-            for (uint32_t r = tid; r < nR; r += DEC_THREADS) {
-                uint32_t *row = o + (size_t)r * nC;
-                uint32_t prior = row[0];
-                // inside a row the flag follows the residual just decoded; (r,0) was null iff its value is
-                bool nullFlag = prior == GF_NULL_CODE;
-                for (uint32_t c = 1; c < nC; c++) {
-                    const uint32_t test = row[c];
-                    if (test == GF_NULL_CODE) {
-                        nullFlag = true;
-                    } else {
-                        if (nullFlag) { nullFlag = false; prior = seed; }
-                        prior += test;
-                        row[c] = prior;
-                    }
-                }
-            }
-        }
+        gf_predictor_inverse(model, seed, o, nR, nC, a.debug ? a.debug + t * 16 + 9 : nullptr);
         GF_DSTAMP(10);
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();

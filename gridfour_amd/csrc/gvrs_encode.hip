@@ -31,14 +31,8 @@
 
 namespace {
 
-constexpr int ENC_THREADS = GF_ENC_THREADS;
-constexpr int ENC_WAVES = GF_ENC_WAVES;
-constexpr int HIST_R = 4;                       // histogram replicas
-constexpr int IMG_WORDS = GF_IMG_WORDS;
-constexpr int WIN_WORDS = 4096;                 // bit-pack window (16 KB)
-constexpr int WIN_SLACK = 8;
-constexpr int CPT = 8;                          // cells per thread per step of the flat scans
-constexpr uint32_t STEP_CELLS = ENC_THREADS * CPT;
+#include "gvrs_encode_common.h"
+
 
 union EncScratch {
     uint32_t histR[3][256 * HIST_R];            // phase A
@@ -46,89 +40,6 @@ union EncScratch {
     uint32_t win[WIN_WORDS + WIN_SLACK];        // phase C
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
-{
-    (void)lane;
-    return gf_wave_incl_scan(v);
-}
-
-// exclusive scan over the workgroup; *total = sum over all threads
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *waveSum, uint32_t *total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = wave_incl_scan(v, lane);
-    if (lane == 63) waveSum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < ENC_WAVES; w++) {
-        uint32_t s = waveSum[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    __syncthreads();
-    *total = tot;
-    return base + incl - v;
-}
-
-// residual of one cell for a model (generic form, used by the border segments and fallbacks)
-__device__ __forceinline__ uint32_t cell_residual(int model, const uint32_t *__restrict__ tile, uint32_t nC,
-                                                  uint32_t idx, uint32_t r, uint32_t c, uint32_t seed)
-{
-    const uint32_t v = tile[idx];
-    switch (model) {
-    case 1: return v - (c > 0 ? tile[idx - 1] : tile[idx - nC]);
-    case 2:
-        if (c >= 2) return v - (2u * tile[idx - 1] - tile[idx - 2]);
-        return v - (c == 1 ? tile[idx - 1] : tile[idx - nC]);
-    case 3:
-        if (r == 0) return v - tile[idx - 1];
-        if (c == 0) return v - tile[idx - nC];
-        return v - (tile[idx - 1] + tile[idx - nC] - tile[idx - nC - 1]);
-    default: {
-        // PredictorModelDifferencingWithNulls.java:109-131: prior = left neighbour, or the
-        // first cell of the previous row at a row start; the seed replaces a null prior.
-        if (v == GF_NULL_CODE) return GF_NULL_CODE;
-        uint32_t prior;
-        if (c > 0) prior = tile[idx - 1];
-        else prior = r > 0 ? tile[idx - nC] : GF_NULL_CODE;
-        if (prior == GF_NULL_CODE) prior = seed;
-        return v - prior;
-    }
-    }
-}
-
-// 8 consecutive cells starting at flat index i0 plus what their predictors need
-struct Cells8 {
-    uint32_t cur[CPT], up[CPT], wm1, wm2, upm1;
-};
-
-__device__ __forceinline__ void load_cells8(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells,
-                                            uint32_t i0, Cells8 &Q)
-{
-    if (i0 >= nC + 2 && i0 + (CPT - 1) < nCells) {       // interior: every word exists
-        const GfU4 a = *reinterpret_cast<const GfU4 *>(tile + i0);
-        const GfU4 b = *reinterpret_cast<const GfU4 *>(tile + i0 + 4);
-        const GfU4 c = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC));
-        const GfU4 d = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC) + 4);
-        Q.wm1 = tile[i0 - 1];
-        Q.wm2 = tile[i0 - 2];
-        Q.upm1 = tile[i0 - nC - 1];
-        Q.cur[0] = a.x; Q.cur[1] = a.y; Q.cur[2] = a.z; Q.cur[3] = a.w;
-        Q.cur[4] = b.x; Q.cur[5] = b.y; Q.cur[6] = b.z; Q.cur[7] = b.w;
-        Q.up[0] = c.x; Q.up[1] = c.y; Q.up[2] = c.z; Q.up[3] = c.w;
-        Q.up[4] = d.x; Q.up[5] = d.y; Q.up[6] = d.z; Q.up[7] = d.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < CPT; j++) {
-            Q.cur[j] = i0 + j < nCells ? tile[i0 + j] : 0u;
-            Q.up[j] = (i0 + j >= nC && i0 + j < nCells) ? tile[i0 + j - nC] : 0u;
-        }
-        Q.wm1 = (i0 >= 1 && i0 - 1 < nCells) ? tile[i0 - 1] : 0u;
-        Q.wm2 = (i0 >= 2 && i0 - 2 < nCells) ? tile[i0 - 2] : 0u;
-        Q.upm1 = (i0 >= nC + 1 && i0 - nC - 1 < nCells) ? tile[i0 - nC - 1] : 0u;
-    }
-}
 
 // first M32 byte of residual x and whether it is the whole encoding (CodecM32.java:257-283)
 __device__ __forceinline__ uint32_t m32_first_byte(uint32_t x, bool *single)
@@ -140,38 +51,6 @@ __device__ __forceinline__ uint32_t m32_first_byte(uint32_t x, bool *single)
     return one ? (isNull ? 0x80u : (x & 0xffu)) : intro;
 }
 
-// Bitonic sort, ascending, of the 64*NREG 32-bit keys held in k[0..NREG) (element e = r*64 + lane).
-template <int NREG>
-__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&k)[4], int lane)
-{
-#pragma unroll
-    for (int size = 2; size <= 64 * NREG; size <<= 1) {
-#pragma unroll
-        for (int j = size >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                const int rj = j >> 6;           // partner lives in another register of the same lane
-#pragma unroll
-                for (int r = 0; r < NREG; r++) {
-                    if ((r & rj) == 0) {
-                        const int r2 = r | rj;
-                        const bool asc = ((r * 64) & size) == 0;
-                        const uint32_t lo = min(k[r], k[r2]), hi = max(k[r], k[r2]);
-                        k[r] = asc ? lo : hi;
-                        k[r2] = asc ? hi : lo;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < NREG; r++) {
-                    const uint32_t other = (uint32_t)__shfl_xor((int)k[r], j, 64);
-                    const bool asc = (((r * 64) | lane) & size) == 0;
-                    const bool lower = (lane & j) == 0;
-                    k[r] = (lower == asc) ? min(k[r], other) : max(k[r], other);
-                }
-            }
-        }
-    }
-}
 
 // Huffman tree of one predictor by data-parallel rounds (one wave).  K holds the live nodes in
 // list order as keys (count << 9 | tie), 4 per lane, dead slots = 0xFFFFFFFF.  Each round pairs up
@@ -234,96 +113,8 @@ __device__ __forceinline__ void wave_huff_rounds(GfHuffTree &T, uint32_t (&K)[4]
                 (uint32_t)__builtin_amdgcn_s_memtime();                                   \
     } while (0)
 
-struct BitSink {
-    uint32_t *win;
-    uint64_t acc;
-    uint32_t nacc;      // valid bits in acc (< 32 between puts)
-    uint32_t wp;        // window word the low bits of acc belong to
-    bool first;         // the first word is shared with the previous thread
 
-    __device__ __forceinline__ void init(uint32_t *w, uint32_t bitPos)
-    {
-        win = w;
-        wp = bitPos >> 5;
-        nacc = bitPos & 31u;
-        acc = 0;
-        first = true;
-    }
-    __device__ __forceinline__ void flushWord()
-    {
-        uint32_t lo = (uint32_t)acc;
-        if (first) { atomicOr(&win[wp], lo); first = false; }
-        else win[wp] = lo;
-        wp++;
-        acc >>= 32;
-        nacc -= 32;
-    }
-    // len <= 32; (code, len) = (0, 0) is a no-op
-    __device__ __forceinline__ void put32(uint32_t code, uint32_t len)
-    {
-        acc |= (uint64_t)code << nacc;
-        nacc += len;
-        if (nacc >= 32) flushWord();
-    }
-    __device__ __forceinline__ void put(uint64_t code, uint32_t len)
-    {
-        if (len > 32) {
-            put32((uint32_t)code, 32);
-            put32((uint32_t)(code >> 32), len - 32);
-        } else {
-            put32((uint32_t)code, len);
-        }
-    }
-    __device__ __forceinline__ void finish()
-    {
-        if (nacc > 0) atomicOr(&win[wp], (uint32_t)acc);
-    }
-};
 
-// residual and emit mask of cell j of a Cells8 block for one model (flat-scan form)
-template <int MODEL>
-__device__ __forceinline__ uint32_t flat_residual(const Cells8 &Q, int j, uint32_t idx, uint32_t c, uint32_t nC,
-                                                  uint32_t nCells, uint32_t seed, bool *emit)
-{
-    const uint32_t v = Q.cur[j];
-    const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
-    if (MODEL == 1) {
-        *emit = idx >= 1 && idx < nCells;
-        return v - (c > 0 ? W : Q.up[j]);                               // PredictorModelDifferencing.java:120-137
-    } else if (MODEL == 2) {
-        const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
-        *emit = c >= 2 && idx < nCells;
-        return v - (2u * W - WW);                                       // PredictorModelLinear.java:128-141
-    } else if (MODEL == 3) {
-        const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
-        *emit = idx >= nC && c >= 1 && idx < nCells;
-        return v - (W + Q.up[j] - NW);                                  // PredictorModelTriangle.java:130-142
-    } else {
-        *emit = idx < nCells;
-        uint32_t prior = c > 0 ? W : (idx >= nC ? Q.up[j] : GF_NULL_CODE);
-        if (prior == GF_NULL_CODE) prior = seed;                        // ...DifferencingWithNulls.java:109-131
-        return v == GF_NULL_CODE ? GF_NULL_CODE : v - prior;
-    }
-}
-
-struct PackState {
-    uint32_t bitBase;    // next free bit of the packing (absolute)
-    uint32_t wordBase;   // words already flushed to the output slot
-};
-
-// moves the completed words of the window to the output slot and slides the window
-// (call after a barrier that ends the emission into the window)
-__device__ __forceinline__ void window_flush(uint32_t *win, uint32_t *__restrict__ out32, PackState &ps)
-{
-    const uint32_t tid = threadIdx.x;
-    const uint32_t fullWords = (ps.bitBase >> 5) - ps.wordBase;
-    for (uint32_t j = tid; j < fullWords; j += ENC_THREADS) out32[ps.wordBase + j] = win[j];
-    const uint32_t partial = win[fullWords];
-    __syncthreads();
-    for (uint32_t j = tid; j <= fullWords; j += ENC_THREADS) win[j] = j == 0 ? partial : 0u;
-    ps.wordBase += fullWords;
-    __syncthreads();
-}
 
 // stream elements [sBegin, sEnd) of `model`, any residual size: the general (slow) packer
 __device__ void pack_generic(int model, const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,

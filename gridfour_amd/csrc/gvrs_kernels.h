@@ -12,6 +12,8 @@
 #define GF_K_OVERFLOW 2
 #define GF_K_ERR_FORMAT (-1)
 #define GF_K_ERR_BOUNDS (-2)
+#define GF_K_ERR_ARG (-4)
+#define GF_K_ERR_UNSUPPORTED (-7)
 
 struct GfEncodeArgs {
     const int32_t *values;     // nTiles * nRows*nCols
@@ -51,6 +53,11 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
 unsigned gf_huffman_decode_grid(size_t nTiles);
 uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols);
 uint32_t gf_huffman_decode_lds_text(int nRows, int nCols);
+
+// CodecCanonHuffman (gvrs_canon_encode.hip / gvrs_canon_decode.hip); same argument blocks as the legacy codec
+hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
+hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
+uint32_t gf_canon_decode_lds_text(int nRows, int nCols);
 
 hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStride,
                              const uint32_t *lengths, uint64_t *offsets, uint8_t *blob,

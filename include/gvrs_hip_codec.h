@@ -140,6 +140,32 @@ gf_status gf_compact_dev(gf_context *ctx, void *stream, size_t n_tiles, const ui
                          size_t slot_stride, const uint32_t *d_lengths, uint64_t *d_offsets,
                          uint8_t *d_blob, size_t blob_cap);
 
+/* ---- CodecCanonHuffman (compress/canonicalHuffman/CodecCanonHuffman.java:70-195), the default integer
+ * codec of current Gridfour (gvrs/GvrsFileSpecification.java:229): same predictors, integer residuals coded
+ * with the 260-symbol canonical Huffman stage (CanonicalHuffman.java:177-283, 441-519), 6-byte header
+ * codec_index, predictor, seed LE; uniform tiles pack to 6 bytes with predictor 0 (:95-110).
+ * Same calling conventions, layouts and statuses as the gf_huffman_* entry points; additionally
+ * GF_ERR_ARG where the Java encoder throws IllegalArgumentException (Triangle on a one-row tile, :183)
+ * and GF_ERR_UNSUPPORTED for tiles of 2^20 cells or more.                                             */
+size_t gf_canon_max_packing(int n_rows, int n_cols);
+gf_status gf_canon_encode_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols, const int32_t *values,
+                              uint8_t *out, size_t out_cap, size_t *out_len);
+gf_status gf_canon_decode_i32(gf_context *ctx, int n_rows, int n_cols, const uint8_t *packing, size_t packing_len,
+                              int32_t *values);
+gf_status gf_canon_encode_batch_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                    const int32_t *values, uint8_t *blob, size_t blob_cap, uint64_t *offsets,
+                                    uint8_t *predictors, int32_t *status);
+gf_status gf_canon_decode_batch_i32(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                    const uint64_t *offsets, int32_t *values, int32_t *status);
+gf_status gf_canon_encode_batch_i32_dev(gf_context *ctx, void *stream, int codec_index, int n_rows, int n_cols,
+                                        size_t n_tiles, const int32_t *d_values, uint8_t *d_out, size_t slot_stride,
+                                        uint32_t *d_lengths, uint8_t *d_predictors, int32_t *d_status,
+                                        int predictor_mask);
+gf_status gf_canon_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                        const uint8_t *d_blob, size_t blob_bytes, const uint64_t *d_offsets,
+                                        size_t slot_stride, const uint32_t *d_lengths, int32_t *d_values,
+                                        int32_t *d_status);
+
 /* ---- CodecFloat (compress/CodecFloat.java:328-458): float32 tiles ---------------------------
  * The five byte planes (sign bits, exponent, three byte-delta coded mantissa bytes) are split and
  * merged on the GPU; the Deflate stage of each plane runs on the host's zlib (its bytes are defined

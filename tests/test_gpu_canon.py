@@ -1,0 +1,165 @@
+"""GPU parity tests of the CodecCanonHuffman path (gf_canon_* of the C ABI) against the CPU oracle
+(oracle/gvrs_oracle_canon.c), bit for bit.  The oracle itself is unpinned for this codec (no reference
+fixture holds canonical-Huffman bytes)."""
+import numpy as np
+import pytest
+
+import oracle
+from tilegen import KINDS, NULL, add_nulls, make_tile
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(10, 10), (2, 2), (7, 9), (1, 2), (1, 37), (33, 65), (120, 150), (200, 200), (3, 2), (64, 64), (5, 300), (9, 1)]
+
+
+@pytest.fixture(scope="module")
+def codec():
+    import gridfour_amd
+    return gridfour_amd.CodecCanonHuffmanHip()
+
+
+def _check_tiles(codec, n_rows, n_cols, tiles, codec_index=3):
+    packs, preds, status = codec.encode_batch(codec_index, n_rows, n_cols, tiles)
+    for t, v in enumerate(tiles):
+        try:
+            ref, used = oracle.codec_canon_encode(codec_index, n_rows, n_cols, v)
+        except ValueError as ex:
+            want = -2 if "rc=-2" in str(ex) else -4      # AIOOBE (Linear, 1 column) / IllegalArgument (Triangle, 1 row)
+            assert packs[t] is None and status[t] == want, (t, status[t], str(ex))
+            continue
+        if ref is None:
+            assert packs[t] is None and status[t] == 1, (t, status[t])
+            continue
+        assert status[t] == 0, (t, status[t])
+        assert preds[t] == used, ("predictor", t, preds[t], used)
+        assert len(packs[t]) == len(ref), ("length", t, len(packs[t]), len(ref), used)
+        if packs[t] != ref:
+            first = next(i for i in range(len(ref)) if packs[t][i] != ref[i])
+            raise AssertionError("tile %d differs at byte %d of %d (model %d): got %s want %s" % (
+                t, first, len(ref), used, packs[t][first:first + 8].hex(), ref[first:first + 8].hex()))
+    good = [p for p in packs if p is not None]
+    if not good:
+        return
+    vals, st = codec.decode_batch(n_rows, n_cols, good)
+    k = 0
+    for t, v in enumerate(tiles):
+        if packs[t] is None:
+            continue
+        assert st[k] == 0, (t, st[k])
+        want = oracle.codec_canon_decode(n_rows, n_cols, packs[t])      # == v except for the reference's range quirk
+        if not np.array_equal(vals[k], want):
+            bad = np.nonzero(vals[k] != want)[0]
+            raise AssertionError("decode of tile %d (model %d) differs at %d cells, first %d: got %d want %d" % (
+                t, preds[t], bad.size, bad[0], vals[k][bad[0]], want[bad[0]]))
+        k += 1
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%d" % s)
+def test_encode_decode_parity_kinds(codec, shape):
+    n_rows, n_cols = shape
+    tiles = np.stack([make_tile(k, n_rows, n_cols) for k in KINDS])
+    _check_tiles(codec, n_rows, n_cols, tiles)
+
+
+@pytest.mark.parametrize("shape", [(10, 10), (6, 17), (1, 9), (9, 1), (120, 150), (50, 50)], ids=lambda s: "%dx%d" % s)
+def test_nulls_parity(codec, shape):
+    n_rows, n_cols = shape
+    tiles = []
+    for frac, blocks in ((0.02, False), (0.3, False), (0.9, False), (0.2, True)):
+        tiles.append(add_nulls(make_tile("smooth", n_rows, n_cols), n_rows, n_cols, frac, blocks=blocks))
+    v = make_tile("smooth", n_rows, n_cols)
+    v[0] = NULL
+    tiles.append(v)
+    v = make_tile("ramp", n_rows, n_cols)
+    v[::n_cols] = NULL
+    tiles.append(v)
+    tiles.append(np.full(n_rows * n_cols, NULL, np.int32))
+    _check_tiles(codec, n_rows, n_cols, np.stack(tiles))
+
+
+def test_escape_classes_and_quirk(codec):
+    # every escape class of CanonicalHuffman.java:223-275 incl. the -8333608 / -8388608 mismatch
+    rng = np.random.default_rng(5)
+    base = rng.integers(-3, 4, 40 * 50).cumsum().astype(np.int64)
+    tiles = []
+    for span in (500, 2000, 8000, 32000, 8_000_000, 2_000_000_000):
+        v = base.copy()
+        idx = rng.integers(1, v.size, 60)
+        v[idx] += rng.integers(-span, span, idx.size)
+        tiles.append(v.astype(np.int32))
+    v = base.copy()
+    v[100] += -8388608 + 17                       # a residual inside the quirk's gap
+    v[101:] += -8388608 + 17
+    tiles.append(v.astype(np.int32))
+    _check_tiles(codec, 40, 50, np.stack(tiles))
+
+
+def test_length_limited_codes():
+    # Fibonacci-like residual counts: unrestricted Huffman depth > 15 -> the PackageMerge path on the device.
+    # The tile is built so that the Differencing residuals are exactly that multiset; only Differencing is tried.
+    import gridfour_amd
+    n_rows, n_cols = 150, 190
+    fib = [1, 1]
+    while len(fib) < 22:
+        fib.append(fib[-1] + fib[-2])
+    res = np.concatenate([np.full(c, i - 11, np.int32) for i, c in enumerate(fib)])
+    np.random.default_rng(3).shuffle(res)
+    res = np.resize(res, n_rows * n_cols - 1)
+    v = oracle.predictor_decode_int(1, 1000, n_rows, n_cols, res)
+    ref, used = oracle.codec_canon_encode(4, n_rows, n_cols, v, predictor_mask=1)
+    _, _, cl = oracle.canon_encode(res)
+    assert cl.max() <= 15 and used == 1
+    ctx = gridfour_amd.GvrsHipContext(0)
+    b = gridfour_amd.DeviceTileBatch(ctx, n_rows, n_cols, 1, codec="canon")
+    b.values.upload(v)
+    b.encode(codec_index=4, predictor_mask=1)
+    b.decode()
+    ctx.synchronize()
+    assert b.get_enc_status()[0] == 0 and b.get_dec_status()[0] == 0
+    assert b.get_packing(0) == ref
+    assert np.array_equal(b.get_decoded()[0], v)
+    b.free()
+
+
+def test_single_tile_interface(codec):
+    v = make_tile("smooth", 120, 150)
+    ref, used = oracle.codec_canon_encode(2, 120, 150, v)
+    got = codec.encode(2, 120, 150, v)
+    assert got == ref
+    assert np.array_equal(codec.decode(120, 150, got), v)
+    assert codec.encode(2, 4, 4, np.full(16, NULL, np.int32)) is None
+    u = codec.encode(7, 4, 4, np.full(16, 9, np.int32))
+    assert u == bytes([7, 0, 9, 0, 0, 0])
+    assert np.array_equal(codec.decode(4, 4, u), np.full(16, 9, np.int32))
+
+
+def test_decode_errors(codec):
+    v = make_tile("smooth", 20, 30)
+    good = codec.encode(1, 20, 30, v)
+    with pytest.raises(IOError):
+        codec.decode(20, 30, good[:1] + bytes([9]) + good[2:])      # unknown predictor
+    with pytest.raises(IOError):
+        codec.decode(20, 30, good[:len(good) // 2])                 # text cut off: no end-of-text symbol
+    with pytest.raises(IOError):
+        codec.decode(20, 30, good[:4])                              # shorter than the header
+
+
+def test_device_batch_dem_roundtrip_and_sampled_parity():
+    import gridfour_amd
+    ctx = gridfour_amd.GvrsHipContext(0)
+    n_rows, n_cols, nt = 120, 150, 600
+    b = gridfour_amd.DeviceTileBatch(ctx, n_rows, n_cols, nt, codec="canon")
+    b.synth_dem(0x9E3779B97F4A7C15 + 3, 30)
+    b.encode(codec_index=1)
+    b.decode()
+    ctx.synchronize()
+    assert np.all(b.get_enc_status() == 0) and np.all(b.get_dec_status() == 0)
+    vals = b.get_values()
+    assert np.array_equal(b.get_decoded(), vals)
+    lengths = b.get_lengths()
+    preds = b.get_predictors()
+    for t in range(0, nt, 37):
+        ref, used = oracle.codec_canon_encode(1, n_rows, n_cols, vals[t])
+        assert preds[t] == used and lengths[t] == len(ref)
+        assert b.get_packing(t, int(lengths[t])) == ref
+    b.free()
