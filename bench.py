@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="etopo1", choices=sorted(WORKLOADS))
+    ap.add_argument("--codec", default="huffman", choices=["huffman", "canon"],
+                    help="huffman = CodecHuffman (the north-star path, default); canon = CodecCanonHuffman")
     ap.add_argument("--cpu-sample-tiles", type=int, default=-1, help="tiles timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exactness checks")
     return ap.parse_args()
@@ -96,7 +98,7 @@ def main():
     cells = n_rows * n_cols
     ctx = gridfour_amd.GvrsHipContext(local_rank)
     stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
-    batch = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride)
+    batch = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
     seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3}[args.workload]
     # rank r owns the contiguous tile range starting at r * n_tiles of the global grid
     batch.synth_dem(seed, tiles_per_row, tile0=rank * n_tiles)
@@ -156,7 +158,8 @@ def main():
         sample = list(range(0, n_tiles, max(1, n_tiles // 64)))[:64]
         parity_ok = True
         for t in sample:
-            ref, used = oracle.codec_huffman_encode(0, n_rows, n_cols, vals[t])
+            ref, used = (oracle.codec_canon_encode if args.codec == "canon" else oracle.codec_huffman_encode)(
+                0, n_rows, n_cols, vals[t])
             if ref != batch.get_packing(t, int(lengths[t])) or used != preds[t]:
                 parity_ok = False
                 break
@@ -169,9 +172,15 @@ def main():
         if ns > 0 and world == 1:
             sub = vals[:ns]
             c0 = time.perf_counter()
-            out, ln, _ = oracle.batch_huffman_encode(0, n_rows, n_cols, sub)
+            if args.codec == "canon":
+                out, ln, _ = oracle.batch_canon_encode(0, n_rows, n_cols, sub)
+            else:
+                out, ln, _ = oracle.batch_huffman_encode(0, n_rows, n_cols, sub)
             c1 = time.perf_counter()
-            dec = oracle.batch_huffman_decode(n_rows, n_cols, out, ln)
+            if args.codec == "canon":
+                dec = oracle.batch_canon_decode(n_rows, n_cols, out, ln)
+            else:
+                dec = oracle.batch_huffman_decode(n_rows, n_cols, out, ln)
             c2 = time.perf_counter()
             assert np.array_equal(dec, sub)
             mb = sub.nbytes / 1e6
@@ -193,7 +202,8 @@ def main():
     enc_avg, dec_avg = float(np.mean(enc_ms)), float(np.mean(dec_ms))
     # algorithmic bytes per launch: encode reads 4 B/cell and writes c; decode reads c, writes 4
     alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
-    dom_name, dom_ms = ("k_huffman_decode", dec_avg) if dec_avg >= enc_avg else ("k_huffman_encode", enc_avg)
+    kname = "k_canon" if args.codec == "canon" else "k_huffman"
+    dom_name, dom_ms = (kname + "_decode", dec_avg) if dec_avg >= enc_avg else (kname + "_encode", enc_avg)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     traffic = _pmc_traffic(args.workload, dom_name)
     out = {
@@ -210,7 +220,8 @@ def main():
         "dtype": "int32",
         "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, descr), "tile_rows": n_rows, "tile_cols": n_cols,
-                   "tiles_per_gpu": n_tiles, "codec": "CodecHuffman (Differencing/Linear/Triangle + M32 + Huffman)",
+                   "tiles_per_gpu": n_tiles, "codec": ("CodecCanonHuffman (Differencing/Linear/Triangle + canonical Huffman)" if args.codec == "canon"
+                             else "CodecHuffman (Differencing/Linear/Triangle + M32 + Huffman)"),
                    "sharding": "contiguous tile ranges, no collective"},
         "bit_exact": bit_exact,
         "compressed_bytes_per_cell": round(c_per_cell, 4),

@@ -51,6 +51,20 @@ SIGNATURES = {
                                                 C.c_size_t, _vp, _vp, _vp, C.c_int]),
     "gf_canon_decode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp,
                                                 C.c_size_t, _vp, _vp, _vp]),
+    "gf_lsop12_residual_count": (C.c_size_t, [C.c_int, C.c_int]),
+    "gf_lsop12_max_packing": (C.c_size_t, [C.c_int, C.c_int]),
+    "gf_lsop12_predict_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "gf_lsop12_reconstruct_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_lsop12_encode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t,
+                                                 _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "gf_lsop12_decode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp,
+                                                 C.c_size_t, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "gf_lsop12_encode_batch_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t,
+                                             _vp, _vp, _vp]),
+    "gf_lsop12_decode_batch_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_lsop12_encode_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]),
+    "gf_lsop12_decode_i32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "gf_compact_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t]),
     "gf_float_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "gf_float_planes_encode_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t]),

@@ -12,9 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvrs_hip.so")
 SOURCES = ["gvrs_api.hip", "gvrs_encode.hip", "gvrs_decode.hip", "gvrs_aux.hip", "gvrs_float.hip",
-           "gvrs_canon_encode.hip", "gvrs_canon_decode.hip"]
+           "gvrs_canon_encode.hip", "gvrs_canon_decode.hip", "gvrs_lsop.hip", "gvrs_lsop_decode.hip"]
 HEADERS = ["gvrs_common.h", "gvrs_kernels.h", "huff_build.h", "gvrs_encode_layout.h", "gvrs_encode_common.h",
-           "gvrs_decode_common.h", "gvrs_canon_common.h", os.path.join("..", "..", "include", "gvrs_hip_codec.h")]
+           "gvrs_decode_common.h", "gvrs_canon_common.h", "gvrs_canon_decode_common.h", os.path.join("..", "..", "include", "gvrs_hip_codec.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 

@@ -364,3 +364,113 @@ class CodecFloatHip:
         check(lib().gf_float_decode_batch_f32(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets), _ptr(out),
                                               _ptr(status)), "gf_float_decode_batch_f32")
         return out, status
+
+
+class LsCodecHip:
+    """Drop-in for org.gridfour.lsop.LsEncoder12 + LsDecoder12 (codec id "LSOP12", LsCodecUtility.java:53),
+    computed on the MI355X; the Deflate alternative container uses the host's zlib as the reference uses the JDK's."""
+
+    def __init__(self, context=None, device=0, deflate_enabled=True):
+        self.ctx = context if context is not None else GvrsHipContext(device)
+        self.deflate_enabled = bool(deflate_enabled)           # LsEncoder12.setDeflateEnabled, default true
+
+    def setDeflateEnabled(self, enabled):
+        self.deflate_enabled = bool(enabled)
+
+    # ---- ICompressionEncoder ----
+    def encode(self, codecIndex, nRows, nCols, values):
+        packs, _, status = self.encode_batch(codecIndex, nRows, nCols, np.asarray(values).reshape(1, -1))
+        if status[0] == _lib.DECLINED:
+            return None
+        check(int(status[0]), "gf_lsop12_encode_batch_i32")
+        return packs[0]
+
+    def encodeFloats(self, codecIndex, nRows, nCols, values):
+        return None                                             # LsEncoder12.java:222-224
+
+    def implementsFloatingPointEncoding(self):
+        return False
+
+    def implementsIntegerEncoding(self):
+        return True
+
+    # ---- ICompressionDecoder ----
+    def decode(self, nRows, nColumns, packing):
+        vals, status = self.decode_batch(nRows, nColumns, [packing])
+        if status[0] in (_lib.ERR_FORMAT, _lib.ERR_BOUNDS):
+            raise IOError(lib().gf_status_string(int(status[0])).decode())
+        check(int(status[0]), "gf_lsop12_decode_batch_i32")
+        return vals[0]
+
+    def decodeFloats(self, nRows, nColumns, packing):
+        return None
+
+    # ---- batched forms (host memory) ----
+    def encode_batch(self, codecIndex, nRows, nCols, tiles):
+        """Returns (packings: list[bytes|None], container types uint8, status int32)."""
+        v = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        cap = nt * int(lib().gf_lsop12_max_packing(nRows, nCols)) + 64
+        blob = np.empty(cap, np.uint8)
+        offsets = np.zeros(nt + 1, np.uint64)
+        types = np.zeros(nt, np.uint8)
+        status = np.zeros(nt, np.int32)
+        check(lib().gf_lsop12_encode_batch_i32(self.ctx.handle, codecIndex, nRows, nCols, nt, _ptr(v),
+                                               int(self.deflate_enabled), _ptr(blob), cap, _ptr(offsets), _ptr(types),
+                                               _ptr(status)), "gf_lsop12_encode_batch_i32")
+        packs = [bytes(blob[int(offsets[t]):int(offsets[t + 1])]) if status[t] == _lib.OK else None for t in range(nt)]
+        return packs, types, status
+
+    def decode_batch(self, nRows, nCols, packings):
+        nt = len(packings)
+        offsets = np.zeros(nt + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(p) for p in packings])
+        blob = np.frombuffer(b"".join(packings) + b"\0" * 16, dtype=np.uint8)
+        out = np.zeros((nt, nRows * nCols), np.int32)
+        status = np.zeros(nt, np.int32)
+        check(lib().gf_lsop12_decode_batch_i32(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets), _ptr(out),
+                                               _ptr(status)), "gf_lsop12_decode_batch_i32")
+        return out, status
+
+    # ---- the predictor stage alone (device buffers handled here; used by tests and tools) ----
+    def predict(self, nRows, nCols, tiles):
+        """LsOptimalPredictor12.encode: returns (seed, coefficients float32[nt,12], residuals int32[nt,n], status)."""
+        v = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        n = int(lib().gf_lsop12_residual_count(nRows, nCols))
+        stride = (n + 3) // 4 * 4
+        dv, dr, dc, ds = (DeviceBuffer(self.ctx, v.nbytes), DeviceBuffer(self.ctx, nt * stride * 4 + 16),
+                          DeviceBuffer(self.ctx, nt * 64), DeviceBuffer(self.ctx, nt * 4))
+        dv.upload(v)
+        check(lib().gf_lsop12_predict_dev(self.ctx.handle, None, nRows, nCols, nt, dv.ptr, dr.ptr, stride, dc.ptr, ds.ptr),
+              "gf_lsop12_predict_dev")
+        self.ctx.synchronize()
+        res = dr.download(np.int32, nt * stride).reshape(nt, stride)[:, :n]
+        coefs = dc.download(np.uint32, nt * 16).reshape(nt, 16)
+        status = ds.download(np.int32, nt)
+        for b in (dv, dr, dc, ds):
+            b.free()
+        return coefs[:, 0].astype(np.int32), coefs[:, 1:13].copy().view(np.float32), res, status
+
+    def reconstruct(self, nRows, nCols, seeds, coefficients, residuals):
+        """LsDecoder12.unpackInitializers/unpackInterior: returns (values int32[nt, cells], status)."""
+        res = np.ascontiguousarray(residuals, dtype=np.int32)
+        nt, n = res.shape
+        stride = (n + 3) // 4 * 4
+        padded = np.zeros((nt, stride), np.int32)
+        padded[:, :n] = res
+        coefs = np.zeros((nt, 16), np.uint32)
+        coefs[:, 0] = np.asarray(seeds, np.int32).view(np.uint32)
+        coefs[:, 1:13] = np.ascontiguousarray(coefficients, np.float32).view(np.uint32).reshape(nt, 12)
+        dv, dr, dc, ds = (DeviceBuffer(self.ctx, nt * nRows * nCols * 4), DeviceBuffer(self.ctx, padded.nbytes + 16),
+                          DeviceBuffer(self.ctx, nt * 64), DeviceBuffer(self.ctx, nt * 4))
+        dr.upload(padded)
+        dc.upload(coefs)
+        check(lib().gf_lsop12_reconstruct_dev(self.ctx.handle, None, nRows, nCols, nt, dr.ptr, stride, dc.ptr, None, dv.ptr,
+                                              ds.ptr), "gf_lsop12_reconstruct_dev")
+        self.ctx.synchronize()
+        vals = dv.download(np.int32, nt * nRows * nCols).reshape(nt, nRows * nCols)
+        status = ds.download(np.int32, nt)
+        for b in (dv, dr, dc, ds):
+            b.free()
+        return vals, status

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <zlib.h>
@@ -69,6 +70,7 @@ struct gf_context {
     // staging for the host-memory entry points
     DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
     DevBuf dPlanes;        // CodecFloat plane staging
+    DevBuf dResiduals, dCoefs, dStatus2;   // LSOP staging
 };
 
 struct gf_timer {
@@ -153,6 +155,9 @@ void gf_context_destroy(gf_context *c)
     c->dStatus.release();
     c->dOffsets.release();
     c->dPlanes.release();
+    c->dResiduals.release();
+    c->dCoefs.release();
+    c->dStatus2.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -763,6 +768,381 @@ gf_status gf_huffman_decode_i32(gf_context *c, int nRows, int nCols, const uint8
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
     gf_status s = gf_huffman_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
+    if (s != GF_OK) return s;
+    return (gf_status)st;
+}
+
+
+// ------------------------------------------------------------------ LSOP12
+
+size_t gf_lsop12_residual_count(int nRows, int nCols)
+{
+    if (nRows < 6 || nCols < 6) return 0;
+    return (size_t)4 * nRows + (size_t)2 * nCols - 9 + (size_t)(nRows - 2) * (size_t)(nCols - 4);
+}
+
+size_t gf_lsop12_max_packing(int nRows, int nCols)
+{
+    // 55 header bytes + two canonical-Huffman streams (tables < 750 bytes each, at most 84 bits per value + end-of-text)
+    const size_t n = gf_lsop12_residual_count(nRows, nCols);
+    return roundUp(55 + 2 * 768 + (n * 84 + 2 * 15 + 7) / 8 + 16, 16);
+}
+
+gf_status gf_lsop12_predict_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const int32_t *dValues,
+                                int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dStatus)
+{
+    if (!c || !dValues || !dResiduals || !dCoefs || !dStatus || nRows < 1 || nCols < 1) return GF_ERR_ARG;
+    if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (nRows < 6 || nCols < 6) {                       // LsOptimalPredictor12.java:114-116 -> null
+        if (nTiles) GF_HIP(hipMemsetD32Async((hipDeviceptr_t)dStatus, GF_DECLINED, nTiles, st));
+        return GF_OK;
+    }
+    if (resStride < gf_lsop12_residual_count(nRows, nCols)) return GF_ERR_ARG;
+    GF_HIP(gf_launch_lsop_predict(dValues, dResiduals, resStride, dCoefs, dStatus, nTiles, nRows, nCols, st));
+    return GF_OK;
+}
+
+gf_status gf_lsop12_reconstruct_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
+                                    const int32_t *dResiduals, size_t resStride, const uint32_t *dCoefs,
+                                    const int32_t *dInStatus, int32_t *dValues, int32_t *dStatus)
+{
+    if (!c || !dValues || !dResiduals || !dCoefs || !dStatus) return GF_ERR_ARG;
+    if (nRows < 6 || nCols < 6 || resStride < gf_lsop12_residual_count(nRows, nCols)) return GF_ERR_ARG;
+    GF_HIP(gf_launch_lsop_reconstruct(dResiduals, resStride, dCoefs, dInStatus, dValues, dStatus, nTiles, nRows, nCols,
+                                      stream ? (hipStream_t)stream : c->stream));
+    return GF_OK;
+}
+
+gf_status gf_lsop12_encode_batch_i32_dev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                         const int32_t *dValues, uint8_t *dOut, size_t slotStride, uint32_t *dLengths,
+                                         int32_t *dStatus, int32_t *dResiduals, size_t resStride, uint32_t *dCoefs,
+                                         int32_t *dScratchStatus)
+{
+    if (!c || !dValues || !dOut || !dLengths || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
+    if (slotStride % 16 != 0 || ((uintptr_t)dOut & 15) != 0 || slotStride < 64) return GF_ERR_ARG;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (nRows < 6 || nCols < 6) {
+        if (nTiles) {
+            GF_HIP(hipMemsetD32Async((hipDeviceptr_t)dStatus, GF_DECLINED, nTiles, st));
+            GF_HIP(hipMemsetD32Async((hipDeviceptr_t)dLengths, 0, nTiles, st));
+        }
+        return GF_OK;
+    }
+    gf_status s = gf_lsop12_predict_dev(c, stream, nRows, nCols, nTiles, dValues, dResiduals, resStride, dCoefs, dScratchStatus);
+    if (s != GF_OK) return s;
+    const uint32_t n0 = (uint32_t)(4 * nRows + 2 * nCols - 9), n1 = (uint32_t)((nRows - 2) * (nCols - 4));
+    if (4ull * ((uint64_t)n1 + 1) >= (1ull << 22)) return GF_ERR_UNSUPPORTED;       // 22-bit counts in the tree keys
+    GF_HIP(gf_launch_canon_pack2(dResiduals, resStride, dCoefs, dScratchStatus, dOut, slotStride, dLengths, dStatus, nTiles,
+                                 n0, n1, codecIndex, st));
+    return GF_OK;
+}
+
+gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
+                                         const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets, size_t slotStride,
+                                         const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus, int32_t *dResiduals,
+                                         size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus)
+{
+    if (!c || !dBlob || !dLengths || !dValues || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
+    if (((uintptr_t)dBlob & 3) != 0) return GF_ERR_ARG;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (nRows < 6 || nCols < 6) {
+        if (nTiles) GF_HIP(hipMemsetD32Async((hipDeviceptr_t)dStatus, GF_ERR_BOUNDS, nTiles, st));
+        return GF_OK;
+    }
+    if (resStride < gf_lsop12_residual_count(nRows, nCols)) return GF_ERR_ARG;
+    const unsigned grid = gf_huffman_decode_grid(nTiles);
+    GF_HIP(gf_launch_lsop_unpack2(dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride, dCoefs,
+                                  dScratchStatus, nTiles, nRows, nCols, gf_canon_decode_lds_text(nRows, nCols), grid, st));
+    return gf_lsop12_reconstruct_dev(c, stream, nRows, nCols, nTiles, dResiduals, resStride, dCoefs, dScratchStatus, dValues,
+                                     dStatus);
+}
+
+}  // extern "C"
+
+namespace {
+
+// CodecM32.encode (compress/CodecM32.java:257-311) of a residual array: host-side glue for the Deflate container
+size_t m32Pack(const int32_t *x, size_t n, std::vector<uint8_t> &out)
+{
+    out.resize(6 * n + 8);
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int len = gf_m32_len((uint32_t)x[i]);
+        for (int b = 0; b < len; b++) out[k++] = (uint8_t)gf_m32_byte((uint32_t)x[i], len, b);
+    }
+    out.resize(k);
+    return k;
+}
+
+// CodecM32.decode (:327-356) of exactly nValues values from nBytes bytes
+bool m32Unpack(const uint8_t *m, size_t nBytes, int32_t *out, size_t nValues)
+{
+    size_t pos = 0;
+    for (size_t i = 0; i < nValues; i++) {
+        if (pos >= nBytes) return false;
+        const int8_t sb = (int8_t)m[pos++];
+        if (sb == -128) { out[i] = (int32_t)0x80000000; continue; }
+        if (sb != 127 && sb != -127) { out[i] = sb; continue; }
+        uint32_t delta = 0;
+        int groups = 0;
+        for (;;) {
+            if (pos >= nBytes) return false;
+            const uint8_t b = m[pos++];
+            delta = (delta << 7) | (b & 0x7fu);
+            groups++;
+            if (!(b & 0x80u)) break;
+            if (groups >= 5) return false;
+        }
+        static const uint32_t base[5] = {127u, 255u, 16639u, 2113791u, 270549247u};
+        const uint32_t a = delta + base[groups - 1];
+        out[i] = sb == 127 ? (int32_t)a : (int32_t)(0u - a);
+    }
+    return true;
+}
+
+void putLE32(uint8_t *p, uint32_t x) { p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24); }
+uint32_t getLE32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+template <class F>
+void parallelFor(size_t n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    if (n < 2 * nt) nt = 1;
+    if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nt; w++)
+        th.emplace_back([=]() { for (size_t i = w; i < n; i += nt) f(i); });
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+// LsEncoder12.encode :122-219 for a batch in host memory.  deflateEnabled mirrors setDeflateEnabled (default true):
+// the canonical-Huffman packing comes from the GPU; with Deflate enabled the host's zlib (level 6) compresses the two
+// M32 streams and replaces the packing when strictly smaller (:180-216).  types[t] = container type written (2 / 1).
+gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                                     int deflateEnabled, uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *types,
+                                     int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    if (nRows < 6 || nCols < 6) {
+        for (size_t t = 0; t <= nTiles; t++) offsets[t] = 0;
+        for (size_t t = 0; t < nTiles; t++) { if (status) status[t] = GF_DECLINED; if (types) types[t] = 0; }
+        return GF_OK;
+    }
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const size_t nRes = gf_lsop12_residual_count(nRows, nCols), resStride = roundUp(nRes, 4);
+    const size_t nInit = (size_t)4 * nRows + 2 * nCols - 9, nInt = nRes - nInit;
+    const size_t stride = gf_lsop12_max_packing(nRows, nCols);
+    gf_status s;
+    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dSlots.ensure(nTiles * stride + 16)) != GF_OK) return s;
+    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus2.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dResiduals.ensure(nTiles * resStride * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dCoefs.ensure(nTiles * 64 + 16)) != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
+    s = gf_lsop12_encode_batch_i32_dev(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
+                                       (uint8_t *)c->dSlots.p, stride, (uint32_t *)c->dLengths.p, (int32_t *)c->dStatus.p,
+                                       (int32_t *)c->dResiduals.p, resStride, (uint32_t *)c->dCoefs.p,
+                                       (int32_t *)c->dStatus2.p);
+    if (s != GF_OK) return s;
+    std::vector<uint32_t> lengths(nTiles);
+    std::vector<int32_t> st(nTiles);
+    std::vector<uint8_t> slots(nTiles * stride);
+    GF_HIP(hipMemcpyAsync(lengths.data(), c->dLengths.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(slots.data(), c->dSlots.p, nTiles * stride, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> res;
+    std::vector<uint32_t> coefs;
+    if (deflateEnabled) {
+        res.resize(nTiles * resStride);
+        coefs.resize(nTiles * 16);
+        GF_HIP(hipMemcpyAsync(res.data(), c->dResiduals.p, nTiles * resStride * 4, hipMemcpyDeviceToHost, c->stream));
+        GF_HIP(hipMemcpyAsync(coefs.data(), c->dCoefs.p, nTiles * 64, hipMemcpyDeviceToHost, c->stream));
+    }
+    GF_HIP(hipStreamSynchronize(c->stream));
+
+    std::vector<std::vector<uint8_t>> alt(nTiles);          // Deflate container where it wins
+    if (deflateEnabled) {
+        parallelFor(nTiles, [&](size_t t) {
+            if (st[t] != GF_OK) return;
+            const size_t canonLength = lengths[t] - 55;
+            const int32_t *r = res.data() + t * resStride;
+            std::vector<uint8_t> mInt, mInit, zInt, zInit;
+            const size_t nMX = m32Pack(r + nInit, nInt, mInt);
+            if (!zDeflate(mInt.data(), nMX, 6, zInt)) return;
+            if (zInt.empty() || zInt.size() >= canonLength || zInt.size() > nMX + 128) return;      // :185-187
+            const size_t nMI = m32Pack(r, nInit, mInit);
+            if (!zDeflate(mInit.data(), nMI, 6, zInit)) return;
+            if (zInit.empty() || zInit.size() + zInt.size() >= canonLength || zInit.size() > nMI + 128) return;   // :194-196
+            std::vector<uint8_t> &p = alt[t];
+            p.resize(63 + zInit.size() + zInt.size());
+            p[0] = (uint8_t)codecIndex;
+            p[1] = 0x41;                                     // COMPRESSION_TYPE_DEFLATE | REVISION_FLAG
+            p[2] = 12;
+            for (int k = 0; k < 13; k++) putLE32(&p[3 + 4 * k], coefs[t * 16 + k]);
+            putLE32(&p[55], (uint32_t)nMI);
+            putLE32(&p[59], (uint32_t)nMX);
+            memcpy(&p[63], zInit.data(), zInit.size());
+            memcpy(&p[63 + zInit.size()], zInt.data(), zInt.size());
+        });
+    }
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        offsets[t] = total;
+        if (st[t] == GF_OK) total += alt[t].empty() ? lengths[t] : alt[t].size();
+        if (types) types[t] = st[t] == GF_OK ? (alt[t].empty() ? 2 : 1) : 0;
+    }
+    offsets[nTiles] = total;
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    if (total > blobCap) return GF_ERR_CAPACITY;
+    for (size_t t = 0; t < nTiles; t++) {
+        if (st[t] != GF_OK) continue;
+        if (alt[t].empty()) memcpy(blob + offsets[t], slots.data() + t * stride, lengths[t]);
+        else memcpy(blob + offsets[t], alt[t].data(), alt[t].size());
+    }
+    return GF_OK;
+}
+
+// LsDecoder12.decode :94-160 for a batch in host memory.  Canonical-Huffman containers are decoded on the GPU; Deflate
+// containers (either header revision) are inflated by the host's zlib, their M32 bytes unpacked, and the tile rebuilt on
+// the GPU; the legacy Huffman-of-M32 container (type 0, written only by old Gridfour versions) is GF_ERR_UNSUPPORTED.
+gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                     const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    if (nRows < 6 || nCols < 6) {
+        for (size_t t = 0; t < nTiles && status; t++) status[t] = GF_ERR_BOUNDS;
+        return GF_OK;
+    }
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const size_t nRes = gf_lsop12_residual_count(nRows, nCols), resStride = roundUp(nRes, 4);
+    const size_t nInit = (size_t)4 * nRows + 2 * nCols - 9, nInt = nRes - nInit;
+    const uint64_t total = offsets[nTiles];
+    gf_status s;
+    if ((s = c->dBlob.ensure(total + 32)) != GF_OK) return s;
+    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus2.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
+    if ((s = c->dResiduals.ensure(nTiles * resStride * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dCoefs.ensure(nTiles * 64 + 16)) != GF_OK) return s;
+    std::vector<uint32_t> lengths(nTiles);
+    for (size_t t = 0; t < nTiles; t++) {
+        if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
+        lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
+    }
+    GF_HIP(hipMemcpyAsync(c->dBlob.p, blob, total, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dOffsets.p, offsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = gf_huffman_decode_grid(nTiles);
+    GF_HIP(gf_launch_lsop_unpack2((const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
+                                  (const uint32_t *)c->dLengths.p, (int32_t *)c->dResiduals.p, resStride,
+                                  (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p, nTiles, nRows, nCols,
+                                  gf_canon_decode_lds_text(nRows, nCols), grid, c->stream));
+    std::vector<int32_t> st(nTiles);
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus2.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+
+    // Deflate containers: inflate + M32 unpack on the host, then upload residuals, coefficients and status
+    std::vector<size_t> hostTiles;
+    for (size_t t = 0; t < nTiles; t++)
+        if (st[t] == GF_ERR_UNSUPPORTED) hostTiles.push_back(t);
+    if (!hostTiles.empty()) {
+        std::vector<int32_t> hres(hostTiles.size() * resStride, 0);
+        std::vector<uint32_t> hcoef(hostTiles.size() * 16, 0);
+        std::vector<int32_t> hst(hostTiles.size(), GF_ERR_UNSUPPORTED);
+        parallelFor(hostTiles.size(), [&](size_t i) {
+            const size_t t = hostTiles[i];
+            const uint8_t *pk = blob + offsets[t];
+            const size_t len = lengths[t];
+            size_t o = 1;
+            int type = 0;
+            bool checksum = false;
+            const bool revised = pk[1] & 0x40;
+            if (revised) { type = pk[1] & 0x0f; checksum = pk[1] & 0x80; o = 2; }
+            if (len < o + 1 + 4 + 48 + 9) { hst[i] = GF_ERR_BOUNDS; return; }
+            if (pk[o++] != 12) { hst[i] = GF_ERR_FORMAT; return; }
+            for (int k = 0; k < 13; k++) hcoef[i * 16 + k] = getLE32(pk + o + 4 * k);
+            o += 52;
+            const uint32_t nMI = getLE32(pk + o), nMX = getLE32(pk + o + 4);
+            o += 8;
+            if (!revised) { type = pk[o] & 0x0f; checksum = pk[o] & 0x80; o++; }
+            if (checksum) o += 4;
+            if (type != 1) return;                                        // type 0: unsupported here
+            if (o > len || nMI > 6 * nInit || nMX > 6 * nInt) { hst[i] = GF_ERR_FORMAT; return; }
+            std::vector<uint8_t> mI(nMI + 8), mX(nMX + 8);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit(&zs) != Z_OK) { hst[i] = GF_ERR_FORMAT; return; }
+            zs.next_in = (Bytef *)(pk + o); zs.avail_in = (uInt)(len - o);
+            zs.next_out = mI.data(); zs.avail_out = nMI;
+            int zr = inflate(&zs, Z_PARTIAL_FLUSH);
+            const size_t used = zs.total_in, got = zs.total_out;
+            inflateEnd(&zs);
+            if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got < nMI) { hst[i] = GF_ERR_FORMAT; return; }
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit(&zs) != Z_OK) { hst[i] = GF_ERR_FORMAT; return; }
+            zs.next_in = (Bytef *)(pk + o + used); zs.avail_in = (uInt)(len - o - used);
+            zs.next_out = mX.data(); zs.avail_out = nMX;
+            zr = inflate(&zs, Z_PARTIAL_FLUSH);
+            const size_t got2 = zs.total_out;
+            inflateEnd(&zs);
+            if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got2 < nMX) { hst[i] = GF_ERR_FORMAT; return; }
+            if (!m32Unpack(mI.data(), nMI, hres.data() + i * resStride, nInit) ||
+                !m32Unpack(mX.data(), nMX, hres.data() + i * resStride + nInit, nInt)) { hst[i] = GF_ERR_BOUNDS; return; }
+            hst[i] = GF_OK;
+        });
+        for (size_t i = 0; i < hostTiles.size(); i++) {
+            const size_t t = hostTiles[i];
+            st[t] = hst[i];
+            if (hst[i] != GF_OK) continue;
+            GF_HIP(hipMemcpyAsync((int32_t *)c->dResiduals.p + t * resStride, hres.data() + i * resStride, nRes * 4,
+                                  hipMemcpyHostToDevice, c->stream));
+            GF_HIP(hipMemcpyAsync((uint32_t *)c->dCoefs.p + t * 16, hcoef.data() + i * 16, 64, hipMemcpyHostToDevice, c->stream));
+        }
+        GF_HIP(hipMemcpyAsync(c->dStatus2.p, st.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
+        GF_HIP(hipStreamSynchronize(c->stream));           // the staging vectors go out of scope below
+    }
+    s = gf_lsop12_reconstruct_dev(c, c->stream, nRows, nCols, nTiles, (const int32_t *)c->dResiduals.p, resStride,
+                                  (const uint32_t *)c->dCoefs.p, (const int32_t *)c->dStatus2.p, (int32_t *)c->dValues.p,
+                                  (int32_t *)c->dStatus.p);
+    if (s != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    return GF_OK;
+}
+
+gf_status gf_lsop12_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, int deflateEnabled,
+                               uint8_t *out, size_t outCap, size_t *outLen)
+{
+    if (!outLen) return GF_ERR_ARG;
+    uint64_t offsets[2] = {0, 0};
+    int32_t st = 0;
+    gf_status s = gf_lsop12_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, deflateEnabled, out, outCap, offsets,
+                                             nullptr, &st);
+    *outLen = (size_t)offsets[1];
+    if (s != GF_OK) return s;
+    return (gf_status)st;
+}
+
+gf_status gf_lsop12_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values)
+{
+    uint64_t offsets[2] = {0, (uint64_t)len};
+    int32_t st = 0;
+    gf_status s = gf_lsop12_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
     if (s != GF_OK) return s;
     return (gf_status)st;
 }

@@ -1,0 +1,369 @@
+// gvrs_canon_decode_common.h -- device side of CanonicalHuffman.decode (compress/canonicalHuffman/), shared by the
+// CodecCanonHuffman and LSOP decode kernels.  Include inside the kernel file's anonymous namespace after
+// gvrs_decode_common.h.  See gvrs_canon_decode.hip for the phases.
+#pragma once
+
+constexpr int CN_SYMS = 260;
+constexpr int CN_NULL = 256, CN_ESC1 = 257, CN_ESC2 = 258, CN_EOT = 259;
+constexpr int CN_META = 20;
+constexpr int CD_LUT_BITS = 11;
+constexpr int CD_MAXQ = 512;
+constexpr uint32_t CD_WARM = 128;
+constexpr uint32_t CD_END_EOT = 0xFFFFFFFFu;     // subsequence ended on the end-of-text symbol
+constexpr uint32_t CD_END_BAD = 0xFFFFFFFEu;     // subsequence ran into an invalid code / the end of the data
+
+struct CanonDec {
+    uint16_t lut[1 << CD_LUT_BITS];             // (len << 9) | symbol; 0 = longer than 11 bits (or no code)
+    uint16_t symByOrder[320];                   // symbols ordered by (length, symbol)
+    uint32_t first[16], count[16], offset[16];  // canonical code of the first symbol of a length, how many, where
+    uint8_t len[320];
+    uint8_t metaLen[160];
+    uint16_t metaLut[256];                      // (len << 5) | symbol over 8 bits
+    uint16_t metaSym[32];
+    uint32_t mfirst[16], mcount[16], moffset[16];
+    uint32_t qs[CD_MAXQ], qe[CD_MAXQ], qc[CD_MAXQ], qx[CD_MAXQ];   // start, end, values, bit after the end-of-text symbol
+    uint32_t waveSum[DEC_WAVES];
+    uint32_t textStart;
+    int32_t parseStatus;
+    uint32_t changed;
+    uint32_t qStar;
+    uint32_t carry;
+    int32_t runStatus;
+};
+
+// 32 stream bits at absolute bit position pos (LSB-first) of the word array T
+struct CdText {
+    const uint32_t *w;      // LDS copy of the packing, or the blob itself for packings larger than the copy
+    uint32_t nWords;        // readable words
+};
+
+__device__ __forceinline__ uint32_t cd_peek(const CdText T, uint32_t pos)
+{
+    const uint32_t i = pos >> 5;
+    const uint32_t lo = i < T.nWords ? T.w[i] : 0u, hi = i + 1 < T.nWords ? T.w[i + 1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, pos & 31u);
+}
+
+// canonical search over lengths [lmin, lmax]: c = next bits most-significant first (bit-reversed window)
+__device__ __forceinline__ uint32_t cd_search(const uint32_t *first, const uint32_t *count, const uint32_t *offset,
+                                              const uint16_t *symByOrder, uint32_t c, int lmin, int lmax, uint32_t *len)
+{
+    for (int l = lmin; l <= lmax; l++) {
+        const uint32_t d = (c >> (32 - l)) - first[l];
+        if (d < count[l]) {
+            *len = (uint32_t)l;
+            return symByOrder[offset[l] + d];
+        }
+    }
+    *len = 0;
+    return 0;
+}
+
+// lengths -> canonical decode tables (one wave): CanonHuffTreeDecoder.java:68-95 (sort by length, symbol;
+// consecutive codes, shifted when the length grows)
+template <int NREG>
+__device__ __forceinline__ void cd_tables(const uint8_t *len, int nSym, uint32_t *first, uint32_t *count, uint32_t *offset,
+                                          uint16_t *symByOrder, int lane, uint32_t *nUsed)
+{
+    uint32_t L[NREG], rank[NREG];
+#pragma unroll
+    for (int r = 0; r < NREG; r++) {
+        const int e = r * 64 + lane;
+        L[r] = e < nSym ? len[e] : 0u;
+        rank[r] = 0;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t code = 0, off = 0;
+    for (uint32_t l = 1; l <= 15; l++) {
+        uint32_t running = 0;
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+            const unsigned long long m = __ballot(L[r] == l);
+            if (L[r] == l) rank[r] = running + (uint32_t)__popcll(m & lt);
+            running += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) { first[l] = code; count[l] = running; offset[l] = off; }
+#pragma unroll
+        for (int r = 0; r < NREG; r++)
+            if (L[r] == l) symByOrder[off + rank[r]] = (uint16_t)(r * 64 + lane);
+        code = (code + running) << 1;
+        off += running;
+    }
+    if (lane == 0) { first[0] = 0; count[0] = 0; offset[0] = 0; }
+    *nUsed = off;
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct CdTok {
+    uint32_t sym, bits, raw;     // bits = code + raw bits; sym == 0xFFFF: no such code
+};
+
+__device__ __forceinline__ CdTok cd_token(const CanonDec &S, const CdText T, uint32_t pos)
+{
+    const uint32_t w = cd_peek(T, pos);
+    const uint32_t e = S.lut[w & ((1u << CD_LUT_BITS) - 1u)];
+    CdTok t;
+    uint32_t cl;
+    if (e) {
+        t.sym = e & 511u;
+        cl = e >> 9;
+    } else {
+        t.sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(w), CD_LUT_BITS + 1, 15, &cl);
+        if (cl == 0) { t.sym = 0xFFFFu; t.bits = 1; t.raw = 0; return t; }
+    }
+    const uint32_t extra = t.sym == (uint32_t)CN_ESC2 ? 2u : t.sym == (uint32_t)CN_ESC1 ? 8u : 0u;
+    t.raw = (w >> cl) & ((1u << extra) - 1u);
+    t.bits = cl + extra;
+    return t;
+}
+
+// decodes subsequence q from bit p: tokens until the next boundary; returns where it ended and how many
+// values started in it
+__device__ __forceinline__ void cd_run(const CanonDec &S, const CdText T, uint32_t p, uint32_t bound, uint32_t endBit,
+                                       uint32_t *endOut, uint32_t *cntOut, uint32_t *eotEnd)
+{
+    uint32_t cnt = 0, end;
+    for (;;) {
+        if (p >= bound) { end = p; break; }
+        if (p >= endBit) { end = CD_END_BAD; break; }
+        const CdTok t = cd_token(S, T, p);
+        if (t.sym == 0xFFFFu) { end = CD_END_BAD; break; }
+        if (t.sym == (uint32_t)CN_EOT) { end = CD_END_EOT; *eotEnd = p + t.bits; break; }
+        cnt += t.sym <= (uint32_t)CN_NULL ? 1u : 0u;
+        p += t.bits;
+    }
+    *endOut = end;
+    *cntOut = cnt;
+}
+
+// One canonical-Huffman stream (CanonicalHuffman.decode :441-519) starting at bit startBit of T, by the whole
+// workgroup: code tables, subsequence synchronisation, then every value k handed to sink(k, value); values the
+// text does not supply up to fillTo are handed over as 0.  More than maxValues values is the reference's
+// ArrayIndexOutOfBounds.  Returns the tile status (same in all threads); *endPos = bit after the end-of-text symbol.
+template <class Sink>
+__device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T, uint32_t startBit, uint32_t endBit,
+                                                    uint32_t maxValues, uint32_t fillTo, Sink sink, uint32_t *endPos,
+                                                    uint32_t *nValuesOut)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { S.parseStatus = GF_K_OK; S.runStatus = GF_K_OK; S.qStar = 0xFFFFFFFFu; S.carry = 0; }
+    __syncthreads();
+    // ---------------- phase 0: code tables ----------------
+    if (wave == 0) {
+        uint32_t pos = startBit + 1u;                           // reserved bit, CanonicalHuffman.java:451
+        int32_t st = GF_K_OK;
+        // LengthEncoder.readEncodedLengths :197-236
+        {
+            uint32_t k = 0, prior = 0;
+            while (k < (uint32_t)CN_META && st == GF_K_OK) {
+                if (pos + 12u > endBit + 32u) { st = GF_K_ERR_BOUNDS; break; }
+                const uint32_t w = GF_UNI(cd_peek(T, pos));
+                const uint32_t idx = w & 31u;
+                pos += 5;
+                if (idx <= 15u) {
+                    if (lane == 0) S.metaLen[k] = (uint8_t)idx;
+                    k++;
+                    prior = idx;
+                } else if (idx <= 18u) {
+                    const uint32_t nb = idx == 16u ? 2u : idx == 17u ? 3u : 7u;
+                    const uint32_t n = ((w >> 5) & ((1u << nb) - 1u)) + (idx == 18u ? 11u : 3u);
+                    pos += nb;
+                    if (idx != 16u) prior = 0;
+                    if (k + n > (uint32_t)CN_META) { st = GF_K_ERR_BOUNDS; break; }       // symbols[k++] past the array
+                    for (uint32_t j = (uint32_t)lane; j < n; j += 64) S.metaLen[k + j] = (uint8_t)prior;
+                    k += n;
+                }                                               // 19..31: ignored by the switch's default
+                if (pos > endBit) st = GF_K_ERR_BOUNDS;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t nUsed = 0;
+        if (st == GF_K_OK) {
+            cd_tables<1>(S.metaLen, CN_META, S.mfirst, S.mcount, S.moffset, S.metaSym, lane, &nUsed);
+            if (nUsed == 0) st = GF_K_ERR_BOUNDS;               // sortNodes[0] of an empty array
+        }
+        if (st == GF_K_OK) {
+            for (uint32_t e = (uint32_t)lane; e < 256u; e += 64) {
+                uint32_t cl;
+                const uint32_t sym = cd_search(S.mfirst, S.mcount, S.moffset, S.metaSym, __brev(e), 1, 8, &cl);
+                S.metaLut[e] = cl ? (uint16_t)((cl << 5) | sym) : 0;
+            }
+            for (uint32_t e = (uint32_t)lane; e < 320u; e += 64) S.len[e] = 0;
+            __builtin_amdgcn_wave_barrier();
+            // CanonHuffTreeDecoder.decodeTree :133-177
+            uint32_t i = 0, prior = 0;
+            while (i < (uint32_t)CN_SYMS && st == GF_K_OK) {
+                if (pos >= endBit) { st = GF_K_ERR_BOUNDS; break; }
+                const uint32_t w = GF_UNI(cd_peek(T, pos));
+                uint32_t e = S.metaLut[w & 255u], cl, sym;
+                if (e) { cl = e >> 5; sym = e & 31u; }
+                else {
+                    sym = cd_search(S.mfirst, S.mcount, S.moffset, S.metaSym, __brev(w), 9, 15, &cl);
+                    if (cl == 0) { st = GF_K_ERR_BOUNDS; break; }  // walks into a missing node
+                }
+                sym = GF_UNI(sym);
+                cl = GF_UNI(cl);
+                pos += cl;
+                if (sym <= 15u) {
+                    if (lane == 0) S.len[i] = (uint8_t)sym;
+                    i++;
+                    prior = sym;
+                } else if (sym <= 18u) {
+                    const uint32_t nb = sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+                    const uint32_t n = ((w >> cl) & ((1u << nb) - 1u)) + (sym == 18u ? 11u : 3u);
+                    pos += nb;
+                    if (sym != 16u) prior = 0;
+                    if (i + n > (uint32_t)CN_SYMS + 1u) { st = GF_K_ERR_BOUNDS; break; }   // int[N_SYMBOLS_TOTAL + 1]
+                    for (uint32_t j = (uint32_t)lane; j < n; j += 64) S.len[i + j] = (uint8_t)prior;
+                    i += n;
+                } else {
+                    i++;                                        // symbol 19 (meta end-of-text): no store, :170
+                }
+                if (pos > endBit) st = GF_K_ERR_BOUNDS;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (st == GF_K_OK) {
+            cd_tables<5>(S.len, CN_SYMS + 1, S.first, S.count, S.offset, S.symByOrder, lane, &nUsed);
+            if (nUsed == 0) st = GF_K_ERR_BOUNDS;
+        }
+        if (lane == 0) { S.parseStatus = st; S.textStart = pos; }
+    }
+    __syncthreads();
+    if (S.parseStatus != GF_K_OK) {
+        const int32_t st = S.parseStatus;
+        __syncthreads();
+        return st;
+    }
+    for (uint32_t e = tid; e < (1u << CD_LUT_BITS); e += DEC_THREADS) {
+        uint32_t cl;
+        const uint32_t sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(e), 1, CD_LUT_BITS, &cl);
+        S.lut[e] = cl ? (uint16_t)((cl << 9) | sym) : 0;
+    }
+    __syncthreads();
+
+    // ---------------- phase 1: synchronise the subsequences, count their values ----------------
+    const uint32_t T0 = S.textStart;
+    const uint32_t span = endBit > T0 ? endBit - T0 : 1u;
+    const uint32_t unit = max(256u, ((span + CD_MAXQ - 1) / CD_MAXQ + 31u) & ~31u);
+    const uint32_t Q = (span + unit - 1) / unit;
+    for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
+        const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
+        uint32_t p = Bq;
+        if (q > 0) {                                            // warm-up: walk in from 128 bits before the boundary
+            p = Bq - T0 > CD_WARM ? Bq - CD_WARM : T0;
+            while (p < Bq) {
+                const CdTok tk = cd_token(S, T, p);
+                if (tk.sym == 0xFFFFu || tk.sym == (uint32_t)CN_EOT) { p = Bq; break; }
+                p += tk.bits;
+            }
+        }
+        uint32_t e, c;
+        cd_run(S, T, p, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+        S.qs[q] = p;
+        S.qe[q] = e;
+        S.qc[q] = c;
+    }
+    __syncthreads();
+    for (uint32_t round = 0; round < (uint32_t)CD_MAXQ; round++) {
+        if (tid == 0) S.changed = 0;
+        uint32_t want[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t q = tid + j * DEC_THREADS;
+            want[j] = (q >= 1 && q < Q) ? S.qe[q - 1] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t q = tid + j * DEC_THREADS;
+            if (q >= 1 && q < Q && want[j] < CD_END_BAD && want[j] != S.qs[q]) {
+                const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
+                uint32_t e, c;
+                // a value's escapes may carry the previous subsequence past this one's end: then it is empty
+                if (want[j] >= Bn && Bn != endBit) { e = want[j]; c = 0; }
+                else cd_run(S, T, want[j], Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+                S.qs[q] = want[j];
+                S.qe[q] = e;
+                S.qc[q] = c;
+                S.changed = 1;
+            }
+        }
+        __syncthreads();
+        if (!S.changed) break;
+        __syncthreads();
+    }
+    // the true chain ends at the first subsequence that met the end-of-text symbol (or an error)
+    for (uint32_t q = tid; q < Q; q += DEC_THREADS)
+        if (S.qe[q] >= CD_END_BAD) atomicMin(&S.qStar, q);
+    __syncthreads();
+    const uint32_t qStar = S.qStar;
+    int32_t tileStatus = GF_K_OK;
+    if (qStar == 0xFFFFFFFFu || S.qe[qStar] != CD_END_EOT) tileStatus = GF_K_ERR_BOUNDS;   // no end-of-text: read past the data
+    // exclusive prefix sum of the counts over the chain
+    uint32_t base[2];
+    {
+        uint32_t running = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t q = tid + j * DEC_THREADS;
+            const uint32_t c = (q < Q && q <= qStar) ? S.qc[q] : 0u;
+            uint32_t tot;
+            base[j] = running + block_excl_scan(c, S.waveSum, &tot);
+            running += tot;
+        }
+        if (tid == 0) S.carry = running;
+    }
+    __syncthreads();
+    const uint32_t nValues = S.carry;
+    if (nValues > maxValues) tileStatus = GF_K_ERR_BOUNDS;      // text[iSymbol++] past the array
+    if (tileStatus != GF_K_OK) {
+        __syncthreads();
+        return tileStatus;
+    }
+
+    // ---------------- phase 2: values to their cells ----------------
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uint32_t q = tid + j * DEC_THREADS;
+        if (q < Q && q <= qStar) {
+            const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
+            const uint32_t bound = Bn == endBit ? 0xFFFFFFF0u : Bn;
+            uint32_t p = S.qs[q], k = base[j];
+            bool started = q != 0;                                // q == 0: an escape before any value is text[-1]
+            while (p < bound) {
+                CdTok tk = cd_token(S, T, p);
+                if (tk.sym == (uint32_t)CN_EOT || tk.sym == 0xFFFFu) break;
+                p += tk.bits;
+                if (tk.sym > (uint32_t)CN_NULL) {                 // escape belonging to the previous value, or spare symbol 260
+                    if (!started && tk.sym != 260u) S.runStatus = GF_K_ERR_BOUNDS;
+                    continue;
+                }
+                started = true;
+                uint32_t v = tk.sym == (uint32_t)CN_NULL ? GF_NULL_CODE : tk.sym - 128u;
+                for (;;) {                                        // the escapes that extend this value (:495-504)
+                    tk = cd_token(S, T, p);
+                    if (tk.sym == (uint32_t)CN_ESC2) v = (v << 2) | tk.raw;
+                    else if (tk.sym == (uint32_t)CN_ESC1) v = (v << 8) | tk.raw;
+                    else if (tk.sym != 260u) break;
+                    p += tk.bits;
+                }
+                sink(k, v);
+                k++;
+            }
+        }
+    }
+    // a text shorter than its reader expects leaves zeros (fresh int[] in Java)
+    for (uint32_t k = nValues + tid; k < fillTo; k += DEC_THREADS) sink(k, 0u);
+    __syncthreads();
+    {
+        const int32_t st = S.runStatus;
+        __syncthreads();
+        if (st != GF_K_OK) return st;
+    }
+
+    *endPos = S.qx[qStar];
+    *nValuesOut = nValues;
+    __syncthreads();
+    return GF_K_OK;
+}

@@ -70,3 +70,18 @@ hipError_t gf_launch_float_planes_encode(const uint32_t *raw, uint8_t *planes, s
                                          int nCols, hipStream_t stream);
 hipError_t gf_launch_float_planes_decode(const uint8_t *planes, uint32_t *raw, size_t planeStride, size_t nTiles, int nRows,
                                          int nCols, hipStream_t stream);
+
+// LSOP12 (gvrs_lsop.hip, gvrs_lsop_decode.hip).  residuals: per tile resStride ints [initialisers | interior];
+// coefs: per tile 16 words (seed, 12 float bit patterns, 3 spare)
+hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, size_t resStride, uint32_t *coefs,
+                                  int32_t *status, size_t nTiles, int nRows, int nCols, hipStream_t stream);
+hipError_t gf_launch_canon_pack2(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
+                                 uint8_t *out, size_t slotStride, uint32_t *lengths, int32_t *status, size_t nTiles,
+                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream);
+hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
+                                      int32_t *values, int32_t *status, size_t nTiles, int nRows, int nCols,
+                                      hipStream_t stream);
+hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
+                                  const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
+                                  int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
+                                  hipStream_t stream);

@@ -1,0 +1,687 @@
+// gvrs_lsop.hip -- the LSOP12 codec (optimal 12-coefficient linear predictor) for a batch of tiles on gfx950.
+//
+// Reference (core/src/main/java/org/gridfour/):
+//   lsop/LsOptimalPredictor12.java:109-292   encode: initialiser stream, coefficients, interior stream
+//   lsop/LsOptimalPredictor12.java:311-383   computeCoefficients: 13x13 normal equations with a Lagrange row
+//   util/jama/LUDecomposition.java:70-134, 253-284   Crout LU with partial pivoting, solve
+//   lsop/LsEncoder12.java:122-219, lsop/LsHeader.java:210-265   container: header + canonical Huffman of the two
+//       integer streams in one bit store (compression type 2)
+//   lsop/LsDecoder12.java:94-160, 186-221, 311-383   decode
+//
+// Four kernels, all one tile per workgroup (k_lsop_reconstruct: one tile per WAVE):
+//   k_lsop_predict      tile -> seed, 12 float coefficients, residual ints [initialisers | interior]
+//   k_canon_pack2       header + CanonicalHuffman(initialisers) + CanonicalHuffman(interior) -> packing
+//   k_lsop_unpack2      packing -> seed, coefficients, residual ints (two canonical-Huffman streams back to back)
+//   k_lsop_reconstruct  residual ints -> tile: prefix sums for the border cells, then the interior as a
+//                       slope-3 wavefront (cell (r,c) needs (r-1,c+2) and (r-2,c+2): step = c + 3r)
+//
+// Floating point: the normal equations are accumulated in FP64.  When max|v|^2 * cells < 2^53 every partial sum
+// is an exact integer, so any order (and FMA) gives the reference's bits: lanes split the cells, waves split the
+// 104 accumulators.  Otherwise 104 threads own one accumulator each and add in the reference's scan order with
+// separately rounded multiply and add.  LU, solve and the float32 prediction follow the reference's operation
+// order exactly (no contraction: the library is built with -ffp-contract=off).
+
+#include <hip/hip_runtime.h>
+
+#include "gvrs_kernels.h"
+#include "gvrs_encode_layout.h"
+#include "huff_build.h"
+
+namespace {
+
+#include "gvrs_encode_common.h"
+#include "gvrs_canon_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// shared by predict and reconstruct
+// ------------------------------------------------------------------------------------------------
+
+// StrictMath.round(float): closest int, ties toward +infinity, NaN -> 0, saturating
+__device__ __forceinline__ int32_t lsop_round(float p)
+{
+    if (p != p) return 0;
+    const double f = floor((double)p + 0.5);
+    if (f >= 2147483647.0) return 2147483647;
+    if (f <= -2147483648.0) return (int32_t)0x80000000;
+    return (int32_t)f;
+}
+
+// u1*z1 + ... + u12*z12 in float32, left to right (LsOptimalPredictor12.java:254-267)
+__device__ __forceinline__ float lsop_predict12(const float *u, const int32_t *v, uint32_t idx, uint32_t nC)
+{
+    float p = u[0] * (float)v[idx - 1];
+    p = p + u[1] * (float)v[idx - nC - 1];
+    p = p + u[2] * (float)v[idx - nC];
+    p = p + u[3] * (float)v[idx - nC + 1];
+    p = p + u[4] * (float)v[idx - nC + 2];
+    p = p + u[5] * (float)v[idx - 2];
+    p = p + u[6] * (float)v[idx - nC - 2];
+    p = p + u[7] * (float)v[idx - 2 * nC - 2];
+    p = p + u[8] * (float)v[idx - 2 * nC - 1];
+    p = p + u[9] * (float)v[idx - 2 * nC];
+    p = p + u[10] * (float)v[idx - 2 * nC + 1];
+    p = p + u[11] * (float)v[idx - 2 * nC + 2];
+    return p;
+}
+
+// initialiser element k -> its cell and whether it is a plain difference (kind 0: left, 1: up) or a triangle
+// residual (kind 2); order of LsOptimalPredictor12.java:143-209
+__device__ __forceinline__ uint32_t lsop_init_cell(uint32_t k, uint32_t nR, uint32_t nC, uint32_t *kind)
+{
+    if (k < nC - 1u) { *kind = 0; return k + 1u; }
+    k -= nC - 1u;
+    if (k < nR - 1u) { *kind = 1; return (k + 1u) * nC; }
+    k -= nR - 1u;
+    *kind = 2;
+    if (k < nC - 1u) return nC + k + 1u;
+    k -= nC - 1u;
+    if (k < nR - 2u) return (k + 2u) * nC + 1u;
+    k -= nR - 2u;
+    return (2u + (k >> 1)) * nC + nC - 2u + (k & 1u);
+}
+
+__device__ __forceinline__ uint32_t lsop_n_init(uint32_t nR, uint32_t nC) { return 4u * nR + 2u * nC - 9u; }
+__device__ __forceinline__ uint32_t lsop_n_interior(uint32_t nR, uint32_t nC) { return (nR - 2u) * (nC - 4u); }
+
+// ------------------------------------------------------------------------------------------------
+// k_lsop_predict
+// ------------------------------------------------------------------------------------------------
+
+// the 104 accumulators: pairs (i, j) with i <= j over z0..z12 plus z13 = 1 (the plain sums), without (13,13)
+struct PairTab {
+    int8_t i[104], j[104];
+};
+constexpr PairTab make_pairs()
+{
+    PairTab t{};
+    int p = 0;
+    for (int i = 0; i < 13; i++)
+        for (int j = i; j < 14; j++) { t.i[p] = (int8_t)i; t.j[p] = (int8_t)j; p++; }
+    return t;
+}
+__device__ constexpr PairTab PAIRS = make_pairs();
+
+struct LsopShared {
+    double G[104];
+    double LU[13][13];
+    double X[13], col[13];
+    int piv[13];
+    float u[12];
+    uint32_t maxAbs;
+    int32_t status;
+    int32_t off[14];
+};
+
+// z_i of the cell at idx as an offset into the tile (LsOptimalPredictor12.java:322-334)
+__device__ __forceinline__ int32_t lsop_z_offset(int i, int32_t nC)
+{
+    switch (i) {
+    case 0: return 0;
+    case 1: return -1;
+    case 2: return -nC - 1;
+    case 3: return -nC;
+    case 4: return -nC + 1;
+    case 5: return -nC + 2;
+    case 6: return -2;
+    case 7: return -nC - 2;
+    case 8: return -2 * nC - 2;
+    case 9: return -2 * nC - 1;
+    case 10: return -2 * nC;
+    case 11: return -2 * nC + 1;
+    default: return -2 * nC + 2;
+    }
+}
+
+// fast path: wave W accumulates pairs [26 W, 26 W + 26) over the cells its lanes own
+template <int W>
+__device__ __forceinline__ void lsop_gram_wave(const int32_t *__restrict__ v, uint32_t nC, uint32_t nInt, double *G, int lane)
+{
+    double acc[26];
+#pragma unroll
+    for (int q = 0; q < 26; q++) acc[q] = 0.0;
+    const uint32_t wI = nC - 4u;
+    for (uint32_t e = (uint32_t)lane; e < nInt; e += 64) {
+        const uint32_t r = e / wI, c = e - r * wI;
+        const int32_t *p = v + (size_t)(r + 2u) * nC + (c + 2u);
+        const int32_t n = (int32_t)nC;
+        double z[14];
+        z[0] = (double)p[0];
+        z[1] = (double)p[-1];
+        z[2] = (double)p[-n - 1];
+        z[3] = (double)p[-n];
+        z[4] = (double)p[-n + 1];
+        z[5] = (double)p[-n + 2];
+        z[6] = (double)p[-2];
+        z[7] = (double)p[-n - 2];
+        z[8] = (double)p[-2 * n - 2];
+        z[9] = (double)p[-2 * n - 1];
+        z[10] = (double)p[-2 * n];
+        z[11] = (double)p[-2 * n + 1];
+        z[12] = (double)p[-2 * n + 2];
+        z[13] = 1.0;
+#pragma unroll
+        for (int q = 0; q < 26; q++) acc[q] += z[PAIRS.i[W * 26 + q]] * z[PAIRS.j[W * 26 + q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 26; q++) {
+        double a = acc[q];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) G[W * 26 + q] = a;
+    }
+}
+
+struct GfLsopPredictArgs {
+    const int32_t *values;
+    int32_t *residuals;        // per tile resStride ints: [initialisers | interior]
+    size_t resStride;
+    uint32_t *coefs;           // per tile 16 words: seed, 12 float bit patterns, 3 spare
+    int32_t *status;
+    size_t nTiles;
+    int nRows, nCols;
+};
+
+__global__ __launch_bounds__(256) void k_lsop_predict(GfLsopPredictArgs a)
+{
+    __shared__ LsopShared S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    const uint32_t nInit = lsop_n_init(nR, nC), nInt = lsop_n_interior(nR, nC);
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        const int32_t *__restrict__ v = a.values + t * (size_t)nCells;
+        int32_t *__restrict__ res = a.residuals + t * a.resStride;
+        if (tid == 0) { S.maxAbs = 0; S.status = GF_K_OK; }
+        __syncthreads();
+
+        // initialiser stream (:143-209) and max |v|
+        for (uint32_t k = tid; k < nInit; k += 256) {
+            uint32_t kind;
+            const uint32_t idx = lsop_init_cell(k, nR, nC, &kind);
+            const uint32_t x = (uint32_t)v[idx];
+            uint32_t r;
+            if (kind == 0) r = x - (uint32_t)v[idx - 1];
+            else if (kind == 1) r = x - (uint32_t)v[idx - nC];
+            else r = x - ((uint32_t)v[idx - 1] + (uint32_t)v[idx - nC] - (uint32_t)v[idx - nC - 1]);
+            res[k] = (int32_t)r;
+        }
+        uint32_t m = 0;
+        for (uint32_t i = tid; i < nCells; i += 256) {
+            const int32_t x = v[i];
+            m = max(m, x < 0 ? 0u - (uint32_t)x : (uint32_t)x);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if (lane == 0) atomicMax(&S.maxAbs, m);
+        __syncthreads();
+
+        // normal equations (:335-342)
+        const double bound = (double)S.maxAbs * (double)S.maxAbs * (double)nInt;
+        if (bound < 9007199254740992.0) {
+            if (wave == 0) lsop_gram_wave<0>(v, nC, nInt, S.G, lane);
+            else if (wave == 1) lsop_gram_wave<1>(v, nC, nInt, S.G, lane);
+            else if (wave == 2) lsop_gram_wave<2>(v, nC, nInt, S.G, lane);
+            else lsop_gram_wave<3>(v, nC, nInt, S.G, lane);
+        } else if (tid < 104) {
+            // inexact sums: one accumulator per thread, the reference's scan order, multiply and add rounded separately
+            const int pi = PAIRS.i[tid], pj = PAIRS.j[tid];
+            const int32_t oi = lsop_z_offset(pi, (int32_t)nC), oj = pj == 13 ? 0 : lsop_z_offset(pj, (int32_t)nC);
+            double acc = 0.0;
+            for (uint32_t r = 2; r < nR; r++) {
+                const int32_t *row = v + (size_t)r * nC;
+                for (uint32_t c = 2; c < nC - 2u; c++) {
+                    const double zi = (double)row[(int32_t)c + oi];
+                    const double zj = pj == 13 ? 1.0 : (double)row[(int32_t)c + oj];
+                    acc = __dadd_rn(acc, pj == 13 ? zi : __dmul_rn(zi, zj));
+                }
+            }
+            S.G[tid] = acc;
+        }
+        __syncthreads();
+
+        // 13x13 bordered system, LU, solve (:353-378; LUDecomposition.java:70-134, 253-284): one thread, the
+        // reference's operation order
+        if (tid == 0) {
+            auto Cij = [&](int i, int j) -> double {          // c[i][j], symmetric (:345-349)
+                if (i > j) { const int q = i; i = j; j = q; }
+                // pairs of row i start at sum_{k<i} (14 - k)
+                const int base = i * 14 - (i * (i - 1)) / 2;
+                return S.G[base + (j - i)];
+            };
+            auto Si = [&](int i) -> double { return S.G[i * 14 - (i * (i - 1)) / 2 + (13 - i)]; };
+            for (int i = 1; i < 13; i++) {
+                for (int j = 1; j < 13; j++) S.LU[i - 1][j - 1] = Cij(i, j);
+                S.LU[i - 1][12] = Si(i);
+            }
+            for (int j = 1; j < 13; j++) S.LU[12][j - 1] = Si(j);
+            S.LU[12][12] = 0.0;
+            double b[13];
+            for (int i = 1; i < 13; i++) b[i - 1] = Cij(0, i);
+            b[12] = Si(0);
+            for (int i = 0; i < 13; i++) S.piv[i] = i;
+            for (int j = 0; j < 13; j++) {
+                for (int i = 0; i < 13; i++) S.col[i] = S.LU[i][j];
+                for (int i = 0; i < 13; i++) {
+                    const int kmax = i < j ? i : j;
+                    double s = 0.0;
+                    for (int k = 0; k < kmax; k++) s = __dadd_rn(s, __dmul_rn(S.LU[i][k], S.col[k]));
+                    S.col[i] = __dsub_rn(S.col[i], s);
+                    S.LU[i][j] = S.col[i];
+                }
+                int p = j;
+                for (int i = j + 1; i < 13; i++)
+                    if (fabs(S.col[i]) > fabs(S.col[p])) p = i;
+                if (p != j) {
+                    for (int k = 0; k < 13; k++) { const double q = S.LU[p][k]; S.LU[p][k] = S.LU[j][k]; S.LU[j][k] = q; }
+                    const int q = S.piv[p]; S.piv[p] = S.piv[j]; S.piv[j] = q;
+                }
+                if (S.LU[j][j] != 0.0)
+                    for (int i = j + 1; i < 13; i++) S.LU[i][j] = __ddiv_rn(S.LU[i][j], S.LU[j][j]);
+            }
+            bool singular = false;
+            for (int j = 0; j < 13; j++) singular |= S.LU[j][j] == 0.0;
+            if (singular) {
+                S.status = GF_K_DECLINED;                       // "Matrix is singular." -> computeCoefficients returns null
+            } else {
+                for (int i = 0; i < 13; i++) S.X[i] = b[S.piv[i]];
+                for (int k = 0; k < 13; k++)
+                    for (int i = k + 1; i < 13; i++) S.X[i] = __dsub_rn(S.X[i], __dmul_rn(S.X[k], S.LU[i][k]));
+                for (int k = 12; k >= 0; k--) {
+                    S.X[k] = __ddiv_rn(S.X[k], S.LU[k][k]);
+                    for (int i = 0; i < k; i++) S.X[i] = __dsub_rn(S.X[i], __dmul_rn(S.X[k], S.LU[i][k]));
+                }
+                for (int i = 0; i < 12; i++) S.u[i] = (float)S.X[i];
+            }
+        }
+        __syncthreads();
+        if (S.status != GF_K_OK) {
+            if (tid == 0) a.status[t] = S.status;
+            __syncthreads();
+            continue;
+        }
+        float u[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) u[i] = S.u[i];
+        if (tid < 16) a.coefs[t * 16 + tid] = tid == 0 ? (uint32_t)v[0] : tid <= 12 ? __float_as_uint(S.u[tid - 1]) : 0u;
+
+        // interior stream (:248-272)
+        const uint32_t wI = nC - 4u;
+        for (uint32_t e = tid; e < nInt; e += 256) {
+            const uint32_t r = e / wI, c = e - r * wI;
+            const uint32_t idx = (r + 2u) * nC + c + 2u;
+            const int32_t est = lsop_round(lsop_predict12(u, v, idx, nC));
+            res[nInit + e] = (int32_t)((uint32_t)v[idx] - (uint32_t)est);
+        }
+        if (tid == 0) a.status[t] = GF_K_OK;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_canon_pack2: header + two canonical-Huffman streams in one bit store
+// ------------------------------------------------------------------------------------------------
+
+struct Pack2Persist {
+    uint32_t hist[2][CN_HIST];
+    uint32_t tab[2][CN_HIST];
+    uint32_t img[2][CN_IMG_WORDS];
+    unsigned long long textBits[2];
+    uint32_t imgBits[2];
+    uint32_t maxLen[2];
+    uint32_t maxKind[2];
+    uint32_t nGap[2];
+    uint32_t waveSum[ENC_WAVES];
+};
+
+union Pack2Union {
+    uint32_t histR[2][CN_HIST * HIST_R];
+    CanonScratch tree[2];
+    uint32_t win[WIN_WORDS + WIN_SLACK];
+};
+
+__device__ __forceinline__ uint32_t p2_elem_max_bits(uint32_t maxLen, uint32_t maxKind)
+{
+    if (maxKind == 0u) return maxLen;
+    if (maxKind <= 3u) return maxLen + maxKind * (maxLen + 2u);
+    return maxLen + 3u * (maxLen + 8u);
+}
+
+// text of one stream held as an int array
+__device__ void p2_pack_array(const int32_t *__restrict__ arr, uint32_t n, const uint32_t *tab, uint32_t elemMaxBits,
+                              uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t E = 4;
+    while (E > 1 && (uint64_t)ENC_THREADS * E * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u) E >>= 1;
+    uint32_t active = ENC_THREADS;
+    if ((uint64_t)ENC_THREADS * elemMaxBits > (uint64_t)(WIN_WORDS - 2) * 32u)
+        active = max(1u, (uint32_t)(((uint64_t)(WIN_WORDS - 2) * 32u) / elemMaxBits));
+    const uint32_t chunkElems = active * E;
+    for (uint32_t chunk = 0; chunk < n; chunk += chunkElems) {
+        uint32_t xs[4];
+        uint32_t myBits = 0;
+        const uint32_t s0 = chunk + tid * E;
+        const uint32_t cEnd = min(n, chunk + chunkElems);
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++) {
+            xs[e] = 0;
+            const uint32_t s = s0 + e;
+            if (e < E && tid < active && s < cEnd) {
+                xs[e] = (uint32_t)arr[s];
+                myBits += cn_value_bits(tab, xs[e]);
+            }
+        }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
+        if (myBits) {
+            BitSink sink;
+            sink.init(win, ps.bitBase + excl - ps.wordBase * 32u);
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                const uint32_t s = s0 + e;
+                if (e < E && tid < active && s < cEnd) cn_value_emit(sink, tab, xs[e]);
+            }
+            sink.finish();
+        }
+        __syncthreads();
+        ps.bitBase += total;
+        window_flush(win, out32, ps);
+    }
+}
+
+// appends nbits of the image (a bit string starting at bit 0 of img) and then the end-of-text code eot to the window
+__device__ void p2_append_bits(const uint32_t *img, uint32_t nbits, uint32_t *win, uint32_t *__restrict__ out32, PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t words = (nbits + 31u) >> 5;
+    const uint32_t base = ps.bitBase - ps.wordBase * 32u;
+    for (uint32_t i = tid; i < words; i += ENC_THREADS) {
+        const uint32_t nb = min(32u, nbits - i * 32u);
+        const uint32_t w = nb < 32u ? img[i] & ((1u << nb) - 1u) : img[i];
+        cn_img_or(win, base + i * 32u, w, nb);
+    }
+    __syncthreads();
+    ps.bitBase += nbits;
+    window_flush(win, out32, ps);
+}
+
+struct GfPack2Args {
+    const int32_t *residuals;  // per tile resStride ints: stream 0 (n0), stream 1 (n1)
+    size_t resStride;
+    const uint32_t *coefs;     // per tile 16 words: seed, 12 float bit patterns
+    const int32_t *inStatus;   // status of the predict stage (tiles it declined are passed through)
+    uint8_t *out;
+    size_t slotStride;
+    uint32_t *lengths;
+    int32_t *status;
+    size_t nTiles;
+    uint32_t n0, n1;
+    int codecIndex;
+};
+
+constexpr uint32_t LSOP_HEADER_BYTES = 55;     // LsHeader.packHeader :219-222 for the canonical container: 7 + 12*4
+
+__global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_pack2(GfPack2Args a)
+{
+    __shared__ Pack2Persist P;
+    __shared__ Pack2Union S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if (a.inStatus[t] != GF_K_OK) {
+            if (tid == 0) { a.lengths[t] = 0; a.status[t] = a.inStatus[t]; }
+            __syncthreads();
+            continue;
+        }
+        const int32_t *__restrict__ res = a.residuals + t * a.resStride;
+        uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
+
+        for (int i = tid; i < 2 * CN_HIST * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
+        if (tid < 2) { P.maxKind[tid] = 0; P.nGap[tid] = 0; }
+        __syncthreads();
+        const uint32_t rep = (uint32_t)lane & (HIST_R - 1);
+        for (int sidx = 0; sidx < 2; sidx++) {
+            const int32_t *arr = sidx == 0 ? res : res + a.n0;
+            const uint32_t n = sidx == 0 ? a.n0 : a.n1;
+            uint32_t *h = &S.histR[sidx][rep];
+            uint32_t mk = 0, gaps = 0;
+            for (uint32_t i = tid; i < n; i += ENC_THREADS) {
+                const uint32_t x = (uint32_t)arr[i];
+                if (x + 128u < 256u) { atomicAdd(h + (x + 128u) * HIST_R, 1u); continue; }
+                uint32_t kind;
+                const uint32_t target = cn_classify_count(x, &kind);
+                atomicAdd(h + target * HIST_R, 1u);
+                if (kind >= 1u && kind <= 3u) atomicAdd(h + CN_ESC2 * HIST_R, kind);
+                else if (kind >= 4u && kind <= 6u) atomicAdd(h + CN_ESC1 * HIST_R, kind - 3u);
+                if (cn_is_gap(x)) { gaps++; kind = 6u; }
+                mk = max(mk, kind == 7u ? 0u : kind);
+            }
+            if (mk) atomicMax(&P.maxKind[sidx], mk);
+            if (gaps) atomicAdd(&P.nGap[sidx], gaps);
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * CN_HIST; i += ENC_THREADS) {
+            const int p = i / CN_HIST, s = i - p * CN_HIST;
+            const uint32_t *h = &S.histR[p][0] + (size_t)s * HIST_R;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < HIST_R; k++) sum += h[k];
+            if (s == CN_EOT) sum = 1;
+            if (s >= CN_SYMS) sum = 0;
+            P.hist[p][s] = sum;
+        }
+        for (int i = tid; i < 2 * CN_IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
+        __syncthreads();
+        if (wave < 2) {
+            const CanonBuilt B = cn_build(S.tree[wave], P.hist[wave], P.nGap[wave], P.tab[wave], P.img[wave], lane);
+            if (lane == 0) { P.imgBits[wave] = B.imgBits; P.maxLen[wave] = B.maxLen; P.textBits[wave] = B.textBits; }
+        }
+        __syncthreads();
+
+        const unsigned long long totalBits =
+            8ull * LSOP_HEADER_BYTES + P.imgBits[0] + P.textBits[0] + P.imgBits[1] + P.textBits[1];
+        const unsigned long long bytes = (totalBits + 7) >> 3;
+        if (tid == 0) {
+            a.lengths[t] = (uint32_t)min(bytes, 0xffffffffull);
+            a.status[t] = bytes > a.slotStride ? GF_K_OVERFLOW : GF_K_OK;
+        }
+        if (bytes > a.slotStride) { __syncthreads(); continue; }
+
+        // header bytes (LsHeader.packHeader :224-246): codec index, type 2 | revision flag, 12, seed, 12 floats
+        for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) S.win[i] = 0;
+        __syncthreads();
+        if (tid < 14) {
+            const uint32_t *cf = a.coefs + t * 16;
+            // byte stream: [codec][0x42][12] then 13 little-endian words (seed, coefficients) from byte 3 on
+            if (tid == 0) atomicOr(&S.win[0], ((uint32_t)a.codecIndex & 0xffu) | (0x42u << 8) | (12u << 16));
+            if (tid < 13) {
+                const uint32_t w = cf[tid];
+                atomicOr(&S.win[tid], w << 24);
+                atomicOr(&S.win[tid + 1], w >> 8);
+            }
+        }
+        __syncthreads();
+        PackState ps;
+        ps.bitBase = 8u * LSOP_HEADER_BYTES;
+        ps.wordBase = 0;
+        window_flush(S.win, out32, ps);
+        for (int sidx = 0; sidx < 2; sidx++) {
+            const int32_t *arr = sidx == 0 ? res : res + a.n0;
+            const uint32_t n = sidx == 0 ? a.n0 : a.n1;
+            p2_append_bits(P.img[sidx], P.imgBits[sidx], S.win, out32, ps);
+            const uint32_t emb = max(1u, p2_elem_max_bits(P.maxLen[sidx], P.maxKind[sidx]));
+            p2_pack_array(arr, n, P.tab[sidx], emb, S.win, out32, P.waveSum, ps);
+            const uint32_t e = P.tab[sidx][CN_EOT];
+            if (tid == 0) cn_img_or(S.win, ps.bitBase - ps.wordBase * 32u, e & 0xffffu, e >> 16);
+            __syncthreads();
+            ps.bitBase += e >> 16;
+            window_flush(S.win, out32, ps);
+        }
+        {
+            const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
+            const uint32_t remWords = (remBits + 31u) >> 5;
+            const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
+            for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
+                if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = S.win[j];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_lsop_reconstruct: one tile per wave
+// ------------------------------------------------------------------------------------------------
+
+struct GfLsopReconArgs {
+    const int32_t *residuals;
+    size_t resStride;
+    const uint32_t *coefs;
+    const int32_t *inStatus;   // may be null; tiles with a status other than GF_K_OK are skipped
+    int32_t *values;
+    int32_t *status;
+    size_t nTiles;
+    int nRows, nCols;
+};
+
+__global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wavesPerGrid = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    const uint32_t nInit = lsop_n_init(nR, nC);
+    const uint32_t wI = nC - 4u;
+
+    for (size_t t = wid; t < a.nTiles; t += wavesPerGrid) {
+        if (a.inStatus && a.inStatus[t] != GF_K_OK) {
+            if (lane == 0) a.status[t] = a.inStatus[t];
+            continue;
+        }
+        const int32_t *__restrict__ res = a.residuals + t * a.resStride;
+        const int32_t *__restrict__ inter = res + nInit;
+        int32_t *v = a.values + t * (size_t)nCells;
+        const uint32_t *cf = a.coefs + t * 16;
+        const uint32_t seed = cf[0];
+        float u[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) u[i] = __uint_as_float(cf[1 + i]);
+
+        // LsDecoder12.unpackInitializers :186-221 as prefix sums
+        // row 0
+        {
+            uint32_t carry = seed;
+            if (lane == 0) v[0] = (int32_t)seed;
+            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                if (c < nC) v[c] = (int32_t)incl;
+                carry = (uint32_t)__shfl((int)incl, 63, 64);
+            }
+        }
+        // column 0
+        {
+            uint32_t carry = seed;
+            for (uint32_t r0 = 1; r0 < nR; r0 += 64) {
+                const uint32_t r = r0 + lane;
+                const uint32_t x = r < nR ? (uint32_t)res[nC - 1 + r - 1] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                if (r < nR) v[(size_t)r * nC] = (int32_t)incl;
+                carry = (uint32_t)__shfl((int)incl, 63, 64);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // row 1: v[1][c] - v[0][c] is a running sum of the triangle residuals, starting from v[1][0] - v[0][0]
+        {
+            uint32_t carry = (uint32_t)v[nC] - (uint32_t)v[0];
+            const uint32_t base = nC - 1u + nR - 1u;
+            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const uint32_t x = c < nC ? (uint32_t)res[base + c - 1] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                if (c < nC) v[nC + c] = (int32_t)(incl + (uint32_t)v[c]);
+                carry = (uint32_t)__shfl((int)incl, 63, 64);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // column 1, rows 2..: v[r][1] - v[r][0] is a running sum, starting from v[1][1] - v[1][0]
+        {
+            uint32_t carry = (uint32_t)v[nC + 1] - (uint32_t)v[nC];
+            const uint32_t base = 2u * (nC - 1u) + nR - 1u;
+            for (uint32_t r0 = 2; r0 < nR; r0 += 64) {
+                const uint32_t r = r0 + lane;
+                const uint32_t x = r < nR ? (uint32_t)res[base + r - 2] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                if (r < nR) v[(size_t)r * nC + 1] = (int32_t)(incl + (uint32_t)v[(size_t)r * nC]);
+                carry = (uint32_t)__shfl((int)incl, 63, 64);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        // interior and the last two columns: LsDecoder12.unpackInterior :311-383 as a wavefront, step = c + 3 r
+        const uint32_t tailBase = 2u * (nC - 1u) + nR - 1u + nR - 2u;
+        const uint32_t sEnd = (nC - 1u) + 3u * (nR - 1u);
+        for (uint32_t s = 8; s <= sEnd; s++) {
+            for (uint32_t r0 = 2; r0 < nR; r0 += 64) {
+                const uint32_t r = r0 + lane;
+                if (r < nR && s >= 3u * r + 2u && s - 3u * r <= nC - 1u) {
+                    const uint32_t c = s - 3u * r;
+                    const uint32_t idx = r * nC + c;
+                    uint32_t val;
+                    if (c <= nC - 3u) {
+                        const int32_t est = lsop_round(lsop_predict12(u, v, idx, nC));
+                        val = (uint32_t)est + (uint32_t)inter[(r - 2u) * wI + (c - 2u)];
+                    } else {
+                        const uint32_t x = (uint32_t)res[tailBase + 2u * (r - 2u) + (c - (nC - 2u))];
+                        val = x + ((uint32_t)v[idx - 1] + (uint32_t)v[idx - nC] - (uint32_t)v[idx - nC - 1]);
+                    }
+                    v[idx] = (int32_t)val;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) a.status[t] = GF_K_OK;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+
+hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, size_t resStride, uint32_t *coefs,
+                                  int32_t *status, size_t nTiles, int nRows, int nCols, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    GfLsopPredictArgs a{values, residuals, resStride, coefs, status, nTiles, nRows, nCols};
+    const unsigned grid = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
+    hipLaunchKernelGGL(k_lsop_predict, dim3(grid), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_canon_pack2(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
+                                 uint8_t *out, size_t slotStride, uint32_t *lengths, int32_t *status, size_t nTiles,
+                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    GfPack2Args a{residuals, resStride, coefs, inStatus, out, slotStride, lengths, status, nTiles, n0, n1, codecIndex};
+    const unsigned grid = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
+    hipLaunchKernelGGL(k_canon_pack2, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
+                                      int32_t *values, int32_t *status, size_t nTiles, int nRows, int nCols,
+                                      hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    GfLsopReconArgs a{residuals, resStride, coefs, inStatus, values, status, nTiles, nRows, nCols};
+    const size_t wgs = (nTiles + 3) / 4;
+    const unsigned grid = (unsigned)(wgs < 65536 * 16 ? wgs : 65536 * 16);
+    hipLaunchKernelGGL(k_lsop_reconstruct, dim3(grid), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}

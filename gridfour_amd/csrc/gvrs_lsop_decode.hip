@@ -1,0 +1,125 @@
+// gvrs_lsop_decode.hip -- entropy stage of LsDecoder12.decode for the canonical-Huffman container
+// (lsop/LsDecoder12.java:107-119, lsop/LsHeader.java:131-185): header, then two CanonicalHuffman streams in one
+// bit store (initialisers, interior).  Output: seed + coefficients and the residual ints that
+// k_lsop_reconstruct (gvrs_lsop.hip) turns into the tile.  Containers of type 0 (legacy Huffman of M32) and
+// type 1 (Deflate of M32) are not entropy-decoded here: the host API inflates type 1 with zlib and reports
+// type 0 as unsupported.
+
+#include <hip/hip_runtime.h>
+
+#include "gvrs_kernels.h"
+#include "huff_build.h"
+
+namespace {
+
+constexpr int DEC_THREADS = 256;
+constexpr int DEC_WAVES = DEC_THREADS / 64;
+
+#include "gvrs_decode_common.h"
+#include "gvrs_canon_decode_common.h"
+
+struct GfLsopUnpackArgs {
+    const uint8_t *blob;
+    size_t blobBytes;
+    const uint64_t *offsets;
+    size_t slotStride;
+    const uint32_t *lengths;
+    int32_t *residuals;
+    size_t resStride;
+    uint32_t *coefs;
+    int32_t *status;
+    size_t nTiles;
+    int nRows, nCols;
+    uint32_t ldsTextBytes;
+};
+
+__global__ __launch_bounds__(DEC_THREADS) void k_lsop_unpack2(GfLsopUnpackArgs a)
+{
+    __shared__ CanonDec S;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsText[];
+
+    const int tid = threadIdx.x;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols;
+    const uint32_t nInit = 4u * nR + 2u * nC - 9u, nInt = (nR - 2u) * (nC - 4u);
+    const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);
+    const uint64_t nWords = (a.blobBytes + 3) >> 2;
+    const uint32_t capWords = a.ldsTextBytes >> 2;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
+        const uint32_t len = a.lengths[t];
+        const uint8_t *__restrict__ pk = a.blob + off;
+        int32_t *res = a.residuals + t * a.resStride;
+
+        int32_t early = GF_K_OK;
+        if (len < 3 || off + len > a.blobBytes) early = GF_K_ERR_BOUNDS;
+        else if (!(pk[1] & 0x40)) early = GF_K_ERR_UNSUPPORTED;            // legacy header (LsHeader.java:139-160)
+        else if ((pk[1] & 0x0f) != 2) early = GF_K_ERR_UNSUPPORTED;        // Huffman-of-M32 / Deflate containers
+        else if (pk[2] != 12) early = GF_K_ERR_FORMAT;                     // u[11] would index out of bounds
+        else {
+            const uint32_t hdr = 55u + ((pk[1] & 0x80) ? 4u : 0u);         // value checksum, if present, is skipped
+            if (len < hdr) early = GF_K_ERR_BOUNDS;
+        }
+        if (early != GF_K_OK) {
+            if (tid == 0) a.status[t] = early;
+            __syncthreads();
+            continue;
+        }
+        const uint32_t hdr = 55u + ((pk[1] & 0x80) ? 4u : 0u);
+        if (tid < 13) {
+            const uint8_t *p = pk + 3 + 4 * tid;
+            a.coefs[t * 16 + tid] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        }
+
+        const uint64_t word0 = off >> 2;
+        const uint32_t bias = (uint32_t)(off & 3u) * 8u;
+        const uint32_t endBit = bias + len * 8u;
+        const uint32_t needWords = (endBit + 31u) / 32u + 2u;
+        CdText T;
+        if (needWords <= capWords) {
+            for (uint32_t i = tid; i < needWords; i += DEC_THREADS) {
+                uint32_t w = word0 + i < nWords ? w32[word0 + i] : 0u;
+                const uint32_t b0 = i * 32u;
+                if (b0 + 32u > endBit) w = b0 >= endBit ? 0u : (w & ((1u << (endBit - b0)) - 1u));
+                ldsText[i] = w;
+            }
+            T.w = ldsText;
+            T.nWords = needWords;
+        } else {
+            T.w = w32 + word0;
+            T.nWords = (uint32_t)min((uint64_t)needWords, nWords - word0);
+        }
+        __syncthreads();
+
+        uint32_t pos = bias + hdr * 8u, nv;
+        auto sink0 = [&](uint32_t k, uint32_t v) { if (k < nInit) res[k] = (int32_t)v; };
+        int32_t st = cd_decode_stream(S, T, pos, endBit, nInit, nInit, sink0, &pos, &nv);
+        if (st == GF_K_OK) {
+            auto sink1 = [&](uint32_t k, uint32_t v) { if (k < nInt) res[nInit + k] = (int32_t)v; };
+            st = cd_decode_stream(S, T, pos, endBit, nInt, nInt, sink1, &pos, &nv);
+        }
+        if (tid == 0) a.status[t] = st;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
+                                  const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
+                                  int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
+                                  hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    GfLsopUnpackArgs a{blob, blobBytes, offsets, slotStride, lengths, residuals, resStride, coefs, status, nTiles, nRows, nCols,
+                       ldsTextBytes};
+    static size_t maxDynSet = 0;
+    if (ldsTextBytes > maxDynSet) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsop_unpack2),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTextBytes);
+        if (e != hipSuccess) return e;
+        maxDynSet = ldsTextBytes;
+    }
+    hipLaunchKernelGGL(k_lsop_unpack2, dim3(grid), dim3(DEC_THREADS), ldsTextBytes, stream, a);
+    return hipGetLastError();
+}

@@ -166,6 +166,48 @@ gf_status gf_canon_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_row
                                         size_t slot_stride, const uint32_t *d_lengths, int32_t *d_values,
                                         int32_t *d_status);
 
+/* ---- LSOP12 (lsop/LsEncoder12.java:122-219, lsop/LsDecoder12.java:94-160, lsop/LsOptimalPredictor12.java:109-383,
+ * lsop/LsHeader.java:131-265, util/jama/LUDecomposition.java:70-134, 253-284): the optimal 12-coefficient linear
+ * predictor.  Tiles need at least 6 rows and 6 columns (else GF_DECLINED, Java null); a singular system is GF_DECLINED too.
+ *   residuals: per tile res_stride ints (>= gf_lsop12_residual_count): [4R+2C-9 initialisers | (R-2)(C-4) interior]
+ *   coefs:     per tile 16 words: seed, the 12 float32 coefficients as bit patterns, 3 spare
+ * The encoder writes the current container: header (LsHeader.packHeader) + CanonicalHuffman of the two integer streams
+ * in one bit store (compression type 2).  The Deflate alternative (type 1, LsEncoder12.java:180-216) is produced by the
+ * host entry points with the host's zlib when deflate_enabled != 0 (the reference's default).  Decoding accepts types
+ * 2 (GPU) and 1 (zlib on the host, tile rebuilt on the GPU), with either header revision; type 0, the legacy
+ * Huffman-of-M32 container of old Gridfour versions, is GF_ERR_UNSUPPORTED.                                          */
+size_t gf_lsop12_residual_count(int n_rows, int n_cols);
+size_t gf_lsop12_max_packing(int n_rows, int n_cols);
+/* LsOptimalPredictor12.encode: tile -> coefficients + residual streams (d_status: GF_OK / GF_DECLINED per tile) */
+gf_status gf_lsop12_predict_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                const int32_t *d_values, int32_t *d_residuals, size_t res_stride, uint32_t *d_coefs,
+                                int32_t *d_status);
+/* LsDecoder12.unpackInitializers + unpackInterior: residual streams -> tile.  d_in_status (may be NULL): tiles whose
+ * entry is not GF_OK are skipped and that value is passed through to d_status.                                     */
+gf_status gf_lsop12_reconstruct_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                    const int32_t *d_residuals, size_t res_stride, const uint32_t *d_coefs,
+                                    const int32_t *d_in_status, int32_t *d_values, int32_t *d_status);
+/* device-resident batches; d_residuals / d_coefs / d_scratch_status (n_tiles ints) are caller-provided work buffers */
+gf_status gf_lsop12_encode_batch_i32_dev(gf_context *ctx, void *stream, int codec_index, int n_rows, int n_cols,
+                                         size_t n_tiles, const int32_t *d_values, uint8_t *d_out, size_t slot_stride,
+                                         uint32_t *d_lengths, int32_t *d_status, int32_t *d_residuals, size_t res_stride,
+                                         uint32_t *d_coefs, int32_t *d_scratch_status);
+gf_status gf_lsop12_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                         const uint8_t *d_blob, size_t blob_bytes, const uint64_t *d_offsets,
+                                         size_t slot_stride, const uint32_t *d_lengths, int32_t *d_values,
+                                         int32_t *d_status, int32_t *d_residuals, size_t res_stride, uint32_t *d_coefs,
+                                         int32_t *d_scratch_status);
+/* host memory: replace LsEncoder12.encode / LsDecoder12.decode.  types[n_tiles] (optional): container type written */
+gf_status gf_lsop12_encode_batch_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                     const int32_t *values, int deflate_enabled, uint8_t *blob, size_t blob_cap,
+                                     uint64_t *offsets, uint8_t *types, int32_t *status);
+gf_status gf_lsop12_decode_batch_i32(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                     const uint64_t *offsets, int32_t *values, int32_t *status);
+gf_status gf_lsop12_encode_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols, const int32_t *values,
+                               int deflate_enabled, uint8_t *out, size_t out_cap, size_t *out_len);
+gf_status gf_lsop12_decode_i32(gf_context *ctx, int n_rows, int n_cols, const uint8_t *packing, size_t packing_len,
+                               int32_t *values);
+
 /* ---- CodecFloat (compress/CodecFloat.java:328-458): float32 tiles ---------------------------
  * The five byte planes (sign bits, exponent, three byte-delta coded mantissa bytes) are split and
  * merged on the GPU; the Deflate stage of each plane runs on the host's zlib (its bytes are defined

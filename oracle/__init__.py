@@ -397,7 +397,7 @@ def codec_canon_decode(n_rows, n_cols, packing):
 def batch_canon_encode(codec_index, n_rows, n_cols, tiles, stride=None):
     v = _i32(tiles).reshape(-1, n_rows * n_cols)
     nt = v.shape[0]
-    stride = stride or int(lib().gvo_codec_canon_bound(n_rows * n_cols))
+    stride = stride or (4 * n_rows * n_cols + 4096)
     out = np.zeros(nt * stride, np.uint8)
     ln = np.zeros(nt, np.uint32)
     pr = np.zeros(nt, np.uint8)
