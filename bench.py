@@ -48,8 +48,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="etopo1", choices=sorted(WORKLOADS))
-    ap.add_argument("--codec", default="huffman", choices=["huffman", "canon"],
-                    help="huffman = CodecHuffman (the north-star path, default); canon = CodecCanonHuffman")
+    ap.add_argument("--codec", default="huffman", choices=["huffman", "canon", "lsop"],
+                    help="huffman = CodecHuffman (the north-star path, default); canon = CodecCanonHuffman; lsop = LSOP12, canonical container")
     ap.add_argument("--cpu-sample-tiles", type=int, default=-1, help="tiles timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exactness checks")
     return ap.parse_args()
@@ -158,8 +158,12 @@ def main():
         sample = list(range(0, n_tiles, max(1, n_tiles // 64)))[:64]
         parity_ok = True
         for t in sample:
-            ref, used = (oracle.codec_canon_encode if args.codec == "canon" else oracle.codec_huffman_encode)(
-                0, n_rows, n_cols, vals[t])
+            if args.codec == "lsop":
+                ref, _ = oracle.lsop12_encode(0, n_rows, n_cols, vals[t], False)
+                used = preds[t]
+            else:
+                ref, used = (oracle.codec_canon_encode if args.codec == "canon" else oracle.codec_huffman_encode)(
+                    0, n_rows, n_cols, vals[t])
             if ref != batch.get_packing(t, int(lengths[t])) or used != preds[t]:
                 parity_ok = False
                 break
@@ -172,12 +176,16 @@ def main():
         if ns > 0 and world == 1:
             sub = vals[:ns]
             c0 = time.perf_counter()
-            if args.codec == "canon":
+            if args.codec == "lsop":
+                out, ln = oracle.batch_lsop12_encode(0, n_rows, n_cols, sub)
+            elif args.codec == "canon":
                 out, ln, _ = oracle.batch_canon_encode(0, n_rows, n_cols, sub)
             else:
                 out, ln, _ = oracle.batch_huffman_encode(0, n_rows, n_cols, sub)
             c1 = time.perf_counter()
-            if args.codec == "canon":
+            if args.codec == "lsop":
+                dec = oracle.batch_lsop12_decode(n_rows, n_cols, out, ln)
+            elif args.codec == "canon":
                 dec = oracle.batch_canon_decode(n_rows, n_cols, out, ln)
             else:
                 dec = oracle.batch_huffman_decode(n_rows, n_cols, out, ln)
@@ -202,7 +210,7 @@ def main():
     enc_avg, dec_avg = float(np.mean(enc_ms)), float(np.mean(dec_ms))
     # algorithmic bytes per launch: encode reads 4 B/cell and writes c; decode reads c, writes 4
     alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
-    kname = "k_canon" if args.codec == "canon" else "k_huffman"
+    kname = {"canon": "k_canon", "lsop": "lsop", "huffman": "k_huffman"}[args.codec]
     dom_name, dom_ms = (kname + "_decode", dec_avg) if dec_avg >= enc_avg else (kname + "_encode", enc_avg)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     traffic = _pmc_traffic(args.workload, dom_name)
@@ -220,8 +228,9 @@ def main():
         "dtype": "int32",
         "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, descr), "tile_rows": n_rows, "tile_cols": n_cols,
-                   "tiles_per_gpu": n_tiles, "codec": ("CodecCanonHuffman (Differencing/Linear/Triangle + canonical Huffman)" if args.codec == "canon"
-                             else "CodecHuffman (Differencing/Linear/Triangle + M32 + Huffman)"),
+                   "tiles_per_gpu": n_tiles, "codec": {"canon": "CodecCanonHuffman (Differencing/Linear/Triangle + canonical Huffman)",
+                             "lsop": "LSOP12 (12-coefficient optimal predictor + canonical Huffman container)",
+                             "huffman": "CodecHuffman (Differencing/Linear/Triangle + M32 + Huffman)"}[args.codec],
                    "sharding": "contiguous tile ranges, no collective"},
         "bit_exact": bit_exact,
         "compressed_bytes_per_cell": round(c_per_cell, 4),

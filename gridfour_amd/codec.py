@@ -207,7 +207,7 @@ class DeviceTileBatch:
     """
 
     def __init__(self, ctx, n_rows, n_cols, n_tiles, slot_stride=None, codec="huffman"):
-        assert codec in ("huffman", "canon")
+        assert codec in ("huffman", "canon", "lsop")
         self.codec = codec
         self.ctx, self.n_rows, self.n_cols, self.n_tiles = ctx, int(n_rows), int(n_cols), int(n_tiles)
         self.cells = self.n_rows * self.n_cols
@@ -222,18 +222,38 @@ class DeviceTileBatch:
         self.enc_status = DeviceBuffer(ctx, nt * 4)
         self.dec_status = DeviceBuffer(ctx, nt * 4)
         ctx.reserve(n_rows, n_cols, nt)
+        if codec == "lsop":                          # work buffers of the LSOP stages
+            n = int(lib().gf_lsop12_residual_count(n_rows, n_cols))
+            self.res_stride = (n + 3) // 4 * 4
+            self.residuals = DeviceBuffer(ctx, nt * self.res_stride * 4 + 16)
+            self.coefs = DeviceBuffer(ctx, nt * 64)
+            self.scratch_status = DeviceBuffer(ctx, nt * 4)
 
     def synth_dem(self, seed, tiles_per_row, tile0=0, stream=None):
         check(lib().gf_synth_dem_dev(self.ctx.handle, stream, seed & (2 ** 64 - 1), self.n_rows, self.n_cols,
                                      tiles_per_row, tile0, self.n_tiles, self.values.ptr), "gf_synth_dem_dev")
 
     def encode(self, codec_index=0, predictor_mask=_lib.PM_ALL, stream=None):
+        if self.codec == "lsop":
+            check(lib().gf_lsop12_encode_batch_i32_dev(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols,
+                                                       self.n_tiles, self.values.ptr, self.slots.ptr, self.stride,
+                                                       self.lengths.ptr, self.enc_status.ptr, self.residuals.ptr,
+                                                       self.res_stride, self.coefs.ptr, self.scratch_status.ptr),
+                  "gf_lsop12_encode_batch_i32_dev")
+            return
         fn = getattr(lib(), "gf_%s_encode_batch_i32_dev" % self.codec)
         check(fn(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols, self.n_tiles, self.values.ptr,
                  self.slots.ptr, self.stride, self.lengths.ptr, self.predictors.ptr, self.enc_status.ptr,
                  predictor_mask), "gf_%s_encode_batch_i32_dev" % self.codec)
 
     def decode(self, stream=None):
+        if self.codec == "lsop":
+            check(lib().gf_lsop12_decode_batch_i32_dev(self.ctx.handle, stream, self.n_rows, self.n_cols, self.n_tiles,
+                                                       self.slots.ptr, self.n_tiles * self.stride, None, self.stride,
+                                                       self.lengths.ptr, self.decoded.ptr, self.dec_status.ptr,
+                                                       self.residuals.ptr, self.res_stride, self.coefs.ptr,
+                                                       self.scratch_status.ptr), "gf_lsop12_decode_batch_i32_dev")
+            return
         fn = getattr(lib(), "gf_%s_decode_batch_i32_dev" % self.codec)
         check(fn(self.ctx.handle, stream, self.n_rows, self.n_cols, self.n_tiles, self.slots.ptr,
                  self.n_tiles * self.stride, None, self.stride, self.lengths.ptr, self.decoded.ptr,

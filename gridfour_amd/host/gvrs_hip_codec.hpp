@@ -197,4 +197,96 @@ private:
     int level_;
 };
 
+/** Drop-in for org.gridfour.compress.canonicalHuffman.CodecCanonHuffman (CodecCanonHuffman.java:70-195), the default
+ *  integer codec of current Gridfour. */
+class CodecCanonHuffmanHip : public ICompressionEncoder, public ICompressionDecoder {
+public:
+    explicit CodecCanonHuffmanHip(int device = 0)
+    {
+        const gf_status s = gf_context_create(device, &ctx_);
+        if (s != GF_OK) throw std::runtime_error(std::string("CodecCanonHuffmanHip: ") + gf_status_string(s) + " [" + gf_last_error() + "]");
+    }
+    ~CodecCanonHuffmanHip() override { gf_context_destroy(ctx_); }
+    CodecCanonHuffmanHip(const CodecCanonHuffmanHip &) = delete;
+    CodecCanonHuffmanHip &operator=(const CodecCanonHuffmanHip &) = delete;
+
+    std::optional<std::vector<uint8_t>> encode(int codecIndex, int nRows, int nCols, const std::vector<int32_t> &values) override
+    {
+        if ((size_t)nRows * (size_t)nCols != values.size()) throw std::invalid_argument("values.length != nRows*nCols");
+        std::vector<uint8_t> out(gf_canon_max_packing(nRows, nCols));
+        size_t n = 0;
+        const gf_status s = gf_canon_encode_i32(ctx_, codecIndex, nRows, nCols, values.data(), out.data(), out.size(), &n);
+        if (s == GF_DECLINED) return std::nullopt;                       // CodecCanonHuffman.java:85-87
+        if (s == GF_ERR_BOUNDS) throw ArrayIndexOutOfBoundsException("PredictorModelLinear needs nCols >= 2");
+        if (s == GF_ERR_ARG) throw std::invalid_argument("Empty or null data input data");   // CanonicalHuffman.java:183-185
+        if (s < 0) throw std::runtime_error(std::string("gf_canon_encode_i32: ") + gf_status_string(s));
+        out.resize(n);
+        return out;
+    }
+    std::optional<std::vector<uint8_t>> encodeFloats(int, int, int, const std::vector<float> &) override { return std::nullopt; }
+    bool implementsFloatingPointEncoding() const override { return false; }
+    bool implementsIntegerEncoding() const override { return true; }
+    std::vector<int32_t> decode(int nRows, int nColumns, const std::vector<uint8_t> &packing) override
+    {
+        std::vector<int32_t> out((size_t)nRows * (size_t)nColumns);
+        const gf_status s = gf_canon_decode_i32(ctx_, nRows, nColumns, packing.data(), packing.size(), out.data());
+        if (s == GF_ERR_FORMAT || s == GF_ERR_BOUNDS) throw IOException(gf_status_string(s));
+        if (s < 0) throw std::runtime_error(std::string("gf_canon_decode_i32: ") + gf_status_string(s));
+        return out;
+    }
+    std::optional<std::vector<float>> decodeFloats(int, int, const std::vector<uint8_t> &) override { return std::nullopt; }
+    void analyze(int, int, const std::vector<uint8_t> &) override {}
+    void reportAnalysisData(std::FILE *ps, int) override { std::fprintf(ps, "GVRS Canonical Huffman (HIP)\n"); }
+    void clearAnalysisData() override {}
+
+private:
+    gf_context *ctx_ = nullptr;
+};
+
+/** Drop-in for org.gridfour.lsop.LsEncoder12 + LsDecoder12 (codec id "LSOP12"). */
+class LsCodecHip : public ICompressionEncoder, public ICompressionDecoder {
+public:
+    explicit LsCodecHip(int device = 0, bool deflateEnabled = true) : deflate_(deflateEnabled)
+    {
+        const gf_status s = gf_context_create(device, &ctx_);
+        if (s != GF_OK) throw std::runtime_error(std::string("LsCodecHip: ") + gf_status_string(s) + " [" + gf_last_error() + "]");
+    }
+    ~LsCodecHip() override { gf_context_destroy(ctx_); }
+    LsCodecHip(const LsCodecHip &) = delete;
+    LsCodecHip &operator=(const LsCodecHip &) = delete;
+    void setDeflateEnabled(bool enabled) { deflate_ = enabled; }         // LsEncoder12.java:94-96
+
+    std::optional<std::vector<uint8_t>> encode(int codecIndex, int nRows, int nCols, const std::vector<int32_t> &values) override
+    {
+        if ((size_t)nRows * (size_t)nCols != values.size()) throw std::invalid_argument("values.length != nRows*nCols");
+        std::vector<uint8_t> out(gf_lsop12_max_packing(nRows, nCols) + 64);
+        size_t n = 0;
+        const gf_status s = gf_lsop12_encode_i32(ctx_, codecIndex, nRows, nCols, values.data(), deflate_ ? 1 : 0, out.data(),
+                                                 out.size(), &n);
+        if (s == GF_DECLINED) return std::nullopt;                       // LsEncoder12.java:124-127
+        if (s < 0) throw std::runtime_error(std::string("gf_lsop12_encode_i32: ") + gf_status_string(s));
+        out.resize(n);
+        return out;
+    }
+    std::optional<std::vector<uint8_t>> encodeFloats(int, int, int, const std::vector<float> &) override { return std::nullopt; }
+    bool implementsFloatingPointEncoding() const override { return false; }
+    bool implementsIntegerEncoding() const override { return true; }
+    std::vector<int32_t> decode(int nRows, int nColumns, const std::vector<uint8_t> &packing) override
+    {
+        std::vector<int32_t> out((size_t)nRows * (size_t)nColumns);
+        const gf_status s = gf_lsop12_decode_i32(ctx_, nRows, nColumns, packing.data(), packing.size(), out.data());
+        if (s == GF_ERR_FORMAT || s == GF_ERR_BOUNDS) throw IOException(gf_status_string(s));
+        if (s < 0) throw std::runtime_error(std::string("gf_lsop12_decode_i32: ") + gf_status_string(s));
+        return out;
+    }
+    std::optional<std::vector<float>> decodeFloats(int, int, const std::vector<uint8_t> &) override { return std::nullopt; }
+    void analyze(int, int, const std::vector<uint8_t> &) override {}
+    void reportAnalysisData(std::FILE *ps, int) override { std::fprintf(ps, "LSOP12 (HIP)\n"); }
+    void clearAnalysisData() override {}
+
+private:
+    gf_context *ctx_ = nullptr;
+    bool deflate_;
+};
+
 }  // namespace gridfour

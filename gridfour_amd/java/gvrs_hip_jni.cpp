@@ -101,4 +101,77 @@ JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(J
     return result;
 }
 
+
+// ---- org.gridfour.hip.HipCodecNative: the same two calls for every integer codec of the library ----
+// kind 0 = CodecHuffman, 1 = CodecCanonHuffman, 2 = LSOP12 (Deflate alternative disabled), 3 = LSOP12 (reference default)
+JNIEXPORT jlong JNICALL Java_org_gridfour_hip_HipCodecNative_create(JNIEnv *env, jclass cls, jint device)
+{
+    return Java_org_gridfour_hip_CodecHuffmanHip_createNative(env, cls, device);
+}
+
+JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_destroy(JNIEnv *env, jclass cls, jlong handle)
+{
+    Java_org_gridfour_hip_CodecHuffmanHip_destroyNative(env, cls, handle);
+}
+
+JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_encode(JNIEnv *env, jclass, jlong handle, jint kind,
+                                                                         jint codecIndex, jint nRows, jint nCols, jintArray values)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    const size_t cap = kind == 0 ? gf_huffman_max_packing(nRows, nCols)
+                     : kind == 1 ? gf_canon_max_packing(nRows, nCols) : gf_lsop12_max_packing(nRows, nCols) + 64;
+    jbyte *out = new jbyte[cap];
+    size_t n = 0;
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        jint *v = (jint *)env->GetPrimitiveArrayCritical(values, nullptr);
+        if (kind == 0) s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
+        else if (kind == 1) s = gf_canon_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
+        else s = gf_lsop12_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, kind == 3, (uint8_t *)out, cap, &n);
+        env->ReleasePrimitiveArrayCritical(values, v, JNI_ABORT);
+    }
+    jbyteArray result = nullptr;
+    if (s == GF_OK) {
+        result = env->NewByteArray((jsize)n);
+        if (result) env->SetByteArrayRegion(result, 0, (jsize)n, out);
+    } else if (s == GF_ERR_BOUNDS) {
+        jclass c = env->FindClass("java/lang/ArrayIndexOutOfBoundsException");
+        if (c) env->ThrowNew(c, "tile has fewer than 2 columns");
+    } else if (s == GF_ERR_ARG && kind == 1) {
+        jclass c = env->FindClass("java/lang/IllegalArgumentException");      // CanonicalHuffman.java:183-185
+        if (c) env->ThrowNew(c, "Empty or null data input data");
+    } else if (s != GF_DECLINED) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, gf_status_string(s));
+    }
+    delete[] out;
+    return result;
+}
+
+JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_HipCodecNative_decode(JNIEnv *env, jclass, jlong handle, jint kind, jint nRows,
+                                                                        jint nCols, jbyteArray packing)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    const jsize len = env->GetArrayLength(packing);
+    jintArray result = env->NewIntArray(nRows * nCols);
+    if (!result) return nullptr;
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        jbyte *p = (jbyte *)env->GetPrimitiveArrayCritical(packing, nullptr);
+        jint *o = (jint *)env->GetPrimitiveArrayCritical(result, nullptr);
+        if (kind == 0) s = gf_huffman_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
+        else if (kind == 1) s = gf_canon_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
+        else s = gf_lsop12_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
+        env->ReleasePrimitiveArrayCritical(result, o, 0);
+        env->ReleasePrimitiveArrayCritical(packing, p, JNI_ABORT);
+    }
+    if (s != GF_OK) {
+        throwIo(env, gf_status_string(s));
+        return nullptr;
+    }
+    return result;
+}
+
 }  // extern "C"

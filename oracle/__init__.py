@@ -476,3 +476,29 @@ def lsop12_decode(n_rows, n_cols, packing):
     if rc != OK:
         raise IOError("lsop12_decode rc=%d" % rc)
     return out
+
+
+def batch_lsop12_encode(codec_index, n_rows, n_cols, tiles, deflate_enabled=False, stride=None):
+    v = _i32(tiles).reshape(-1, n_rows * n_cols)
+    nt = v.shape[0]
+    stride = stride or (4 * n_rows * n_cols + 4096)
+    out = np.zeros(nt * stride, np.uint8)
+    ln = np.zeros(nt, np.uint32)
+    ty = np.zeros(nt, np.uint8)
+    rc = lib().gvo_batch_lsop12_encode(codec_index, n_rows, n_cols, nt, _p(v, C.c_int32), int(deflate_enabled),
+                                       _p(out, C.c_uint8), stride, _p(ln, C.c_uint32), _p(ty, C.c_uint8))
+    if rc != OK:
+        raise ValueError("batch_lsop12_encode rc=%d" % rc)
+    return out.reshape(nt, stride), ln
+
+
+def batch_lsop12_decode(n_rows, n_cols, slots, lengths):
+    s = np.ascontiguousarray(slots, np.uint8)
+    nt, stride = s.shape
+    ln = np.ascontiguousarray(lengths, np.uint32)
+    out = np.zeros((nt, n_rows * n_cols), np.int32)
+    rc = lib().gvo_batch_lsop12_decode(n_rows, n_cols, nt, _p(s, C.c_uint8), stride, _p(ln, C.c_uint32),
+                                       _p(out, C.c_int32))
+    if rc != OK:
+        raise IOError("batch_lsop12_decode rc=%d" % rc)
+    return out
