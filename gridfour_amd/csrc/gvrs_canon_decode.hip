@@ -31,10 +31,9 @@ constexpr int DEC_WAVES = DEC_THREADS / 64;
 
 #include "gvrs_canon_decode_common.h"
 
-__global__ __launch_bounds__(DEC_THREADS) void k_canon_decode(GfDecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
 {
     __shared__ CanonDec S;
-    extern __shared__ __attribute__((aligned(16))) uint32_t ldsText[];
 
     const int tid = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
@@ -72,21 +71,11 @@ __global__ __launch_bounds__(DEC_THREADS) void k_canon_decode(GfDecodeArgs a)
         const uint64_t word0 = off >> 2;
         const uint32_t bias = (uint32_t)(off & 3u) * 8u;
         const uint32_t endBit = bias + len * 8u;
-        const uint32_t needWords = (endBit + 31u) / 32u + 2u;
-        CdText T;
-        if (needWords <= capWords) {
-            for (uint32_t i = tid; i < needWords; i += DEC_THREADS) {
-                uint32_t w = word0 + i < nWords ? w32[word0 + i] : 0u;
-                const uint32_t b0 = i * 32u;
-                if (b0 + 32u > endBit) w = b0 >= endBit ? 0u : (w & ((1u << (endBit - b0)) - 1u));
-                ldsText[i] = w;
-            }
-            T.w = ldsText;
-            T.nWords = needWords;
-        } else {
-            T.w = w32 + word0;                                     // huge packing: read it where it lies
-            T.nWords = (uint32_t)min((uint64_t)needWords, nWords - word0);
-        }
+        const uint32_t needWords = (endBit + 31u) / 32u + 4u;       // the readers look up to three words ahead
+        const bool textInLds = needWords <= capWords;
+        if (textInLds) cd_stage_text(w32, word0, nWords, endBit, needWords);
+        const CdTextLds TL{needWords};
+        const CdTextGlobal TG{w32 + word0, (uint32_t)min((uint64_t)needWords, nWords - word0)};   // huge packing: read in place
         __syncthreads();
 
         // ---------------- phases 0-2: the canonical-Huffman stream, values to their cells ----------------
@@ -94,11 +83,12 @@ __global__ __launch_bounds__(DEC_THREADS) void k_canon_decode(GfDecodeArgs a)
         const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
         const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
         const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
-        auto sink = [&](uint32_t k, uint32_t v) {
-            if (k < nStream) o[stream_cell_fast(model, nR, nC, k, magic, useMagic && wMain > 1)] = v;
-        };
+        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, !(a.phaseLimit & 0x100)};
         uint32_t endPos, nValues;
-        const int32_t st = cd_decode_stream(S, T, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues);
+        uint32_t *stamps = a.debug ? a.debug + t * 16 : nullptr;
+        if (stamps && tid == 0) stamps[0] = (uint32_t)__builtin_amdgcn_s_memtime();
+        const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps)
+                                     : cd_decode_stream(S, TG, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps);
         if (st != GF_K_OK) {
             if (tid == 0) a.status[t] = st;
             __syncthreads();
@@ -107,6 +97,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_canon_decode(GfDecodeArgs a)
 
         // ---------------- phase 3: predictor inverse ----------------
         gf_predictor_inverse(model, seed, o, nR, nC, nullptr);
+        if (stamps && tid == 0) stamps[6] = (uint32_t)__builtin_amdgcn_s_memtime();
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();
     }

@@ -31,17 +31,38 @@ struct CanonDec {
     int32_t runStatus;
 };
 
-// 32 stream bits at absolute bit position pos (LSB-first) of the word array T
-struct CdText {
-    const uint32_t *w;      // LDS copy of the packing, or the blob itself for packings larger than the copy
-    uint32_t nWords;        // readable words
+// The packing's text as 32-bit words, read either from the LDS copy (the normal case; an explicit LDS array so that
+// the reads are ds_read, not flat loads) or, for packings larger than the copy, from the blob where it lies.
+extern __shared__ __attribute__((aligned(16))) uint32_t cdLdsText[];
+
+struct CdTextLds {
+    uint32_t nWords;
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return cdLdsText[i]; }
+};
+struct CdTextGlobal {
+    const uint32_t *w;
+    uint32_t nWords;
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return i < nWords ? w[i] : 0u; }
 };
 
-__device__ __forceinline__ uint32_t cd_peek(const CdText T, uint32_t pos)
+// 32 stream bits at absolute bit position pos (LSB-first); the LDS copy is padded with two zero words
+template <class Text>
+__device__ __forceinline__ uint32_t cd_peek(const Text T, uint32_t pos)
 {
     const uint32_t i = pos >> 5;
-    const uint32_t lo = i < T.nWords ? T.w[i] : 0u, hi = i + 1 < T.nWords ? T.w[i + 1] : 0u;
-    return __builtin_amdgcn_alignbit(hi, lo, pos & 31u);
+    return __builtin_amdgcn_alignbit(T.word(i + 1), T.word(i), pos & 31u);
+}
+
+// copies a packing (bits [0, endBit) of the word array starting at w32[word0]) into the LDS text, zero beyond its end
+__device__ __forceinline__ void cd_stage_text(const uint32_t *__restrict__ w32, uint64_t word0, uint64_t nWords, uint32_t endBit,
+                                              uint32_t needWords)
+{
+    for (uint32_t i = threadIdx.x; i < needWords; i += DEC_THREADS) {
+        uint32_t w = word0 + i < nWords ? w32[word0 + i] : 0u;
+        const uint32_t b0 = i * 32u;
+        if (b0 + 32u > endBit) w = b0 >= endBit ? 0u : (w & ((1u << (endBit - b0)) - 1u));
+        cdLdsText[i] = w;
+    }
 }
 
 // canonical search over lengths [lmin, lmax]: c = next bits most-significant first (bit-reversed window)
@@ -98,53 +119,132 @@ struct CdTok {
     uint32_t sym, bits, raw;     // bits = code + raw bits; sym == 0xFFFF: no such code
 };
 
-__device__ __forceinline__ CdTok cd_token(const CanonDec &S, const CdText T, uint32_t pos)
+// lookup-table entry: symbol (9 bits) | code length << 9 | escape kind << 13 (1: two raw bits follow, 2: a raw byte)
+__device__ __forceinline__ uint16_t cd_lut_entry(uint32_t sym, uint32_t cl)
 {
-    const uint32_t w = cd_peek(T, pos);
-    const uint32_t e = S.lut[w & ((1u << CD_LUT_BITS) - 1u)];
+    const uint32_t kind = sym == (uint32_t)CN_ESC2 ? 1u : sym == (uint32_t)CN_ESC1 ? 2u : 0u;
+    return (uint16_t)(sym | (cl << 9) | (kind << 13));
+}
+
+// the token whose code starts at bit 0 of the 32-bit window w
+__device__ __forceinline__ CdTok cd_token_of(const CanonDec &S, uint32_t w)
+{
+    uint32_t e = S.lut[w & ((1u << CD_LUT_BITS) - 1u)];
     CdTok t;
-    uint32_t cl;
-    if (e) {
-        t.sym = e & 511u;
-        cl = e >> 9;
-    } else {
-        t.sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(w), CD_LUT_BITS + 1, 15, &cl);
+    if (!e) {                                             // longer than the table's 11 bits, or no such code
+        uint32_t cl;
+        const uint32_t sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(w), CD_LUT_BITS + 1, 15, &cl);
         if (cl == 0) { t.sym = 0xFFFFu; t.bits = 1; t.raw = 0; return t; }
+        e = cd_lut_entry(sym, cl);
     }
-    const uint32_t extra = t.sym == (uint32_t)CN_ESC2 ? 2u : t.sym == (uint32_t)CN_ESC1 ? 8u : 0u;
+    const uint32_t cl = (e >> 9) & 15u, kind = e >> 13;
+    const uint32_t extra = (kind & 1u) * 2u + (kind >> 1) * 8u;
+    t.sym = e & 511u;
     t.raw = (w >> cl) & ((1u << extra) - 1u);
     t.bits = cl + extra;
     return t;
 }
 
-// decodes subsequence q from bit p: tokens until the next boundary; returns where it ended and how many
-// values started in it
-__device__ __forceinline__ void cd_run(const CanonDec &S, const CdText T, uint32_t p, uint32_t bound, uint32_t endBit,
+// Sequential reader: three words of the text in registers, the third fetched a word ahead of its use, the decode
+// window formed with one v_alignbit_b32 -- the only latency on the per-token path is the table lookup.
+template <class Text>
+struct CdCur {
+    uint32_t w0, w1, w2, sh, wi, pos;
+    __device__ __forceinline__ void seek(const Text &T, uint32_t p)
+    {
+        pos = p;
+        wi = p >> 5;
+        sh = p & 31u;
+        w0 = T.word(wi);
+        w1 = T.word(wi + 1);
+        w2 = T.word(wi + 2);
+    }
+    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w1, w0, sh); }
+    __device__ __forceinline__ void advance(const Text &T, uint32_t n)     // n < 32
+    {
+        pos += n;
+        sh += n;
+        if (sh >= 32u) {
+            sh -= 32u;
+            w0 = w1;
+            w1 = w2;
+            wi++;
+            w2 = T.word(wi + 2);
+        }
+    }
+};
+
+// decodes from the cursor's position: tokens until the next boundary; returns where it ended and how many
+// values started on the way
+template <class Text>
+__device__ __forceinline__ void cd_run(const CanonDec &S, const Text &T, CdCur<Text> &cur, uint32_t bound, uint32_t endBit,
                                        uint32_t *endOut, uint32_t *cntOut, uint32_t *eotEnd)
 {
     uint32_t cnt = 0, end;
     for (;;) {
-        if (p >= bound) { end = p; break; }
-        if (p >= endBit) { end = CD_END_BAD; break; }
-        const CdTok t = cd_token(S, T, p);
+        if (cur.pos >= bound) { end = cur.pos; break; }
+        if (cur.pos >= endBit) { end = CD_END_BAD; break; }
+        const CdTok t = cd_token_of(S, cur.window());
         if (t.sym == 0xFFFFu) { end = CD_END_BAD; break; }
-        if (t.sym == (uint32_t)CN_EOT) { end = CD_END_EOT; *eotEnd = p + t.bits; break; }
+        if (t.sym == (uint32_t)CN_EOT) { end = CD_END_EOT; *eotEnd = cur.pos + t.bits; break; }
         cnt += t.sym <= (uint32_t)CN_NULL ? 1u : 0u;
-        p += t.bits;
+        cur.advance(T, t.bits);
     }
     *endOut = end;
     *cntOut = cnt;
 }
 
+// value sinks of cd_decode_stream: one(k, v) and quad(k0, four values), k0 a multiple of 4
+struct CdArraySink {                      // value k -> dst[k], k < n
+    int32_t *dst;
+    uint32_t n;
+    __device__ __forceinline__ void one(uint32_t k, uint32_t v) const { if (k < n) dst[k] = (int32_t)v; }
+    __device__ __forceinline__ void quad(uint32_t k0, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const
+    {
+        if (k0 + 3u < n) {
+            GfU4 x;
+            x.x = a; x.y = b; x.z = c; x.w = d;
+            *reinterpret_cast<GfU4 *>(dst + k0) = x;
+        } else { one(k0, a); one(k0 + 1u, b); one(k0 + 2u, c); one(k0 + 3u, d); }
+    }
+};
+
+struct CdCellSink {                       // value k of a predictor's stream -> its cell of the tile
+    uint32_t *o;
+    int model;
+    uint32_t nR, nC, nStream, magic;
+    bool useMagic;
+    __device__ __forceinline__ uint32_t cell(uint32_t k) const { return stream_cell_fast(model, nR, nC, k, magic, useMagic); }
+    bool enabled;                         // false: diagnostic ablation (no stores)
+    __device__ __forceinline__ void one(uint32_t k, uint32_t v) const { if (k < nStream && enabled) o[cell(k)] = v; }
+    __device__ __forceinline__ void quad(uint32_t k0, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const
+    {
+        if (k0 + 3u < nStream) {
+            const uint32_t c0 = cell(k0), c3 = cell(k0 + 3u);
+            if (c3 - c0 == 3u) {                                  // four neighbouring cells of one row
+                GfU4 x;
+                x.x = a; x.y = b; x.z = c; x.w = d;
+                *reinterpret_cast<GfU4 *>(o + c0) = x;
+                return;
+            }
+        }
+        one(k0, a); one(k0 + 1u, b); one(k0 + 2u, c); one(k0 + 3u, d);
+    }
+};
+
 // One canonical-Huffman stream (CanonicalHuffman.decode :441-519) starting at bit startBit of T, by the whole
 // workgroup: code tables, subsequence synchronisation, then every value k handed to sink(k, value); values the
 // text does not supply up to fillTo are handed over as 0.  More than maxValues values is the reference's
 // ArrayIndexOutOfBounds.  Returns the tile status (same in all threads); *endPos = bit after the end-of-text symbol.
-template <class Sink>
-__device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T, uint32_t startBit, uint32_t endBit,
+template <class Text, class Sink>
+__device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, uint32_t startBit, uint32_t endBit,
                                                     uint32_t maxValues, uint32_t fillTo, Sink sink, uint32_t *endPos,
-                                                    uint32_t *nValuesOut)
+                                                    uint32_t *nValuesOut, uint32_t *stamps = nullptr)
 {
+#define CD_STAMP(i)                                                                        \
+    do {                                                                                   \
+        if (stamps && threadIdx.x == 0) stamps[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
+    } while (0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { S.parseStatus = GF_K_OK; S.runStatus = GF_K_OK; S.qStar = 0xFFFFFFFFu; S.carry = 0; }
     __syncthreads();
@@ -230,6 +330,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T,
         if (lane == 0) { S.parseStatus = st; S.textStart = pos; }
     }
     __syncthreads();
+    CD_STAMP(1);                                  // code lengths read
     if (S.parseStatus != GF_K_OK) {
         const int32_t st = S.parseStatus;
         __syncthreads();
@@ -238,28 +339,32 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T,
     for (uint32_t e = tid; e < (1u << CD_LUT_BITS); e += DEC_THREADS) {
         uint32_t cl;
         const uint32_t sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(e), 1, CD_LUT_BITS, &cl);
-        S.lut[e] = cl ? (uint16_t)((cl << 9) | sym) : 0;
+        S.lut[e] = cl ? cd_lut_entry(sym, cl) : 0;
     }
     __syncthreads();
 
+    CD_STAMP(2);                                  // tables + LUT done
     // ---------------- phase 1: synchronise the subsequences, count their values ----------------
     const uint32_t T0 = S.textStart;
     const uint32_t span = endBit > T0 ? endBit - T0 : 1u;
-    const uint32_t unit = max(256u, ((span + CD_MAXQ - 1) / CD_MAXQ + 31u) & ~31u);
+    const uint32_t unit = max(128u, ((span + CD_MAXQ - 1) / CD_MAXQ + 31u) & ~31u);
     const uint32_t Q = (span + unit - 1) / unit;
     for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
         const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
-        uint32_t p = Bq;
+        CdCur<Text> cur;
         if (q > 0) {                                            // warm-up: walk in from 128 bits before the boundary
-            p = Bq - T0 > CD_WARM ? Bq - CD_WARM : T0;
-            while (p < Bq) {
-                const CdTok tk = cd_token(S, T, p);
-                if (tk.sym == 0xFFFFu || tk.sym == (uint32_t)CN_EOT) { p = Bq; break; }
-                p += tk.bits;
+            cur.seek(T, Bq - T0 > CD_WARM ? Bq - CD_WARM : T0);
+            while (cur.pos < Bq) {
+                const CdTok tk = cd_token_of(S, cur.window());
+                if (tk.sym == 0xFFFFu || tk.sym == (uint32_t)CN_EOT) { cur.seek(T, Bq); break; }
+                cur.advance(T, tk.bits);
             }
+        } else {
+            cur.seek(T, Bq);
         }
+        const uint32_t p = cur.pos;
         uint32_t e, c;
-        cd_run(S, T, p, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+        cd_run(S, T, cur, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
         S.qs[q] = p;
         S.qe[q] = e;
         S.qc[q] = c;
@@ -282,7 +387,11 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T,
                 uint32_t e, c;
                 // a value's escapes may carry the previous subsequence past this one's end: then it is empty
                 if (want[j] >= Bn && Bn != endBit) { e = want[j]; c = 0; }
-                else cd_run(S, T, want[j], Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+                else {
+                    CdCur<Text> cur;
+                    cur.seek(T, want[j]);
+                    cd_run(S, T, cur, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+                }
                 S.qs[q] = want[j];
                 S.qe[q] = e;
                 S.qc[q] = c;
@@ -293,6 +402,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T,
         if (!S.changed) break;
         __syncthreads();
     }
+    CD_STAMP(3);                                  // synchronised
     // the true chain ends at the first subsequence that met the end-of-text symbol (or an error)
     for (uint32_t q = tid; q < Q; q += DEC_THREADS)
         if (S.qe[q] >= CD_END_BAD) atomicMin(&S.qStar, q);
@@ -322,39 +432,43 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T,
         return tileStatus;
     }
 
-    // ---------------- phase 2: values to their cells ----------------
+    CD_STAMP(4);                                  // counted
+    // ---------------- phase 2: values to their sink ----------------
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const uint32_t q = tid + j * DEC_THREADS;
         if (q < Q && q <= qStar) {
             const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
             const uint32_t bound = Bn == endBit ? 0xFFFFFFF0u : Bn;
-            uint32_t p = S.qs[q], k = base[j];
+            uint32_t k = base[j];
             bool started = q != 0;                                // q == 0: an escape before any value is text[-1]
-            while (p < bound) {
-                CdTok tk = cd_token(S, T, p);
+            CdCur<Text> cur;
+            cur.seek(T, S.qs[q]);
+            CdTok tk = cd_token_of(S, cur.window());              // tk is always the token at the cursor
+            while (cur.pos < bound) {
                 if (tk.sym == (uint32_t)CN_EOT || tk.sym == 0xFFFFu) break;
-                p += tk.bits;
+                cur.advance(T, tk.bits);
                 if (tk.sym > (uint32_t)CN_NULL) {                 // escape belonging to the previous value, or spare symbol 260
                     if (!started && tk.sym != 260u) S.runStatus = GF_K_ERR_BOUNDS;
+                    tk = cd_token_of(S, cur.window());
                     continue;
                 }
                 started = true;
                 uint32_t v = tk.sym == (uint32_t)CN_NULL ? GF_NULL_CODE : tk.sym - 128u;
                 for (;;) {                                        // the escapes that extend this value (:495-504)
-                    tk = cd_token(S, T, p);
+                    tk = cd_token_of(S, cur.window());
                     if (tk.sym == (uint32_t)CN_ESC2) v = (v << 2) | tk.raw;
                     else if (tk.sym == (uint32_t)CN_ESC1) v = (v << 8) | tk.raw;
                     else if (tk.sym != 260u) break;
-                    p += tk.bits;
+                    cur.advance(T, tk.bits);
                 }
-                sink(k, v);
+                sink.one(k, v);
                 k++;
             }
         }
     }
     // a text shorter than its reader expects leaves zeros (fresh int[] in Java)
-    for (uint32_t k = nValues + tid; k < fillTo; k += DEC_THREADS) sink(k, 0u);
+    for (uint32_t k = nValues + tid; k < fillTo; k += DEC_THREADS) sink.one(k, 0u);
     __syncthreads();
     {
         const int32_t st = S.runStatus;
@@ -362,8 +476,10 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const CdText T,
         if (st != GF_K_OK) return st;
     }
 
+    CD_STAMP(5);                                  // values written
     *endPos = S.qx[qStar];
     *nValuesOut = nValues;
     __syncthreads();
     return GF_K_OK;
+#undef CD_STAMP
 }

@@ -30,6 +30,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "gvrs_kernels.h"
 #include "huff_build.h"
 
@@ -349,7 +351,7 @@ __device__ void resolve_chain(DecShared &S, Cursor cur, uint32_t start, uint32_t
 // phase 1 body: Huffman text -> nM32 bytes at m32; returns GF_K_OK or the Java error it mirrors
 template <class TextPtr>
 __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32_t textStart, uint32_t endBit,
-                                  uint32_t nM32, uint8_t *m32, uint32_t *dbg)
+                                  uint32_t nM32, uint8_t *m32, uint32_t *dbg, uint32_t warmBits)
 {
     const uint32_t tid = threadIdx.x;
     int32_t status = GF_K_OK;
@@ -357,7 +359,7 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
     uint32_t unit = (textBits + MAXQ - 1) / MAXQ;
     unit = max(128u, (unit + 31u) & ~31u);
     const uint32_t Q = max(1u, (textBits + unit - 1) / unit);
-    resolve_chain(S, cur, textStart, endBit, unit, Q, 128u, dbg);       // warm-up: 128 bits, about 25 symbols
+    resolve_chain(S, cur, textStart, endBit, unit, Q, warmBits, dbg);   // warm-up: 128 bits = about 25 symbols by default
     if (dbg && tid == 0) dbg[-7] = (uint32_t)__builtin_amdgcn_s_memtime();      // stamp 4
     if (S.chainTotal < nM32) status = GF_K_ERR_BOUNDS;                   // ran out of bits
     if (tid == 0) S.chainEnd = 0;
@@ -544,7 +546,8 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
         GF_DSTAMP(2);
-        if (a.phaseLimit == 1) continue;
+        if ((a.phaseLimit & 0xff) == 1) continue;
+        const uint32_t warmBits = (a.phaseLimit >> 8) ? (uint32_t)(a.phaseLimit >> 8) : 128u;   // experiment hook
 
         // dynamic LDS / spill layout: [M32 bytes][start bitmap][bitmap rank base]
         uint8_t *m32;
@@ -625,14 +628,14 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                 cur.nW = pkWords;
                 cur.sh0 = sh0;
                 cur.S = &S;
-                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg);
+                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
             } else {
                 HuffCursorT<const uint32_t *> cur;
                 cur.base32 = w32 + baseWord;
                 cur.nW = (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord);
                 cur.sh0 = sh0;
                 cur.S = &S;
-                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg);
+                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
             }
         }
         if (tileStatus != GF_K_OK) {
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
         GF_DSTAMP(5);
-        if (a.phaseLimit == 2) continue;
+        if ((a.phaseLimit & 0xff) == 2) continue;
 
         // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
         {
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             continue;
         }
         GF_DSTAMP(8);
-        if (a.phaseLimit == 3) continue;
+        if ((a.phaseLimit & 0xff) == 3) continue;
 
         // ---------------- phase 3: predictor inverse (wrap-around prefix sums) ----------------
         gf_predictor_inverse(model, seed, o, nR, nC, a.debug ? a.debug + t * 16 + 9 : nullptr);
@@ -812,6 +815,7 @@ uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
     // typical M32 streams are ~1.0-1.1 bytes per cell; larger ones spill to the workspace
     size_t cells = (size_t)nRows * (size_t)nCols;
     size_t want = cells + cells / 8 + 512;
+    if (const char *e = getenv("GF_DEC_LDS_M32")) return (uint32_t)(atoi(e) & ~31);      // experiment hook
     if (want < 8192) want = 8192;
     if (want > 65536) want = 65536;             // with bitmap, rank bases, text and the static part: < 160 KB
     return (uint32_t)((want + 31) & ~(size_t)31);

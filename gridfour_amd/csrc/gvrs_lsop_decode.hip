@@ -33,10 +33,9 @@ struct GfLsopUnpackArgs {
     uint32_t ldsTextBytes;
 };
 
-__global__ __launch_bounds__(DEC_THREADS) void k_lsop_unpack2(GfLsopUnpackArgs a)
+__global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArgs a)
 {
     __shared__ CanonDec S;
-    extern __shared__ __attribute__((aligned(16))) uint32_t ldsText[];
 
     const int tid = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols;
@@ -74,29 +73,21 @@ __global__ __launch_bounds__(DEC_THREADS) void k_lsop_unpack2(GfLsopUnpackArgs a
         const uint64_t word0 = off >> 2;
         const uint32_t bias = (uint32_t)(off & 3u) * 8u;
         const uint32_t endBit = bias + len * 8u;
-        const uint32_t needWords = (endBit + 31u) / 32u + 2u;
-        CdText T;
-        if (needWords <= capWords) {
-            for (uint32_t i = tid; i < needWords; i += DEC_THREADS) {
-                uint32_t w = word0 + i < nWords ? w32[word0 + i] : 0u;
-                const uint32_t b0 = i * 32u;
-                if (b0 + 32u > endBit) w = b0 >= endBit ? 0u : (w & ((1u << (endBit - b0)) - 1u));
-                ldsText[i] = w;
-            }
-            T.w = ldsText;
-            T.nWords = needWords;
-        } else {
-            T.w = w32 + word0;
-            T.nWords = (uint32_t)min((uint64_t)needWords, nWords - word0);
-        }
+        const uint32_t needWords = (endBit + 31u) / 32u + 4u;       // the readers look up to three words ahead
+        const bool textInLds = needWords <= capWords;
+        if (textInLds) cd_stage_text(w32, word0, nWords, endBit, needWords);
+        const CdTextLds TL{needWords};
+        const CdTextGlobal TG{w32 + word0, (uint32_t)min((uint64_t)needWords, nWords - word0)};   // huge packing: read in place
         __syncthreads();
 
         uint32_t pos = bias + hdr * 8u, nv;
-        auto sink0 = [&](uint32_t k, uint32_t v) { if (k < nInit) res[k] = (int32_t)v; };
-        int32_t st = cd_decode_stream(S, T, pos, endBit, nInit, nInit, sink0, &pos, &nv);
+        const CdArraySink sink0{res, nInit};
+        int32_t st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInit, nInit, sink0, &pos, &nv)
+                               : cd_decode_stream(S, TG, pos, endBit, nInit, nInit, sink0, &pos, &nv);
         if (st == GF_K_OK) {
-            auto sink1 = [&](uint32_t k, uint32_t v) { if (k < nInt) res[nInit + k] = (int32_t)v; };
-            st = cd_decode_stream(S, T, pos, endBit, nInt, nInt, sink1, &pos, &nv);
+            const CdArraySink sink1{res + nInit, nInt};
+            st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv)
+                           : cd_decode_stream(S, TG, pos, endBit, nInt, nInt, sink1, &pos, &nv);
         }
         if (tid == 0) a.status[t] = st;
         __syncthreads();

@@ -24,10 +24,14 @@ def main():
     b.encode()
     b.decode()
     ctx.synchronize()
+    L.gf_internal_set_phase_limits.argtypes = [C.c_int, C.c_int]
+    warm = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    L.gf_internal_set_phase_limits(0, warm << 8)
     L.gf_internal_set_decode_debug(dbg.ptr)
     b.decode()
     ctx.synchronize()
     L.gf_internal_set_decode_debug(None)
+    L.gf_internal_set_phase_limits(0, 0)
     st = dbg.download(np.uint32, 16 * nt).reshape(nt, 16).astype(np.int64)
     d = np.diff(st[:, :11], axis=1) & 0xFFFFFFFF
     names = ["0 header copy", "0 tree parse", "1 LUT build", "1 huffman chain sync", "1 huffman write pass", "2 m32 chain sync",
