@@ -103,9 +103,6 @@ __device__ constexpr PairTab PAIRS = make_pairs();
 
 struct LsopShared {
     double G[104];
-    double LU[13][13];
-    double X[13], col[13];
-    int piv[13];
     float u[12];
     uint32_t maxAbs;
     int32_t status;
@@ -140,8 +137,8 @@ __device__ __forceinline__ void lsop_gram_wave(const int32_t *__restrict__ v, ui
 #pragma unroll
     for (int q = 0; q < 26; q++) acc[q] = 0.0;
     const uint32_t wI = nC - 4u;
+    uint32_t r = (uint32_t)lane / wI, c = (uint32_t)lane - r * wI;          // row / column of cell e, kept incrementally
     for (uint32_t e = (uint32_t)lane; e < nInt; e += 64) {
-        const uint32_t r = e / wI, c = e - r * wI;
         const int32_t *p = v + (size_t)(r + 2u) * nC + (c + 2u);
         const int32_t n = (int32_t)nC;
         double z[14];
@@ -160,7 +157,9 @@ __device__ __forceinline__ void lsop_gram_wave(const int32_t *__restrict__ v, ui
         z[12] = (double)p[-2 * n + 2];
         z[13] = 1.0;
 #pragma unroll
-        for (int q = 0; q < 26; q++) acc[q] += z[PAIRS.i[W * 26 + q]] * z[PAIRS.j[W * 26 + q]];
+        for (int q = 0; q < 26; q++) acc[q] = __fma_rn(z[PAIRS.i[W * 26 + q]], z[PAIRS.j[W * 26 + q]], acc[q]);   // exact: see the guard
+        c += 64u;
+        while (c >= wI) { c -= wI; r++; }
     }
 #pragma unroll
     for (int q = 0; q < 26; q++) {
@@ -169,6 +168,78 @@ __device__ __forceinline__ void lsop_gram_wave(const int32_t *__restrict__ v, ui
         for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
         if (lane == 0) G[W * 26 + q] = a;
     }
+}
+
+__device__ __forceinline__ double lsop_bcast(double x, int k)           // value of lane k (k wave-uniform)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k), hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+
+// JAMA's LU (LUDecomposition.java:70-134) and solve (:253-284) of the 13x13 system of
+// LsOptimalPredictor12.computeCoefficients :353-378 on one wave: lane i holds row i in registers.  The reference's
+// inner loop  s += LU[i][k] * LUcolj[k]  runs over k in the same order here, for all rows in lockstep (row i stops at
+// k = min(i, j)); the column value of row k is final exactly when step k needs it.  Every multiply and add is
+// rounded separately, as in Java.  Writes S.u / S.status.
+__device__ __forceinline__ void lsop_lu_solve_wave(LsopShared &S, int lane)
+{
+    auto Cij = [&](int i, int j) -> double {              // c[i][j], symmetric (:345-349)
+        if (i > j) { const int q = i; i = j; j = q; }
+        return S.G[i * 14 - (i * (i - 1)) / 2 + (j - i)];
+    };
+    auto Si = [&](int i) -> double { return S.G[i * 14 - (i * (i - 1)) / 2 + (13 - i)]; };
+    const int row = lane < 13 ? lane : 12;                // lanes >= 13 shadow row 12 (results unused)
+    double r[13], x;
+#pragma unroll
+    for (int j = 0; j < 12; j++) r[j] = row < 12 ? Cij(row + 1, j + 1) : Si(j + 1);
+    r[12] = row < 12 ? Si(row + 1) : 0.0;
+    x = row < 12 ? Cij(0, row + 1) : Si(0);               // right-hand side, permuted along with the rows
+    bool singular = false;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+        double colv = r[j], s = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+            const double ck = lsop_bcast(__dsub_rn(colv, s), k);      // LUcolj[k] after its own update
+            if (lane > k) s = __dadd_rn(s, __dmul_rn(r[k], ck));
+        }
+        colv = __dsub_rn(colv, s);
+        r[j] = colv;
+        // pivot: first row >= j with the largest |value| (strict > in scan order)
+        int p = j;
+        double ap = fabs(lsop_bcast(colv, j));
+#pragma unroll
+        for (int i = j + 1; i < 13; i++) {
+            const double ai = fabs(lsop_bcast(colv, i));
+            if (ai > ap) { p = i; ap = ai; }
+        }
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p != j) {
+            const int partner = lane == j ? p : lane == p ? j : lane;
+#pragma unroll
+            for (int c = 0; c < 13; c++) r[c] = __shfl(r[c], partner, 64);
+            x = __shfl(x, partner, 64);
+        }
+        const double djj = lsop_bcast(r[j], j);
+        if (djj != 0.0) { if (lane > j) r[j] = __ddiv_rn(r[j], djj); }
+        else singular = true;
+    }
+    if (singular) {
+        if (lane == 0) S.status = GF_K_DECLINED;          // "Matrix is singular." -> computeCoefficients returns null
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 13; k++) {                        // L y = b(piv)
+        const double xk = lsop_bcast(x, k);
+        if (lane > k) x = __dsub_rn(x, __dmul_rn(xk, r[k]));
+    }
+#pragma unroll
+    for (int k = 12; k >= 0; k--) {                       // U x = y
+        if (lane == k) x = __ddiv_rn(x, r[k]);
+        const double xk = lsop_bcast(x, k);
+        if (lane < k) x = __dsub_rn(x, __dmul_rn(xk, r[k]));
+    }
+    if (lane < 12) S.u[lane] = (float)x;
 }
 
 struct GfLsopPredictArgs {
@@ -181,7 +252,7 @@ struct GfLsopPredictArgs {
     int nRows, nCols;
 };
 
-__global__ __launch_bounds__(256) void k_lsop_predict(GfLsopPredictArgs a)
+__global__ __launch_bounds__(256, 4) void k_lsop_predict(GfLsopPredictArgs a)
 {
     __shared__ LsopShared S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,6 +289,9 @@ __global__ __launch_bounds__(256) void k_lsop_predict(GfLsopPredictArgs a)
         // normal equations (:335-342)
         const double bound = (double)S.maxAbs * (double)S.maxAbs * (double)nInt;
         if (bound < 9007199254740992.0) {
+            // Exact sums: lanes split the cells, the four waves split the 104 accumulators (26 each), FMA.
+            // (v_mfma_f64_16x16x4_f64 was measured here: 64-cycle issue for 1024 MACs of which 416 are needed --
+            //  6.7 ms against 3.7 ms for this form; FP64 MFMA has the vector rate on gfx950, so padding loses.)
             if (wave == 0) lsop_gram_wave<0>(v, nC, nInt, S.G, lane);
             else if (wave == 1) lsop_gram_wave<1>(v, nC, nInt, S.G, lane);
             else if (wave == 2) lsop_gram_wave<2>(v, nC, nInt, S.G, lane);
@@ -239,60 +313,8 @@ __global__ __launch_bounds__(256) void k_lsop_predict(GfLsopPredictArgs a)
         }
         __syncthreads();
 
-        // 13x13 bordered system, LU, solve (:353-378; LUDecomposition.java:70-134, 253-284): one thread, the
-        // reference's operation order
-        if (tid == 0) {
-            auto Cij = [&](int i, int j) -> double {          // c[i][j], symmetric (:345-349)
-                if (i > j) { const int q = i; i = j; j = q; }
-                // pairs of row i start at sum_{k<i} (14 - k)
-                const int base = i * 14 - (i * (i - 1)) / 2;
-                return S.G[base + (j - i)];
-            };
-            auto Si = [&](int i) -> double { return S.G[i * 14 - (i * (i - 1)) / 2 + (13 - i)]; };
-            for (int i = 1; i < 13; i++) {
-                for (int j = 1; j < 13; j++) S.LU[i - 1][j - 1] = Cij(i, j);
-                S.LU[i - 1][12] = Si(i);
-            }
-            for (int j = 1; j < 13; j++) S.LU[12][j - 1] = Si(j);
-            S.LU[12][12] = 0.0;
-            double b[13];
-            for (int i = 1; i < 13; i++) b[i - 1] = Cij(0, i);
-            b[12] = Si(0);
-            for (int i = 0; i < 13; i++) S.piv[i] = i;
-            for (int j = 0; j < 13; j++) {
-                for (int i = 0; i < 13; i++) S.col[i] = S.LU[i][j];
-                for (int i = 0; i < 13; i++) {
-                    const int kmax = i < j ? i : j;
-                    double s = 0.0;
-                    for (int k = 0; k < kmax; k++) s = __dadd_rn(s, __dmul_rn(S.LU[i][k], S.col[k]));
-                    S.col[i] = __dsub_rn(S.col[i], s);
-                    S.LU[i][j] = S.col[i];
-                }
-                int p = j;
-                for (int i = j + 1; i < 13; i++)
-                    if (fabs(S.col[i]) > fabs(S.col[p])) p = i;
-                if (p != j) {
-                    for (int k = 0; k < 13; k++) { const double q = S.LU[p][k]; S.LU[p][k] = S.LU[j][k]; S.LU[j][k] = q; }
-                    const int q = S.piv[p]; S.piv[p] = S.piv[j]; S.piv[j] = q;
-                }
-                if (S.LU[j][j] != 0.0)
-                    for (int i = j + 1; i < 13; i++) S.LU[i][j] = __ddiv_rn(S.LU[i][j], S.LU[j][j]);
-            }
-            bool singular = false;
-            for (int j = 0; j < 13; j++) singular |= S.LU[j][j] == 0.0;
-            if (singular) {
-                S.status = GF_K_DECLINED;                       // "Matrix is singular." -> computeCoefficients returns null
-            } else {
-                for (int i = 0; i < 13; i++) S.X[i] = b[S.piv[i]];
-                for (int k = 0; k < 13; k++)
-                    for (int i = k + 1; i < 13; i++) S.X[i] = __dsub_rn(S.X[i], __dmul_rn(S.X[k], S.LU[i][k]));
-                for (int k = 12; k >= 0; k--) {
-                    S.X[k] = __ddiv_rn(S.X[k], S.LU[k][k]);
-                    for (int i = 0; i < k; i++) S.X[i] = __dsub_rn(S.X[i], __dmul_rn(S.X[k], S.LU[i][k]));
-                }
-                for (int i = 0; i < 12; i++) S.u[i] = (float)S.X[i];
-            }
-        }
+        // 13x13 bordered system, LU, solve (:353-378; LUDecomposition.java:70-134, 253-284) by wave 0
+        if (wave == 0) lsop_lu_solve_wave(S, lane);
         __syncthreads();
         if (S.status != GF_K_OK) {
             if (tid == 0) a.status[t] = S.status;
