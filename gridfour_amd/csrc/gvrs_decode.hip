@@ -50,7 +50,6 @@ constexpr int L2_ENTRIES = 2048;               // shared by all second-level tab
 
 struct DecShared {
     uint16_t lut[1 << LUT_BITS];               // (len << 8) | sym ; 0x8000 | sub-table ; 0xFFFF = search
-    uint16_t lut2[L2_ENTRIES];                 // (len << 8) | sym ; 0xFFFF = search the leaf table
     unsigned long long leafCode[256];          // per leaf, in pre-order: path bits root->leaf, first step in bit 0
     uint8_t leafLen[256];
     uint8_t leafSym[256];
@@ -89,6 +88,8 @@ struct HuffCursorT {
     uint32_t nW;                   // words readable from base32
     uint32_t sh0;                  // position of packing bit 0 inside base32[0]
     const DecShared *S;
+    const uint16_t *lut2;          // second-level table: (len << 8) | sym ; 0xFFFF = search the leaf table.  It lives in the
+                                   // dynamic LDS area that phase 2 reuses for its bitmap (disjoint lifetimes)
     uint32_t pos;                  // packing-relative bit position of the next symbol
     uint32_t sh;                   // (pos + sh0) & 31 : offset of the next symbol inside w0
     uint32_t wi;                   // index of w0
@@ -124,7 +125,7 @@ struct HuffCursorT {
     __device__ __forceinline__ uint32_t resolve_long(uint32_t e, uint32_t w32v) const
     {
         const uint32_t l2 = S->l2bits, sub = e & 0x7fffu;
-        e = sub < ((uint32_t)L2_ENTRIES >> l2) ? S->lut2[(sub << l2) | ((w32v >> LUT_BITS) & ((1u << l2) - 1u))] : 0xFFFFu;
+        e = sub < ((uint32_t)L2_ENTRIES >> l2) ? lut2[(sub << l2) | ((w32v >> LUT_BITS) & ((1u << l2) - 1u))] : 0xFFFFu;
         if (e == 0xFFFFu) {
             // 64 bits of text for the leaf-table search (rare)
             const uint64_t lo = ((uint64_t)w1 << 32) | w0;
@@ -393,7 +394,7 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
     } while (0)
 
 
-__global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
@@ -549,7 +550,11 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
         if ((a.phaseLimit & 0xff) == 1) continue;
         const uint32_t warmBits = (a.phaseLimit >> 8) ? (uint32_t)(a.phaseLimit >> 8) : 128u;   // experiment hook
 
-        // dynamic LDS / spill layout: [M32 bytes][start bitmap][bitmap rank base]
+        // dynamic LDS / spill layout: [M32 bytes][start bitmap][bitmap rank base]; the bitmap area holds the second-level
+        // lookup table while phase 1 runs
+        const size_t bmRaw = 2 * (((size_t)a.ldsM32Bytes >> 5) + 2) * 4;
+        const size_t bmArea = bmRaw > 2 * L2_ENTRIES ? bmRaw : 2 * L2_ENTRIES;
+        uint16_t *lut2 = reinterpret_cast<uint16_t *>(ldsDyn + a.ldsM32Bytes);
         uint8_t *m32;
         uint32_t *bm, *wb;
         const uint32_t bmWords = (nM32 + 31u) >> 5;
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                 const uint32_t nLeaves = S.nLeaves;
                 const uint32_t nSub = S.nSub;
                 const uint32_t l2 = S.l2bits;
-                for (uint32_t x = tid; x < (nSub << l2); x += DEC_THREADS) S.lut2[x] = 0xFFFFu;
+                for (uint32_t x = tid; x < (nSub << l2); x += DEC_THREADS) lut2[x] = 0xFFFFu;
                 if ((uint32_t)tid < nLeaves) {
                     const uint32_t cl = S.leafLen[tid];
                     if (cl > 5 && cl <= LUT_BITS) {
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                         const uint64_t code = S.leafCode[tid];
                         const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffu;
                         if (subIdx < nSub) {
-                            uint16_t *sub = &S.lut2[subIdx << l2];
+                            uint16_t *sub = &lut2[subIdx << l2];
                             const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
                             for (uint32_t x = (uint32_t)(code >> LUT_BITS); x < (1u << l2); x += 1u << (cl - LUT_BITS))
                                 sub[x] = e;
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
             uint32_t *dbg = a.debug ? a.debug + t * 16 + 11 : nullptr;
             if (pkWords * 4u <= a.ldsTextBytes) {
                 // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
-                uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + 2 * (((size_t)a.ldsM32Bytes >> 5) + 2) * 4);
+                uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + bmArea);
                 const uint64_t avail = nWords - baseWord;
                 for (uint32_t i = tid; i < pkWords; i += DEC_THREADS) txt[i] = i < avail ? w32[baseWord + i] : 0u;
                 __syncthreads();
@@ -628,6 +633,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                 cur.nW = pkWords;
                 cur.sh0 = sh0;
                 cur.S = &S;
+                cur.lut2 = lut2;
                 tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
             } else {
                 HuffCursorT<const uint32_t *> cur;
@@ -635,6 +641,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_huffman_decode(GfDecodeArgs a)
                 cur.nW = (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord);
                 cur.sh0 = sh0;
                 cur.S = &S;
+                cur.lut2 = lut2;
                 tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
             }
         }
@@ -824,7 +831,9 @@ uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
 // dynamic LDS bytes for a given M32 capacity: bytes + start bitmap + rank bases
 static size_t decodeDynLds(uint32_t ldsM32Bytes, uint32_t ldsTextBytes)
 {
-    return (size_t)ldsM32Bytes + 2 * ((size_t)(ldsM32Bytes >> 5) + 2) * 4 + ldsTextBytes;
+    // the bitmap + rank area doubles as the second-level lookup table (L2_ENTRIES uint16) during phase 1
+    const size_t bm = 2 * ((size_t)(ldsM32Bytes >> 5) + 2) * 4;
+    return (size_t)ldsM32Bytes + (bm > 2 * L2_ENTRIES ? bm : 2 * L2_ENTRIES) + ldsTextBytes;
 }
 
 uint32_t gf_huffman_decode_lds_text(int nRows, int nCols)
