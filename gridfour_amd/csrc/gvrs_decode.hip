@@ -772,8 +772,34 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                 if (bits) {
                     const uint32_t word = bm[i0 >> 5];
                     uint32_t k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
+                    uint32_t d0 = m32w[dw];
+                    // Fast path (most dwords of terrain data): four value starts, none an introducer (0x7f / 0x81) or the
+                    // null code (0x80) -> four sign-extended bytes; if their cells are neighbours, one 16-byte store.
+                    {
+                        const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
+                        const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) &
+                                                 0x80808080u;
+                        if (bits == 0xfu && !special && k + 3u < nStream) {
+                            const uint32_t v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu), v1 = (uint32_t)((int32_t)(d0 << 16) >> 24),
+                                           v2 = (uint32_t)((int32_t)(d0 << 8) >> 24), v3 = (uint32_t)((int32_t)d0 >> 24);
+                            const bool fastCell = useMagic && wMain > 1;
+                            const uint32_t c0 = stream_cell_fast(model, nR, nC, k, magic, fastCell);
+                            const uint32_t c3 = stream_cell_fast(model, nR, nC, k + 3u, magic, fastCell);
+                            if (c3 - c0 == 3u) {
+                                GfU4 q;
+                                q.x = v0; q.y = v1; q.z = v2; q.w = v3;
+                                *reinterpret_cast<GfU4 *>(o + c0) = q;
+                            } else {
+                                o[c0] = v0;
+                                o[stream_cell_fast(model, nR, nC, k + 1u, magic, fastCell)] = v1;
+                                o[stream_cell_fast(model, nR, nC, k + 2u, magic, fastCell)] = v2;
+                                o[c3] = v3;
+                            }
+                            continue;
+                        }
+                    }
                     // bytes i0 .. i0+11, zero beyond nM32
-                    uint32_t d0 = m32w[dw], d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
+                    uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
                     if (i0 + 12 > nM32) {
                         const uint32_t valid = nM32 - i0;            // 1..11 bytes
                         if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
