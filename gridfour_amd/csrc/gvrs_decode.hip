@@ -39,7 +39,7 @@ namespace {
 
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
-constexpr int LUT_BITS = 11;
+constexpr int LUT_BITS = 10;                    // first-level window: most symbol PAIRS of terrain data fit 10 bits
 constexpr int MAXQ = 512;                      // subsequences per chain
 constexpr int HEAD_WORDS = 88;                 // 10 header + 1 + ceil(2559/8) tree bytes = 332 -> 83 words, + slack
 constexpr int MAX_DEPTH = 63;                  // code length limit of the register tree parser
@@ -49,7 +49,8 @@ constexpr int L2_ENTRIES = 2048;               // shared by all second-level tab
                                                // 2^l2bits entries, l2bits = min(8, longest code - 11) per tile
 
 struct DecShared {
-    uint16_t lut[1 << LUT_BITS];               // (len << 8) | sym ; 0x8000 | sub-table ; 0xFFFF = search
+    uint32_t lut[1 << LUT_BITS];               // sym1 | sym2 << 8 | len1 << 16 | (len1 + len2) << 22 (== len1 << 22: one symbol);
+                                               // bit 31 | sub-table: the code is longer than the window
     unsigned long long leafCode[256];          // per leaf, in pre-order: path bits root->leaf, first step in bit 0
     uint8_t leafLen[256];
     uint8_t leafSym[256];
@@ -71,6 +72,9 @@ struct DecShared {
 };
 
 #include "gvrs_decode_common.h"
+
+// lookup entry of one symbol
+__device__ __forceinline__ uint32_t lut_single(uint32_t sym, uint32_t len) { return sym | (len << 16) | (len << 22); }   // len <= 63
 
 // ---- cursors: sequential readers of the two variable-length layers ----
 
@@ -121,12 +125,13 @@ struct HuffCursorT {
             w2 = ld(wi + 2);
         }
     }
-    // codes longer than 11 bits: second level, then (longer than 19 bits, or out of tables) the leaf table
+    // codes longer than the window: second level, then (longer than that, or out of tables) the leaf table.
+    // Returns a single-symbol entry.
     __device__ __forceinline__ uint32_t resolve_long(uint32_t e, uint32_t w32v) const
     {
-        const uint32_t l2 = S->l2bits, sub = e & 0x7fffu;
-        e = sub < ((uint32_t)L2_ENTRIES >> l2) ? lut2[(sub << l2) | ((w32v >> LUT_BITS) & ((1u << l2) - 1u))] : 0xFFFFu;
-        if (e == 0xFFFFu) {
+        const uint32_t l2 = S->l2bits, sub = e & 0x7fffffffu;
+        uint32_t e16 = sub < ((uint32_t)L2_ENTRIES >> l2) ? lut2[(sub << l2) | ((w32v >> LUT_BITS) & ((1u << l2) - 1u))] : 0xFFFFu;
+        if (e16 == 0xFFFFu) {
             // 64 bits of text for the leaf-table search (rare)
             const uint64_t lo = ((uint64_t)w1 << 32) | w0;
             uint64_t w = lo >> sh;
@@ -136,21 +141,21 @@ struct HuffCursorT {
                 const uint32_t cl = S->leafLen[i];
                 const uint64_t mask = cl >= 64 ? ~0ull : ((1ull << cl) - 1ull);
                 if (cl > LUT_BITS && (w & mask) == S->leafCode[i]) {
-                    e = (cl << 8) | S->leafSym[i];
+                    e16 = (cl << 8) | S->leafSym[i];
                     break;
                 }
             }
-            if (e == 0xFFFFu) e = (1u << 8);       // cannot happen for a complete tree; keep moving
+            if (e16 == 0xFFFFu) e16 = (1u << 8);   // cannot happen for a complete tree; keep moving
         }
-        return e;
+        return lut_single(e16 & 0xffu, e16 >> 8);
     }
     // decodes one symbol, advances
     __device__ __forceinline__ uint32_t next()
     {
         const uint32_t w = prepare();
         uint32_t e = lookup(w);
-        if (e & 0x8000u) e = resolve_long(e, w);
-        advance(e >> 8);
+        if (e & 0x80000000u) e = resolve_long(e, w);
+        advance((e >> 16) & 63u);
         return e & 0xffu;
     }
 };
@@ -238,21 +243,27 @@ __device__ __forceinline__ uint32_t m32_value(uint32_t lo, uint32_t hi, uint32_t
 // advance two cursors of the same kind by one symbol each where active; the two table lookups
 // are issued back to back so that their latencies overlap
 template <class TextPtr>
-__device__ __forceinline__ void step2(HuffCursorT<TextPtr> &c0, bool r0, uint32_t *s0, HuffCursorT<TextPtr> &c1, bool r1,
-                                      uint32_t *s1)
+__device__ __forceinline__ void step2(HuffCursorT<TextPtr> &c0, bool r0, uint32_t lim0, uint32_t room0, uint32_t *s0, uint32_t *n0,
+                                      HuffCursorT<TextPtr> &c1, bool r1, uint32_t lim1, uint32_t room1, uint32_t *s1, uint32_t *n1)
 {
+    // lim: the second symbol of a pair is taken only if it starts before lim; room: symbols still wanted (>= 1)
     const uint32_t w0 = c0.prepare(), w1 = c1.prepare();
     uint32_t e0 = c0.lookup(w0), e1 = c1.lookup(w1);
-    if ((e0 | e1) & 0x8000u) {
-        if (e0 & 0x8000u) e0 = c0.resolve_long(e0, w0);
-        if (e1 & 0x8000u) e1 = c1.resolve_long(e1, w1);
+    if ((e0 | e1) & 0x80000000u) {
+        if (e0 & 0x80000000u) e0 = c0.resolve_long(e0, w0);
+        if (e1 & 0x80000000u) e1 = c1.resolve_long(e1, w1);
     }
-    c0.advance(r0 ? (e0 >> 8) : 0u);
-    c1.advance(r1 ? (e1 >> 8) : 0u);
-    *s0 = e0 & 0xffu;
-    *s1 = e1 & 0xffu;
+    const uint32_t a0 = (e0 >> 16) & 63u, t0 = e0 >> 22, a1 = (e1 >> 16) & 63u, t1 = e1 >> 22;
+    const bool two0 = t0 != a0 && c0.pos + a0 < lim0 && room0 > 1u, two1 = t1 != a1 && c1.pos + a1 < lim1 && room1 > 1u;
+    c0.advance(r0 ? (two0 ? t0 : a0) : 0u);
+    c1.advance(r1 ? (two1 ? t1 : a1) : 0u);
+    *s0 = e0 & 0xffffu;
+    *s1 = e1 & 0xffffu;
+    *n0 = two0 ? 2u : 1u;
+    *n1 = two1 ? 2u : 1u;
 }
-__device__ __forceinline__ void step2(M32Cursor &c0, bool r0, uint32_t *s0, M32Cursor &c1, bool r1, uint32_t *s1)
+__device__ __forceinline__ void step2(M32Cursor &c0, bool r0, uint32_t, uint32_t, uint32_t *s0, uint32_t *n0, M32Cursor &c1, bool r1,
+                                      uint32_t, uint32_t, uint32_t *s1, uint32_t *n1)
 {
     uint32_t lo0, hi0, lo1, hi1;
     c0.prepare(&lo0, &hi0);
@@ -261,6 +272,8 @@ __device__ __forceinline__ void step2(M32Cursor &c0, bool r0, uint32_t *s0, M32C
     c1.pos += r1 ? M32Cursor::length(lo1, hi1) : 0u;
     *s0 = 0;
     *s1 = 0;
+    *n0 = 1;
+    *n1 = 1;
 }
 
 // Self-synchronising parse of [start, end) cut into Q <= 2*DEC_THREADS subsequences of `unit`.  On
@@ -300,10 +313,11 @@ __device__ void resolve_chain(DecShared &S, Cursor cur, uint32_t start, uint32_t
                 c0.seek(d0 ? w0 : end);
                 c1.seek(d1 ? w1 : end);
                 for (;;) {
-                    const bool r0 = d0 && c0.pos < min(b0, end), r1 = d1 && c1.pos < min(b1, end);
+                    const uint32_t wl0 = min(b0, end), wl1 = min(b1, end);
+                    const bool r0 = d0 && c0.pos < wl0, r1 = d1 && c1.pos < wl1;
                     if (!r0 && !r1) break;
-                    uint32_t u0, u1;
-                    step2(c0, r0, &u0, c1, r1, &u1);
+                    uint32_t u0, u1, n0, n1;
+                    step2(c0, r0, wl0, 2u, &u0, &n0, c1, r1, wl1, 2u, &u1, &n1);
                 }
                 s0 = c0.pos;
                 s1 = c1.pos;
@@ -314,10 +328,10 @@ __device__ void resolve_chain(DecShared &S, Cursor cur, uint32_t start, uint32_t
             for (;;) {
                 const bool r0 = d0 && c0.pos < lim0, r1 = d1 && c1.pos < lim1;
                 if (!r0 && !r1) break;
-                uint32_t u0, u1;
-                step2(c0, r0, &u0, c1, r1, &u1);
-                cnt0 += r0 ? 1u : 0u;
-                cnt1 += r1 ? 1u : 0u;
+                uint32_t u0, u1, n0, n1;
+                step2(c0, r0, lim0, 2u, &u0, &n0, c1, r1, lim1, 2u, &u1, &n1);
+                cnt0 += r0 ? n0 : 0u;
+                cnt1 += r1 ? n1 : 0u;
             }
             if (d0) { S.qs[q0] = s0; S.qe[q0] = c0.pos; S.qn[q0] = cnt0; S.qdirty[q0] = 0; }
             if (d1) { S.qs[q1] = s1; S.qe[q1] = c1.pos; S.qn[q1] = cnt1; S.qdirty[q1] = 0; }
@@ -376,10 +390,20 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
         for (;;) {
             const bool r0 = d0 && c0.pos < lim0 && k0 < nM32, r1 = d1 && c1.pos < lim1 && k1 < nM32;
             if (!r0 && !r1) break;
-            uint32_t u0, u1;
-            step2(c0, r0, &u0, c1, r1, &u1);
-            if (r0) { m32[k0++] = (uint8_t)u0; if (k0 == nM32) S.chainEnd = c0.pos; }
-            if (r1) { m32[k1++] = (uint8_t)u1; if (k1 == nM32) S.chainEnd = c1.pos; }
+            uint32_t u0, u1, n0, n1;
+            step2(c0, r0, lim0, nM32 - k0, &u0, &n0, c1, r1, lim1, nM32 - k1, &u1, &n1);
+            if (r0) {
+                m32[k0] = (uint8_t)u0;
+                if (n0 == 2u) m32[k0 + 1] = (uint8_t)(u0 >> 8);
+                k0 += n0;
+                if (k0 == nM32) S.chainEnd = c0.pos;
+            }
+            if (r1) {
+                m32[k1] = (uint8_t)u1;
+                if (n1 == 2u) m32[k1 + 1] = (uint8_t)(u1 >> 8);
+                k1 += n1;
+                if (k1 == nM32) S.chainEnd = c1.pos;
+            }
         }
     }
     __syncthreads();
@@ -494,7 +518,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                         if (depth + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }   // see DESIGN.md (unsupported depth)
                         if (depth < LUT_BITS && depth + z >= LUT_BITS) {
                             // the branch at depth 11 on this path: its 11-bit prefix continues into a second-level table
-                            if (writer) S.lut[(uint32_t)path & ((1u << LUT_BITS) - 1u)] = (uint16_t)(0x8000u | nSub);
+                            if (writer) S.lut[(uint32_t)path & ((1u << LUT_BITS) - 1u)] = 0x80000000u | nSub;
                             nSub++;
                         }
                         depth += z;
@@ -587,7 +611,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                 if ((uint32_t)tid < nLeaves) {
                     const uint32_t cl = S.leafLen[tid];
                     if (cl > 5 && cl <= LUT_BITS) {
-                        const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
+                        const uint32_t e = lut_single(S.leafSym[tid], cl);
                         for (uint32_t x = (uint32_t)S.leafCode[tid]; x < (1u << LUT_BITS); x += 1u << cl) S.lut[x] = e;
                     }
                 }
@@ -595,17 +619,29 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                 for (uint32_t j = 0; j < nShort; j++) {             // few, large fills: all threads together
                     const uint32_t i = S.shortLeaf[j];
                     const uint32_t cl = S.leafLen[i];
-                    const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[i]);
+                    const uint32_t e = lut_single(S.leafSym[i], cl);
                     for (uint32_t x = (uint32_t)S.leafCode[i] + ((uint32_t)tid << cl); x < (1u << LUT_BITS);
                          x += (uint32_t)DEC_THREADS << cl)
                         S.lut[x] = e;
                 }
                 __syncthreads();                                     // lut2 cleared, first level complete
+                // pair up: where the code behind an entry's symbol is short enough to lie inside the window too, the
+                // entry yields both symbols (its first-symbol fields stay as they are, so in-place update is safe)
+                for (uint32_t x = tid; x < (1u << LUT_BITS); x += DEC_THREADS) {
+                    const uint32_t e = S.lut[x];
+                    if (!(e & 0x80000000u)) {
+                        const uint32_t l1 = (e >> 16) & 63u;
+                        const uint32_t e2 = S.lut[x >> l1];                // the following bits, zero-extended
+                        const uint32_t l2b = (e2 >> 16) & 63u;
+                        if (!(e2 & 0x80000000u) && l1 + l2b <= (uint32_t)LUT_BITS)
+                            S.lut[x] = (e & 0x003F00FFu) | ((e2 & 0xffu) << 8) | ((l1 + l2b) << 22);
+                    }
+                }
                 if ((uint32_t)tid < nLeaves) {
                     const uint32_t cl = S.leafLen[tid];
                     if (cl > LUT_BITS && cl <= LUT_BITS + l2) {
                         const uint64_t code = S.leafCode[tid];
-                        const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffu;
+                        const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffffffu;
                         if (subIdx < nSub) {
                             uint16_t *sub = &lut2[subIdx << l2];
                             const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);

@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t row_scan_segment(uint32_t x, uint32_t carry,
 {
     const uint32_t incl = wave_incl_scan(x, lane) + carry;
     *outv = incl;
-    return __shfl(incl, 63, 64);
+    return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 
 constexpr int ROW_BATCH = 4;                    // rows a wave keeps in flight in the row scans
@@ -134,11 +134,18 @@ __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, u
                 }
             }
             if (model == 2) cStart = 2;
+            uint32_t xn[ROW_BATCH];                                 // the next chunk is loaded while this one is scanned
+#pragma unroll
+            for (int b = 0; b < ROW_BATCH; b++)
+                xn[b] = (rb + b < nR && cStart + lane < nC) ? o[(size_t)(rb + b) * nC + cStart + lane] : 0u;
             for (uint32_t c0 = cStart; c0 < nC; c0 += 64) {
                 const uint32_t c = c0 + lane;
                 uint32_t x[ROW_BATCH];
 #pragma unroll
-                for (int b = 0; b < ROW_BATCH; b++) x[b] = (rb + b < nR && c < nC) ? o[(size_t)(rb + b) * nC + c] : 0u;
+                for (int b = 0; b < ROW_BATCH; b++) x[b] = xn[b];
+#pragma unroll
+                for (int b = 0; b < ROW_BATCH; b++)
+                    xn[b] = (rb + b < nR && c + 64u < nC) ? o[(size_t)(rb + b) * nC + c + 64u] : 0u;
 #pragma unroll
                 for (int b = 0; b < ROW_BATCH; b++) {
                     uint32_t v;
