@@ -90,7 +90,7 @@ __device__ __forceinline__ void cn_rounds(uint16_t *parent, uint32_t (&K)[8], in
             if ((uint32_t)(r * 64) < 2u * P) {                      // wave-uniform
                 const uint32_t e = (uint32_t)(r * 64 + lane);
                 const uint32_t mine = K[r];
-                const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
+                const uint32_t other = gf_lane_xor(mine, 1);
                 const uint32_t tieM = mine & 1023u;
                 const uint32_t idM = tieM >= 512u ? tieM - 512u : un + (510u - tieM);
                 const uint32_t k = kbase + (e >> 1);

@@ -108,6 +108,30 @@ GF_HD uint32_t gf_stream_cell(int model, uint32_t nR, uint32_t nC, uint32_t s)
 }
 
 #if defined(__HIPCC__)
+// Value of lane (lane ^ j), j a compile-time power of two: DPP for j <= 8 (quad permutes, row mirrors and rotates:
+// one or two VALU moves), ds_swizzle for 16, the LDS crossbar only for 32.  A __shfl_xor costs a ds_bpermute
+// (> 100 cycles of latency) at every stage of a sorting network; 18 of the 21 stages of a 64-key bitonic sort have j <= 8.
+__device__ __forceinline__ uint32_t gf_lane_xor(uint32_t v, int j)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int x = (int)v;
+    switch (j) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);            // quad_perm [1,0,3,2]
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);            // quad_perm [2,3,0,1]
+    case 4: {                                                                                      // i ^ 7, then reverse each quad
+        const int h = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);                   // row_half_mirror
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, h, 0x1B, 0xf, 0xf, true);                 // quad_perm [3,2,1,0]
+    }
+    case 8: return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);            // row_ror:8
+    case 16: return (uint32_t)__builtin_amdgcn_ds_swizzle(x, 0x401F);                             // bit mode: xor 0x10
+    default: return (uint32_t)__shfl_xor(x, j, 64);
+    }
+#else
+    (void)j;
+    return v;                                                                                      // host pass of hipcc: never executed
+#endif
+}
+
 // Wave64 inclusive prefix sum with DPP row shifts/broadcasts: 6 VALU steps, no LDS crossbar
 // (a __shfl_up ladder costs 6 dependent ds_bpermute round trips).
 __device__ __forceinline__ uint32_t gf_wave_incl_scan(uint32_t v)

@@ -76,7 +76,7 @@ __device__ __forceinline__ void wave_huff_rounds(GfHuffTree &T, uint32_t (&K)[4]
                 const uint32_t e = (uint32_t)(r * 64 + lane);
                 const bool inPair = e < 2u * P;
                 const uint32_t mine = K[r];
-                const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
+                const uint32_t other = gf_lane_xor(mine, 1);
                 const uint32_t tieM = mine & 511u, tieO = other & 511u;
                 const uint32_t idM = tieM >= 256u ? tieM - 256u : un + (254u - tieM);
                 const uint32_t idO = tieO >= 256u ? tieO - 256u : un + (254u - tieO);

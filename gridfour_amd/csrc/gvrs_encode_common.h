@@ -120,7 +120,7 @@ __device__ __forceinline__ void wave_bitonic_sort(Arr &k, int lane)
             } else {
 #pragma unroll
                 for (int r = 0; r < NREG; r++) {
-                    const uint32_t other = (uint32_t)__shfl_xor((int)k[r], j, 64);
+                    const uint32_t other = gf_lane_xor(k[r], j);
                     const bool asc = (((r * 64) | lane) & size) == 0;
                     const bool lower = (lane & j) == 0;
                     k[r] = (lower == asc) ? min(k[r], other) : max(k[r], other);
