@@ -168,7 +168,7 @@ __device__ __forceinline__ void cn_package_merge(CanonScratch &S, int nb, uint8_
             if ((w << 5) < n && n - (w << 5) < 32u) m &= (1u << (n - (w << 5))) - 1u;
             uint32_t pcnt = (uint32_t)__popc(m);
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) pcnt += (uint32_t)__shfl_xor((int)pcnt, o, 64);
+            for (int o = 32; o >= 1; o >>= 1) pcnt += gf_lane_xor(pcnt, o);
             merged += pcnt;
         }
         if (lane == 0) S.pmB[d] = n - merged;
@@ -238,7 +238,7 @@ __device__ __forceinline__ int cn_code_lengths(CanonScratch &S, const uint32_t *
         }
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) maxLen = max(maxLen, (uint32_t)__shfl_xor((int)maxLen, o, 64));
+    for (int o = 32; o >= 1; o >>= 1) maxLen = max(maxLen, gf_lane_xor(maxLen, o));
     if (maxLen > (uint32_t)CN_MAXLEN) {                              // TreeBuilder.java:173-178
         uint8_t *lenSorted = reinterpret_cast<uint8_t *>(S.parent);  // the tree is no longer needed
         cn_package_merge(S, n, lenSorted, lane);
@@ -249,7 +249,7 @@ __device__ __forceinline__ int cn_code_lengths(CanonScratch &S, const uint32_t *
             if (e < n) { depth[r] = lenSorted[e]; maxLen = max(maxLen, depth[r]); }
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) maxLen = max(maxLen, (uint32_t)__shfl_xor((int)maxLen, o, 64));
+        for (int o = 32; o >= 1; o >>= 1) maxLen = max(maxLen, gf_lane_xor(maxLen, o));
         __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
@@ -360,7 +360,7 @@ __device__ __forceinline__ int cn_rle(CanonScratch &S, const uint8_t *len, int n
                 else for (uint32_t q = 0; q < rr; q++) { tokCode[o] = (uint8_t)v; tokRun[o] = 0; o++; }
             }
         }
-        base += (int)__shfl((int)incl, 63, 64);
+        base += (int)__builtin_amdgcn_readlane((int)incl, 63);
     }
     __builtin_amdgcn_wave_barrier();
     return base;
@@ -409,7 +409,7 @@ __device__ __forceinline__ CanonBuilt cn_build(CanonScratch &S, const uint32_t *
         const uint32_t nb = lane < nMtok ? 5u + cn_run_bits(c) : 0u;
         const uint32_t incl = wave_incl_scan(nb, lane);
         if (lane < nMtok) cn_img_or(img, pos + incl - nb, c | ((uint32_t)S.mtokRun[lane] << 5), nb);
-        pos += (uint32_t)__shfl((int)incl, 63, 64);
+        pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     for (int i0 = 0; i0 < nTok; i0 += 64) {
         const int i = i0 + lane;
@@ -423,7 +423,7 @@ __device__ __forceinline__ CanonBuilt cn_build(CanonScratch &S, const uint32_t *
         }
         const uint32_t incl = wave_incl_scan(nb, lane);
         if (i < nTok) cn_img_or(img, pos + incl - nb, v, nb);
-        pos += (uint32_t)__shfl((int)incl, 63, 64);
+        pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     // exact size of the text: every counted symbol at its code length, raw escape bits, the quirk's extra escape
     unsigned long long bits = 0;

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_encode(GfEncodeArgs 
                 if (lane == 0 && n > 1) gf_huff_merge_t<false>(T, n, true);
             }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) nM32 += __shfl_xor(nM32, d, 64);
+            for (int d = 32; d >= 1; d >>= 1) nM32 += gf_lane_xor(nM32, d);
             __builtin_amdgcn_wave_barrier();
             GF_STAMP(4);
             // B3  header image, codes, serialised tree, exact bit totals
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_encode(GfEncodeArgs 
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 textBits += __shfl_xor(textBits, d, 64);
-                maxLen = max(maxLen, (uint32_t)__shfl_xor(maxLen, d, 64));
+                maxLen = max(maxLen, gf_lane_xor(maxLen, d));
             }
             if (lane == 0) {
                 const uint32_t treeBits = n == 1 ? 17u : (8u + 10u * (uint32_t)n - 1u);

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_decode(const uint8
                     b = gf_wave_incl_scan(b) + carry2;
                     d = gf_wave_incl_scan(d) + carry3;
                     if (in) { col0[0][rb + lane] = a & 0xffu; col0[1][rb + lane] = b & 0xffu; col0[2][rb + lane] = d & 0xffu; }
-                    carry1 = __shfl(a, 63, 64) & 0xffu;
-                    carry2 = __shfl(b, 63, 64) & 0xffu;
-                    carry3 = __shfl(d, 63, 64) & 0xffu;
+                    carry1 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63) & 0xffu;
+                    carry2 = (uint32_t)__builtin_amdgcn_readlane((int)b, 63) & 0xffu;
+                    carry3 = (uint32_t)__builtin_amdgcn_readlane((int)d, 63) & 0xffu;
                 }
             }
             __syncthreads();
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_decode(const uint8
                     a = gf_wave_incl_scan(a) + c1;
                     b = gf_wave_incl_scan(b) + c2;
                     d = gf_wave_incl_scan(d) + c3;
-                    c1 = __shfl(a, 63, 64);
-                    c2 = __shfl(b, 63, 64);
-                    c3 = __shfl(d, 63, 64);
+                    c1 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+                    c2 = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+                    c3 = (uint32_t)__builtin_amdgcn_readlane((int)d, 63);
                     if (in) {
                         const size_t i = rowOff + cc;
                         const uint32_t s = (pSign[i >> 3] >> (i & 7)) & 1u;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 4) void k_lsop_predict(GfLsopPredictArgs a)
             m = max(m, x < 0 ? 0u - (uint32_t)x : (uint32_t)x);
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, gf_lane_xor(m, o));
         if (lane == 0) atomicMax(&S.maxAbs, m);
         __syncthreads();
 
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs
                 const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 if (c < nC) v[c] = (int32_t)incl;
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         // column 0
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs
                 const uint32_t x = r < nR ? (uint32_t)res[nC - 1 + r - 1] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 if (r < nR) v[(size_t)r * nC] = (int32_t)incl;
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs
                 const uint32_t x = c < nC ? (uint32_t)res[base + c - 1] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 if (c < nC) v[nC + c] = (int32_t)(incl + (uint32_t)v[c]);
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs
                 const uint32_t x = r < nR ? (uint32_t)res[base + r - 2] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 if (r < nR) v[(size_t)r * nC + 1] = (int32_t)(incl + (uint32_t)v[(size_t)r * nC]);
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
                 const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 if (c < nC) { v[c] = (int32_t)incl; L[prev0 + c] = incl; }
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         uint32_t v10 = 0;                                  // v[1][0]
@@ -723,8 +723,8 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
                 const uint32_t x = r < nR ? (uint32_t)res[nC - 1 + r - 1] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 if (r < nR) v[(size_t)r * nC] = (int32_t)incl;
-                if (r0 == 1) v10 = (uint32_t)__shfl((int)incl, 0, 64);
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                if (r0 == 1) v10 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 0);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         if (lane == 0) L[prev1] = v10;
@@ -739,8 +739,8 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 const uint32_t val = incl + (c < nC ? L[prev0 + c] : 0u);
                 if (c < nC) { v[nC + c] = (int32_t)val; L[prev1 + c] = val; }
-                if (c0 == 1) v11 = (uint32_t)__shfl((int)val, 0, 64);
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                if (c0 == 1) v11 = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // column 0 is read back below
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
                 const uint32_t x = r < nR ? (uint32_t)res[base + r - 2] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
                 if (r < nR) v[(size_t)r * nC + 1] = (int32_t)(incl + (uint32_t)v[(size_t)r * nC]);
-                carry = (uint32_t)__shfl((int)incl, 63, 64);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
