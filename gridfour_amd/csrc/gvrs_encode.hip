@@ -245,7 +245,7 @@ __device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32
     }
 }
 
-__global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_encode(GfEncodeArgs a)
+__global__ __launch_bounds__(ENC_THREADS, 5) void k_huffman_encode(GfEncodeArgs a)
 {
     __shared__ EncPersist P;
     __shared__ EncScratch S;
