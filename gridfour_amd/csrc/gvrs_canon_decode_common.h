@@ -13,7 +13,7 @@ constexpr uint32_t CD_END_EOT = 0xFFFFFFFFu;     // subsequence ended on the end
 constexpr uint32_t CD_END_BAD = 0xFFFFFFFEu;     // subsequence ran into an invalid code / the end of the data
 
 struct CanonDec {
-    uint16_t lut[1 << CD_LUT_BITS];             // (len << 9) | symbol; 0 = longer than 11 bits (or no code)
+    uint32_t lut[1 << CD_LUT_BITS];             // see cd_entry(); 0 = longer than 11 bits (or no code)
     uint16_t symByOrder[320];                   // symbols ordered by (length, symbol)
     uint32_t first[16], count[16], offset[16];  // canonical code of the first symbol of a length, how many, where
     uint8_t len[320];
@@ -119,31 +119,47 @@ struct CdTok {
     uint32_t sym, bits, raw;     // bits = code + raw bits; sym == 0xFFFF: no such code
 };
 
-// lookup-table entry: symbol (9 bits) | code length << 9 | escape kind << 13 (1: two raw bits follow, 2: a raw byte)
-__device__ __forceinline__ uint16_t cd_lut_entry(uint32_t sym, uint32_t cl)
+// Lookup-table entry (32 bits): symbol (9 bits) | code length << 9 (4 bits) | escape kind << 13 (1: two raw bits
+// follow, 2: a raw byte).  Where the window holds TWO complete codes of plain values (symbols < 256) the entry also
+// carries the second one: symbol2 << 15 (8 bits) | both lengths << 23 (5 bits) | bit 31.  The fields of the first
+// symbol are valid either way.
+__device__ __forceinline__ uint32_t cd_entry(uint32_t sym, uint32_t cl)
 {
     const uint32_t kind = sym == (uint32_t)CN_ESC2 ? 1u : sym == (uint32_t)CN_ESC1 ? 2u : 0u;
-    return (uint16_t)(sym | (cl << 9) | (kind << 13));
+    return sym | (cl << 9) | (kind << 13);
 }
+__device__ __forceinline__ uint32_t cd_e_sym(uint32_t e) { return e & 511u; }
+__device__ __forceinline__ uint32_t cd_e_len(uint32_t e) { return (e >> 9) & 15u; }
+__device__ __forceinline__ uint32_t cd_e_extra(uint32_t e) { const uint32_t k = (e >> 13) & 3u; return (k & 1u) * 2u + (k >> 1) * 8u; }
+__device__ __forceinline__ bool cd_e_pair(uint32_t e) { return e >> 31; }
+__device__ __forceinline__ uint32_t cd_e_sym2(uint32_t e) { return (e >> 15) & 255u; }
+__device__ __forceinline__ uint32_t cd_e_len12(uint32_t e) { return (e >> 23) & 31u; }
 
-// the token whose code starts at bit 0 of the 32-bit window w
-__device__ __forceinline__ CdTok cd_token_of(const CanonDec &S, uint32_t w)
+// entry of the code that starts at bit 0 of the 32-bit window w; 0x7FFFFFFF: no such code
+__device__ __forceinline__ uint32_t cd_entry_of(const CanonDec &S, uint32_t w)
 {
     uint32_t e = S.lut[w & ((1u << CD_LUT_BITS) - 1u)];
-    CdTok t;
     if (!e) {                                             // longer than the table's 11 bits, or no such code
         uint32_t cl;
         const uint32_t sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(w), CD_LUT_BITS + 1, 15, &cl);
-        if (cl == 0) { t.sym = 0xFFFFu; t.bits = 1; t.raw = 0; return t; }
-        e = cd_lut_entry(sym, cl);
+        e = cl ? cd_entry(sym, cl) : 0x7FFFFFFFu;
     }
-    const uint32_t cl = (e >> 9) & 15u, kind = e >> 13;
-    const uint32_t extra = (kind & 1u) * 2u + (kind >> 1) * 8u;
-    t.sym = e & 511u;
+    return e;
+}
+
+// the FIRST token of an entry: symbol, total bits (code + raw), raw bits
+__device__ __forceinline__ CdTok cd_token_from(uint32_t e, uint32_t w)
+{
+    CdTok t;
+    if (e == 0x7FFFFFFFu) { t.sym = 0xFFFFu; t.bits = 1; t.raw = 0; return t; }
+    const uint32_t cl = cd_e_len(e), extra = cd_e_extra(e);
+    t.sym = cd_e_sym(e);
     t.raw = (w >> cl) & ((1u << extra) - 1u);
     t.bits = cl + extra;
     return t;
 }
+
+__device__ __forceinline__ CdTok cd_token_of(const CanonDec &S, uint32_t w) { return cd_token_from(cd_entry_of(S, w), w); }
 
 // Sequential reader: three words of the text in registers, the third fetched a word ahead of its use, the decode
 // window formed with one v_alignbit_b32 -- the only latency on the per-token path is the table lookup.
@@ -184,7 +200,14 @@ __device__ __forceinline__ void cd_run(const CanonDec &S, const Text &T, CdCur<T
     for (;;) {
         if (cur.pos >= bound) { end = cur.pos; break; }
         if (cur.pos >= endBit) { end = CD_END_BAD; break; }
-        const CdTok t = cd_token_of(S, cur.window());
+        const uint32_t w = cur.window();
+        const uint32_t e = cd_entry_of(S, w);
+        if (cd_e_pair(e) && cur.pos + cd_e_len(e) < bound) {     // two plain values, the second one starts before the boundary
+            cnt += 2u;
+            cur.advance(T, cd_e_len12(e));
+            continue;
+        }
+        const CdTok t = cd_token_from(e, w);
         if (t.sym == 0xFFFFu) { end = CD_END_BAD; break; }
         if (t.sym == (uint32_t)CN_EOT) { end = CD_END_EOT; *eotEnd = cur.pos + t.bits; break; }
         cnt += t.sym <= (uint32_t)CN_NULL ? 1u : 0u;
@@ -339,7 +362,17 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     for (uint32_t e = tid; e < (1u << CD_LUT_BITS); e += DEC_THREADS) {
         uint32_t cl;
         const uint32_t sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(e), 1, CD_LUT_BITS, &cl);
-        S.lut[e] = cl ? cd_lut_entry(sym, cl) : 0;
+        S.lut[e] = cl ? cd_entry(sym, cl) : 0;
+    }
+    __syncthreads();
+    for (uint32_t x = tid; x < (1u << CD_LUT_BITS); x += DEC_THREADS) {     // pair up plain values that share a window
+        const uint32_t e = S.lut[x];
+        if (e && cd_e_sym(e) < 256u) {
+            const uint32_t l1 = cd_e_len(e);
+            const uint32_t e2 = S.lut[x >> l1];                               // the following bits, zero-extended
+            if (e2 && cd_e_sym(e2) < 256u && l1 + cd_e_len(e2) <= (uint32_t)CD_LUT_BITS)
+                S.lut[x] = (e & 0x7FFFu) | (cd_e_sym(e2) << 15) | ((l1 + cd_e_len(e2)) << 23) | 0x80000000u;
+        }
     }
     __syncthreads();
 
@@ -355,7 +388,10 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
         if (q > 0) {                                            // warm-up: walk in from 128 bits before the boundary
             cur.seek(T, Bq - T0 > CD_WARM ? Bq - CD_WARM : T0);
             while (cur.pos < Bq) {
-                const CdTok tk = cd_token_of(S, cur.window());
+                const uint32_t w = cur.window();
+                const uint32_t e = cd_entry_of(S, w);
+                if (cd_e_pair(e) && cur.pos + cd_e_len(e) < Bq) { cur.advance(T, cd_e_len12(e)); continue; }
+                const CdTok tk = cd_token_from(e, w);
                 if (tk.sym == 0xFFFFu || tk.sym == (uint32_t)CN_EOT) { cur.seek(T, Bq); break; }
                 cur.advance(T, tk.bits);
             }
@@ -444,19 +480,33 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
             bool started = q != 0;                                // q == 0: an escape before any value is text[-1]
             CdCur<Text> cur;
             cur.seek(T, S.qs[q]);
-            CdTok tk = cd_token_of(S, cur.window());              // tk is always the token at the cursor
+            uint32_t w = cur.window();
+            uint32_t e = cd_entry_of(S, w);                       // e is always the entry at the cursor
             while (cur.pos < bound) {
+                if (cd_e_pair(e) && cur.pos + cd_e_len(e) < bound) {
+                    // two plain values in the window: the first one is complete (a value follows it, not an escape)
+                    started = true;
+                    sink.one(k, cd_e_sym(e) - 128u);
+                    k++;
+                    cur.advance(T, cd_e_len(e));
+                    w = cur.window();
+                    e = cd_entry(cd_e_sym2(e), cd_e_len12(e) - cd_e_len(e));
+                }
+                CdTok tk = cd_token_from(e, w);
                 if (tk.sym == (uint32_t)CN_EOT || tk.sym == 0xFFFFu) break;
                 cur.advance(T, tk.bits);
                 if (tk.sym > (uint32_t)CN_NULL) {                 // escape belonging to the previous value, or spare symbol 260
                     if (!started && tk.sym != 260u) S.runStatus = GF_K_ERR_BOUNDS;
-                    tk = cd_token_of(S, cur.window());
+                    w = cur.window();
+                    e = cd_entry_of(S, w);
                     continue;
                 }
                 started = true;
                 uint32_t v = tk.sym == (uint32_t)CN_NULL ? GF_NULL_CODE : tk.sym - 128u;
                 for (;;) {                                        // the escapes that extend this value (:495-504)
-                    tk = cd_token_of(S, cur.window());
+                    w = cur.window();
+                    e = cd_entry_of(S, w);
+                    tk = cd_token_from(e, w);
                     if (tk.sym == (uint32_t)CN_ESC2) v = (v << 2) | tk.raw;
                     else if (tk.sym == (uint32_t)CN_ESC1) v = (v << 8) | tk.raw;
                     else if (tk.sym != 260u) break;
