@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t row_scan_segment(uint32_t x, uint32_t carry,
     return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 
-constexpr int ROW_BATCH = 4;                    // rows a wave keeps in flight in the row scans
+constexpr int ROW_BATCH = 8;                    // rows a wave keeps in flight in the row scans
 
 // Predictor inverse in place (residuals at their cells -> values), int32 wrap-around prefix sums:
 // PredictorModelDifferencing.java:145-167, PredictorModelLinear.java:66-101, PredictorModelTriangle.java:62-98,
