@@ -132,9 +132,9 @@ __device__ __forceinline__ void wave_bitonic_sort(Arr &k, int lane)
 
 struct BitSink {
     uint32_t *win;
-    uint64_t acc;
+    uint32_t acc;       // bits of the current window word
     uint32_t nacc;      // valid bits in acc (< 32 between puts)
-    uint32_t wp;        // window word the low bits of acc belong to
+    uint32_t wp;        // window word acc belongs to
     bool first;         // the first word is shared with the previous thread
 
     __device__ __forceinline__ void init(uint32_t *w, uint32_t bitPos)
@@ -145,21 +145,19 @@ struct BitSink {
         acc = 0;
         first = true;
     }
-    __device__ __forceinline__ void flushWord()
-    {
-        uint32_t lo = (uint32_t)acc;
-        if (first) { atomicOr(&win[wp], lo); first = false; }
-        else win[wp] = lo;
-        wp++;
-        acc >>= 32;
-        nacc -= 32;
-    }
-    // len <= 32; (code, len) = (0, 0) is a no-op
+    // len <= 32; (code, len) = (0, 0) is a no-op.  32-bit arithmetic only on the common path (64-bit shifts run at
+    // a quarter of the rate): the bits that do not fit the current word are recovered in the (rarer) flush branch.
     __device__ __forceinline__ void put32(uint32_t code, uint32_t len)
     {
-        acc |= (uint64_t)code << nacc;
+        acc |= code << nacc;                   // nacc < 32
         nacc += len;
-        if (nacc >= 32) flushWord();
+        if (nacc >= 32u) {
+            if (first) { atomicOr(&win[wp], acc); first = false; }
+            else win[wp] = acc;
+            wp++;
+            nacc -= 32u;                       // bits of `code` that spilled into the next word
+            acc = nacc ? code >> (len - nacc) : 0u;
+        }
     }
     __device__ __forceinline__ void put(uint64_t code, uint32_t len)
     {
@@ -172,7 +170,7 @@ struct BitSink {
     }
     __device__ __forceinline__ void finish()
     {
-        if (nacc > 0) atomicOr(&win[wp], (uint32_t)acc);
+        if (nacc > 0) atomicOr(&win[wp], acc);
     }
 };
 
