@@ -31,12 +31,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "gvrs_kernels.h"
 #include "huff_build.h"
 
 namespace {
 
+constexpr int GF_K_SKIP = 0x7fff0001;           // internal: a diagnostic phase limit ended the tile early
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int LUT_BITS = 10;                    // first-level window: most symbol PAIRS of terrain data fit 10 bits
@@ -579,288 +581,292 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
         const size_t bmRaw = 2 * (((size_t)a.ldsM32Bytes >> 5) + 2) * 4;
         const size_t bmArea = bmRaw > 2 * L2_ENTRIES ? bmRaw : 2 * L2_ENTRIES;
         uint16_t *lut2 = reinterpret_cast<uint16_t *>(ldsDyn + a.ldsM32Bytes);
-        uint8_t *m32;
-        uint32_t *bm, *wb;
+        // Phases 1 and 2 run on the M32 buffer, its start bitmap and the rank bases -- in LDS, or in the workspace for
+        // tiles whose stream does not fit.  The body is instantiated once per memory space: with a pointer that may be
+        // either, every access would be a flat_* instruction (slow even when it lands in LDS).
         const uint32_t bmWords = (nM32 + 31u) >> 5;
-        if (nM32 <= a.ldsM32Bytes) {
-            m32 = ldsDyn;
-            bm = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes);
-            wb = bm + (a.ldsM32Bytes >> 5) + 1;
-        } else {
-            uint8_t *ws = a.workspace + (size_t)blockIdx.x * a.workspaceStride;
-            m32 = ws;
-            const size_t cap = ((size_t)6 * nCells + 31) & ~(size_t)31;
-            bm = reinterpret_cast<uint32_t *>(ws + cap);
-            wb = bm + (cap >> 5) + 1;
-        }
-        int32_t tileStatus = GF_K_OK;
+        auto phases12 = [&](auto inLds) -> int32_t {
+            uint8_t *m32;
+            uint32_t *bm, *wb;
+            if constexpr (decltype(inLds)::value) {
+                m32 = ldsDyn;
+                bm = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes);
+                wb = bm + (a.ldsM32Bytes >> 5) + 1;
+            } else {
+                uint8_t *ws = a.workspace + (size_t)blockIdx.x * a.workspaceStride;
+                m32 = ws;
+                const size_t cap = ((size_t)6 * nCells + 31) & ~(size_t)31;
+                bm = reinterpret_cast<uint32_t *>(ws + cap);
+                wb = bm + (cap >> 5) + 1;
+            }
+            int32_t tileStatus = GF_K_OK;
 
-        // ---------------- phase 1: Huffman text -> M32 bytes ----------------
-        if (S.uniformSym >= 0) {
-            const uint8_t sym = (uint8_t)S.uniformSym;
-            for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
-            __syncthreads();
-        } else {
-            // LUT from the leaf table: a leaf with a code of <= 11 bits owns 2^(11-len) first-level entries,
-            // one of 12..19 bits owns 2^(19-len) entries of its prefix's second-level table
-            {
-                const uint32_t nLeaves = S.nLeaves;
-                const uint32_t nSub = S.nSub;
-                const uint32_t l2 = S.l2bits;
-                for (uint32_t x = tid; x < (nSub << l2); x += DEC_THREADS) lut2[x] = 0xFFFFu;
-                if ((uint32_t)tid < nLeaves) {
-                    const uint32_t cl = S.leafLen[tid];
-                    if (cl > 5 && cl <= LUT_BITS) {
-                        const uint32_t e = lut_single(S.leafSym[tid], cl);
-                        for (uint32_t x = (uint32_t)S.leafCode[tid]; x < (1u << LUT_BITS); x += 1u << cl) S.lut[x] = e;
+            // ---------------- phase 1: Huffman text -> M32 bytes ----------------
+            if (S.uniformSym >= 0) {
+                const uint8_t sym = (uint8_t)S.uniformSym;
+                for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
+                __syncthreads();
+            } else {
+                // LUT from the leaf table: a leaf with a code of <= 11 bits owns 2^(11-len) first-level entries,
+                // one of 12..19 bits owns 2^(19-len) entries of its prefix's second-level table
+                {
+                    const uint32_t nLeaves = S.nLeaves;
+                    const uint32_t nSub = S.nSub;
+                    const uint32_t l2 = S.l2bits;
+                    for (uint32_t x = tid; x < (nSub << l2); x += DEC_THREADS) lut2[x] = 0xFFFFu;
+                    if ((uint32_t)tid < nLeaves) {
+                        const uint32_t cl = S.leafLen[tid];
+                        if (cl > 5 && cl <= LUT_BITS) {
+                            const uint32_t e = lut_single(S.leafSym[tid], cl);
+                            for (uint32_t x = (uint32_t)S.leafCode[tid]; x < (1u << LUT_BITS); x += 1u << cl) S.lut[x] = e;
+                        }
                     }
-                }
-                const uint32_t nShort = min(S.nShort, 64u);
-                for (uint32_t j = 0; j < nShort; j++) {             // few, large fills: all threads together
-                    const uint32_t i = S.shortLeaf[j];
-                    const uint32_t cl = S.leafLen[i];
-                    const uint32_t e = lut_single(S.leafSym[i], cl);
-                    for (uint32_t x = (uint32_t)S.leafCode[i] + ((uint32_t)tid << cl); x < (1u << LUT_BITS);
-                         x += (uint32_t)DEC_THREADS << cl)
-                        S.lut[x] = e;
-                }
-                __syncthreads();                                     // lut2 cleared, first level complete
-                // pair up: where the code behind an entry's symbol is short enough to lie inside the window too, the
-                // entry yields both symbols (its first-symbol fields stay as they are, so in-place update is safe)
-                for (uint32_t x = tid; x < (1u << LUT_BITS); x += DEC_THREADS) {
-                    const uint32_t e = S.lut[x];
-                    if (!(e & 0x80000000u)) {
-                        const uint32_t l1 = (e >> 16) & 63u;
-                        const uint32_t e2 = S.lut[x >> l1];                // the following bits, zero-extended
-                        const uint32_t l2b = (e2 >> 16) & 63u;
-                        if (!(e2 & 0x80000000u) && l1 + l2b <= (uint32_t)LUT_BITS)
-                            S.lut[x] = (e & 0x003F00FFu) | ((e2 & 0xffu) << 8) | ((l1 + l2b) << 22);
+                    const uint32_t nShort = min(S.nShort, 64u);
+                    for (uint32_t j = 0; j < nShort; j++) {             // few, large fills: all threads together
+                        const uint32_t i = S.shortLeaf[j];
+                        const uint32_t cl = S.leafLen[i];
+                        const uint32_t e = lut_single(S.leafSym[i], cl);
+                        for (uint32_t x = (uint32_t)S.leafCode[i] + ((uint32_t)tid << cl); x < (1u << LUT_BITS);
+                             x += (uint32_t)DEC_THREADS << cl)
+                            S.lut[x] = e;
                     }
-                }
-                if ((uint32_t)tid < nLeaves) {
-                    const uint32_t cl = S.leafLen[tid];
-                    if (cl > LUT_BITS && cl <= LUT_BITS + l2) {
-                        const uint64_t code = S.leafCode[tid];
-                        const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffffffu;
-                        if (subIdx < nSub) {
-                            uint16_t *sub = &lut2[subIdx << l2];
-                            const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
-                            for (uint32_t x = (uint32_t)(code >> LUT_BITS); x < (1u << l2); x += 1u << (cl - LUT_BITS))
-                                sub[x] = e;
+                    __syncthreads();                                     // lut2 cleared, first level complete
+                    // pair up: where the code behind an entry's symbol is short enough to lie inside the window too, the
+                    // entry yields both symbols (its first-symbol fields stay as they are, so in-place update is safe)
+                    for (uint32_t x = tid; x < (1u << LUT_BITS); x += DEC_THREADS) {
+                        const uint32_t e = S.lut[x];
+                        if (!(e & 0x80000000u)) {
+                            const uint32_t l1 = (e >> 16) & 63u;
+                            const uint32_t e2 = S.lut[x >> l1];                // the following bits, zero-extended
+                            const uint32_t l2b = (e2 >> 16) & 63u;
+                            if (!(e2 & 0x80000000u) && l1 + l2b <= (uint32_t)LUT_BITS)
+                                S.lut[x] = (e & 0x003F00FFu) | ((e2 & 0xffu) << 8) | ((l1 + l2b) << 22);
+                        }
+                    }
+                    if ((uint32_t)tid < nLeaves) {
+                        const uint32_t cl = S.leafLen[tid];
+                        if (cl > LUT_BITS && cl <= LUT_BITS + l2) {
+                            const uint64_t code = S.leafCode[tid];
+                            const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffffffu;
+                            if (subIdx < nSub) {
+                                uint16_t *sub = &lut2[subIdx << l2];
+                                const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
+                                for (uint32_t x = (uint32_t)(code >> LUT_BITS); x < (1u << l2); x += 1u << (cl - LUT_BITS))
+                                    sub[x] = e;
+                            }
                         }
                     }
                 }
-            }
-            __syncthreads();
-            GF_DSTAMP(3);
-            const uint32_t textStart = S.textStart, endBit = len * 8u;
-            const uint64_t baseWord = (off * 8ull) >> 5;
-            const uint32_t sh0 = (uint32_t)(off * 8ull) & 31u;
-            const uint32_t pkWords = (sh0 + endBit + 31u) >> 5;          // words that hold the packing
-            uint32_t *dbg = a.debug ? a.debug + t * 16 + 11 : nullptr;
-            if (pkWords * 4u <= a.ldsTextBytes) {
-                // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
-                uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + bmArea);
-                const uint64_t avail = nWords - baseWord;
-                for (uint32_t i = tid; i < pkWords; i += DEC_THREADS) txt[i] = i < avail ? w32[baseWord + i] : 0u;
                 __syncthreads();
-                HuffCursorT<const uint32_t *> cur;
-                cur.base32 = txt;
-                cur.nW = pkWords;
-                cur.sh0 = sh0;
-                cur.S = &S;
-                cur.lut2 = lut2;
-                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
-            } else {
-                HuffCursorT<const uint32_t *> cur;
-                cur.base32 = w32 + baseWord;
-                cur.nW = (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord);
-                cur.sh0 = sh0;
-                cur.S = &S;
-                cur.lut2 = lut2;
-                tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                GF_DSTAMP(3);
+                const uint32_t textStart = S.textStart, endBit = len * 8u;
+                const uint64_t baseWord = (off * 8ull) >> 5;
+                const uint32_t sh0 = (uint32_t)(off * 8ull) & 31u;
+                const uint32_t pkWords = (sh0 + endBit + 31u) >> 5;          // words that hold the packing
+                uint32_t *dbg = a.debug ? a.debug + t * 16 + 11 : nullptr;
+                if (pkWords * 4u <= a.ldsTextBytes) {
+                    // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
+                    uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + bmArea);
+                    const uint64_t avail = nWords - baseWord;
+                    for (uint32_t i = tid; i < pkWords; i += DEC_THREADS) txt[i] = i < avail ? w32[baseWord + i] : 0u;
+                    __syncthreads();
+                    HuffCursorT<const uint32_t *> cur;
+                    cur.base32 = txt;
+                    cur.nW = pkWords;
+                    cur.sh0 = sh0;
+                    cur.S = &S;
+                    cur.lut2 = lut2;
+                    tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                } else {
+                    HuffCursorT<const uint32_t *> cur;
+                    cur.base32 = w32 + baseWord;
+                    cur.nW = (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord);
+                    cur.sh0 = sh0;
+                    cur.S = &S;
+                    cur.lut2 = lut2;
+                    tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                }
             }
-        }
-        if (tileStatus != GF_K_OK) {
-            if (tid == 0) a.status[t] = tileStatus;
-            __syncthreads();
-            continue;
-        }
-        GF_DSTAMP(5);
-        if ((a.phaseLimit & 0xff) == 2) continue;
+            if (tileStatus != GF_K_OK) return tileStatus;
+            GF_DSTAMP(5);
+            if ((a.phaseLimit & 0xff) == 2) return (int32_t)GF_K_SKIP;
 
-        // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
-        {
-            M32Cursor cur;
-            cur.m = m32;
-            cur.n = nM32;
-            cur.pos = 0;
-            cur.base = 0;
-            cur.d0 = cur.d1 = cur.d2 = 0;
-            const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
-            const uint32_t nDw = (nM32 + 3u) >> 2;
-            // bitmap of the bytes that start a value
-            for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
-            if (tid == 0) { S.chainEnd = 0; S.dense = 0; }
-            __syncthreads();
-            // Local resolution, one dword of the stream per thread and step: a byte is certainly a value
-            // start when none of the five bytes before it can be an introducer (0x7f / 0x81) -- no value
-            // is longer than 6 bytes.  Where introducer candidates are near, walk the few values from
-            // the nearest certain start ("anchor").  No chain, no rounds; only a stream that is dense in
-            // multi-byte values (no anchor within 11 bytes) falls back to the chain resolution.
+            // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
             {
-                // 0x80 in every byte that may be an introducer (false positives are harmless)
-                auto cand = [](uint32_t x) -> uint32_t {
-                    const uint32_t p = x ^ 0x7F7F7F7Fu, q = x ^ 0x81818181u;
-                    return (((p - 0x01010101u) & ~p) | ((q - 0x01010101u) & ~q)) & 0x80808080u;
-                };
-                auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits
-                    return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
-                };
+                M32Cursor cur;
+                cur.m = m32;
+                cur.n = nM32;
+                cur.pos = 0;
+                cur.base = 0;
+                cur.d0 = cur.d1 = cur.d2 = 0;
+                const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
+                const uint32_t nDw = (nM32 + 3u) >> 2;
+                // bitmap of the bytes that start a value
+                for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
+                if (tid == 0) { S.chainEnd = 0; S.dense = 0; }
+                __syncthreads();
+                // Local resolution, one dword of the stream per thread and step: a byte is certainly a value
+                // start when none of the five bytes before it can be an introducer (0x7f / 0x81) -- no value
+                // is longer than 6 bytes.  Where introducer candidates are near, walk the few values from
+                // the nearest certain start ("anchor").  No chain, no rounds; only a stream that is dense in
+                // multi-byte values (no anchor within 11 bytes) falls back to the chain resolution.
+                {
+                    // 0x80 in every byte that may be an introducer (false positives are harmless)
+                    auto cand = [](uint32_t x) -> uint32_t {
+                        const uint32_t p = x ^ 0x7F7F7F7Fu, q = x ^ 0x81818181u;
+                        return (((p - 0x01010101u) & ~p) | ((q - 0x01010101u) & ~q)) & 0x80808080u;
+                    };
+                    auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits
+                        return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
+                    };
+                    for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
+                        const uint32_t i0 = dw << 2;
+                        uint32_t d0 = m32w[dw];
+                        if (i0 + 4 > nM32) d0 &= (1u << ((nM32 - i0) * 8u)) - 1u;
+                        const uint32_t dm1 = dw >= 1 ? m32w[dw - 1] : 0u, dm2 = dw >= 2 ? m32w[dw - 2] : 0u;
+                        const uint32_t c0 = cand(d0), cm1 = cand(dm1), cm2 = cand(dm2);
+                        const uint32_t validNib = i0 + 4 <= nM32 ? 0xFu : ((1u << (nM32 - i0)) - 1u);
+                        uint32_t nib;
+                        if (!((cm1 | (cm2 & 0x80000000u)) | c0)) {
+                            nib = validNib;                         // four single-byte values
+                        } else {
+                            const uint32_t dm3 = dw >= 3 ? m32w[dw - 3] : 0u, dm4 = dw >= 4 ? m32w[dw - 4] : 0u;
+                            // candidate bit b <-> byte i0 - 16 + b
+                            const uint32_t C = nib4(cand(dm4)) | (nib4(cand(dm3)) << 4) | (nib4(cm2) << 8) | (nib4(cm1) << 12) |
+                                               (nib4(c0) << 16);
+                            const uint32_t U = C | (C << 1) | (C << 2) | (C << 3) | (C << 4);   // bit m: a candidate in bytes m-4..m
+                            // position index j (byte i0-16+j) is a certain start iff U bit j-1 is clear; want the largest j <= 16
+                            const uint32_t safe = ~U & 0xFFF0u;                                  // j-1 in 4..15
+                            nib = 0;
+                            if (!safe) {
+                                S.dense = 1;
+                            } else {
+                                const uint32_t j = 32u - (uint32_t)__builtin_clz(safe);          // (j-1)+1
+                                const uint32_t anchor = i0 + j >= 16u ? i0 + j - 16u : 0u;
+                                M32Cursor c = cur;
+                                c.seek(anchor);
+                                const uint32_t stop = min(i0 + 4u, nM32);
+                                while (c.pos < stop) {
+                                    if (c.pos >= i0) nib |= 1u << (c.pos - i0);
+                                    c.next();
+                                }
+                            }
+                        }
+                        if (nib) atomicOr(&bm[i0 >> 5], nib << (i0 & 31u));
+                    }
+                }
+                __syncthreads();
+                GF_DSTAMP(6);
+                if (S.dense) {
+                    // chain resolution over the bytes (same scheme as the Huffman text), then mark the starts
+                    for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
+                    uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
+                    unit = max(16u, unit);
+                    const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
+                    resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, a.debug ? a.debug + t * 16 + 13 : nullptr);   // warm-up: 8 bytes
+                    for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
+                        const uint32_t limit = min(nM32, (q + 1) * unit);
+                        M32Cursor c = cur;
+                        c.seek(S.qs[q]);
+                        uint32_t word = c.pos >> 5, mask = 0;
+                        while (c.pos < limit) {
+                            const uint32_t w = c.pos >> 5;
+                            if (w != word) {
+                                if (mask) atomicOr(&bm[word], mask);
+                                word = w;
+                                mask = 0;
+                            }
+                            mask |= 1u << (c.pos & 31u);
+                            c.next();
+                        }
+                        if (mask) atomicOr(&bm[word], mask);
+                    }
+                    __syncthreads();
+                }
+                // rank base of every bitmap word (exclusive popcount prefix)
+                if (tid == 0) S.carry = 0;
+                __syncthreads();
+                for (uint32_t base = 0; base < bmWords; base += DEC_THREADS) {
+                    const uint32_t w = base + tid;
+                    const uint32_t pc = w < bmWords ? (uint32_t)__popc(bm[w]) : 0u;
+                    uint32_t tot;
+                    const uint32_t ex = block_excl_scan(pc, S.waveSum, &tot);
+                    if (w < bmWords) wb[w] = S.carry + ex;
+                    __syncthreads();
+                    if (tid == 0) S.carry += tot;
+                    __syncthreads();
+                }
+                GF_DSTAMP(7);
+                if (S.carry < nStream) tileStatus = GF_K_ERR_BOUNDS;         // predictor reads past codeM32s
+                // four byte positions per thread and step: consecutive bytes are (mostly) consecutive cells,
+                // so the stores of a wave are coalesced.  12 bytes of the buffer cover every value that
+                // starts in the thread's dword.
+                const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
+                const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
+                const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
                 for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
                     const uint32_t i0 = dw << 2;
-                    uint32_t d0 = m32w[dw];
-                    if (i0 + 4 > nM32) d0 &= (1u << ((nM32 - i0) * 8u)) - 1u;
-                    const uint32_t dm1 = dw >= 1 ? m32w[dw - 1] : 0u, dm2 = dw >= 2 ? m32w[dw - 2] : 0u;
-                    const uint32_t c0 = cand(d0), cm1 = cand(dm1), cm2 = cand(dm2);
-                    const uint32_t validNib = i0 + 4 <= nM32 ? 0xFu : ((1u << (nM32 - i0)) - 1u);
-                    uint32_t nib;
-                    if (!((cm1 | (cm2 & 0x80000000u)) | c0)) {
-                        nib = validNib;                         // four single-byte values
-                    } else {
-                        const uint32_t dm3 = dw >= 3 ? m32w[dw - 3] : 0u, dm4 = dw >= 4 ? m32w[dw - 4] : 0u;
-                        // candidate bit b <-> byte i0 - 16 + b
-                        const uint32_t C = nib4(cand(dm4)) | (nib4(cand(dm3)) << 4) | (nib4(cm2) << 8) | (nib4(cm1) << 12) |
-                                           (nib4(c0) << 16);
-                        const uint32_t U = C | (C << 1) | (C << 2) | (C << 3) | (C << 4);   // bit m: a candidate in bytes m-4..m
-                        // position index j (byte i0-16+j) is a certain start iff U bit j-1 is clear; want the largest j <= 16
-                        const uint32_t safe = ~U & 0xFFF0u;                                  // j-1 in 4..15
-                        nib = 0;
-                        if (!safe) {
-                            S.dense = 1;
-                        } else {
-                            const uint32_t j = 32u - (uint32_t)__builtin_clz(safe);          // (j-1)+1
-                            const uint32_t anchor = i0 + j >= 16u ? i0 + j - 16u : 0u;
-                            M32Cursor c = cur;
-                            c.seek(anchor);
-                            const uint32_t stop = min(i0 + 4u, nM32);
-                            while (c.pos < stop) {
-                                if (c.pos >= i0) nib |= 1u << (c.pos - i0);
-                                c.next();
+                    const uint32_t bits = (bm[i0 >> 5] >> (i0 & 31u)) & 0xfu;
+                    if (bits) {
+                        const uint32_t word = bm[i0 >> 5];
+                        uint32_t k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
+                        uint32_t d0 = m32w[dw];
+                        // Fast path (most dwords of terrain data): four value starts, none an introducer (0x7f / 0x81) or the
+                        // null code (0x80) -> four sign-extended bytes; if their cells are neighbours, one 16-byte store.
+                        {
+                            const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
+                            const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) &
+                                                     0x80808080u;
+                            if (bits == 0xfu && !special && k + 3u < nStream) {
+                                const uint32_t v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu), v1 = (uint32_t)((int32_t)(d0 << 16) >> 24),
+                                               v2 = (uint32_t)((int32_t)(d0 << 8) >> 24), v3 = (uint32_t)((int32_t)d0 >> 24);
+                                const bool fastCell = useMagic && wMain > 1;
+                                const uint32_t c0 = stream_cell_fast(model, nR, nC, k, magic, fastCell);
+                                const uint32_t c3 = stream_cell_fast(model, nR, nC, k + 3u, magic, fastCell);
+                                if (c3 - c0 == 3u) {
+                                    GfU4 q;
+                                    q.x = v0; q.y = v1; q.z = v2; q.w = v3;
+                                    *reinterpret_cast<GfU4 *>(o + c0) = q;
+                                } else {
+                                    o[c0] = v0;
+                                    o[stream_cell_fast(model, nR, nC, k + 1u, magic, fastCell)] = v1;
+                                    o[stream_cell_fast(model, nR, nC, k + 2u, magic, fastCell)] = v2;
+                                    o[c3] = v3;
+                                }
+                                continue;
+                            }
+                        }
+                        // bytes i0 .. i0+11, zero beyond nM32
+                        uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
+                        if (i0 + 12 > nM32) {
+                            const uint32_t valid = nM32 - i0;            // 1..11 bytes
+                            if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
+                            if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
+                            d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
+                        }
+    #pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            if ((bits >> j) & 1u) {
+                                if (k < nStream) {
+                                    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
+                                    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
+                                    uint32_t vlen;
+                                    const uint32_t val = m32_value(lo, hi, &vlen);
+                                    o[stream_cell_fast(model, nR, nC, k, magic, useMagic && wMain > 1)] = val;
+                                    if (k == nStream - 1) S.chainEnd = i0 + j + vlen;
+                                }
+                                k++;
                             }
                         }
                     }
-                    if (nib) atomicOr(&bm[i0 >> 5], nib << (i0 & 31u));
-                }
-            }
-            __syncthreads();
-            GF_DSTAMP(6);
-            if (S.dense) {
-                // chain resolution over the bytes (same scheme as the Huffman text), then mark the starts
-                for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
-                uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
-                unit = max(16u, unit);
-                const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
-                resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, a.debug ? a.debug + t * 16 + 13 : nullptr);   // warm-up: 8 bytes
-                for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-                    const uint32_t limit = min(nM32, (q + 1) * unit);
-                    M32Cursor c = cur;
-                    c.seek(S.qs[q]);
-                    uint32_t word = c.pos >> 5, mask = 0;
-                    while (c.pos < limit) {
-                        const uint32_t w = c.pos >> 5;
-                        if (w != word) {
-                            if (mask) atomicOr(&bm[word], mask);
-                            word = w;
-                            mask = 0;
-                        }
-                        mask |= 1u << (c.pos & 31u);
-                        c.next();
-                    }
-                    if (mask) atomicOr(&bm[word], mask);
                 }
                 __syncthreads();
+                if (tileStatus == GF_K_OK && S.chainEnd > nM32) tileStatus = GF_K_ERR_BOUNDS;   // last value truncated
             }
-            // rank base of every bitmap word (exclusive popcount prefix)
-            if (tid == 0) S.carry = 0;
-            __syncthreads();
-            for (uint32_t base = 0; base < bmWords; base += DEC_THREADS) {
-                const uint32_t w = base + tid;
-                const uint32_t pc = w < bmWords ? (uint32_t)__popc(bm[w]) : 0u;
-                uint32_t tot;
-                const uint32_t ex = block_excl_scan(pc, S.waveSum, &tot);
-                if (w < bmWords) wb[w] = S.carry + ex;
-                __syncthreads();
-                if (tid == 0) S.carry += tot;
-                __syncthreads();
-            }
-            GF_DSTAMP(7);
-            if (S.carry < nStream) tileStatus = GF_K_ERR_BOUNDS;         // predictor reads past codeM32s
-            // four byte positions per thread and step: consecutive bytes are (mostly) consecutive cells,
-            // so the stores of a wave are coalesced.  12 bytes of the buffer cover every value that
-            // starts in the thread's dword.
-            const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
-            const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
-            const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
-            for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
-                const uint32_t i0 = dw << 2;
-                const uint32_t bits = (bm[i0 >> 5] >> (i0 & 31u)) & 0xfu;
-                if (bits) {
-                    const uint32_t word = bm[i0 >> 5];
-                    uint32_t k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
-                    uint32_t d0 = m32w[dw];
-                    // Fast path (most dwords of terrain data): four value starts, none an introducer (0x7f / 0x81) or the
-                    // null code (0x80) -> four sign-extended bytes; if their cells are neighbours, one 16-byte store.
-                    {
-                        const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
-                        const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) &
-                                                 0x80808080u;
-                        if (bits == 0xfu && !special && k + 3u < nStream) {
-                            const uint32_t v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu), v1 = (uint32_t)((int32_t)(d0 << 16) >> 24),
-                                           v2 = (uint32_t)((int32_t)(d0 << 8) >> 24), v3 = (uint32_t)((int32_t)d0 >> 24);
-                            const bool fastCell = useMagic && wMain > 1;
-                            const uint32_t c0 = stream_cell_fast(model, nR, nC, k, magic, fastCell);
-                            const uint32_t c3 = stream_cell_fast(model, nR, nC, k + 3u, magic, fastCell);
-                            if (c3 - c0 == 3u) {
-                                GfU4 q;
-                                q.x = v0; q.y = v1; q.z = v2; q.w = v3;
-                                *reinterpret_cast<GfU4 *>(o + c0) = q;
-                            } else {
-                                o[c0] = v0;
-                                o[stream_cell_fast(model, nR, nC, k + 1u, magic, fastCell)] = v1;
-                                o[stream_cell_fast(model, nR, nC, k + 2u, magic, fastCell)] = v2;
-                                o[c3] = v3;
-                            }
-                            continue;
-                        }
-                    }
-                    // bytes i0 .. i0+11, zero beyond nM32
-                    uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
-                    if (i0 + 12 > nM32) {
-                        const uint32_t valid = nM32 - i0;            // 1..11 bytes
-                        if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
-                        if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
-                        d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
-                    }
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        if ((bits >> j) & 1u) {
-                            if (k < nStream) {
-                                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
-                                const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
-                                uint32_t vlen;
-                                const uint32_t val = m32_value(lo, hi, &vlen);
-                                o[stream_cell_fast(model, nR, nC, k, magic, useMagic && wMain > 1)] = val;
-                                if (k == nStream - 1) S.chainEnd = i0 + j + vlen;
-                            }
-                            k++;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (tileStatus == GF_K_OK && S.chainEnd > nM32) tileStatus = GF_K_ERR_BOUNDS;   // last value truncated
-        }
+            return tileStatus;
+        };
+        const int32_t tileStatus = nM32 <= a.ldsM32Bytes ? phases12(std::true_type{}) : phases12(std::false_type{});
+        if (tileStatus == (int32_t)GF_K_SKIP) continue;
         if (tileStatus != GF_K_OK) {
             if (tid == 0) a.status[t] = tileStatus;
             __syncthreads();
