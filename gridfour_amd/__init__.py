@@ -8,9 +8,9 @@ the reference interface used by tests, bench.py and Python callers.
 """
 from ._lib import (GvrsHipError, OK, DECLINED, OVERFLOW, ERR_FORMAT, ERR_BOUNDS, ERR_CAPACITY,  # noqa: F401
                    ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, PM_ALL, lib, lib_path)
-from .codec import (CodecHuffmanHip, CodecCanonHuffmanHip, CodecFloatHip, LsCodecHip, GvrsHipContext, DeviceBuffer, DeviceTileBatch, GpuTimer,  # noqa: F401
+from .codec import (CodecHuffmanHip, CodecDeflateHip, CodecCanonHuffmanHip, CodecFloatHip, LsCodecHip, GvrsHipContext, DeviceBuffer, DeviceTileBatch, GpuTimer,  # noqa: F401
                     INT4_NULL_CODE)
 from .sharding import shard_range  # noqa: F401
 
-__all__ = ["CodecHuffmanHip", "CodecCanonHuffmanHip", "CodecFloatHip", "LsCodecHip", "GvrsHipContext", "GvrsHipError", "INT4_NULL_CODE", "lib", "lib_path",
+__all__ = ["CodecHuffmanHip", "CodecCanonHuffmanHip", "CodecDeflateHip", "CodecFloatHip", "LsCodecHip", "GvrsHipContext", "GvrsHipError", "INT4_NULL_CODE", "lib", "lib_path",
            "shard_range"]

@@ -65,6 +65,15 @@ SIGNATURES = {
     "gf_lsop12_encode_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t,
                                        C.POINTER(C.c_size_t)]),
     "gf_lsop12_decode_i32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
+    "gf_m32_default_stride": (C.c_size_t, [C.c_int, C.c_int]),
+    "gf_m32_max_stream": (C.c_size_t, [C.c_int, C.c_int]),
+    "gf_m32_encode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_m32_decode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp,
+                                              _vp, _vp]),
+    "gf_deflate_encode_batch_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "gf_deflate_decode_batch_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_deflate_encode_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gf_deflate_decode_i32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "gf_compact_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t]),
     "gf_float_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "gf_float_planes_encode_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t]),

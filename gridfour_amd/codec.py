@@ -150,6 +150,18 @@ class CodecHuffmanHip:
         return out, status
 
 
+class CodecDeflateHip(CodecHuffmanHip):
+    """Drop-in for org.gridfour.compress.CodecDeflate: predictor + CodecM32 on the MI355X, Deflate (level 6) on the host's
+    zlib as the reference uses the JDK's."""
+
+    _PREFIX = "gf_deflate"
+
+    def _fn(self, name):
+        if name == "max_packing":                    # nM32 + 128 bytes at most (CodecDeflate.java:204)
+            return lambda r, c: int(lib().gf_m32_max_stream(r, c)) + 256
+        return getattr(lib(), "%s_%s" % (self._PREFIX, name))
+
+
 class CodecCanonHuffmanHip(CodecHuffmanHip):
     """Drop-in for org.gridfour.compress.canonicalHuffman.CodecCanonHuffman (the default integer codec of
     current Gridfour, GvrsFileSpecification.java:229), computed on the MI355X."""

@@ -71,6 +71,7 @@ struct gf_context {
     DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
     DevBuf dPlanes;        // CodecFloat plane staging
     DevBuf dResiduals, dCoefs, dStatus2;   // LSOP staging
+    DevBuf dM32, dM32Len, dM32Models, dSeeds;   // CodecDeflate staging
 };
 
 struct gf_timer {
@@ -158,6 +159,10 @@ void gf_context_destroy(gf_context *c)
     c->dResiduals.release();
     c->dCoefs.release();
     c->dStatus2.release();
+    c->dM32.release();
+    c->dM32Len.release();
+    c->dM32Models.release();
+    c->dSeeds.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -206,7 +211,7 @@ size_t gf_huffman_max_packing(int nRows, int nCols)
 }  // extern "C"
 
 // codec kinds behind the shared batch plumbing
-enum { KIND_HUFFMAN = 0, KIND_CANON = 1 };
+enum { KIND_HUFFMAN = 0, KIND_CANON = 1, KIND_RAW_M32 = 2 };
 
 static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
                                 size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
@@ -264,6 +269,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     a.nCols = nCols;
     a.phaseLimit = g_decPhaseLimit;
     a.debug = g_decodeDebug;
+    a.rawM32 = kind == KIND_RAW_M32 ? 1 : 0;
     if (kind == KIND_CANON) {
         a.ldsM32Bytes = 0;
         a.ldsTextBytes = gf_canon_decode_lds_text(nRows, nCols);
@@ -1143,6 +1149,232 @@ gf_status gf_lsop12_decode_i32(gf_context *c, int nRows, int nCols, const uint8_
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
     gf_status s = gf_lsop12_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
+    if (s != GF_OK) return s;
+    return (gf_status)st;
+}
+
+
+// ------------------------------------------------------------------ CodecDeflate (predictor + M32 on the GPU, Deflate on the host)
+
+size_t gf_m32_default_stride(int nRows, int nCols)
+{
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    return roundUp(cells + cells / 4 + 256, 16);
+}
+
+size_t gf_m32_max_stream(int nRows, int nCols) { return roundUp((size_t)6 * (size_t)nRows * (size_t)nCols + 16, 16); }
+
+gf_status gf_m32_encode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const int32_t *dValues,
+                                      uint8_t *dStreams, size_t subStride, uint32_t *dLengths, uint8_t *dModels,
+                                      uint32_t *dSeeds, int32_t *dStatus)
+{
+    if (!c || nRows < 1 || nCols < 1 || !dValues || !dStreams || !dLengths || !dModels || !dSeeds || !dStatus) return GF_ERR_ARG;
+    if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
+    if (subStride % 16 != 0 || subStride < 16 || ((uintptr_t)dStreams & 15) != 0) return GF_ERR_ARG;
+    GfM32Args a;
+    a.values = dValues;
+    a.out = dStreams;
+    a.subStride = subStride;
+    a.lengths = dLengths;
+    a.models = dModels;
+    a.seeds = dSeeds;
+    a.status = dStatus;
+    a.nTiles = nTiles;
+    a.nRows = nRows;
+    a.nCols = nCols;
+    GF_HIP(gf_launch_m32_streams(a, stream ? (hipStream_t)stream : c->stream));
+    return GF_OK;
+}
+
+gf_status gf_m32_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
+                                      size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
+                                      int32_t *dValues, int32_t *dStatus)
+{
+    return decodeBatchDev(KIND_RAW_M32, c, stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths,
+                          dValues, dStatus);
+}
+
+// CodecDeflate.encode :157-199 + compress :201-228 for a batch in host memory: the candidate M32 streams come from the GPU,
+// java.util.zip.Deflater(6) is the host's zlib, the strictly shortest packing wins (earlier predictor on ties).
+gf_status gf_deflate_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                                      uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *predictors, int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    size_t sub = gf_m32_default_stride(nRows, nCols);
+    gf_status s;
+    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dM32.ensure(nTiles * 3 * sub + 16)) != GF_OK) return s;
+    if ((s = c->dM32Len.ensure(nTiles * 12 + 16)) != GF_OK) return s;
+    if ((s = c->dM32Models.ensure(nTiles * 3 + 16)) != GF_OK) return s;
+    if ((s = c->dSeeds.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
+    s = gf_m32_encode_batch_i32_dev(c, c->stream, nRows, nCols, nTiles, (const int32_t *)c->dValues.p, (uint8_t *)c->dM32.p, sub,
+                                    (uint32_t *)c->dM32Len.p, (uint8_t *)c->dM32Models.p, (uint32_t *)c->dSeeds.p,
+                                    (int32_t *)c->dStatus.p);
+    if (s != GF_OK) return s;
+    std::vector<uint8_t> streams(nTiles * 3 * sub), models(nTiles * 3);
+    std::vector<uint32_t> lens(nTiles * 3), seeds(nTiles);
+    std::vector<int32_t> st(nTiles);
+    GF_HIP(hipMemcpyAsync(streams.data(), c->dM32.p, nTiles * 3 * sub, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(lens.data(), c->dM32Len.p, nTiles * 12, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(models.data(), c->dM32Models.p, nTiles * 3, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(seeds.data(), c->dSeeds.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+
+    // tiles with a stream longer than the default sub-slot: once more, one at a time, into worst-case slots
+    std::vector<std::vector<uint8_t>> big(nTiles);
+    for (size_t t = 0; t < nTiles; t++) {
+        if (st[t] != GF_OVERFLOW) continue;
+        const size_t maxSub = gf_m32_max_stream(nRows, nCols);
+        DevBuf slot, meta;
+        if ((s = slot.ensure(3 * maxSub)) != GF_OK) return s;
+        if ((s = meta.ensure(64)) != GF_OK) { slot.release(); return s; }
+        uint8_t *m = (uint8_t *)meta.p;
+        s = gf_m32_encode_batch_i32_dev(c, c->stream, nRows, nCols, 1, (const int32_t *)c->dValues.p + t * cells, (uint8_t *)slot.p,
+                                        maxSub, (uint32_t *)m, m + 16, (uint32_t *)(m + 32), (int32_t *)(m + 48));
+        big[t].resize(3 * maxSub);
+        hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+        if (s == GF_OK) {
+            e1 = hipMemcpyAsync(big[t].data(), slot.p, 3 * maxSub, hipMemcpyDeviceToHost, c->stream);
+            e2 = hipMemcpyAsync(&st[t], m + 48, 4, hipMemcpyDeviceToHost, c->stream);
+            e3 = hipStreamSynchronize(c->stream);
+        }
+        slot.release();
+        meta.release();
+        if (s != GF_OK) return s;
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return hipFail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3, "m32 overflow tile");
+    }
+
+    std::vector<std::vector<uint8_t>> packs(nTiles);
+    std::vector<uint8_t> chosen(nTiles, 0);
+    parallelFor(nTiles, [&](size_t t) {
+        if (st[t] != GF_OK) return;
+        const bool isBig = !big[t].empty();
+        const size_t stride = isBig ? gf_m32_max_stream(nRows, nCols) : sub;
+        const uint8_t *base = isBig ? big[t].data() : streams.data() + t * 3 * sub;
+        std::vector<uint8_t> z;
+        for (int p = 0; p < 3; p++) {
+            const uint32_t n = lens[t * 3 + p];
+            const int model = models[t * 3 + p];
+            if (model == 0 || n == 0) continue;                          // mCodeLength > 0 (:189)
+            if (!zDeflate(base + p * stride, n, 6, z)) continue;
+            size_t dN = z.size();
+            if (dN > (size_t)n + 118) dN = (size_t)n + 118;             // Deflater wrote into byte[nM32 + 128] from offset 10 (:204-205)
+            if (dN == 0) continue;
+            if (packs[t].empty() || dN + 10 < packs[t].size()) {        // strictly shorter (:195)
+                std::vector<uint8_t> &pk = packs[t];
+                pk.resize(dN + 10);
+                pk[0] = (uint8_t)codecIndex;
+                pk[1] = (uint8_t)model;
+                putLE32(&pk[2], seeds[t]);
+                putLE32(&pk[6], n);
+                memcpy(&pk[10], z.data(), dN);
+                chosen[t] = (uint8_t)model;
+            }
+        }
+        if (packs[t].empty()) st[t] = GF_DECLINED;
+    });
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        offsets[t] = total;
+        if (st[t] == GF_OK) total += packs[t].size();
+    }
+    offsets[nTiles] = total;
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    if (predictors) memcpy(predictors, chosen.data(), nTiles);
+    if (total > blobCap) return GF_ERR_CAPACITY;
+    for (size_t t = 0; t < nTiles; t++)
+        if (st[t] == GF_OK) memcpy(blob + offsets[t], packs[t].data(), packs[t].size());
+    return GF_OK;
+}
+
+// CodecDeflate.decode :108-155: the host's zlib inflates the M32 bytes, the GPU turns them into the tile.
+gf_status gf_deflate_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                      const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    std::vector<std::vector<uint8_t>> raw(nTiles);
+    std::vector<int32_t> hst(nTiles, GF_OK);
+    parallelFor(nTiles, [&](size_t t) {
+        if (offsets[t + 1] < offsets[t]) { hst[t] = GF_ERR_ARG; return; }
+        const uint8_t *pk = blob + offsets[t];
+        const size_t len = (size_t)(offsets[t + 1] - offsets[t]);
+        if (len < 10) { hst[t] = GF_ERR_BOUNDS; return; }
+        const uint32_t nM32 = getLE32(pk + 6);
+        if ((int32_t)nM32 < 0) { hst[t] = GF_ERR_BOUNDS; return; }      // NegativeArraySizeException
+        if ((uint64_t)nM32 > 6ull * cells) { hst[t] = GF_ERR_FORMAT; return; }
+        raw[t].assign(10 + (size_t)nM32, 0);
+        memcpy(raw[t].data(), pk, 10);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) { hst[t] = GF_ERR_FORMAT; return; }
+        zs.next_in = (Bytef *)(pk + 10);
+        zs.avail_in = (uInt)(len - 10);
+        zs.next_out = raw[t].data() + 10;
+        zs.avail_out = nM32;
+        const int zr = inflate(&zs, Z_PARTIAL_FLUSH);
+        const size_t got = zs.total_out;
+        inflateEnd(&zs);
+        if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) { hst[t] = GF_ERR_FORMAT; return; }   // DataFormatException
+        if (got == 0) hst[t] = GF_ERR_FORMAT;                           // decode returns null (:147-153)
+    });
+    std::vector<uint64_t> roff(nTiles + 1);
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        roff[t] = total;
+        if (hst[t] == GF_OK) total += roundUp(raw[t].size(), 4);
+    }
+    roff[nTiles] = total;
+    std::vector<uint8_t> staged(total + 16, 0);
+    std::vector<uint32_t> lengths(nTiles, 0);
+    for (size_t t = 0; t < nTiles; t++)
+        if (hst[t] == GF_OK) { memcpy(staged.data() + roff[t], raw[t].data(), raw[t].size()); lengths[t] = (uint32_t)raw[t].size(); }
+    gf_status s;
+    if ((s = c->dBlob.ensure(total + 32)) != GF_OK) return s;
+    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
+    GF_HIP(hipMemcpyAsync(c->dBlob.p, staged.data(), total + 16, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dOffsets.p, roff.data(), (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
+    s = gf_m32_decode_batch_i32_dev(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total + 16,
+                                    (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p, (int32_t *)c->dValues.p,
+                                    (int32_t *)c->dStatus.p);
+    if (s != GF_OK) return s;
+    std::vector<int32_t> st(nTiles);
+    GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    for (size_t t = 0; t < nTiles; t++)
+        if (hst[t] != GF_OK) st[t] = hst[t];
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    return GF_OK;
+}
+
+gf_status gf_deflate_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, uint8_t *out,
+                                size_t outCap, size_t *outLen)
+{
+    if (!outLen) return GF_ERR_ARG;
+    uint64_t offsets[2] = {0, 0};
+    int32_t st = 0;
+    gf_status s = gf_deflate_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, out, outCap, offsets, nullptr, &st);
+    *outLen = (size_t)offsets[1];
+    if (s != GF_OK) return s;
+    return (gf_status)st;
+}
+
+gf_status gf_deflate_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values)
+{
+    uint64_t offsets[2] = {0, (uint64_t)len};
+    int32_t st = 0;
+    gf_status s = gf_deflate_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
     if (s != GF_OK) return s;
     return (gf_status)st;
 }

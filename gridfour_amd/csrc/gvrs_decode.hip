@@ -468,7 +468,9 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
         }
 
         GF_DSTAMP(1);
-        if (wave == 0) {
+        if (a.rawM32) {
+            if (tid == 0) { S.parseStatus = len < 10ull + nM32 ? GF_K_ERR_BOUNDS : GF_K_OK; S.uniformSym = -1; S.textStart = 80; }
+        } else if (wave == 0) {
             // HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161) as a wave-uniform scalar loop: the
             // serialised tree (<= 83 dwords) and the node stack live in VGPRs and are read with
             // v_readlane, so a node costs a few dozen scalar instructions and no LDS round trip.
@@ -602,7 +604,11 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
             int32_t tileStatus = GF_K_OK;
 
             // ---------------- phase 1: Huffman text -> M32 bytes ----------------
-            if (S.uniformSym >= 0) {
+            if (a.rawM32) {
+                // the M32 bytes lie behind the header (the host inflated a CodecDeflate packing, CodecDeflate.java:141-147)
+                for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = pk[10 + i];
+                __syncthreads();
+            } else if (S.uniformSym >= 0) {
                 const uint8_t sym = (uint8_t)S.uniformSym;
                 for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
                 __syncthreads();

@@ -620,6 +620,125 @@ __global__ __launch_bounds__(ENC_THREADS, 5) void k_huffman_encode(GfEncodeArgs 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_m32_streams: the predictor -> CodecM32 stage on its own, for the codecs whose entropy stage is the host's zlib
+// (CodecDeflate.java:157-199: every applicable predictor's M32 stream is deflated, the shortest packing wins).
+// An M32 stream is what the packers above produce with the identity code table (every byte its own 8-bit code).
+// ------------------------------------------------------------------------------------------------
+struct M32Shared {
+    uint64_t tab[256];
+    uint32_t win[WIN_WORDS + WIN_SLACK];
+    uint32_t waveSum[ENC_WAVES];
+    uint32_t flags, seed, nStart;
+    unsigned long long sumStart;
+};
+
+__global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
+{
+    __shared__ M32Shared S;
+    const int tid = threadIdx.x;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    S.tab[tid] = (8ull << 56) | (uint64_t)tid;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
+        if (tid == 0) { S.flags = 0; S.sumStart = 0; S.nStart = 0; }
+        __syncthreads();
+        uint32_t myFlags = 0;
+        for (uint32_t i = tid; i < nCells; i += ENC_THREADS) myFlags |= tile[i] == GF_NULL_CODE ? 1u : 2u;
+        if (myFlags) atomicOr(&S.flags, myFlags);
+        __syncthreads();
+        const bool anyNull = S.flags & 1u, anyValid = S.flags & 2u;
+        const bool triOk = nR >= 2 && nC >= 2;
+        int32_t early = 99;
+        if (!anyValid) early = GF_K_DECLINED;                               // CodecDeflate.java:168-170 -> null
+        else if (!anyNull && nC < 2) early = GF_K_ERR_BOUNDS;               // PredictorModelLinear indexes values[1]
+        if (early != 99) {
+            if (tid < 3) { a.lengths[t * 3 + tid] = 0; a.models[t * 3 + tid] = 0; }
+            if (tid == 0) { a.status[t] = early; a.seeds[t] = 0; }
+            __syncthreads();
+            continue;
+        }
+        if (anyNull) {
+            // seed of the nulls predictor (PredictorModelDifferencingWithNulls.java:79-105)
+            long long mySum = 0;
+            uint32_t myCnt = 0;
+            for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
+                const uint32_t v = tile[idx];
+                if (v == GF_NULL_CODE) continue;
+                const uint32_t r = idx / nC, c = idx - r * nC;
+                bool flag;
+                if (c > 0) flag = tile[idx - 1] == GF_NULL_CODE;
+                else flag = r == 0 ? true : tile[idx - nC] == GF_NULL_CODE;
+                if (flag) { mySum += (int32_t)v; myCnt++; }
+            }
+            if (myCnt) {
+                atomicAdd(&S.sumStart, (unsigned long long)mySum);
+                atomicAdd(&S.nStart, myCnt);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const double avg = (double)(long long)S.sumStart / (double)S.nStart;
+                const double f = floor(avg + 0.5);
+                int32_t sd;
+                if (f >= 2147483647.0) sd = 2147483647;
+                else if (f <= -2147483648.0) sd = (int32_t)0x80000000;
+                else sd = (int32_t)f;
+                S.seed = (uint32_t)sd;
+            }
+        } else if (tid == 0) {
+            S.seed = tile[0];
+        }
+        __syncthreads();
+        const uint32_t seed = S.seed;
+        bool overflow = false;
+        for (int p = 0; p < 3; p++) {
+            const int model = anyNull ? (p == 0 ? 4 : 0) : (p == 2 ? (triOk ? 3 : 0) : p + 1);
+            if (model == 0) {
+                if (tid == 0) { a.lengths[t * 3 + p] = 0; a.models[t * 3 + p] = 0; }
+                continue;
+            }
+            uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + (t * 3 + (size_t)p) * a.subStride);
+            for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) S.win[i] = 0;
+            __syncthreads();
+            PackState ps;
+            ps.bitBase = 0;
+            ps.wordBase = 0;
+            ps.capWords = (uint32_t)(a.subStride >> 2);
+            const uint32_t nStream = gf_stream_len(model, nR, nC);
+            const uint32_t emb = 48;                                        // six bytes at most per value
+            if (nStream > 0) {
+                if (nC < 2) {
+                    pack_generic(model, tile, nR, nC, seed, S.tab, emb, 0u, nStream, S.win, out32, S.waveSum, ps);
+                } else if (model == 1) {
+                    pack_flat<1>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                } else if (model == 2) {
+                    pack_generic(2, tile, nR, nC, seed, S.tab, emb, 0u, 2u * nR - 1u, S.win, out32, S.waveSum, ps);
+                    pack_flat<2>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                } else if (model == 3) {
+                    pack_generic(3, tile, nR, nC, seed, S.tab, emb, 0u, nC - 1u + nR - 1u, S.win, out32, S.waveSum, ps);
+                    pack_flat<3>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                } else {
+                    pack_flat<4>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                }
+            }
+            {
+                const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
+                const uint32_t remWords = (remBits + 31u) >> 5;
+                for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
+                    if (ps.wordBase + j < ps.capWords) out32[ps.wordBase + j] = S.win[j];
+            }
+            const uint32_t nBytes = ps.bitBase >> 3;
+            if (nBytes > a.subStride) overflow = true;
+            if (tid == 0) { a.lengths[t * 3 + p] = nBytes; a.models[t * 3 + p] = (uint8_t)model; }
+            __syncthreads();
+        }
+        if (tid == 0) { a.status[t] = overflow ? GF_K_OVERFLOW : GF_K_OK; a.seeds[t] = seed; }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
@@ -627,5 +746,13 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (a.nTiles == 0) return hipSuccess;
     const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
     hipLaunchKernelGGL(k_huffman_encode, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_m32_streams(const GfM32Args &a, hipStream_t stream)
+{
+    if (a.nTiles == 0) return hipSuccess;
+    const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
+    hipLaunchKernelGGL(k_m32_streams, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }

@@ -46,6 +46,7 @@ struct GfDecodeArgs {
     uint32_t ldsTextBytes;     // capacity of the in-LDS copy of the packing (multiple of 16)
     int phaseLimit;            // diagnostic: stop after phase 0/1/2 (value 1/2/3); 0 = run everything
     uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
+    int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
 };
 
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
@@ -85,3 +86,17 @@ hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const u
                                   const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
                                   int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
                                   hipStream_t stream);
+
+// predictor -> M32 stage alone (gvrs_encode.hip): per tile up to three candidate M32 streams (CodecDeflate.java:157-199)
+struct GfM32Args {
+    const int32_t *values;
+    uint8_t *out;              // per tile 3 sub-slots of subStride bytes (candidates in the order D, L, T; nulls: slot 0)
+    size_t subStride;          // multiple of 16
+    uint32_t *lengths;         // 3 per tile: M32 bytes of the candidate (0 = not a candidate)
+    uint8_t *models;           // 3 per tile: predictor code of the candidate or 0
+    uint32_t *seeds;           // 1 per tile
+    int32_t *status;           // GF_K_OK / DECLINED / OVERFLOW (a candidate did not fit; its length is still exact) / ERR_BOUNDS
+    size_t nTiles;
+    int nRows, nCols;
+};
+hipError_t gf_launch_m32_streams(const GfM32Args &a, hipStream_t stream);

@@ -289,4 +289,49 @@ private:
     bool deflate_;
 };
 
+/** Drop-in for org.gridfour.compress.CodecDeflate (CodecDeflate.java:108-228): predictor + CodecM32 on the GPU,
+ *  Deflate (level 6) on the host's zlib. */
+class CodecDeflateHip : public ICompressionEncoder, public ICompressionDecoder {
+public:
+    explicit CodecDeflateHip(int device = 0)
+    {
+        const gf_status s = gf_context_create(device, &ctx_);
+        if (s != GF_OK) throw std::runtime_error(std::string("CodecDeflateHip: ") + gf_status_string(s) + " [" + gf_last_error() + "]");
+    }
+    ~CodecDeflateHip() override { gf_context_destroy(ctx_); }
+    CodecDeflateHip(const CodecDeflateHip &) = delete;
+    CodecDeflateHip &operator=(const CodecDeflateHip &) = delete;
+
+    std::optional<std::vector<uint8_t>> encode(int codecIndex, int nRows, int nCols, const std::vector<int32_t> &values) override
+    {
+        if ((size_t)nRows * (size_t)nCols != values.size()) throw std::invalid_argument("values.length != nRows*nCols");
+        std::vector<uint8_t> out(gf_m32_max_stream(nRows, nCols) + 256);
+        size_t n = 0;
+        const gf_status s = gf_deflate_encode_i32(ctx_, codecIndex, nRows, nCols, values.data(), out.data(), out.size(), &n);
+        if (s == GF_DECLINED) return std::nullopt;                       // CodecDeflate.java:168-170
+        if (s == GF_ERR_BOUNDS) throw ArrayIndexOutOfBoundsException("PredictorModelLinear needs nCols >= 2");
+        if (s < 0) throw std::runtime_error(std::string("gf_deflate_encode_i32: ") + gf_status_string(s));
+        out.resize(n);
+        return out;
+    }
+    std::optional<std::vector<uint8_t>> encodeFloats(int, int, int, const std::vector<float> &) override { return std::nullopt; }
+    bool implementsFloatingPointEncoding() const override { return false; }
+    bool implementsIntegerEncoding() const override { return true; }
+    std::vector<int32_t> decode(int nRows, int nColumns, const std::vector<uint8_t> &packing) override
+    {
+        std::vector<int32_t> out((size_t)nRows * (size_t)nColumns);
+        const gf_status s = gf_deflate_decode_i32(ctx_, nRows, nColumns, packing.data(), packing.size(), out.data());
+        if (s == GF_ERR_FORMAT || s == GF_ERR_BOUNDS) throw IOException(gf_status_string(s));
+        if (s < 0) throw std::runtime_error(std::string("gf_deflate_decode_i32: ") + gf_status_string(s));
+        return out;
+    }
+    std::optional<std::vector<float>> decodeFloats(int, int, const std::vector<uint8_t> &) override { return std::nullopt; }
+    void analyze(int, int, const std::vector<uint8_t> &) override {}
+    void reportAnalysisData(std::FILE *ps, int) override { std::fprintf(ps, "Gridfour_Deflate (HIP)\n"); }
+    void clearAnalysisData() override {}
+
+private:
+    gf_context *ctx_ = nullptr;
+};
+
 }  // namespace gridfour

@@ -103,7 +103,8 @@ JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(J
 
 
 // ---- org.gridfour.hip.HipCodecNative: the same two calls for every integer codec of the library ----
-// kind 0 = CodecHuffman, 1 = CodecCanonHuffman, 2 = LSOP12 (Deflate alternative disabled), 3 = LSOP12 (reference default)
+// kind 0 = CodecHuffman, 1 = CodecCanonHuffman, 2 = LSOP12 (Deflate alternative disabled), 3 = LSOP12 (reference default),
+// 4 = CodecDeflate
 JNIEXPORT jlong JNICALL Java_org_gridfour_hip_HipCodecNative_create(JNIEnv *env, jclass cls, jint device)
 {
     return Java_org_gridfour_hip_CodecHuffmanHip_createNative(env, cls, device);
@@ -119,7 +120,8 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_encode(JNIEnv 
 {
     Handle *h = (Handle *)(intptr_t)handle;
     const size_t cap = kind == 0 ? gf_huffman_max_packing(nRows, nCols)
-                     : kind == 1 ? gf_canon_max_packing(nRows, nCols) : gf_lsop12_max_packing(nRows, nCols) + 64;
+                     : kind == 1 ? gf_canon_max_packing(nRows, nCols)
+                     : kind == 4 ? gf_m32_max_stream(nRows, nCols) + 256 : gf_lsop12_max_packing(nRows, nCols) + 64;
     jbyte *out = new jbyte[cap];
     size_t n = 0;
     gf_status s;
@@ -128,6 +130,7 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_encode(JNIEnv 
         jint *v = (jint *)env->GetPrimitiveArrayCritical(values, nullptr);
         if (kind == 0) s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
         else if (kind == 1) s = gf_canon_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
+        else if (kind == 4) s = gf_deflate_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
         else s = gf_lsop12_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, kind == 3, (uint8_t *)out, cap, &n);
         env->ReleasePrimitiveArrayCritical(values, v, JNI_ABORT);
     }
@@ -163,6 +166,7 @@ JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_HipCodecNative_decode(JNIEnv *
         jint *o = (jint *)env->GetPrimitiveArrayCritical(result, nullptr);
         if (kind == 0) s = gf_huffman_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
         else if (kind == 1) s = gf_canon_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
+        else if (kind == 4) s = gf_deflate_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
         else s = gf_lsop12_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
         env->ReleasePrimitiveArrayCritical(result, o, 0);
         env->ReleasePrimitiveArrayCritical(packing, p, JNI_ABORT);

@@ -1,7 +1,7 @@
 /*
  * Native entry points shared by the adapters of this package (JNI shim: gvrs_hip_jni.cpp; C ABI:
  * include/gvrs_hip_codec.h).  kind: 0 CodecHuffman, 1 CodecCanonHuffman, 2 LSOP12 without the Deflate
- * alternative, 3 LSOP12 with it (the reference's default).  Not compiled in the build image (no JDK).
+ * alternative, 3 LSOP12 with it (the reference's default), 4 CodecDeflate.  Not compiled in the build image (no JDK).
  */
 package org.gridfour.hip;
 

@@ -166,6 +166,33 @@ gf_status gf_canon_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_row
                                         size_t slot_stride, const uint32_t *d_lengths, int32_t *d_values,
                                         int32_t *d_status);
 
+/* ---- CodecDeflate (compress/CodecDeflate.java:108-228): predictor -> CodecM32 on the GPU, Deflate (level 6) on the host's
+ * zlib, 10-byte header codec_index, predictor, seed LE, nM32 LE.  The encoder deflates the M32 stream of every applicable
+ * predictor and keeps the strictly shortest packing (:176-199).  The predictor + M32 stage is available on its own:
+ *   gf_m32_encode_batch_i32_dev: per tile three candidate streams (sub-slots of sub_stride bytes, order Differencing, Linear,
+ *     Triangle; a tile with nulls has the DifferencingWithNulls stream in sub-slot 0), d_lengths[3 n], d_models[3 n]
+ *     (predictor code, 0 = no candidate), d_seeds[n]; per-tile status GF_OVERFLOW when a stream is longer than sub_stride
+ *     (its length is still exact).
+ *   gf_m32_decode_batch_i32_dev: "raw" containers = 10-byte CodecDeflate/CodecHuffman header followed by the M32 bytes
+ *     themselves -> tiles (the stage after Inflater.inflate, CodecDeflate.java:141-147); layout as gf_huffman_decode_batch_i32_dev. */
+size_t gf_m32_default_stride(int n_rows, int n_cols);
+size_t gf_m32_max_stream(int n_rows, int n_cols);
+gf_status gf_m32_encode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                      const int32_t *d_values, uint8_t *d_streams, size_t sub_stride, uint32_t *d_lengths,
+                                      uint8_t *d_models, uint32_t *d_seeds, int32_t *d_status);
+gf_status gf_m32_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                      const uint8_t *d_blob, size_t blob_bytes, const uint64_t *d_offsets, size_t slot_stride,
+                                      const uint32_t *d_lengths, int32_t *d_values, int32_t *d_status);
+gf_status gf_deflate_encode_batch_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                      const int32_t *values, uint8_t *blob, size_t blob_cap, uint64_t *offsets,
+                                      uint8_t *predictors, int32_t *status);
+gf_status gf_deflate_decode_batch_i32(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                      const uint64_t *offsets, int32_t *values, int32_t *status);
+gf_status gf_deflate_encode_i32(gf_context *ctx, int codec_index, int n_rows, int n_cols, const int32_t *values,
+                                uint8_t *out, size_t out_cap, size_t *out_len);
+gf_status gf_deflate_decode_i32(gf_context *ctx, int n_rows, int n_cols, const uint8_t *packing, size_t packing_len,
+                                int32_t *values);
+
 /* ---- LSOP12 (lsop/LsEncoder12.java:122-219, lsop/LsDecoder12.java:94-160, lsop/LsOptimalPredictor12.java:109-383,
  * lsop/LsHeader.java:131-265, util/jama/LUDecomposition.java:70-134, 253-284): the optimal 12-coefficient linear
  * predictor.  Tiles need at least 6 rows and 6 columns (else GF_DECLINED, Java null); a singular system is GF_DECLINED too.

@@ -775,6 +775,9 @@ int gvo_codec_deflate_encode(int codecIndex, int nRows, int nCols,
         if (values[i] == GVO_INT4_NULL) containsNull = 1; else containsValid = 1;
     }
     if (!containsValid) return GVO_DECLINED;
+    /* PredictorModelLinear.encode indexes values[index + 1] (:113-126): with one column that runs past the array
+     * (ArrayIndexOutOfBoundsException out of CodecDeflate.encode) */
+    if (!containsNull && nCols < 2) return GVO_ERR_BOUNDS;
     uint8_t *mCode = (uint8_t *)malloc(6 * nCells + 8);
     uint8_t *test = (uint8_t *)malloc(6 * nCells + 138);
     uint8_t *best = (uint8_t *)malloc(6 * nCells + 138);

@@ -1,0 +1,101 @@
+"""GPU parity tests of the CodecDeflate path (predictor + CodecM32 on the GPU, zlib level 6 on the host) against the reference's
+own fixtures (Sample04/05/07: 40-byte packings reproduced byte for byte) and against the CPU oracle."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import oracle
+from gvrs_walk import tile_packings
+from tilegen import KINDS, NULL, add_nulls, make_tile
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def codec():
+    import gridfour_amd
+    return gridfour_amd.CodecDeflateHip()
+
+
+@pytest.mark.parametrize("name", ["Sample04_ShortComp.gvrs", "Sample05_IntComp.gvrs", "Sample07_ICFComp.gvrs"])
+def test_reference_fixtures_byte_exact(codec, golden_dir, name):
+    tiles = tile_packings(os.path.join(golden_dir, "ref_samples", name))
+    vals, packs = [], []
+    for idx in sorted(tiles):
+        (packing,) = tiles[idx]
+        tr, tc = divmod(idx, 2)
+        rows = np.arange(50)[:, None] + tr * 50
+        cols = np.arange(50)[None, :] + tc * 50
+        vals.append((rows * 100 + cols - 1).astype(np.int32).ravel())
+        packs.append(packing)
+    got, preds, status = codec.encode_batch(1, 50, 50, np.stack(vals))
+    assert (status == 0).all() and (preds == oracle.PM_LINEAR).all()
+    assert got == packs                                      # the GPU + zlib packing IS the reference's stored packing
+    dec, st = codec.decode_batch(50, 50, packs)
+    assert (st == 0).all() and np.array_equal(dec, np.stack(vals))
+
+
+def _check(codec, n_rows, n_cols, tiles):
+    packs, preds, status = codec.encode_batch(2, n_rows, n_cols, tiles)
+    good, idx = [], []
+    for t, v in enumerate(tiles):
+        try:
+            ref, used = oracle.codec_deflate_encode(2, n_rows, n_cols, v)
+        except ValueError:
+            assert packs[t] is None and status[t] == -2, (t, status[t])
+            continue
+        if ref is None:
+            assert packs[t] is None and status[t] == 1, (t, status[t])
+            continue
+        assert status[t] == 0 and preds[t] == used, (t, status[t], preds[t], used)
+        assert packs[t] == ref, (t, len(packs[t]), len(ref))
+        good.append(ref)
+        idx.append(t)
+    if good:
+        vals, st = codec.decode_batch(n_rows, n_cols, good)
+        for k, t in enumerate(idx):
+            assert st[k] == 0 and np.array_equal(vals[k], tiles[t]), (t, st[k])
+
+
+@pytest.mark.parametrize("shape", [(10, 10), (2, 2), (7, 9), (1, 37), (33, 65), (120, 150), (200, 200), (5, 300), (9, 1)],
+                         ids=lambda s: "%dx%d" % s)
+def test_parity_kinds(codec, shape):
+    n_rows, n_cols = shape
+    _check(codec, n_rows, n_cols, np.stack([make_tile(k, n_rows, n_cols) for k in KINDS]))
+
+
+@pytest.mark.parametrize("shape", [(10, 10), (6, 17), (1, 9), (120, 150)], ids=lambda s: "%dx%d" % s)
+def test_nulls_parity(codec, shape):
+    n_rows, n_cols = shape
+    tiles = [add_nulls(make_tile("smooth", n_rows, n_cols), n_rows, n_cols, f, blocks=b)
+             for f, b in ((0.02, False), (0.3, False), (0.9, False), (0.2, True))]
+    tiles.append(np.full(n_rows * n_cols, NULL, np.int32))
+    _check(codec, n_rows, n_cols, np.stack(tiles))
+
+
+def test_m32_stage_on_device():
+    import gridfour_amd
+    from gridfour_amd import DeviceBuffer, lib
+    ctx = gridfour_amd.GvrsHipContext(0)
+    n_rows, n_cols, nt = 64, 96, 20
+    tiles = np.stack([make_tile(KINDS[i % len(KINDS)], n_rows, n_cols, seed=i) for i in range(nt)])
+    sub = int(lib().gf_m32_max_stream(n_rows, n_cols))
+    dv, ds = DeviceBuffer(ctx, tiles.nbytes), DeviceBuffer(ctx, nt * 3 * sub + 16)
+    dl, dm, dsd, dst = DeviceBuffer(ctx, nt * 12), DeviceBuffer(ctx, nt * 3), DeviceBuffer(ctx, nt * 4), DeviceBuffer(ctx, nt * 4)
+    dv.upload(tiles)
+    gridfour_amd._lib.check(lib().gf_m32_encode_batch_i32_dev(ctx.handle, None, n_rows, n_cols, nt, dv.ptr, ds.ptr, sub, dl.ptr,
+                                                               dm.ptr, dsd.ptr, dst.ptr), "m32 encode")
+    ctx.synchronize()
+    lens, models, seeds = dl.download(np.uint32, nt * 3), dm.download(np.uint8, nt * 3), dsd.download(np.int32, nt)
+    streams = ds.download(np.uint8, nt * 3 * sub)
+    assert (dst.download(np.int32, nt) == 0).all()
+    for t in range(nt):
+        for p in range(3):
+            m32, seed = oracle.predictor_encode(p + 1, n_rows, n_cols, tiles[t])
+            assert models[t * 3 + p] == p + 1 and lens[t * 3 + p] == len(m32) and seeds[t] == seed
+            off = (t * 3 + p) * sub
+            assert bytes(streams[off:off + len(m32)]) == m32, (t, p)
+    for b in (dv, ds, dl, dm, dsd, dst):
+        b.free()
