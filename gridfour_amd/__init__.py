@@ -8,7 +8,7 @@ the reference interface used by tests, bench.py and Python callers.
 """
 from ._lib import (GvrsHipError, OK, DECLINED, OVERFLOW, ERR_FORMAT, ERR_BOUNDS, ERR_CAPACITY,  # noqa: F401
                    ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, PM_ALL, lib, lib_path)
-from .codec import (CodecHuffmanHip, CodecDeflateHip, CodecCanonHuffmanHip, CodecFloatHip, LsCodecHip, GvrsHipContext, DeviceBuffer, DeviceTileBatch, GpuTimer,  # noqa: F401
+from .codec import (CodecMasterHip, STANDARD_CODEC_LIST, CodecHuffmanHip, CodecDeflateHip, CodecCanonHuffmanHip, CodecFloatHip, LsCodecHip, GvrsHipContext, DeviceBuffer, DeviceTileBatch, GpuTimer,  # noqa: F401
                     INT4_NULL_CODE)
 from .sharding import shard_range  # noqa: F401
 

@@ -506,3 +506,48 @@ class LsCodecHip:
         for b in (dv, dr, dc, ds):
             b.free()
         return vals, status
+
+
+CODEC_NONE, CODEC_HUFFMAN, CODEC_DEFLATE, CODEC_CANON_HUFFMAN, CODEC_LSOP12 = 0, 1, 2, 3, 4
+STANDARD_CODEC_LIST = (CODEC_HUFFMAN, CODEC_DEFLATE, CODEC_NONE, CODEC_CANON_HUFFMAN)    # GvrsFileSpecification.java:221-230
+
+
+class CodecMasterHip:
+    """org.gridfour.gvrs.CodecMaster over a codec list, batched: the strictly shortest packing per tile (list order
+    breaks ties), decode dispatch on packing[0]."""
+
+    def __init__(self, codec_list=STANDARD_CODEC_LIST, context=None, device=0):
+        self.ctx = context if context is not None else GvrsHipContext(device)
+        self.codecs = np.asarray(codec_list, dtype=np.int32)
+
+    def encode_batch(self, nRows, nCols, tiles):
+        """Returns (packings: list[bytes|None], codec index used uint8 (255 = none), status)."""
+        v = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        cap = nt * (4 * nRows * nCols + 1024) + 64
+        offsets = np.zeros(nt + 1, np.uint64)
+        used = np.zeros(nt, np.uint8)
+        status = np.zeros(nt, np.int32)
+        while True:
+            blob = np.empty(cap, np.uint8)
+            st = lib().gf_codec_master_encode_batch_i32(self.ctx.handle, _ptr(self.codecs), self.codecs.size, nRows, nCols, nt,
+                                                        _ptr(v), _ptr(blob), cap, _ptr(offsets), _ptr(used), _ptr(status))
+            if st == _lib.ERR_CAPACITY:
+                cap = int(offsets[nt]) + 64
+                continue
+            check(st, "gf_codec_master_encode_batch_i32")
+            break
+        packs = [bytes(blob[int(offsets[t]):int(offsets[t + 1])]) if status[t] == _lib.OK else None for t in range(nt)]
+        return packs, used, status
+
+    def decode_batch(self, nRows, nCols, packings):
+        nt = len(packings)
+        offsets = np.zeros(nt + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(p) for p in packings])
+        blob = np.frombuffer(b"".join(packings) + b"\0" * 16, dtype=np.uint8)
+        out = np.zeros((nt, nRows * nCols), np.int32)
+        status = np.zeros(nt, np.int32)
+        check(lib().gf_codec_master_decode_batch_i32(self.ctx.handle, _ptr(self.codecs), self.codecs.size, nRows, nCols, nt,
+                                                     _ptr(blob), _ptr(offsets), _ptr(out), _ptr(status)),
+              "gf_codec_master_decode_batch_i32")
+        return out, status

@@ -1379,4 +1379,104 @@ gf_status gf_deflate_decode_i32(gf_context *c, int nRows, int nCols, const uint8
     return (gf_status)st;
 }
 
+
+// ------------------------------------------------------------------ CodecMaster: the shortest packing over a codec list
+
+// gvrs/CodecMaster.java:150-169 for a batch in host memory.  codecs[k] = GF_CODEC_* of the k-th entry of the file's codec list
+// (GF_CODEC_NONE for an entry that has no integer encoder, e.g. CodecFloat); k is the codec index written to packing[0].
+// Every integer codec encodes the batch; per tile the strictly shortest non-null packing wins, list order breaks ties.
+gf_status gf_codec_master_encode_batch_i32(gf_context *c, const int *codecs, int nCodecs, int nRows, int nCols, size_t nTiles,
+                                           const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
+                                           uint8_t *codecUsed, int32_t *status)
+{
+    if (!c || !codecs || nCodecs < 1 || nCodecs > 255 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    std::vector<std::vector<uint8_t>> best(nTiles);
+    std::vector<int32_t> bestSt(nTiles, GF_DECLINED);
+    std::vector<uint8_t> used(nTiles, 0xff);
+    std::vector<uint8_t> tmp;
+    std::vector<uint64_t> off(nTiles + 1);
+    std::vector<int32_t> st(nTiles);
+    for (int k = 0; k < nCodecs; k++) {
+        const int kind = codecs[k];
+        if (kind == GF_CODEC_NONE) continue;
+        size_t cap = nTiles * (4 * cells + 1024) + 64;
+        gf_status s = GF_OK;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            tmp.resize(cap);
+            switch (kind) {
+            case GF_CODEC_HUFFMAN: s = gf_huffman_encode_batch_i32(c, k, nRows, nCols, nTiles, values, tmp.data(), cap, off.data(), nullptr, st.data()); break;
+            case GF_CODEC_DEFLATE: s = gf_deflate_encode_batch_i32(c, k, nRows, nCols, nTiles, values, tmp.data(), cap, off.data(), nullptr, st.data()); break;
+            case GF_CODEC_CANON_HUFFMAN: s = gf_canon_encode_batch_i32(c, k, nRows, nCols, nTiles, values, tmp.data(), cap, off.data(), nullptr, st.data()); break;
+            case GF_CODEC_LSOP12: s = gf_lsop12_encode_batch_i32(c, k, nRows, nCols, nTiles, values, 1, tmp.data(), cap, off.data(), nullptr, st.data()); break;
+            default: return GF_ERR_ARG;
+            }
+            if (s != GF_ERR_CAPACITY) break;
+            cap = (size_t)off[nTiles] + 64;
+        }
+        if (s != GF_OK) return s;
+        for (size_t t = 0; t < nTiles; t++) {
+            if (st[t] < 0) { if (bestSt[t] >= 0 && best[t].empty()) bestSt[t] = st[t]; continue; }   // the Java encoder threw
+            if (st[t] != GF_OK) continue;
+            const size_t len = (size_t)(off[t + 1] - off[t]);
+            if (best[t].empty() || len < best[t].size()) {                               // strictly shorter (:161-164)
+                best[t].assign(tmp.begin() + (ptrdiff_t)off[t], tmp.begin() + (ptrdiff_t)off[t + 1]);
+                used[t] = (uint8_t)k;
+                bestSt[t] = GF_OK;
+            }
+        }
+    }
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        offsets[t] = total;
+        if (bestSt[t] == GF_OK) total += best[t].size();
+    }
+    offsets[nTiles] = total;
+    if (status) memcpy(status, bestSt.data(), nTiles * 4);
+    if (codecUsed) memcpy(codecUsed, used.data(), nTiles);
+    if (total > blobCap) return GF_ERR_CAPACITY;
+    for (size_t t = 0; t < nTiles; t++)
+        if (bestSt[t] == GF_OK) memcpy(blob + offsets[t], best[t].data(), best[t].size());
+    return GF_OK;
+}
+
+// gvrs/CodecMaster.java:195-203: dispatch on packing[0]
+gf_status gf_codec_master_decode_batch_i32(gf_context *c, const int *codecs, int nCodecs, int nRows, int nCols, size_t nTiles,
+                                           const uint8_t *blob, const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    if (!c || !codecs || nCodecs < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    std::vector<int32_t> st(nTiles, GF_ERR_FORMAT);
+    for (int k = 0; k < nCodecs; k++) {
+        std::vector<size_t> sel;
+        for (size_t t = 0; t < nTiles; t++)
+            if (offsets[t + 1] > offsets[t] && blob[offsets[t]] == (uint8_t)k) sel.push_back(t);
+        if (sel.empty() || codecs[k] == GF_CODEC_NONE) continue;
+        std::vector<uint64_t> off(sel.size() + 1);
+        std::vector<uint8_t> sub;
+        for (size_t i = 0; i < sel.size(); i++) {
+            off[i] = sub.size();
+            sub.insert(sub.end(), blob + offsets[sel[i]], blob + offsets[sel[i] + 1]);
+        }
+        off[sel.size()] = sub.size();
+        sub.resize(sub.size() + 16);
+        std::vector<int32_t> out(sel.size() * cells), sst(sel.size());
+        gf_status s;
+        switch (codecs[k]) {
+        case GF_CODEC_HUFFMAN: s = gf_huffman_decode_batch_i32(c, nRows, nCols, sel.size(), sub.data(), off.data(), out.data(), sst.data()); break;
+        case GF_CODEC_DEFLATE: s = gf_deflate_decode_batch_i32(c, nRows, nCols, sel.size(), sub.data(), off.data(), out.data(), sst.data()); break;
+        case GF_CODEC_CANON_HUFFMAN: s = gf_canon_decode_batch_i32(c, nRows, nCols, sel.size(), sub.data(), off.data(), out.data(), sst.data()); break;
+        case GF_CODEC_LSOP12: s = gf_lsop12_decode_batch_i32(c, nRows, nCols, sel.size(), sub.data(), off.data(), out.data(), sst.data()); break;
+        default: return GF_ERR_ARG;
+        }
+        if (s != GF_OK) return s;
+        for (size_t i = 0; i < sel.size(); i++) {
+            st[sel[i]] = sst[i];
+            if (sst[i] == GF_OK) memcpy(values + sel[i] * cells, out.data() + i * cells, cells * 4);
+        }
+    }
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    return GF_OK;
+}
+
 }  // extern "C"

@@ -235,6 +235,24 @@ gf_status gf_lsop12_encode_i32(gf_context *ctx, int codec_index, int n_rows, int
 gf_status gf_lsop12_decode_i32(gf_context *ctx, int n_rows, int n_cols, const uint8_t *packing, size_t packing_len,
                                int32_t *values);
 
+/* ---- CodecMaster (gvrs/CodecMaster.java:150-169, 195-203): a file's codec list in one batched call ------------------
+ * codecs[k] names the k-th entry of the codec list (the standard list of gvrs/GvrsFileSpecification.java:221-230 is
+ * {GF_CODEC_HUFFMAN, GF_CODEC_DEFLATE, GF_CODEC_NONE (CodecFloat), GF_CODEC_CANON_HUFFMAN}); k is the codec index written
+ * to packing[0].  Encode: every integer codec of the list encodes the batch, per tile the strictly shortest non-null packing
+ * wins, list order breaks ties; codec_used[t] = winning index (255: none).  Decode dispatches on packing[0]; an index outside
+ * the list is GF_ERR_FORMAT (IOException "Invalid compression-type code").                                                */
+#define GF_CODEC_NONE 0
+#define GF_CODEC_HUFFMAN 1
+#define GF_CODEC_DEFLATE 2
+#define GF_CODEC_CANON_HUFFMAN 3
+#define GF_CODEC_LSOP12 4
+gf_status gf_codec_master_encode_batch_i32(gf_context *ctx, const int *codecs, int n_codecs, int n_rows, int n_cols,
+                                           size_t n_tiles, const int32_t *values, uint8_t *blob, size_t blob_cap,
+                                           uint64_t *offsets, uint8_t *codec_used, int32_t *status);
+gf_status gf_codec_master_decode_batch_i32(gf_context *ctx, const int *codecs, int n_codecs, int n_rows, int n_cols,
+                                           size_t n_tiles, const uint8_t *blob, const uint64_t *offsets, int32_t *values,
+                                           int32_t *status);
+
 /* ---- CodecFloat (compress/CodecFloat.java:328-458): float32 tiles ---------------------------
  * The five byte planes (sign bits, exponent, three byte-delta coded mantissa bytes) are split and
  * merged on the GPU; the Deflate stage of each plane runs on the host's zlib (its bytes are defined

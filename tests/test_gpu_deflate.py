@@ -99,3 +99,35 @@ def test_m32_stage_on_device():
             assert bytes(streams[off:off + len(m32)]) == m32, (t, p)
     for b in (dv, ds, dl, dm, dsd, dst):
         b.free()
+
+
+def test_codec_master_standard_list():
+    # CodecMaster.java:150-169 over the standard codec list {Huffman, Deflate, Float, CanonicalHuffman}
+    import gridfour_amd
+    master = gridfour_amd.CodecMasterHip()
+    n_rows, n_cols = 60, 90
+    tiles = np.stack([make_tile(k, n_rows, n_cols) for k in KINDS] +
+                     [add_nulls(make_tile("smooth", n_rows, n_cols), n_rows, n_cols, 0.1), np.full(n_rows * n_cols, NULL, np.int32)])
+    packs, used, status = master.encode_batch(n_rows, n_cols, tiles)
+    encoders = {0: oracle.codec_huffman_encode, 1: lambda ci, r, c, v: oracle.codec_deflate_encode(ci, r, c, v),
+                3: oracle.codec_canon_encode}
+    for t, v in enumerate(tiles):
+        best, best_k = None, 255
+        for k in (0, 1, 3):
+            ref = encoders[k](k, n_rows, n_cols, v)[0]
+            if ref is not None and (best is None or len(ref) < len(best)):
+                best, best_k = ref, k
+        if best is None:
+            assert packs[t] is None and used[t] == 255 and status[t] == 1
+        else:
+            assert status[t] == 0 and used[t] == best_k and packs[t] == best, (t, used[t], best_k)
+    good = [p for p in packs if p is not None]
+    vals, st = master.decode_batch(n_rows, n_cols, good)
+    k = 0
+    for t, v in enumerate(tiles):
+        if packs[t] is None:
+            continue
+        assert st[k] == 0 and np.array_equal(vals[k], v), t
+        k += 1
+    _, st = master.decode_batch(n_rows, n_cols, [bytes([9]) + good[0][1:]])
+    assert st[0] == -1                                   # "Invalid compression-type code"
