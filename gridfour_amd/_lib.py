@@ -77,6 +77,8 @@ SIGNATURES = {
     "gf_codec_master_encode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp,
                                                    _vp, _vp]),
     "gf_codec_master_decode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_tile_payload_encode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "gf_tile_payload_decode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
     "gf_compact_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t]),
     "gf_float_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "gf_float_planes_encode_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t]),

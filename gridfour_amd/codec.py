@@ -551,3 +551,29 @@ class CodecMasterHip:
                                                      _ptr(blob), _ptr(offsets), _ptr(out), _ptr(status)),
               "gf_codec_master_decode_batch_i32")
         return out, status
+
+    # ---- tile payloads: RasterTile.getCompressedPacking over TileElementInt.encode (one integer element per tile) ----
+    def tile_payloads(self, nRows, nCols, tiles):
+        """Returns (payloads: list[bytes], codec index used uint8 (255 = raw cells))."""
+        v = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        cap = nt * (4 * nRows * nCols + 8)
+        blob = np.empty(cap, np.uint8)
+        offsets = np.zeros(nt + 1, np.uint64)
+        used = np.zeros(nt, np.uint8)
+        check(lib().gf_tile_payload_encode_batch_i32(self.ctx.handle, _ptr(self.codecs), self.codecs.size, nRows, nCols, nt,
+                                                     _ptr(v), _ptr(blob), cap, _ptr(offsets), _ptr(used)),
+              "gf_tile_payload_encode_batch_i32")
+        return [bytes(blob[int(offsets[t]):int(offsets[t + 1])]) for t in range(nt)], used
+
+    def tiles_from_payloads(self, nRows, nCols, payloads):
+        nt = len(payloads)
+        offsets = np.zeros(nt + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(p) for p in payloads])
+        blob = np.frombuffer(b"".join(payloads) + b"\0" * 16, dtype=np.uint8)
+        out = np.zeros((nt, nRows * nCols), np.int32)
+        status = np.zeros(nt, np.int32)
+        check(lib().gf_tile_payload_decode_batch_i32(self.ctx.handle, _ptr(self.codecs), self.codecs.size, nRows, nCols, nt,
+                                                     _ptr(blob), _ptr(offsets), _ptr(out), _ptr(status)),
+              "gf_tile_payload_decode_batch_i32")
+        return out, status

@@ -1479,4 +1479,85 @@ gf_status gf_codec_master_decode_batch_i32(gf_context *c, const int *codecs, int
     return GF_OK;
 }
 
+
+// ------------------------------------------------------------------ tile payloads (one integer element per tile)
+
+// RasterTile.getCompressedPacking (gvrs/RasterTile.java:234-256) over TileElementInt.encode (gvrs/TileElementInt.java:196-207)
+// for a batch: per tile [int32 LE n][n bytes], the bytes being the CodecMaster packing, or the raw little-endian cells when
+// no codec produced one or it is not shorter than them.  What RecordManager.writeTile stores behind the tile index.
+gf_status gf_tile_payload_encode_batch_i32(gf_context *c, const int *codecs, int nCodecs, int nRows, int nCols, size_t nTiles,
+                                           const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
+                                           uint8_t *codecUsed)
+{
+    if (!c || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols, rawBytes = cells * 4;
+    std::vector<uint8_t> packs(nTiles * (rawBytes + 1024) + 64);
+    std::vector<uint64_t> off(nTiles + 1);
+    std::vector<int32_t> st(nTiles);
+    std::vector<uint8_t> used(nTiles);
+    gf_status s = gf_codec_master_encode_batch_i32(c, codecs, nCodecs, nRows, nCols, nTiles, values, packs.data(), packs.size(),
+                                                   off.data(), used.data(), st.data());
+    if (s == GF_ERR_CAPACITY) {
+        packs.resize((size_t)off[nTiles] + 64);
+        s = gf_codec_master_encode_batch_i32(c, codecs, nCodecs, nRows, nCols, nTiles, values, packs.data(), packs.size(), off.data(),
+                                             used.data(), st.data());
+    }
+    if (s != GF_OK) return s;
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        if (st[t] < 0) return (gf_status)st[t];                          // an encoder threw: the Java call fails as a whole
+        const size_t n = st[t] == GF_OK ? (size_t)(off[t + 1] - off[t]) : 0;
+        const bool raw = st[t] != GF_OK || n >= rawBytes;
+        offsets[t] = total;
+        total += 4 + (raw ? rawBytes : n);
+        if (raw) used[t] = 0xff;
+    }
+    offsets[nTiles] = total;
+    if (codecUsed) memcpy(codecUsed, used.data(), nTiles);
+    if (total > blobCap) return GF_ERR_CAPACITY;
+    for (size_t t = 0; t < nTiles; t++) {
+        uint8_t *p = blob + offsets[t];
+        const size_t n = (size_t)(offsets[t + 1] - offsets[t]) - 4;
+        putLE32(p, (uint32_t)n);
+        if (used[t] == 0xff) memcpy(p + 4, values + t * cells, rawBytes);   // little-endian host == the file's byte order
+        else memcpy(p + 4, packs.data() + off[t], n);
+    }
+    return GF_OK;
+}
+
+// TileElementInt.decode (gvrs/TileElementInt.java:209-219): an encoding of exactly 4*cells bytes is the raw cells
+gf_status gf_tile_payload_decode_batch_i32(gf_context *c, const int *codecs, int nCodecs, int nRows, int nCols, size_t nTiles,
+                                           const uint8_t *blob, const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    if (!c || !blob || !offsets || !values) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols, rawBytes = cells * 4;
+    std::vector<uint64_t> off(nTiles + 1, 0);
+    std::vector<uint8_t> sub;
+    std::vector<int32_t> st(nTiles, GF_OK);
+    std::vector<uint8_t> isRaw(nTiles, 0);
+    for (size_t t = 0; t < nTiles; t++) {
+        off[t] = sub.size();
+        const size_t len = (size_t)(offsets[t + 1] - offsets[t]);
+        if (len < 4) { st[t] = GF_ERR_BOUNDS; continue; }
+        const uint8_t *p = blob + offsets[t];
+        const size_t n = getLE32(p);
+        if (n + 4 > len) { st[t] = GF_ERR_BOUNDS; continue; }
+        if (n == rawBytes) { isRaw[t] = 1; memcpy(values + t * cells, p + 4, rawBytes); continue; }
+        sub.insert(sub.end(), p + 4, p + 4 + n);
+    }
+    off[nTiles] = sub.size();
+    sub.resize(sub.size() + 16);
+    std::vector<int32_t> out(nTiles * cells), dst(nTiles);
+    gf_status s = gf_codec_master_decode_batch_i32(c, codecs, nCodecs, nRows, nCols, nTiles, sub.data(), off.data(), out.data(),
+                                                   dst.data());
+    if (s != GF_OK) return s;
+    for (size_t t = 0; t < nTiles; t++) {
+        if (isRaw[t] || st[t] != GF_OK) continue;
+        st[t] = dst[t];
+        if (dst[t] == GF_OK) memcpy(values + t * cells, out.data() + t * cells, rawBytes);
+    }
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    return GF_OK;
+}
+
 }  // extern "C"

@@ -253,6 +253,17 @@ gf_status gf_codec_master_decode_batch_i32(gf_context *ctx, const int *codecs, i
                                            size_t n_tiles, const uint8_t *blob, const uint64_t *offsets, int32_t *values,
                                            int32_t *status);
 
+/* ---- tile payloads (gvrs/RasterTile.java:234-256, gvrs/TileElementInt.java:196-219), tiles of one integer element:
+ * per tile [int32 LE n][n bytes] = the CodecMaster packing, or the raw little-endian cells when no codec produced a packing or
+ * it is not shorter than 4*cells bytes (codec_used[t] = 255).  This is what RecordManager.writeTile stores behind the tile
+ * index (gvrs/RecordManager.java:417-431).  Decode treats an element of exactly 4*cells bytes as raw cells.               */
+gf_status gf_tile_payload_encode_batch_i32(gf_context *ctx, const int *codecs, int n_codecs, int n_rows, int n_cols,
+                                           size_t n_tiles, const int32_t *values, uint8_t *blob, size_t blob_cap,
+                                           uint64_t *offsets, uint8_t *codec_used);
+gf_status gf_tile_payload_decode_batch_i32(gf_context *ctx, const int *codecs, int n_codecs, int n_rows, int n_cols,
+                                           size_t n_tiles, const uint8_t *blob, const uint64_t *offsets, int32_t *values,
+                                           int32_t *status);
+
 /* ---- CodecFloat (compress/CodecFloat.java:328-458): float32 tiles ---------------------------
  * The five byte planes (sign bits, exponent, three byte-delta coded mantissa bytes) are split and
  * merged on the GPU; the Deflate stage of each plane runs on the host's zlib (its bytes are defined

@@ -131,3 +131,31 @@ def test_codec_master_standard_list():
         k += 1
     _, st = master.decode_batch(n_rows, n_cols, [bytes([9]) + good[0][1:]])
     assert st[0] == -1                                   # "Invalid compression-type code"
+
+
+def test_tile_payloads_equal_the_fixture_records(golden_dir):
+    # the tile records of Sample05_IntComp.gvrs hold [int32 tileIndex][int32 n][packing]: everything behind the tile index
+    # is reproduced from the cell values (standard codec list, CodecDeflate wins on these ramps as it did in the reference)
+    import gridfour_amd
+    master = gridfour_amd.CodecMasterHip()
+    tiles = tile_packings(os.path.join(golden_dir, "ref_samples", "Sample05_IntComp.gvrs"))
+    vals, want = [], []
+    for idx in sorted(tiles):
+        (packing,) = tiles[idx]
+        tr, tc = divmod(idx, 2)
+        rows = np.arange(50)[:, None] + tr * 50
+        cols = np.arange(50)[None, :] + tc * 50
+        vals.append((rows * 100 + cols - 1).astype(np.int32).ravel())
+        want.append(struct.pack("<i", len(packing)) + packing)
+    payloads, used = master.tile_payloads(50, 50, np.stack(vals))
+    assert payloads == want and (used == 1).all()
+    back, st = master.tiles_from_payloads(50, 50, payloads)
+    assert (st == 0).all() and np.array_equal(back, np.stack(vals))
+    # incompressible and all-null tiles fall back to the raw cells (TileElementInt.java:198-204)
+    noise = make_tile("noise32", 50, 50)
+    nulls = np.full(2500, NULL, np.int32)
+    payloads, used = master.tile_payloads(50, 50, np.stack([noise, nulls]))
+    assert (used == 255).all()
+    assert payloads[0] == struct.pack("<i", 10000) + noise.astype("<i4").tobytes()
+    back, st = master.tiles_from_payloads(50, 50, payloads)
+    assert (st == 0).all() and np.array_equal(back[0], noise) and np.array_equal(back[1], nulls)
