@@ -1162,7 +1162,7 @@ size_t gf_m32_default_stride(int nRows, int nCols)
     return roundUp(cells + cells / 4 + 256, 16);
 }
 
-size_t gf_m32_max_stream(int nRows, int nCols) { return roundUp((size_t)6 * (size_t)nRows * (size_t)nCols + 16, 16); }
+size_t gf_m32_max_stream(int nRows, int nCols) { return roundUp((size_t)6 * (size_t)nRows * (size_t)nCols + 32, 16); }
 
 gf_status gf_m32_encode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const int32_t *dValues,
                                       uint8_t *dStreams, size_t subStride, uint32_t *dLengths, uint8_t *dModels,

@@ -507,37 +507,44 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
             if (rootBit == 1) {
                 uniformSym = (int32_t)take(8);
             } else {
-                // Pre-order walk without building nodes: `path` bit d = side (0 left, 1 right) of the child
-                // currently being read under the open branch at depth d; a leaf's code is path[0..depth].
-                // A run of z branch records (z zero bits) is consumed in one step: depth += z.
-                uint64_t path = 0;
-                uint32_t depth = 0;
+                // Pre-order walk without building nodes.  `c` is the code of the node about to be read as an integer of
+                // L bits, most significant bit = first step (0 left, 1 right).  One iteration per leaf: a run of z branch
+                // records (zero bits) appends z zeros to the code; the leaf that follows takes the code as it stands; the
+                // next node is the right sibling of the deepest ancestor still on its left side: strip the trailing ones,
+                // turn the zero in front of them into a one.
+                uint64_t c = 0;
+                uint32_t L = 1;                                              // the root's left child
                 uint32_t leaves = 0, records = 0;
+                bool complete = false;
                 while (leaves < nLeaves) {
                     refill();
                     if (records > 511) { st = GF_K_ERR_BOUNDS; break; }
-                    if (!(buf & 1ull)) {
-                        uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
-                        z = min(z, have);
-                        if (depth + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }   // see DESIGN.md (unsupported depth)
-                        if (depth < LUT_BITS && depth + z >= LUT_BITS) {
-                            // the branch at depth 11 on this path: its 11-bit prefix continues into a second-level table
-                            if (writer) S.lut[(uint32_t)path & ((1u << LUT_BITS) - 1u)] = 0x80000000u | nSub;
+                    uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
+                    z = min(z, have);
+                    if (z) {
+                        if (L - 1u + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }   // see DESIGN.md (unsupported depth)
+                        if (L <= (uint32_t)LUT_BITS && L + z > (uint32_t)LUT_BITS) {
+                            // a branch at depth LUT_BITS on this path: codes below it continue into a second-level table,
+                            // indexed by the first LUT_BITS bits of the path (first step in bit 0)
+                            const uint32_t prefix = (uint32_t)((c << z) >> (L + z - LUT_BITS));
+                            if (writer) S.lut[__brev(prefix) >> (32 - LUT_BITS)] = 0x80000000u | nSub;
                             nSub++;
                         }
-                        depth += z;
+                        c <<= z;                                             // z <= 63 here
+                        L += z;
                         records += z;
                         buf >>= z;
                         have -= z;
                         bp += z;
-                        continue;
+                        if (have == 0u || !(buf & 1ull)) continue;           // the run continues beyond the buffered bits
+                        refill();
                     }
                     const uint32_t rec = take(9);
                     const uint32_t sym = rec >> 1;
-                    const uint32_t clen = depth + 1u;
+                    const uint32_t clen = L;
                     records++;
                     if (writer) {
-                        S.leafCode[leaves] = path;
+                        S.leafCode[leaves] = __brevll(c) >> (64u - L);       // path bits, first step in bit 0
                         S.leafLen[leaves] = (uint8_t)clen;
                         S.leafSym[leaves] = (uint8_t)sym;
                         if (clen <= 5) S.shortLeaf[nShort & 63u] = (uint8_t)leaves;
@@ -545,16 +552,14 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                     if (clen <= 5) nShort++;
                     maxLen = max(maxLen, clen);
                     leaves++;
-                    if (leaves == nLeaves) break;
-                    // next record: right child of the deepest open branch that is still on its left child
-                    const uint64_t open = ~path & (depth >= 63 ? ~0ull : ((2ull << depth) - 1ull));
-                    if (open == 0) { st = GF_K_ERR_BOUNDS; break; }          // tree complete but leaves missing
-                    const uint32_t nd = 63u - (uint32_t)__builtin_clzll(open);
-                    path = (path & ((1ull << nd) - 1ull)) | (1ull << nd);
-                    depth = nd;
+                    const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;   // trailing ones
+                    if (leaves == nLeaves) { complete = t1 >= L; break; }
+                    if (t1 >= L) { st = GF_K_ERR_BOUNDS; break; }            // tree complete but leaves missing
+                    c = (c >> t1) | 1ull;
+                    L -= t1;
                 }
                 // all leaves read: the tree must be complete (every open branch is on its right child)
-                if (st == GF_K_OK && path != ((depth >= 63) ? ~0ull : ((2ull << depth) - 1ull))) st = GF_K_ERR_FORMAT;
+                if (st == GF_K_OK && !complete) st = GF_K_ERR_FORMAT;
             }
             if (st == GF_K_OK && bp > totalBits) st = GF_K_ERR_BOUNDS;   // read past end of data
             if (writer) {

@@ -631,6 +631,7 @@ struct M32Shared {
     uint32_t win[WIN_WORDS + WIN_SLACK];
     uint32_t waveSum[ENC_WAVES];
     uint32_t flags, seed, nStart;
+    uint32_t nBytes[3];         // exact M32 bytes of the candidates
     unsigned long long sumStart;
 };
 
@@ -690,13 +691,59 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
         } else if (tid == 0) {
             S.seed = tile[0];
         }
+        if (tid < 3) S.nBytes[tid] = 0;
         __syncthreads();
         const uint32_t seed = S.seed;
+        // exact stream lengths first (a candidate longer than its sub-slot is reported, not written)
+        {
+            uint32_t n1 = 0, n2 = 0, n3 = 0;
+            if (anyNull) {
+                for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
+                    const uint32_t r = idx / nC, c = idx - r * nC;
+                    n1 += (uint32_t)gf_m32_len(cell_residual(4, tile, nC, idx, r, c, seed));
+                }
+            } else {
+                uint32_t c0 = ((uint32_t)tid * CPT) % nC;
+                const uint32_t cStep = STEP_CELLS % nC;
+                for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
+                    Cells8 Q;
+                    load_cells8(tile, nC, nCells, i0, Q);
+                    uint32_t c = c0;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t idx = i0 + j;
+                        if (idx > 0 && idx < nCells) {                           // every cell but the seed has one residual per model
+                            const uint32_t v = Q.cur[j];
+                            const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+                            const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
+                            const uint32_t N = Q.up[j];
+                            const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+                            const uint32_t d = v - (c > 0 ? W : N);
+                            n1 += (uint32_t)gf_m32_len(d);
+                            n2 += (uint32_t)gf_m32_len(c >= 2 ? v - (2u * W - WW) : d);
+                            n3 += (uint32_t)gf_m32_len((idx >= nC && c > 0) ? v - (W + N - NW) : d);
+                        }
+                        if (++c == nC) c = 0;
+                    }
+                    c0 += cStep;
+                    if (c0 >= nC) c0 -= nC;
+                }
+            }
+            if (n1) atomicAdd(&S.nBytes[0], n1);
+            if (n2) atomicAdd(&S.nBytes[1], n2);
+            if (n3) atomicAdd(&S.nBytes[2], n3);
+        }
+        __syncthreads();
         bool overflow = false;
         for (int p = 0; p < 3; p++) {
             const int model = anyNull ? (p == 0 ? 4 : 0) : (p == 2 ? (triOk ? 3 : 0) : p + 1);
             if (model == 0) {
                 if (tid == 0) { a.lengths[t * 3 + p] = 0; a.models[t * 3 + p] = 0; }
+                continue;
+            }
+            if (S.nBytes[p] + 8u > a.subStride) {                            // does not fit (the flushes write whole words)
+                overflow = true;
+                if (tid == 0) { a.lengths[t * 3 + p] = S.nBytes[p]; a.models[t * 3 + p] = (uint8_t)model; }
                 continue;
             }
             uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + (t * 3 + (size_t)p) * a.subStride);
@@ -705,7 +752,6 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
             PackState ps;
             ps.bitBase = 0;
             ps.wordBase = 0;
-            ps.capWords = (uint32_t)(a.subStride >> 2);
             const uint32_t nStream = gf_stream_len(model, nR, nC);
             const uint32_t emb = 48;                                        // six bytes at most per value
             if (nStream > 0) {
@@ -727,10 +773,9 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
                 const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
                 const uint32_t remWords = (remBits + 31u) >> 5;
                 for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
-                    if (ps.wordBase + j < ps.capWords) out32[ps.wordBase + j] = S.win[j];
+                    out32[ps.wordBase + j] = S.win[j];
             }
             const uint32_t nBytes = ps.bitBase >> 3;
-            if (nBytes > a.subStride) overflow = true;
             if (tid == 0) { a.lengths[t * 3 + p] = nBytes; a.models[t * 3 + p] = (uint8_t)model; }
             __syncthreads();
         }

@@ -203,7 +203,6 @@ __device__ __forceinline__ uint32_t flat_residual(const Cells8 &Q, int j, uint32
 struct PackState {
     uint32_t bitBase;    // next free bit of the packing (absolute)
     uint32_t wordBase;   // words already flushed to the output slot
-    uint32_t capWords = 0xFFFFFFFFu;   // words the output slot can take (bits keep being counted beyond it)
 };
 
 // moves the completed words of the window to the output slot and slides the window
@@ -212,8 +211,7 @@ __device__ __forceinline__ void window_flush(uint32_t *win, uint32_t *__restrict
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t fullWords = (ps.bitBase >> 5) - ps.wordBase;
-    for (uint32_t j = tid; j < fullWords; j += ENC_THREADS)
-        if (ps.wordBase + j < ps.capWords) out32[ps.wordBase + j] = win[j];
+    for (uint32_t j = tid; j < fullWords; j += ENC_THREADS) out32[ps.wordBase + j] = win[j];
     const uint32_t partial = win[fullWords];
     __syncthreads();
     for (uint32_t j = tid; j <= fullWords; j += ENC_THREADS) win[j] = j == 0 ? partial : 0u;
