@@ -282,6 +282,41 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     return GF_OK;
 }
 
+// second entropy pass of the LSOP12 decode: containers k_lsop_unpack2 left marked GF_ERR_UNSUPPORTED (legacy Huffman of
+// M32; with rawM32 also the host-inflated Deflate ones)
+static gf_status lsopUnpackM32(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
+                               size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
+                               int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus, int rawM32)
+{
+    const unsigned grid = gf_huffman_decode_grid(nTiles);
+    const size_t wsStride = decodeWorkspaceStride(nRows, nCols);
+    if (c->workspace.bytes < (size_t)grid * wsStride) {
+        // not capture-safe: callers that capture graphs call gf_context_reserve first
+        GF_HIP(hipSetDevice(c->device));
+        gf_status s = c->workspace.ensure((size_t)grid * wsStride);
+        if (s != GF_OK) return s;
+    }
+    GfLsopM32Args a;
+    a.blob = dBlob;
+    a.blobBytes = blobBytes;
+    a.offsets = dOffsets;
+    a.slotStride = slotStride;
+    a.lengths = dLengths;
+    a.residuals = dResiduals;
+    a.resStride = resStride;
+    a.coefs = dCoefs;
+    a.status = dScratchStatus;
+    a.workspace = (uint8_t *)c->workspace.p;
+    a.workspaceStride = wsStride;
+    a.nTiles = nTiles;
+    a.nRows = nRows;
+    a.nCols = nCols;
+    a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
+    a.rawM32 = rawM32;
+    GF_HIP(gf_launch_lsop_unpack_m32(a, st, grid));
+    return GF_OK;
+}
+
 extern "C" {
 
 gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
@@ -860,6 +895,9 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
     const unsigned grid = gf_huffman_decode_grid(nTiles);
     GF_HIP(gf_launch_lsop_unpack2(dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride, dCoefs,
                                   dScratchStatus, nTiles, nRows, nCols, gf_canon_decode_lds_text(nRows, nCols), grid, st));
+    gf_status s = lsopUnpackM32(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals,
+                                resStride, dCoefs, dScratchStatus, 0);
+    if (s != GF_OK) return s;
     return gf_lsop12_reconstruct_dev(c, stream, nRows, nCols, nTiles, dResiduals, resStride, dCoefs, dScratchStatus, dValues,
                                      dStatus);
 }
@@ -879,32 +917,6 @@ size_t m32Pack(const int32_t *x, size_t n, std::vector<uint8_t> &out)
     }
     out.resize(k);
     return k;
-}
-
-// CodecM32.decode (:327-356) of exactly nValues values from nBytes bytes
-bool m32Unpack(const uint8_t *m, size_t nBytes, int32_t *out, size_t nValues)
-{
-    size_t pos = 0;
-    for (size_t i = 0; i < nValues; i++) {
-        if (pos >= nBytes) return false;
-        const int8_t sb = (int8_t)m[pos++];
-        if (sb == -128) { out[i] = (int32_t)0x80000000; continue; }
-        if (sb != 127 && sb != -127) { out[i] = sb; continue; }
-        uint32_t delta = 0;
-        int groups = 0;
-        for (;;) {
-            if (pos >= nBytes) return false;
-            const uint8_t b = m[pos++];
-            delta = (delta << 7) | (b & 0x7fu);
-            groups++;
-            if (!(b & 0x80u)) break;
-            if (groups >= 5) return false;
-        }
-        static const uint32_t base[5] = {127u, 255u, 16639u, 2113791u, 270549247u};
-        const uint32_t a = delta + base[groups - 1];
-        out[i] = sb == 127 ? (int32_t)a : (int32_t)(0u - a);
-    }
-    return true;
 }
 
 void putLE32(uint8_t *p, uint32_t x) { p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24); }
@@ -1018,9 +1030,9 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
     return GF_OK;
 }
 
-// LsDecoder12.decode :94-160 for a batch in host memory.  Canonical-Huffman containers are decoded on the GPU; Deflate
-// containers (either header revision) are inflated by the host's zlib, their M32 bytes unpacked, and the tile rebuilt on
-// the GPU; the legacy Huffman-of-M32 container (type 0, written only by old Gridfour versions) is GF_ERR_UNSUPPORTED.
+// LsDecoder12.decode :94-160 for a batch in host memory.  Every container type is entropy-decoded on the GPU: canonical
+// Huffman (type 2) and legacy Huffman of M32 (type 0, either header revision) as stored; for Deflate containers (type 1)
+// the host's zlib inflates the two streams first and the GPU receives the header followed by the inflated M32 bytes.
 gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                      const uint64_t *offsets, int32_t *values, int32_t *status)
 {
@@ -1033,7 +1045,89 @@ gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t
     const size_t cells = (size_t)nRows * (size_t)nCols;
     const size_t nRes = gf_lsop12_residual_count(nRows, nCols), resStride = roundUp(nRes, 4);
     const size_t nInit = (size_t)4 * nRows + 2 * nCols - 9, nInt = nRes - nInit;
-    const uint64_t total = offsets[nTiles];
+    std::vector<uint32_t> lengths(nTiles);
+    for (size_t t = 0; t < nTiles; t++) {
+        if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
+        lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
+    }
+
+    // Deflate containers: inflate on the host, hand the GPU [header][initialiser M32 bytes][interior M32 bytes]
+    struct Inflated { size_t tile; std::vector<uint8_t> bytes; int32_t st; };
+    std::vector<Inflated> infl;
+    std::vector<uint32_t> hdrLen;
+    for (size_t t = 0; t < nTiles; t++) {
+        const uint8_t *pk = blob + offsets[t];
+        const size_t len = lengths[t];
+        if (len < 3) continue;
+        const bool revised = pk[1] & 0x40;
+        size_t o = revised ? 2 : 1;
+        if (len < o + 1 + 52 + 8 + (revised ? 0 : 1) || pk[o] != 12) continue;      // the GPU reports these
+        int type = revised ? pk[1] & 0x0f : pk[o + 61] & 0x0f;
+        bool checksum = revised ? pk[1] & 0x80 : pk[o + 61] & 0x80;
+        o += 61 + (revised ? 0 : 1) + (checksum ? 4 : 0);
+        if (type == 0 || type == 2 || o > len) continue;
+        infl.push_back(Inflated{t, {}, GF_OK});
+        hdrLen.push_back((uint32_t)o);
+    }
+    parallelFor(infl.size(), [&](size_t i) {
+        Inflated &I = infl[i];
+        const uint8_t *pk = blob + offsets[I.tile];
+        const size_t len = lengths[I.tile], o = hdrLen[i];
+        // the byte counts sit right behind the 12 coefficients in both header revisions
+        const size_t at = ((pk[1] & 0x40) ? 3 : 2) + 52;
+        const uint32_t nMI = getLE32(pk + at), nMX = getLE32(pk + at + 4);
+        if (nMI > 6 * nInit + 64 || nMX > 6 * nInt + 64) { I.st = GF_ERR_FORMAT; return; }
+        I.bytes.resize(o + nMI + nMX);
+        memcpy(I.bytes.data(), pk, o);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) { I.st = GF_ERR_FORMAT; return; }
+        zs.next_in = (Bytef *)(pk + o); zs.avail_in = (uInt)(len - o);
+        zs.next_out = I.bytes.data() + o; zs.avail_out = nMI;
+        int zr = inflate(&zs, Z_PARTIAL_FLUSH);
+        const size_t used = zs.total_in, got = zs.total_out;
+        inflateEnd(&zs);
+        if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got < nMI) { I.st = GF_ERR_FORMAT; return; }
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) { I.st = GF_ERR_FORMAT; return; }
+        zs.next_in = (Bytef *)(pk + o + used); zs.avail_in = (uInt)(len - o - used);
+        zs.next_out = I.bytes.data() + o + nMI; zs.avail_out = nMX;
+        zr = inflate(&zs, Z_PARTIAL_FLUSH);
+        const size_t got2 = zs.total_out;
+        inflateEnd(&zs);
+        if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got2 < nMX) { I.st = GF_ERR_FORMAT; return; }
+    });
+    const uint8_t *gpuBlob = blob;
+    const uint64_t *gpuOffsets = offsets;
+    std::vector<uint8_t> blob2;
+    std::vector<uint64_t> offsets2;
+    if (!infl.empty()) {
+        offsets2.resize(nTiles + 1);
+        uint64_t total2 = 0;
+        size_t k = 0;
+        for (size_t t = 0; t < nTiles; t++) {
+            offsets2[t] = total2;
+            if (k < infl.size() && infl[k].tile == t) {
+                if (infl[k].st == GF_OK) lengths[t] = (uint32_t)infl[k].bytes.size();
+                k++;
+            }
+            total2 += lengths[t];
+        }
+        offsets2[nTiles] = total2;
+        blob2.resize(total2 + 4);
+        k = 0;
+        for (size_t t = 0; t < nTiles; t++) {
+            if (k < infl.size() && infl[k].tile == t) {
+                if (infl[k].st == GF_OK) { memcpy(blob2.data() + offsets2[t], infl[k].bytes.data(), lengths[t]); k++; continue; }
+                k++;
+            }
+            memcpy(blob2.data() + offsets2[t], blob + offsets[t], lengths[t]);
+        }
+        gpuBlob = blob2.data();
+        gpuOffsets = offsets2.data();
+    }
+    const uint64_t total = gpuOffsets[nTiles];
+
     gf_status s;
     if ((s = c->dBlob.ensure(total + 32)) != GF_OK) return s;
     if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
@@ -1043,90 +1137,28 @@ gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t
     if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
     if ((s = c->dResiduals.ensure(nTiles * resStride * 4 + 16)) != GF_OK) return s;
     if ((s = c->dCoefs.ensure(nTiles * 64 + 16)) != GF_OK) return s;
-    std::vector<uint32_t> lengths(nTiles);
-    for (size_t t = 0; t < nTiles; t++) {
-        if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
-        lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
-    }
-    GF_HIP(hipMemcpyAsync(c->dBlob.p, blob, total, hipMemcpyHostToDevice, c->stream));
-    GF_HIP(hipMemcpyAsync(c->dOffsets.p, offsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dBlob.p, gpuBlob, total, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dOffsets.p, gpuOffsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
     GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
     const unsigned grid = gf_huffman_decode_grid(nTiles);
     GF_HIP(gf_launch_lsop_unpack2((const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
                                   (const uint32_t *)c->dLengths.p, (int32_t *)c->dResiduals.p, resStride,
                                   (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p, nTiles, nRows, nCols,
                                   gf_canon_decode_lds_text(nRows, nCols), grid, c->stream));
-    std::vector<int32_t> st(nTiles);
-    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus2.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipStreamSynchronize(c->stream));
-
-    // Deflate containers: inflate + M32 unpack on the host, then upload residuals, coefficients and status
-    std::vector<size_t> hostTiles;
-    for (size_t t = 0; t < nTiles; t++)
-        if (st[t] == GF_ERR_UNSUPPORTED) hostTiles.push_back(t);
-    if (!hostTiles.empty()) {
-        std::vector<int32_t> hres(hostTiles.size() * resStride, 0);
-        std::vector<uint32_t> hcoef(hostTiles.size() * 16, 0);
-        std::vector<int32_t> hst(hostTiles.size(), GF_ERR_UNSUPPORTED);
-        parallelFor(hostTiles.size(), [&](size_t i) {
-            const size_t t = hostTiles[i];
-            const uint8_t *pk = blob + offsets[t];
-            const size_t len = lengths[t];
-            size_t o = 1;
-            int type = 0;
-            bool checksum = false;
-            const bool revised = pk[1] & 0x40;
-            if (revised) { type = pk[1] & 0x0f; checksum = pk[1] & 0x80; o = 2; }
-            if (len < o + 1 + 4 + 48 + 9) { hst[i] = GF_ERR_BOUNDS; return; }
-            if (pk[o++] != 12) { hst[i] = GF_ERR_FORMAT; return; }
-            for (int k = 0; k < 13; k++) hcoef[i * 16 + k] = getLE32(pk + o + 4 * k);
-            o += 52;
-            const uint32_t nMI = getLE32(pk + o), nMX = getLE32(pk + o + 4);
-            o += 8;
-            if (!revised) { type = pk[o] & 0x0f; checksum = pk[o] & 0x80; o++; }
-            if (checksum) o += 4;
-            if (type != 1) return;                                        // type 0: unsupported here
-            if (o > len || nMI > 6 * nInit || nMX > 6 * nInt) { hst[i] = GF_ERR_FORMAT; return; }
-            std::vector<uint8_t> mI(nMI + 8), mX(nMX + 8);
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit(&zs) != Z_OK) { hst[i] = GF_ERR_FORMAT; return; }
-            zs.next_in = (Bytef *)(pk + o); zs.avail_in = (uInt)(len - o);
-            zs.next_out = mI.data(); zs.avail_out = nMI;
-            int zr = inflate(&zs, Z_PARTIAL_FLUSH);
-            const size_t used = zs.total_in, got = zs.total_out;
-            inflateEnd(&zs);
-            if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got < nMI) { hst[i] = GF_ERR_FORMAT; return; }
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit(&zs) != Z_OK) { hst[i] = GF_ERR_FORMAT; return; }
-            zs.next_in = (Bytef *)(pk + o + used); zs.avail_in = (uInt)(len - o - used);
-            zs.next_out = mX.data(); zs.avail_out = nMX;
-            zr = inflate(&zs, Z_PARTIAL_FLUSH);
-            const size_t got2 = zs.total_out;
-            inflateEnd(&zs);
-            if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got2 < nMX) { hst[i] = GF_ERR_FORMAT; return; }
-            if (!m32Unpack(mI.data(), nMI, hres.data() + i * resStride, nInit) ||
-                !m32Unpack(mX.data(), nMX, hres.data() + i * resStride + nInit, nInt)) { hst[i] = GF_ERR_BOUNDS; return; }
-            hst[i] = GF_OK;
-        });
-        for (size_t i = 0; i < hostTiles.size(); i++) {
-            const size_t t = hostTiles[i];
-            st[t] = hst[i];
-            if (hst[i] != GF_OK) continue;
-            GF_HIP(hipMemcpyAsync((int32_t *)c->dResiduals.p + t * resStride, hres.data() + i * resStride, nRes * 4,
-                                  hipMemcpyHostToDevice, c->stream));
-            GF_HIP(hipMemcpyAsync((uint32_t *)c->dCoefs.p + t * 16, hcoef.data() + i * 16, 64, hipMemcpyHostToDevice, c->stream));
-        }
-        GF_HIP(hipMemcpyAsync(c->dStatus2.p, st.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
-        GF_HIP(hipStreamSynchronize(c->stream));           // the staging vectors go out of scope below
-    }
+    s = lsopUnpackM32(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
+                      (const uint32_t *)c->dLengths.p, (int32_t *)c->dResiduals.p, resStride, (uint32_t *)c->dCoefs.p,
+                      (int32_t *)c->dStatus2.p, 1);
+    if (s != GF_OK) return s;
     s = gf_lsop12_reconstruct_dev(c, c->stream, nRows, nCols, nTiles, (const int32_t *)c->dResiduals.p, resStride,
                                   (const uint32_t *)c->dCoefs.p, (const int32_t *)c->dStatus2.p, (int32_t *)c->dValues.p,
                                   (int32_t *)c->dStatus.p);
     if (s != GF_OK) return s;
+    std::vector<int32_t> st(nTiles);
     GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
     GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
     GF_HIP(hipStreamSynchronize(c->stream));
+    for (const Inflated &I : infl)
+        if (I.st != GF_OK) st[I.tile] = I.st;                  // the zlib stream itself was damaged
     if (status) memcpy(status, st.data(), nTiles * 4);
     return GF_OK;
 }

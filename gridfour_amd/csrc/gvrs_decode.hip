@@ -67,7 +67,7 @@ struct DecShared {
     uint32_t textStart;                        // bit offset of the Huffman text in the packing
     int32_t parseStatus;
     int32_t uniformSym;                        // >= 0: single-symbol encoding
-    uint32_t nLeaves, nShort, nSub, l2bits;
+    uint32_t nLeaves, nShort, nSub, l2bits, maxLen;
     uint32_t chainEnd;                         // position after the last needed symbol
     uint32_t chainTotal;
     uint32_t dense;                            // M32 stream too dense in multi-byte values for local start resolution
@@ -414,6 +414,362 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
 }
 
 
+// HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161), run by ONE wave.  S.head holds the packing words around the
+// serialised tree; the tree starts at bit relBit of S.head (= bit absBit of the packing, totalBits long).  Leaves go to
+// S.leaf*, sub-table markers to S.lut, the position of the first code to S.textStart.
+__device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, uint32_t totalBits)
+{
+    // HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161) as a wave-uniform scalar loop: the
+    // serialised tree (<= 83 dwords) and the node stack live in VGPRs and are read with
+    // v_readlane, so a node costs a few dozen scalar instructions and no LDS round trip.
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t hw0 = S.head[lane];
+    const uint32_t hw1 = lane < HEAD_WORDS - 64 ? S.head[64 + lane] : 0u;
+    auto word = [&](uint32_t wi) -> uint32_t {
+        if (wi >= HEAD_WORDS) return 0u;
+        return (uint32_t)__builtin_amdgcn_readlane((int)(wi < 64 ? hw0 : hw1), (int)(wi & 63u));
+    };
+    // scalar bit buffer: `buf` holds the next `have` bits of the serialised tree, LSB first
+    const uint32_t fw = relBit >> 5, fs = relBit & 31u;
+    uint64_t buf = (((uint64_t)word(fw + 1u) << 32) | word(fw)) >> fs;
+    uint32_t have = 64u - fs, wnext = fw + 2u, bp = absBit;
+    auto refill = [&]() {
+        if (have <= 32) {
+            buf |= (uint64_t)word(wnext) << have;
+            have += 32;
+            wnext++;
+        }
+    };
+    auto take = [&](uint32_t nb) -> uint32_t {          // nb <= 9, needs have >= nb
+        const uint32_t v = (uint32_t)buf & ((1u << nb) - 1u);
+        buf >>= nb;
+        have -= nb;
+        bp += nb;
+        return v;
+    };
+    const bool writer = lane == 0;
+    int32_t st = GF_K_OK;
+    int32_t uniformSym = -1;
+    const uint32_t nLeaves = take(8) + 1;
+    const uint32_t rootBit = take(1);
+    uint32_t nShort = 0, nSub = 0, maxLen = 1;
+    if (rootBit == 1) {
+        uniformSym = (int32_t)take(8);
+    } else {
+        // Pre-order walk without building nodes.  `c` is the code of the node about to be read as an integer of
+        // L bits, most significant bit = first step (0 left, 1 right).  One iteration per leaf: a run of z branch
+        // records (zero bits) appends z zeros to the code; the leaf that follows takes the code as it stands; the
+        // next node is the right sibling of the deepest ancestor still on its left side: strip the trailing ones,
+        // turn the zero in front of them into a one.
+        uint64_t c = 0;
+        uint32_t L = 1;                                              // the root's left child
+        uint32_t leaves = 0, records = 0;
+        bool complete = false;
+        while (leaves < nLeaves) {
+            refill();
+            if (records > 511) { st = GF_K_ERR_BOUNDS; break; }
+            uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
+            z = min(z, have);
+            if (z) {
+                if (L - 1u + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }   // see DESIGN.md (unsupported depth)
+                if (L <= (uint32_t)LUT_BITS && L + z > (uint32_t)LUT_BITS) {
+                    // a branch at depth LUT_BITS on this path: codes below it continue into a second-level table,
+                    // indexed by the first LUT_BITS bits of the path (first step in bit 0)
+                    const uint32_t prefix = (uint32_t)((c << z) >> (L + z - LUT_BITS));
+                    if (writer) S.lut[__brev(prefix) >> (32 - LUT_BITS)] = 0x80000000u | nSub;
+                    nSub++;
+                }
+                c <<= z;                                             // z <= 63 here
+                L += z;
+                records += z;
+                buf >>= z;
+                have -= z;
+                bp += z;
+                if (have == 0u || !(buf & 1ull)) continue;           // the run continues beyond the buffered bits
+                refill();
+            }
+            const uint32_t rec = take(9);
+            const uint32_t sym = rec >> 1;
+            const uint32_t clen = L;
+            records++;
+            if (writer) {
+                S.leafCode[leaves] = __brevll(c) >> (64u - L);       // path bits, first step in bit 0
+                S.leafLen[leaves] = (uint8_t)clen;
+                S.leafSym[leaves] = (uint8_t)sym;
+                if (clen <= 5) S.shortLeaf[nShort & 63u] = (uint8_t)leaves;
+            }
+            if (clen <= 5) nShort++;
+            maxLen = max(maxLen, clen);
+            leaves++;
+            const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;   // trailing ones
+            if (leaves == nLeaves) { complete = t1 >= L; break; }
+            if (t1 >= L) { st = GF_K_ERR_BOUNDS; break; }            // tree complete but leaves missing
+            c = (c >> t1) | 1ull;
+            L -= t1;
+        }
+        // all leaves read: the tree must be complete (every open branch is on its right child)
+        if (st == GF_K_OK && !complete) st = GF_K_ERR_FORMAT;
+    }
+    if (st == GF_K_OK && bp > totalBits) st = GF_K_ERR_BOUNDS;   // read past end of data
+    if (writer) {
+        S.uniformSym = uniformSym;
+        S.textStart = bp;
+        S.parseStatus = st;
+        S.nLeaves = nLeaves;
+        S.nShort = nShort;
+        const uint32_t l2 = maxLen > LUT_BITS ? min((uint32_t)L2_MAX_BITS, maxLen - LUT_BITS) : 1u;
+        S.l2bits = l2;
+        S.nSub = min(nSub, (uint32_t)L2_ENTRIES >> l2);
+        S.maxLen = maxLen;
+    }
+}
+
+// Lookup tables from the leaf table, by the whole workgroup; ends with a barrier.
+template <class Lut2Ptr>
+__device__ __forceinline__ void build_lut(DecShared &S, Lut2Ptr lut2)
+{
+    const uint32_t tid = threadIdx.x;
+    // LUT from the leaf table: a leaf with a code of <= 11 bits owns 2^(11-len) first-level entries,
+    // one of 12..19 bits owns 2^(19-len) entries of its prefix's second-level table
+    {
+        const uint32_t nLeaves = S.nLeaves;
+        const uint32_t nSub = S.nSub;
+        const uint32_t l2 = S.l2bits;
+        for (uint32_t x = tid; x < (nSub << l2); x += DEC_THREADS) lut2[x] = 0xFFFFu;
+        if ((uint32_t)tid < nLeaves) {
+            const uint32_t cl = S.leafLen[tid];
+            if (cl > 5 && cl <= LUT_BITS) {
+                const uint32_t e = lut_single(S.leafSym[tid], cl);
+                for (uint32_t x = (uint32_t)S.leafCode[tid]; x < (1u << LUT_BITS); x += 1u << cl) S.lut[x] = e;
+            }
+        }
+        const uint32_t nShort = min(S.nShort, 64u);
+        for (uint32_t j = 0; j < nShort; j++) {             // few, large fills: all threads together
+            const uint32_t i = S.shortLeaf[j];
+            const uint32_t cl = S.leafLen[i];
+            const uint32_t e = lut_single(S.leafSym[i], cl);
+            for (uint32_t x = (uint32_t)S.leafCode[i] + ((uint32_t)tid << cl); x < (1u << LUT_BITS);
+                 x += (uint32_t)DEC_THREADS << cl)
+                S.lut[x] = e;
+        }
+        __syncthreads();                                     // lut2 cleared, first level complete
+        // pair up: where the code behind an entry's symbol is short enough to lie inside the window too, the
+        // entry yields both symbols (its first-symbol fields stay as they are, so in-place update is safe)
+        for (uint32_t x = tid; x < (1u << LUT_BITS); x += DEC_THREADS) {
+            const uint32_t e = S.lut[x];
+            if (!(e & 0x80000000u)) {
+                const uint32_t l1 = (e >> 16) & 63u;
+                const uint32_t e2 = S.lut[x >> l1];                // the following bits, zero-extended
+                const uint32_t l2b = (e2 >> 16) & 63u;
+                if (!(e2 & 0x80000000u) && l1 + l2b <= (uint32_t)LUT_BITS)
+                    S.lut[x] = (e & 0x003F00FFu) | ((e2 & 0xffu) << 8) | ((l1 + l2b) << 22);
+            }
+        }
+        if ((uint32_t)tid < nLeaves) {
+            const uint32_t cl = S.leafLen[tid];
+            if (cl > LUT_BITS && cl <= LUT_BITS + l2) {
+                const uint64_t code = S.leafCode[tid];
+                const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffffffu;
+                if (subIdx < nSub) {
+                    uint16_t *sub = &lut2[subIdx << l2];
+                    const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
+                    for (uint32_t x = (uint32_t)(code >> LUT_BITS); x < (1u << l2); x += 1u << (cl - LUT_BITS))
+                        sub[x] = e;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// CodecM32.decode (CodecM32.java:327-356) of the first nStream values of the byte stream m32[0..nM32), by the whole
+// workgroup: value k goes to o[map(k)].  bm / wb: start bitmap and its rank bases (same memory space as m32).
+// Returns GF_K_OK, or GF_K_ERR_BOUNDS where the reference's reads run off the stream.
+struct CellMapPredictor {
+    int model;
+    uint32_t nR, nC, magic;
+    bool fast;
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return stream_cell_fast(model, nR, nC, k, magic, fast); }
+};
+struct CellMapIdentity {
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return k; }
+};
+
+template <class M32Ptr, class BmPtr, class Map>
+__device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint32_t nM32, BmPtr bm, BmPtr wb, uint32_t nStream,
+                                                 const Map map, uint32_t *o, uint32_t *stamps)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bmWords = (nM32 + 31u) >> 5;
+    int32_t tileStatus = GF_K_OK;
+    M32Cursor cur;
+    cur.m = m32;
+    cur.n = nM32;
+    cur.pos = 0;
+    cur.base = 0;
+    cur.d0 = cur.d1 = cur.d2 = 0;
+    const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
+    const uint32_t nDw = (nM32 + 3u) >> 2;
+    // bitmap of the bytes that start a value
+    for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
+    if (tid == 0) { S.chainEnd = 0; S.dense = 0; }
+    __syncthreads();
+    // Local resolution, one dword of the stream per thread and step: a byte is certainly a value
+    // start when none of the five bytes before it can be an introducer (0x7f / 0x81) -- no value
+    // is longer than 6 bytes.  Where introducer candidates are near, walk the few values from
+    // the nearest certain start ("anchor").  No chain, no rounds; only a stream that is dense in
+    // multi-byte values (no anchor within 11 bytes) falls back to the chain resolution.
+    {
+        // 0x80 in every byte that may be an introducer (false positives are harmless)
+        auto cand = [](uint32_t x) -> uint32_t {
+            const uint32_t p = x ^ 0x7F7F7F7Fu, q = x ^ 0x81818181u;
+            return (((p - 0x01010101u) & ~p) | ((q - 0x01010101u) & ~q)) & 0x80808080u;
+        };
+        auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits
+            return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
+        };
+        for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
+            const uint32_t i0 = dw << 2;
+            uint32_t d0 = m32w[dw];
+            if (i0 + 4 > nM32) d0 &= (1u << ((nM32 - i0) * 8u)) - 1u;
+            const uint32_t dm1 = dw >= 1 ? m32w[dw - 1] : 0u, dm2 = dw >= 2 ? m32w[dw - 2] : 0u;
+            const uint32_t c0 = cand(d0), cm1 = cand(dm1), cm2 = cand(dm2);
+            const uint32_t validNib = i0 + 4 <= nM32 ? 0xFu : ((1u << (nM32 - i0)) - 1u);
+            uint32_t nib;
+            if (!((cm1 | (cm2 & 0x80000000u)) | c0)) {
+                nib = validNib;                         // four single-byte values
+            } else {
+                const uint32_t dm3 = dw >= 3 ? m32w[dw - 3] : 0u, dm4 = dw >= 4 ? m32w[dw - 4] : 0u;
+                // candidate bit b <-> byte i0 - 16 + b
+                const uint32_t C = nib4(cand(dm4)) | (nib4(cand(dm3)) << 4) | (nib4(cm2) << 8) | (nib4(cm1) << 12) |
+                                   (nib4(c0) << 16);
+                const uint32_t U = C | (C << 1) | (C << 2) | (C << 3) | (C << 4);   // bit m: a candidate in bytes m-4..m
+                // position index j (byte i0-16+j) is a certain start iff U bit j-1 is clear; want the largest j <= 16
+                const uint32_t safe = ~U & 0xFFF0u;                                  // j-1 in 4..15
+                nib = 0;
+                if (!safe) {
+                    S.dense = 1;
+                } else {
+                    const uint32_t j = 32u - (uint32_t)__builtin_clz(safe);          // (j-1)+1
+                    const uint32_t anchor = i0 + j >= 16u ? i0 + j - 16u : 0u;
+                    M32Cursor c = cur;
+                    c.seek(anchor);
+                    const uint32_t stop = min(i0 + 4u, nM32);
+                    while (c.pos < stop) {
+                        if (c.pos >= i0) nib |= 1u << (c.pos - i0);
+                        c.next();
+                    }
+                }
+            }
+            if (nib) atomicOr(&bm[i0 >> 5], nib << (i0 & 31u));
+        }
+    }
+    __syncthreads();
+    if (stamps && tid == 0) stamps[6] = (uint32_t)__builtin_amdgcn_s_memtime();
+    if (S.dense) {
+        // chain resolution over the bytes (same scheme as the Huffman text), then mark the starts
+        for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
+        uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
+        unit = max(16u, unit);
+        const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
+        resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, stamps ? stamps + 13 : nullptr);   // warm-up: 8 bytes
+        for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
+            const uint32_t limit = min(nM32, (q + 1) * unit);
+            M32Cursor c = cur;
+            c.seek(S.qs[q]);
+            uint32_t word = c.pos >> 5, mask = 0;
+            while (c.pos < limit) {
+                const uint32_t w = c.pos >> 5;
+                if (w != word) {
+                    if (mask) atomicOr(&bm[word], mask);
+                    word = w;
+                    mask = 0;
+                }
+                mask |= 1u << (c.pos & 31u);
+                c.next();
+            }
+            if (mask) atomicOr(&bm[word], mask);
+        }
+        __syncthreads();
+    }
+    // rank base of every bitmap word (exclusive popcount prefix)
+    if (tid == 0) S.carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < bmWords; base += DEC_THREADS) {
+        const uint32_t w = base + tid;
+        const uint32_t pc = w < bmWords ? (uint32_t)__popc(bm[w]) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(pc, S.waveSum, &tot);
+        if (w < bmWords) wb[w] = S.carry + ex;
+        __syncthreads();
+        if (tid == 0) S.carry += tot;
+        __syncthreads();
+    }
+    if (stamps && tid == 0) stamps[7] = (uint32_t)__builtin_amdgcn_s_memtime();
+    if (S.carry < nStream) tileStatus = GF_K_ERR_BOUNDS;         // predictor reads past codeM32s
+    // four byte positions per thread and step: consecutive bytes are (mostly) consecutive cells,
+    // so the stores of a wave are coalesced.  12 bytes of the buffer cover every value that
+    // starts in the thread's dword.
+    for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
+        const uint32_t i0 = dw << 2;
+        const uint32_t bits = (bm[i0 >> 5] >> (i0 & 31u)) & 0xfu;
+        if (bits) {
+            const uint32_t word = bm[i0 >> 5];
+            uint32_t k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
+            uint32_t d0 = m32w[dw];
+            // Fast path (most dwords of terrain data): four value starts, none an introducer (0x7f / 0x81) or the
+            // null code (0x80) -> four sign-extended bytes; if their cells are neighbours, one 16-byte store.
+            {
+                const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
+                const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) &
+                                         0x80808080u;
+                if (bits == 0xfu && !special && k + 3u < nStream) {
+                    const uint32_t v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu), v1 = (uint32_t)((int32_t)(d0 << 16) >> 24),
+                                   v2 = (uint32_t)((int32_t)(d0 << 8) >> 24), v3 = (uint32_t)((int32_t)d0 >> 24);
+                    const uint32_t c0 = map(k);
+                    const uint32_t c3 = map(k + 3u);
+                    if (c3 - c0 == 3u) {
+                        GfU4 q;
+                        q.x = v0; q.y = v1; q.z = v2; q.w = v3;
+                        *reinterpret_cast<GfU4 *>(o + c0) = q;
+                    } else {
+                        o[c0] = v0;
+                        o[map(k + 1u)] = v1;
+                        o[map(k + 2u)] = v2;
+                        o[c3] = v3;
+                    }
+                    continue;
+                }
+            }
+            // bytes i0 .. i0+11, zero beyond nM32
+            uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
+            if (i0 + 12 > nM32) {
+                const uint32_t valid = nM32 - i0;            // 1..11 bytes
+                if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
+                if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
+                d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
+            }
+    #pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if ((bits >> j) & 1u) {
+                    if (k < nStream) {
+                        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
+                        const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
+                        uint32_t vlen;
+                        const uint32_t val = m32_value(lo, hi, &vlen);
+                        o[map(k)] = val;
+                        if (k == nStream - 1) S.chainEnd = i0 + j + vlen;
+                    }
+                    k++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tileStatus == GF_K_OK && S.chainEnd > nM32) tileStatus = GF_K_ERR_BOUNDS;   // last value truncated
+    return tileStatus;
+}
+
 #define GF_DSTAMP(i)                                                                   \
     do {                                                                               \
         if (a.debug && tid == 0) (a.debug + t * 16)[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
@@ -471,107 +827,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
         if (a.rawM32) {
             if (tid == 0) { S.parseStatus = len < 10ull + nM32 ? GF_K_ERR_BOUNDS : GF_K_OK; S.uniformSym = -1; S.textStart = 80; }
         } else if (wave == 0) {
-            // HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161) as a wave-uniform scalar loop: the
-            // serialised tree (<= 83 dwords) and the node stack live in VGPRs and are read with
-            // v_readlane, so a node costs a few dozen scalar instructions and no LDS round trip.
-            const uint32_t hw0 = S.head[lane];
-            const uint32_t hw1 = lane < HEAD_WORDS - 64 ? S.head[64 + lane] : 0u;
-            const uint32_t totalBits = len * 8u;
-            auto word = [&](uint32_t wi) -> uint32_t {
-                if (wi >= HEAD_WORDS) return 0u;
-                return (uint32_t)__builtin_amdgcn_readlane((int)(wi < 64 ? hw0 : hw1), (int)(wi & 63u));
-            };
-            // scalar bit buffer: `buf` holds the next `have` bits of the serialised tree, LSB first
-            uint64_t buf = (((uint64_t)word(3) << 32) | word(2)) >> 16;      // packing bit 80 = bit 16 of word 2
-            uint32_t have = 48, wnext = 4, bp = 80;
-            auto refill = [&]() {
-                if (have <= 32) {
-                    buf |= (uint64_t)word(wnext) << have;
-                    have += 32;
-                    wnext++;
-                }
-            };
-            auto take = [&](uint32_t nb) -> uint32_t {          // nb <= 9, needs have >= nb
-                const uint32_t v = (uint32_t)buf & ((1u << nb) - 1u);
-                buf >>= nb;
-                have -= nb;
-                bp += nb;
-                return v;
-            };
-            const bool writer = lane == 0;
-            int32_t st = GF_K_OK;
-            int32_t uniformSym = -1;
-            const uint32_t nLeaves = take(8) + 1;
-            const uint32_t rootBit = take(1);
-            uint32_t nShort = 0, nSub = 0, maxLen = 1;
-            if (rootBit == 1) {
-                uniformSym = (int32_t)take(8);
-            } else {
-                // Pre-order walk without building nodes.  `c` is the code of the node about to be read as an integer of
-                // L bits, most significant bit = first step (0 left, 1 right).  One iteration per leaf: a run of z branch
-                // records (zero bits) appends z zeros to the code; the leaf that follows takes the code as it stands; the
-                // next node is the right sibling of the deepest ancestor still on its left side: strip the trailing ones,
-                // turn the zero in front of them into a one.
-                uint64_t c = 0;
-                uint32_t L = 1;                                              // the root's left child
-                uint32_t leaves = 0, records = 0;
-                bool complete = false;
-                while (leaves < nLeaves) {
-                    refill();
-                    if (records > 511) { st = GF_K_ERR_BOUNDS; break; }
-                    uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
-                    z = min(z, have);
-                    if (z) {
-                        if (L - 1u + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }   // see DESIGN.md (unsupported depth)
-                        if (L <= (uint32_t)LUT_BITS && L + z > (uint32_t)LUT_BITS) {
-                            // a branch at depth LUT_BITS on this path: codes below it continue into a second-level table,
-                            // indexed by the first LUT_BITS bits of the path (first step in bit 0)
-                            const uint32_t prefix = (uint32_t)((c << z) >> (L + z - LUT_BITS));
-                            if (writer) S.lut[__brev(prefix) >> (32 - LUT_BITS)] = 0x80000000u | nSub;
-                            nSub++;
-                        }
-                        c <<= z;                                             // z <= 63 here
-                        L += z;
-                        records += z;
-                        buf >>= z;
-                        have -= z;
-                        bp += z;
-                        if (have == 0u || !(buf & 1ull)) continue;           // the run continues beyond the buffered bits
-                        refill();
-                    }
-                    const uint32_t rec = take(9);
-                    const uint32_t sym = rec >> 1;
-                    const uint32_t clen = L;
-                    records++;
-                    if (writer) {
-                        S.leafCode[leaves] = __brevll(c) >> (64u - L);       // path bits, first step in bit 0
-                        S.leafLen[leaves] = (uint8_t)clen;
-                        S.leafSym[leaves] = (uint8_t)sym;
-                        if (clen <= 5) S.shortLeaf[nShort & 63u] = (uint8_t)leaves;
-                    }
-                    if (clen <= 5) nShort++;
-                    maxLen = max(maxLen, clen);
-                    leaves++;
-                    const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;   // trailing ones
-                    if (leaves == nLeaves) { complete = t1 >= L; break; }
-                    if (t1 >= L) { st = GF_K_ERR_BOUNDS; break; }            // tree complete but leaves missing
-                    c = (c >> t1) | 1ull;
-                    L -= t1;
-                }
-                // all leaves read: the tree must be complete (every open branch is on its right child)
-                if (st == GF_K_OK && !complete) st = GF_K_ERR_FORMAT;
-            }
-            if (st == GF_K_OK && bp > totalBits) st = GF_K_ERR_BOUNDS;   // read past end of data
-            if (writer) {
-                S.uniformSym = uniformSym;
-                S.textStart = bp;
-                S.parseStatus = st;
-                S.nLeaves = nLeaves;
-                S.nShort = nShort;
-                const uint32_t l2 = maxLen > LUT_BITS ? min((uint32_t)L2_MAX_BITS, maxLen - LUT_BITS) : 1u;
-                S.l2bits = l2;
-                S.nSub = min(nSub, (uint32_t)L2_ENTRIES >> l2);
-            }
+            parse_tree_wave(S, 80u, 80u, len * 8u);
         }
         __syncthreads();
         if (S.parseStatus != GF_K_OK) {
@@ -591,7 +847,6 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
         // Phases 1 and 2 run on the M32 buffer, its start bitmap and the rank bases -- in LDS, or in the workspace for
         // tiles whose stream does not fit.  The body is instantiated once per memory space: with a pointer that may be
         // either, every access would be a flat_* instruction (slow even when it lands in LDS).
-        const uint32_t bmWords = (nM32 + 31u) >> 5;
         auto phases12 = [&](auto inLds) -> int32_t {
             uint8_t *m32;
             uint32_t *bm, *wb;
@@ -618,57 +873,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                 for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
                 __syncthreads();
             } else {
-                // LUT from the leaf table: a leaf with a code of <= 11 bits owns 2^(11-len) first-level entries,
-                // one of 12..19 bits owns 2^(19-len) entries of its prefix's second-level table
-                {
-                    const uint32_t nLeaves = S.nLeaves;
-                    const uint32_t nSub = S.nSub;
-                    const uint32_t l2 = S.l2bits;
-                    for (uint32_t x = tid; x < (nSub << l2); x += DEC_THREADS) lut2[x] = 0xFFFFu;
-                    if ((uint32_t)tid < nLeaves) {
-                        const uint32_t cl = S.leafLen[tid];
-                        if (cl > 5 && cl <= LUT_BITS) {
-                            const uint32_t e = lut_single(S.leafSym[tid], cl);
-                            for (uint32_t x = (uint32_t)S.leafCode[tid]; x < (1u << LUT_BITS); x += 1u << cl) S.lut[x] = e;
-                        }
-                    }
-                    const uint32_t nShort = min(S.nShort, 64u);
-                    for (uint32_t j = 0; j < nShort; j++) {             // few, large fills: all threads together
-                        const uint32_t i = S.shortLeaf[j];
-                        const uint32_t cl = S.leafLen[i];
-                        const uint32_t e = lut_single(S.leafSym[i], cl);
-                        for (uint32_t x = (uint32_t)S.leafCode[i] + ((uint32_t)tid << cl); x < (1u << LUT_BITS);
-                             x += (uint32_t)DEC_THREADS << cl)
-                            S.lut[x] = e;
-                    }
-                    __syncthreads();                                     // lut2 cleared, first level complete
-                    // pair up: where the code behind an entry's symbol is short enough to lie inside the window too, the
-                    // entry yields both symbols (its first-symbol fields stay as they are, so in-place update is safe)
-                    for (uint32_t x = tid; x < (1u << LUT_BITS); x += DEC_THREADS) {
-                        const uint32_t e = S.lut[x];
-                        if (!(e & 0x80000000u)) {
-                            const uint32_t l1 = (e >> 16) & 63u;
-                            const uint32_t e2 = S.lut[x >> l1];                // the following bits, zero-extended
-                            const uint32_t l2b = (e2 >> 16) & 63u;
-                            if (!(e2 & 0x80000000u) && l1 + l2b <= (uint32_t)LUT_BITS)
-                                S.lut[x] = (e & 0x003F00FFu) | ((e2 & 0xffu) << 8) | ((l1 + l2b) << 22);
-                        }
-                    }
-                    if ((uint32_t)tid < nLeaves) {
-                        const uint32_t cl = S.leafLen[tid];
-                        if (cl > LUT_BITS && cl <= LUT_BITS + l2) {
-                            const uint64_t code = S.leafCode[tid];
-                            const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffffffu;
-                            if (subIdx < nSub) {
-                                uint16_t *sub = &lut2[subIdx << l2];
-                                const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
-                                for (uint32_t x = (uint32_t)(code >> LUT_BITS); x < (1u << l2); x += 1u << (cl - LUT_BITS))
-                                    sub[x] = e;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
+                build_lut(S, lut2);
                 GF_DSTAMP(3);
                 const uint32_t textStart = S.textStart, endBit = len * 8u;
                 const uint64_t baseWord = (off * 8ull) >> 5;
@@ -704,175 +909,10 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
 
             // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
             {
-                M32Cursor cur;
-                cur.m = m32;
-                cur.n = nM32;
-                cur.pos = 0;
-                cur.base = 0;
-                cur.d0 = cur.d1 = cur.d2 = 0;
-                const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
-                const uint32_t nDw = (nM32 + 3u) >> 2;
-                // bitmap of the bytes that start a value
-                for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
-                if (tid == 0) { S.chainEnd = 0; S.dense = 0; }
-                __syncthreads();
-                // Local resolution, one dword of the stream per thread and step: a byte is certainly a value
-                // start when none of the five bytes before it can be an introducer (0x7f / 0x81) -- no value
-                // is longer than 6 bytes.  Where introducer candidates are near, walk the few values from
-                // the nearest certain start ("anchor").  No chain, no rounds; only a stream that is dense in
-                // multi-byte values (no anchor within 11 bytes) falls back to the chain resolution.
-                {
-                    // 0x80 in every byte that may be an introducer (false positives are harmless)
-                    auto cand = [](uint32_t x) -> uint32_t {
-                        const uint32_t p = x ^ 0x7F7F7F7Fu, q = x ^ 0x81818181u;
-                        return (((p - 0x01010101u) & ~p) | ((q - 0x01010101u) & ~q)) & 0x80808080u;
-                    };
-                    auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits
-                        return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
-                    };
-                    for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
-                        const uint32_t i0 = dw << 2;
-                        uint32_t d0 = m32w[dw];
-                        if (i0 + 4 > nM32) d0 &= (1u << ((nM32 - i0) * 8u)) - 1u;
-                        const uint32_t dm1 = dw >= 1 ? m32w[dw - 1] : 0u, dm2 = dw >= 2 ? m32w[dw - 2] : 0u;
-                        const uint32_t c0 = cand(d0), cm1 = cand(dm1), cm2 = cand(dm2);
-                        const uint32_t validNib = i0 + 4 <= nM32 ? 0xFu : ((1u << (nM32 - i0)) - 1u);
-                        uint32_t nib;
-                        if (!((cm1 | (cm2 & 0x80000000u)) | c0)) {
-                            nib = validNib;                         // four single-byte values
-                        } else {
-                            const uint32_t dm3 = dw >= 3 ? m32w[dw - 3] : 0u, dm4 = dw >= 4 ? m32w[dw - 4] : 0u;
-                            // candidate bit b <-> byte i0 - 16 + b
-                            const uint32_t C = nib4(cand(dm4)) | (nib4(cand(dm3)) << 4) | (nib4(cm2) << 8) | (nib4(cm1) << 12) |
-                                               (nib4(c0) << 16);
-                            const uint32_t U = C | (C << 1) | (C << 2) | (C << 3) | (C << 4);   // bit m: a candidate in bytes m-4..m
-                            // position index j (byte i0-16+j) is a certain start iff U bit j-1 is clear; want the largest j <= 16
-                            const uint32_t safe = ~U & 0xFFF0u;                                  // j-1 in 4..15
-                            nib = 0;
-                            if (!safe) {
-                                S.dense = 1;
-                            } else {
-                                const uint32_t j = 32u - (uint32_t)__builtin_clz(safe);          // (j-1)+1
-                                const uint32_t anchor = i0 + j >= 16u ? i0 + j - 16u : 0u;
-                                M32Cursor c = cur;
-                                c.seek(anchor);
-                                const uint32_t stop = min(i0 + 4u, nM32);
-                                while (c.pos < stop) {
-                                    if (c.pos >= i0) nib |= 1u << (c.pos - i0);
-                                    c.next();
-                                }
-                            }
-                        }
-                        if (nib) atomicOr(&bm[i0 >> 5], nib << (i0 & 31u));
-                    }
-                }
-                __syncthreads();
-                GF_DSTAMP(6);
-                if (S.dense) {
-                    // chain resolution over the bytes (same scheme as the Huffman text), then mark the starts
-                    for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
-                    uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
-                    unit = max(16u, unit);
-                    const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
-                    resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, a.debug ? a.debug + t * 16 + 13 : nullptr);   // warm-up: 8 bytes
-                    for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
-                        const uint32_t limit = min(nM32, (q + 1) * unit);
-                        M32Cursor c = cur;
-                        c.seek(S.qs[q]);
-                        uint32_t word = c.pos >> 5, mask = 0;
-                        while (c.pos < limit) {
-                            const uint32_t w = c.pos >> 5;
-                            if (w != word) {
-                                if (mask) atomicOr(&bm[word], mask);
-                                word = w;
-                                mask = 0;
-                            }
-                            mask |= 1u << (c.pos & 31u);
-                            c.next();
-                        }
-                        if (mask) atomicOr(&bm[word], mask);
-                    }
-                    __syncthreads();
-                }
-                // rank base of every bitmap word (exclusive popcount prefix)
-                if (tid == 0) S.carry = 0;
-                __syncthreads();
-                for (uint32_t base = 0; base < bmWords; base += DEC_THREADS) {
-                    const uint32_t w = base + tid;
-                    const uint32_t pc = w < bmWords ? (uint32_t)__popc(bm[w]) : 0u;
-                    uint32_t tot;
-                    const uint32_t ex = block_excl_scan(pc, S.waveSum, &tot);
-                    if (w < bmWords) wb[w] = S.carry + ex;
-                    __syncthreads();
-                    if (tid == 0) S.carry += tot;
-                    __syncthreads();
-                }
-                GF_DSTAMP(7);
-                if (S.carry < nStream) tileStatus = GF_K_ERR_BOUNDS;         // predictor reads past codeM32s
-                // four byte positions per thread and step: consecutive bytes are (mostly) consecutive cells,
-                // so the stores of a wave are coalesced.  12 bytes of the buffer cover every value that
-                // starts in the thread's dword.
                 const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
                 const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
-                const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
-                for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
-                    const uint32_t i0 = dw << 2;
-                    const uint32_t bits = (bm[i0 >> 5] >> (i0 & 31u)) & 0xfu;
-                    if (bits) {
-                        const uint32_t word = bm[i0 >> 5];
-                        uint32_t k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
-                        uint32_t d0 = m32w[dw];
-                        // Fast path (most dwords of terrain data): four value starts, none an introducer (0x7f / 0x81) or the
-                        // null code (0x80) -> four sign-extended bytes; if their cells are neighbours, one 16-byte store.
-                        {
-                            const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
-                            const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) &
-                                                     0x80808080u;
-                            if (bits == 0xfu && !special && k + 3u < nStream) {
-                                const uint32_t v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu), v1 = (uint32_t)((int32_t)(d0 << 16) >> 24),
-                                               v2 = (uint32_t)((int32_t)(d0 << 8) >> 24), v3 = (uint32_t)((int32_t)d0 >> 24);
-                                const bool fastCell = useMagic && wMain > 1;
-                                const uint32_t c0 = stream_cell_fast(model, nR, nC, k, magic, fastCell);
-                                const uint32_t c3 = stream_cell_fast(model, nR, nC, k + 3u, magic, fastCell);
-                                if (c3 - c0 == 3u) {
-                                    GfU4 q;
-                                    q.x = v0; q.y = v1; q.z = v2; q.w = v3;
-                                    *reinterpret_cast<GfU4 *>(o + c0) = q;
-                                } else {
-                                    o[c0] = v0;
-                                    o[stream_cell_fast(model, nR, nC, k + 1u, magic, fastCell)] = v1;
-                                    o[stream_cell_fast(model, nR, nC, k + 2u, magic, fastCell)] = v2;
-                                    o[c3] = v3;
-                                }
-                                continue;
-                            }
-                        }
-                        // bytes i0 .. i0+11, zero beyond nM32
-                        uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
-                        if (i0 + 12 > nM32) {
-                            const uint32_t valid = nM32 - i0;            // 1..11 bytes
-                            if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
-                            if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
-                            d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
-                        }
-    #pragma unroll
-                        for (uint32_t j = 0; j < 4; j++) {
-                            if ((bits >> j) & 1u) {
-                                if (k < nStream) {
-                                    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
-                                    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
-                                    uint32_t vlen;
-                                    const uint32_t val = m32_value(lo, hi, &vlen);
-                                    o[stream_cell_fast(model, nR, nC, k, magic, useMagic && wMain > 1)] = val;
-                                    if (k == nStream - 1) S.chainEnd = i0 + j + vlen;
-                                }
-                                k++;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tileStatus == GF_K_OK && S.chainEnd > nM32) tileStatus = GF_K_ERR_BOUNDS;   // last value truncated
+                const CellMapPredictor map{model, nR, nC, (uint32_t)(((1ull << 32) + wMain - 1) / wMain), useMagic && wMain > 1};
+                tileStatus = m32_to_values(S, m32, nM32, bm, wb, nStream, map, o, a.debug ? a.debug + t * 16 : nullptr);
             }
             return tileStatus;
         };
@@ -890,6 +930,137 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
         gf_predictor_inverse(model, seed, o, nR, nC, a.debug ? a.debug + t * 16 + 9 : nullptr);
         GF_DSTAMP(10);
         if (tid == 0) a.status[t] = GF_K_OK;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LsDecoder12.decode for the containers that carry CodecM32 bytes (lsop/LsDecoder12.java:107-150): header (either
+// revision, lsop/LsHeader.java:131-185), then the initialiser and interior M32 streams -- type 0: two legacy Huffman
+// segments back to back in one bit store, the second starting at the bit after the first one's last code
+// (LsDecoder12.java:116-124); type 1: two zlib streams, inflated by the host before the launch (rawM32).  Output:
+// seed + coefficients and the residual ints that k_lsop_reconstruct (gvrs_lsop.hip) turns into the tile.
+__global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Args a)
+{
+    __shared__ DecShared S;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
+
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    const uint32_t nInit = 4u * nR + 2u * nC - 9u, nInt = (nR - 2u) * (nC - 4u);
+    const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);
+    const uint64_t nWords = (a.blobBytes + 3) >> 2;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if (a.status[t] != GF_K_ERR_UNSUPPORTED) continue;               // decoded (or rejected) by k_lsop_unpack2
+        const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
+        const uint32_t len = a.lengths[t];
+        const uint8_t *__restrict__ pk = a.blob + off;
+        uint32_t *res = reinterpret_cast<uint32_t *>(a.residuals) + t * a.resStride;
+        auto le32 = [&](uint32_t o) -> uint32_t {
+            return (uint32_t)pk[o] | ((uint32_t)pk[o + 1] << 8) | ((uint32_t)pk[o + 2] << 16) | ((uint32_t)pk[o + 3] << 24);
+        };
+
+        // header: codec index, [type | flags], nCoef, seed, 12 floats, the two M32 byte counts, [type | flags]
+        int32_t early = GF_K_OK;
+        uint32_t o = 1, type = 0, nMI = 0, nMX = 0;
+        bool checksum = false;
+        if (len < 3 || off + len > a.blobBytes) early = GF_K_ERR_BOUNDS;
+        else {
+            const bool revised = pk[1] & 0x40;
+            if (revised) { type = pk[1] & 0x0fu; checksum = pk[1] & 0x80; o = 2; }
+            if (len < o + 1u + 52u + 8u + (revised ? 0u : 1u)) early = GF_K_ERR_BOUNDS;
+            else if (pk[o] != 12) early = GF_K_ERR_FORMAT;                // u[11] would index out of bounds
+            else {
+                o += 53;
+                nMI = le32(o);
+                nMX = le32(o + 4);
+                o += 8;
+                if (!revised) { type = pk[o] & 0x0fu; checksum = pk[o] & 0x80; o++; }
+                if (checksum) o += 4;                                     // value checksum: skipped
+                if (o > len) early = GF_K_ERR_BOUNDS;
+                else if (type == 2) early = GF_K_ERR_UNSUPPORTED;         // canonical text behind a legacy header: never written
+                else if (type != 0 && !a.rawM32) early = GF_K_ERR_UNSUPPORTED;   // Deflate: needs the host's inflate first
+                else if (nMI > 6u * nInit + 64u || nMX > 6u * nInt + 64u) early = GF_K_ERR_FORMAT;   // no encoder emits this
+                else if (type != 0 && (uint64_t)o + nMI + nMX > len) early = GF_K_ERR_BOUNDS;
+            }
+        }
+        if (early != GF_K_OK) {
+            if (tid == 0) a.status[t] = early;
+            __syncthreads();
+            continue;
+        }
+        if (tid < 13) a.coefs[t * 16 + tid] = le32((pk[1] & 0x40 ? 3u : 2u) + 4u * tid);
+
+        uint32_t startBit = o * 8u;                                       // type 0: where the next Huffman segment begins
+        uint32_t rawAt = o;                                               // type 1: where the next M32 stream begins
+        int32_t tileStatus = GF_K_OK;
+        for (int seg = 0; seg < 2 && tileStatus == GF_K_OK; seg++) {
+            const uint32_t nM32 = seg ? nMX : nMI, nVals = seg ? nInt : nInit;
+            uint32_t *out = res + (seg ? nInit : 0u);
+            auto segment = [&](auto inLds) -> int32_t {
+                uint8_t *m32;
+                uint32_t *bm, *wb;
+                if constexpr (decltype(inLds)::value) {
+                    m32 = ldsDyn;
+                    bm = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes);
+                    wb = bm + (a.ldsM32Bytes >> 5) + 1;
+                } else {
+                    uint8_t *ws = a.workspace + (size_t)blockIdx.x * a.workspaceStride;
+                    m32 = ws;
+                    const size_t cap = ((size_t)6 * nCells + 31) & ~(size_t)31;
+                    bm = reinterpret_cast<uint32_t *>(ws + cap);
+                    wb = bm + (cap >> 5) + 1;
+                }
+                if (type != 0) {
+                    for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = pk[rawAt + i];
+                    __syncthreads();
+                } else {
+                    // the serialised tree: stage the words around it, parse, build the tables
+                    const uint32_t hb0 = (startBit >> 5) << 2;
+                    {
+                        uint8_t *hb = reinterpret_cast<uint8_t *>(S.head);
+                        for (uint32_t i = tid; i < HEAD_WORDS * 4; i += DEC_THREADS) hb[i] = hb0 + i < len ? pk[hb0 + i] : 0;
+                    }
+                    __syncthreads();
+                    if (wave == 0) parse_tree_wave(S, startBit & 31u, startBit, len * 8u);
+                    __syncthreads();
+                    if (S.parseStatus != GF_K_OK) return S.parseStatus;
+                    if (S.uniformSym >= 0) {
+                        const uint8_t sym = (uint8_t)S.uniformSym;
+                        for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
+                        if (tid == 0) S.chainEnd = S.textStart;          // no text (HuffmanDecoder.java:170-177)
+                        __syncthreads();
+                    } else {
+                        // second-level table: always in LDS, in the area the in-LDS bitmap uses later (as in k_huffman_decode)
+                        uint16_t *lut2 = reinterpret_cast<uint16_t *>(ldsDyn + a.ldsM32Bytes);
+                        build_lut(S, lut2);
+                        const uint32_t textStart = S.textStart;
+                        // the segment ends no later than nM32 codes of the longest length beyond its start
+                        const uint32_t endBit = (uint32_t)min((uint64_t)len * 8u, (uint64_t)textStart + (uint64_t)nM32 * S.maxLen);
+                        const uint64_t baseWord = (off * 8ull) >> 5;
+                        HuffCursorT<const uint32_t *> cur;
+                        cur.base32 = w32 + baseWord;
+                        cur.nW = (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord);
+                        cur.sh0 = (uint32_t)(off * 8ull) & 31u;
+                        cur.S = &S;
+                        cur.lut2 = lut2;
+                        const int32_t st = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, nullptr, 128u);
+                        if (st != GF_K_OK) return st;
+                        if (nM32 == 0 && tid == 0) S.chainEnd = textStart;
+                        __syncthreads();
+                    }
+                }
+                const uint32_t segEnd = S.chainEnd;
+                __syncthreads();                                          // m32_to_values reuses chainEnd
+                const int32_t st = m32_to_values(S, m32, nM32, bm, wb, nVals, CellMapIdentity{}, out, nullptr);
+                startBit = segEnd;
+                rawAt += nM32;
+                return st;
+            };
+            tileStatus = nM32 <= a.ldsM32Bytes ? segment(std::true_type{}) : segment(std::false_type{});
+        }
+        if (tid == 0) a.status[t] = tileStatus;
         __syncthreads();
     }
 }
@@ -943,5 +1114,20 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         maxDynSet = dyn;
     }
     hipLaunchKernelGGL(k_huffman_decode, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream, unsigned grid)
+{
+    if (a.nTiles == 0) return hipSuccess;
+    const size_t dyn = decodeDynLds(a.ldsM32Bytes, 0);
+    static size_t maxDynSet = 0;
+    if (dyn > maxDynSet) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsop_unpack_m32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) return e;
+        maxDynSet = dyn;
+    }
+    hipLaunchKernelGGL(k_lsop_unpack_m32, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();
 }

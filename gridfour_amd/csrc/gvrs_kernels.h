@@ -49,6 +49,28 @@ struct GfDecodeArgs {
     int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
 };
 
+// LSOP12 containers whose entropy stage is CodecM32 bytes: type 0 (legacy Huffman of the two M32 streams) and, with
+// rawM32 = 1, type 1 after the host inflated it (gvrs_decode.hip: k_lsop_unpack_m32)
+struct GfLsopM32Args {
+    const uint8_t *blob;       // 4-byte aligned
+    size_t blobBytes;
+    const uint64_t *offsets;   // may be null -> t * slotStride
+    size_t slotStride;
+    const uint32_t *lengths;
+    int32_t *residuals;        // nTiles * resStride ints: initialisers, then interior
+    size_t resStride;
+    uint32_t *coefs;           // nTiles * 16 words: seed, 12 float bit patterns
+    int32_t *status;           // in: only tiles marked GF_K_ERR_UNSUPPORTED are touched; out: their decode status
+    uint8_t *workspace;        // gridDim.x * workspaceStride bytes (M32 spill)
+    size_t workspaceStride;
+    size_t nTiles;
+    int nRows, nCols;
+    uint32_t ldsM32Bytes;
+    int rawM32;                // 1: type-1 containers hold the inflated M32 bytes of both streams behind the header
+};
+
+hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream, unsigned grid);
+
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 unsigned gf_huffman_decode_grid(size_t nTiles);

@@ -2,8 +2,8 @@
 // (lsop/LsDecoder12.java:107-119, lsop/LsHeader.java:131-185): header, then two CanonicalHuffman streams in one
 // bit store (initialisers, interior).  Output: seed + coefficients and the residual ints that
 // k_lsop_reconstruct (gvrs_lsop.hip) turns into the tile.  Containers of type 0 (legacy Huffman of M32) and
-// type 1 (Deflate of M32) are not entropy-decoded here: the host API inflates type 1 with zlib and reports
-// type 0 as unsupported.
+// type 1 (Deflate of M32) are left marked GF_K_ERR_UNSUPPORTED here for k_lsop_unpack_m32 (gvrs_decode.hip), which
+// shares the legacy Huffman / M32 device code of CodecHuffman.
 
 #include <hip/hip_runtime.h>
 

@@ -200,9 +200,10 @@ gf_status gf_deflate_decode_i32(gf_context *ctx, int n_rows, int n_cols, const u
  *   coefs:     per tile 16 words: seed, the 12 float32 coefficients as bit patterns, 3 spare
  * The encoder writes the current container: header (LsHeader.packHeader) + CanonicalHuffman of the two integer streams
  * in one bit store (compression type 2).  The Deflate alternative (type 1, LsEncoder12.java:180-216) is produced by the
- * host entry points with the host's zlib when deflate_enabled != 0 (the reference's default).  Decoding accepts types
- * 2 (GPU) and 1 (zlib on the host, tile rebuilt on the GPU), with either header revision; type 0, the legacy
- * Huffman-of-M32 container of old Gridfour versions, is GF_ERR_UNSUPPORTED.                                          */
+ * host entry points with the host's zlib when deflate_enabled != 0 (the reference's default).  Decoding accepts every
+ * container the reference's decoder does (LsDecoder12.java:107-150), with either header revision: type 2 and type 0
+ * (legacy Huffman of the two M32 streams, what Sample14_LSOP.gvrs holds) entirely on the GPU; type 1 after the host's
+ * zlib inflated its two streams (host entry points only: the _dev form reports GF_ERR_UNSUPPORTED for it).           */
 size_t gf_lsop12_residual_count(int n_rows, int n_cols);
 size_t gf_lsop12_max_packing(int n_rows, int n_cols);
 /* LsOptimalPredictor12.encode: tile -> coefficients + residual streams (d_status: GF_OK / GF_DECLINED per tile) */

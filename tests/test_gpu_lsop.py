@@ -109,10 +109,155 @@ def test_declines_and_errors(codec):
         codec.decode(20, 30, good[:len(good) // 2])
 
 
-def test_legacy_type0_container_is_reported_unsupported(codec, sample14):
+def _surface(n=101):
+    # the generator behind Sample14: z = floor(1000 sin(x pi) sin(y pi) + 0.5)
+    import math
+    v = np.zeros((n, n), np.int32)
+    for r in range(n):
+        for c in range(n):
+            x, y = c / (n - 1.0), r / (n - 1.0)
+            v[r, c] = int(math.floor(1000.0 * math.sin(x * math.pi) * math.sin(y * math.pi) + 0.5))
+    return v
+
+
+def test_sample14_reference_packing_decodes_on_device(codec, sample14):
+    """The one LSOP12 packing the reference's own resources hold (legacy header, two legacy-Huffman segments of M32
+    bytes in one bit store) goes through the C ABI and comes back as the analytic surface it was written from."""
+    got = codec.decode(101, 101, sample14)
+    assert np.array_equal(got.reshape(101, 101), _surface())
+    vals, st = codec.decode_batch(101, 101, [sample14] * 5)
+    assert np.all(st == 0) and all(np.array_equal(v, got) for v in vals)
+
+
+LEGACY_SHAPES = [(6, 6), (7, 9), (20, 30), (64, 64), (120, 150), (9, 200), (200, 200)]
+
+
+@pytest.mark.parametrize("shape", LEGACY_SHAPES, ids=lambda s: "%dx%d" % s)
+def test_legacy_huffman_container_decode(codec, shape):
+    """Type-0 containers as old Gridfour versions wrote them (made by the oracle's restatement, which reproduces
+    Sample14 byte for byte): smooth terrain, large residuals (multi-byte M32 values, long codes), and mixed batches
+    with the current container types."""
+    nr, nc = shape
+    tiles = [_terrain(nr, nc, k).ravel() for k in range(3)]
+    tiles.append(make_tile("noise16", nr, nc))
+    tiles.append((_terrain(nr, nc, 9, amp=200000).ravel() * 37).astype(np.int32))
+    packs, want = [], []
+    for k, v in enumerate(tiles):
+        try:
+            pk = oracle.lsop12_encode_legacy_huffman(k, nr, nc, v)
+        except ValueError:
+            continue                                      # singular system: the encoder declines
+        assert np.array_equal(oracle.lsop12_decode(nr, nc, pk), v)
+        packs.append(pk)
+        want.append(v)
+        cur, _ = oracle.lsop12_encode(k, nr, nc, v, k % 2 == 0)           # canonical / Deflate neighbours
+        if cur is not None:
+            packs.append(cur)
+            want.append(v)
+    assert packs
+    vals, st = codec.decode_batch(nr, nc, packs)
+    for k, v in enumerate(want):
+        assert st[k] == 0, (k, st[k])
+        assert np.array_equal(vals[k], v), k
+
+
+def _handmade_type0(nr, nc, seed, coefs, init, interior, revised=False, checksum=False):
+    """A type-0 container around chosen residual streams (LsHeader.java:139-185 both revisions, LsDecoder12.java:116-124)."""
+    m_init, m_int = oracle.m32_encode_seq(init), oracle.m32_encode_seq(interior)
+    co = np.asarray(coefs, "<f4").tobytes()
+    if revised:
+        head = bytes([3, 0x40 | (0x80 if checksum else 0), 12]) + struct.pack("<i", seed) + co + struct.pack("<ii", len(m_init), len(m_int))
+    else:
+        head = bytes([3, 12]) + struct.pack("<i", seed) + co + struct.pack("<ii", len(m_init), len(m_int)) + bytes([0x80 if checksum else 0])
+    if checksum:
+        head += b"\x12\x34\x56\x78"
+    buf, pos, _, _ = oracle.huffman_encode(np.frombuffer(m_init, np.uint8), len(head) * 8, head)
+    buf, pos, _, _ = oracle.huffman_encode(np.frombuffer(m_int, np.uint8), pos, buf)
+    return buf
+
+
+@pytest.mark.parametrize("revised,checksum", [(False, False), (True, False), (True, True), (False, True)])
+def test_legacy_container_handmade_streams(codec, revised, checksum):
+    """Segments the encoder seldom produces: single-symbol trees (HuffmanEncoder.java:147-157, 17 bits and no text) in
+    either position, segments that start at every bit phase, values of every M32 length, long codes."""
+    nr, nc = 24, 40
+    n_init, n_int = 4 * nr + 2 * nc - 9, (nr - 2) * (nc - 4)
+    rng = np.random.default_rng(2024)
+    coefs = (rng.standard_normal(12) * 0.2).astype(np.float32)
+    wide = rng.integers(-2**31, 2**31, n_int, dtype=np.int64).astype(np.int32)
+    wide[rng.random(n_int) < 0.7] = 0
+    skew = np.where(rng.random(n_int) < 0.97, 0, rng.integers(-120, 120, n_int)).astype(np.int32)   # long codes
+    streams = [
+        (rng.integers(-5, 6, n_init), np.zeros(n_int, np.int64)),                    # interior: one symbol
+        (np.full(n_init, 7), rng.integers(-300, 300, n_int)),                        # initialisers: one symbol
+        (np.zeros(n_init, np.int64), np.zeros(n_int, np.int64)),                     # both
+        (rng.integers(-70000, 70000, n_init), wide),
+        (rng.integers(-2, 3, n_init), skew),
+    ]
+    for k in range(8):                                                               # bit phases of the second segment
+        streams.append((rng.integers(-3, 4, n_init)[: n_init], rng.integers(-(k + 2), k + 3, n_int)))
+    packs = [_handmade_type0(nr, nc, 1000 + i, coefs, a, b, revised, checksum) for i, (a, b) in enumerate(streams)]
+    want = [oracle.lsop12_decode(nr, nc, pk) for pk in packs]
+    vals, st = codec.decode_batch(nr, nc, packs)
+    for k in range(len(packs)):
+        assert st[k] == 0, (k, st[k])
+        assert np.array_equal(vals[k], want[k]), k
+
+
+def test_legacy_container_damage_is_reported(codec, sample14):
+    rng = np.random.default_rng(11)
+    packs = [sample14[:n] for n in (2, 40, 62, 63, 64, 200, 800, 1596)]
+    for k in range(40):
+        b = bytearray(sample14)
+        for _ in range(1 + k % 4):
+            b[int(rng.integers(1, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        packs.append(bytes(b))
+    vals, st = codec.decode_batch(101, 101, packs)
+    assert set(int(x) for x in st) <= {0, -1, -2, -7}
+    for k, pk in enumerate(packs):
+        try:
+            ref = oracle.lsop12_decode(101, 101, pk)
+        except Exception:
+            ref = None
+        if ref is None:
+            continue
+        if st[k] == 0:
+            assert np.array_equal(vals[k], ref), k
+
+
+def test_device_resident_legacy_containers(sample14):
+    """gf_lsop12_decode_batch_i32_dev on packings already in HBM: type 0 is decoded entirely on the device; a Deflate
+    container there (no inflate on the device) is reported unsupported."""
     import gridfour_amd
-    with pytest.raises(gridfour_amd.GvrsHipError):
-        codec.decode(101, 101, sample14)
+    from gridfour_amd import DeviceBuffer, lib
+    ctx = gridfour_amd.GvrsHipContext(0)
+    nr = nc = 101
+    v = oracle.lsop12_decode(nr, nc, sample14)
+    canon, typ = oracle.lsop12_encode(0, nr, nc, v, False)
+    defl, typ1 = oracle.lsop12_encode(0, nr, nc, v, True)
+    assert typ == 2
+    packs = [sample14, canon, defl, sample14]
+    stride = 4096 * 4
+    nt = len(packs)
+    blob = np.zeros(nt * stride, np.uint8)
+    for k, pk in enumerate(packs):
+        blob[k * stride:k * stride + len(pk)] = np.frombuffer(pk, np.uint8)
+    lengths = np.array([len(pk) for pk in packs], np.uint32)
+    n = int(lib().gf_lsop12_residual_count(nr, nc))
+    rs = (n + 3) // 4 * 4
+    dblob, dlen, dval, dst = (DeviceBuffer(ctx, blob.nbytes), DeviceBuffer(ctx, nt * 4), DeviceBuffer(ctx, nt * nr * nc * 4),
+                              DeviceBuffer(ctx, nt * 4))
+    dres, dco, dsc = DeviceBuffer(ctx, nt * rs * 4), DeviceBuffer(ctx, nt * 64), DeviceBuffer(ctx, nt * 4)
+    dblob.upload(blob)
+    dlen.upload(lengths)
+    gridfour_amd._lib.check(lib().gf_lsop12_decode_batch_i32_dev(ctx.handle, None, nr, nc, nt, dblob.ptr, blob.nbytes, None, stride,
+                                                                  dlen.ptr, dval.ptr, dst.ptr, dres.ptr, rs, dco.ptr, dsc.ptr), "dec")
+    ctx.synchronize()
+    st = dst.download(np.int32, nt)
+    got = dval.download(np.int32, nt * nr * nc).reshape(nt, -1)
+    for k in (0, 1, 3):
+        assert st[k] == 0 and np.array_equal(got[k], v), (k, st[k])
+    assert st[2] == (-7 if typ1 == 1 else 0)
 
 
 def test_device_batch_dem_roundtrip():
