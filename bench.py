@@ -39,6 +39,7 @@ WORKLOADS = {
     "etopo1": (120, 150, 12960, 144, "ETOPO1-shaped 10800x21600 int32 grid, 120x150 tiles, full encode+decode roundtrip"),
     "dem1024": (200, 200, 1024, 32, "1024-tile batch, 200x200 int32 synthetic DEM, all 3 predictors + Huffman"),
     "gebco_shard": (200, 200, 11664, 432, "1/8 shard of the GEBCO_2023-shaped 43200x86400 int32 grid, 200x200 tiles"),
+    "float256": (256, 256, 4096, 64, "4096 tiles of 256x256 float32 (DEM x 0.1f), CodecFloat byte-plane stage"),
 }
 
 
@@ -48,8 +49,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="etopo1", choices=sorted(WORKLOADS))
-    ap.add_argument("--codec", default="huffman", choices=["huffman", "canon", "lsop"],
-                    help="huffman = CodecHuffman (the north-star path, default); canon = CodecCanonHuffman; lsop = LSOP12, canonical container")
+    ap.add_argument("--codec", default="huffman", choices=["huffman", "canon", "lsop", "float"],
+                    help="huffman = CodecHuffman (the north-star path, default); canon = CodecCanonHuffman; lsop = LSOP12, canonical container; "
+                         "float = CodecFloat plane split/merge (use with --workload float256)")
     ap.add_argument("--cpu-sample-tiles", type=int, default=-1, help="tiles timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU port on every host core")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exactness checks")
@@ -72,6 +74,122 @@ def _pmc_traffic(workload, kernel):
         if kernel in name:
             return int(d["traffic"])
     return None
+
+
+def run_float(args, ctx, rank, world, dist, torch):
+    """BASELINE config 5(i): CodecFloat.  The GPU stage is the five byte planes (split + delta on encode, running sums +
+    merge on decode, CodecFloat.java:328-458); the Deflate stage is the host's zlib and is timed separately, on a sample,
+    through the host entry points.  One step = planes-encode then planes-decode of every tile, device-resident."""
+    import gridfour_amd
+    from gridfour_amd import DeviceBuffer, DeviceTileBatch, GpuTimer, lib
+    from gridfour_amd._lib import check
+    n_rows, n_cols, n_tiles, tiles_per_row, descr = WORKLOADS[args.workload]
+    cells = n_rows * n_cols
+    # floats = integer DEM x 0.1f (SURVEY 8d): generated on the device as int32, converted on the host once
+    gen = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=16)
+    gen.synth_dem(0x9E3779B97F4A7C15 + 5, tiles_per_row, tile0=rank * n_tiles)
+    ctx.synchronize()
+    vals = (gen.get_values().astype(np.float32) * np.float32(0.1)).reshape(n_tiles, cells)
+    del gen
+    pstride = int(lib().gf_float_planes_bytes(n_rows, n_cols))
+    pstride = (pstride + 15) // 16 * 16
+    d_in, d_planes, d_out = (DeviceBuffer(ctx, vals.nbytes), DeviceBuffer(ctx, n_tiles * pstride),
+                             DeviceBuffer(ctx, vals.nbytes))
+    d_in.upload(vals)
+    t_enc = [GpuTimer(ctx) for _ in range(args.steps)]
+    t_dec = [GpuTimer(ctx) for _ in range(args.steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    def step(i=None):
+        if i is not None:
+            t_enc[i].start()
+        check(lib().gf_float_planes_encode_dev(ctx.handle, None, n_rows, n_cols, n_tiles, d_in.ptr, d_planes.ptr, pstride), "enc")
+        if i is not None:
+            t_enc[i].stop()
+            t_dec[i].start()
+        check(lib().gf_float_planes_decode_dev(ctx.handle, None, n_rows, n_cols, n_tiles, d_planes.ptr, pstride, d_out.ptr), "dec")
+        if i is not None:
+            t_dec[i].stop()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    enc_avg = float(np.mean([t.elapsed_ms() for t in t_enc]))
+    dec_avg = float(np.mean([t.elapsed_ms() for t in t_dec]))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    bit_exact, cpu_baseline, host_path = None, None, None
+    if not args.no_verify:
+        import oracle
+        back = d_out.download(np.uint32, n_tiles * cells).reshape(n_tiles, cells)
+        roundtrip_ok = bool(np.array_equal(back, vals.view(np.uint32)))
+        planes = d_planes.download(np.uint8, n_tiles * pstride).reshape(n_tiles, pstride)
+        nb = int(lib().gf_float_planes_bytes(n_rows, n_cols))
+        parity_ok = all(planes[t, :nb].tobytes() == bytes(oracle.float_planes_encode(n_rows, n_cols, vals[t].view(np.uint32)))
+                        for t in range(0, n_tiles, max(1, n_tiles // 16)))
+        bit_exact = bool(roundtrip_ok and parity_ok)
+        ns = args.cpu_sample_tiles if args.cpu_sample_tiles >= 0 else 48
+        if ns > 0 and world == 1:
+            sub = vals[:ns]
+            mb = sub.nbytes / 1e6
+            c0 = time.perf_counter()
+            packs = [oracle.codec_float_encode(0, n_rows, n_cols, x.view(np.uint32), 9) for x in sub]
+            c1 = time.perf_counter()
+            dec = [oracle.codec_float_decode(n_rows, n_cols, pk) for pk in packs]
+            c2 = time.perf_counter()
+            assert all(np.array_equal(np.asarray(d, np.uint32), x.view(np.uint32)) for d, x in zip(dec, sub))
+            cpu_baseline = {"value": round(mb / (c2 - c0), 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                            "sample": "first %d tiles (%.0f MB): oracle CodecFloat incl. zlib level 9, 1 thread; encode %.1f, "
+                                      "decode %.1f MB/s" % (ns, mb, mb / (c1 - c0), mb / (c2 - c1))}
+            codec = gridfour_amd.CodecFloatHip(ctx, level=9)
+            h0 = time.perf_counter()
+            hp = codec.encode_floats_batch(0, n_rows, n_cols, sub)
+            h1 = time.perf_counter()
+            hv, hst = codec.decode_floats_batch(n_rows, n_cols, hp)
+            h2 = time.perf_counter()
+            host_path = {"encode_MBps": round(mb / (h1 - h0), 1), "decode_MBps": round(mb / (h2 - h1), 1),
+                         "equals_oracle_packings": bool(hp == packs), "compressed_bytes_per_cell": round(sum(map(len, hp)) / (ns * cells), 4),
+                         "note": "host entry points on the same sample: PCIe + GPU planes + zlib level 9 on the host's threads"}
+            assert np.array_equal(hv.view(np.uint32), sub.view(np.uint32)) and (hst == 0).all()
+    steps = args.steps
+    raw_mb = n_tiles * cells * 4 / 1e6
+    plane_bytes = 4.125                              # sign bit + exponent + three mantissa bytes per cell
+    alg_bytes = (4.0 + plane_bytes) * n_tiles * cells
+    dom_name, dom_ms = ("k_float_planes_decode", dec_avg) if dec_avg >= enc_avg else ("k_float_planes_encode", enc_avg)
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    out = {
+        "metric": "CodecFloat plane stage encode+decode MB/s on float32 tiles (GPU stage; Deflate on the host's zlib)",
+        "value": round(raw_mb * world * steps / elapsed, 1), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, descr), "tile_rows": n_rows, "tile_cols": n_cols, "tiles_per_gpu": n_tiles,
+                   "codec": "CodecFloat (sign / exponent / 3 delta-coded mantissa byte planes)", "sharding": "contiguous tile ranges, no collective"},
+        "bit_exact": bit_exact, "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": _pmc_traffic(args.workload, dom_name),
+                     "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(dom_ms, 4),
+                     "roundtrip_frac": round((2 * alg_bytes) / ((enc_avg + dec_avg) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "cpu_baseline": cpu_baseline, "host_path": host_path,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -98,6 +216,10 @@ def main():
     n_rows, n_cols, n_tiles, tiles_per_row, descr = WORKLOADS[args.workload]
     cells = n_rows * n_cols
     ctx = gridfour_amd.GvrsHipContext(local_rank)
+    if (args.codec == "float") != (args.workload == "float256"):
+        raise SystemExit("--codec float goes with --workload float256 (and only with it)")
+    if args.codec == "float":
+        return run_float(args, ctx, rank, world, dist, torch)
     stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
     batch = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
     seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3}[args.workload]

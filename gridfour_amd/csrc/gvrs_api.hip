@@ -79,6 +79,22 @@ struct gf_timer {
     hipEvent_t start, stop;
 };
 
+// tiles are independent: the host-side zlib stages run on up to 32 threads
+template <class F>
+static void parallelFor(size_t n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    if (nt > n) nt = (unsigned)n;
+    if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nt; w++)
+        th.emplace_back([=]() { for (size_t i = w; i < n; i += nt) f(i); });
+    for (auto &x : th) x.join();
+}
+
+
 extern "C" {
 
 const char *gf_version(void) { return "gvrs-hip-codec 0.1 (gfx950)"; }
@@ -433,33 +449,34 @@ gf_status gf_float_encode_batch_f32(gf_context *c, int codecIndex, int nRows, in
     GF_HIP(hipMemcpyAsync(planes.data(), c->dPlanes.p, nTiles * stride, hipMemcpyDeviceToHost, c->stream));
     GF_HIP(hipStreamSynchronize(c->stream));
     // framing, CodecFloat.java:371-391: codecIndex, 0, then five [int32 LE length, zlib stream]
-    uint64_t total = 0;
-    bool fits = true;
-    std::vector<uint8_t> z;
-    for (size_t t = 0; t < nTiles; t++) {
-        offsets[t] = total;
+    std::vector<std::vector<uint8_t>> packed(nTiles);
+    std::vector<uint8_t> failed(nTiles, 0);
+    parallelFor(nTiles, [&](size_t t) {
         const uint8_t *p = planes.data() + t * stride;
-        size_t off = total;
-        if (fits && off + 2 <= blobCap) { blob[off] = (uint8_t)codecIndex; blob[off + 1] = 0; } else fits = false;
-        off += 2;
+        std::vector<uint8_t> &out = packed[t];
+        std::vector<uint8_t> z;
+        out.push_back((uint8_t)codecIndex);
+        out.push_back(0);
         size_t planeOff = 0;
         for (int k = 0; k < 5; k++) {
             const size_t pl = k == 0 ? nSign : n;
-            if (!zDeflate(p + planeOff, pl, zlibLevel, z)) return GF_ERR_ARG;
+            if (!zDeflate(p + planeOff, pl, zlibLevel, z)) { failed[t] = 1; return; }
             planeOff += pl;
-            if (fits && off + 4 + z.size() <= blobCap) {
-                const uint32_t zn = (uint32_t)z.size();
-                for (int b = 0; b < 4; b++) blob[off + b] = (uint8_t)(zn >> (8 * b));
-                memcpy(blob + off + 4, z.data(), z.size());
-            } else {
-                fits = false;
-            }
-            off += 4 + z.size();
+            const uint32_t zn = (uint32_t)z.size();
+            for (int b = 0; b < 4; b++) out.push_back((uint8_t)(zn >> (8 * b)));
+            out.insert(out.end(), z.begin(), z.end());
         }
-        total = off;
+    });
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        if (failed[t]) return GF_ERR_ARG;                     // zlib rejected the level
+        offsets[t] = total;
+        total += packed[t].size();
     }
     offsets[nTiles] = total;
-    return fits ? GF_OK : GF_ERR_CAPACITY;
+    if (total > blobCap) return GF_ERR_CAPACITY;
+    parallelFor(nTiles, [&](size_t t) { memcpy(blob + offsets[t], packed[t].data(), packed[t].size()); });
+    return GF_OK;
 }
 
 gf_status gf_float_decode_batch_f32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
@@ -470,8 +487,8 @@ gf_status gf_float_decode_batch_f32(gf_context *c, int nRows, int nCols, size_t 
     const size_t n = (size_t)nRows * (size_t)nCols, nSign = (n + 7) / 8;
     const size_t stride = roundUp(gf_float_planes_bytes(nRows, nCols), 16);
     std::vector<uint8_t> planes(nTiles * stride, 0);
-    gf_status overall = GF_OK;
-    for (size_t t = 0; t < nTiles; t++) {
+    std::vector<int32_t> tileSt(nTiles, GF_OK);
+    parallelFor(nTiles, [&](size_t t) {
         const uint8_t *pk = blob + offsets[t];
         const size_t len = (size_t)(offsets[t + 1] - offsets[t]);
         int32_t st = GF_OK;
@@ -488,8 +505,12 @@ gf_status gf_float_decode_batch_f32(gf_context *c, int nRows, int nCols, size_t 
             off += zn;
             planeOff += pl;
         }
-        if (status) status[t] = st;
-        if (st != GF_OK && overall == GF_OK) overall = (gf_status)st;
+        tileSt[t] = st;
+    });
+    gf_status overall = GF_OK;
+    for (size_t t = 0; t < nTiles; t++) {
+        if (status) status[t] = tileSt[t];
+        if (tileSt[t] != GF_OK && overall == GF_OK) overall = (gf_status)tileSt[t];
     }
     gf_status s;
     if ((s = c->dValues.ensure(nTiles * n * 4 + 16)) != GF_OK) return s;
@@ -921,20 +942,6 @@ size_t m32Pack(const int32_t *x, size_t n, std::vector<uint8_t> &out)
 
 void putLE32(uint8_t *p, uint32_t x) { p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24); }
 uint32_t getLE32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-
-template <class F>
-void parallelFor(size_t n, F f)
-{
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    if (nt > 32) nt = 32;
-    if (n < 2 * nt) nt = 1;
-    if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-    std::vector<std::thread> th;
-    for (unsigned w = 0; w < nt; w++)
-        th.emplace_back([=]() { for (size_t i = w; i < n; i += nt) f(i); });
-    for (auto &x : th) x.join();
-}
 
 }  // namespace
 

@@ -21,6 +21,10 @@ namespace {
 
 constexpr int FLT_THREADS = 256;
 
+// a dword of four plane bytes at any byte address (the planes of a tile follow one another without padding)
+struct __attribute__((packed, aligned(1))) PlaneWord { uint32_t v; };
+struct __attribute__((packed, aligned(16))) Cells4 { uint32_t x, y, z, w; };
+
 __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_encode(const uint32_t *__restrict__ raw, uint8_t *__restrict__ planes,
                                                                     size_t planeStride, size_t nTiles, int nRows, int nCols)
 {
@@ -31,7 +35,43 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_encode(const uint3
         const uint32_t *__restrict__ c = raw + t * (size_t)n;
         uint8_t *pSign = planes + t * planeStride;
         uint8_t *pExp = pSign + nSign, *pM1 = pExp + n, *pM2 = pM1 + n, *pM3 = pM2 + n;
-        // whole waves walk 64 consecutive cells so that one ballot yields 8 sign bytes
+        if ((nC & 3u) == 0 && (((uintptr_t)c) & 15u) == 0) {
+            // four cells of one row per lane: one 16-byte load, one dword store per byte plane; the sign bits of 32
+            // cells are gathered over 8 lanes into one dword
+            for (uint32_t i0 = threadIdx.x * 4u; i0 < ((n + 31u) & ~31u); i0 += FLT_THREADS * 4u) {
+                const bool in = i0 < n;
+                Cells4 q{0u, 0u, 0u, 0u};
+                uint32_t p = 0;
+                if (in) {
+                    q = *reinterpret_cast<const Cells4 *>(c + i0);
+                    const uint32_t col = i0 % nC;
+                    p = col > 0 ? c[i0 - 1] : (i0 >= nC ? c[i0 - nC] : 0u);
+                }
+                const uint32_t v0 = q.x, v1 = q.y, v2 = q.z, v3 = q.w;
+                uint32_t sg = ((v0 >> 31) | ((v1 >> 31) << 1) | ((v2 >> 31) << 2) | ((v3 >> 31) << 3)) << (4u * (lane & 7));
+                sg |= gf_lane_xor(sg, 1);
+                sg |= gf_lane_xor(sg, 2);
+                sg |= gf_lane_xor(sg, 4);
+                if (in) {
+                    if ((lane & 7) == 0) {
+                        if (i0 + 32u <= n) reinterpret_cast<PlaneWord *>(pSign + (i0 >> 3))->v = sg;
+                        else for (uint32_t b = 0; i0 + 8u * b < n; b++) pSign[(i0 >> 3) + b] = (uint8_t)(sg >> (8u * b));
+                    }
+                    auto bytes4 = [](uint32_t a, uint32_t b, uint32_t cc, uint32_t d) -> uint32_t {
+                        return (a & 0xffu) | ((b & 0xffu) << 8) | ((cc & 0xffu) << 16) | (d << 24);
+                    };
+                    reinterpret_cast<PlaneWord *>(pExp + i0)->v = bytes4(v0 >> 23, v1 >> 23, v2 >> 23, v3 >> 23);
+                    reinterpret_cast<PlaneWord *>(pM1 + i0)->v =
+                        bytes4(((v0 >> 16) & 0x7fu) - ((p >> 16) & 0x7fu), ((v1 >> 16) & 0x7fu) - ((v0 >> 16) & 0x7fu),
+                               ((v2 >> 16) & 0x7fu) - ((v1 >> 16) & 0x7fu), ((v3 >> 16) & 0x7fu) - ((v2 >> 16) & 0x7fu));
+                    reinterpret_cast<PlaneWord *>(pM2 + i0)->v =
+                        bytes4((v0 >> 8) - (p >> 8), (v1 >> 8) - (v0 >> 8), (v2 >> 8) - (v1 >> 8), (v3 >> 8) - (v2 >> 8));
+                    reinterpret_cast<PlaneWord *>(pM3 + i0)->v = bytes4(v0 - p, v1 - v0, v2 - v1, v3 - v2);
+                }
+            }
+            continue;
+        }
+        // any shape: whole waves walk 64 consecutive cells so that one ballot yields 8 sign bytes
         for (uint32_t base = (threadIdx.x >> 6) * 64u; base < n; base += FLT_THREADS) {
             const uint32_t i = base + lane;
             const bool in = i < n;
@@ -85,7 +125,60 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_decode(const uint8
             carry1 = col0[0][rows - 1];
             carry2 = col0[1][rows - 1];
             carry3 = col0[2][rows - 1];
-            for (uint32_t rr = wave; rr < rows; rr += FLT_THREADS / 64) {
+            const bool quads = (nC & 3u) == 0 && (((uintptr_t)o) & 15u) == 0;
+            for (uint32_t rr = wave; quads && rr < rows; rr += FLT_THREADS / 64) {
+                // four columns per lane: a dword per plane, byte-wise running sums inside the lane, one wave scan of the
+                // lane totals per plane, one 16-byte store
+                const uint32_t r = r0 + rr;
+                const size_t rowOff = (size_t)r * nC;
+                uint32_t c1 = 0, c2 = 0, c3 = 0;
+                for (uint32_t cb = 0; cb < nC; cb += 256) {
+                    const uint32_t cc = cb + 4u * lane;
+                    const bool in = cc < nC;
+                    const size_t i = rowOff + cc;
+                    uint32_t w1 = 0, w2 = 0, w3 = 0, we = 0, sb = 0;
+                    if (in) {
+                        w1 = reinterpret_cast<const PlaneWord *>(pM1 + i)->v;
+                        w2 = reinterpret_cast<const PlaneWord *>(pM2 + i)->v;
+                        w3 = reinterpret_cast<const PlaneWord *>(pM3 + i)->v;
+                        we = reinterpret_cast<const PlaneWord *>(pExp + i)->v;
+                        sb = ((uint32_t)pSign[i >> 3] >> (i & 7)) & 0xfu;          // i is a multiple of 4: one byte holds the four bits
+                    }
+                    if (cc == 0) {                                                 // first cell of the row: already decoded
+                        w1 = (w1 & ~0xffu) | col0[0][rr];
+                        w2 = (w2 & ~0xffu) | col0[1][rr];
+                        w3 = (w3 & ~0xffu) | col0[2][rr];
+                    }
+                    auto sums = [](uint32_t w, uint32_t *a, uint32_t *b, uint32_t *cc2, uint32_t *d) {
+                        *a = w & 0xffu;
+                        *b = *a + ((w >> 8) & 0xffu);
+                        *cc2 = *b + ((w >> 16) & 0xffu);
+                        *d = *cc2 + (w >> 24);
+                    };
+                    uint32_t a0, a1, a2, a3, b0, b1, b2, b3, d0, d1, d2, d3;
+                    sums(w1, &a0, &a1, &a2, &a3);
+                    sums(w2, &b0, &b1, &b2, &b3);
+                    sums(w3, &d0, &d1, &d2, &d3);
+                    const uint32_t ia = gf_wave_incl_scan(a3), ib = gf_wave_incl_scan(b3), id = gf_wave_incl_scan(d3);
+                    const uint32_t ea = ia - a3 + c1, eb = ib - b3 + c2, ed = id - d3 + c3;   // sums of everything to the left
+                    c1 += (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+                    c2 += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+                    c3 += (uint32_t)__builtin_amdgcn_readlane((int)id, 63);
+                    if (in) {
+                        auto cell = [&](uint32_t k, uint32_t a, uint32_t b, uint32_t d) -> uint32_t {
+                            return (((sb >> k) & 1u) << 31) | (((we >> (8u * k)) & 0xffu) << 23) | (((a + ea) & 0x7fu) << 16) |
+                                   (((b + eb) & 0xffu) << 8) | ((d + ed) & 0xffu);
+                        };
+                        Cells4 q;
+                        q.x = cell(0, a0, b0, d0);
+                        q.y = cell(1, a1, b1, d1);
+                        q.z = cell(2, a2, b2, d2);
+                        q.w = cell(3, a3, b3, d3);
+                        *reinterpret_cast<Cells4 *>(o + i) = q;
+                    }
+                }
+            }
+            for (uint32_t rr = wave; !quads && rr < rows; rr += FLT_THREADS / 64) {
                 const uint32_t r = r0 + rr;
                 const size_t rowOff = (size_t)r * nC;
                 uint32_t c1 = 0, c2 = 0, c3 = 0;                // running sums carried along the row

@@ -33,7 +33,7 @@ def _float_tiles(rng, n_rows, n_cols):
     return [smooth, ramp, noise, special, tiny]
 
 
-@pytest.mark.parametrize("shape", [(50, 50), (7, 9), (1, 5), (5, 1), (64, 65), (256, 256), (3, 1100)], ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("shape", [(50, 50), (7, 9), (1, 5), (5, 1), (64, 65), (256, 256), (3, 1100), (5, 12), (7, 20), (1, 4), (120, 152), (9, 260)], ids=lambda s: "%dx%d" % s)
 def test_planes_and_packings_match_oracle(fcodec, shape):
     import gridfour_amd
     from gridfour_amd import DeviceBuffer, lib
