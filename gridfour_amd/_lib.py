@@ -79,6 +79,12 @@ SIGNATURES = {
     "gf_codec_master_decode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
     "gf_tile_payload_encode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp]),
     "gf_tile_payload_decode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_tile_record_max_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "gf_crc32c": (C.c_uint32, [_vp, C.c_size_t]),
+    "gf_tile_record_encode_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_int,
+                                              _vp, C.c_size_t, _vp, _vp]),
+    "gf_tile_record_decode_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_int, _vp, _vp,
+                                              _vp]),
     "gf_compact_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t]),
     "gf_float_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "gf_float_planes_encode_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t]),

@@ -566,6 +566,40 @@ class CodecMasterHip:
               "gf_tile_payload_encode_batch_i32")
         return [bytes(blob[int(offsets[t]):int(offsets[t + 1])]) for t in range(nt)], used
 
+    # ---- tile records: RecordManager.writeTile / readTile for a batch of dirty tiles (one integer-coded element) ----
+    def tile_records(self, nRows, nCols, tile_indices, tiles, element="int", fill_value=-32768, checksums=True):
+        """Returns (records: list[bytes] exactly as RecordManager appends them to the file, codec index used (255 = raw))."""
+        short = element == "short"
+        v = np.ascontiguousarray(tiles, dtype=np.int16 if short else np.int32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        idx = np.ascontiguousarray(tile_indices, dtype=np.int32)
+        assert idx.size == nt
+        cap = nt * int(lib().gf_tile_record_max_bytes(int(short), nRows, nCols))
+        blob = np.empty(max(cap, 16), np.uint8)
+        offsets = np.zeros(nt + 1, np.uint64)
+        used = np.zeros(nt, np.uint8)
+        codecs = self.codecs if self.codecs.size else np.zeros(1, np.int32)
+        check(lib().gf_tile_record_encode_batch(self.ctx.handle, _ptr(codecs), self.codecs.size, int(short), int(fill_value),
+                                                nRows, nCols, nt, _ptr(idx), _ptr(v), int(bool(checksums)), _ptr(blob), cap,
+                                                _ptr(offsets), _ptr(used)), "gf_tile_record_encode_batch")
+        return [bytes(blob[int(offsets[t]):int(offsets[t + 1])]) for t in range(nt)], used
+
+    def tiles_from_records(self, nRows, nCols, records, element="int", verify_checksums=True):
+        """Returns (tile indices, values [nt, cells] int32 / int16, status per record)."""
+        short = element == "short"
+        nt = len(records)
+        offsets = np.zeros(nt + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(p) for p in records])
+        blob = np.frombuffer(b"".join(records) + b"\0" * 16, dtype=np.uint8)
+        out = np.zeros((nt, nRows * nCols), np.int16 if short else np.int32)
+        idx = np.full(nt, -1, np.int32)
+        status = np.zeros(nt, np.int32)
+        codecs = self.codecs if self.codecs.size else np.zeros(1, np.int32)
+        check(lib().gf_tile_record_decode_batch(self.ctx.handle, _ptr(codecs), self.codecs.size, int(short), nRows, nCols, nt,
+                                                _ptr(blob), _ptr(offsets), int(bool(verify_checksums)), _ptr(idx), _ptr(out),
+                                                _ptr(status)), "gf_tile_record_decode_batch")
+        return idx, out, status
+
     def tiles_from_payloads(self, nRows, nCols, payloads):
         nt = len(payloads)
         offsets = np.zeros(nt + 1, np.uint64)

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -1595,6 +1596,179 @@ gf_status gf_tile_payload_decode_batch_i32(gf_context *c, const int *codecs, int
         st[t] = dst[t];
         if (dst[t] == GF_OK) memcpy(values + t * cells, out.data() + t * cells, rawBytes);
     }
+    if (status) memcpy(status, st.data(), nTiles * 4);
+    return GF_OK;
+}
+
+// ------------------------------------------------------------------ tile records (RecordManager framing)
+
+static uint32_t crc32cTable[256];
+static std::once_flag crc32cOnce;
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) as util/GridfourCRC32C.java:330-338 applies it
+uint32_t gf_crc32c(const uint8_t *data, size_t n)
+{
+    std::call_once(crc32cOnce, []() {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t x = i;
+            for (int k = 0; k < 8; k++) x = (x >> 1) ^ ((x & 1u) ? 0x82F63B78u : 0u);
+            crc32cTable[i] = x;
+        }
+    });
+    uint32_t crc = 0xffffffffu;
+    for (size_t i = 0; i < n; i++) crc = crc32cTable[(crc ^ data[i]) & 0xffu] ^ (crc >> 8);
+    return crc ^ 0xffffffffu;
+}
+
+static size_t elemStandardSize(int elemType, size_t cells)
+{
+    // TileElement.java:86-93: bytes per sample * cells, rounded up to a multiple of 4
+    return elemType == GF_ELEM_SHORT ? ((cells * 2 + 3) & ~(size_t)3) : cells * 4;
+}
+
+size_t gf_tile_record_max_bytes(int elemType, int nRows, int nCols)
+{
+    const size_t content = 8 + elemStandardSize(elemType, (size_t)nRows * (size_t)nCols);
+    return (content + 12 + 7) & ~(size_t)7;
+}
+
+// RecordManager.writeTile (gvrs/RecordManager.java:386-470) for tiles of one integer-coded element, each record as
+// fileSpaceAlloc / fileSpaceInitRecord / fileSpaceFinishRecord lay it out when the file is extended (:153-204, 217-262):
+//   [int32 size, multiple of 8][type 2][0 0 0][int32 tileIndex][int32 n][n bytes][zero padding][CRC-32C of all before | 0]
+// The element bytes are the CodecMaster packing or, when no codec helps, the standard form (TileElementInt.java:196-207,
+// TileElementShort.java:211-229: shorts go to the codecs as ints with the fill value mapped to INT4_NULL_CODE).
+gf_status gf_tile_record_encode_batch(gf_context *c, const int *codecs, int nCodecs, int elemType, int fillValue, int nRows,
+                                      int nCols, size_t nTiles, const int32_t *tileIndices, const void *values,
+                                      int checksumEnabled, uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *codecUsed)
+{
+    if (!c || !values || !offsets || !tileIndices || (!blob && blobCap)) return GF_ERR_ARG;
+    if (elemType != GF_ELEM_INT && elemType != GF_ELEM_SHORT) return GF_ERR_ARG;
+    if (nRows < 1 || nCols < 1) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols, stdSize = elemStandardSize(elemType, cells);
+    const int32_t *iv = (const int32_t *)values;
+    std::vector<int32_t> widened;
+    if (elemType == GF_ELEM_SHORT) {
+        const int16_t *sv = (const int16_t *)values;
+        widened.resize(nTiles * cells);
+        parallelFor(nTiles, [&](size_t t) {
+            for (size_t i = t * cells; i < (t + 1) * cells; i++)
+                widened[i] = sv[i] == (int16_t)fillValue ? (int32_t)0x80000000 : (int32_t)sv[i];
+        });
+        iv = widened.data();
+    }
+    std::vector<uint8_t> packs;
+    std::vector<uint64_t> off(nTiles + 1, 0);
+    std::vector<int32_t> st(nTiles, GF_DECLINED);
+    std::vector<uint8_t> used(nTiles, 0xff);
+    if (nCodecs > 0 && nTiles > 0) {                                   // data compression enabled (:417)
+        packs.resize(nTiles * (cells * 4 + 1024) + 64);
+        gf_status s = gf_codec_master_encode_batch_i32(c, codecs, nCodecs, nRows, nCols, nTiles, iv, packs.data(), packs.size(),
+                                                       off.data(), used.data(), st.data());
+        if (s == GF_ERR_CAPACITY) {
+            packs.resize((size_t)off[nTiles] + 64);
+            s = gf_codec_master_encode_batch_i32(c, codecs, nCodecs, nRows, nCols, nTiles, iv, packs.data(), packs.size(),
+                                                 off.data(), used.data(), st.data());
+        }
+        if (s != GF_OK) return s;
+    }
+    uint64_t total = 0;
+    std::vector<uint32_t> elemLen(nTiles);
+    for (size_t t = 0; t < nTiles; t++) {
+        if (st[t] < 0) return (gf_status)st[t];                          // an encoder threw: the Java call fails as a whole
+        const size_t n = st[t] == GF_OK ? (size_t)(off[t + 1] - off[t]) : 0;
+        const bool raw = st[t] != GF_OK || n >= stdSize;
+        if (raw) used[t] = 0xff;
+        elemLen[t] = (uint32_t)(raw ? stdSize : n);
+        offsets[t] = total;
+        total += (8 + elemLen[t] + 12 + 7) & ~(uint64_t)7;              // multipleOf8(content + RECORD_OVERHEAD_SIZE)
+    }
+    offsets[nTiles] = total;
+    if (codecUsed) memcpy(codecUsed, used.data(), nTiles);
+    if (total > blobCap) return GF_ERR_CAPACITY;
+    parallelFor(nTiles, [&](size_t t) {
+        uint8_t *r = blob + offsets[t];
+        const size_t size = (size_t)(offsets[t + 1] - offsets[t]);
+        memset(r, 0, size);
+        putLE32(r, (uint32_t)size);
+        r[4] = 2;                                                      // RecordType.Tile
+        putLE32(r + 8, (uint32_t)tileIndices[t]);
+        putLE32(r + 12, elemLen[t]);
+        if (used[t] != 0xff) memcpy(r + 16, packs.data() + off[t], elemLen[t]);
+        else if (elemType == GF_ELEM_SHORT) memcpy(r + 16, (const int16_t *)values + t * cells, cells * 2);   // little-endian host
+        else memcpy(r + 16, (const int32_t *)values + t * cells, cells * 4);
+        if (checksumEnabled) putLE32(r + size - 4, gf_crc32c(r, size - 4));
+    });
+    return GF_OK;
+}
+
+// RecordManager.readTile (gvrs/RecordManager.java:472-520) + TileElementInt.decode / TileElementShort.decode for a batch of
+// tile records: status[t] = GF_OK, GF_ERR_FORMAT (not a tile record, checksum mismatch when verifyChecksum != 0, a packing
+// the codecs reject) or GF_ERR_BOUNDS (lengths that do not fit the record).
+gf_status gf_tile_record_decode_batch(gf_context *c, const int *codecs, int nCodecs, int elemType, int nRows, int nCols,
+                                      size_t nTiles, const uint8_t *blob, const uint64_t *offsets, int verifyChecksum,
+                                      int32_t *tileIndices, void *values, int32_t *status)
+{
+    if (!c || !blob || !offsets || !values) return GF_ERR_ARG;
+    if (elemType != GF_ELEM_INT && elemType != GF_ELEM_SHORT) return GF_ERR_ARG;
+    if (nRows < 1 || nCols < 1) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols, stdSize = elemStandardSize(elemType, cells);
+    std::vector<int32_t> st(nTiles, GF_OK);
+    std::vector<uint8_t> isRaw(nTiles, 0);
+    std::vector<uint64_t> off(nTiles + 1, 0);
+    std::vector<uint32_t> elemAt(nTiles, 0), elemLen(nTiles, 0);
+    for (size_t t = 0; t < nTiles; t++) {
+        off[t + 1] = off[t];
+        const uint8_t *r = blob + offsets[t];
+        const size_t len = (size_t)(offsets[t + 1] - offsets[t]);
+        if (len < 20) { st[t] = GF_ERR_BOUNDS; continue; }
+        const size_t size = getLE32(r);
+        if (size > len || size < 20 || (size & 7)) { st[t] = GF_ERR_BOUNDS; continue; }
+        if (r[4] != 2) { st[t] = GF_ERR_FORMAT; continue; }
+        if (tileIndices) tileIndices[t] = (int32_t)getLE32(r + 8);
+        const size_t n = getLE32(r + 12);
+        if (16 + n > size) { st[t] = GF_ERR_BOUNDS; continue; }
+        elemAt[t] = 16;
+        elemLen[t] = (uint32_t)n;
+        if (n == stdSize) isRaw[t] = 1;
+        else off[t + 1] = off[t] + n;
+    }
+    if (verifyChecksum) {
+        parallelFor(nTiles, [&](size_t t) {
+            if (st[t] != GF_OK) return;
+            const uint8_t *r = blob + offsets[t];
+            const size_t size = getLE32(r);
+            if (getLE32(r + size - 4) != gf_crc32c(r, size - 4)) st[t] = GF_ERR_FORMAT;
+        });
+    }
+    std::vector<uint8_t> sub((size_t)off[nTiles] + 16);
+    for (size_t t = 0; t < nTiles; t++)
+        if (st[t] == GF_OK && !isRaw[t]) memcpy(sub.data() + off[t], blob + offsets[t] + elemAt[t], elemLen[t]);
+    std::vector<int32_t> out, dst(nTiles, GF_OK);
+    if (off[nTiles] > 0 && nCodecs < 1) {
+        for (size_t t = 0; t < nTiles; t++)
+            if (st[t] == GF_OK && !isRaw[t]) dst[t] = GF_ERR_FORMAT;   // a packing in a file without codecs
+    } else if (off[nTiles] > 0) {
+        out.resize(nTiles * cells);
+        gf_status s = gf_codec_master_decode_batch_i32(c, codecs, nCodecs, nRows, nCols, nTiles, sub.data(), off.data(), out.data(),
+                                                       dst.data());
+        if (s != GF_OK) return s;
+    }
+    parallelFor(nTiles, [&](size_t t) {
+        if (st[t] != GF_OK) return;
+        const uint8_t *e = blob + offsets[t] + elemAt[t];
+        if (elemType == GF_ELEM_SHORT) {
+            int16_t *o = (int16_t *)values + t * cells;
+            if (isRaw[t]) { memcpy(o, e, cells * 2); return; }
+            if (dst[t] != GF_OK) { st[t] = dst[t]; return; }
+            const int32_t *d = out.data() + t * cells;                  // TileElementShort.java:239-246
+            for (size_t i = 0; i < cells; i++) o[i] = d[i] == (int32_t)0x80000000 ? (int16_t)-32768 : (int16_t)d[i];
+        } else {
+            int32_t *o = (int32_t *)values + t * cells;
+            if (isRaw[t]) { memcpy(o, e, cells * 4); return; }
+            if (dst[t] != GF_OK) { st[t] = dst[t]; return; }
+            memcpy(o, out.data() + t * cells, cells * 4);
+        }
+    });
     if (status) memcpy(status, st.data(), nTiles * 4);
     return GF_OK;
 }

@@ -265,6 +265,26 @@ gf_status gf_tile_payload_decode_batch_i32(gf_context *ctx, const int *codecs, i
                                            size_t n_tiles, const uint8_t *blob, const uint64_t *offsets, int32_t *values,
                                            int32_t *status);
 
+/* ---- tile records (gvrs/RecordManager.java:153-204, 217-262, 386-520; gvrs/TileElementInt.java:196-219,
+ * gvrs/TileElementShort.java:211-250; util/GridfourCRC32C.java): what RecordManager.writeTile appends to the file for a
+ * tile of one integer-coded element, for a whole batch of dirty tiles in one call (flush()):
+ *   [int32 LE size, multiple of 8][type 2][0 0 0][int32 tileIndex][int32 n][n element bytes][zeros][CRC-32C | 0]
+ * element bytes = CodecMaster packing, or the standard (raw little-endian) form when no codec is listed / produced a
+ * packing / it is not shorter (codec_used[t] = 255).  GF_ELEM_SHORT: values are int16, widened with fill_value mapped to
+ * INT4_NULL_CODE for the codecs; on decode INT4_NULL_CODE comes back as -32768 (TileElementShort.java:241-243).
+ * Reproduces the tile records of the reference's sample files byte for byte (tests/test_gpu_records.py).             */
+#define GF_ELEM_INT 0
+#define GF_ELEM_SHORT 1
+size_t gf_tile_record_max_bytes(int elem_type, int n_rows, int n_cols);
+uint32_t gf_crc32c(const uint8_t *data, size_t n);
+gf_status gf_tile_record_encode_batch(gf_context *ctx, const int *codecs, int n_codecs, int elem_type, int fill_value,
+                                      int n_rows, int n_cols, size_t n_tiles, const int32_t *tile_indices, const void *values,
+                                      int checksum_enabled, uint8_t *blob, size_t blob_cap, uint64_t *offsets,
+                                      uint8_t *codec_used);
+gf_status gf_tile_record_decode_batch(gf_context *ctx, const int *codecs, int n_codecs, int elem_type, int n_rows, int n_cols,
+                                      size_t n_tiles, const uint8_t *blob, const uint64_t *offsets, int verify_checksum,
+                                      int32_t *tile_indices, void *values, int32_t *status);
+
 /* ---- CodecFloat (compress/CodecFloat.java:328-458): float32 tiles ---------------------------
  * The five byte planes (sign bits, exponent, three byte-delta coded mantissa bytes) are split and
  * merged on the GPU; the Deflate stage of each plane runs on the host's zlib (its bytes are defined

@@ -64,3 +64,18 @@ def test_shard_range_partitions_exactly():
                 assert lo == seen
                 seen += cnt
             assert seen == n
+
+
+def test_crc32c_known_answers(golden_dir):
+    """gf_crc32c (host-side, used for the record checksums) against the CRC-32C check value and against the checksum the
+    reference stored in the header record of one of its sample files (util/GridfourCRC32C.java)."""
+    import ctypes as C
+    import os
+    import struct
+    from gridfour_amd._lib import lib
+    msg = b"123456789"
+    assert lib().gf_crc32c(C.c_char_p(msg), len(msg)) == 0xE3069283
+    data = open(os.path.join(golden_dir, "ref_samples", "Sample05_IntComp.gvrs"), "rb").read()
+    (size,) = struct.unpack_from("<i", data, 16)
+    rec = data[16:16 + size]
+    assert lib().gf_crc32c(C.c_char_p(rec[:size - 4]), size - 4) == struct.unpack_from("<I", rec, size - 4)[0]
