@@ -10,6 +10,7 @@
 #include <jni.h>
 
 #include <mutex>
+#include <vector>
 
 #include "gvrs_hip_codec.h"
 
@@ -176,6 +177,76 @@ JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_HipCodecNative_decode(JNIEnv *
         return nullptr;
     }
     return result;
+}
+
+// byte[] tileRecords(long handle, int[] codecKinds, int elemType, int fillValue, int nRows, int nCols, int[] tileIndices,
+//                    Object cells, boolean checksums, long[] recordOffsets)
+JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_tileRecords(JNIEnv *env, jclass, jlong handle, jintArray codecKinds,
+                                                                              jint elemType, jint fillValue, jint nRows, jint nCols,
+                                                                              jintArray tileIndices, jobject cells, jboolean checksums,
+                                                                              jlongArray recordOffsets)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    const jsize nTiles = env->GetArrayLength(tileIndices), nCodecs = env->GetArrayLength(codecKinds);
+    if (env->GetArrayLength(recordOffsets) < nTiles + 1) return nullptr;
+    const size_t cap = (size_t)nTiles * gf_tile_record_max_bytes(elemType, nRows, nCols);
+    std::vector<uint8_t> blob(cap ? cap : 8);
+    std::vector<uint64_t> offsets((size_t)nTiles + 1);
+    std::vector<int> kinds((size_t)nCodecs + 1);
+    env->GetIntArrayRegion(codecKinds, 0, nCodecs, (jint *)kinds.data());
+    std::vector<int32_t> idx((size_t)nTiles + 1);
+    env->GetIntArrayRegion(tileIndices, 0, nTiles, (jint *)idx.data());
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        void *v = env->GetPrimitiveArrayCritical((jarray)cells, nullptr);
+        s = gf_tile_record_encode_batch(h->ctx, kinds.data(), nCodecs, elemType, fillValue, nRows, nCols, (size_t)nTiles, idx.data(), v,
+                                        checksums ? 1 : 0, blob.data(), cap, offsets.data(), nullptr);
+        env->ReleasePrimitiveArrayCritical((jarray)cells, v, JNI_ABORT);
+    }
+    if (s != GF_OK) {
+        jclass c = env->FindClass("java/io/IOException");
+        if (c) env->ThrowNew(c, gf_last_error());
+        return nullptr;
+    }
+    env->SetLongArrayRegion(recordOffsets, 0, nTiles + 1, (const jlong *)offsets.data());
+    jbyteArray result = env->NewByteArray((jsize)offsets[nTiles]);
+    if (result) env->SetByteArrayRegion(result, 0, (jsize)offsets[nTiles], (const jbyte *)blob.data());
+    return result;
+}
+
+// void tilesFromRecords(long handle, int[] codecKinds, int elemType, int nRows, int nCols, byte[] records, long[] recordOffsets,
+//                       boolean verifyChecksums, int[] tileIndices, Object cells, int[] status)
+JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_tilesFromRecords(JNIEnv *env, jclass, jlong handle, jintArray codecKinds,
+                                                                             jint elemType, jint nRows, jint nCols, jbyteArray records,
+                                                                             jlongArray recordOffsets, jboolean verifyChecksums,
+                                                                             jintArray tileIndices, jobject cells, jintArray status)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    const jsize nTiles = env->GetArrayLength(tileIndices), nCodecs = env->GetArrayLength(codecKinds);
+    std::vector<int> kinds((size_t)nCodecs + 1);
+    env->GetIntArrayRegion(codecKinds, 0, nCodecs, (jint *)kinds.data());
+    std::vector<uint64_t> offsets((size_t)nTiles + 1);
+    env->GetLongArrayRegion(recordOffsets, 0, nTiles + 1, (jlong *)offsets.data());
+    std::vector<int32_t> idx((size_t)nTiles + 1), st((size_t)nTiles + 1);
+    const jsize len = env->GetArrayLength(records);
+    std::vector<uint8_t> blob((size_t)len + 16);
+    env->GetByteArrayRegion(records, 0, len, (jbyte *)blob.data());
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        void *v = env->GetPrimitiveArrayCritical((jarray)cells, nullptr);
+        s = gf_tile_record_decode_batch(h->ctx, kinds.data(), nCodecs, elemType, nRows, nCols, (size_t)nTiles, blob.data(), offsets.data(),
+                                        verifyChecksums ? 1 : 0, idx.data(), v, st.data());
+        env->ReleasePrimitiveArrayCritical((jarray)cells, v, 0);
+    }
+    if (s != GF_OK) {
+        jclass c = env->FindClass("java/io/IOException");
+        if (c) env->ThrowNew(c, gf_last_error());
+        return;
+    }
+    env->SetIntArrayRegion(tileIndices, 0, nTiles, (const jint *)idx.data());
+    env->SetIntArrayRegion(status, 0, nTiles, (const jint *)st.data());
 }
 
 }  // extern "C"

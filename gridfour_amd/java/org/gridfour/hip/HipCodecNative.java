@@ -17,6 +17,22 @@ final class HipCodecNative {
   static native byte[] encode(long handle, int kind, int codecIndex, int nRows, int nCols, int[] values);
   static native int[] decode(long handle, int kind, int nRows, int nColumns, byte[] packing) throws IOException;
 
+  /**
+   * All dirty tiles of a flush in one call (RecordManager.writeTile framing, gf_tile_record_encode_batch):
+   * codecKinds lists the file's codecs in CodecMaster order (GF_CODEC_* of the C header; empty when compression
+   * is off); cells holds nTiles x nRows x nCols values (int[] or short[], elemType 0 / 1); recordOffsets receives
+   * nTiles + 1 offsets into the returned bytes, which are the finished tile records, ready to append to the file.
+   */
+  static native byte[] tileRecords(long handle, int[] codecKinds, int elemType, int fillValue, int nRows, int nCols,
+    int[] tileIndices, Object cells, boolean checksums, long[] recordOffsets) throws IOException;
+
+  /**
+   * The read side (RecordManager.readTile for a batch, gf_tile_record_decode_batch): records back to tile indices
+   * and cells; status[t] != 0 marks a record that the reference would have rejected with an IOException.
+   */
+  static native void tilesFromRecords(long handle, int[] codecKinds, int elemType, int nRows, int nCols, byte[] records,
+    long[] recordOffsets, boolean verifyChecksums, int[] tileIndices, Object cells, int[] status) throws IOException;
+
   private HipCodecNative() {
   }
 }
