@@ -60,6 +60,12 @@ class GvrsHipContext:
             pass
 
 
+# struct gf_codec_stats (include/gvrs_hip_codec.h) = the sums of compress/CodecStats.java
+CODEC_STATS_DTYPE = np.dtype([("n_tiles", "<i8"), ("n_bytes", "<i8"), ("n_symbols", "<i8"), ("n_bits_overhead", "<i8"),
+                              ("n_m32_counted", "<i8"), ("sum_length_m32", "<i8"), ("sum_observed_m32", "<i8"),
+                              ("sum_entropy_m32", "<f8")])
+
+
 class CodecHuffmanHip:
     """Drop-in for org.gridfour.compress.CodecHuffman, computed on the MI355X."""
 
@@ -110,6 +116,54 @@ class CodecHuffmanHip:
 
     def decodeFloats(self, nRows, nColumns, packing):
         return None                                  # CodecHuffman.java:242-244
+
+    # ---- analysis (CodecHuffman.java:172-234 over CodecStats.java) ----
+    _STAT_LABELS = ("None", "Differencing", "Linear", "Triangle", "DifferencingWithNulls", "All Predictors")
+
+    def analyze(self, nRows, nColumns, packing):
+        st = self.analyze_batch(nRows, nColumns, [packing])
+        if st[0] != 0:
+            raise IOError(lib().gf_status_string(int(st[0])).decode())
+
+    def analyze_batch(self, nRows, nCols, packings):
+        """analyze() of every packing in one GPU pass; returns the per-packing status (non-zero: analyze would throw)."""
+        if self._PREFIX != "gf_huffman":
+            raise NotImplementedError("statistics are gathered for CodecHuffman only")
+        if getattr(self, "_stats", None) is None:
+            self._stats = np.zeros(6, dtype=CODEC_STATS_DTYPE)
+        nt = len(packings)
+        offsets = np.zeros(nt + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(p) for p in packings])
+        blob = np.frombuffer(b"".join(packings) + b"\0" * 16, dtype=np.uint8)
+        status = np.zeros(nt, np.int32)
+        check(lib().gf_huffman_analyze_batch(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets), _ptr(self._stats),
+                                             _ptr(status)), "gf_huffman_analyze_batch")
+        return status
+
+    def analysis_data(self):
+        """The accumulated sums, one record per predictor code 0..4 and one for all (CodecStats fields)."""
+        s = getattr(self, "_stats", None)
+        return None if s is None else s.copy()
+
+    def reportAnalysisData(self, ps, nTilesInRaster):
+        ps.write("Gridfour_Huffman                               Compressed Output    |       Predictor Residuals\n")
+        s = getattr(self, "_stats", None)
+        if s is None or nTilesInRaster == 0:
+            ps.write("   Tiles Compressed:  0\n")
+            return
+        ps.write("  Predictor                Times Used        bits/sym    bits/tile  |  m32 avg-len   avg-unique  entropy | bits in tree\n")
+        for label, r in zip(self._STAT_LABELS, s):
+            if label == "None":
+                continue
+            n, nm = int(r["n_tiles"]), int(r["n_m32_counted"])
+            bits_per_symbol = 8.0 * r["n_bytes"] / r["n_symbols"] if r["n_symbols"] else 0.0
+            ps.write("   %-20.20s %8d (%4.1f %%)     %5.2f  %12.1f   | %10.1f      %6.1f    %6.2f   | %6.1f\n" % (
+                label, n, 100.0 * n / nTilesInRaster, bits_per_symbol, (r["n_bytes"] / n * 8 if n else 0.0),
+                (r["sum_length_m32"] / nm if nm else 0.0), (r["sum_observed_m32"] / n if n else 0.0),
+                (r["sum_entropy_m32"] / nm if nm else 0.0), (r["n_bits_overhead"] / n if n else 0.0)))
+
+    def clearAnalysisData(self):
+        self._stats = None
 
     # ---- batched forms (host memory) ----
     def encode_batch(self, codecIndex, nRows, nCols, tiles):

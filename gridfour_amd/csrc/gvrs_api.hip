@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -258,7 +259,7 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
 
 static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
                                 const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets, size_t slotStride,
-                                const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus)
+                                const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus, uint32_t *analysis = nullptr)
 {
     if (!c || nRows < 1 || nCols < 1 || !dBlob || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
@@ -287,6 +288,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     a.phaseLimit = g_decPhaseLimit;
     a.debug = g_decodeDebug;
     a.rawM32 = kind == KIND_RAW_M32 ? 1 : 0;
+    a.analysis = analysis;
     if (kind == KIND_CANON) {
         a.ldsM32Bytes = 0;
         a.ldsTextBytes = gf_canon_decode_lds_text(nRows, nCols);
@@ -1770,6 +1772,80 @@ gf_status gf_tile_record_decode_batch(gf_context *c, const int *codecs, int nCod
         }
     });
     if (status) memcpy(status, st.data(), nTiles * 4);
+    return GF_OK;
+}
+
+// ------------------------------------------------------------------ CodecHuffman.analyze
+
+// ICompressionDecoder.analyze for a batch of CodecHuffman packings (compress/CodecHuffman.java:172-199): the packings are
+// Huffman-decoded on the GPU, which returns per tile the predictor, the M32 byte count, the bits of the serialised tree and
+// the 256-bin histogram of the M32 bytes; the sums of CodecStats.addToCounts / addCountsForM32 (compress/CodecStats.java:
+// 100-141) are then accumulated here in tile order.  stats[p], p = 0..4 by predictor code (PredictorModelType ordinal),
+// stats[5] = "All Predictors"; counts ADD to what stats already holds (clearAnalysisData = zero the array).  The pair
+// counts behind CodecStats.getH2 (not part of reportAnalysisData) are not collected.
+gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob, const uint64_t *offsets,
+                                   gf_codec_stats *stats, int32_t *status)
+{
+    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !stats) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    const uint64_t total = offsets[nTiles];
+    gf_status s;
+    if ((s = c->dBlob.ensure(total + 32)) != GF_OK) return s;
+    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
+    if ((s = c->dResiduals.ensure(nTiles * GF_ANALYSIS_WORDS * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dValues.ensure(16)) != GF_OK) return s;
+    std::vector<uint32_t> lengths(nTiles);
+    for (size_t t = 0; t < nTiles; t++) {
+        if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
+        lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
+    }
+    GF_HIP(hipMemcpyAsync(c->dBlob.p, blob, total, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dOffsets.p, offsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
+    s = decodeBatchDev(KIND_HUFFMAN, c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total,
+                       (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p, (int32_t *)c->dValues.p,
+                       (int32_t *)c->dStatus.p, (uint32_t *)c->dResiduals.p);
+    if (s != GF_OK) return s;
+    std::vector<uint32_t> rec(nTiles * GF_ANALYSIS_WORDS);
+    std::vector<int32_t> st(nTiles);
+    GF_HIP(hipMemcpyAsync(rec.data(), c->dResiduals.p, rec.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+    GF_HIP(hipStreamSynchronize(c->stream));
+    const double LOG2 = std::log(2.0);
+    const int64_t nValues = (int64_t)nRows * nCols;
+    for (size_t t = 0; t < nTiles; t++) {
+        if (status) status[t] = st[t];
+        if (st[t] != GF_OK) continue;                                   // analyze throws: nothing is counted
+        const uint32_t *r = rec.data() + t * GF_ANALYSIS_WORDS;
+        const uint32_t nM32 = r[1];
+        int64_t observed = 0;
+        double e = 0;
+        if (nM32 > 0) {
+            const double d = (double)nM32;
+            for (int i = 0; i < 256; i++) {
+                if (r[4 + i] > 0) {
+                    observed++;
+                    const double p = r[4 + i] / d;
+                    e += p * std::log(p) / LOG2;
+                }
+            }
+        }
+        gf_codec_stats *two[2] = {&stats[r[0] <= 4 ? r[0] : 0], &stats[5]};
+        for (gf_codec_stats *g : two) {
+            g->n_tiles++;
+            g->n_bytes += r[3];
+            g->n_symbols += nValues;
+            g->n_bits_overhead += r[2];
+            if (nM32 > 0) {
+                g->n_m32_counted++;
+                g->sum_length_m32 += nM32;
+                g->sum_observed_m32 += observed;
+                g->sum_entropy_m32 -= e;
+            }
+        }
+    }
     return GF_OK;
 }
 

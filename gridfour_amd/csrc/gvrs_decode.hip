@@ -906,6 +906,25 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
             if (tileStatus != GF_K_OK) return tileStatus;
             GF_DSTAMP(5);
             if ((a.phaseLimit & 0xff) == 2) return (int32_t)GF_K_SKIP;
+            if (a.analysis) {
+                // CodecHuffman.analyze (CodecHuffman.java:172-199): what CodecStats.addToCounts / addCountsForM32 consume
+                uint32_t *hist = S.lut;                                  // the lookup table is no longer needed
+                for (uint32_t i = tid; i < 256; i += DEC_THREADS) hist[i] = 0;
+                __syncthreads();
+                for (uint32_t i = tid; i < nM32; i += DEC_THREADS) atomicAdd(&hist[m32[i]], 1u);
+                __syncthreads();
+                uint32_t *rec = a.analysis + t * GF_ANALYSIS_WORDS;
+                if (tid == 0) {
+                    rec[0] = (uint32_t)model;
+                    rec[1] = nM32;
+                    rec[2] = S.textStart - 80u;                          // HuffmanDecoder.getBitsInTreeCount
+                    rec[3] = len - 10u;
+                    a.status[t] = GF_K_OK;
+                }
+                for (uint32_t i = tid; i < 256; i += DEC_THREADS) rec[4 + i] = hist[i];
+                __syncthreads();
+                return (int32_t)GF_K_SKIP;
+            }
 
             // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
             {

@@ -47,7 +47,10 @@ struct GfDecodeArgs {
     int phaseLimit;            // diagnostic: stop after phase 0/1/2 (value 1/2/3); 0 = run everything
     uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
     int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
+    uint32_t *analysis;        // non-null: CodecHuffman.analyze mode -- per tile GF_ANALYSIS_WORDS words (predictor, nM32,
+                               // bits in tree, packing bytes - 10, 256-bin histogram of the M32 bytes); no values are written
 };
+constexpr int GF_ANALYSIS_WORDS = 260;
 
 // LSOP12 containers whose entropy stage is CodecM32 bytes: type 0 (legacy Huffman of the two M32 streams) and, with
 // rawM32 = 1, type 1 after the host inflated it (gvrs_decode.hip: k_lsop_unpack_m32)

@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -89,22 +90,44 @@ public:
     }
     std::optional<std::vector<float>> decodeFloats(int, int, const std::vector<uint8_t> &) override { return std::nullopt; }
 
-    // statistics (CodecHuffman.java:172-234): kept on the host, fed by the packing headers only
-    void analyze(int, int, const std::vector<uint8_t> &packing) override
+    // statistics (CodecHuffman.java:172-234 over CodecStats.java): the packing is Huffman-decoded and its M32 bytes are
+    // histogrammed on the GPU (gf_huffman_analyze_batch); the sums live here
+    void analyze(int nRows, int nColumns, const std::vector<uint8_t> &packing) override
     {
-        if (packing.size() < 10) throw IOException("short packing");
-        const unsigned p = packing[1];
-        if (p < 5) { tiles_[p]++; bytes_[p] += packing.size() - 10; }
+        const uint64_t offsets[2] = {0, packing.size()};
+        std::vector<uint8_t> padded(packing);
+        padded.resize(packing.size() + 16);
+        int32_t st = 0;
+        check(gf_huffman_analyze_batch(ctx_, nRows, nColumns, 1, padded.data(), offsets, stats_, &st), "gf_huffman_analyze_batch");
+        if (st != GF_OK) throw IOException(gf_status_string((gf_status)st));
     }
+    // analyze() of a whole batch in one GPU pass; returns the per-packing status
+    std::vector<int32_t> analyzeBatch(int nRows, int nColumns, size_t nTiles, const uint8_t *blob, const uint64_t *offsets)
+    {
+        std::vector<int32_t> st(nTiles);
+        check(gf_huffman_analyze_batch(ctx_, nRows, nColumns, nTiles, blob, offsets, stats_, st.data()), "gf_huffman_analyze_batch");
+        return st;
+    }
+    const gf_codec_stats *analysisData() const { return stats_; }
     void reportAnalysisData(std::FILE *ps, int nTilesInRaster) override
     {
-        std::fprintf(ps, "Gridfour_Huffman (HIP)\n");
-        static const char *names[5] = {"None", "Differencing", "Linear", "Triangle", "DifferencingWithNulls"};
-        for (int p = 1; p < 5; p++)
-            std::fprintf(ps, "   %-22s %8ld (%4.1f %%)  %12.1f bytes/tile\n", names[p], tiles_[p],
-                         nTilesInRaster ? 100.0 * tiles_[p] / nTilesInRaster : 0.0, tiles_[p] ? (double)bytes_[p] / tiles_[p] : 0.0);
+        std::fprintf(ps, "Gridfour_Huffman                               Compressed Output    |       Predictor Residuals\n");
+        if (stats_[5].n_tiles == 0 || nTilesInRaster == 0) {
+            std::fprintf(ps, "   Tiles Compressed:  0\n");
+            return;
+        }
+        std::fprintf(ps, "  Predictor                Times Used        bits/sym    bits/tile  |  m32 avg-len   avg-unique  entropy | bits in tree\n");
+        static const char *names[6] = {"None", "Differencing", "Linear", "Triangle", "DifferencingWithNulls", "All Predictors"};
+        for (int p = 1; p < 6; p++) {
+            const gf_codec_stats &r = stats_[p];
+            const double n = (double)r.n_tiles, nm = (double)r.n_m32_counted;
+            std::fprintf(ps, "   %-20.20s %8ld (%4.1f %%)     %5.2f  %12.1f   | %10.1f      %6.1f    %6.2f   | %6.1f\n", names[p],
+                         (long)r.n_tiles, 100.0 * n / nTilesInRaster, r.n_symbols ? 8.0 * r.n_bytes / r.n_symbols : 0.0,
+                         n ? r.n_bytes / n * 8 : 0.0, nm ? r.sum_length_m32 / nm : 0.0, n ? r.sum_observed_m32 / n : 0.0,
+                         nm ? r.sum_entropy_m32 / nm : 0.0, n ? r.n_bits_overhead / n : 0.0);
+        }
     }
-    void clearAnalysisData() override { for (int p = 0; p < 5; p++) tiles_[p] = bytes_[p] = 0; }
+    void clearAnalysisData() override { std::memset(stats_, 0, sizeof stats_); }
 
     // ---- batched forms: what the GPU is for (one launch per batch, not per tile) ----
     struct Batch {
@@ -150,8 +173,7 @@ private:
         if (s < 0) throw std::runtime_error(std::string(where) + ": " + gf_status_string(s) + " [" + gf_last_error() + "]");
     }
     gf_context *ctx_ = nullptr;
-    long tiles_[5] = {0, 0, 0, 0, 0};
-    long bytes_[5] = {0, 0, 0, 0, 0};
+    gf_codec_stats stats_[6] = {};          // by predictor code 0..4, [5] = all predictors
 };
 
 /** Drop-in for org.gridfour.compress.CodecFloat (CodecFloat.java:328-458): byte planes on the GPU,

@@ -265,6 +265,25 @@ gf_status gf_tile_payload_decode_batch_i32(gf_context *ctx, const int *codecs, i
                                            size_t n_tiles, const uint8_t *blob, const uint64_t *offsets, int32_t *values,
                                            int32_t *status);
 
+/* ---- ICompressionDecoder.analyze for CodecHuffman (compress/CodecHuffman.java:172-234, compress/CodecStats.java:49-290):
+ * the per-predictor statistics the reference gathers by decoding every packing on the CPU, from a GPU pass that
+ * Huffman-decodes the batch and histograms the M32 bytes.  stats[0..4] by predictor code (None, Differencing, Linear,
+ * Triangle, DifferencingWithNulls), stats[5] = "All Predictors"; the call ADDS to stats (zero it = clearAnalysisData).
+ * The getters of CodecStats are ratios of these sums: bits/symbol = 8 n_bytes / n_symbols, entropy = sum_entropy_m32 /
+ * n_m32_counted, ... (CodecStats.java:196-290).  status[t] != GF_OK: the reference's analyze would throw; not counted. */
+typedef struct gf_codec_stats {
+    int64_t n_tiles;          /* nTilesCounted      */
+    int64_t n_bytes;          /* nBytesTotal        : packing bytes - 10 */
+    int64_t n_symbols;        /* nSymbolsTotal      : cells */
+    int64_t n_bits_overhead;  /* nBitsOverheadTotal : bits of the serialised Huffman tree */
+    int64_t n_m32_counted;    /* nM32Counted        */
+    int64_t sum_length_m32;   /* sumLengthM32       */
+    int64_t sum_observed_m32; /* sumObservedM32     : distinct M32 byte values per tile, summed */
+    double sum_entropy_m32;   /* sumEntropyM32      : zero-order entropy of the M32 bytes per tile, summed */
+} gf_codec_stats;
+gf_status gf_huffman_analyze_batch(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                   const uint64_t *offsets, gf_codec_stats *stats, int32_t *status);
+
 /* ---- tile records (gvrs/RecordManager.java:153-204, 217-262, 386-520; gvrs/TileElementInt.java:196-219,
  * gvrs/TileElementShort.java:211-250; util/GridfourCRC32C.java): what RecordManager.writeTile appends to the file for a
  * tile of one integer-coded element, for a whole batch of dirty tiles in one call (flush()):
