@@ -288,7 +288,7 @@ __device__ __forceinline__ void step2(M32Cursor &c0, bool r0, uint32_t, uint32_t
 // Starts are then checked against the predecessor's end; only a mismatch (rare) marks a
 // subsequence dirty for another, barrier-synchronised, round.  Every thread owns subsequences
 // tid and tid + DEC_THREADS and advances them in lockstep (their lookups overlap).
-template <class Cursor>
+template <int OWNER, class Cursor>                 // OWNER: see huffman_to_m32
 __device__ void resolve_chain(DecShared &S, Cursor cur, uint32_t start, uint32_t end, uint32_t unit, uint32_t Q,
                               uint32_t warm, uint32_t *dbg = nullptr)
 {
@@ -365,8 +365,10 @@ __device__ void resolve_chain(DecShared &S, Cursor cur, uint32_t start, uint32_t
     __syncthreads();
 }
 
-// phase 1 body: Huffman text -> nM32 bytes at m32; returns GF_K_OK or the Java error it mirrors
-template <class TextPtr>
+// phase 1 body: Huffman text -> nM32 bytes at m32; returns GF_K_OK or the Java error it mirrors.  OWNER: one copy per
+// kernel -- the function is not inlined, and a copy shared between kernels loses the address-space knowledge the compiler
+// propagates from a single caller (flat accesses and pointer tests on the per-symbol path; measured 2.01 -> 2.10 ms)
+template <int OWNER, class TextPtr>
 __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32_t textStart, uint32_t endBit,
                                   uint32_t nM32, uint8_t *m32, uint32_t *dbg, uint32_t warmBits)
 {
@@ -376,7 +378,7 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
     uint32_t unit = (textBits + MAXQ - 1) / MAXQ;
     unit = max(128u, (unit + 31u) & ~31u);
     const uint32_t Q = max(1u, (textBits + unit - 1) / unit);
-    resolve_chain(S, cur, textStart, endBit, unit, Q, warmBits, dbg);   // warm-up: 128 bits = about 25 symbols by default
+    resolve_chain<OWNER>(S, cur, textStart, endBit, unit, Q, warmBits, dbg);   // warm-up: 128 bits = about 25 symbols by default
     if (dbg && tid == 0) dbg[-7] = (uint32_t)__builtin_amdgcn_s_memtime();      // stamp 4
     if (S.chainTotal < nM32) status = GF_K_ERR_BOUNDS;                   // ran out of bits
     if (tid == 0) S.chainEnd = 0;
@@ -672,7 +674,7 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
         uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
         unit = max(16u, unit);
         const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
-        resolve_chain(S, cur, 0u, nM32, unit, Q, 8u, stamps ? stamps + 13 : nullptr);   // warm-up: 8 bytes
+        resolve_chain<0>(S, cur, 0u, nM32, unit, Q, 8u, stamps ? stamps + 13 : nullptr);   // warm-up: 8 bytes
         for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
             const uint32_t limit = min(nM32, (q + 1) * unit);
             M32Cursor c = cur;
@@ -776,6 +778,9 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
     } while (0)
 
 
+// ANALYZE: CodecHuffman.analyze mode (statistics instead of values); a separate instantiation so that the decode proper
+// keeps its register allocation
+template <bool ANALYZE>
 __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                     cur.sh0 = sh0;
                     cur.S = &S;
                     cur.lut2 = lut2;
-                    tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                    tileStatus = huffman_to_m32<ANALYZE ? 1 : 0>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
                 } else {
                     HuffCursorT<const uint32_t *> cur;
                     cur.base32 = w32 + baseWord;
@@ -900,13 +905,13 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
                     cur.sh0 = sh0;
                     cur.S = &S;
                     cur.lut2 = lut2;
-                    tileStatus = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                    tileStatus = huffman_to_m32<ANALYZE ? 1 : 0>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
                 }
             }
             if (tileStatus != GF_K_OK) return tileStatus;
             GF_DSTAMP(5);
             if ((a.phaseLimit & 0xff) == 2) return (int32_t)GF_K_SKIP;
-            if (a.analysis) {
+            if constexpr (ANALYZE) {
                 // CodecHuffman.analyze (CodecHuffman.java:172-199): what CodecStats.addToCounts / addCountsForM32 consume
                 uint32_t *hist = S.lut;                                  // the lookup table is no longer needed
                 for (uint32_t i = tid; i < 256; i += DEC_THREADS) hist[i] = 0;
@@ -1064,7 +1069,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
                         cur.sh0 = (uint32_t)(off * 8ull) & 31u;
                         cur.S = &S;
                         cur.lut2 = lut2;
-                        const int32_t st = huffman_to_m32(S, cur, textStart, endBit, nM32, m32, nullptr, 128u);
+                        const int32_t st = huffman_to_m32<2>(S, cur, textStart, endBit, nM32, m32, nullptr, 128u);
                         if (st != GF_K_OK) return st;
                         if (nM32 == 0 && tid == 0) S.chainEnd = textStart;
                         __syncthreads();
@@ -1127,12 +1132,16 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
     const size_t dyn = decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
     static size_t maxDynSet = 0;                   // dynamic LDS beyond the default limit must be opted into
     if (dyn > maxDynSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_decode),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_decode<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_decode<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         if (e != hipSuccess) return e;
         maxDynSet = dyn;
     }
-    hipLaunchKernelGGL(k_huffman_decode, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    if (a.analysis) hipLaunchKernelGGL(k_huffman_decode<true>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    else hipLaunchKernelGGL(k_huffman_decode<false>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Regenerates the judged artifacts of a round on the GPU box: full GPU test suite, smoke, bench lines of every codec,
+# rocprofv3 kernel statistics of the default bench command, HBM traffic (PMC passes).
+# usage: tools/round_artifacts.sh <tag>        (writes gpurun_out/<tag>/)
+TAG=${1:-r01_vX}
+OUT=gpurun_out/$TAG
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p $OUT
+timeout 1200 python3 -m pytest tests -m gpu -q -rs > $OUT/pytest_gpu.txt 2>&1; tail -5 $OUT/pytest_gpu.txt
+timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
+timeout 600 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench.json
+timeout 600 python3 bench.py --cpu-all-cores 2>/dev/null | tail -1 > $OUT/bench_allcores.json
+timeout 600 python3 bench.py --codec canon 2>/dev/null | tail -1 > $OUT/bench_canon.json
+timeout 600 python3 bench.py --codec lsop 2>/dev/null | tail -1 > $OUT/bench_lsop.json
+timeout 600 python3 bench.py --workload dem1024 2>/dev/null | tail -1 > $OUT/bench_dem1024.json
+timeout 600 python3 bench.py --workload gebco_shard --cpu-sample-tiles 0 2>/dev/null | tail -1 > $OUT/bench_gebco_shard.json
+timeout 600 python3 bench.py --codec float --workload float256 2>/dev/null | tail -1 > $OUT/bench_float256.json
+for c in "" canon lsop; do
+  rm -rf $OUT/prof$c
+  if [ -z "$c" ]; then
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --cpu-sample-tiles 0 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.log
+  else
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof$c -- python3 bench.py --codec $c --cpu-sample-tiles 0 > /dev/null 2>> $OUT/rocprof.log
+  fi
+  f=$(find $OUT/prof$c -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/kernel_stats${c:+_$c}.csv
+  rm -rf $OUT/prof$c
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proff -- python3 bench.py --codec float --workload float256 --cpu-sample-tiles 0 > /dev/null 2>> $OUT/rocprof.log
+f=$(find $OUT/proff -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_float.csv; rm -rf $OUT/proff
+bash tools/pmc_hbm.sh $OUT/hbm etopo1 > $OUT/pmc_hbm.txt 2>&1
+cp $OUT/hbm/hbm_traffic.json $OUT/hbm_traffic.json 2>/dev/null
+rm -rf $OUT/hbm/FETCH_SIZE $OUT/hbm/WRITE_SIZE
+head -c 600 $OUT/bench.json; echo; head -5 $OUT/kernel_stats.csv
