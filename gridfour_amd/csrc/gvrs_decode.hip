@@ -416,6 +416,15 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
 }
 
 
+// v_writelane_b32 (this hipcc has no builtin for it): lane `lane` of `old` becomes the wave-uniform `value`
+__device__ __forceinline__ int gf_writelane(int value, int lane, int old)
+{
+    const int sv = __builtin_amdgcn_readfirstlane(value), sl = __builtin_amdgcn_readfirstlane(lane);   // into SGPRs
+    // gfx9: one SGPR per VALU instruction -- the lane select goes through M0
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sv), "s"(sl) : "m0");
+    return old;
+}
+
 // HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161), run by ONE wave.  S.head holds the packing words around the
 // serialised tree; the tree starts at bit relBit of S.head (= bit absBit of the packing, totalBits long).  Leaves go to
 // S.leaf*, sub-table markers to S.lut, the position of the first code to S.textStart.
@@ -467,6 +476,25 @@ __device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, 
         uint32_t L = 1;                                              // the root's left child
         uint32_t leaves = 0, records = 0;
         bool complete = false;
+        // leaf records gather in registers, lane = leaf index mod 64 (v_writelane from the scalar loop), and go to LDS 64
+        // at a time with every lane storing its own: a predicated single-lane LDS store per field and leaf was the
+        // larger part of the loop
+        int recLo = 0, recHi = 0, recLS = 0;
+        auto flush = [&](uint32_t base, uint32_t count) {            // leaves base .. base + count - 1 are in the registers
+            const bool mine = lane < count;
+            const uint32_t len = (uint32_t)recLS >> 8;
+            if (mine) {
+                S.leafCode[base + lane] = ((unsigned long long)(uint32_t)recHi << 32) | (uint32_t)recLo;
+                S.leafLen[base + lane] = (uint8_t)len;
+                S.leafSym[base + lane] = (uint8_t)recLS;
+            }
+            const unsigned long long shortMask = __ballot(mine && len <= 5u);
+            if (mine && len <= 5u) {
+                const uint32_t slot = nShort + (uint32_t)__popcll(shortMask & ((1ull << lane) - 1ull));
+                S.shortLeaf[slot & 63u] = (uint8_t)(base + lane);
+            }
+            nShort += (uint32_t)__popcll(shortMask);
+        };
         while (leaves < nLeaves) {
             refill();
             if (records > 511) { st = GF_K_ERR_BOUNDS; break; }
@@ -494,21 +522,23 @@ __device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, 
             const uint32_t sym = rec >> 1;
             const uint32_t clen = L;
             records++;
-            if (writer) {
-                S.leafCode[leaves] = __brevll(c) >> (64u - L);       // path bits, first step in bit 0
-                S.leafLen[leaves] = (uint8_t)clen;
-                S.leafSym[leaves] = (uint8_t)sym;
-                if (clen <= 5) S.shortLeaf[nShort & 63u] = (uint8_t)leaves;
+            {
+                const unsigned long long path = __brevll(c) >> (64u - L);   // path bits, first step in bit 0
+                const int ln = (int)(leaves & 63u);
+                recLo = gf_writelane((int)(uint32_t)path, ln, recLo);
+                recHi = gf_writelane((int)(uint32_t)(path >> 32), ln, recHi);
+                recLS = gf_writelane((int)((clen << 8) | sym), ln, recLS);
             }
-            if (clen <= 5) nShort++;
             maxLen = max(maxLen, clen);
             leaves++;
+            if ((leaves & 63u) == 0u) flush(leaves - 64u, 64u);
             const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;   // trailing ones
             if (leaves == nLeaves) { complete = t1 >= L; break; }
             if (t1 >= L) { st = GF_K_ERR_BOUNDS; break; }            // tree complete but leaves missing
             c = (c >> t1) | 1ull;
             L -= t1;
         }
+        if (leaves & 63u) flush(leaves & ~63u, leaves & 63u);
         // all leaves read: the tree must be complete (every open branch is on its right child)
         if (st == GF_K_OK && !complete) st = GF_K_ERR_FORMAT;
     }
