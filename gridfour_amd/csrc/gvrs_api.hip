@@ -69,6 +69,7 @@ struct gf_context {
     int device = 0;
     hipStream_t stream = nullptr;
     DevBuf workspace;      // decode spill: grid * 6*cells
+    DevBuf trees;          // leaf records of the tree pre-pass: GF_TREE_REC_WORDS per tile
     // staging for the host-memory entry points
     DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
     DevBuf dPlanes;        // CodecFloat plane staging
@@ -166,6 +167,7 @@ void gf_context_destroy(gf_context *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->workspace.release();
+    c->trees.release();
     c->dValues.release();
     c->dSlots.release();
     c->dBlob.release();
@@ -207,6 +209,8 @@ gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
     if (!c || nRows < 1 || nCols < 1) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     const unsigned grid = gf_huffman_decode_grid(nTiles);
+    gf_status s = c->trees.ensure(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16);
+    if (s != GF_OK) return s;
     return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
 }
 
@@ -289,6 +293,19 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     a.debug = g_decodeDebug;
     a.rawM32 = kind == KIND_RAW_M32 ? 1 : 0;
     a.analysis = analysis;
+    a.trees = nullptr;
+    if (kind == KIND_HUFFMAN) {
+        // tree pre-pass: one lane per tile walks the serialised tree; the decode kernel starts from the leaf records
+        const size_t need = nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16;
+        if (c->trees.bytes < need) {
+            GF_HIP(hipSetDevice(c->device));               // not capture-safe either: gf_context_reserve sizes this too
+            gf_status s = c->trees.ensure(need);
+            if (s != GF_OK) return s;
+        }
+        GF_HIP(gf_launch_huffman_parse_trees(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
+                                             stream ? (hipStream_t)stream : c->stream));
+        a.trees = (const uint32_t *)c->trees.p;
+    }
     if (kind == KIND_CANON) {
         a.ldsM32Bytes = 0;
         a.ldsTextBytes = gf_canon_decode_lds_text(nRows, nCols);

@@ -50,6 +50,9 @@ constexpr int L2_MAX_BITS = 8;                 // second-level LUT: up to 8 more
 constexpr int L2_ENTRIES = 2048;               // shared by all second-level tables: 2048 >> l2bits tables of
                                                // 2^l2bits entries, l2bits = min(8, longest code - 11) per tile
 
+// a dword at any byte address (global memory)
+struct __attribute__((packed, aligned(1))) PackedWord { uint32_t v; };
+
 struct DecShared {
     uint32_t lut[1 << LUT_BITS];               // sym1 | sym2 << 8 | len1 << 16 | (len1 + len2) << 22 (== len1 << 22: one symbol);
                                                // bit 31 | sub-table: the code is longer than the window
@@ -861,6 +864,46 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
         GF_DSTAMP(1);
         if (a.rawM32) {
             if (tid == 0) { S.parseStatus = len < 10ull + nM32 ? GF_K_ERR_BOUNDS : GF_K_OK; S.uniformSym = -1; S.textStart = 80; }
+        } else if (a.trees) {
+            // the tree was walked by k_huffman_parse_trees: fetch the leaf records, then mark the first-level entries
+            // whose codes continue in a second-level table (one per distinct LUT_BITS-bit prefix among the longer codes,
+            // numbered in pre-order) and list the short leaves -- in parallel, a leaf per thread
+            const uint32_t *rec = a.trees + t * GF_TREE_REC_WORDS;
+            const uint32_t nLeaves = rec[1];
+            const bool mine = (uint32_t)tid < nLeaves && rec[0] == (uint32_t)GF_K_OK && (int32_t)rec[4] < 0;
+            unsigned long long code = 0;
+            uint32_t clen = 0;
+            if (mine) {
+                code = reinterpret_cast<const unsigned long long *>(rec + 8)[tid];
+                clen = reinterpret_cast<const uint8_t *>(rec + 8 + 512)[tid];
+                S.leafCode[tid] = code;
+                S.leafLen[tid] = (uint8_t)clen;
+                S.leafSym[tid] = reinterpret_cast<const uint8_t *>(rec + 8 + 512 + 64)[tid];
+            }
+            __syncthreads();
+            const uint32_t prefix = (uint32_t)code & ((1u << LUT_BITS) - 1u);
+            const bool deep = mine && clen > (uint32_t)LUT_BITS;
+            bool opens = deep;
+            if (deep && tid > 0 && S.leafLen[tid - 1] > LUT_BITS)
+                opens = ((uint32_t)S.leafCode[tid - 1] & ((1u << LUT_BITS) - 1u)) != prefix;
+            uint32_t nSub, nShort;
+            const uint32_t subIdx = block_excl_scan(opens ? 1u : 0u, S.waveSum, &nSub);
+            if (opens) S.lut[prefix] = 0x80000000u | subIdx;
+            const bool isShort = mine && clen <= 5u;
+            const uint32_t slot = block_excl_scan(isShort ? 1u : 0u, S.waveSum, &nShort);
+            if (isShort) S.shortLeaf[slot & 63u] = (uint8_t)tid;
+            if (tid == 0) {
+                const uint32_t maxLen = rec[3];
+                S.uniformSym = (int32_t)rec[4];
+                S.textStart = rec[2];
+                S.parseStatus = (int32_t)rec[0];
+                S.nLeaves = nLeaves;
+                S.nShort = nShort;
+                const uint32_t l2 = maxLen > LUT_BITS ? min((uint32_t)L2_MAX_BITS, maxLen - LUT_BITS) : 1u;
+                S.l2bits = l2;
+                S.nSub = min(nSub, (uint32_t)L2_ENTRIES >> l2);
+                S.maxLen = maxLen;
+            }
         } else if (wave == 0) {
             parse_tree_wave(S, 80u, 80u, len * 8u);
         }
@@ -1119,6 +1162,104 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tree pre-pass: HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161) for a whole batch, ONE LANE PER TILE.  The walk
+// is serial per tree (about a hundred leaves, a hundred instructions each); as a scalar loop inside the decode kernel it
+// kept three of a workgroup's four waves idle for a sixth of the tile time.  Here 64 trees advance per wave instruction
+// and the decode kernel starts from the leaf records.  Same walk, same checks and statuses as parse_tree_wave.
+__global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__restrict__ blob, size_t blobBytes,
+                                                            const uint64_t *__restrict__ offsets, size_t slotStride,
+                                                            const uint32_t *__restrict__ lengths, uint32_t *__restrict__ trees,
+                                                            size_t nTiles)
+{
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= nTiles) return;
+    const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
+    const uint32_t len = lengths[t];
+    uint32_t *rec = trees + t * GF_TREE_REC_WORDS;
+    unsigned long long *codes = reinterpret_cast<unsigned long long *>(rec + 8);
+    uint8_t *lens = reinterpret_cast<uint8_t *>(rec + 8 + 512), *syms = lens + 256;
+    if (len < 10 || off + len > blobBytes) {                 // the decode kernel rejects the tile before looking here
+        rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
+        return;
+    }
+    const uint8_t *__restrict__ pk = blob + off;
+    // the walk sees what parse_tree_wave sees: the packing's bytes, zero beyond its end and beyond the staged head
+    const uint32_t visible = min(len, (uint32_t)(HEAD_WORDS * 4));
+    auto ld32 = [&](uint32_t i) -> uint32_t {                // bytes i .. i+3 of the packing, little-endian
+        if (i + 4u <= visible) return reinterpret_cast<const PackedWord *>(pk + i)->v;
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < 4; k++)
+            if (i + k < visible) w |= (uint32_t)pk[i + k] << (8u * k);
+        return w;
+    };
+    uint64_t buf = ((uint64_t)ld32(14) << 32) | ld32(10);    // packing bit 80 = byte 10
+    uint32_t have = 64, next = 18, bp = 80;
+    auto refill = [&]() {
+        if (have <= 32) {
+            buf |= (uint64_t)ld32(next) << have;
+            have += 32;
+            next += 4;
+        }
+    };
+    auto take = [&](uint32_t nb) -> uint32_t {               // nb <= 9, needs have >= nb
+        const uint32_t v = (uint32_t)buf & ((1u << nb) - 1u);
+        buf >>= nb;
+        have -= nb;
+        bp += nb;
+        return v;
+    };
+    int32_t st = GF_K_OK;
+    int32_t uniformSym = -1;
+    const uint32_t nLeaves = take(8) + 1;
+    const uint32_t rootBit = take(1);
+    uint32_t maxLen = 1;
+    if (rootBit == 1) {
+        uniformSym = (int32_t)take(8);
+    } else {
+        uint64_t c = 0;
+        uint32_t L = 1;
+        uint32_t leaves = 0, records = 0;
+        bool complete = false;
+        while (leaves < nLeaves) {
+            refill();
+            if (records > 511) { st = GF_K_ERR_BOUNDS; break; }
+            uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
+            z = min(z, have);
+            if (z) {
+                if (L - 1u + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }
+                c <<= z;
+                L += z;
+                records += z;
+                buf >>= z;
+                have -= z;
+                bp += z;
+                if (have == 0u || !(buf & 1ull)) continue;
+                refill();
+            }
+            const uint32_t r9 = take(9);
+            records++;
+            codes[leaves] = __brevll(c) >> (64u - L);
+            lens[leaves] = (uint8_t)L;
+            syms[leaves] = (uint8_t)(r9 >> 1);
+            maxLen = max(maxLen, L);
+            leaves++;
+            const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;
+            if (leaves == nLeaves) { complete = t1 >= L; break; }
+            if (t1 >= L) { st = GF_K_ERR_BOUNDS; break; }
+            c = (c >> t1) | 1ull;
+            L -= t1;
+        }
+        if (st == GF_K_OK && !complete) st = GF_K_ERR_FORMAT;
+    }
+    if (st == GF_K_OK && bp > len * 8u) st = GF_K_ERR_BOUNDS;
+    rec[0] = (uint32_t)st;
+    rec[1] = nLeaves;
+    rec[2] = bp;
+    rec[3] = maxLen;
+    rec[4] = (uint32_t)uniformSym;
+}
+
 }  // namespace
 
 uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
@@ -1187,5 +1328,14 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
         maxDynSet = dyn;
     }
     hipLaunchKernelGGL(k_lsop_unpack_m32, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
+                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_huffman_parse_trees, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
+                       slotStride, lengths, trees, nTiles);
     return hipGetLastError();
 }

@@ -47,10 +47,16 @@ struct GfDecodeArgs {
     int phaseLimit;            // diagnostic: stop after phase 0/1/2 (value 1/2/3); 0 = run everything
     uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
     int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
+    const uint32_t *trees;     // non-null: the Huffman trees were parsed by k_huffman_parse_trees (GF_TREE_REC_WORDS per tile)
     uint32_t *analysis;        // non-null: CodecHuffman.analyze mode -- per tile GF_ANALYSIS_WORDS words (predictor, nM32,
                                // bits in tree, packing bytes - 10, 256-bin histogram of the M32 bytes); no values are written
 };
 constexpr int GF_ANALYSIS_WORDS = 260;
+// per-tile record of the tree pre-pass: 8 header words (status, leaves, bit position of the first code, longest code,
+// single-symbol value or -1, 3 spare), then 256 x (path bits uint64), 256 x code length, 256 x symbol
+constexpr int GF_TREE_REC_WORDS = 8 + 512 + 64 + 64;
+hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
+                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream);
 
 // LSOP12 containers whose entropy stage is CodecM32 bytes: type 0 (legacy Huffman of the two M32 streams) and, with
 // rawM32 = 1, type 1 after the host inflated it (gvrs_decode.hip: k_lsop_unpack_m32)
