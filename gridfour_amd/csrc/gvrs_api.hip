@@ -307,6 +307,18 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         a.trees = (const uint32_t *)c->trees.p;
     }
     if (kind == KIND_CANON) {
+        // the same for the canonical decoder's code lengths
+        const size_t need = nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16;
+        if (c->trees.bytes < need) {
+            GF_HIP(hipSetDevice(c->device));
+            gf_status s = c->trees.ensure(need);
+            if (s != GF_OK) return s;
+        }
+        GF_HIP(gf_launch_canon_parse_lengths(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
+                                             stream ? (hipStream_t)stream : c->stream));
+        a.trees = (const uint32_t *)c->trees.p;
+    }
+    if (kind == KIND_CANON) {
         a.ldsM32Bytes = 0;
         a.ldsTextBytes = gf_canon_decode_lds_text(nRows, nCols);
         GF_HIP(gf_launch_canon_decode(a, stream ? (hipStream_t)stream : c->stream, grid));

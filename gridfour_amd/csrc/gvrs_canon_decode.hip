@@ -87,8 +87,9 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
         uint32_t endPos, nValues;
         uint32_t *stamps = a.debug ? a.debug + t * 16 : nullptr;
         if (stamps && tid == 0) stamps[0] = (uint32_t)__builtin_amdgcn_s_memtime();
-        const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps)
-                                     : cd_decode_stream(S, TG, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps);
+        const uint32_t *pre = a.trees ? a.trees + t * GF_CANON_REC_WORDS : nullptr;
+        const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias)
+                                     : cd_decode_stream(S, TG, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias);
         if (st != GF_K_OK) {
             if (tid == 0) a.status[t] = st;
             __syncthreads();
@@ -101,6 +102,142 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Code-length pre-pass of the canonical decoder, ONE LANE PER TILE: LengthEncoder.readEncodedLengths (:197-236) and
+// CanonHuffTreeDecoder.decodeTree (:133-177) are a serial walk over some three hundred tokens; inside the decode kernel
+// it kept one wave busy and three idle for a fifth of the tile time.  Same walk, same checks and statuses as phase 0 of
+// cd_decode_stream; bit positions are relative to the packing (the stream starts at bit 48).
+struct __attribute__((packed, aligned(1))) CdPackedWord { uint32_t v; };
+
+__global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__restrict__ blob, size_t blobBytes,
+                                                            const uint64_t *__restrict__ offsets, size_t slotStride,
+                                                            const uint32_t *__restrict__ lengths, uint32_t *__restrict__ recs,
+                                                            size_t nTiles)
+{
+    __shared__ uint8_t sMetaLen[CN_META * 64], sOrder[CN_META * 64];   // per-lane columns
+    const uint32_t lane = threadIdx.x;
+    const size_t t0 = (size_t)blockIdx.x * 64;
+    // records start out zero: only non-zero lengths are stored below
+    {
+        const size_t n = min((size_t)64, nTiles - t0) * GF_CANON_REC_WORDS;
+        uint32_t *r0 = recs + t0 * GF_CANON_REC_WORDS;
+        for (size_t i = lane; i < n; i += 64) r0[i] = 0;
+        __threadfence_block();
+    }
+    const size_t t = t0 + lane;
+    if (t >= nTiles) return;
+    const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
+    const uint32_t len = lengths[t];
+    uint32_t *rec = recs + t * GF_CANON_REC_WORDS;
+    uint8_t *outLen = reinterpret_cast<uint8_t *>(rec + 8);
+    if (len < 7 || off + len > blobBytes) {                   // no stream: the decode kernel does not look here
+        rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
+        return;
+    }
+    const uint8_t *__restrict__ pk = blob + off;
+    const uint32_t endBit = len * 8u;
+    auto peek = [&](uint32_t pos) -> uint32_t {               // 32 bits of the packing from bit pos, zero beyond its end
+        const uint32_t b = pos >> 3;
+        uint64_t w;
+        if (b + 8u <= len) {
+            w = ((uint64_t)reinterpret_cast<const CdPackedWord *>(pk + b + 4)->v << 32) | reinterpret_cast<const CdPackedWord *>(pk + b)->v;
+        } else {
+            w = 0;
+            for (uint32_t k = 0; k < 8; k++)
+                if (b + k < len) w |= (uint64_t)pk[b + k] << (8u * k);
+        }
+        return (uint32_t)(w >> (pos & 7u));
+    };
+    uint32_t pos = 48u + 1u;                                  // reserved bit, CanonicalHuffman.java:451
+    int32_t st = GF_K_OK;
+    // LengthEncoder.readEncodedLengths :197-236: the 20 lengths of the meta alphabet
+    for (uint32_t k = 0; k < (uint32_t)CN_META; k++) sMetaLen[k * 64 + lane] = 0;
+    {
+        uint32_t k = 0, prior = 0;
+        while (k < (uint32_t)CN_META && st == GF_K_OK) {
+            if (pos + 12u > endBit + 32u) { st = GF_K_ERR_BOUNDS; break; }
+            const uint32_t w = peek(pos);
+            const uint32_t idx = w & 31u;
+            pos += 5;
+            if (idx <= 15u) {
+                sMetaLen[k * 64 + lane] = (uint8_t)idx;
+                k++;
+                prior = idx;
+            } else if (idx <= 18u) {
+                const uint32_t nb = idx == 16u ? 2u : idx == 17u ? 3u : 7u;
+                const uint32_t n = ((w >> 5) & ((1u << nb) - 1u)) + (idx == 18u ? 11u : 3u);
+                pos += nb;
+                if (idx != 16u) prior = 0;
+                if (k + n > (uint32_t)CN_META) { st = GF_K_ERR_BOUNDS; break; }
+                for (uint32_t j = 0; j < n; j++) sMetaLen[(k + j) * 64 + lane] = (uint8_t)prior;
+                k += n;
+            }
+            if (pos > endBit) st = GF_K_ERR_BOUNDS;
+        }
+    }
+    // canonical tables of the meta code: symbols per length (8-bit counters packed in two words), symbols ordered by
+    // (length, symbol)
+    unsigned long long cntLo = 0, cntHi = 0;
+    auto cnt8 = [&](uint32_t l) -> uint32_t { return (uint32_t)((l < 8 ? cntLo >> (8u * l) : cntHi >> (8u * (l - 8u))) & 0xffu); };
+    uint32_t nUsed = 0;
+    if (st == GF_K_OK) {
+        for (uint32_t k = 0; k < (uint32_t)CN_META; k++) {
+            const uint32_t l = sMetaLen[k * 64 + lane];
+            if (l) {
+                if (l < 8) cntLo += 1ull << (8u * l); else cntHi += 1ull << (8u * (l - 8u));
+                nUsed++;
+            }
+        }
+        if (nUsed == 0) st = GF_K_ERR_BOUNDS;                 // sortNodes[0] of an empty array
+        uint32_t slot = 0;
+        for (uint32_t l = 1; l <= 15 && st == GF_K_OK; l++)
+            for (uint32_t k = 0; k < (uint32_t)CN_META; k++)
+                if (sMetaLen[k * 64 + lane] == l) sOrder[(slot++) * 64 + lane] = (uint8_t)k;
+    }
+    // CanonHuffTreeDecoder.decodeTree :133-177: the 260 (+1) code lengths
+    uint32_t nonZero = 0;
+    if (st == GF_K_OK) {
+        uint32_t i = 0, prior = 0;
+        while (i < (uint32_t)CN_SYMS && st == GF_K_OK) {
+            if (pos >= endBit) { st = GF_K_ERR_BOUNDS; break; }
+            const uint32_t w = peek(pos);
+            const uint32_t c = __brev(w);
+            uint32_t cl = 0, sym = 0, code = 0, offs = 0;
+            for (uint32_t l = 1; l <= 15; l++) {              // canonical search (cd_search)
+                const uint32_t n = cnt8(l);
+                const uint32_t d = (c >> (32u - l)) - code;
+                if (d < n) { cl = l; sym = sOrder[(offs + d) * 64 + lane]; break; }
+                code = (code + n) << 1;
+                offs += n;
+            }
+            if (cl == 0) { st = GF_K_ERR_BOUNDS; break; }     // walks into a missing node
+            pos += cl;
+            if (sym <= 15u) {
+                if (sym) { outLen[i] = (uint8_t)sym; nonZero++; }
+                i++;
+                prior = sym;
+            } else if (sym <= 18u) {
+                const uint32_t nb = sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+                const uint32_t n = ((w >> cl) & ((1u << nb) - 1u)) + (sym == 18u ? 11u : 3u);
+                pos += nb;
+                if (sym != 16u) prior = 0;
+                if (i + n > (uint32_t)CN_SYMS + 1u) { st = GF_K_ERR_BOUNDS; break; }
+                if (prior) {
+                    for (uint32_t j = 0; j < n; j++) outLen[i + j] = (uint8_t)prior;
+                    nonZero += n;
+                }
+                i += n;
+            } else {
+                i++;                                          // symbol 19 (meta end-of-text): no store
+            }
+            if (pos > endBit) st = GF_K_ERR_BOUNDS;
+        }
+    }
+    rec[0] = (uint32_t)st;
+    rec[1] = pos;
+    rec[2] = nonZero;
 }
 
 }  // namespace
@@ -126,5 +263,14 @@ hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, uns
         maxDynSet = dyn;
     }
     hipLaunchKernelGGL(k_canon_decode, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
+                                         const uint32_t *lengths, uint32_t *recs, size_t nTiles, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_canon_parse_lengths, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
+                       slotStride, lengths, recs, nTiles);
     return hipGetLastError();
 }

@@ -262,7 +262,8 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
 template <class Text, class Sink>
 __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, uint32_t startBit, uint32_t endBit,
                                                     uint32_t maxValues, uint32_t fillTo, Sink sink, uint32_t *endPos,
-                                                    uint32_t *nValuesOut, uint32_t *stamps = nullptr)
+                                                    uint32_t *nValuesOut, uint32_t *stamps = nullptr,
+                                                    const uint32_t *pre = nullptr, uint32_t preBase = 0)
 {
 #define CD_STAMP(i)                                                                        \
     do {                                                                                   \
@@ -272,7 +273,20 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     if (tid == 0) { S.parseStatus = GF_K_OK; S.runStatus = GF_K_OK; S.qStar = 0xFFFFFFFFu; S.carry = 0; }
     __syncthreads();
     // ---------------- phase 0: code tables ----------------
-    if (wave == 0) {
+    if (wave == 0 && pre) {
+        // the code lengths were read by k_canon_parse_lengths (one lane per tile): pre = its record, preBase = the bit
+        // position its packing-relative positions are counted from
+        int32_t st = (int32_t)pre[0];
+        uint32_t nUsed = 0;
+        if (st == GF_K_OK) {
+            const uint8_t *pl = reinterpret_cast<const uint8_t *>(pre + 8);
+            for (uint32_t e = (uint32_t)lane; e < 320u; e += 64) S.len[e] = e < 272u ? pl[e] : (uint8_t)0;
+            __builtin_amdgcn_wave_barrier();
+            cd_tables<5>(S.len, CN_SYMS + 1, S.first, S.count, S.offset, S.symByOrder, lane, &nUsed);
+            if (nUsed == 0) st = GF_K_ERR_BOUNDS;
+        }
+        if (lane == 0) { S.parseStatus = st; S.textStart = preBase + pre[1]; }
+    } else if (wave == 0) {
         uint32_t pos = startBit + 1u;                           // reserved bit, CanonicalHuffman.java:451
         int32_t st = GF_K_OK;
         // LengthEncoder.readEncodedLengths :197-236

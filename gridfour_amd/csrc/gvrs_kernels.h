@@ -86,6 +86,12 @@ unsigned gf_huffman_decode_grid(size_t nTiles);
 uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols);
 uint32_t gf_huffman_decode_lds_text(int nRows, int nCols);
 
+// per-tile record of the canonical decoder's code-length pre-pass: 8 header words (status, bit position of the text
+// relative to the packing, 6 spare), then the 261 code lengths (CanonHuffTreeDecoder.decodeTree) padded to 272 bytes
+constexpr int GF_CANON_REC_WORDS = 8 + 68;
+hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
+                                         const uint32_t *lengths, uint32_t *recs, size_t nTiles, hipStream_t stream);
+
 // CodecCanonHuffman (gvrs_canon_encode.hip / gvrs_canon_decode.hip); same argument blocks as the legacy codec
 hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
 hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
