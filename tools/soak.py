@@ -106,7 +106,13 @@ def main():
                 for k, t in enumerate(idx):
                     # the reference is the arbiter: with extreme values its canonical container does not round-trip
                     # (CanonicalHuffman.java:258 vs :395), and the library reproduces that
-                    ref = oracle.lsop12_decode(nr, nc, good[k])
+                    try:
+                        ref = oracle.lsop12_decode(nr, nc, good[k])
+                    except IOError:
+                        # residuals in (-8388608, -8333608] are counted as one symbol and written as another: the
+                        # reference cannot read such a stream back, and neither may the library
+                        assert st[k] != 0, (tag, "lsop: undecodable stream accepted", t)
+                        continue
                     if not (st[k] == 0 and np.array_equal(vals[k], ref)):
                         bad = np.flatnonzero(vals[k] != ref)
                         np.save("gpurun_out/soak_fail_tile.npy", tiles[t])
