@@ -70,10 +70,14 @@ def _pmc_traffic(workload, kernel):
         return None
     if rec.get("workload") != workload:
         return None
-    for name, d in rec.get("kernels", {}).items():
-        if kernel in name:
-            return int(d["traffic"])
-    return None
+    total, found = 0, False
+    for part in kernel.split("+"):                      # a launch may be a pre-pass kernel + the main kernel
+        for name, d in rec.get("kernels", {}).items():
+            if part in name:
+                total += int(d["traffic"])
+                found = True
+                break
+    return total if found else None
 
 
 def run_float(args, ctx, rank, world, dist, torch):
@@ -351,8 +355,12 @@ def main():
     enc_avg, dec_avg = float(np.mean(enc_ms)), float(np.mean(dec_ms))
     # algorithmic bytes per launch: encode reads 4 B/cell and writes c; decode reads c, writes 4
     alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
-    kname = {"canon": "k_canon", "lsop": "lsop", "huffman": "k_huffman"}[args.codec]
-    dom_name, dom_ms = (kname + "_decode", dec_avg) if dec_avg >= enc_avg else (kname + "_encode", enc_avg)
+    # the decode side of the two Huffman codecs is a per-tile pre-pass kernel followed by the decode kernel: both are inside
+    # the HIP-event bracket and both are named, so that the rocprofv3 averages under profiles/ add up to avg_launch_ms
+    enc_name = {"canon": "k_canon_encode", "lsop": "k_lsop_predict+k_canon_pack2", "huffman": "k_huffman_encode"}[args.codec]
+    dec_name = {"canon": "k_canon_parse_lengths+k_canon_decode", "lsop": "k_lsop_unpack2+k_lsop_unpack_m32+k_lsop_reconstruct",
+                "huffman": "k_huffman_parse_trees+k_huffman_decode"}[args.codec]
+    dom_name, dom_ms = (dec_name, dec_avg) if dec_avg >= enc_avg else (enc_name, enc_avg)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     traffic = _pmc_traffic(args.workload, dom_name)
     out = {
