@@ -16,9 +16,11 @@
 // counts then tells every thread where its output goes.
 //
 // Phases of a workgroup (256 threads) on one tile
-//   0  header + tree: wave 0 walks the pre-order serialisation as a scalar loop (bits and the
-//      node stack live in registers, read with v_readlane), emitting per-leaf (code, length,
-//      symbol); then all threads fill the 11-bit decode LUT from the leaf table
+//   0  header + tree: the pre-order serialisation is walked by k_huffman_parse_trees, a pre-pass kernel
+//      with one lane per tile, which leaves per-leaf (code, length, symbol) records in HBM (the scalar
+//      walk of one wave, parse_tree_wave, remains for trees at data-dependent positions: LSOP legacy
+//      containers); the workgroup loads the records, marks the second-level prefixes with a block scan
+//      and fills the 10-bit two-symbol decode LUT from the leaf table
 //   1  Huffman text -> M32 bytes in LDS (global spill buffer for oversized tiles); every thread
 //      keeps a 96-bit window of the text in registers and refills it one dword at a time
 //   2  M32 bytes -> residuals: value starts are marked in a bitmap, ranked by a popcount prefix
@@ -46,7 +48,7 @@ constexpr int MAXQ = 512;                      // subsequences per chain
 constexpr int HEAD_WORDS = 88;                 // 10 header + 1 + ceil(2559/8) tree bytes = 332 -> 83 words, + slack
 constexpr int MAX_DEPTH = 63;                  // code length limit of the register tree parser
 
-constexpr int L2_MAX_BITS = 8;                 // second-level LUT: up to 8 more bits (codes of 12..19 bits)
+constexpr int L2_MAX_BITS = 8;                 // second-level LUT: up to 8 more bits (codes of 11..18 bits)
 constexpr int L2_ENTRIES = 2048;               // shared by all second-level tables: 2048 >> l2bits tables of
                                                // 2^l2bits entries, l2bits = min(8, longest code - 11) per tile
 
@@ -564,8 +566,8 @@ template <class Lut2Ptr>
 __device__ __forceinline__ void build_lut(DecShared &S, Lut2Ptr lut2)
 {
     const uint32_t tid = threadIdx.x;
-    // LUT from the leaf table: a leaf with a code of <= 11 bits owns 2^(11-len) first-level entries,
-    // one of 12..19 bits owns 2^(19-len) entries of its prefix's second-level table
+    // LUT from the leaf table: a leaf with a code of <= LUT_BITS bits owns 2^(LUT_BITS-len) first-level entries,
+    // a longer one (up to LUT_BITS + l2bits) owns entries of its prefix's second-level table
     {
         const uint32_t nLeaves = S.nLeaves;
         const uint32_t nSub = S.nSub;
