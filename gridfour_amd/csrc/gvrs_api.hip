@@ -314,7 +314,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
             gf_status s = c->trees.ensure(need);
             if (s != GF_OK) return s;
         }
-        GF_HIP(gf_launch_canon_parse_lengths(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
+        GF_HIP(gf_launch_canon_parse_lengths(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles, 0,
                                              stream ? (hipStream_t)stream : c->stream));
         a.trees = (const uint32_t *)c->trees.p;
     }
@@ -327,6 +327,20 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
         GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     }
+    return GF_OK;
+}
+
+// code-length pre-pass for the first stream of LSOP12 containers of the canonical type
+static gf_status lsopParseLengths(gf_context *c, hipStream_t st, size_t nTiles, const uint8_t *dBlob, size_t blobBytes,
+                                  const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths)
+{
+    const size_t need = nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16;
+    if (c->trees.bytes < need) {
+        GF_HIP(hipSetDevice(c->device));                   // not capture-safe: gf_context_reserve sizes this too
+        gf_status s = c->trees.ensure(need);
+        if (s != GF_OK) return s;
+    }
+    GF_HIP(gf_launch_canon_parse_lengths(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles, 1, st));
     return GF_OK;
 }
 
@@ -946,9 +960,12 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
     }
     if (resStride < gf_lsop12_residual_count(nRows, nCols)) return GF_ERR_ARG;
     const unsigned grid = gf_huffman_decode_grid(nTiles);
+    gf_status s = lsopParseLengths(c, st, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths);
+    if (s != GF_OK) return s;
     GF_HIP(gf_launch_lsop_unpack2(dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride, dCoefs,
-                                  dScratchStatus, nTiles, nRows, nCols, gf_canon_decode_lds_text(nRows, nCols), grid, st));
-    gf_status s = lsopUnpackM32(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals,
+                                  dScratchStatus, nTiles, nRows, nCols, gf_canon_decode_lds_text(nRows, nCols), grid, st,
+                                  (const uint32_t *)c->trees.p));
+    s = lsopUnpackM32(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals,
                                 resStride, dCoefs, dScratchStatus, 0);
     if (s != GF_OK) return s;
     return gf_lsop12_reconstruct_dev(c, stream, nRows, nCols, nTiles, dResiduals, resStride, dCoefs, dScratchStatus, dValues,
@@ -1180,10 +1197,12 @@ gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t
     GF_HIP(hipMemcpyAsync(c->dOffsets.p, gpuOffsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
     GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
     const unsigned grid = gf_huffman_decode_grid(nTiles);
+    if ((s = lsopParseLengths(c, c->stream, nTiles, (const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
+                              (const uint32_t *)c->dLengths.p)) != GF_OK) return s;
     GF_HIP(gf_launch_lsop_unpack2((const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
                                   (const uint32_t *)c->dLengths.p, (int32_t *)c->dResiduals.p, resStride,
                                   (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p, nTiles, nRows, nCols,
-                                  gf_canon_decode_lds_text(nRows, nCols), grid, c->stream));
+                                  gf_canon_decode_lds_text(nRows, nCols), grid, c->stream, (const uint32_t *)c->trees.p));
     s = lsopUnpackM32(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
                       (const uint32_t *)c->dLengths.p, (int32_t *)c->dResiduals.p, resStride, (uint32_t *)c->dCoefs.p,
                       (int32_t *)c->dStatus2.p, 1);

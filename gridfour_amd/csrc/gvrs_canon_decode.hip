@@ -114,7 +114,7 @@ struct __attribute__((packed, aligned(1))) CdPackedWord { uint32_t v; };
 __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__restrict__ blob, size_t blobBytes,
                                                             const uint64_t *__restrict__ offsets, size_t slotStride,
                                                             const uint32_t *__restrict__ lengths, uint32_t *__restrict__ recs,
-                                                            size_t nTiles)
+                                                            size_t nTiles, int lsopContainer)
 {
     __shared__ uint8_t sMetaLen[CN_META * 64], sOrder[CN_META * 64];   // per-lane columns
     const uint32_t lane = threadIdx.x;
@@ -138,6 +138,17 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
     }
     const uint8_t *__restrict__ pk = blob + off;
     const uint32_t endBit = len * 8u;
+    // where the stream starts: behind the 6-byte header of CodecCanonHuffman, or (lsopContainer) behind the header of an
+    // LSOP12 container of the canonical type (LsHeader.java:131-185; the other types are not read through this record)
+    uint32_t startBit = 48u;
+    if (lsopContainer) {
+        const uint32_t hdr = 55u + ((pk[1] & 0x80) ? 4u : 0u);
+        if (!(pk[1] & 0x40) || (pk[1] & 0x0f) != 2 || pk[2] != 12 || len < hdr) {
+            rec[0] = (uint32_t)GF_K_ERR_UNSUPPORTED;
+            return;
+        }
+        startBit = hdr * 8u;
+    }
     auto peek = [&](uint32_t pos) -> uint32_t {               // 32 bits of the packing from bit pos, zero beyond its end
         const uint32_t b = pos >> 3;
         uint64_t w;
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
         }
         return (uint32_t)(w >> (pos & 7u));
     };
-    uint32_t pos = 48u + 1u;                                  // reserved bit, CanonicalHuffman.java:451
+    uint32_t pos = startBit + 1u;                             // reserved bit, CanonicalHuffman.java:451
     int32_t st = GF_K_OK;
     // LengthEncoder.readEncodedLengths :197-236: the 20 lengths of the meta alphabet
     for (uint32_t k = 0; k < (uint32_t)CN_META; k++) sMetaLen[k * 64 + lane] = 0;
@@ -267,10 +278,11 @@ hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, uns
 }
 
 hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
-                                         const uint32_t *lengths, uint32_t *recs, size_t nTiles, hipStream_t stream)
+                                         const uint32_t *lengths, uint32_t *recs, size_t nTiles, int lsopContainer,
+                                         hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_canon_parse_lengths, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
-                       slotStride, lengths, recs, nTiles);
+                       slotStride, lengths, recs, nTiles, lsopContainer);
     return hipGetLastError();
 }

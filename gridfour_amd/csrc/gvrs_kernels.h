@@ -90,7 +90,8 @@ uint32_t gf_huffman_decode_lds_text(int nRows, int nCols);
 // relative to the packing, 6 spare), then the 261 code lengths (CanonHuffTreeDecoder.decodeTree) padded to 272 bytes
 constexpr int GF_CANON_REC_WORDS = 8 + 68;
 hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
-                                         const uint32_t *lengths, uint32_t *recs, size_t nTiles, hipStream_t stream);
+                                         const uint32_t *lengths, uint32_t *recs, size_t nTiles, int lsopContainer,
+                                         hipStream_t stream);
 
 // CodecCanonHuffman (gvrs_canon_encode.hip / gvrs_canon_decode.hip); same argument blocks as the legacy codec
 hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
@@ -122,7 +123,7 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
 hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                   const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
                                   int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const uint32_t *pre = nullptr);   // pre: records of the first stream's lengths
 
 // predictor -> M32 stage alone (gvrs_encode.hip): per tile up to three candidate M32 streams (CodecDeflate.java:157-199)
 struct GfM32Args {

@@ -31,6 +31,7 @@ struct GfLsopUnpackArgs {
     size_t nTiles;
     int nRows, nCols;
     uint32_t ldsTextBytes;
+    const uint32_t *pre;       // code-length records of the first stream (k_canon_parse_lengths), or null
 };
 
 __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArgs a)
@@ -82,8 +83,9 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArg
 
         uint32_t pos = bias + hdr * 8u, nv;
         const CdArraySink sink0{res, nInit};
-        int32_t st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInit, nInit, sink0, &pos, &nv)
-                               : cd_decode_stream(S, TG, pos, endBit, nInit, nInit, sink0, &pos, &nv);
+        const uint32_t *pre = a.pre ? a.pre + t * GF_CANON_REC_WORDS : nullptr;
+        int32_t st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias)
+                               : cd_decode_stream(S, TG, pos, endBit, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias);
         if (st == GF_K_OK) {
             const CdArraySink sink1{res + nInit, nInt};
             st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv)
@@ -99,11 +101,11 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArg
 hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                   const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
                                   int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
-                                  hipStream_t stream)
+                                  hipStream_t stream, const uint32_t *pre)
 {
     if (nTiles == 0) return hipSuccess;
     GfLsopUnpackArgs a{blob, blobBytes, offsets, slotStride, lengths, residuals, resStride, coefs, status, nTiles, nRows, nCols,
-                       ldsTextBytes};
+                       ldsTextBytes, pre};
     static size_t maxDynSet = 0;
     if (ldsTextBytes > maxDynSet) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsop_unpack2),
