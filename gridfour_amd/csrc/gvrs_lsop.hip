@@ -328,11 +328,30 @@ __global__ __launch_bounds__(256, 4) void k_lsop_predict(GfLsopPredictArgs a)
 
         // interior stream (:248-272)
         const uint32_t wI = nC - 4u;
-        for (uint32_t e = tid; e < nInt; e += 256) {
-            const uint32_t r = e / wI, c = e - r * wI;
-            const uint32_t idx = (r + 2u) * nC + c + 2u;
-            const int32_t est = lsop_round(lsop_predict12(u, v, idx, nC));
-            res[nInit + e] = (int32_t)((uint32_t)v[idx] - (uint32_t)est);
+        {
+            // four cells per thread in flight (their 52 loads are independent); row / column kept incrementally
+            constexpr int U = 4;
+            const uint32_t dr = 256u / wI, dc = 256u - dr * wI;
+            uint32_t r = (uint32_t)tid / wI, c = (uint32_t)tid - r * wI;
+            for (uint32_t e0 = tid; e0 < nInt; e0 += 256u * U) {
+                uint32_t idx[U];
+                float p[U];
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    const bool in = e0 + 256u * k < nInt;
+                    idx[k] = in ? (r + 2u) * nC + c + 2u : 2u * nC + 2u;      // a harmless cell for the idle slots
+                    r += dr;
+                    c += dc;
+                    if (c >= wI) { c -= wI; r++; }
+                }
+#pragma unroll
+                for (int k = 0; k < U; k++) p[k] = lsop_predict12(u, v, idx[k], nC);
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    const uint32_t e = e0 + 256u * k;
+                    if (e < nInt) res[nInit + e] = (int32_t)((uint32_t)v[idx[k]] - (uint32_t)lsop_round(p[k]));
+                }
+            }
         }
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();
