@@ -74,6 +74,8 @@ constexpr int ROW_BATCH = 8;                    // rows a wave keeps in flight i
 // PredictorModelDifferencing.java:145-167, PredictorModelLinear.java:66-101, PredictorModelTriangle.java:62-98,
 // PredictorModelDifferencingWithNulls.java:137-166 (and the decodeInt twins).  Whole workgroup; o[0] need not
 // hold the seed.  stamp (optional) receives a cycle stamp after the column-0 chain.
+constexpr int COL_BATCH = 16;                   // rows of a column in flight in the Triangle column sums
+
 __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, uint32_t *o, uint32_t nR, uint32_t nC,
                                                      uint32_t *stamp)
 {
@@ -83,12 +85,12 @@ __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, u
         if (model == 3) {
             for (uint32_t c = 1 + tid; c < nC; c += DEC_THREADS) {
                 uint32_t acc = o[c];
-                for (uint32_t r = 1; r < nR; r += 8) {
-                    uint32_t x[8];
+                for (uint32_t r = 1; r < nR; r += COL_BATCH) {
+                    uint32_t x[COL_BATCH];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) x[j] = r + j < nR ? o[(size_t)(r + j) * nC + c] : 0u;
+                    for (int j = 0; j < COL_BATCH; j++) x[j] = r + j < nR ? o[(size_t)(r + j) * nC + c] : 0u;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
+                    for (int j = 0; j < COL_BATCH; j++) {
                         acc += x[j];
                         if (r + j < nR) o[(size_t)(r + j) * nC + c] = acc;
                     }
