@@ -70,6 +70,7 @@ struct gf_context {
     hipStream_t stream = nullptr;
     DevBuf workspace;      // decode spill: grid * 6*cells
     DevBuf trees;          // leaf records of the tree pre-pass: GF_TREE_REC_WORDS per tile
+    DevBuf packRecs;       // encoder: selection records between k_huffman_encode and k_huffman_pack
     // staging for the host-memory entry points
     DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
     DevBuf dPlanes;        // CodecFloat plane staging
@@ -168,6 +169,7 @@ void gf_context_destroy(gf_context *c)
     (void)hipStreamSynchronize(c->stream);
     c->workspace.release();
     c->trees.release();
+    c->packRecs.release();
     c->dValues.release();
     c->dSlots.release();
     c->dBlob.release();
@@ -211,6 +213,7 @@ gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
     const unsigned grid = gf_huffman_decode_grid(nTiles);
     gf_status s = c->trees.ensure(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16);
     if (s != GF_OK) return s;
+    if ((s = c->packRecs.ensure(nTiles * (size_t)GF_PACK_REC_WORDS * 4 + 16)) != GF_OK) return s;
     return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
 }
 
@@ -256,6 +259,16 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
     a.predictorMask = predictorMask & GF_PM_ALL;
     a.debug = g_encodeDebug;
     a.phaseLimit = g_encPhaseLimit;
+    a.packRecs = nullptr;
+    if (kind == KIND_HUFFMAN) {
+        const size_t need = nTiles * (size_t)GF_PACK_REC_WORDS * 4 + 16;
+        if (c->packRecs.bytes < need) {
+            GF_HIP(hipSetDevice(c->device));               // not capture-safe: gf_context_reserve sizes this too
+            gf_status s = c->packRecs.ensure(need);
+            if (s != GF_OK) return s;
+        }
+        a.packRecs = (uint32_t *)c->packRecs.p;
+    }
     if (kind == KIND_CANON) GF_HIP(gf_launch_canon_encode(a, stream ? (hipStream_t)stream : c->stream));
     else GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
     return GF_OK;

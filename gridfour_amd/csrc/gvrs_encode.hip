@@ -7,6 +7,8 @@
 //   compress/HuffmanEncoder.java:124-305       histogram, tree, serialisation, text
 //   io/BitOutputStore.java:205-288             LSB-first bit order
 //
+// Two kernels: k_huffman_encode runs phases A and B and the selection and leaves the winner's code table and tree
+// image in a per-tile record; k_huffman_pack runs phase C from it (each with its own register budget, see below).
 // Phases of a workgroup (256 threads = 4 waves) on one tile
 //   A  one flat pass over the tile, 8 consecutive cells per thread (two 16-byte loads + the row
 //      above + 3 halo words, all issued before use): residuals of all three predictors, M32
@@ -21,8 +23,8 @@
 //      workgroup and each thread ORs its bits into an LDS window that is flushed to the
 //      tile's output slot with coalesced dword stores (tile re-read hits L2).
 // HBM traffic per cell: 4 B read + c B written; everything else stays on chip.
-// This integer pipeline is instruction-bound, not bandwidth-bound: the fast
-// paths are written branch-free to keep VALU and SALU (exec-mask) instruction counts down.
+// This integer pipeline is bound by dependent-instruction latency at the occupancy LDS and registers allow, not by
+// bandwidth.
 
 #include <hip/hip_runtime.h>
 
@@ -245,7 +247,13 @@ __device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32
     }
 }
 
-__global__ __launch_bounds__(ENC_THREADS, 5) void k_huffman_encode(GfEncodeArgs a)
+// Two kernels per batch: k_huffman_encode (phases A and B and the selection) and k_huffman_pack (phase C).  Fused into
+// one kernel the phases shared one register budget (96 VGPRs at five workgroups per CU, 428 bytes of scratch per lane,
+// the calls into the packers saving and restoring two dozen registers); apart, each runs at six workgroups per CU
+// with 80 VGPRs and little scratch: 1.63 -> 1.51 ms on the ETOPO1-shaped batch (sweep: 4..8 workgroups per CU each).
+constexpr int ENC_AB_WGS = 6, ENC_PACK_WGS = 6;
+
+__global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
     __shared__ EncPersist P;
     __shared__ EncScratch S;
@@ -573,48 +581,85 @@ __global__ __launch_bounds__(ENC_THREADS, 5) void k_huffman_encode(GfEncodeArgs 
             if (a.predictors) a.predictors[t] = (uint8_t)model;
         }
         if (bestBytes > a.slotStride) { __syncthreads(); continue; }
+        {
+            // the pack phase runs as k_huffman_pack, with its own register budget and occupancy: leave it the selection
+            uint32_t *rec = a.packRecs + t * (size_t)GF_PACK_REC_WORDS;
+            if (tid == 0) {
+                rec[0] = (uint32_t)model;
+                rec[1] = P.treeEndBit[best];
+                rec[2] = P.seed;
+                rec[3] = P.maxN[best];
+                rec[4] = P.maxLen[best];
+            }
+            for (int i = tid; i < GF_IMG_WORDS; i += ENC_THREADS) rec[8 + i] = P.img[best][i];
+            const uint32_t *tw = reinterpret_cast<const uint32_t *>(P.tab[best]);
+            for (int i = tid; i < 512; i += ENC_THREADS) rec[8 + 88 + i] = tw[i];
+            __syncthreads();
+        }
+    }
+}
 
-        const uint32_t treeEnd = P.treeEndBit[best];
+
+// k_huffman_pack: phase C of the encoder as its own kernel (see GfEncodeArgs::packRecs)
+struct PackShared {
+    uint64_t tab[256];
+    uint32_t waveSum[ENC_WAVES];
+};
+
+__global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEncodeArgs a)
+{
+    __shared__ PackShared P;
+    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+
+    const int tid = threadIdx.x;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if (a.status[t] != GF_K_OK) continue;                             // declined, overflow: nothing to write
+        const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
+        uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
+        GF_STAMP(6);
+        const uint32_t *rec = a.packRecs + t * (size_t)GF_PACK_REC_WORDS;
+        const int model = (int)rec[0];
+        const uint32_t treeEnd = rec[1], seed = rec[2], maxN = rec[3], maxLen = rec[4];
         const uint32_t imgWords = (treeEnd + 31u) >> 5;
-        for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) S.win[i] = i < (int)imgWords ? P.img[best][i] : 0u;
+        for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) win[i] = i < (int)imgWords ? rec[8 + i] : 0u;
+        {
+            uint32_t *tw = reinterpret_cast<uint32_t *>(P.tab);
+            for (int i = tid; i < 512; i += ENC_THREADS) tw[i] = rec[8 + 88 + i];
+        }
         __syncthreads();
 
         const uint32_t nStream = gf_stream_len(model, nR, nC);
-        const uint32_t seed = P.seed;
-        const uint64_t *tab = P.tab[best];
-        const uint32_t elemMaxBits = max(1u, P.maxN[best] * P.maxLen[best]);
+        const uint64_t *tab = P.tab;
+        const uint32_t elemMaxBits = max(1u, maxN * maxLen);
         PackState ps;
         ps.bitBase = treeEnd;
         ps.wordBase = 0;
-        GF_STAMP(6);
-        window_flush(S.win, out32, ps);          // header + tree image
-        if (nStream > 0 && P.maxLen[best] > 0) {
-            // one step of the flat scan emits at most STEP_CELLS elements; it must fit the window
+        window_flush(win, out32, ps);            // header + tree image
+        if (nStream > 0 && maxLen > 0) {
             const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
             if (!fast) {
-                pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, S.win, out32, P.waveSum, ps);
+                pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
             } else if (model == 1) {
-                pack_flat<1>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                pack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else if (model == 2) {
-                // seed chain first: (0,1), then (r,0),(r,1) for r >= 1  (PredictorModelLinear.java:113-126)
-                pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, S.win, out32, P.waveSum, ps);
-                pack_flat<2>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                pack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else if (model == 3) {
-                // row 0 and column 0 first  (PredictorModelTriangle.java:114-127)
-                pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, S.win, out32, P.waveSum, ps);
-                pack_flat<3>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                pack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else {
-                pack_flat<4>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             }
         }
         GF_STAMP(7);
-        // tail: whatever is left in the window (also covers uniform tiles)
         {
             const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
             const uint32_t remWords = (remBits + 31u) >> 5;
             const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
             for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
-                if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = S.win[j];
+                if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = win[j];
         }
         __syncthreads();
     }
@@ -789,8 +834,10 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
 {
     if (a.nTiles == 0) return hipSuccess;
+    if (!a.packRecs) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
     hipLaunchKernelGGL(k_huffman_encode, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_huffman_pack, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -28,7 +28,11 @@ struct GfEncodeArgs {
     int predictorMask;
     uint32_t *debug;           // optional diagnostic dump (GF_ENC_DEBUG_WORDS per tile), normally null
     int phaseLimit;            // diagnostic: stop after phase A (1) / B (2); 0 = run everything
+    uint32_t *packRecs;        // non-null (CodecHuffman only): k_huffman_encode stops after the selection and leaves per tile
+                               // GF_PACK_REC_WORDS words (model, tree end bit, seed, maxN, maxLen, tree image, code table)
+                               // for k_huffman_pack, which writes the packing
 };
+constexpr int GF_PACK_REC_WORDS = 8 + 88 + 512;
 
 struct GfDecodeArgs {
     const uint8_t *blob;       // 4-byte aligned

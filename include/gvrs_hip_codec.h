@@ -75,8 +75,9 @@ int gf_device_count(void);
  * independent (this is how tile batches shard over the GPUs of a node).      */
 gf_status gf_context_create(int device, gf_context **ctx);
 void gf_context_destroy(gf_context *ctx);
-/* pre-allocates the decode workspace (M32 spill per resident workgroup; per-tile records of the tree / code-length
- * pre-pass kernels) for batches up to n_tiles tiles of n_rows x n_cols; without it the first larger _dev decode grows it */
+/* pre-allocates the workspace (decode: M32 spill per resident workgroup, per-tile records of the tree / code-length
+ * pre-pass kernels; encode: per-tile selection records between the two encoder kernels) for batches up to n_tiles tiles
+ * of n_rows x n_cols; without it the first larger _dev call grows it */
 gf_status gf_context_reserve(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles);
 /* the context's own stream (hipStream_t) */
 void *gf_context_stream(gf_context *ctx);
