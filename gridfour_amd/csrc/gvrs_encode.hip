@@ -247,6 +247,139 @@ __device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32
     }
 }
 
+// The same segment with wave-private bit windows: every wave packs one contiguous quarter of the cells into its own
+// quarter of the LDS window, starting at bit 0, with a wave-level scan and no workgroup barrier inside the loop; the
+// four bit strings are then shifted into place (they follow one another in the stream) and written out.  Returns
+// false -- nothing written, ps untouched -- when a quarter does not fit its window; the caller then uses pack_flat.
+constexpr uint32_t WAVE_WIN = WIN_WORDS / ENC_WAVES;                 // words per wave
+template <int MODEL>
+__device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                                const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                                PackState &ps, uint32_t slotWords)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t carryWord = win[0];                               // bits of the stream so far in its last, partial word
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;
+    if (tid < ENC_WAVES) waveSum[tid] = 0xFFFFFFFFu;                 // = this wave's quarter did not fit
+    __syncthreads();
+    const uint32_t quarter = (((nCells + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
+    const uint32_t segBegin = wave * quarter, segEnd = min(nCells, segBegin + quarter);
+    uint32_t *wwin = win + wave * WAVE_WIN;
+    const uint32_t capBits = (WAVE_WIN - 2u) * 32u;
+    uint32_t bits = 0;
+    bool fits = true;
+    uint32_t c0 = (segBegin + lane * CPT) % nC;
+    const uint32_t cStep = (64u * CPT) % nC;
+    for (uint32_t base = segBegin; base < segEnd; base += 64u * CPT) {
+        const uint32_t i0 = base + lane * CPT;
+        uint64_t cl[CPT];
+        uint32_t xs[CPT];
+        uint32_t myBits = 0, multi = 0;
+        if (i0 < segEnd) {
+            Cells8 Q;
+            load_cells8(tile, nC, nCells, i0, Q);
+            uint32_t c = c0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                bool emit, single;
+                const uint32_t x = flat_residual<MODEL>(Q, j, i0 + j, c, nC, nCells, seed, &emit);
+                const uint32_t b0 = m32_first_byte(x, &single);
+                const uint64_t e = emit ? tab[b0] : 0ull;
+                cl[j] = e;
+                xs[j] = x;
+                myBits += (uint32_t)(e >> 56);
+                if (emit && !single) multi |= 1u << j;
+                if (++c == nC) c = 0;
+            }
+            if (multi) {                                              // continuation bytes (rare)
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    if ((multi >> j) & 1u) {
+                        const uint32_t x = xs[j];
+                        const int n = gf_m32_len(x);
+                        for (int k = 1; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) { cl[j] = 0; xs[j] = 0; }
+        }
+        c0 += cStep;
+        if (c0 >= nC) c0 -= nC;
+
+        const uint32_t incl = gf_wave_incl_scan(myBits);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (bits + total > capBits) { fits = false; break; }         // wave-uniform
+        if (myBits) {
+            BitSink sink;
+            sink.init(wwin, bits + incl - myBits);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                sink.put(cl[j] & 0x00ffffffffffffffull, (uint32_t)(cl[j] >> 56));
+                if ((multi >> j) & 1u) {
+                    const uint32_t x = xs[j];
+                    const int n = gf_m32_len(x);
+                    for (int k = 1; k < n; k++) {
+                        const uint64_t e = tab[gf_m32_byte(x, n, k)];
+                        sink.put(e & 0x00ffffffffffffffull, (uint32_t)(e >> 56));
+                    }
+                }
+            }
+            sink.finish();
+        }
+        bits += total;
+    }
+    if (lane == 0 && fits) waveSum[wave] = bits;
+    __syncthreads();
+    uint32_t L[ENC_WAVES];
+    bool all = true;
+#pragma unroll
+    for (int w = 0; w < ENC_WAVES; w++) {
+        L[w] = waveSum[w];
+        all = all && L[w] != 0xFFFFFFFFu;
+    }
+    if (!all) {                                                       // back to the state the caller left: partial word, zeros
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = i == 0 ? carryWord : 0u;
+        __syncthreads();
+        return false;
+    }
+    // concatenate: the bit string of wave w lands at bit D[w] of the packing
+    uint32_t D[ENC_WAVES + 1];
+    D[0] = ps.bitBase;
+#pragma unroll
+    for (int w = 0; w < ENC_WAVES; w++) D[w + 1] = D[w] + L[w];
+    const uint32_t firstWord = ps.wordBase, endWord = (D[ENC_WAVES] + 31u) >> 5;
+    for (uint32_t J = firstWord + tid; J < endWord; J += ENC_THREADS) {
+        uint32_t val = J == firstWord ? carryWord : 0u;
+#pragma unroll
+        for (int w = 0; w < ENC_WAVES; w++) {
+            const int32_t rel = (int32_t)(32u * J) - (int32_t)D[w];   // first bit of word J inside string w
+            if (rel > -32 && rel < (int32_t)L[w]) {
+                const uint32_t *src = win + w * WAVE_WIN;
+                uint32_t x;
+                if (rel >= 0) {
+                    const uint32_t k = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31u;
+                    x = src[k] >> sh;
+                    if (sh) x |= src[k + 1] << (32u - sh);            // bits beyond L[w] are zero
+                } else {
+                    x = src[0] << (uint32_t)(-rel);
+                }
+                val |= x;
+            }
+        }
+        if (J < slotWords) out32[J] = val;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;   // nothing left for the tail
+    ps.wordBase = endWord;
+    ps.bitBase = endWord * 32u;
+    __syncthreads();
+    return true;
+}
+
 // Two kernels per batch: k_huffman_encode (phases A and B and the selection) and k_huffman_pack (phase C).  Fused into
 // one kernel the phases shared one register budget (96 VGPRs at five workgroups per CU, 428 bytes of scratch per lane,
 // the calls into the packers saving and restoring two dozen registers); apart, each runs at six workgroups per CU
@@ -642,15 +775,19 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
             if (!fast) {
                 pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
             } else if (model == 1) {
-                pack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                if (!pack_flat_waves<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
+                    pack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else if (model == 2) {
                 pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
-                pack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                if (!pack_flat_waves<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
+                    pack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else if (model == 3) {
                 pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
-                pack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                if (!pack_flat_waves<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
+                    pack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else {
-                pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                if (!pack_flat_waves<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
+                    pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             }
         }
         GF_STAMP(7);
