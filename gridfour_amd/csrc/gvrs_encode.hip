@@ -179,17 +179,19 @@ __device__ void pack_generic(int model, const uint32_t *__restrict__ tile, uint3
 template <int MODEL>
 __device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                           const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
-                          PackState &ps)
+                          PackState &ps, uint32_t cellBegin = 0, uint32_t cellEnd = 0xFFFFFFFFu)
 {
+    // cells [cellBegin, cellEnd): cellBegin a multiple of CPT, cellEnd a multiple of CPT or the end of the tile
     const uint32_t tid = threadIdx.x;
-    uint32_t c0 = (tid * CPT) % nC;
+    cellEnd = min(cellEnd, nCells);
+    uint32_t c0 = (cellBegin + tid * CPT) % nC;
     const uint32_t cStep = STEP_CELLS % nC;
-    for (uint32_t base = 0; base < nCells; base += STEP_CELLS) {
+    for (uint32_t base = cellBegin; base < cellEnd; base += STEP_CELLS) {
         const uint32_t i0 = base + tid * CPT;
         uint64_t cl[CPT];
         uint32_t xs[CPT];
         uint32_t myBits = 0, multi = 0;
-        if (i0 < nCells) {
+        if (i0 < cellEnd) {
             Cells8 Q;
             load_cells8(tile, nC, nCells, i0, Q);
             uint32_t c = c0;
@@ -255,16 +257,18 @@ constexpr uint32_t WAVE_WIN = WIN_WORDS / ENC_WAVES;                 // words pe
 template <int MODEL>
 __device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                 const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
-                                PackState &ps, uint32_t slotWords)
+                                PackState &ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
 {
+    // cells [cellBegin, cellEnd) as for pack_flat; on return the window again holds the partial last word at win[0]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    cellEnd = min(cellEnd, nCells);
     const uint32_t carryWord = win[0];                               // bits of the stream so far in its last, partial word
     __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;
     if (tid < ENC_WAVES) waveSum[tid] = 0xFFFFFFFFu;                 // = this wave's quarter did not fit
     __syncthreads();
-    const uint32_t quarter = (((nCells + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
-    const uint32_t segBegin = wave * quarter, segEnd = min(nCells, segBegin + quarter);
+    const uint32_t quarter = (((cellEnd - cellBegin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
+    const uint32_t segBegin = min(cellEnd, cellBegin + wave * quarter), segEnd = min(cellEnd, segBegin + quarter);
     uint32_t *wwin = win + wave * WAVE_WIN;
     const uint32_t capBits = (WAVE_WIN - 2u) * 32u;
     uint32_t bits = 0;
@@ -351,8 +355,10 @@ __device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, 
     D[0] = ps.bitBase;
 #pragma unroll
     for (int w = 0; w < ENC_WAVES; w++) D[w + 1] = D[w] + L[w];
-    const uint32_t firstWord = ps.wordBase, endWord = (D[ENC_WAVES] + 31u) >> 5;
-    for (uint32_t J = firstWord + tid; J < endWord; J += ENC_THREADS) {
+    // full words go out; the last, partial one stays in the window for whoever continues the stream
+    const uint32_t firstWord = ps.wordBase, endWord = D[ENC_WAVES] >> 5;
+    uint32_t partial = 0;
+    for (uint32_t J = firstWord + tid; J <= endWord; J += ENC_THREADS) {
         uint32_t val = J == firstWord ? carryWord : 0u;
 #pragma unroll
         for (int w = 0; w < ENC_WAVES; w++) {
@@ -370,21 +376,25 @@ __device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, 
                 val |= x;
             }
         }
-        if (J < slotWords) out32[J] = val;
+        if (J == endWord) partial = val;
+        else if (J < slotWords) out32[J] = val;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;   // nothing left for the tail
+    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;
+    __syncthreads();
+    if (((endWord - firstWord) % ENC_THREADS) == tid) win[0] = partial;      // the thread that computed word endWord
     ps.wordBase = endWord;
-    ps.bitBase = endWord * 32u;
+    ps.bitBase = D[ENC_WAVES];
     __syncthreads();
     return true;
 }
 
 // Two kernels per batch: k_huffman_encode (phases A and B and the selection) and k_huffman_pack (phase C).  Fused into
 // one kernel the phases shared one register budget (96 VGPRs at five workgroups per CU, 428 bytes of scratch per lane,
-// the calls into the packers saving and restoring two dozen registers); apart, each runs at six workgroups per CU
-// with 80 VGPRs and little scratch: 1.63 -> 1.51 ms on the ETOPO1-shaped batch (sweep: 4..8 workgroups per CU each).
-constexpr int ENC_AB_WGS = 6, ENC_PACK_WGS = 6;
+// the calls into the packers saving and restoring two dozen registers); apart, they run at six workgroups per CU
+// (80 VGPRs) resp. eight (64 VGPRs, with the wave-private windows of pack_flat_waves): 1.63 -> 1.40 ms on the ETOPO1-shaped
+// batch (sweep: 4..8 workgroups per CU each).
+constexpr int ENC_AB_WGS = 6, ENC_PACK_WGS = 8;
 
 __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
@@ -723,6 +733,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 rec[2] = P.seed;
                 rec[3] = P.maxN[best];
                 rec[4] = P.maxLen[best];
+                rec[5] = (uint32_t)min(P.totalBits[best] - P.treeEndBit[best], (uint64_t)0xFFFFFFFFu);   // bits of the text
             }
             for (int i = tid; i < GF_IMG_WORDS; i += ENC_THREADS) rec[8 + i] = P.img[best][i];
             const uint32_t *tw = reinterpret_cast<const uint32_t *>(P.tab[best]);
@@ -732,6 +743,23 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
     }
 }
 
+
+// the flat scan of a tile through the wave-private windows, in as many cell ranges as its bit count asks for (a wave's
+// share of a range must fit its quarter of the window); a range that does not fit after all goes through pack_flat
+template <int MODEL>
+__device__ __forceinline__ void pack_flat_ranges(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                                                 const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                                                 PackState &ps, uint32_t slotWords, uint32_t textBits)
+{
+    const uint32_t capBits = (WAVE_WIN - 2u) * 32u;
+    const uint64_t want = ((uint64_t)textBits + (textBits >> 2)) / ENC_WAVES;           // a wave's share, with 25 % slack
+    const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / capBits + 1u);
+    const uint32_t per = (((nCells + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);
+    for (uint32_t b = 0; b < nCells; b += per) {
+        if (!pack_flat_waves<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per))
+            pack_flat<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, b, b + per);
+    }
+}
 
 // k_huffman_pack: phase C of the encoder as its own kernel (see GfEncodeArgs::packRecs)
 struct PackShared {
@@ -754,7 +782,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
         GF_STAMP(6);
         const uint32_t *rec = a.packRecs + t * (size_t)GF_PACK_REC_WORDS;
         const int model = (int)rec[0];
-        const uint32_t treeEnd = rec[1], seed = rec[2], maxN = rec[3], maxLen = rec[4];
+        const uint32_t treeEnd = rec[1], seed = rec[2], maxN = rec[3], maxLen = rec[4], textBits = rec[5];
         const uint32_t imgWords = (treeEnd + 31u) >> 5;
         for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) win[i] = i < (int)imgWords ? rec[8 + i] : 0u;
         {
@@ -775,19 +803,15 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
             if (!fast) {
                 pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
             } else if (model == 1) {
-                if (!pack_flat_waves<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
-                    pack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                pack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 2) {
                 pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
-                if (!pack_flat_waves<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
-                    pack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                pack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 3) {
                 pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
-                if (!pack_flat_waves<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
-                    pack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                pack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else {
-                if (!pack_flat_waves<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
-                    pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                pack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             }
         }
         GF_STAMP(7);
