@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -213,7 +214,7 @@ gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
     const unsigned grid = gf_huffman_decode_grid(nTiles);
     gf_status s = c->trees.ensure(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16);
     if (s != GF_OK) return s;
-    if ((s = c->packRecs.ensure(nTiles * (size_t)GF_PACK_REC_WORDS * 4 + 16)) != GF_OK) return s;
+    if ((s = c->packRecs.ensure(nTiles * std::max((size_t)GF_PACK_REC_WORDS, gf_canon_pack_rec_words()) * 4 + 16)) != GF_OK) return s;
     return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
 }
 
@@ -260,8 +261,8 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
     a.debug = g_encodeDebug;
     a.phaseLimit = g_encPhaseLimit;
     a.packRecs = nullptr;
-    if (kind == KIND_HUFFMAN) {
-        const size_t need = nTiles * (size_t)GF_PACK_REC_WORDS * 4 + 16;
+    {
+        const size_t need = nTiles * (kind == KIND_CANON ? gf_canon_pack_rec_words() : (size_t)GF_PACK_REC_WORDS) * 4 + 16;
         if (c->packRecs.bytes < need) {
             GF_HIP(hipSetDevice(c->device));               // not capture-safe: gf_context_reserve sizes this too
             gf_status s = c->packRecs.ensure(need);

@@ -27,6 +27,10 @@ namespace {
 #include "gvrs_encode_common.h"
 #include "gvrs_canon_common.h"
 
+// per-tile record between k_canon_encode (phases A, B, selection) and k_canon_pack (phase C): model, seed, image bits, longest
+// code, largest escape kind, 3 spare, then the serialised code tables and the winner's code table (GfEncodeArgs::packRecs)
+constexpr int CN_PACK_REC_WORDS = 8 + CN_IMG_WORDS + CN_HIST;
+
 struct CanonPersist {
     uint32_t hist[3][CN_HIST];
     uint32_t tab[3][CN_HIST];
@@ -47,7 +51,6 @@ struct CanonPersist {
 union CanonUnion {
     uint32_t histR[3][CN_HIST * HIST_R];        // phase A
     CanonScratch tree[3];                       // phase B
-    uint32_t win[WIN_WORDS + WIN_SLACK];        // phase C
 };
 
 // upper bound of the bits one value can take given the longest code and the largest escape kind
@@ -163,7 +166,11 @@ __device__ void cpack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint3
     }
 }
 
-__global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_encode(GfEncodeArgs a)
+// workgroups per CU: the histogram + table kernel is capped at four by its 34 KB of LDS (sweep 4..6: 1.81 / 2.00 / 2.00 ms),
+// the pack kernel runs six (80 VGPRs; eight are no faster)
+constexpr int CN_AB_WGS = 4, CN_PACK_WGS = 6;
+
+__global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncodeArgs a)
 {
     __shared__ CanonPersist P;
     __shared__ CanonUnion S;
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_encode(GfEncodeArgs a)
                 P.totalBits[p] = 48ull + B.imgBits + B.textBits;
             }
         }
-        __syncthreads();                         // trees dead from here: S.win may be written
+        __syncthreads();
 
         // ---------------- phase C: pick the shortest, pack it ----------------
         int best = -1;
@@ -374,16 +381,58 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_encode(GfEncodeArgs a)
         }
         if (bestBytes > a.slotStride) { __syncthreads(); continue; }
 
+        {
+            // the pack phase runs as k_canon_pack with its own register budget and occupancy: leave it the selection
+            uint32_t *rec = a.packRecs + t * (size_t)CN_PACK_REC_WORDS;
+            if (tid == 0) {
+                rec[0] = (uint32_t)model;
+                rec[1] = P.seed;
+                rec[2] = P.imgBits[best];
+                rec[3] = P.maxLen[best];
+                rec[4] = P.maxKind[best];
+            }
+            for (int i = tid; i < CN_IMG_WORDS; i += ENC_THREADS) rec[8 + i] = P.img[best][i];
+            for (int i = tid; i < CN_HIST; i += ENC_THREADS) rec[8 + CN_IMG_WORDS + i] = P.tab[best][i];
+            __syncthreads();
+        }
+    }
+}
+
+// k_canon_pack: phase C of the encoder as its own kernel (see k_huffman_pack in gvrs_encode.hip for the measurements)
+struct CanonPackShared {
+    uint32_t tab[CN_HIST];
+    uint32_t img[CN_IMG_WORDS];
+    uint32_t waveSum[ENC_WAVES];
+};
+
+__global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncodeArgs a)
+{
+    __shared__ CanonPackShared P;
+    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+
+    const int tid = threadIdx.x;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        // declined, overflow: nothing to write; a uniform tile (exactly the 6 header bytes) was written by k_canon_encode
+        if (a.status[t] != GF_K_OK || a.lengths[t] <= 6u) continue;
+        const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
+        uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
+        const uint32_t *rec = a.packRecs + t * (size_t)CN_PACK_REC_WORDS;
+        const int model = (int)rec[0];
+        const uint32_t seed = rec[1], imgBits = rec[2], maxLen = rec[3], maxKind = rec[4];
+        for (int i = tid; i < CN_IMG_WORDS; i += ENC_THREADS) P.img[i] = rec[8 + i];
+        for (int i = tid; i < CN_HIST; i += ENC_THREADS) P.tab[i] = rec[8 + CN_IMG_WORDS + i];
+        __syncthreads();
+
         // header (6 bytes = 48 bits) + code tables image shifted behind it
-        const uint32_t seed = P.seed;
-        const uint32_t imgBits = P.imgBits[best];
         const uint32_t headEnd = 48u + imgBits;
         const uint32_t headWords = (headEnd + 31u) >> 5;
         for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) {
             uint32_t w = 0;
             if (i < (int)headWords) {
                 // image bit b lives at packing bit 48 + b: word i takes image bits [32 i - 48, 32 i - 16)
-                const uint32_t *img = P.img[best];
+                const uint32_t *img = P.img;
                 if (i == 0) w = ((uint32_t)a.codecIndex & 0xffu) | ((uint32_t)model << 8) | (seed << 16);
                 else if (i == 1) w = (seed >> 16) | (img[0] << 16);
                 else {
@@ -391,38 +440,38 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_encode(GfEncodeArgs a)
                     w = (lo >> 16) | (hi << 16);
                 }
             }
-            S.win[i] = w;
+            win[i] = w;
         }
         __syncthreads();
 
         const uint32_t nStream = gf_stream_len(model, nR, nC);
-        const uint32_t *tab = P.tab[best];
-        const uint32_t elemMaxBits = max(1u, cn_elem_max_bits(P.maxLen[best], P.maxKind[best]));
+        const uint32_t *tab = P.tab;
+        const uint32_t elemMaxBits = max(1u, cn_elem_max_bits(maxLen, maxKind));
         PackState ps;
         ps.bitBase = headEnd;
         ps.wordBase = 0;
-        window_flush(S.win, out32, ps);
+        window_flush(win, out32, ps);
         if (nStream > 0) {
             const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
             if (!fast) {
-                cpack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, S.win, out32, P.waveSum, ps);
+                cpack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
             } else if (model == 1) {
-                cpack_flat<1>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                cpack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else if (model == 2) {
-                cpack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, S.win, out32, P.waveSum, ps);
-                cpack_flat<2>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                cpack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                cpack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else if (model == 3) {
-                cpack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, S.win, out32, P.waveSum, ps);
-                cpack_flat<3>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                cpack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                cpack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             } else {
-                cpack_flat<4>(tile, nC, nCells, seed, tab, S.win, out32, P.waveSum, ps);
+                cpack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
             }
         }
         // end-of-text symbol (CanonicalHuffman.java:278), then the tail of the window
         if (tid == 0) {
             const uint32_t e = tab[CN_EOT];
             BitSink sink;
-            sink.init(S.win, ps.bitBase - ps.wordBase * 32u);
+            sink.init(win, ps.bitBase - ps.wordBase * 32u);
             sink.put32(e & 0xffffu, e >> 16);
             sink.finish();
         }
@@ -433,7 +482,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_encode(GfEncodeArgs a)
             const uint32_t remWords = (remBits + 31u) >> 5;
             const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
             for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
-                if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = S.win[j];
+                if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = win[j];
         }
         __syncthreads();
     }
@@ -445,6 +494,10 @@ hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream)
 {
     if (a.nTiles == 0) return hipSuccess;
     const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
+    if (!a.packRecs) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_canon_encode, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_canon_pack, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
+
+size_t gf_canon_pack_rec_words() { return (size_t)CN_PACK_REC_WORDS; }

@@ -39,7 +39,6 @@ namespace {
 union EncScratch {
     uint32_t histR[3][256 * HIST_R];            // phase A
     GfHuffTree tree[3];                         // phase B
-    uint32_t win[WIN_WORDS + WIN_SLACK];        // phase C
 };
 
 
