@@ -111,16 +111,18 @@ __device__ void cpack_generic(int model, const uint32_t *__restrict__ tile, uint
 template <int MODEL>
 __device__ void cpack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                            const uint32_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
-                           PackState &ps)
+                           PackState &ps, uint32_t cellBegin = 0, uint32_t cellEnd = 0xFFFFFFFFu)
 {
+    // cells [cellBegin, cellEnd): cellBegin a multiple of CPT, cellEnd a multiple of CPT or the end of the tile
     const uint32_t tid = threadIdx.x;
-    uint32_t c0 = (tid * CPT) % nC;
+    cellEnd = min(cellEnd, nCells);
+    uint32_t c0 = (cellBegin + tid * CPT) % nC;
     const uint32_t cStep = STEP_CELLS % nC;
-    for (uint32_t base = 0; base < nCells; base += STEP_CELLS) {
+    for (uint32_t base = cellBegin; base < cellEnd; base += STEP_CELLS) {
         const uint32_t i0 = base + tid * CPT;
         uint32_t cl[CPT], xs[CPT];
         uint32_t myBits = 0, wide = 0;
-        if (i0 < nCells) {
+        if (i0 < cellEnd) {
             Cells8 Q;
             load_cells8(tile, nC, nCells, i0, Q);
             uint32_t c = c0;
@@ -163,6 +165,88 @@ __device__ void cpack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint3
         __syncthreads();
         ps.bitBase += total;
         window_flush(win, out32, ps);
+    }
+}
+
+// cpack_flat over cells [cellBegin, cellEnd) with wave-private bit windows (gvrs_encode_common.h: wave_windows_*); false =
+// a wave's share did not fit, nothing was written
+template <int MODEL>
+__device__ bool cpack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                                 const uint32_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                                 PackState &ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    cellEnd = min(cellEnd, nCells);
+    const uint32_t carryWord = wave_windows_begin(win, waveSum);
+    const uint32_t quarter = (((cellEnd - cellBegin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
+    const uint32_t segBegin = min(cellEnd, cellBegin + wave * quarter), segEnd = min(cellEnd, segBegin + quarter);
+    uint32_t *wwin = win + wave * WAVE_WIN;
+    uint32_t bits = 0;
+    bool fits = true;
+    uint32_t c0 = (segBegin + lane * CPT) % nC;
+    const uint32_t cStep = (64u * CPT) % nC;
+    for (uint32_t base = segBegin; base < segEnd; base += 64u * CPT) {
+        const uint32_t i0 = base + lane * CPT;
+        uint32_t cl[CPT], xs[CPT];
+        uint32_t myBits = 0, wide = 0;
+        if (i0 < segEnd) {
+            Cells8 Q;
+            load_cells8(tile, nC, nCells, i0, Q);
+            uint32_t c = c0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                bool emit;
+                const uint32_t x = flat_residual<MODEL>(Q, j, i0 + j, c, nC, nCells, seed, &emit);
+                const bool narrow = x + 128u < 256u;
+                const uint32_t e = emit ? (narrow ? tab[x + 128u] : 0u) : 0u;
+                cl[j] = e;
+                xs[j] = x;
+                myBits += e >> 16;
+                if (emit && !narrow) wide |= 1u << j;
+                if (++c == nC) c = 0;
+            }
+            if (wide) {                                               // values outside a byte (rare on terrain)
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if ((wide >> j) & 1u) myBits += cn_value_bits(tab, xs[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) { cl[j] = 0; xs[j] = 0; }
+        }
+        c0 += cStep;
+        if (c0 >= nC) c0 -= nC;
+
+        const uint32_t incl = gf_wave_incl_scan(myBits);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (bits + total > WAVE_WIN_BITS) { fits = false; break; }   // wave-uniform
+        if (myBits) {
+            BitSink sink;
+            sink.init(wwin, bits + incl - myBits);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                if ((wide >> j) & 1u) cn_value_emit(sink, tab, xs[j]);
+                else sink.put32(cl[j] & 0xffffu, cl[j] >> 16);
+            }
+            sink.finish();
+        }
+        bits += total;
+    }
+    return wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
+}
+
+// the flat scan of a tile in as many cell ranges as its bit count asks for (see pack_flat_ranges in gvrs_encode.hip)
+template <int MODEL>
+__device__ __forceinline__ void cpack_flat_ranges(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                                                  const uint32_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                                                  PackState &ps, uint32_t slotWords, uint32_t textBits)
+{
+    const uint64_t want = ((uint64_t)textBits + (textBits >> 2)) / ENC_WAVES;           // a wave's share, with 25 % slack
+    const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / WAVE_WIN_BITS + 1u);
+    const uint32_t per = (((nCells + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);
+    for (uint32_t b = 0; b < nCells; b += per) {
+        if (!cpack_flat_waves<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per))
+            cpack_flat<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, b, b + per);
     }
 }
 
@@ -390,6 +474,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
                 rec[2] = P.imgBits[best];
                 rec[3] = P.maxLen[best];
                 rec[4] = P.maxKind[best];
+                rec[5] = (uint32_t)min(P.totalBits[best] - 48ull - P.imgBits[best], (unsigned long long)0xFFFFFFFFu);   // text bits
             }
             for (int i = tid; i < CN_IMG_WORDS; i += ENC_THREADS) rec[8 + i] = P.img[best][i];
             for (int i = tid; i < CN_HIST; i += ENC_THREADS) rec[8 + CN_IMG_WORDS + i] = P.tab[best][i];
@@ -420,7 +505,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncod
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
         const uint32_t *rec = a.packRecs + t * (size_t)CN_PACK_REC_WORDS;
         const int model = (int)rec[0];
-        const uint32_t seed = rec[1], imgBits = rec[2], maxLen = rec[3], maxKind = rec[4];
+        const uint32_t seed = rec[1], imgBits = rec[2], maxLen = rec[3], maxKind = rec[4], textBits = rec[5];
         for (int i = tid; i < CN_IMG_WORDS; i += ENC_THREADS) P.img[i] = rec[8 + i];
         for (int i = tid; i < CN_HIST; i += ENC_THREADS) P.tab[i] = rec[8 + CN_IMG_WORDS + i];
         __syncthreads();
@@ -456,15 +541,15 @@ __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncod
             if (!fast) {
                 cpack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
             } else if (model == 1) {
-                cpack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                cpack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 2) {
                 cpack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
-                cpack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                cpack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 3) {
                 cpack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
-                cpack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                cpack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else {
-                cpack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                cpack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             }
         }
         // end-of-text symbol (CanonicalHuffman.java:278), then the tail of the window

@@ -252,7 +252,6 @@ __device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32
 // quarter of the LDS window, starting at bit 0, with a wave-level scan and no workgroup barrier inside the loop; the
 // four bit strings are then shifted into place (they follow one another in the stream) and written out.  Returns
 // false -- nothing written, ps untouched -- when a quarter does not fit its window; the caller then uses pack_flat.
-constexpr uint32_t WAVE_WIN = WIN_WORDS / ENC_WAVES;                 // words per wave
 template <int MODEL>
 __device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                 const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
@@ -261,15 +260,11 @@ __device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, 
     // cells [cellBegin, cellEnd) as for pack_flat; on return the window again holds the partial last word at win[0]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     cellEnd = min(cellEnd, nCells);
-    const uint32_t carryWord = win[0];                               // bits of the stream so far in its last, partial word
-    __syncthreads();
-    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;
-    if (tid < ENC_WAVES) waveSum[tid] = 0xFFFFFFFFu;                 // = this wave's quarter did not fit
-    __syncthreads();
+    const uint32_t carryWord = wave_windows_begin(win, waveSum);
     const uint32_t quarter = (((cellEnd - cellBegin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
     const uint32_t segBegin = min(cellEnd, cellBegin + wave * quarter), segEnd = min(cellEnd, segBegin + quarter);
     uint32_t *wwin = win + wave * WAVE_WIN;
-    const uint32_t capBits = (WAVE_WIN - 2u) * 32u;
+    const uint32_t capBits = WAVE_WIN_BITS;
     uint32_t bits = 0;
     bool fits = true;
     uint32_t c0 = (segBegin + lane * CPT) % nC;
@@ -334,58 +329,7 @@ __device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, 
         }
         bits += total;
     }
-    if (lane == 0 && fits) waveSum[wave] = bits;
-    __syncthreads();
-    uint32_t L[ENC_WAVES];
-    bool all = true;
-#pragma unroll
-    for (int w = 0; w < ENC_WAVES; w++) {
-        L[w] = waveSum[w];
-        all = all && L[w] != 0xFFFFFFFFu;
-    }
-    if (!all) {                                                       // back to the state the caller left: partial word, zeros
-        __syncthreads();
-        for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = i == 0 ? carryWord : 0u;
-        __syncthreads();
-        return false;
-    }
-    // concatenate: the bit string of wave w lands at bit D[w] of the packing
-    uint32_t D[ENC_WAVES + 1];
-    D[0] = ps.bitBase;
-#pragma unroll
-    for (int w = 0; w < ENC_WAVES; w++) D[w + 1] = D[w] + L[w];
-    // full words go out; the last, partial one stays in the window for whoever continues the stream
-    const uint32_t firstWord = ps.wordBase, endWord = D[ENC_WAVES] >> 5;
-    uint32_t partial = 0;
-    for (uint32_t J = firstWord + tid; J <= endWord; J += ENC_THREADS) {
-        uint32_t val = J == firstWord ? carryWord : 0u;
-#pragma unroll
-        for (int w = 0; w < ENC_WAVES; w++) {
-            const int32_t rel = (int32_t)(32u * J) - (int32_t)D[w];   // first bit of word J inside string w
-            if (rel > -32 && rel < (int32_t)L[w]) {
-                const uint32_t *src = win + w * WAVE_WIN;
-                uint32_t x;
-                if (rel >= 0) {
-                    const uint32_t k = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31u;
-                    x = src[k] >> sh;
-                    if (sh) x |= src[k + 1] << (32u - sh);            // bits beyond L[w] are zero
-                } else {
-                    x = src[0] << (uint32_t)(-rel);
-                }
-                val |= x;
-            }
-        }
-        if (J == endWord) partial = val;
-        else if (J < slotWords) out32[J] = val;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;
-    __syncthreads();
-    if (((endWord - firstWord) % ENC_THREADS) == tid) win[0] = partial;      // the thread that computed word endWord
-    ps.wordBase = endWord;
-    ps.bitBase = D[ENC_WAVES];
-    __syncthreads();
-    return true;
+    return wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
 }
 
 // Two kernels per batch: k_huffman_encode (phases A and B and the selection) and k_huffman_pack (phase C).  Fused into
@@ -750,7 +694,7 @@ __device__ __forceinline__ void pack_flat_ranges(const uint32_t *__restrict__ ti
                                                  const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                                  PackState &ps, uint32_t slotWords, uint32_t textBits)
 {
-    const uint32_t capBits = (WAVE_WIN - 2u) * 32u;
+    const uint32_t capBits = WAVE_WIN_BITS;
     const uint64_t want = ((uint64_t)textBits + (textBits >> 2)) / ENC_WAVES;           // a wave's share, with 25 % slack
     const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / capBits + 1u);
     const uint32_t per = (((nCells + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);

@@ -218,3 +218,82 @@ __device__ __forceinline__ void window_flush(uint32_t *win, uint32_t *__restrict
     ps.wordBase += fullWords;
     __syncthreads();
 }
+
+// ---- wave-private bit windows (the pack kernels) ----------------------------------------------------------------------
+// Every wave packs a contiguous share of a cell range into its own quarter of the LDS window, from bit 0, with a wave-level
+// scan and no workgroup barrier inside the loop; the four bit strings follow one another in the stream and are shifted into
+// place at the end.  wave_windows_begin saves the stream's partial last word (win[0], the convention of window_flush) and
+// clears the windows; wave_windows_end takes every wave's bit count (fits = false: its share did not fit), and either
+// restores the window and returns false (nothing written, ps untouched: the caller packs the range the old way) or writes
+// the full words, leaves the new partial word in win[0], advances ps and returns true.
+constexpr uint32_t WAVE_WIN = WIN_WORDS / ENC_WAVES;                 // words per wave
+constexpr uint32_t WAVE_WIN_BITS = (WAVE_WIN - 2u) * 32u;            // what a wave may put into its window
+
+__device__ __forceinline__ uint32_t wave_windows_begin(uint32_t *win, uint32_t *waveSum)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t carryWord = win[0];                               // bits of the stream so far in its last, partial word
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;
+    if (tid < ENC_WAVES) waveSum[tid] = 0xFFFFFFFFu;                 // = this wave's share did not fit
+    __syncthreads();
+    return carryWord;
+}
+
+__device__ __forceinline__ bool wave_windows_end(uint32_t *win, uint32_t *waveSum, uint32_t carryWord, uint32_t bits, bool fits,
+                                                 uint32_t *__restrict__ out32, uint32_t slotWords, PackState &ps)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (lane == 0 && fits) waveSum[wave] = bits;
+    __syncthreads();
+    uint32_t L[ENC_WAVES];
+    bool all = true;
+#pragma unroll
+    for (int w = 0; w < ENC_WAVES; w++) {
+        L[w] = waveSum[w];
+        all = all && L[w] != 0xFFFFFFFFu;
+    }
+    if (!all) {                                                       // back to the state the caller left: partial word, zeros
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = i == 0 ? carryWord : 0u;
+        __syncthreads();
+        return false;
+    }
+    // concatenate: the bit string of wave w lands at bit D[w] of the packing
+    uint32_t D[ENC_WAVES + 1];
+    D[0] = ps.bitBase;
+#pragma unroll
+    for (int w = 0; w < ENC_WAVES; w++) D[w + 1] = D[w] + L[w];
+    // full words go out; the last, partial one stays in the window for whoever continues the stream
+    const uint32_t firstWord = ps.wordBase, endWord = D[ENC_WAVES] >> 5;
+    uint32_t partial = 0;
+    for (uint32_t J = firstWord + tid; J <= endWord; J += ENC_THREADS) {
+        uint32_t val = J == firstWord ? carryWord : 0u;
+#pragma unroll
+        for (int w = 0; w < ENC_WAVES; w++) {
+            const int32_t rel = (int32_t)(32u * J) - (int32_t)D[w];   // first bit of word J inside string w
+            if (rel > -32 && rel < (int32_t)L[w]) {
+                const uint32_t *src = win + w * WAVE_WIN;
+                uint32_t x;
+                if (rel >= 0) {
+                    const uint32_t k = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31u;
+                    x = src[k] >> sh;
+                    if (sh) x |= src[k + 1] << (32u - sh);            // bits beyond L[w] are zero
+                } else {
+                    x = src[0] << (uint32_t)(-rel);
+                }
+                val |= x;
+            }
+        }
+        if (J == endWord) partial = val;
+        else if (J < slotWords) out32[J] = val;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)(WIN_WORDS + WIN_SLACK); i += ENC_THREADS) win[i] = 0;
+    __syncthreads();
+    if (((endWord - firstWord) % ENC_THREADS) == tid) win[0] = partial;      // the thread that computed word endWord
+    ps.wordBase = endWord;
+    ps.bitBase = D[ENC_WAVES];
+    __syncthreads();
+    return true;
+}
