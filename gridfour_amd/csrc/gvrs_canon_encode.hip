@@ -251,7 +251,7 @@ __device__ __forceinline__ void cpack_flat_ranges(const uint32_t *__restrict__ t
 }
 
 // workgroups per CU: the histogram + table kernel is capped at four by its 34 KB of LDS (sweep 4..6: 1.81 / 2.00 / 2.00 ms),
-// the pack kernel runs six (80 VGPRs; eight are no faster)
+// the pack kernel runs six (80 VGPRs; eight, at 64 VGPRs, cost 0.3 ms with the wave-private windows)
 constexpr int CN_AB_WGS = 4, CN_PACK_WGS = 6;
 
 __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncodeArgs a)
