@@ -388,6 +388,58 @@ __device__ __forceinline__ uint32_t p2_elem_max_bits(uint32_t maxLen, uint32_t m
 }
 
 // text of one stream held as an int array
+// elements [begin, end) of a residual array through wave-private bit windows (gvrs_encode_common.h: wave_windows_*), eight
+// consecutive elements per lane; false = a wave's share did not fit its window, nothing was written
+__device__ bool p2_pack_array_waves(const int32_t *__restrict__ arr, uint32_t begin, uint32_t end, const uint32_t *tab,
+                                    uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps,
+                                    uint32_t slotWords)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t carryWord = wave_windows_begin(win, waveSum);
+    const uint32_t quarter = (((end - begin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
+    const uint32_t segBegin = min(end, begin + wave * quarter), segEnd = min(end, segBegin + quarter);
+    uint32_t *wwin = win + wave * WAVE_WIN;
+    uint32_t bits = 0;
+    bool fits = true;
+    for (uint32_t base = segBegin; base < segEnd; base += 64u * CPT) {
+        const uint32_t i0 = base + lane * CPT;
+        uint32_t cl[CPT], xs[CPT];
+        uint32_t myBits = 0, wide = 0;
+#pragma unroll
+        for (int j = 0; j < CPT; j++) xs[j] = i0 + j < segEnd ? (uint32_t)arr[i0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const bool emit = i0 + j < segEnd;
+            const uint32_t x = xs[j];
+            const bool narrow = x + 128u < 256u;
+            const uint32_t e = emit ? (narrow ? tab[x + 128u] : 0u) : 0u;
+            cl[j] = e;
+            myBits += e >> 16;
+            if (emit && !narrow) wide |= 1u << j;
+        }
+        if (wide) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if ((wide >> j) & 1u) myBits += cn_value_bits(tab, xs[j]);
+        }
+        const uint32_t incl = gf_wave_incl_scan(myBits);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (bits + total > WAVE_WIN_BITS) { fits = false; break; }   // wave-uniform
+        if (myBits) {
+            BitSink sink;
+            sink.init(wwin, bits + incl - myBits);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                if ((wide >> j) & 1u) cn_value_emit(sink, tab, xs[j]);
+                else sink.put32(cl[j] & 0xffffu, cl[j] >> 16);
+            }
+            sink.finish();
+        }
+        bits += total;
+    }
+    return wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
+}
+
 __device__ void p2_pack_array(const int32_t *__restrict__ arr, uint32_t n, const uint32_t *tab, uint32_t elemMaxBits,
                               uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps)
 {
@@ -486,16 +538,23 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_pack2(GfPack2Args a)
             const uint32_t n = sidx == 0 ? a.n0 : a.n1;
             uint32_t *h = &S.histR[sidx][rep];
             uint32_t mk = 0, gaps = 0;
-            for (uint32_t i = tid; i < n; i += ENC_THREADS) {
-                const uint32_t x = (uint32_t)arr[i];
-                if (x + 128u < 256u) { atomicAdd(h + (x + 128u) * HIST_R, 1u); continue; }
-                uint32_t kind;
-                const uint32_t target = cn_classify_count(x, &kind);
-                atomicAdd(h + target * HIST_R, 1u);
-                if (kind >= 1u && kind <= 3u) atomicAdd(h + CN_ESC2 * HIST_R, kind);
-                else if (kind >= 4u && kind <= 6u) atomicAdd(h + CN_ESC1 * HIST_R, kind - 3u);
-                if (cn_is_gap(x)) { gaps++; kind = 6u; }
-                mk = max(mk, kind == 7u ? 0u : kind);
+            for (uint32_t i0 = tid; i0 < n; i0 += 4u * ENC_THREADS) {       // four independent loads in flight
+                uint32_t xv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) xv[k] = i0 + k * ENC_THREADS < n ? (uint32_t)arr[i0 + k * ENC_THREADS] : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (i0 + k * ENC_THREADS >= n) break;
+                    const uint32_t x = xv[k];
+                    if (x + 128u < 256u) { atomicAdd(h + (x + 128u) * HIST_R, 1u); continue; }
+                    uint32_t kind;
+                    const uint32_t target = cn_classify_count(x, &kind);
+                    atomicAdd(h + target * HIST_R, 1u);
+                    if (kind >= 1u && kind <= 3u) atomicAdd(h + CN_ESC2 * HIST_R, kind);
+                    else if (kind >= 4u && kind <= 6u) atomicAdd(h + CN_ESC1 * HIST_R, kind - 3u);
+                    if (cn_is_gap(x)) { gaps++; kind = 6u; }
+                    mk = max(mk, kind == 7u ? 0u : kind);
+                }
             }
             if (mk) atomicMax(&P.maxKind[sidx], mk);
             if (gaps) atomicAdd(&P.nGap[sidx], gaps);
@@ -551,7 +610,18 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_pack2(GfPack2Args a)
             const uint32_t n = sidx == 0 ? a.n0 : a.n1;
             p2_append_bits(P.img[sidx], P.imgBits[sidx], S.win, out32, ps);
             const uint32_t emb = max(1u, p2_elem_max_bits(P.maxLen[sidx], P.maxKind[sidx]));
-            p2_pack_array(arr, n, P.tab[sidx], emb, S.win, out32, P.waveSum, ps);
+            {
+                // in as many element ranges as the text's bit count asks for; a range that does not fit goes the old way
+                const unsigned long long tb = P.textBits[sidx];
+                const uint64_t want = (tb + (tb >> 2)) / ENC_WAVES;
+                const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / WAVE_WIN_BITS + 1u);
+                const uint32_t per = (((n + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);
+                for (uint32_t b = 0; b < n; b += per) {
+                    const uint32_t e2 = min(n, b + per);
+                    if (!p2_pack_array_waves(arr, b, e2, P.tab[sidx], S.win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2)))
+                        p2_pack_array(arr + b, e2 - b, P.tab[sidx], emb, S.win, out32, P.waveSum, ps);
+                }
+            }
             const uint32_t e = P.tab[sidx][CN_EOT];
             if (tid == 0) cn_img_or(S.win, ps.bitBase - ps.wordBase * 32u, e & 0xffffu, e >> 16);
             __syncthreads();
