@@ -48,6 +48,13 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
+    # the legacy decoder once more with 512-thread workgroups (large tiles, see gvrs_decode.hip)
+    obj = os.path.join(LIBDIR, "gvrs_decode_t512.o")
+    cmd = [hipcc] + FLAGS + ["-DGF_DEC_THREADS=512", "-DGF_DEC_VARIANT", "-c", os.path.join(CSRC, "gvrs_decode.hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    objs.append(obj)
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd))

@@ -339,7 +339,11 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     } else {
         a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
-        GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
+        // tiles whose M32 stream leaves LDS for ONE 256-thread workgroup per CU run with 512-thread workgroups (measured:
+        // 256x256 tiles 4.51 -> 2.85 ms; at two workgroups per CU -- 200x200 -- the 512-thread form is the slower one)
+        const bool big = (size_t)a.ldsM32Bytes + 4096 + 14336 > (160 * 1024) / 2 && !getenv("GF_DEC_T256");
+        if (big) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
+        else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     }
     return GF_OK;
 }

@@ -41,10 +41,19 @@
 namespace {
 
 constexpr int GF_K_SKIP = 0x7fff0001;           // internal: a diagnostic phase limit ended the tile early
-constexpr int DEC_THREADS = 256;
+// The file is compiled twice: as is (256 threads per workgroup), and with -DGF_DEC_THREADS=512 -DGF_DEC_VARIANT for tiles
+// whose M32 stream leaves room for only one 256-thread workgroup per CU (>= ~57 K cells, e.g. 256x256): twice the waves
+// per tile there.  The variant object exports gf_launch_huffman_decode_t512 only.
+#ifndef GF_DEC_THREADS
+#define GF_DEC_THREADS 256
+#endif
+#ifdef GF_DEC_VARIANT
+#define gf_launch_huffman_decode gf_launch_huffman_decode_t512
+#endif
+constexpr int DEC_THREADS = GF_DEC_THREADS;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int LUT_BITS = 10;                    // first-level window: most symbol PAIRS of terrain data fit 10 bits
-constexpr int MAXQ = 512;                      // subsequences per chain
+constexpr int MAXQ = 2 * GF_DEC_THREADS;         // subsequences per chain: two per thread, advanced in lockstep
 constexpr int HEAD_WORDS = 88;                 // 10 header + 1 + ceil(2559/8) tree bytes = 332 -> 83 words, + slack
 constexpr int MAX_DEPTH = 63;                  // code length limit of the register tree parser
 
@@ -816,7 +825,7 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
 // ANALYZE: CodecHuffman.analyze mode (statistics instead of values); a separate instantiation so that the decode proper
 // keeps its register allocation
 template <bool ANALYZE>
-__global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
@@ -1033,6 +1042,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_huffman_decode(GfDecodeArgs 
     }
 }
 
+#ifndef GF_DEC_VARIANT
 // ---------------------------------------------------------------------------------------------------------------
 // LsDecoder12.decode for the containers that carry CodecM32 bytes (lsop/LsDecoder12.java:107-150): header (either
 // revision, lsop/LsHeader.java:131-185), then the initialiser and interior M32 streams -- type 0: two legacy Huffman
@@ -1262,8 +1272,11 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     rec[4] = (uint32_t)uniformSym;
 }
 
+#endif  // GF_DEC_VARIANT
+
 }  // namespace
 
+#ifndef GF_DEC_VARIANT
 uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
 {
     // typical M32 streams are ~1.0-1.1 bytes per cell; larger ones spill to the workspace
@@ -1275,6 +1288,8 @@ uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
     return (uint32_t)((want + 31) & ~(size_t)31);
 }
 
+#endif
+
 // dynamic LDS bytes for a given M32 capacity: bytes + start bitmap + rank bases
 static size_t decodeDynLds(uint32_t ldsM32Bytes, uint32_t ldsTextBytes)
 {
@@ -1283,6 +1298,7 @@ static size_t decodeDynLds(uint32_t ldsM32Bytes, uint32_t ldsTextBytes)
     return (size_t)ldsM32Bytes + (bm > 2 * L2_ENTRIES ? bm : 2 * L2_ENTRIES) + ldsTextBytes;
 }
 
+#ifndef GF_DEC_VARIANT
 uint32_t gf_huffman_decode_lds_text(int nRows, int nCols)
 {
     // LDS copy of the packing text: measured on MI355X (ETOPO1-shaped batch) the copy makes a decode
@@ -1298,6 +1314,8 @@ unsigned gf_huffman_decode_grid(size_t nTiles)
     const size_t cap = 256 * 8;                    // workgroups resident on the chip, upper bound
     return (unsigned)(nTiles < cap ? (nTiles ? nTiles : 1) : cap);
 }
+
+#endif
 
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid)
 {
@@ -1318,6 +1336,7 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
     return hipGetLastError();
 }
 
+#ifndef GF_DEC_VARIANT
 hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream, unsigned grid)
 {
     if (a.nTiles == 0) return hipSuccess;
@@ -1341,3 +1360,4 @@ hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, 
                        slotStride, lengths, trees, nTiles);
     return hipGetLastError();
 }
+#endif  // GF_DEC_VARIANT

@@ -86,6 +86,7 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
 
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
+hipError_t gf_launch_huffman_decode_t512(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);   // 512-thread workgroups
 unsigned gf_huffman_decode_grid(size_t nTiles);
 uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols);
 uint32_t gf_huffman_decode_lds_text(int nRows, int nCols);
