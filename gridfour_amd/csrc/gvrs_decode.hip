@@ -430,13 +430,11 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
 }
 
 
-// v_writelane_b32 (this hipcc has no builtin for it): lane `lane` of `old` becomes the wave-uniform `value`
+// lane `lane` of `old` becomes the wave-uniform `value` (this hipcc has no v_writelane builtin; a compare and a select
+// do the same without inline assembly)
 __device__ __forceinline__ int gf_writelane(int value, int lane, int old)
 {
-    const int sv = __builtin_amdgcn_readfirstlane(value), sl = __builtin_amdgcn_readfirstlane(lane);   // into SGPRs
-    // gfx9: one SGPR per VALU instruction -- the lane select goes through M0
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sv), "s"(sl) : "m0");
-    return old;
+    return (int)(threadIdx.x & 63u) == lane ? value : old;
 }
 
 // HuffmanDecoder.decodeTree (HuffmanDecoder.java:65-161), run by ONE wave.  S.head holds the packing words around the
