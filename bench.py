@@ -148,7 +148,7 @@ def run_float(args, ctx, rank, world, dist, torch):
         parity_ok = all(planes[t, :nb].tobytes() == bytes(oracle.float_planes_encode(n_rows, n_cols, vals[t].view(np.uint32)))
                         for t in range(0, n_tiles, max(1, n_tiles // 16)))
         bit_exact = bool(roundtrip_ok and parity_ok)
-        ns = args.cpu_sample_tiles if args.cpu_sample_tiles >= 0 else 48
+        ns = args.cpu_sample_tiles if args.cpu_sample_tiles >= 0 else min(n_tiles, 400)    # ~10 s: zlib level 9 dominates
         if ns > 0 and world == 1:
             sub = vals[:ns]
             mb = sub.nbytes / 1e6
@@ -307,7 +307,7 @@ def main():
         # ---------------- CPU baseline: the oracle ("port"), 1 core, bounded sample ----------------
         ns = args.cpu_sample_tiles
         if ns < 0:
-            ns = min(n_tiles, max(64, int(300e6 / (4 * cells))))    # about 300 MB of tiles: ~10 s of CPU work
+            ns = min(n_tiles, max(64, int(1200e6 / (4 * cells))))   # up to 1.2 GB of tiles: 9-20 s of CPU work on one core
         if ns > 0 and world == 1:
             sub = vals[:ns]
             c0 = time.perf_counter()
