@@ -349,7 +349,6 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 
     for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
-        uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
 
         GF_STAMP(0);
         // ---------------- phase A: null scan + three histograms ----------------

@@ -774,7 +774,6 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
     const uint32_t wI = nC - 4u, nInt = lsop_n_interior(nR, nC);
     const uint32_t perWave = 64u * 16u + 4u * nC;
     uint32_t *L = reconLds + (size_t)wave * perWave;
-    uint32_t *ring = L;                                   // [64][16]
     const uint32_t RING = 0, ROWS = 64u * 16u;            // word offsets inside L
 
     for (size_t t = wid; t < a.nTiles; t += wavesPerGrid) {
