@@ -1,12 +1,14 @@
 #!/bin/bash
 # HBM traffic of the encode / decode kernels from the L2 memory-side counters (separate passes for
 # FETCH_SIZE and WRITE_SIZE as MI355X_MICROARCH.md prescribes; KB units, FETCH_SIZE doubled on gfx950).
-# usage: tools/pmc_hbm.sh <outdir> [workload]
-OUT=${1:-gpurun_out/hbm}; WL=${2:-etopo1}
+# usage: tools/pmc_hbm.sh <outdir> [workload] ["huffman canon lsop"]   (kernels of all listed codecs go into one JSON)
+OUT=${1:-gpurun_out/hbm}; WL=${2:-etopo1}; CODECS=${3:-huffman}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $OUT
+for k in $CODECS; do
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/$c -- python3 tools/run_kernels.py both 0 0 3 $WL > $OUT/$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/$c/$k -- python3 tools/run_kernels.py both 0 0 3 $WL $k > $OUT/$c.$k.log 2>&1
+done
 done
 python3 - <<PY
 import csv, glob, collections, json, re

@@ -1,5 +1,5 @@
 """Runs the encode and/or decode kernel a few times on a bench workload, optionally phase-limited
-(diagnostic driver for rocprofv3 --pmc runs).  usage: run_kernels.py <enc|dec|both> <encLimit> <decLimit> <reps> [workload]"""
+(diagnostic driver for rocprofv3 --pmc runs).  usage: run_kernels.py <enc|dec|both> <encLimit> <decLimit> <reps> [workload] [huffman|canon|lsop]"""
 import ctypes as C
 import os
 import sys
@@ -13,10 +13,11 @@ from gridfour_amd import DeviceTileBatch, lib  # noqa: E402
 def main():
     which, el, dl, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     wl = sys.argv[5] if len(sys.argv) > 5 else "etopo1"
+    codec = sys.argv[6] if len(sys.argv) > 6 else "huffman"
     n_rows, n_cols, nt, tpr = {"etopo1": (120, 150, 12960, 144), "dem1024": (200, 200, 1024, 32)}[wl]
     ctx = gridfour_amd.GvrsHipContext(0)
     cells = n_rows * n_cols
-    b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * cells + 1024 + 15) // 16 * 16)
+    b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * cells + 1024 + 15) // 16 * 16, codec=codec)
     b.synth_dem(0x9E3779B97F4A7C15 + 2, tpr)
     L = lib()
     L.gf_internal_set_phase_limits.argtypes = [C.c_int, C.c_int]
