@@ -77,6 +77,7 @@ struct DecShared {
     uint8_t qdirty[MAXQ];
     uint32_t head[HEAD_WORDS];
     uint32_t waveSum[DEC_WAVES];
+    uint32_t fusedTot[2 * 3 * DEC_WAVES];      // m32_to_tile: wave totals of the chunk scans, double-buffered
     uint32_t carry;
     uint32_t textStart;                        // bit offset of the Huffman text in the packing
     int32_t parseStatus;
@@ -639,13 +640,13 @@ struct CellMapIdentity {
     __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return k; }
 };
 
-template <class M32Ptr, class BmPtr, class Map>
-__device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint32_t nM32, BmPtr bm, BmPtr wb, uint32_t nStream,
-                                                 const Map map, uint32_t *o, uint32_t *stamps)
+// Marks the bytes of m32[0..nM32) that start a value (bitmap bm) and ranks them (wb[w] = number of starts before bitmap
+// word w); S.carry = number of values in the stream.  Whole workgroup; ends with a barrier.
+template <class M32Ptr, class BmPtr>
+__device__ __forceinline__ void m32_mark_starts(DecShared &S, M32Ptr m32, uint32_t nM32, BmPtr bm, BmPtr wb)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t bmWords = (nM32 + 31u) >> 5;
-    int32_t tileStatus = GF_K_OK;
     M32Cursor cur;
     cur.m = m32;
     cur.n = nM32;
@@ -709,14 +710,13 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
         }
     }
     __syncthreads();
-    if (stamps && tid == 0) stamps[6] = (uint32_t)__builtin_amdgcn_s_memtime();
     if (S.dense) {
         // chain resolution over the bytes (same scheme as the Huffman text), then mark the starts
         for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
         uint32_t unit = (nM32 + MAXQ - 1) / MAXQ;
         unit = max(16u, unit);
         const uint32_t Q = max(1u, (nM32 + unit - 1) / unit);
-        resolve_chain<0>(S, cur, 0u, nM32, unit, Q, 8u, stamps ? stamps + 13 : nullptr);   // warm-up: 8 bytes
+        resolve_chain<0>(S, cur, 0u, nM32, unit, Q, 8u);   // warm-up: 8 bytes
         for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
             const uint32_t limit = min(nM32, (q + 1) * unit);
             M32Cursor c = cur;
@@ -749,7 +749,17 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
         if (tid == 0) S.carry += tot;
         __syncthreads();
     }
-    if (stamps && tid == 0) stamps[7] = (uint32_t)__builtin_amdgcn_s_memtime();
+}
+
+template <class M32Ptr, class BmPtr, class Map>
+__device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint32_t nM32, BmPtr bm, BmPtr wb, uint32_t nStream,
+                                                 const Map map, uint32_t *o)
+{
+    const uint32_t tid = threadIdx.x;
+    int32_t tileStatus = GF_K_OK;
+    const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
+    const uint32_t nDw = (nM32 + 3u) >> 2;
+    m32_mark_starts(S, m32, nM32, bm, wb);
     if (S.carry < nStream) tileStatus = GF_K_ERR_BOUNDS;         // predictor reads past codeM32s
     // four byte positions per thread and step: consecutive bytes are (mostly) consecutive cells,
     // so the stores of a wave are coalesced.  12 bytes of the buffer cover every value that
@@ -812,6 +822,320 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
     __syncthreads();
     if (tileStatus == GF_K_OK && S.chainEnd > nM32) tileStatus = GF_K_ERR_BOUNDS;   // last value truncated
     return tileStatus;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused phases 2 + 3: M32 bytes -> cell values, every cell stored to HBM exactly once.
+//
+// The predictor inverses are prefix sums (int32 wrap-around), so they run on the residuals while these are still on the
+// chip.  With F = running sum of the residuals in STREAM order (the order the reference emits them, row-major inside
+// the interior), a row's own prefix is F minus F at the row start, and what is left per model is a per-row constant:
+//   Differencing (PredictorModelDifferencing.java:145-167)   v(r,c) = C(r) + F(r,c) - F(r,0)
+//   Linear       (PredictorModelLinear.java:66-101)          v(r,c) = v(r,1) + (c-1) (d1(r) - F1ex(r)) + F2(r,c) - F2ex(r),
+//                F2 = running sum of F1 (the second differences are summed twice), d1 = v(r,1) - v(r,0)
+//   Triangle     (PredictorModelTriangle.java:62-98)         v(r,c) = v(r-1,c) + c0(r) + F(r,c) - Fex(r)   (2-D prefix sum)
+// C(r) = column 0 (a running sum over the rows of the column-0 residuals), Fex = F just before the row's first interior
+// element.  The border residuals (column 0; row 0 for Triangle; column 1 for Linear) sit at stream positions known in
+// closed form and are fetched once per tile by select() on the start bitmap.
+//
+// The M32 bytes are swept in chunks of DEC_THREADS dwords (<= 4 values per thread): decode, workgroup scan, F into a ring
+// in LDS (the decode tables of phase 1 are dead by now: the ring and three per-row arrays alias them); the rows a chunk
+// completes are then finished from the ring -- lane = consecutive cells of a row, so every store instruction writes
+// whole contiguous lines -- and for Triangle the column recurrence is carried in a register per column.
+constexpr uint32_t SCR_WORDS = offsetof(DecShared, qdirty) / 4;   // lut .. qn: free after phase 1
+constexpr uint32_t FUSED_CHUNK = 4u * DEC_THREADS;                // values a chunk can hold at most
+
+struct FusedPlan {
+    uint32_t ring;          // ring entries (0 = tile shape not eligible)
+    bool endBarrier;        // the ring is too short to overlap the next chunk's writes with this chunk's reads
+};
+__device__ __forceinline__ FusedPlan fused_plan(uint32_t nR, uint32_t nC)
+{
+    FusedPlan p;
+    p.ring = 0;
+    p.endBarrier = false;
+    // nC <= 2 * DEC_THREADS: two column registers per thread (Triangle); the products behind the reciprocal divisions stay
+    // below 2^32 by a wide margin at these sizes
+    if (nR < 2u || nC < 4u || nC > 2u * DEC_THREADS || nR > 4096u || 3u * nR + nC + FUSED_CHUNK + 1u > SCR_WORDS) return p;
+    const uint32_t avail = SCR_WORDS - 3u * nR;
+    p.ring = avail;
+    p.endBarrier = avail < 2u * FUSED_CHUNK + nC;
+    return p;
+}
+
+// byte position of value start number k (k < number of starts)
+template <class BmPtr>
+__device__ __forceinline__ uint32_t m32_select(BmPtr bm, BmPtr wb, uint32_t bmWords, uint32_t k)
+{
+    uint32_t lo = min(k >> 5, bmWords - 1u), hi = bmWords;      // every value has at least one byte: word >= k / 32
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (wb[mid] <= k) lo = mid;
+        else hi = mid;
+    }
+    uint32_t x = bm[lo], j = k - wb[lo], pos = 0;
+    uint32_t c = (uint32_t)__popc(x & 0xffffu);
+    if (j >= c) { j -= c; pos += 16u; x >>= 16; }
+    c = (uint32_t)__popc(x & 0xffu);
+    if (j >= c) { j -= c; pos += 8u; x >>= 8; }
+    c = (uint32_t)__popc(x & 0xfu);
+    if (j >= c) { j -= c; pos += 4u; x >>= 4; }
+    c = (uint32_t)__popc(x & 0x3u);
+    if (j >= c) { j -= c; pos += 2u; x >>= 2; }
+    if (j >= (x & 1u)) pos += 1u;
+    return (lo << 5) + pos;
+}
+
+// the value that starts at byte p of the stream; *len = its byte count
+template <class M32Ptr>
+__device__ __forceinline__ uint32_t m32_value_at(M32Ptr m32, uint32_t nM32, uint32_t p, uint32_t *len)
+{
+    M32Cursor c;
+    c.m = m32;
+    c.n = nM32;
+    c.seek(p);
+    uint32_t lo, hi;
+    c.prepare(&lo, &hi);
+    return m32_value(lo, hi, len);
+}
+
+template <class M32Ptr, class BmPtr>
+__device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_t nM32, BmPtr bm, BmPtr wb, const int model,
+                                               const uint32_t seed, const uint32_t nR, const uint32_t nC, const uint32_t nStream,
+                                               const FusedPlan plan, uint32_t *__restrict__ o)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
+    const uint32_t nDw = (nM32 + 3u) >> 2, bmWords = (nM32 + 31u) >> 5;
+    m32_mark_starts(S, m32, nM32, bm, wb);
+    const uint32_t nValues = S.carry;
+    if (nValues < nStream) return GF_K_ERR_BOUNDS;               // predictor reads past codeM32s
+
+    uint32_t *scr = reinterpret_cast<uint32_t *>(&S);
+    const uint32_t RING = plan.ring;
+    uint32_t *ring = scr, *rowA = scr + RING, *rowB = rowA + nR, *rowC = rowB + nR;
+    const uint32_t magicR = (uint32_t)(((1ull << 32) + RING - 1u) / RING);
+    auto ringIdx = [&](uint32_t t) -> uint32_t { return t - __umulhi(t, magicR) * RING; };   // t * RING < 2^32
+
+    // interior stream: element k of the stream is interior element t = k + tOff (t < 0: border), rows of W elements
+    const uint32_t W = model == 1 ? nC : model == 2 ? nC - 2u : nC - 1u;
+    const uint32_t nB = model == 1 ? 0u : model == 2 ? 2u * nR - 1u : nC + nR - 2u;
+    const uint32_t tOff = model == 1 ? 1u : 0u - nB;
+    const uint32_t nRowsI = model == 3 ? nR - 1u : nR;
+    const uint32_t magicW = (uint32_t)(((1ull << 32) + W - 1u) / W);
+    const uint32_t magicC = (uint32_t)(((1ull << 32) + nC - 1u) / nC);
+
+    // ---- borders: per-row constants (and row 0 of Triangle) ----
+    uint32_t colPrev0 = 0, colPrev1 = 0;
+    {
+        uint32_t vlen;
+        if (model == 3) {
+            // row 0: stream elements 0 .. nC-2 are cells (0,1) .. (0,nC-1), each relative to its left neighbour
+            uint32_t carry = seed;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
+                if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
+                const uint32_t x = (c >= 1u && c < nC) ? m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, c - 1u), &vlen) : 0u;
+                uint32_t tot;
+                const uint32_t v = carry + block_excl_scan(x, S.waveSum, &tot) + x;
+                if (c < nC) o[c] = v;
+                if (u == 0) colPrev0 = v;
+                else colPrev1 = v;
+                carry += tot;
+            }
+        }
+        uint32_t carry = seed;
+        for (uint32_t rb = 0; rb < nR; rb += DEC_THREADS) {
+            const uint32_t r = rb + tid;
+            uint32_t x0 = 0, x1 = 0;
+            if (r < nR) {
+                if (model == 1) {
+                    if (r >= 1u) x0 = m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, r * nC - 1u), &vlen);
+                } else if (model == 3) {
+                    if (r >= 1u) x0 = m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, nC - 2u + r), &vlen);
+                } else {
+                    // Linear: element 0 is cell (0,1); elements 2r-1, 2r are cells (r,0), (r,1)
+                    uint32_t p = m32_select(bm, wb, bmWords, r >= 1u ? 2u * r - 1u : 0u);
+                    if (r >= 1u) {
+                        x0 = m32_value_at(m32, nM32, p, &vlen);
+                        p += vlen;
+                    }
+                    x1 = m32_value_at(m32, nM32, p, &vlen);
+                }
+            }
+            uint32_t tot;
+            const uint32_t cv = carry + block_excl_scan(x0, S.waveSum, &tot) + x0;
+            if (r < nR) {
+                rowA[r] = cv;                                    // column 0
+                rowB[r] = model == 3 ? x0 : x1;                  // Triangle: column-0 residual; Linear: v(r,1) - v(r,0)
+            }
+            carry += tot;
+        }
+        if (tid == 0) ring[model == 1 ? 0u : RING - 1u] = 0u;     // F before the first interior element
+    }
+    // (the scan barrier of the first chunk orders these stores before the first reads)
+
+    uint32_t carry1 = 0, carry2 = 0, rowsDone = 0;
+    const uint32_t nIter = (nDw + DEC_THREADS - 1u) / DEC_THREADS;
+    for (uint32_t it = 0; it < nIter; it++) {
+        const uint32_t dw = it * DEC_THREADS + tid;
+        // ---- decode: up to four values, slot j = the value that starts at byte j of the thread's dword ----
+        uint32_t bits = 0, k = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (dw < nDw) {
+            const uint32_t i0 = dw << 2;
+            const uint32_t word = bm[i0 >> 5];
+            bits = (word >> (i0 & 31u)) & 0xfu;
+            if (bits) {
+                k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
+                uint32_t d0 = m32w[dw];
+                const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
+                const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) &
+                                         0x80808080u;
+                if (bits == 0xfu && !special) {
+                    v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu);
+                    v1 = (uint32_t)((int32_t)(d0 << 16) >> 24);
+                    v2 = (uint32_t)((int32_t)(d0 << 8) >> 24);
+                    v3 = (uint32_t)((int32_t)d0 >> 24);
+                } else {
+                    uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
+                    if (i0 + 12 > nM32) {
+                        const uint32_t valid = nM32 - i0;        // 1..11 bytes
+                        if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
+                        if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
+                        d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
+                    }
+                    uint32_t kk = k;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if ((bits >> j) & 1u) {
+                            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
+                            const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
+                            uint32_t vlen;
+                            const uint32_t val = m32_value(lo, hi, &vlen);
+                            if (j == 0) v0 = val;
+                            else if (j == 1) v1 = val;
+                            else if (j == 2) v2 = val;
+                            else v3 = val;
+                            if (kk == nStream - 1u) S.chainEnd = i0 + j + vlen;
+                            kk++;
+                        }
+                    }
+                }
+            }
+        }
+        // stream index of every slot; a slot counts if it holds an interior element of the stream
+        const uint32_t b0 = bits & 1u, b1 = (bits >> 1) & 1u, b2 = (bits >> 2) & 1u, b3 = (bits >> 3) & 1u;
+        const uint32_t t0 = k + tOff, t1 = t0 + b0, t2 = t1 + b1, t3 = t2 + b2;
+        const uint32_t tLim = nStream + tOff;                    // interior elements: 0 <= t < tLim (t as int32)
+        const bool ok0 = b0 && t0 < tLim, ok1 = b1 && t1 < tLim, ok2 = b2 && t2 < tLim, ok3 = b3 && t3 < tLim;
+        const uint32_t f0 = ok0 ? v0 : 0u, f1 = f0 + (ok1 ? v1 : 0u), f2 = f1 + (ok2 ? v2 : 0u), f3 = f2 + (ok3 ? v3 : 0u);
+        const uint32_t incl1 = gf_wave_incl_scan(f3);
+        uint32_t exclN = 0, exclQ = 0;
+        // wave totals, double-buffered by chunk parity so that one barrier per chunk suffices: [parity][quantity][wave]
+        uint32_t *wt = S.fusedTot + (it & 1u) * (3u * DEC_WAVES);
+        if (model == 2) {
+            const uint32_t nv = (uint32_t)ok0 + (uint32_t)ok1 + (uint32_t)ok2 + (uint32_t)ok3;
+            const uint32_t q = nv * (incl1 - f3) + (ok0 ? f0 : 0u) + (ok1 ? f1 : 0u) + (ok2 ? f2 : 0u) + (ok3 ? f3 : 0u);
+            const uint32_t inclN = gf_wave_incl_scan(nv), inclQ = gf_wave_incl_scan(q);
+            exclN = inclN - nv;
+            exclQ = inclQ - q;
+            if (lane == 63u) { wt[DEC_WAVES + wave] = inclN; wt[2 * DEC_WAVES + wave] = inclQ; }
+        }
+        if (lane == 63u) wt[wave] = incl1;
+        __syncthreads();
+        uint32_t base1 = carry1, base2 = carry2;                 // F1 / F2 before this wave's first element
+        {
+            uint32_t c1 = carry1, c2 = carry2;
+#pragma unroll
+            for (uint32_t w = 0; w < (uint32_t)DEC_WAVES; w++) {
+                if (w == wave) { base1 = c1; base2 = c2; }
+                if (model == 2) c2 += wt[DEC_WAVES + w] * c1 + wt[2 * DEC_WAVES + w];
+                c1 += wt[w];
+            }
+            carry1 = c1;
+            carry2 = c2;
+        }
+        {
+            const uint32_t e1 = base1 + (incl1 - f3);            // F1 before this thread's first slot
+            uint32_t F0 = e1 + f0, F1 = e1 + f1, F2 = e1 + f2, F3 = e1 + f3;
+            if (model == 2) {
+                uint32_t g = base2 + base1 * exclN + exclQ;      // F2 before this thread's first slot
+                const uint32_t G0 = g + F0;
+                g = ok0 ? G0 : g;
+                const uint32_t G1 = g + F1;
+                g = ok1 ? G1 : g;
+                const uint32_t G2 = g + F2;
+                g = ok2 ? G2 : g;
+                const uint32_t G3 = g + F3;
+                // F1 at the end of a row: the next row's F1ex
+                if (ok0) { const uint32_t r = __umulhi(t0, magicW); if (t0 - r * W == W - 1u) rowC[r] = F0; }
+                if (ok1) { const uint32_t r = __umulhi(t1, magicW); if (t1 - r * W == W - 1u) rowC[r] = F1; }
+                if (ok2) { const uint32_t r = __umulhi(t2, magicW); if (t2 - r * W == W - 1u) rowC[r] = F2; }
+                if (ok3) { const uint32_t r = __umulhi(t3, magicW); if (t3 - r * W == W - 1u) rowC[r] = F3; }
+                F0 = G0; F1 = G1; F2 = G2; F3 = G3;
+            }
+            if (ok0) ring[ringIdx(t0)] = F0;
+            if (ok1) ring[ringIdx(t1)] = F1;
+            if (ok2) ring[ringIdx(t2)] = F2;
+            if (ok3) ring[ringIdx(t3)] = F3;
+        }
+        __syncthreads();
+        // ---- rows completed by this chunk ----
+        uint32_t kEnd;
+        {
+            const uint32_t pEnd = (it + 1u) * FUSED_CHUNK;       // multiple of 32
+            kEnd = pEnd >= nM32 ? nValues : wb[pEnd >> 5];
+            kEnd = min(kEnd, nStream);
+        }
+        const uint32_t tEnd = kEnd + tOff;
+        uint32_t rowsNew = (int32_t)tEnd > 0 ? min(nRowsI, __umulhi(tEnd, magicW)) : 0u;
+        rowsNew = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowsNew);
+        if (model == 1) {
+            const uint32_t cellHi = rowsNew * nC;
+            for (uint32_t cell = rowsDone * nC + tid; cell < cellHi; cell += DEC_THREADS) {
+                const uint32_t r = __umulhi(cell, magicC);
+                o[cell] = rowA[r] + ring[ringIdx(cell)] - ring[ringIdx(r * nC)];
+            }
+        } else if (model == 2) {
+            const uint32_t cellHi = rowsNew * nC;
+            for (uint32_t cell = rowsDone * nC + tid; cell < cellHi; cell += DEC_THREADS) {
+                const uint32_t r = __umulhi(cell, magicC), c = cell - r * nC;
+                const uint32_t cv = rowA[r], d1 = rowB[r];
+                uint32_t v = cv;
+                if (c == 1u) v = cv + d1;
+                else if (c >= 2u) {
+                    const uint32_t tS = r * W;
+                    const uint32_t F1ex = r ? rowC[r - 1u] : 0u, F2ex = ring[ringIdx(tS + RING - 1u)];
+                    v = cv + d1 + (c - 1u) * (d1 - F1ex) + ring[ringIdx(tS + c - 2u)] - F2ex;
+                }
+                o[cell] = v;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
+                if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
+                if (c < nC) {
+                    uint32_t cp = u == 0 ? colPrev0 : colPrev1;
+                    for (uint32_t row = rowsDone; row < rowsNew; row++) {
+                        const uint32_t r = row + 1u, tS = row * W;
+                        uint32_t v;
+                        if (c == 0u) v = rowA[r];
+                        else v = cp + rowB[r] + ring[ringIdx(tS + c - 1u)] - ring[ringIdx(tS + RING - 1u)];
+                        cp = v;
+                        o[(size_t)r * nC + c] = v;
+                    }
+                    if (u == 0) colPrev0 = cp;
+                    else colPrev1 = cp;
+                }
+            }
+        }
+        rowsDone = rowsNew;
+        if (plan.endBarrier) __syncthreads();
+    }
+    __syncthreads();
+    return S.chainEnd > nM32 ? GF_K_ERR_BOUNDS : GF_K_OK;       // last value truncated
 }
 
 #define GF_DSTAMP(i)                                                                   \
@@ -934,6 +1258,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
         // Phases 1 and 2 run on the M32 buffer, its start bitmap and the rank bases -- in LDS, or in the workspace for
         // tiles whose stream does not fit.  The body is instantiated once per memory space: with a pointer that may be
         // either, every access would be a flat_* instruction (slow even when it lands in LDS).
+        bool fused = false;                                           // the predictor inverse ran inside phase 2
         auto phases12 = [&](auto inLds) -> int32_t {
             uint8_t *m32;
             uint32_t *bm, *wb;
@@ -1013,12 +1338,20 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                 return (int32_t)GF_K_SKIP;
             }
 
+            // ---------------- phases 2 + 3 fused: M32 bytes -> values, one store per cell ----------------
+            if constexpr (decltype(inLds)::value) {
+                const FusedPlan plan = fused_plan(nR, nC);
+                if (plan.ring && model >= 1 && model <= 3) {
+                    fused = true;
+                    return m32_to_tile(S, m32, nM32, bm, wb, model, seed, nR, nC, nStream, plan, o);
+                }
+            }
             // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
             {
                 const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
                 const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
                 const CellMapPredictor map{model, nR, nC, (uint32_t)(((1ull << 32) + wMain - 1) / wMain), useMagic && wMain > 1};
-                tileStatus = m32_to_values(S, m32, nM32, bm, wb, nStream, map, o, a.debug ? a.debug + t * 16 : nullptr);
+                tileStatus = m32_to_values(S, m32, nM32, bm, wb, nStream, map, o);
             }
             return tileStatus;
         };
@@ -1033,7 +1366,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
         if ((a.phaseLimit & 0xff) == 3) continue;
 
         // ---------------- phase 3: predictor inverse (wrap-around prefix sums) ----------------
-        gf_predictor_inverse(model, seed, o, nR, nC, a.debug ? a.debug + t * 16 + 9 : nullptr);
+        if (!fused) gf_predictor_inverse(model, seed, o, nR, nC, a.debug ? a.debug + t * 16 + 9 : nullptr);
         GF_DSTAMP(10);
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();
@@ -1160,7 +1493,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
                 }
                 const uint32_t segEnd = S.chainEnd;
                 __syncthreads();                                          // m32_to_values reuses chainEnd
-                const int32_t st = m32_to_values(S, m32, nM32, bm, wb, nVals, CellMapIdentity{}, out, nullptr);
+                const int32_t st = m32_to_values(S, m32, nM32, bm, wb, nVals, CellMapIdentity{}, out);
                 startBit = segEnd;
                 rawAt += nM32;
                 return st;
