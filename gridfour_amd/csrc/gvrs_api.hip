@@ -71,6 +71,7 @@ struct gf_context {
     hipStream_t stream = nullptr;
     DevBuf workspace;      // decode spill: grid * 6*cells
     DevBuf trees;          // leaf records of the tree pre-pass: GF_TREE_REC_WORDS per tile
+    DevBuf flags;          // one word: tiles the fast decode kernel left to the general one (GfDecodeArgs::retryFlag)
     DevBuf packRecs;       // encoder: selection records between k_huffman_encode and k_huffman_pack
     // staging for the host-memory entry points
     DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
@@ -159,6 +160,12 @@ gf_status gf_context_create(int device, gf_context **out)
         hipFail(e, "hipStreamCreate");
         return GF_ERR_NO_DEVICE;
     }
+    gf_status s = c->flags.ensure(64);
+    if (s != GF_OK) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return s;
+    }
     *out = c;
     return GF_OK;
 }
@@ -170,6 +177,7 @@ void gf_context_destroy(gf_context *c)
     (void)hipStreamSynchronize(c->stream);
     c->workspace.release();
     c->trees.release();
+    c->flags.release();
     c->packRecs.release();
     c->dValues.release();
     c->dSlots.release();
@@ -308,6 +316,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     a.rawM32 = kind == KIND_RAW_M32 ? 1 : 0;
     a.analysis = analysis;
     a.trees = nullptr;
+    a.retryFlag = nullptr;
     if (kind == KIND_HUFFMAN) {
         // tree pre-pass: one lane per tile walks the serialised tree; the decode kernel starts from the leaf records
         const size_t need = nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16;
@@ -319,6 +328,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         GF_HIP(gf_launch_huffman_parse_trees(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
                                              stream ? (hipStream_t)stream : c->stream));
         a.trees = (const uint32_t *)c->trees.p;
+        if (!analysis) a.retryFlag = (uint32_t *)c->flags.p;
     }
     if (kind == KIND_CANON) {
         // the same for the canonical decoder's code lengths

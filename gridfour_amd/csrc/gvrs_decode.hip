@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "gvrs_kernels.h"
@@ -1138,26 +1139,54 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     return S.chainEnd > nM32 ? GF_K_ERR_BOUNDS : GF_K_OK;       // last value truncated
 }
 
+// Diagnostics (cycle stamps per phase, phase ablation, warm-up sweep) exist only in the -DGF_DIAG build that tools/ use
+// (gridfour_amd/build.py: libgvrs_hip_diag.so); the shipping kernels carry none of it.
+#ifdef GF_DIAG
 #define GF_DSTAMP(i)                                                                   \
     do {                                                                               \
         if (a.debug && tid == 0) (a.debug + t * 16)[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
     } while (0)
+#define GF_DPHASE_LIMIT(n, what) \
+    if ((a.phaseLimit & 0xff) == (n)) what
+#else
+#define GF_DSTAMP(i) do { } while (0)
+#define GF_DPHASE_LIMIT(n, what)
+#endif
 
+constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel leaves this tile to the general one
 
-// ANALYZE: CodecHuffman.analyze mode (statistics instead of values); a separate instantiation so that the decode proper
-// keeps its register allocation
-template <bool ANALYZE>
+// One kernel body, three instantiations:
+//   DEC_FAST     what a CodecHuffman batch consists of: tree records from the pre-pass, M32 stream in LDS, text read from
+//                global memory, fused value decode + predictor inverse.  Anything else (stream larger than its LDS buffer,
+//                nulls predictor, tile shapes the fused stage does not take) is marked GF_K_RETRY and left to
+//   DEC_GENERAL  every container the codec accepts (CodecDeflate's raw M32 bytes, trees parsed in the kernel, spill
+//                workspace, the unfused value pass + in-place inverse).  With a.retryFlag it touches only the tiles the fast
+//                kernel marked, and returns at once when there are none.
+//   DEC_ANALYZE  CodecHuffman.analyze: statistics instead of values.
+// The general body is several times the size of the fast one; run for every tile it kept the instruction cache of a CU
+// (shared by the workgroups of different phases) missing.
+enum { DEC_GENERAL = 0, DEC_ANALYZE = 1, DEC_FAST = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
+    constexpr bool ANALYZE = MODE == DEC_ANALYZE;
+    constexpr bool FAST = MODE == DEC_FAST;
 
     const int tid = threadIdx.x, wave = tid >> 6;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
+    if constexpr (MODE == DEC_GENERAL) {
+        if (a.retryFlag && *a.retryFlag == 0u) return;               // the fast kernel decoded every tile
+    }
 
     for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if constexpr (MODE == DEC_GENERAL) {
+            if (a.retryFlag && a.status[t] != GF_K_RETRY) continue;
+        }
         const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
         const uint32_t len = a.lengths[t];
         uint32_t *o = reinterpret_cast<uint32_t *>(a.values) + t * (size_t)nCells;
@@ -1174,7 +1203,8 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
         {
             uint8_t *hb = reinterpret_cast<uint8_t *>(S.head);
             const uint32_t nh = min(len, (uint32_t)(HEAD_WORDS * 4));
-            for (uint32_t i = tid; i < HEAD_WORDS * 4; i += DEC_THREADS) hb[i] = i < nh ? pk[i] : 0;
+            constexpr uint32_t nHead = FAST ? 12u : (uint32_t)(HEAD_WORDS * 4);      // the fast kernel needs the 10 header bytes only
+            for (uint32_t i = tid; i < nHead; i += DEC_THREADS) hb[i] = i < nh ? pk[i] : 0;
         }
         __syncthreads();
         const uint8_t *hb = reinterpret_cast<const uint8_t *>(S.head);
@@ -1188,6 +1218,13 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
         else if ((uint64_t)nM32 > 6ull * nCells) early = GF_K_ERR_FORMAT; // no encoder emits this
         else if ((model == 2 && nC < 2)) early = GF_K_ERR_BOUNDS;       // PredictorModelLinear.java:80 output[1]
         else if (nM32 < nStream) early = GF_K_ERR_BOUNDS;               // M32 reads run off codeM32s
+        const FusedPlan plan = fused_plan(nR, nC);
+        if constexpr (FAST) {
+            if (early == GF_K_OK && (nM32 > a.ldsM32Bytes || model > 3 || !plan.ring)) {
+                early = GF_K_RETRY;
+                if (tid == 0) atomicOr(a.retryFlag, 1u);
+            }
+        }
         if (early != GF_K_OK) {
             if (tid == 0) a.status[t] = early;
             __syncthreads();
@@ -1195,9 +1232,9 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
         }
 
         GF_DSTAMP(1);
-        if (a.rawM32) {
+        if (!FAST && a.rawM32) {
             if (tid == 0) { S.parseStatus = len < 10ull + nM32 ? GF_K_ERR_BOUNDS : GF_K_OK; S.uniformSym = -1; S.textStart = 80; }
-        } else if (a.trees) {
+        } else if (FAST || a.trees) {
             // the tree was walked by k_huffman_parse_trees: fetch the leaf records, then mark the first-level entries
             // whose codes continue in a second-level table (one per distinct LUT_BITS-bit prefix among the longer codes,
             // numbered in pre-order) and list the short leaves -- in parallel, a leaf per thread
@@ -1238,7 +1275,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                 S.maxLen = maxLen;
             }
         } else if (wave == 0) {
-            parse_tree_wave(S, 80u, 80u, len * 8u);
+            if constexpr (!FAST) parse_tree_wave(S, 80u, 80u, len * 8u);
         }
         __syncthreads();
         if (S.parseStatus != GF_K_OK) {
@@ -1247,8 +1284,14 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
             continue;
         }
         GF_DSTAMP(2);
-        if ((a.phaseLimit & 0xff) == 1) continue;
+        GF_DPHASE_LIMIT(1, continue);
+#ifdef GF_DIAG
         const uint32_t warmBits = (a.phaseLimit >> 8) ? (uint32_t)(a.phaseLimit >> 8) : 128u;   // experiment hook
+        uint32_t *const dbg = a.debug ? a.debug + t * 16 + 11 : nullptr;
+#else
+        constexpr uint32_t warmBits = 128u;                           // about 25 symbols
+        constexpr uint32_t *dbg = nullptr;
+#endif
 
         // dynamic LDS / spill layout: [M32 bytes][start bitmap][bitmap rank base]; the bitmap area holds the second-level
         // lookup table while phase 1 runs
@@ -1276,7 +1319,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
             int32_t tileStatus = GF_K_OK;
 
             // ---------------- phase 1: Huffman text -> M32 bytes ----------------
-            if (a.rawM32) {
+            if (!FAST && a.rawM32) {
                 // the M32 bytes lie behind the header (the host inflated a CodecDeflate packing, CodecDeflate.java:141-147)
                 for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = pk[10 + i];
                 __syncthreads();
@@ -1291,8 +1334,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                 const uint64_t baseWord = (off * 8ull) >> 5;
                 const uint32_t sh0 = (uint32_t)(off * 8ull) & 31u;
                 const uint32_t pkWords = (sh0 + endBit + 31u) >> 5;          // words that hold the packing
-                uint32_t *dbg = a.debug ? a.debug + t * 16 + 11 : nullptr;
-                if (pkWords * 4u <= a.ldsTextBytes) {
+                if (!FAST && pkWords * 4u <= a.ldsTextBytes) {
                     // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
                     uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + bmArea);
                     const uint64_t avail = nWords - baseWord;
@@ -1304,7 +1346,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                     cur.sh0 = sh0;
                     cur.S = &S;
                     cur.lut2 = lut2;
-                    tileStatus = huffman_to_m32<ANALYZE ? 1 : 0>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                    tileStatus = huffman_to_m32<MODE>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
                 } else {
                     HuffCursorT<const uint32_t *> cur;
                     cur.base32 = w32 + baseWord;
@@ -1312,12 +1354,12 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                     cur.sh0 = sh0;
                     cur.S = &S;
                     cur.lut2 = lut2;
-                    tileStatus = huffman_to_m32<ANALYZE ? 1 : 0>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                    tileStatus = huffman_to_m32<MODE>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
                 }
             }
             if (tileStatus != GF_K_OK) return tileStatus;
             GF_DSTAMP(5);
-            if ((a.phaseLimit & 0xff) == 2) return (int32_t)GF_K_SKIP;
+            GF_DPHASE_LIMIT(2, return (int32_t)GF_K_SKIP);
             if constexpr (ANALYZE) {
                 // CodecHuffman.analyze (CodecHuffman.java:172-199): what CodecStats.addToCounts / addCountsForM32 consume
                 uint32_t *hist = S.lut;                                  // the lookup table is no longer needed
@@ -1336,26 +1378,27 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                 for (uint32_t i = tid; i < 256; i += DEC_THREADS) rec[4 + i] = hist[i];
                 __syncthreads();
                 return (int32_t)GF_K_SKIP;
-            }
-
-            // ---------------- phases 2 + 3 fused: M32 bytes -> values, one store per cell ----------------
-            if constexpr (decltype(inLds)::value) {
-                const FusedPlan plan = fused_plan(nR, nC);
-                if (plan.ring && model >= 1 && model <= 3) {
-                    fused = true;
-                    return m32_to_tile(S, m32, nM32, bm, wb, model, seed, nR, nC, nStream, plan, o);
+            } else {
+                // ---------------- phases 2 + 3 fused: M32 bytes -> values, one store per cell ----------------
+                if constexpr (decltype(inLds)::value) {
+                    if (FAST || (plan.ring && model >= 1 && model <= 3)) {
+                        fused = true;
+                        return m32_to_tile(S, m32, nM32, bm, wb, model, seed, nR, nC, nStream, plan, o);
+                    }
                 }
+                if constexpr (!FAST) {
+                    // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
+                    const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
+                    const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
+                    const CellMapPredictor map{model, nR, nC, (uint32_t)(((1ull << 32) + wMain - 1) / wMain), useMagic && wMain > 1};
+                    tileStatus = m32_to_values(S, m32, nM32, bm, wb, nStream, map, o);
+                }
+                return tileStatus;
             }
-            // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
-            {
-                const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
-                const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
-                const CellMapPredictor map{model, nR, nC, (uint32_t)(((1ull << 32) + wMain - 1) / wMain), useMagic && wMain > 1};
-                tileStatus = m32_to_values(S, m32, nM32, bm, wb, nStream, map, o);
-            }
-            return tileStatus;
         };
-        const int32_t tileStatus = nM32 <= a.ldsM32Bytes ? phases12(std::true_type{}) : phases12(std::false_type{});
+        int32_t tileStatus;
+        if constexpr (FAST) tileStatus = phases12(std::true_type{});
+        else tileStatus = nM32 <= a.ldsM32Bytes ? phases12(std::true_type{}) : phases12(std::false_type{});
         if (tileStatus == (int32_t)GF_K_SKIP) continue;
         if (tileStatus != GF_K_OK) {
             if (tid == 0) a.status[t] = tileStatus;
@@ -1363,10 +1406,12 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
             continue;
         }
         GF_DSTAMP(8);
-        if ((a.phaseLimit & 0xff) == 3) continue;
+        GF_DPHASE_LIMIT(3, continue);
 
-        // ---------------- phase 3: predictor inverse (wrap-around prefix sums) ----------------
-        if (!fused) gf_predictor_inverse(model, seed, o, nR, nC, a.debug ? a.debug + t * 16 + 9 : nullptr);
+        // ---------------- phase 3: predictor inverse (wrap-around prefix sums), where phase 2 did not include it ----------------
+        if constexpr (!FAST) {
+            if (!fused) gf_predictor_inverse(model, seed, o, nR, nC, nullptr);
+        }
         GF_DSTAMP(10);
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();
@@ -1485,7 +1530,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
                         cur.sh0 = (uint32_t)(off * 8ull) & 31u;
                         cur.S = &S;
                         cur.lut2 = lut2;
-                        const int32_t st = huffman_to_m32<2>(S, cur, textStart, endBit, nM32, m32, nullptr, 128u);
+                        const int32_t st = huffman_to_m32<3>(S, cur, textStart, endBit, nM32, m32, nullptr, 128u);
                         if (st != GF_K_OK) return st;
                         if (nM32 == 0 && tid == 0) S.chainEnd = textStart;
                         __syncthreads();
@@ -1648,22 +1693,43 @@ unsigned gf_huffman_decode_grid(size_t nTiles)
 
 #endif
 
+// dynamic LDS beyond the default limit must be opted into, per kernel and PER DEVICE (hipFuncSetAttribute acts on the
+// current device's copy of the function): the largest size asked for so far is kept per device
+template <class K>
+static hipError_t optInDynLds(K kernel, size_t dyn, size_t (&done)[GF_MAX_DEVICES], std::mutex &mu)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= GF_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dyn <= done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e == hipSuccess) done[dev] = dyn;
+    return e;
+}
+
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid)
 {
     if (a.nTiles == 0) return hipSuccess;
     const size_t dyn = decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
-    static size_t maxDynSet = 0;                   // dynamic LDS beyond the default limit must be opted into
-    if (dyn > maxDynSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_decode<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_decode<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e != hipSuccess) return e;
-        maxDynSet = dyn;
+    static size_t doneG[GF_MAX_DEVICES], doneA[GF_MAX_DEVICES], doneF[GF_MAX_DEVICES];
+    static std::mutex mu;
+    hipError_t e;
+    if (a.analysis) {
+        if ((e = optInDynLds(k_huffman_decode<DEC_ANALYZE>, dyn, doneA, mu)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_huffman_decode<DEC_ANALYZE>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+        return hipGetLastError();
     }
-    if (a.analysis) hipLaunchKernelGGL(k_huffman_decode<true>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
-    else hipLaunchKernelGGL(k_huffman_decode<false>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    if ((e = optInDynLds(k_huffman_decode<DEC_GENERAL>, dyn, doneG, mu)) != hipSuccess) return e;
+    if (a.retryFlag) {
+        // CodecHuffman batches: the fast kernel first; the general one picks up what that one marked (and returns at once
+        // when nothing is marked)
+        if ((e = optInDynLds(k_huffman_decode<DEC_FAST>, dyn, doneF, mu)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(a.retryFlag, 0, 4, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    }
+    hipLaunchKernelGGL(k_huffman_decode<DEC_GENERAL>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();
 }
 
@@ -1672,13 +1738,10 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
 {
     if (a.nTiles == 0) return hipSuccess;
     const size_t dyn = decodeDynLds(a.ldsM32Bytes, 0);
-    static size_t maxDynSet = 0;
-    if (dyn > maxDynSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsop_unpack_m32),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e != hipSuccess) return e;
-        maxDynSet = dyn;
-    }
+    static size_t done[GF_MAX_DEVICES];
+    static std::mutex mu;
+    hipError_t e = optInDynLds(k_lsop_unpack_m32, dyn, done, mu);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lsop_unpack_m32, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();
 }

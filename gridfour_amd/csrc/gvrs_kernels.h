@@ -15,6 +15,8 @@
 #define GF_K_ERR_ARG (-4)
 #define GF_K_ERR_UNSUPPORTED (-7)
 
+constexpr int GF_MAX_DEVICES = 64;            // per-device launch state (dynamic-LDS opt-in) is kept for this many devices
+
 struct GfEncodeArgs {
     const int32_t *values;     // nTiles * nRows*nCols
     uint8_t *out;              // nTiles slots of slotStride bytes
@@ -52,6 +54,9 @@ struct GfDecodeArgs {
     uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
     int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
     const uint32_t *trees;     // non-null: the Huffman trees were parsed by k_huffman_parse_trees (GF_TREE_REC_WORDS per tile)
+    uint32_t *retryFlag;       // non-null (CodecHuffman batches with tree records): one device word; the fast kernel runs first
+                               // and ORs 1 into it for every tile it leaves to the general kernel (status GF_K_RETRY inside
+                               // the launch only)
     uint32_t *analysis;        // non-null: CodecHuffman.analyze mode -- per tile GF_ANALYSIS_WORDS words (predictor, nM32,
                                // bits in tree, packing bytes - 10, 256-bin histogram of the M32 bytes); no values are written
 };

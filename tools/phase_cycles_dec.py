@@ -33,15 +33,14 @@ def main():
     L.gf_internal_set_decode_debug(None)
     L.gf_internal_set_phase_limits(0, 0)
     st = dbg.download(np.uint32, 16 * nt).reshape(nt, 16).astype(np.int64)
-    d = np.diff(st[:, :11], axis=1) & 0xFFFFFFFF
-    names = ["0 header copy", "0 tree parse", "1 LUT build", "1 huffman chain sync", "1 huffman write pass", "2 m32 chain sync",
-             "2 bitmap+rank", "2 value decode+store", "3 colsum+col0", "3 row scans"]
-    for i, nme in enumerate(names):
-        print("  %-26s median %9d  p90 %9d" % (nme, np.median(d[:, i]), np.percentile(d[:, i], 90)))
-    print("  huffman chain: rounds median %d p90 %d max %d; first pass cycles median %d" % (
-        np.median(st[:, 11]), np.percentile(st[:, 11], 90), st[:, 11].max(), np.median(st[:, 12])))
-    print("  m32 chain:     rounds median %d p90 %d max %d; first pass cycles median %d" % (
-        np.median(st[:, 13]), np.percentile(st[:, 13], 90), st[:, 13].max(), np.median(st[:, 14])))
+    rel = (st[:, :11] - st[:, :1]) & 0xFFFFFFFF
+    names = ["0 start", "1 header", "2 tree records", "3 LUT built", "4 huffman sync pass", "5 huffman write pass", "6 -", "7 -",
+             "8 values (+ inverse when fused)", "9 -", "10 end"]
+    for i in (1, 2, 3, 4, 5, 8, 10):
+        print("  after %-34s median %9d  p90 %9d" % (names[i], np.median(rel[:, i]), np.percentile(rel[:, i], 90)))
+    pred = b.get_predictors()
+    if True:
+        print("  predictors chosen:", {int(k): int(v) for k, v in zip(*np.unique(pred, return_counts=True))})
     tot = (st[:, 10] - st[:, 0]) & 0xFFFFFFFF
     print("  total per tile median %d  p90 %d" % (np.median(tot), np.percentile(tot, 90)))
 
