@@ -118,18 +118,24 @@ class GvrsHipError(RuntimeError):
         super().__init__("%s: %s%s" % (where, msg, (" [" + detail + "]") if detail else ""))
 
 
+def _diag():
+    return os.environ.get("GVRS_HIP_DIAG", "") not in ("", "0")
+
+
 def lib_path():
-    return _build.LIB
+    return _build.LIB_DIAG if _diag() else _build.LIB
 
 
 def lib():
-    """Loads libgvrs_hip.so (building it first if the sources are newer).  Raises if it
-    cannot be built or loaded -- the HIP library is the only implementation."""
+    """Loads libgvrs_hip.so (building it first if the sources are newer; builds are serialised by a file lock, see
+    build.py).  Raises if it cannot be built or loaded -- the HIP library is the only implementation.
+    GVRS_HIP_DIAG=1 (tools/ only) selects the diagnostic flavour libgvrs_hip_diag.so."""
     global _lib
     if _lib is None:
-        if _build.needs_build():
-            _build.build()
-        L = C.CDLL(_build.LIB)
+        path = lib_path()
+        if _build.needs_build(path):
+            _build.build(diag=_diag())
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)           # AttributeError if the ABI lost a symbol
             fn.restype = res

@@ -2,21 +2,31 @@
 
 The library is the product: there is no Python or CPU implementation behind it.  hipcc
 cross-compiles without a GPU, so this also runs on the CPU-only build box.
+
+Two flavours from the same sources:
+  libgvrs_hip.so       what ships: no diagnostics in the kernels
+  libgvrs_hip_diag.so  -DGF_DIAG: cycle stamps per phase, phase ablation and the gf_internal_* hooks that tools/ use
+                       (loaded instead of the shipping library when GVRS_HIP_DIAG=1 is set; never by tests or bench)
+
+Concurrency: several processes may import the package at once (torchrun ranks, pytest-xdist).  A build runs under an
+exclusive file lock, compiles into a private directory and moves the finished library into place with os.replace, so a
+reader never maps a half-written file and two builders never share object files.
 """
+import fcntl
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvrs_hip.so")
-SOURCES = ["gvrs_api.hip", "gvrs_encode.hip", "gvrs_decode.hip", "gvrs_aux.hip", "gvrs_float.hip",
-           "gvrs_canon_encode.hip", "gvrs_canon_decode.hip", "gvrs_lsop.hip", "gvrs_lsop_decode.hip"]
-HEADERS = ["gvrs_common.h", "gvrs_kernels.h", "huff_build.h", "gvrs_encode_layout.h", "gvrs_encode_common.h",
-           "gvrs_decode_common.h", "gvrs_canon_common.h", "gvrs_canon_decode_common.h", os.path.join("..", "..", "include", "gvrs_hip_codec.h")]
+LIB_DIAG = os.path.join(LIBDIR, "libgvrs_hip_diag.so")
+SOURCES = ["gvrs_api.hip", "gvrs_multi.hip", "gvrs_encode.hip", "gvrs_decode.hip", "gvrs_aux.hip", "gvrs_float.hip",
+           "gvrs_canon_encode.hip", "gvrs_canon_decode.hip", "gvrs_lsop.hip", "gvrs_lsop_decode.hip", "gvrs_inflate.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
 
 def _hipcc():
@@ -26,41 +36,77 @@ def _hipcc():
     raise RuntimeError("hipcc not found; the HIP codec cannot be built")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _deps():
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(HERE, "..", "include", "gvrs_hip_codec.h"))
+    deps.append(os.path.abspath(__file__))
+    return deps
+
+
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=False):
-    """Compiles every HIP source for gfx950 and links gridfour_amd/lib/libgvrs_hip.so."""
-    if not force and not needs_build():
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+def _compile_all(lib, extra, verbose):
     hipcc = _hipcc()
-    objs = []
-    for s in SOURCES:
-        obj = os.path.join(LIBDIR, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", obj]
+    tmp = tempfile.mkdtemp(prefix=".build-", dir=LIBDIR)
+    try:
+        jobs = []
+        for s in _sources():
+            obj = os.path.join(tmp, os.path.splitext(s)[0] + ".o")
+            jobs.append(([hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", obj], obj))
+        # the legacy decoder once more with 512-thread workgroups (large tiles, see gvrs_decode.hip)
+        obj = os.path.join(tmp, "gvrs_decode_t512.o")
+        jobs.append(([hipcc] + FLAGS + extra + ["-DGF_DEC_THREADS=512", "-DGF_DEC_VARIANT", "-c",
+                                                 os.path.join(CSRC, "gvrs_decode.hip"), "-o", obj], obj))
+        # a few compiles at a time: the translation units are independent
+        width = max(1, min(4, (os.cpu_count() or 2) // 2))
+        running = []
+        for cmd, _ in jobs:
+            if verbose:
+                print(" ".join(cmd))
+            running.append((cmd, subprocess.Popen(cmd)))
+            if len(running) >= width:
+                c, p = running.pop(0)
+                if p.wait() != 0:
+                    raise subprocess.CalledProcessError(p.returncode, c)
+        for c, p in running:
+            if p.wait() != 0:
+                raise subprocess.CalledProcessError(p.returncode, c)
+        out = os.path.join(tmp, os.path.basename(lib))
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out] + [o for _, o in jobs] + ["-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(obj)
-    # the legacy decoder once more with 512-thread workgroups (large tiles, see gvrs_decode.hip)
-    obj = os.path.join(LIBDIR, "gvrs_decode_t512.o")
-    cmd = [hipcc] + FLAGS + ["-DGF_DEC_THREADS=512", "-DGF_DEC_VARIANT", "-c", os.path.join(CSRC, "gvrs_decode.hip"), "-o", obj]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    objs.append(obj)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+        os.replace(out, lib)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def build(force=False, verbose=False, diag=False):
+    """Compiles every HIP source for gfx950 and links gridfour_amd/lib/libgvrs_hip[_diag].so."""
+    lib = LIB_DIAG if diag else LIB
+    if not force and not needs_build(lib):
+        return lib
+    os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            # another process may have finished the same build while this one waited for the lock
+            if force or needs_build(lib):
+                _compile_all(lib, ["-DGF_DIAG"] if diag else [], verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, diag="--diag" in sys.argv))

@@ -24,9 +24,16 @@
 namespace {
 
 thread_local std::string g_lastError;
-int g_encPhaseLimit = 0, g_decPhaseLimit = 0;   // diagnostic phase ablation (tools only)
-uint32_t *g_decodeDebug = nullptr;   // 16 cycle stamps per tile (tools only)
-uint32_t *g_encodeDebug = nullptr;   // diagnostic dump target of the next encode launches (tools only)
+#ifdef GF_DIAG
+// the diagnostic flavour of the library only (libgvrs_hip_diag.so, tools/): process-wide hooks for phase ablation and
+// the kernels' cycle stamps.  The shipping library has no mutable global state.
+int g_encPhaseLimit = 0, g_decPhaseLimit = 0;
+uint32_t *g_decodeDebug = nullptr;   // 16 cycle stamps per tile
+uint32_t *g_encodeDebug = nullptr;   // dump target of the next encode launches
+#else
+constexpr int g_encPhaseLimit = 0, g_decPhaseLimit = 0;
+constexpr uint32_t *g_decodeDebug = nullptr, *g_encodeDebug = nullptr;
+#endif
 
 gf_status hipFail(hipError_t e, const char *what)
 {
@@ -105,12 +112,14 @@ extern "C" {
 
 const char *gf_version(void) { return "gvrs-hip-codec 0.1 (gfx950)"; }
 
-// Not part of the public ABI: lets tools/ capture the encode kernel's on-chip tables
+#ifdef GF_DIAG
+// Not part of the public ABI (diagnostic flavour only): lets tools/ capture the encode kernel's on-chip tables
 // (gvrs_encode_layout.h).  d_words must hold gf_internal_encode_debug_words() uint32 per tile.
 void gf_internal_set_encode_debug(void *d_words) { g_encodeDebug = (uint32_t *)d_words; }
 void gf_internal_set_decode_debug(void *d_words) { g_decodeDebug = (uint32_t *)d_words; }
 void gf_internal_set_phase_limits(int enc, int dec) { g_encPhaseLimit = enc; g_decPhaseLimit = dec; }
-size_t gf_internal_encode_debug_words(void);
+size_t gf_internal_encode_debug_words(void) { return GF_ENC_DEBUG_WORDS; }
+#endif
 
 const char *gf_status_string(int s)
 {
@@ -128,8 +137,6 @@ const char *gf_status_string(int s)
     default: return "unknown status";
     }
 }
-
-size_t gf_internal_encode_debug_words(void) { return GF_ENC_DEBUG_WORDS; }
 
 const char *gf_last_error(void) { return g_lastError.c_str(); }
 
@@ -252,6 +259,7 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
                                 uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus, int predictorMask)
 {
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dOut || !dLengths || !dStatus) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
     if (slotStride % 16 != 0 || ((uintptr_t)dOut & 15) != 0 || slotStride < 16) return GF_ERR_ARG;
     GfEncodeArgs a;
@@ -288,6 +296,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
                                 const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus, uint32_t *analysis = nullptr)
 {
     if (!c || nRows < 1 || nCols < 1 || !dBlob || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
     if (((uintptr_t)dBlob & 3) != 0) return GF_ERR_ARG;
     const unsigned grid = gf_huffman_decode_grid(nTiles);
@@ -351,7 +360,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
         // tiles whose M32 stream leaves LDS for ONE 256-thread workgroup per CU run with 512-thread workgroups (measured:
         // 256x256 tiles 4.51 -> 2.85 ms; at two workgroups per CU -- 200x200 -- the 512-thread form is the slower one)
-        const bool big = (size_t)a.ldsM32Bytes + 4096 + 14336 > (160 * 1024) / 2 && !getenv("GF_DEC_T256");
+        const bool big = (size_t)a.ldsM32Bytes + 4096 + 14336 > (160 * 1024) / 2;
         if (big) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
         else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     }
@@ -362,6 +371,8 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
 static gf_status lsopParseLengths(gf_context *c, hipStream_t st, size_t nTiles, const uint8_t *dBlob, size_t blobBytes,
                                   const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths)
 {
+    if (!c) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     const size_t need = nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16;
     if (c->trees.bytes < need) {
         GF_HIP(hipSetDevice(c->device));                   // not capture-safe: gf_context_reserve sizes this too
@@ -378,6 +389,8 @@ static gf_status lsopUnpackM32(gf_context *c, hipStream_t st, int nRows, int nCo
                                size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
                                int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus, int rawM32)
 {
+    if (!c) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     const unsigned grid = gf_huffman_decode_grid(nTiles);
     const size_t wsStride = decodeWorkspaceStride(nRows, nCols);
     if (c->workspace.bytes < (size_t)grid * wsStride) {
@@ -454,6 +467,7 @@ gf_status gf_compact_dev(gf_context *c, void *stream, size_t nTiles, const uint8
                          const uint32_t *dLengths, uint64_t *dOffsets, uint8_t *dBlob, size_t blobCap)
 {
     if (!c || !dSlots || !dLengths || !dOffsets || !dBlob) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (((uintptr_t)dSlots & 15) != 0 || slotStride % 16 != 0) return GF_ERR_ARG;
     GF_HIP(gf_launch_compact(nTiles, dSlots, slotStride, dLengths, dOffsets, dBlob, blobCap,
                              stream ? (hipStream_t)stream : c->stream));
@@ -464,6 +478,7 @@ gf_status gf_synth_dem_dev(gf_context *c, void *stream, uint64_t seed, int nRows
                            int64_t tile0, size_t nTiles, int32_t *dValues)
 {
     if (!c || nRows < 1 || nCols < 1 || tilesPerRow < 1 || !dValues) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(gf_launch_synth_dem(seed, nRows, nCols, tilesPerRow, tile0, nTiles, dValues,
                                stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
@@ -482,6 +497,7 @@ gf_status gf_float_planes_encode_dev(gf_context *c, void *stream, int nRows, int
                                      uint8_t *dPlanes, size_t planeStride)
 {
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dPlanes || planeStride < gf_float_planes_bytes(nRows, nCols)) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(gf_launch_float_planes_encode((const uint32_t *)dValues, dPlanes, planeStride, nTiles, nRows, nCols,
                                          stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
@@ -491,6 +507,7 @@ gf_status gf_float_planes_decode_dev(gf_context *c, void *stream, int nRows, int
                                      size_t planeStride, float *dValues)
 {
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dPlanes || planeStride < gf_float_planes_bytes(nRows, nCols)) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(gf_launch_float_planes_decode(dPlanes, (uint32_t *)dValues, planeStride, nTiles, nRows, nCols,
                                          stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
@@ -637,6 +654,7 @@ gf_status gf_dev_free(gf_context *c, void *p)
 gf_status gf_dev_memset(gf_context *c, void *p, int value, size_t bytes)
 {
     if (!c) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(hipMemsetAsync(p, value, bytes, c->stream));
     GF_HIP(hipStreamSynchronize(c->stream));
     return GF_OK;
@@ -645,6 +663,7 @@ gf_status gf_dev_memset(gf_context *c, void *p, int value, size_t bytes)
 gf_status gf_dev_upload(gf_context *c, void *d, const void *h, size_t bytes)
 {
     if (!c) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     GF_HIP(hipStreamSynchronize(c->stream));
     return GF_OK;
@@ -653,6 +672,7 @@ gf_status gf_dev_upload(gf_context *c, void *d, const void *h, size_t bytes)
 gf_status gf_dev_download(gf_context *c, void *h, const void *d, size_t bytes)
 {
     if (!c) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     GF_HIP(hipStreamSynchronize(c->stream));
     return GF_OK;
@@ -928,6 +948,7 @@ gf_status gf_lsop12_predict_dev(gf_context *c, void *stream, int nRows, int nCol
                                 int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dStatus)
 {
     if (!c || !dValues || !dResiduals || !dCoefs || !dStatus || nRows < 1 || nCols < 1) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (nRows < 6 || nCols < 6) {                       // LsOptimalPredictor12.java:114-116 -> null
@@ -944,6 +965,7 @@ gf_status gf_lsop12_reconstruct_dev(gf_context *c, void *stream, int nRows, int 
                                     const int32_t *dInStatus, int32_t *dValues, int32_t *dStatus)
 {
     if (!c || !dValues || !dResiduals || !dCoefs || !dStatus) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (nRows < 6 || nCols < 6 || resStride < gf_lsop12_residual_count(nRows, nCols)) return GF_ERR_ARG;
     GF_HIP(gf_launch_lsop_reconstruct(dResiduals, resStride, dCoefs, dInStatus, dValues, dStatus, nTiles, nRows, nCols,
                                       stream ? (hipStream_t)stream : c->stream));
@@ -956,6 +978,7 @@ gf_status gf_lsop12_encode_batch_i32_dev(gf_context *c, void *stream, int codecI
                                          int32_t *dScratchStatus)
 {
     if (!c || !dValues || !dOut || !dLengths || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (slotStride % 16 != 0 || ((uintptr_t)dOut & 15) != 0 || slotStride < 64) return GF_ERR_ARG;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (nRows < 6 || nCols < 6) {
@@ -980,6 +1003,7 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
                                          size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus)
 {
     if (!c || !dBlob || !dLengths || !dValues || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (((uintptr_t)dBlob & 3) != 0) return GF_ERR_ARG;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     if (nRows < 6 || nCols < 6) {
@@ -1287,6 +1311,7 @@ gf_status gf_m32_encode_batch_i32_dev(gf_context *c, void *stream, int nRows, in
                                       uint32_t *dSeeds, int32_t *dStatus)
 {
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dStreams || !dLengths || !dModels || !dSeeds || !dStatus) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
     if (subStride % 16 != 0 || subStride < 16 || ((uintptr_t)dStreams & 15) != 0) return GF_ERR_ARG;
     GfM32Args a;

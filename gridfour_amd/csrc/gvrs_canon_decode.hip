@@ -83,10 +83,15 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
         const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
         const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
         const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
+#ifdef GF_DIAG
         const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, !(a.phaseLimit & 0x100)};
-        uint32_t endPos, nValues;
         uint32_t *stamps = a.debug ? a.debug + t * 16 : nullptr;
         if (stamps && tid == 0) stamps[0] = (uint32_t)__builtin_amdgcn_s_memtime();
+#else
+        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, true};
+        constexpr uint32_t *stamps = nullptr;
+#endif
+        uint32_t endPos, nValues;
         const uint32_t *pre = a.trees ? a.trees + t * GF_CANON_REC_WORDS : nullptr;
         const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias)
                                      : cd_decode_stream(S, TG, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias);
@@ -98,7 +103,9 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
 
         // ---------------- phase 3: predictor inverse ----------------
         gf_predictor_inverse(model, seed, o, nR, nC, nullptr);
+#ifdef GF_DIAG
         if (stamps && tid == 0) stamps[6] = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
         if (tid == 0) a.status[t] = GF_K_OK;
         __syncthreads();
     }
@@ -266,12 +273,10 @@ hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, uns
 {
     if (a.nTiles == 0) return hipSuccess;
     const size_t dyn = a.ldsTextBytes;
-    static size_t maxDynSet = 0;
-    if (dyn > maxDynSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_canon_decode),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    static GfDynLdsOptIn opt;
+    {
+        const hipError_t e = gf_opt_in_dyn_lds(k_canon_decode, dyn, opt);
         if (e != hipSuccess) return e;
-        maxDynSet = dyn;
     }
     hipLaunchKernelGGL(k_canon_decode, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();

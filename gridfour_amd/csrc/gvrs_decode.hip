@@ -54,7 +54,13 @@ constexpr int GF_K_SKIP = 0x7fff0001;           // internal: a diagnostic phase 
 constexpr int DEC_THREADS = GF_DEC_THREADS;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int LUT_BITS = 10;                    // first-level window: most symbol PAIRS of terrain data fit 10 bits
-constexpr int MAXQ = 2 * GF_DEC_THREADS;         // subsequences per chain: two per thread, advanced in lockstep
+#ifndef GF_DEC_MAXQ
+#define GF_DEC_MAXQ (2 * GF_DEC_THREADS)
+#endif
+constexpr int MAXQ = GF_DEC_MAXQ;                // subsequences per chain: two per thread (advanced in lockstep) or one
+#ifndef GF_DEC_WGS
+#define GF_DEC_WGS (GF_DEC_THREADS == 256 ? 4 : 2)
+#endif
 constexpr int HEAD_WORDS = 88;                 // 10 header + 1 + ceil(2559/8) tree bytes = 332 -> 83 words, + slack
 constexpr int MAX_DEPTH = 63;                  // code length limit of the register tree parser
 
@@ -79,6 +85,7 @@ struct DecShared {
     uint32_t head[HEAD_WORDS];
     uint32_t waveSum[DEC_WAVES];
     uint32_t fusedTot[2 * 3 * DEC_WAVES];      // m32_to_tile: wave totals of the chunk scans, double-buffered
+    uint32_t nRedo[2];                         // fast_sync_pass: subsequences to redo, by round parity
     uint32_t carry;
     uint32_t textStart;                        // bit offset of the Huffman text in the packing
     int32_t parseStatus;
@@ -423,6 +430,356 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
                 if (n1 == 2u) m32[k1 + 1] = (uint8_t)(u1 >> 8);
                 k1 += n1;
                 if (k1 == nM32) S.chainEnd = c1.pos;
+            }
+        }
+    }
+    __syncthreads();
+    if (status == GF_K_OK && S.chainEnd > endBit) status = GF_K_ERR_BOUNDS;      // last code ran past the end
+    return status;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two Huffman passes of the fast kernel.  Same results as resolve_chain + the write loop of huffman_to_m32 (same
+// subsequences, same start / end / count per subsequence, same bytes), written for instruction count: the generic
+// cursor above refills its window in a divergent loop around a conditional global load and resolves codes longer than
+// the window in nested divergent branches -- some lane of a wave is in each of them at nearly every step, so a wave paid
+// about 240 instructions per step of its two cursors.  Here
+//   * pass 1 (synchronisation) reads the text from an LDS copy -- the M32 buffer is still empty then -- padded with
+//     zero words, so the window refill is an unconditional prefetch plus three selects;
+//   * pass 2 (write) cannot keep that copy (it fills the M32 buffer), so each cursor loads eight words of its
+//     subsequence into registers at once and shifts them down as bits are consumed; a block of steps ends when some
+//     lane has used up its registers (all lanes consume bits at about the same rate);
+//   * codes longer than the window take ONE branch per step for both cursors, with the second-level lookup straight-line
+//     inside it (the leaf-table search behind that stays a loop: it runs for codes beyond 18 bits only).
+// Requires code lengths <= 32 (longer codes need Fib(34) symbols in a tile; such tiles go to the general kernel).
+struct FastHuff {
+    const DecShared *S;
+    const uint16_t *lut2;
+    uint32_t l2bits, nSub;
+};
+
+// entry of a code longer than the window: second level, then (rare) the leaf table; w = 32 text bits at the code,
+// t0 | t1 << 32 | ... = the text from the code on (for the search)
+__device__ __forceinline__ uint32_t fh_resolve(const FastHuff &H, uint32_t e, uint32_t w, uint32_t x0, uint32_t x1, uint32_t x2,
+                                               uint32_t sh)
+{
+    const uint32_t sub = e & 0x7fffffffu;
+    uint32_t e16 = 0xFFFFu;
+    if (sub < H.nSub) e16 = H.lut2[(sub << H.l2bits) | ((w >> LUT_BITS) & ((1u << H.l2bits) - 1u))];
+    if (e16 == 0xFFFFu) {
+        const uint64_t lo = ((uint64_t)x1 << 32) | x0;
+        uint64_t t = lo >> sh;
+        if (sh) t |= (uint64_t)x2 << (64u - sh);
+        const uint32_t n = H.S->nLeaves;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t cl = H.S->leafLen[i];
+            const uint64_t mask = cl >= 64 ? ~0ull : ((1ull << cl) - 1ull);
+            if (cl > LUT_BITS && (t & mask) == H.S->leafCode[i]) {
+                e16 = (cl << 8) | H.S->leafSym[i];
+                break;
+            }
+        }
+        if (e16 == 0xFFFFu) e16 = (1u << 8);       // cannot happen for a complete tree; keep moving
+    }
+    return lut_single(e16 & 0xffu, e16 >> 8);
+}
+
+struct LCur {                                      // pass 1: text in LDS
+    uint32_t pos, sh, wi, w0, w1, w2, wn;
+};
+__device__ __forceinline__ void lcur_seek(LCur &c, const uint32_t *txt, uint32_t sh0, uint32_t p)
+{
+    const uint32_t a = p + sh0;
+    c.pos = p;
+    c.wi = a >> 5;
+    c.sh = a & 31u;
+    c.w0 = txt[c.wi];
+    c.w1 = txt[c.wi + 1];
+    c.w2 = txt[c.wi + 2];
+    c.wn = txt[c.wi + 3];
+}
+__device__ __forceinline__ void lcur_advance(LCur &c, const uint32_t *txt, uint32_t len)      // len <= 32
+{
+    c.pos += len;
+    const uint32_t sh = c.sh + len;
+    const bool ge = sh >= 32u;
+    c.w0 = ge ? c.w1 : c.w0;
+    c.w1 = ge ? c.w2 : c.w1;
+    c.w2 = ge ? c.wn : c.w2;
+    c.wi += ge ? 1u : 0u;
+    c.sh = sh & 31u;
+    c.wn = txt[c.wi + 3];
+}
+
+constexpr uint32_t FAST_TEXT_PAD = 8;              // zero words behind the LDS copy of the text
+
+constexpr int NCUR = MAXQ / DEC_THREADS;           // cursors per thread: subsequences tid, tid + DEC_THREADS, ...
+
+// Pass 1.  Round 1: every subsequence from its warm-up start.  A subsequence whose start then differs from its predecessor's end
+// is decoded again from that end -- a handful per tile (a few codes in a thousand take longer than the warm-up to fall into
+// step), yet a round costs every wave that owns one of them a full pass.  So from round 2 on the subsequences to redo are
+// listed and dealt out to the lanes of as few waves as possible (wave 0 takes the first 64 * NCUR of them); the other
+// waves go straight to the barrier.  Rounds repeat until no start moves.
+template <int OWNER>
+__device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint32_t *txt, uint32_t sh0, uint32_t start, uint32_t end,
+                               uint32_t unit, uint32_t Q, uint32_t warm, uint32_t *dbg)
+{
+    const uint32_t tid = threadIdx.x;
+    uint16_t *list = reinterpret_cast<uint16_t *>(S.qdirty);      // subsequences to redo (the flags themselves are not used here)
+    constexpr uint32_t LIST_CAP = MAXQ / 2;                        // what does not fit waits for the next round
+#ifdef GF_DIAG
+    uint32_t rounds = 0;
+#else
+    (void)dbg;
+#endif
+    if (tid == 0) { S.nRedo[0] = 0; S.nRedo[1] = 0; }
+    // one round: cursor i of this thread decodes subsequence qv[i] (>= Q: none)
+    auto runRound = [&](const bool first, const uint32_t (&qv)[NCUR]) {
+        bool d[NCUR];
+        uint32_t b[NCUR], lim[NCUR], sPos[NCUR], cnt[NCUR];
+        LCur c[NCUR];
+#pragma unroll
+        for (int i = 0; i < NCUR; i++) {
+            const uint32_t q = qv[i];
+            d[i] = q < Q;
+            b[i] = start + q * unit;                                            // boundary
+            lim[i] = min(end, b[i] + unit);
+            // first round: from a warm-up stretch in front of the boundary (the first position reached at or beyond the
+            // boundary is the start); later rounds: from the predecessor's end
+            uint32_t p;
+            if (first) p = (q > 0 && b[i] - start >= warm) ? b[i] - warm : (q > 0 ? start : b[i]);
+            else p = d[i] ? S.qe[q - 1u] : end;                                 // listed subsequences have q > 0
+            lcur_seek(c[i], txt, sh0, d[i] ? p : end);
+            sPos[i] = p;
+            cnt[i] = 0;
+        }
+        for (;;) {
+            bool r[NCUR], any = false;
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) {
+                r[i] = d[i] && c[i].pos < lim[i];
+                any = any || r[i];
+            }
+            if (!any) break;
+            uint32_t x[NCUR], e[NCUR], anyLong = 0;
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) {
+                x[i] = __builtin_amdgcn_alignbit(c[i].w1, c[i].w0, c[i].sh);
+                e[i] = S.lut[x[i] & ((1u << LUT_BITS) - 1u)];
+                anyLong |= e[i];
+            }
+            if (anyLong & 0x80000000u) {
+#pragma unroll
+                for (int i = 0; i < NCUR; i++)
+                    if (e[i] & 0x80000000u) e[i] = fh_resolve(H, e[i], x[i], c[i].w0, c[i].w1, c[i].w2, c[i].sh);
+            }
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) {
+                const bool m = c[i].pos >= b[i];                                // past the warm-up
+                const uint32_t cl = m ? lim[i] : b[i];                          // a pair must not straddle these
+                const uint32_t a1 = (e[i] >> 16) & 63u, t2 = e[i] >> 22;
+                const bool two = t2 != a1 && c[i].pos + a1 < cl;
+                cnt[i] += (r[i] && m) ? (two ? 2u : 1u) : 0u;
+                lcur_advance(c[i], txt, r[i] ? (two ? t2 : a1) : 0u);
+                sPos[i] = (!m && c[i].pos >= b[i]) ? c[i].pos : sPos[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCUR; i++)
+            if (d[i]) { S.qs[qv[i]] = sPos[i]; S.qe[qv[i]] = c[i].pos; S.qn[qv[i]] = cnt[i]; }
+    };
+    {
+        uint32_t qv[NCUR];
+#pragma unroll
+        for (int i = 0; i < NCUR; i++) qv[i] = tid + i * DEC_THREADS;
+        runRound(true, qv);
+    }
+    for (uint32_t round = 1;; round++) {
+        __syncthreads();                                                        // the round's starts and ends are in place
+#ifdef GF_DIAG
+        rounds++;
+#endif
+        if (tid == 0) S.nRedo[(round + 1u) & 1u] = 0;                           // the next round's counter (last read before this barrier)
+#pragma unroll
+        for (int i = 0; i < NCUR; i++) {
+            const uint32_t q = tid + i * DEC_THREADS;
+            if (q > 0 && q < Q && S.qe[q - 1] != S.qs[q]) {
+                const uint32_t slot = atomicAdd(&S.nRedo[round & 1u], 1u);
+                if (slot < LIST_CAP) list[slot] = (uint16_t)q;
+            }
+        }
+        __syncthreads();
+        const uint32_t nList = min(S.nRedo[round & 1u], LIST_CAP);
+        if (nList == 0) break;
+        uint32_t qv[NCUR];
+#pragma unroll
+        for (int i = 0; i < NCUR; i++) {
+            const uint32_t slot = (tid >> 6) * (64u * NCUR) + (uint32_t)i * 64u + (tid & 63u);
+            qv[i] = slot < nList ? list[slot] : 0xFFFFFFFFu;
+        }
+        runRound(false, qv);
+    }
+    // exclusive prefix sum of qn in subsequence order: thread t sums q = NCUR t .. NCUR t + NCUR - 1
+    uint32_t n[NCUR], sum = 0;
+#pragma unroll
+    for (int i = 0; i < NCUR; i++) {
+        const uint32_t q = NCUR * tid + i;
+        n[i] = q < Q ? S.qn[q] : 0u;
+        sum += n[i];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan(sum, S.waveSum, &tot);
+#pragma unroll
+    for (int i = 0; i < NCUR; i++) {
+        const uint32_t q = NCUR * tid + i;
+        if (q < Q) S.qn[q] = run;
+        run += n[i];
+    }
+    if (tid == 0) S.chainTotal = tot;
+#ifdef GF_DIAG
+    if (dbg && tid == 0) dbg[0] = rounds;
+#endif
+    __syncthreads();
+}
+
+struct RCur {                                      // pass 2: eight words of the text in registers
+    uint32_t pos, sh, r0, r1, r2, r3, r4, r5, r6, r7;
+};
+// words [wi, wi + 8) of the packing's text, wi = the word that holds bit p; beyond the readable words: the last one again
+// (bits behind the packing never reach a result: a code that needs them ends behind the packing, which is an error)
+__device__ __forceinline__ void rcur_load(RCur &c, const uint32_t *__restrict__ base32, uint32_t nW, uint32_t sh0, uint32_t p)
+{
+    const uint32_t a = p + sh0, wi = a >> 5;
+    c.pos = p;
+    c.sh = a & 31u;
+    if (wi + 8u <= nW) {
+        const GfU4 x = *reinterpret_cast<const GfU4 *>(base32 + wi), y = *reinterpret_cast<const GfU4 *>(base32 + wi + 4);
+        c.r0 = x.x; c.r1 = x.y; c.r2 = x.z; c.r3 = x.w;
+        c.r4 = y.x; c.r5 = y.y; c.r6 = y.z; c.r7 = y.w;
+    } else {
+        const uint32_t last = nW - 1u;
+        c.r0 = base32[min(wi, last)];
+        c.r1 = base32[min(wi + 1u, last)];
+        c.r2 = base32[min(wi + 2u, last)];
+        c.r3 = base32[min(wi + 3u, last)];
+        c.r4 = base32[min(wi + 4u, last)];
+        c.r5 = base32[min(wi + 5u, last)];
+        c.r6 = base32[min(wi + 6u, last)];
+        c.r7 = base32[min(wi + 7u, last)];
+    }
+}
+__device__ __forceinline__ void rcur_advance(RCur &c, uint32_t len)                           // len <= 32
+{
+    c.pos += len;
+    const uint32_t sh = c.sh + len;
+    const bool ge = sh >= 32u;
+    c.r0 = ge ? c.r1 : c.r0;
+    c.r1 = ge ? c.r2 : c.r1;
+    c.r2 = ge ? c.r3 : c.r2;
+    c.r3 = ge ? c.r4 : c.r3;
+    c.r4 = ge ? c.r5 : c.r4;
+    c.r5 = ge ? c.r6 : c.r5;
+    c.r6 = ge ? c.r7 : c.r6;
+    c.sh = sh & 31u;
+}
+// bits a cursor may consume from one load: the step after them still finds its window, the second-level index and the
+// 64 bits of a leaf search in r0..r2 without shifting in a word that was never loaded
+constexpr uint32_t RCUR_BUDGET = 256u - 31u - 96u;
+
+template <int OWNER>
+__device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict__ base32, uint32_t nW, uint32_t sh0,
+                                       uint32_t *txt, uint32_t pkWords, const uint16_t *lut2, uint32_t textStart, uint32_t endBit,
+                                       uint32_t nM32, uint8_t *m32, uint32_t *dbg, const uint32_t warmBits)
+{
+    const uint32_t tid = threadIdx.x;
+    int32_t status = GF_K_OK;
+    const uint32_t textBits = endBit - textStart;
+    uint32_t unit = (textBits + MAXQ - 1) / MAXQ;
+    unit = max(128u, (unit + 31u) & ~31u);
+    const uint32_t Q = max(1u, (textBits + unit - 1) / unit);
+    FastHuff H;
+    H.S = &S;
+    H.lut2 = lut2;
+    H.l2bits = S.l2bits;
+    H.nSub = S.nSub;
+    // the packing into LDS (txt = the M32 buffer, not yet in use), zero words behind it
+#ifdef GF_DIAG
+    const uint32_t tStage = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t i = tid; i < pkWords + FAST_TEXT_PAD; i += DEC_THREADS) txt[i] = (i < pkWords && i < nW) ? base32[i] : 0u;
+    __syncthreads();
+#ifdef GF_DIAG
+    if (dbg && tid == 0) dbg[2] = (uint32_t)__builtin_amdgcn_s_memtime() - tStage;
+#endif
+    fast_sync_pass<OWNER>(S, H, txt, sh0, textStart, endBit, unit, Q, warmBits, dbg);
+#ifdef GF_DIAG
+    if (dbg && tid == 0) dbg[-7] = (uint32_t)__builtin_amdgcn_s_memtime();      // stamp 4
+#else
+    (void)dbg;
+#endif
+    if (S.chainTotal < nM32) status = GF_K_ERR_BOUNDS;                   // ran out of bits
+    if (tid == 0) S.chainEnd = 0;
+    __syncthreads();                                                     // every reader of the LDS text is done
+    {
+        bool d[NCUR];
+        uint32_t k[NCUR], lim[NCUR];
+        RCur c[NCUR];
+#pragma unroll
+        for (int i = 0; i < NCUR; i++) {
+            const uint32_t q = tid + i * DEC_THREADS;
+            d[i] = q < Q;
+            k[i] = d[i] ? S.qn[q] : nM32;
+            lim[i] = min(endBit, textStart + (q + 1) * unit);
+            c[i].pos = d[i] ? S.qs[q] : endBit;
+        }
+        for (;;) {
+            bool live[NCUR], anyLive = false;
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) {
+                live[i] = d[i] && c[i].pos < lim[i] && k[i] < nM32;
+                anyLive = anyLive || live[i];
+            }
+            if (!__any(anyLive)) break;
+            uint32_t blk[NCUR];
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) {
+                rcur_load(c[i], base32, nW, sh0, live[i] ? c[i].pos : 0u);
+                if (!live[i]) c[i].pos = endBit;
+                blk[i] = c[i].pos;
+            }
+            for (;;) {
+                bool r[NCUR], any = false;
+#pragma unroll
+                for (int i = 0; i < NCUR; i++) {
+                    r[i] = live[i] && c[i].pos < lim[i] && k[i] < nM32 && c[i].pos - blk[i] <= RCUR_BUDGET;
+                    any = any || r[i];
+                }
+                if (!__any(any)) break;
+                uint32_t x[NCUR], e[NCUR], anyLong = 0;
+#pragma unroll
+                for (int i = 0; i < NCUR; i++) {
+                    x[i] = __builtin_amdgcn_alignbit(c[i].r1, c[i].r0, c[i].sh);
+                    e[i] = S.lut[x[i] & ((1u << LUT_BITS) - 1u)];
+                    anyLong |= e[i];
+                }
+                if (anyLong & 0x80000000u) {
+#pragma unroll
+                    for (int i = 0; i < NCUR; i++)
+                        if (e[i] & 0x80000000u) e[i] = fh_resolve(H, e[i], x[i], c[i].r0, c[i].r1, c[i].r2, c[i].sh);
+                }
+#pragma unroll
+                for (int i = 0; i < NCUR; i++) {
+                    const uint32_t a1 = (e[i] >> 16) & 63u, t2 = e[i] >> 22;
+                    const bool two = t2 != a1 && c[i].pos + a1 < lim[i] && nM32 - k[i] > 1u;
+                    rcur_advance(c[i], r[i] ? (two ? t2 : a1) : 0u);
+                    if (r[i]) {
+                        m32[k[i]] = (uint8_t)e[i];
+                        if (two) m32[k[i] + 1] = (uint8_t)(e[i] >> 8);
+                        k[i] += two ? 2u : 1u;
+                        if (k[i] == nM32) S.chainEnd = c[i].pos;
+                    }
+                }
             }
         }
     }
@@ -868,7 +1225,14 @@ __device__ __forceinline__ FusedPlan fused_plan(uint32_t nR, uint32_t nC)
 template <class BmPtr>
 __device__ __forceinline__ uint32_t m32_select(BmPtr bm, BmPtr wb, uint32_t bmWords, uint32_t k)
 {
-    uint32_t lo = min(k >> 5, bmWords - 1u), hi = bmWords;      // every value has at least one byte: word >= k / 32
+    // every value has at least one byte, so its word is >= k / 32 -- and close to it unless multi-byte values are frequent:
+    // gallop from there, then bisect
+    uint32_t lo = min(k >> 5, bmWords - 1u), hi = bmWords, step = 1u;
+    while (lo + step < bmWords) {
+        if (wb[lo + step] > k) { hi = lo + step; break; }
+        lo += step;
+        step <<= 1;
+    }
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
         if (wb[mid] <= k) lo = mid;
@@ -903,14 +1267,20 @@ __device__ __forceinline__ uint32_t m32_value_at(M32Ptr m32, uint32_t nM32, uint
 template <class M32Ptr, class BmPtr>
 __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_t nM32, BmPtr bm, BmPtr wb, const int model,
                                                const uint32_t seed, const uint32_t nR, const uint32_t nC, const uint32_t nStream,
-                                               const FusedPlan plan, uint32_t *__restrict__ o)
+                                               const FusedPlan plan, uint32_t *__restrict__ o, uint32_t *stamps, const uint32_t diagFlags)
 {
+#ifdef GF_DIAG
+#define GF_TSTAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GF_TSTAMP(i) do { (void)stamps; } while (0)
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
     const uint32_t nDw = (nM32 + 3u) >> 2, bmWords = (nM32 + 31u) >> 5;
     m32_mark_starts(S, m32, nM32, bm, wb);
     const uint32_t nValues = S.carry;
     if (nValues < nStream) return GF_K_ERR_BOUNDS;               // predictor reads past codeM32s
+    GF_TSTAMP(6);
 
     uint32_t *scr = reinterpret_cast<uint32_t *>(&S);
     const uint32_t RING = plan.ring;
@@ -977,8 +1347,64 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     }
     // (the scan barrier of the first chunk orders these stores before the first reads)
 
+    GF_TSTAMP(7);
     uint32_t carry1 = 0, carry2 = 0, rowsDone = 0;
     const uint32_t nIter = (nDw + DEC_THREADS - 1u) / DEC_THREADS;
+    // Stage 2 of chunk i runs AFTER the scan barrier of chunk i + 1: that barrier also publishes chunk i's ring entries, so a
+    // chunk costs one barrier.  The ring keeps two chunks and a row (fused_plan), so the writes of chunk i + 1 that follow the
+    // same barrier never touch what stage 2 of chunk i still reads; with a shorter ring two more barriers frame stage 2.
+    auto finishRows = [&](uint32_t chunk) {
+        uint32_t kEnd;
+        {
+            const uint32_t pEnd = (chunk + 1u) * FUSED_CHUNK;       // multiple of 32
+            kEnd = pEnd >= nM32 ? nValues : wb[pEnd >> 5];
+            kEnd = min(kEnd, nStream);
+        }
+        const uint32_t tEnd = kEnd + tOff;
+        uint32_t rowsNew = (int32_t)tEnd > 0 ? min(nRowsI, __umulhi(tEnd, magicW)) : 0u;
+        rowsNew = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowsNew);
+        if (model == 1) {
+            const uint32_t cellHi = rowsNew * nC;
+            for (uint32_t cell = rowsDone * nC + tid; cell < cellHi; cell += DEC_THREADS) {
+                const uint32_t r = __umulhi(cell, magicC);
+                o[cell] = rowA[r] + ring[ringIdx(cell)] - ring[ringIdx(r * nC)];
+            }
+        } else if (model == 2) {
+            const uint32_t cellHi = rowsNew * nC;
+            for (uint32_t cell = rowsDone * nC + tid; cell < cellHi; cell += DEC_THREADS) {
+                const uint32_t r = __umulhi(cell, magicC), c = cell - r * nC;
+                const uint32_t cv = rowA[r], d1 = rowB[r];
+                uint32_t v = cv;
+                if (c == 1u) v = cv + d1;
+                else if (c >= 2u) {
+                    const uint32_t tS = r * W;
+                    const uint32_t F1ex = r ? rowC[r - 1u] : 0u, F2ex = ring[ringIdx(tS + RING - 1u)];
+                    v = cv + d1 + (c - 1u) * (d1 - F1ex) + ring[ringIdx(tS + c - 2u)] - F2ex;
+                }
+                o[cell] = v;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
+                if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
+                if (c < nC) {
+                    uint32_t cp = u == 0 ? colPrev0 : colPrev1;
+                    for (uint32_t row = rowsDone; row < rowsNew; row++) {
+                        const uint32_t r = row + 1u, tS = row * W;
+                        uint32_t v;
+                        if (c == 0u) v = rowA[r];
+                        else v = cp + rowB[r] + ring[ringIdx(tS + c - 1u)] - ring[ringIdx(tS + RING - 1u)];
+                        cp = v;
+                        o[(size_t)r * nC + c] = v;
+                    }
+                    if (u == 0) colPrev0 = cp;
+                    else colPrev1 = cp;
+                }
+            }
+        }
+        rowsDone = rowsNew;
+    };
     for (uint32_t it = 0; it < nIter; it++) {
         const uint32_t dw = it * DEC_THREADS + tid;
         // ---- decode: up to four values, slot j = the value that starts at byte j of the thread's dword ----
@@ -1081,59 +1507,17 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
             if (ok2) ring[ringIdx(t2)] = F2;
             if (ok3) ring[ringIdx(t3)] = F3;
         }
-        __syncthreads();
-        // ---- rows completed by this chunk ----
-        uint32_t kEnd;
-        {
-            const uint32_t pEnd = (it + 1u) * FUSED_CHUNK;       // multiple of 32
-            kEnd = pEnd >= nM32 ? nValues : wb[pEnd >> 5];
-            kEnd = min(kEnd, nStream);
-        }
-        const uint32_t tEnd = kEnd + tOff;
-        uint32_t rowsNew = (int32_t)tEnd > 0 ? min(nRowsI, __umulhi(tEnd, magicW)) : 0u;
-        rowsNew = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowsNew);
-        if (model == 1) {
-            const uint32_t cellHi = rowsNew * nC;
-            for (uint32_t cell = rowsDone * nC + tid; cell < cellHi; cell += DEC_THREADS) {
-                const uint32_t r = __umulhi(cell, magicC);
-                o[cell] = rowA[r] + ring[ringIdx(cell)] - ring[ringIdx(r * nC)];
-            }
-        } else if (model == 2) {
-            const uint32_t cellHi = rowsNew * nC;
-            for (uint32_t cell = rowsDone * nC + tid; cell < cellHi; cell += DEC_THREADS) {
-                const uint32_t r = __umulhi(cell, magicC), c = cell - r * nC;
-                const uint32_t cv = rowA[r], d1 = rowB[r];
-                uint32_t v = cv;
-                if (c == 1u) v = cv + d1;
-                else if (c >= 2u) {
-                    const uint32_t tS = r * W;
-                    const uint32_t F1ex = r ? rowC[r - 1u] : 0u, F2ex = ring[ringIdx(tS + RING - 1u)];
-                    v = cv + d1 + (c - 1u) * (d1 - F1ex) + ring[ringIdx(tS + c - 2u)] - F2ex;
-                }
-                o[cell] = v;
-            }
+        if (!plan.endBarrier) {
+            if (it > 0u) finishRows(it - 1u);
         } else {
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
-                if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
-                if (c < nC) {
-                    uint32_t cp = u == 0 ? colPrev0 : colPrev1;
-                    for (uint32_t row = rowsDone; row < rowsNew; row++) {
-                        const uint32_t r = row + 1u, tS = row * W;
-                        uint32_t v;
-                        if (c == 0u) v = rowA[r];
-                        else v = cp + rowB[r] + ring[ringIdx(tS + c - 1u)] - ring[ringIdx(tS + RING - 1u)];
-                        cp = v;
-                        o[(size_t)r * nC + c] = v;
-                    }
-                    if (u == 0) colPrev0 = cp;
-                    else colPrev1 = cp;
-                }
-            }
+            __syncthreads();
+            finishRows(it);
+            __syncthreads();
         }
-        rowsDone = rowsNew;
-        if (plan.endBarrier) __syncthreads();
+    }
+    if (!plan.endBarrier) {
+        __syncthreads();
+        finishRows(nIter - 1u);
     }
     __syncthreads();
     return S.chainEnd > nM32 ? GF_K_ERR_BOUNDS : GF_K_OK;       // last value truncated
@@ -1168,7 +1552,7 @@ constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel lea
 enum { DEC_GENERAL = 0, DEC_ANALYZE = 1, DEC_FAST = 2 };
 
 template <int MODE>
-__global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huffman_decode(GfDecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
@@ -1283,6 +1667,18 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
             __syncthreads();
             continue;
         }
+        if constexpr (FAST) {
+            // the fast Huffman passes want the packing (plus padding) in the M32 buffer and codes of at most 32 bits
+            const uint32_t pkWords = (((uint32_t)(off * 8ull) & 31u) + len * 8u + 31u) >> 5;
+            if (S.maxLen > 32u || (pkWords + FAST_TEXT_PAD) * 4u > a.ldsM32Bytes) {
+                if (tid == 0) {
+                    a.status[t] = GF_K_RETRY;
+                    atomicOr(a.retryFlag, 1u);
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         GF_DSTAMP(2);
         GF_DPHASE_LIMIT(1, continue);
 #ifdef GF_DIAG
@@ -1334,7 +1730,11 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                 const uint64_t baseWord = (off * 8ull) >> 5;
                 const uint32_t sh0 = (uint32_t)(off * 8ull) & 31u;
                 const uint32_t pkWords = (sh0 + endBit + 31u) >> 5;          // words that hold the packing
-                if (!FAST && pkWords * 4u <= a.ldsTextBytes) {
+                if constexpr (FAST) {
+                    tileStatus = huffman_to_m32_fast<MODE>(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
+                                                           sh0, reinterpret_cast<uint32_t *>(ldsDyn), pkWords, lut2, textStart,
+                                                           endBit, nM32, m32, dbg, warmBits);
+                } else if (pkWords * 4u <= a.ldsTextBytes) {
                     // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
                     uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + bmArea);
                     const uint64_t avail = nWords - baseWord;
@@ -1383,7 +1783,11 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 2) void k_huf
                 if constexpr (decltype(inLds)::value) {
                     if (FAST || (plan.ring && model >= 1 && model <= 3)) {
                         fused = true;
-                        return m32_to_tile(S, m32, nM32, bm, wb, model, seed, nR, nC, nStream, plan, o);
+                        #ifdef GF_DIAG
+                        return m32_to_tile(S, m32, nM32, bm, wb, model, seed, nR, nC, nStream, plan, o, dbg ? dbg - 11 : nullptr, (uint32_t)a.phaseLimit);
+#else
+                        return m32_to_tile(S, m32, nM32, bm, wb, model, seed, nR, nC, nStream, plan, o, nullptr, 0u);
+#endif
                     }
                 }
                 if constexpr (!FAST) {
@@ -1658,7 +2062,6 @@ uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
     // typical M32 streams are ~1.0-1.1 bytes per cell; larger ones spill to the workspace
     size_t cells = (size_t)nRows * (size_t)nCols;
     size_t want = cells + cells / 8 + 512;
-    if (const char *e = getenv("GF_DEC_LDS_M32")) return (uint32_t)(atoi(e) & ~31);      // experiment hook
     if (want < 8192) want = 8192;
     if (want > 65536) want = 65536;             // with bitmap, rank bases, text and the static part: < 160 KB
     return (uint32_t)((want + 31) & ~(size_t)31);
@@ -1693,39 +2096,22 @@ unsigned gf_huffman_decode_grid(size_t nTiles)
 
 #endif
 
-// dynamic LDS beyond the default limit must be opted into, per kernel and PER DEVICE (hipFuncSetAttribute acts on the
-// current device's copy of the function): the largest size asked for so far is kept per device
-template <class K>
-static hipError_t optInDynLds(K kernel, size_t dyn, size_t (&done)[GF_MAX_DEVICES], std::mutex &mu)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= GF_MAX_DEVICES) return hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(mu);
-    if (dyn <= done[dev]) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (e == hipSuccess) done[dev] = dyn;
-    return e;
-}
-
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid)
 {
     if (a.nTiles == 0) return hipSuccess;
     const size_t dyn = decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
-    static size_t doneG[GF_MAX_DEVICES], doneA[GF_MAX_DEVICES], doneF[GF_MAX_DEVICES];
-    static std::mutex mu;
+    static GfDynLdsOptIn optG, optA, optF;
     hipError_t e;
     if (a.analysis) {
-        if ((e = optInDynLds(k_huffman_decode<DEC_ANALYZE>, dyn, doneA, mu)) != hipSuccess) return e;
+        if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_ANALYZE>, dyn, optA)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_huffman_decode<DEC_ANALYZE>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
         return hipGetLastError();
     }
-    if ((e = optInDynLds(k_huffman_decode<DEC_GENERAL>, dyn, doneG, mu)) != hipSuccess) return e;
+    if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_GENERAL>, dyn, optG)) != hipSuccess) return e;
     if (a.retryFlag) {
         // CodecHuffman batches: the fast kernel first; the general one picks up what that one marked (and returns at once
         // when nothing is marked)
-        if ((e = optInDynLds(k_huffman_decode<DEC_FAST>, dyn, doneF, mu)) != hipSuccess) return e;
+        if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST>, dyn, optF)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(a.retryFlag, 0, 4, stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     }
@@ -1738,9 +2124,8 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
 {
     if (a.nTiles == 0) return hipSuccess;
     const size_t dyn = decodeDynLds(a.ldsM32Bytes, 0);
-    static size_t done[GF_MAX_DEVICES];
-    static std::mutex mu;
-    hipError_t e = optInDynLds(k_lsop_unpack_m32, dyn, done, mu);
+    static GfDynLdsOptIn opt;
+    hipError_t e = gf_opt_in_dyn_lds(k_lsop_unpack_m32, dyn, opt);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lsop_unpack_m32, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();

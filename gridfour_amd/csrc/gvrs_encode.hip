@@ -106,16 +106,18 @@ __device__ __forceinline__ void wave_huff_rounds(GfHuffTree &T, uint32_t (&K)[4]
     if (lane == 0 && n >= 1) T.parent[2 * n - 2] = 0xFFFF;         // root
 }
 
-// diagnostic: cycle stamps per phase (only when a debug buffer is attached)
+// diagnostics: cycle stamps per phase, dump of the on-chip tables, phase ablation -- only in the -DGF_DIAG flavour of the
+// library (tools/); the shipping kernels carry none of it
+#ifdef GF_DIAG
 #define GF_STAMP(i)                                                                       \
     do {                                                                                  \
         if (a.debug && tid == 0)                                                          \
             (a.debug + t * (size_t)GF_ENC_DEBUG_WORDS + GF_ENC_DEBUG_WORDS - 16)[i] =    \
                 (uint32_t)__builtin_amdgcn_s_memtime();                                   \
     } while (0)
-
-
-
+#else
+#define GF_STAMP(i) do { } while (0)
+#endif
 
 // stream elements [sBegin, sEnd) of `model`, any residual size: the general (slow) packer
 __device__ void pack_generic(int model, const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
@@ -413,7 +415,9 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
         __syncthreads();
         const uint32_t flags = P.flags;
         GF_STAMP(1);
+#ifdef GF_DIAG
         if (a.phaseLimit == 1) { __syncthreads(); continue; }
+#endif
         const bool anyNull = flags & 1u, anyValid = flags & 2u;
         // cells that were counted as residual 0 above: the seed cell + the padding of the last step
         uint32_t forcedZeros = ((nCells + CPT - 1) / CPT) * CPT - nCells + 1u;
@@ -631,16 +635,18 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
         }
         __syncthreads();
         GF_STAMP(5);
-        if (a.debug) {                           // diagnostic dump of the on-chip state (tests/tools only)
+#ifdef GF_DIAG
+        if (a.debug) {                           // dump of the on-chip state
             uint32_t *dbg = a.debug + t * (size_t)GF_ENC_DEBUG_WORDS;
             const uint32_t *pw = reinterpret_cast<const uint32_t *>(&P);
             const uint32_t *tw = reinterpret_cast<const uint32_t *>(&S.tree[0]);
             for (uint32_t i = tid; i < sizeof(EncPersist) / 4; i += ENC_THREADS) dbg[i] = pw[i];
             for (uint32_t i = tid; i < 3 * sizeof(GfHuffTree) / 4; i += ENC_THREADS)
                 dbg[sizeof(EncPersist) / 4 + i] = tw[i];
-            __syncthreads();                     // trees dead from here: S.win may be written
+            __syncthreads();
         }
         if (a.phaseLimit == 2) continue;
+#endif
 
         // ---------------- phase C: pick the shortest, pack it ----------------
         int best = -1;

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 // per-tile status values written by the kernels; identical to gf_status in
 // include/gvrs_hip_codec.h
 #define GF_K_OK 0
@@ -15,7 +17,27 @@
 #define GF_K_ERR_ARG (-4)
 #define GF_K_ERR_UNSUPPORTED (-7)
 
-constexpr int GF_MAX_DEVICES = 64;            // per-device launch state (dynamic-LDS opt-in) is kept for this many devices
+// Dynamic LDS beyond the default limit must be opted into, per kernel and PER DEVICE (hipFuncSetAttribute acts on the
+// current device's copy of the function).  One GfDynLdsOptIn per kernel remembers the largest size asked for on each
+// device; contexts on different devices and threads of one process share it safely.
+constexpr int GF_MAX_DEVICES = 64;
+struct GfDynLdsOptIn {
+    size_t done[GF_MAX_DEVICES] = {};
+    std::mutex mu;
+};
+template <class K>
+inline hipError_t gf_opt_in_dyn_lds(K kernel, size_t dyn, GfDynLdsOptIn &st)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= GF_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (dyn <= st.done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e == hipSuccess) st.done[dev] = dyn;
+    return e;
+}
 
 struct GfEncodeArgs {
     const int32_t *values;     // nTiles * nRows*nCols

@@ -990,13 +990,9 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
     const unsigned grid = (unsigned)(wgs < 65536 * 16 ? wgs : 65536 * 16);
     const size_t dyn = (size_t)4 * (64 * 16 + 4 * (size_t)nCols) * 4;      // per wave: 64 rings of 16 + 4 row buffers
     if (dyn <= 96 * 1024) {
-        static size_t maxDynSet = 0;
-        if (dyn > maxDynSet) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsop_reconstruct),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            if (e != hipSuccess) return e;
-            maxDynSet = dyn;
-        }
+        static GfDynLdsOptIn opt;
+        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct, dyn, opt);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_lsop_reconstruct, dim3(grid), dim3(256), dyn, stream, a);
     } else {
         hipLaunchKernelGGL(k_lsop_reconstruct_global, dim3(grid), dim3(256), 0, stream, a);   // very wide tiles

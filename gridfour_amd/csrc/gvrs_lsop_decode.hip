@@ -106,12 +106,10 @@ hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const u
     if (nTiles == 0) return hipSuccess;
     GfLsopUnpackArgs a{blob, blobBytes, offsets, slotStride, lengths, residuals, resStride, coefs, status, nTiles, nRows, nCols,
                        ldsTextBytes, pre};
-    static size_t maxDynSet = 0;
-    if (ldsTextBytes > maxDynSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsop_unpack2),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTextBytes);
+    static GfDynLdsOptIn opt;
+    {
+        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_unpack2, ldsTextBytes, opt);
         if (e != hipSuccess) return e;
-        maxDynSet = ldsTextBytes;
     }
     hipLaunchKernelGGL(k_lsop_unpack2, dim3(grid), dim3(DEC_THREADS), ldsTextBytes, stream, a);
     return hipGetLastError();

@@ -3,6 +3,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ["GVRS_HIP_DIAG"] = "1"           # the diagnostic flavour of the library carries the stamps
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +28,7 @@ def main():
     ctx.synchronize()
     L.gf_internal_set_phase_limits.argtypes = [C.c_int, C.c_int]
     warm = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    L.gf_internal_set_phase_limits(0, warm << 8)
+    L.gf_internal_set_phase_limits(0, (warm << 8) if warm < 256 else warm)     # >= 256: raw diagnostic flags (0x10000: no stores)
     L.gf_internal_set_decode_debug(dbg.ptr)
     b.decode()
     ctx.synchronize()
@@ -34,10 +36,16 @@ def main():
     L.gf_internal_set_phase_limits(0, 0)
     st = dbg.download(np.uint32, 16 * nt).reshape(nt, 16).astype(np.int64)
     rel = (st[:, :11] - st[:, :1]) & 0xFFFFFFFF
-    names = ["0 start", "1 header", "2 tree records", "3 LUT built", "4 huffman sync pass", "5 huffman write pass", "6 -", "7 -",
+    names = ["0 start", "1 header", "2 tree records", "3 LUT built", "4 huffman sync pass", "5 huffman write pass", "6 value starts marked + ranked", "7 border prologue",
              "8 values (+ inverse when fused)", "9 -", "10 end"]
-    for i in (1, 2, 3, 4, 5, 8, 10):
+    for i in (1, 2, 3, 4, 5, 6, 7, 8, 10):
         print("  after %-34s median %9d  p90 %9d" % (names[i], np.median(rel[:, i]), np.percentile(rel[:, i], 90)))
+    for i, nme in ((12, "chunk loop: decode + wave scans"), (13, "chunk loop: barrier"), (14, "chunk loop: bases + ring writes"),
+                   (15, "chunk loop: rows finished from the ring")):
+        print("  %-40s median %9d  p90 %9d   (wave 0, summed over the chunks)" % (nme, np.median(st[:, i]), np.percentile(st[:, i], 90)))
+    print("  huffman sync: rounds median %d p90 %d max %d; first round cycles median %d; text staging cycles median %d; steps of wave 0 in round 1 median %d p90 %d" % (
+        np.median(st[:, 11]), np.percentile(st[:, 11], 90), st[:, 11].max(), np.median(st[:, 12]), np.median(st[:, 13]),
+        np.median(st[:, 14]), np.percentile(st[:, 14], 90)))
     pred = b.get_predictors()
     if True:
         print("  predictors chosen:", {int(k): int(v) for k, v in zip(*np.unique(pred, return_counts=True))})

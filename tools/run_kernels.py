@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ["GVRS_HIP_DIAG"] = "1"           # phase limits exist in the diagnostic flavour of the library only
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gridfour_amd  # noqa: E402

@@ -1,5 +1,6 @@
 """Decode time vs warm-up length of the Huffman subsequence synchronisation (experiment)."""
 import ctypes as C, os, sys
+os.environ["GVRS_HIP_DIAG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gridfour_amd
@@ -11,7 +12,7 @@ b.synth_dem(0x9E3779B97F4A7C15 + 2, 144)
 L = lib(); L.gf_internal_set_phase_limits.argtypes = [C.c_int, C.c_int]
 b.encode(); ctx.synchronize()
 vals = b.get_values()
-for warm in (128, 160, 192, 256, 320, 96):
+for warm in (128, 1, 8, 512, 2048):
     L.gf_internal_set_phase_limits(0, warm << 8)
     for _ in range(2): b.decode()
     tm = GpuTimer(ctx); tm.start()
