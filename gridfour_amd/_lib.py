@@ -100,6 +100,22 @@ SIGNATURES = {
     "gf_dev_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
     "gf_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "gf_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "gf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "gf_host_free": (C.c_int, [_vp]),
+    "gf_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "gf_multi_destroy": (None, [_vp]),
+    "gf_multi_count": (C.c_int, [_vp]),
+    "gf_multi_context": (_vp, [_vp, C.c_int]),
+    "gf_multi_device": (C.c_int, [_vp, C.c_int]),
+    "gf_multi_partition": (None, [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "gf_multi_synchronize": (C.c_int, [_vp]),
+    "gf_huffman_encode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "gf_huffman_decode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_canon_encode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "gf_canon_decode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_huffman_encode_batch_i32_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp,
+                                                        C.c_int]),
+    "gf_huffman_decode_batch_i32_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "gf_timer_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "gf_timer_destroy": (None, [_vp]),
     "gf_timer_start": (C.c_int, [_vp, _vp]),

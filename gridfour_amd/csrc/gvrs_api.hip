@@ -85,7 +85,9 @@ struct gf_context {
     DevBuf dPlanes;        // CodecFloat plane staging
     DevBuf dResiduals, dCoefs, dStatus2;   // LSOP staging
     DevBuf dM32, dM32Len, dM32Models, dSeeds;   // CodecDeflate staging
+    struct gf_host_pipe *pipe = nullptr;        // pipelined staging of the host-memory batch entry points (created on first use)
 };
+void gf_host_pipe_destroy(struct gf_host_pipe *p);
 
 struct gf_timer {
     gf_context *ctx;
@@ -201,6 +203,7 @@ void gf_context_destroy(gf_context *c)
     c->dM32Len.release();
     c->dM32Models.release();
     c->dSeeds.release();
+    gf_host_pipe_destroy(c->pipe);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -635,6 +638,21 @@ gf_status gf_float_decode_f32(gf_context *c, int nRows, int nCols, const uint8_t
 
 // ------------------------------------------------------------------ device memory helpers
 
+// page-locked host memory: the host-memory batch entry points move it over PCIe in place (no staging copy)
+gf_status gf_host_alloc(size_t bytes, void **p)
+{
+    if (!p) return GF_ERR_ARG;
+    *p = nullptr;
+    GF_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable));
+    return GF_OK;
+}
+
+gf_status gf_host_free(void *p)
+{
+    if (p) GF_HIP(hipHostFree(p));
+    return GF_OK;
+}
+
 gf_status gf_dev_malloc(gf_context *c, size_t bytes, void **p)
 {
     if (!c || !p) return GF_ERR_ARG;
@@ -727,133 +745,356 @@ gf_status gf_timer_elapsed_ms(gf_timer *t, float *ms)
 
 }  // extern "C"
 
+// ---- pipelined staging of the host-memory batch entry points ---------------------------------------------------
+// A batch in host memory is cut into chunks of about HOST_CHUNK_BYTES of cell values.  Each chunk travels through one of
+// HOST_SLOTS slots (pinned staging buffers, device buffers, a stream of its own): the calling thread copies the caller's
+// (pageable) memory into the slot's pinned buffer with a few helper threads, enqueues H2D copy + kernels + D2H copy on the
+// slot's stream and moves on to the next chunk, so that the copy-in of chunk k+1, the device work of chunk k and the
+// copy-out of chunk k-1 overlap.  Device and pinned memory are bounded by the chunk, not by the batch.  Memory the caller
+// obtained from gf_host_alloc (or pinned itself) is used in place, without the staging copy.
+constexpr int HOST_SLOTS = 3;
+constexpr size_t HOST_CHUNK_BYTES = (size_t)64 << 20;
+
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    gf_status ensure(size_t need)
+    {
+        if (need <= bytes) return GF_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        need = roundUp(need + need / 8, 1 << 20);
+        GF_HIP(hipHostMalloc(&p, need, hipHostMallocDefault));
+        bytes = need;
+        return GF_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct HostSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t evA = nullptr, evB = nullptr;       // device work enqueued so far / final copy-out done
+    hipEvent_t evK = nullptr;                      // the chunk's codec kernels are done (they use the context's per-tile records)
+    DevBuf dValues, dSlots, dBlob, dLengths, dPred, dStatus, dOffsets;
+    PinBuf hIn, hOut, hMeta;
+    void release()
+    {
+        dValues.release(); dSlots.release(); dBlob.release(); dLengths.release(); dPred.release(); dStatus.release();
+        dOffsets.release(); hIn.release(); hOut.release(); hMeta.release();
+        if (evA) (void)hipEventDestroy(evA);
+        if (evB) (void)hipEventDestroy(evB);
+        if (evK) (void)hipEventDestroy(evK);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr; evA = evB = evK = nullptr;
+    }
+};
+
+struct gf_host_pipe {
+    HostSlot slot[HOST_SLOTS];
+};
+
+static gf_status hostPipe(gf_context *c, gf_host_pipe **out)
+{
+    if (!c->pipe) {
+        gf_host_pipe *p = new (std::nothrow) gf_host_pipe();
+        if (!p) return GF_ERR_ARG;
+        for (int i = 0; i < HOST_SLOTS; i++) {
+            hipError_t e = hipStreamCreateWithFlags(&p->slot[i].stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->slot[i].evA, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->slot[i].evB, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->slot[i].evK, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                for (int j = 0; j <= i; j++) p->slot[j].release();
+                delete p;
+                return hipFail(e, "host pipeline set-up");
+            }
+        }
+        c->pipe = p;
+    }
+    *out = c->pipe;
+    return GF_OK;
+}
+
+void gf_host_pipe_destroy(gf_host_pipe *p)
+{
+    if (!p) return;
+    for (int i = 0; i < HOST_SLOTS; i++) p->slot[i].release();
+    delete p;
+}
+
+// is this host pointer page-locked (hipHostMalloc / hipHostRegister)?  Then the DMA engines read and write it directly.
+static bool isPinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();                   // pageable memory is reported as an error; clear it
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// memcpy with a few helper threads: one thread moves 6-10 GB/s, PCIe Gen5 x16 five times that
+static void parallelCopy(void *dst, const void *src, size_t bytes)
+{
+    const size_t per = (size_t)8 << 20;
+    unsigned nt = (unsigned)std::min<size_t>(8, bytes / per);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && nt > hw) nt = hw;
+    if (nt <= 1) { memcpy(dst, src, bytes); return; }
+    const size_t part = roundUp((bytes + nt - 1) / nt, 4096);
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < nt; w++) {
+        const size_t o = (size_t)w * part;
+        if (o >= bytes) break;
+        th.emplace_back([=]() { memcpy((uint8_t *)dst + o, (const uint8_t *)src + o, std::min(part, bytes - o)); });
+    }
+    memcpy(dst, src, std::min(part, bytes));
+    for (auto &x : th) x.join();
+}
+
+static size_t hostChunkTiles(size_t cells, size_t nTiles)
+{
+    const size_t n = std::max<size_t>(1, HOST_CHUNK_BYTES / (cells * 4));
+    return std::min(n, std::max<size_t>(nTiles, 1));
+}
+
 static gf_status encodeBatchHost(int kind, gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles,
                                  const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
                                  uint8_t *predictors, int32_t *status)
 {
-    if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    if (!c || nRows < 1 || nCols < 1 || (!values && nTiles) || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
+    gf_host_pipe *P;
+    gf_status s = hostPipe(c, &P);
+    if (s != GF_OK) return s;
     const size_t cells = (size_t)nRows * (size_t)nCols;
     const size_t stride = gf_huffman_default_stride(nRows, nCols);
-    gf_status s;
-    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dSlots.ensure(nTiles * stride + 16)) != GF_OK) return s;
-    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dPred.ensure(nTiles + 16)) != GF_OK) return s;
-    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
-    GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
-    s = encodeBatchDev(kind, c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
-                       (uint8_t *)c->dSlots.p, stride, (uint32_t *)c->dLengths.p, (uint8_t *)c->dPred.p,
-                       (int32_t *)c->dStatus.p, GF_PM_ALL);
-    if (s != GF_OK) return s;
-    std::vector<uint32_t> lengths(nTiles);
-    std::vector<int32_t> st(nTiles);
-    GF_HIP(hipMemcpyAsync(lengths.data(), c->dLengths.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-    if (predictors) GF_HIP(hipMemcpyAsync(predictors, c->dPred.p, nTiles, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipStreamSynchronize(c->stream));
+    const size_t chunk = hostChunkTiles(cells, nTiles);
+    const size_t nChunks = (nTiles + chunk - 1) / chunk;
+    const bool pinnedIn = nTiles && isPinned(values), pinnedOut = blob && isPinned(blob);
+    // the per-tile records between the encoder kernels are per context: one launch at a time uses them, so every chunk's
+    // kernels run in the context's stream order (the slot streams carry the copies and wait for / signal the kernels)
+    if ((s = gf_context_reserve(c, nRows, nCols, chunk)) != GF_OK) return s;
 
-    // tiles whose packing did not fit the default slot (longer than the raw tile): redo them one by
-    // one into a worst-case slot so that the bytes are still exactly the reference's
-    std::vector<std::vector<uint8_t>> big(nTiles);
-    bool anyBig = false;
-    for (size_t t = 0; t < nTiles; t++) {
-        if (st[t] != GF_OVERFLOW) continue;
-        anyBig = true;
-        const size_t maxp = kind == KIND_CANON ? gf_canon_max_packing(nRows, nCols) : gf_huffman_max_packing(nRows, nCols);
-        DevBuf slot, meta;
-        if ((s = slot.ensure(maxp)) != GF_OK) return s;
-        if ((s = meta.ensure(64)) != GF_OK) { slot.release(); return s; }
-        uint32_t *dLen = (uint32_t *)meta.p;
-        int32_t *dSt = (int32_t *)((uint8_t *)meta.p + 16);
-        s = encodeBatchDev(kind, c, c->stream, codecIndex, nRows, nCols, 1, (const int32_t *)c->dValues.p + t * cells,
-                           (uint8_t *)slot.p, maxp, dLen, nullptr, dSt, GF_PM_ALL);
-        if (s == GF_OK) {
-            uint32_t l = 0;
-            int32_t tst = 0;
-            hipError_t e1 = hipMemcpyAsync(&l, dLen, 4, hipMemcpyDeviceToHost, c->stream);
-            hipError_t e2 = hipMemcpyAsync(&tst, dSt, 4, hipMemcpyDeviceToHost, c->stream);
-            hipError_t e3 = hipStreamSynchronize(c->stream);
-            big[t].resize(l);
-            hipError_t e4 = l ? hipMemcpy(big[t].data(), slot.p, l, hipMemcpyDeviceToHost) : hipSuccess;
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-                slot.release();
-                meta.release();
-                return hipFail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4,
-                               "overflow tile copy");
+    struct Meta { uint32_t *len; int32_t *st; uint8_t *pred; uint64_t *off; };
+    auto metaOf = [&](HostSlot &S) {
+        Meta m;
+        uint8_t *b = (uint8_t *)S.hMeta.p;
+        m.off = (uint64_t *)b;
+        m.len = (uint32_t *)(b + roundUp((chunk + 1) * 8, 64));
+        m.st = (int32_t *)((uint8_t *)m.len + roundUp(chunk * 4, 64));
+        m.pred = (uint8_t *)m.st + roundUp(chunk * 4, 64);
+        return m;
+    };
+    for (int i = 0; i < HOST_SLOTS && (size_t)i < nChunks; i++) {
+        HostSlot &S = P->slot[i];
+        if ((s = S.dValues.ensure(chunk * cells * 4 + 16)) != GF_OK) return s;
+        if ((s = S.dSlots.ensure(chunk * stride + 16)) != GF_OK) return s;
+        if ((s = S.dBlob.ensure(chunk * stride + 16)) != GF_OK) return s;
+        if ((s = S.dLengths.ensure(chunk * 4 + 16)) != GF_OK) return s;
+        if ((s = S.dPred.ensure(chunk + 16)) != GF_OK) return s;
+        if ((s = S.dStatus.ensure(chunk * 4 + 16)) != GF_OK) return s;
+        if ((s = S.dOffsets.ensure((chunk + 1) * 8 + 16)) != GF_OK) return s;
+        if (!pinnedIn && (s = S.hIn.ensure(chunk * cells * 4)) != GF_OK) return s;
+        if ((s = S.hOut.ensure(chunk * stride)) != GF_OK) return s;
+        if ((s = S.hMeta.ensure(roundUp((chunk + 1) * 8, 64) + 2 * roundUp(chunk * 4, 64) + roundUp(chunk, 64) + 64)) != GF_OK) return s;
+    }
+
+    uint64_t total = 0;                            // bytes of the packings placed so far
+    bool overCap = false;
+    offsets[0] = 0;
+    // stage B of a chunk: its kernels are done -> overflow tiles, then the compact blob comes home
+    auto stageB = [&](size_t k) -> gf_status {
+        HostSlot &S = P->slot[k % HOST_SLOTS];
+        const size_t t0 = k * chunk, n = std::min(chunk, nTiles - t0);
+        const Meta m = metaOf(S);
+        GF_HIP(hipEventSynchronize(S.evA));
+        const uint64_t bytes = m.off[n];
+        if (bytes) GF_HIP(hipMemcpyAsync(S.hOut.p, S.dBlob.p, bytes, hipMemcpyDeviceToHost, S.stream));
+        GF_HIP(hipEventRecord(S.evB, S.stream));
+        return GF_OK;
+    };
+    // stage C: the blob of the chunk is in pinned memory -> the caller's arrays
+    auto stageC = [&](size_t k) -> gf_status {
+        HostSlot &S = P->slot[k % HOST_SLOTS];
+        const size_t t0 = k * chunk, n = std::min(chunk, nTiles - t0);
+        const Meta m = metaOf(S);
+        GF_HIP(hipEventSynchronize(S.evB));
+        bool anyBig = false;
+        for (size_t t = 0; t < n; t++) anyBig = anyBig || m.st[t] == GF_OVERFLOW;
+        if (!anyBig) {
+            const uint64_t bytes = m.off[n];
+            if (total + bytes <= blobCap) {
+                if (bytes) parallelCopy(blob + total, S.hOut.p, bytes);
+            } else {
+                overCap = true;
             }
-            lengths[t] = l;
-            st[t] = tst;
+            for (size_t t = 0; t < n; t++) offsets[t0 + t + 1] = total + m.off[t + 1];
+            total += bytes;
+        } else {
+            // tiles whose packing did not fit the default slot (longer than the raw tile): redone one by one into a
+            // worst-case slot so that the bytes are still exactly the reference's
+            const size_t maxp = kind == KIND_CANON ? gf_canon_max_packing(nRows, nCols) : gf_huffman_max_packing(nRows, nCols);
+            DevBuf slot, meta;
+            gf_status r;
+            for (int i = 0; i < HOST_SLOTS; i++) GF_HIP(hipStreamSynchronize(P->slot[i].stream));   // nothing else uses the records now
+            if ((r = slot.ensure(maxp)) != GF_OK) return r;
+            if ((r = meta.ensure(64)) != GF_OK) { slot.release(); return r; }
+            std::vector<uint8_t> big;
+            for (size_t t = 0; t < n; t++) {
+                uint64_t len = (m.st[t] == GF_OK) ? m.len[t] : 0;
+                const uint8_t *src = (const uint8_t *)S.hOut.p + m.off[t];
+                if (m.st[t] == GF_OVERFLOW) {
+                    uint32_t *dLen = (uint32_t *)meta.p;
+                    int32_t *dSt = (int32_t *)((uint8_t *)meta.p + 16);
+                    r = encodeBatchDev(kind, c, S.stream, codecIndex, nRows, nCols, 1, (const int32_t *)S.dValues.p + t * cells,
+                                       (uint8_t *)slot.p, maxp, dLen, nullptr, dSt, GF_PM_ALL);
+                    uint32_t l = 0;
+                    int32_t tst = 0;
+                    hipError_t e = hipSuccess;
+                    if (r == GF_OK) e = hipMemcpyAsync(&l, dLen, 4, hipMemcpyDeviceToHost, S.stream);
+                    if (r == GF_OK && e == hipSuccess) e = hipMemcpyAsync(&tst, dSt, 4, hipMemcpyDeviceToHost, S.stream);
+                    if (r == GF_OK && e == hipSuccess) e = hipStreamSynchronize(S.stream);
+                    if (r == GF_OK && e == hipSuccess) {
+                        big.resize(l);
+                        if (l) e = hipMemcpy(big.data(), slot.p, l, hipMemcpyDeviceToHost);
+                    }
+                    if (r != GF_OK || e != hipSuccess) {
+                        slot.release();
+                        meta.release();
+                        return r != GF_OK ? r : hipFail(e, "overflow tile copy");
+                    }
+                    m.st[t] = tst;
+                    m.len[t] = l;
+                    len = tst == GF_OK ? l : 0;
+                    src = big.data();
+                }
+                if (total + len <= blobCap) {
+                    if (len) memcpy(blob + total, src, len);
+                } else {
+                    overCap = true;
+                }
+                total += len;
+                offsets[t0 + t + 1] = total;
+            }
+            slot.release();
+            meta.release();
         }
-        slot.release();
-        meta.release();
-        if (s != GF_OK) return s;
-    }
+        if (status) memcpy(status + t0, m.st, n * 4);
+        if (predictors) memcpy(predictors + t0, m.pred, n);
+        return GF_OK;
+    };
 
-    uint64_t total = 0;
-    for (size_t t = 0; t < nTiles; t++) {
-        offsets[t] = total;
-        total += (st[t] == GF_OK) ? lengths[t] : 0;
-    }
-    offsets[nTiles] = total;
-    if (status) memcpy(status, st.data(), nTiles * 4);
-    if (total > blobCap) return GF_ERR_CAPACITY;
-
-    if (!anyBig) {
-        // contiguous blob built on the device, one D2H copy
-        if ((s = c->dBlob.ensure(total + 16)) != GF_OK) return s;
-        // lengths of failed tiles must be zero for the scan
-        bool patched = false;
-        for (size_t t = 0; t < nTiles; t++)
-            if (st[t] != GF_OK && lengths[t]) { lengths[t] = 0; patched = true; }
-        if (patched) GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
-        s = gf_compact_dev(c, c->stream, nTiles, (const uint8_t *)c->dSlots.p, stride, (const uint32_t *)c->dLengths.p,
-                           (uint64_t *)c->dOffsets.p, (uint8_t *)c->dBlob.p, c->dBlob.bytes);
-        if (s != GF_OK) return s;
-        if (total) GF_HIP(hipMemcpyAsync(blob, c->dBlob.p, total, hipMemcpyDeviceToHost, c->stream));
-        GF_HIP(hipStreamSynchronize(c->stream));
-    } else {
-        for (size_t t = 0; t < nTiles; t++) {
-            if (st[t] != GF_OK || lengths[t] == 0) continue;
-            if (!big[t].empty()) memcpy(blob + offsets[t], big[t].data(), lengths[t]);
-            else GF_HIP(hipMemcpy(blob + offsets[t], (const uint8_t *)c->dSlots.p + t * stride, lengths[t],
-                                  hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < nChunks + 2; k++) {
+        if (k >= 2 && k - 2 < nChunks && (s = stageC(k - 2)) != GF_OK) return s;     // frees slot (k - 2) % 3 ... used again at k + 1
+        if (k < nChunks) {
+            HostSlot &S = P->slot[k % HOST_SLOTS];
+            const size_t t0 = k * chunk, n = std::min(chunk, nTiles - t0);
+            const Meta m = metaOf(S);
+            const int32_t *src = values + t0 * cells;
+            if (!pinnedIn) {
+                parallelCopy(S.hIn.p, src, n * cells * 4);
+                src = (const int32_t *)S.hIn.p;
+            }
+            GF_HIP(hipMemcpyAsync(S.dValues.p, src, n * cells * 4, hipMemcpyHostToDevice, S.stream));
+            // the codec kernels of successive chunks share the context's per-tile records: they run one after the other
+            // (the copies around them overlap freely)
+            if (k > 0) GF_HIP(hipStreamWaitEvent(S.stream, P->slot[(k - 1) % HOST_SLOTS].evK, 0));
+            s = encodeBatchDev(kind, c, S.stream, codecIndex, nRows, nCols, n, (const int32_t *)S.dValues.p, (uint8_t *)S.dSlots.p,
+                               stride, (uint32_t *)S.dLengths.p, (uint8_t *)S.dPred.p, (int32_t *)S.dStatus.p, GF_PM_ALL);
+            if (s != GF_OK) return s;
+            GF_HIP(hipEventRecord(S.evK, S.stream));
+            GF_HIP(hipMemcpyAsync(m.len, S.dLengths.p, n * 4, hipMemcpyDeviceToHost, S.stream));
+            GF_HIP(hipMemcpyAsync(m.st, S.dStatus.p, n * 4, hipMemcpyDeviceToHost, S.stream));
+            GF_HIP(hipMemcpyAsync(m.pred, S.dPred.p, n, hipMemcpyDeviceToHost, S.stream));
+            GF_HIP(gf_launch_compact(n, (const uint8_t *)S.dSlots.p, stride, (const uint32_t *)S.dLengths.p, (uint64_t *)S.dOffsets.p,
+                                     (uint8_t *)S.dBlob.p, S.dBlob.bytes, S.stream, (const int32_t *)S.dStatus.p));
+            GF_HIP(hipMemcpyAsync(m.off, S.dOffsets.p, (n + 1) * 8, hipMemcpyDeviceToHost, S.stream));
+            GF_HIP(hipEventRecord(S.evA, S.stream));
         }
+        if (k >= 1 && k - 1 < nChunks && (s = stageB(k - 1)) != GF_OK) return s;
     }
-    return GF_OK;
+    (void)pinnedOut;
+    return overCap ? GF_ERR_CAPACITY : GF_OK;
 }
 
 static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                  const uint64_t *offsets, int32_t *values, int32_t *status)
 {
-    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || (!values && nTiles)) return GF_ERR_ARG;
+    for (size_t t = 0; t < nTiles; t++)
+        if (offsets[t + 1] < offsets[t] || offsets[t + 1] - offsets[t] > 0xFFFFFFFFull) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
-    const size_t cells = (size_t)nRows * (size_t)nCols;
-    const uint64_t total = offsets[nTiles];
-    gf_status s;
-    if ((s = c->dBlob.ensure(total + 32)) != GF_OK) return s;
-    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
-    std::vector<uint32_t> lengths(nTiles);
-    for (size_t t = 0; t < nTiles; t++) {
-        if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
-        lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
-    }
-    GF_HIP(hipMemcpyAsync(c->dBlob.p, blob, total, hipMemcpyHostToDevice, c->stream));
-    GF_HIP(hipMemcpyAsync(c->dOffsets.p, offsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
-    s = decodeBatchDev(kind, c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total,
-                       (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p, (int32_t *)c->dValues.p,
-                       (int32_t *)c->dStatus.p);
+    gf_host_pipe *P;
+    gf_status s = hostPipe(c, &P);
     if (s != GF_OK) return s;
-    GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
-    std::vector<int32_t> st(nTiles);
-    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipStreamSynchronize(c->stream));
-    if (status) memcpy(status, st.data(), nTiles * 4);
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const size_t chunk = hostChunkTiles(cells, nTiles);
+    const size_t nChunks = (nTiles + chunk - 1) / chunk;
+    const bool pinnedOut = nTiles && isPinned(values);
+    if ((s = gf_context_reserve(c, nRows, nCols, chunk)) != GF_OK) return s;
+    // the largest blob slice of a chunk
+    uint64_t maxSlice = 0;
+    for (size_t k = 0; k < nChunks; k++) {
+        const size_t t0 = k * chunk, t1 = std::min(nTiles, t0 + chunk);
+        maxSlice = std::max(maxSlice, offsets[t1] - offsets[t0]);
+    }
+    const size_t metaBytes = roundUp((chunk + 1) * 8, 64) + 2 * roundUp(chunk * 4, 64) + 64;
+    for (int i = 0; i < HOST_SLOTS && (size_t)i < nChunks; i++) {
+        HostSlot &S = P->slot[i];
+        if ((s = S.dValues.ensure(chunk * cells * 4 + 16)) != GF_OK) return s;
+        if ((s = S.dBlob.ensure(maxSlice + 64)) != GF_OK) return s;
+        if ((s = S.dLengths.ensure(chunk * 4 + 16)) != GF_OK) return s;
+        if ((s = S.dStatus.ensure(chunk * 4 + 16)) != GF_OK) return s;
+        if ((s = S.dOffsets.ensure((chunk + 1) * 8 + 16)) != GF_OK) return s;
+        if ((s = S.hIn.ensure(maxSlice + 64)) != GF_OK) return s;
+        if (!pinnedOut && (s = S.hOut.ensure(chunk * cells * 4)) != GF_OK) return s;
+        if ((s = S.hMeta.ensure(metaBytes)) != GF_OK) return s;
+    }
+    auto finish = [&](size_t k) -> gf_status {
+        HostSlot &S = P->slot[k % HOST_SLOTS];
+        const size_t t0 = k * chunk, n = std::min(chunk, nTiles - t0);
+        GF_HIP(hipEventSynchronize(S.evA));
+        if (!pinnedOut) parallelCopy(values + t0 * cells, S.hOut.p, n * cells * 4);
+        if (status) {
+            uint8_t *b = (uint8_t *)S.hMeta.p;
+            memcpy(status + t0, b + roundUp((chunk + 1) * 8, 64) + roundUp(chunk * 4, 64), n * 4);
+        }
+        return GF_OK;
+    };
+    for (size_t k = 0; k < nChunks + (HOST_SLOTS - 1); k++) {
+        if (k >= (size_t)(HOST_SLOTS - 1) && (s = finish(k - (HOST_SLOTS - 1))) != GF_OK) return s;
+        if (k >= nChunks) continue;
+        HostSlot &S = P->slot[k % HOST_SLOTS];
+        const size_t t0 = k * chunk, n = std::min(chunk, nTiles - t0);
+        uint8_t *mb = (uint8_t *)S.hMeta.p;
+        uint64_t *rel = (uint64_t *)mb;
+        uint32_t *len = (uint32_t *)(mb + roundUp((chunk + 1) * 8, 64));
+        int32_t *st = (int32_t *)((uint8_t *)len + roundUp(chunk * 4, 64));
+        const uint64_t base = offsets[t0], bytes = offsets[t0 + n] - base;
+        for (size_t t = 0; t < n; t++) {
+            rel[t] = offsets[t0 + t] - base;
+            len[t] = (uint32_t)(offsets[t0 + t + 1] - offsets[t0 + t]);
+        }
+        rel[n] = bytes;
+        if (bytes) memcpy(S.hIn.p, blob + base, bytes);                   // the slice starts 4-byte aligned in the staging buffer
+        if (bytes) GF_HIP(hipMemcpyAsync(S.dBlob.p, S.hIn.p, bytes, hipMemcpyHostToDevice, S.stream));
+        GF_HIP(hipMemcpyAsync(S.dOffsets.p, rel, (n + 1) * 8, hipMemcpyHostToDevice, S.stream));
+        GF_HIP(hipMemcpyAsync(S.dLengths.p, len, n * 4, hipMemcpyHostToDevice, S.stream));
+        if (k > 0) GF_HIP(hipStreamWaitEvent(S.stream, P->slot[(k - 1) % HOST_SLOTS].evK, 0));   // kernels one chunk at a time
+        s = decodeBatchDev(kind, c, S.stream, nRows, nCols, n, (const uint8_t *)S.dBlob.p, bytes + 32, (const uint64_t *)S.dOffsets.p, 0,
+                           (const uint32_t *)S.dLengths.p, (int32_t *)S.dValues.p, (int32_t *)S.dStatus.p);
+        if (s != GF_OK) return s;
+        GF_HIP(hipEventRecord(S.evK, S.stream));
+        GF_HIP(hipMemcpyAsync(pinnedOut ? (void *)(values + t0 * cells) : S.hOut.p, S.dValues.p, n * cells * 4, hipMemcpyDeviceToHost,
+                              S.stream));
+        GF_HIP(hipMemcpyAsync(st, S.dStatus.p, n * 4, hipMemcpyDeviceToHost, S.stream));
+        GF_HIP(hipEventRecord(S.evA, S.stream));
+    }
     return GF_OK;
 }
 

@@ -7,8 +7,9 @@
 namespace {
 
 // ---- compaction: exclusive scan of the lengths (one workgroup), then one workgroup per tile copies ----
+// status (optional): a tile whose status is not GF_K_OK contributes no bytes
 __global__ __launch_bounds__(1024) void k_scan_lengths(size_t nTiles, const uint32_t *__restrict__ lengths,
-                                                       uint64_t *__restrict__ offsets)
+                                                       const int32_t *__restrict__ status, uint64_t *__restrict__ offsets)
 {
     __shared__ unsigned long long waveSum[16];
     __shared__ unsigned long long carry;
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(1024) void k_scan_lengths(size_t nTiles, const uint
     __syncthreads();
     for (size_t base = 0; base < nTiles; base += 1024) {
         const size_t i = base + tid;
-        const unsigned long long v = i < nTiles ? lengths[i] : 0ull;
+        const unsigned long long v = (i < nTiles && !(status && status[i] != GF_K_OK)) ? lengths[i] : 0ull;
         unsigned long long incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -40,14 +41,14 @@ __global__ __launch_bounds__(1024) void k_scan_lengths(size_t nTiles, const uint
 }
 
 __global__ __launch_bounds__(256) void k_gather(size_t nTiles, const uint8_t *__restrict__ slots, size_t slotStride,
-                                                const uint32_t *__restrict__ lengths,
+                                                const uint32_t *__restrict__ lengths, const int32_t *__restrict__ status,
                                                 const uint64_t *__restrict__ offsets, uint8_t *__restrict__ blob,
                                                 size_t blobCap)
 {
     for (size_t t = blockIdx.x; t < nTiles; t += gridDim.x) {
         const uint8_t *src = slots + t * slotStride;
         const uint64_t off = offsets[t];
-        const uint32_t len = lengths[t];
+        const uint32_t len = (status && status[t] != GF_K_OK) ? 0u : lengths[t];
         if (off + len > blobCap) continue;
         uint8_t *dst = blob + off;
         // head bytes up to 4-byte alignment of dst, then dwords assembled from the (aligned) slot
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void k_gather(size_t nTiles, const uint8_t *__
         uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
         for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
             const uint32_t b = head + 4 * w;                             // source byte offset
-            const uint32_t lo = s32[b >> 2], hi = s32[(b >> 2) + 1];
+            // the word behind lo only where it still holds bytes of the packing (never read behind the slot)
+            const uint32_t lo = s32[b >> 2], hi = ((b >> 2) + 1u < ((len + 3u) >> 2)) ? s32[(b >> 2) + 1] : 0u;
             const uint32_t sh = (b & 3) * 8;
             d32[w] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
         }
@@ -126,12 +128,12 @@ __global__ __launch_bounds__(256) void k_synth_dem(uint64_t seed, int nRows, int
 }  // namespace
 
 hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStride, const uint32_t *lengths,
-                             uint64_t *offsets, uint8_t *blob, size_t blobCap, hipStream_t stream)
+                             uint64_t *offsets, uint8_t *blob, size_t blobCap, hipStream_t stream, const int32_t *status)
 {
-    hipLaunchKernelGGL(k_scan_lengths, dim3(1), dim3(1024), 0, stream, nTiles, lengths, offsets);
+    hipLaunchKernelGGL(k_scan_lengths, dim3(1), dim3(1024), 0, stream, nTiles, lengths, status, offsets);
     if (nTiles) {
         const unsigned grid = (unsigned)(nTiles < 8192 ? nTiles : 8192);
-        hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, stream, nTiles, slots, slotStride, lengths, offsets,
+        hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, stream, nTiles, slots, slotStride, lengths, status, offsets,
                            blob, blobCap);
     }
     return hipGetLastError();

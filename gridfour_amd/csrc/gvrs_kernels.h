@@ -131,9 +131,10 @@ size_t gf_canon_pack_rec_words();      // words per tile of GfEncodeArgs::packRe
 hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 uint32_t gf_canon_decode_lds_text(int nRows, int nCols);
 
+// status (optional): tiles whose status is not GF_K_OK take no room in the blob
 hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStride,
                              const uint32_t *lengths, uint64_t *offsets, uint8_t *blob,
-                             size_t blobCap, hipStream_t stream);
+                             size_t blobCap, hipStream_t stream, const int32_t *status = nullptr);
 hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                                int64_t tile0, size_t nTiles, int32_t *values, hipStream_t stream);
 

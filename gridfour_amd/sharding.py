@@ -1,10 +1,21 @@
-"""Tile-range partition for multi-GPU runs.
+"""Sharding of tile batches over the GPUs of a node.
 
 Tiles are encoded/decoded with no reference to any other tile (reference:
 gvrs/RasterTile.java:237-241 loops elements independently; codecs take only
 (nRows, nCols, values)), so a batch shards over the GPUs of a node as contiguous tile-index
-ranges with NO data-path collective: rank g of G gets tiles [g*T/G, (g+1)*T/G).
+ranges with NO data-path collective: shard g of G gets tiles [g*T/G, (g+1)*T/G).
+
+Two ways to use several GPUs, both on this partition:
+  * one process per GPU (bench.py under torchrun): `shard_range` gives each rank its range;
+  * one process for the node (what a JVM would do): `GvrsHipMulti` wraps the C ABI's gf_multi_* entry points --
+    one context and one host thread per device inside libgvrs_hip.so, packings concatenated by an exclusive scan.
 """
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
 
 
 def shard_range(n_tiles, rank, world_size):
@@ -14,3 +25,98 @@ def shard_range(n_tiles, rank, world_size):
     lo = (n_tiles * rank) // world_size
     hi = (n_tiles * (rank + 1)) // world_size
     return lo, hi - lo
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class PinnedArray:
+    """Page-locked host memory from gf_host_alloc as a numpy array (moved over PCIe in place by the host batch calls)."""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(np.atleast_1d(shape))
+        n = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        check(lib().gf_host_alloc(max(n, 1), C.byref(self._p)), "gf_host_alloc")
+        buf = (C.c_uint8 * max(n, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().gf_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GvrsHipMulti:
+    """gf_multi: one context per listed device (a device may be listed more than once), batches sharded by tile range."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        check(lib().gf_multi_create(devs, len(devices), C.byref(self._h)), "gf_multi_create")
+        self.devices = [int(d) for d in devices]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return int(lib().gf_multi_count(self._h))
+
+    def partition(self, n_tiles, i):
+        t0, t1 = C.c_size_t(0), C.c_size_t(0)
+        lib().gf_multi_partition(n_tiles, len(self), i, C.byref(t0), C.byref(t1))
+        return t0.value, t1.value
+
+    def synchronize(self):
+        check(lib().gf_multi_synchronize(self._h), "gf_multi_synchronize")
+
+    def encode_batch(self, codecIndex, nRows, nCols, tiles, codec="huffman"):
+        """Host memory in, (blob uint8, offsets uint64[n+1], predictors, status) out -- the arrays of the C call."""
+        v = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, nRows * nCols)
+        nt = v.shape[0]
+        fn = getattr(lib(), "gf_%s_encode_batch_i32_multi" % codec)
+        cap = nt * int(lib().gf_huffman_default_stride(nRows, nCols)) // 2 + 4096
+        offsets = np.zeros(nt + 1, np.uint64)
+        preds = np.zeros(nt, np.uint8)
+        status = np.zeros(nt, np.int32)
+        while True:
+            blob = np.empty(cap, np.uint8)
+            st = fn(self._h, codecIndex, nRows, nCols, nt, _ptr(v), _ptr(blob), cap, _ptr(offsets), _ptr(preds), _ptr(status))
+            if st == _lib.ERR_CAPACITY:
+                cap = int(offsets[nt]) + 64
+                continue
+            check(st, "gf_%s_encode_batch_i32_multi" % codec)
+            return blob[:int(offsets[nt])], offsets, preds, status
+
+    def decode_batch(self, nRows, nCols, blob, offsets, codec="huffman"):
+        nt = len(offsets) - 1
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        if b.size < int(offsets[nt]) + 16:
+            b = np.concatenate([b, np.zeros(16, np.uint8)])
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out = np.empty((nt, nRows * nCols), np.int32)
+        status = np.zeros(nt, np.int32)
+        check(getattr(lib(), "gf_%s_decode_batch_i32_multi" % codec)(self._h, nRows, nCols, nt, _ptr(b), _ptr(off), _ptr(out),
+                                                                      _ptr(status)), "gf_%s_decode_batch_i32_multi" % codec)
+        return out, status
+
+    def close(self):
+        if self._h:
+            lib().gf_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

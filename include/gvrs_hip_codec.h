@@ -142,6 +142,56 @@ gf_status gf_compact_dev(gf_context *ctx, void *stream, size_t n_tiles, const ui
                          size_t slot_stride, const uint32_t *d_lengths, uint64_t *d_offsets,
                          uint8_t *d_blob, size_t blob_cap);
 
+/* gf_compact_dev cannot report a blob that is too small without synchronising: a packing that would end behind blob_cap
+ * is skipped; d_offsets[n_tiles] > blob_cap tells the caller (after its own synchronisation) that this happened.        */
+
+/* ---- page-locked host memory ---------------------------------------------------------------------------------------
+ * The host-memory batch entry points cut a batch into chunks of about 64 MB of cells and pipeline them through three
+ * slots (copy-in of chunk k+1, device work of chunk k and copy-out of chunk k-1 overlap; device and staging memory are
+ * bounded by the chunk, not by the batch).  Pageable memory is staged through page-locked buffers by helper threads;
+ * memory obtained here (a JNI binding hands it to Java as a direct ByteBuffer) moves over PCIe in place.               */
+gf_status gf_host_alloc(size_t bytes, void **p);
+gf_status gf_host_free(void *p);
+
+/* ---- several GPUs from one process -----------------------------------------------------------------
+ * What gvrs/CodecMaster.java:142-203 / gvrs/RecordManager.java:386-490 would call to use a whole node from one JVM.
+ * A gf_multi owns one gf_context per listed device (a device may be listed more than once).  A batch of T tiles shards
+ * as contiguous ranges, shard g = tiles [g T / G, (g+1) T / G) (gf_multi_partition); tiles are independent
+ * (gvrs/RasterTile.java:237-241), so there is no exchange between devices and no collective.
+ *   gf_*_batch_i32_multi      host memory: one host thread per context runs the pipelined host path on its range; the
+ *                             packings are concatenated by an exclusive scan of the range totals.  Arguments, results and
+ *                             bytes are those of the single-context call on the whole batch.
+ *   gf_*_batch_i32_multi_dev  device memory: every array argument has gf_multi_count() entries, entry g lives on
+ *                             gf_multi_device(g); the call enqueues each shard on its device's stream and returns;
+ *                             gf_multi_synchronize waits for all devices.                                             */
+typedef struct gf_multi gf_multi;
+gf_status gf_multi_create(const int *devices, int n_devices, gf_multi **multi);
+void gf_multi_destroy(gf_multi *multi);
+int gf_multi_count(const gf_multi *multi);
+gf_context *gf_multi_context(gf_multi *multi, int i);
+int gf_multi_device(const gf_multi *multi, int i);
+void gf_multi_partition(size_t n_tiles, int n_shards, int i, size_t *t0, size_t *t1);
+gf_status gf_multi_synchronize(gf_multi *multi);
+gf_status gf_huffman_encode_batch_i32_multi(gf_multi *multi, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                            const int32_t *values, uint8_t *blob, size_t blob_cap, uint64_t *offsets,
+                                            uint8_t *predictors, int32_t *status);
+gf_status gf_huffman_decode_batch_i32_multi(gf_multi *multi, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                            const uint64_t *offsets, int32_t *values, int32_t *status);
+gf_status gf_canon_encode_batch_i32_multi(gf_multi *multi, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                          const int32_t *values, uint8_t *blob, size_t blob_cap, uint64_t *offsets,
+                                          uint8_t *predictors, int32_t *status);
+gf_status gf_canon_decode_batch_i32_multi(gf_multi *multi, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                          const uint64_t *offsets, int32_t *values, int32_t *status);
+gf_status gf_huffman_encode_batch_i32_multi_dev(gf_multi *multi, int codec_index, int n_rows, int n_cols,
+                                                const size_t *n_tiles, const int32_t *const *d_values, uint8_t *const *d_out,
+                                                size_t slot_stride, uint32_t *const *d_lengths, uint8_t *const *d_predictors,
+                                                int32_t *const *d_status, int predictor_mask);
+gf_status gf_huffman_decode_batch_i32_multi_dev(gf_multi *multi, int n_rows, int n_cols, const size_t *n_tiles,
+                                                const uint8_t *const *d_blob, const size_t *blob_bytes,
+                                                const uint64_t *const *d_offsets, size_t slot_stride,
+                                                const uint32_t *const *d_lengths, int32_t *const *d_values,
+                                                int32_t *const *d_status);
+
 /* ---- CodecCanonHuffman (compress/canonicalHuffman/CodecCanonHuffman.java:70-195), the default integer
  * codec of current Gridfour (gvrs/GvrsFileSpecification.java:229): same predictors, integer residuals coded
  * with the 260-symbol canonical Huffman stage (CanonicalHuffman.java:177-283, 441-519), 6-byte header
