@@ -53,7 +53,7 @@ def parse_args():
                     help="huffman = CodecHuffman (the north-star path, default); canon = CodecCanonHuffman; lsop = LSOP12, canonical container; "
                          "float = CodecFloat plane split/merge (use with --workload float256)")
     ap.add_argument("--cpu-sample-tiles", type=int, default=-1, help="tiles timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU port on every host core")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="(kept for old command lines: the all-cores figure is always reported now)")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exactness checks")
     return ap.parse_args()
 
@@ -62,22 +62,42 @@ def _pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_hbm.sh writes
     profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 corrections applied).
     PMC collection cannot run inside the timed process, so the per-launch figure measured for this same
-    workload is read back; None when no measurement for the workload is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    workload is REPLAYED from that file -- the returned provenance says from which commit of it; None when no
+    measurement for the workload is committed.  Kernel names match exactly (template arguments stripped)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "profiles", "hbm_traffic.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return None, None
     if rec.get("workload") != workload:
-        return None
+        return None, None
+
+    def base(name):
+        name = name.split("(")[0].strip()
+        if name.startswith("void "):
+            name = name[5:]
+        return name.split("<")[0].strip()
+
+    by_name = {}
+    for name, d in rec.get("kernels", {}).items():
+        by_name[base(name)] = by_name.get(base(name), 0) + int(d["traffic"])       # instantiations of one kernel add up
     total, found = 0, False
     for part in kernel.split("+"):                      # a launch may be a pre-pass kernel + the main kernel
-        for name, d in rec.get("kernels", {}).items():
-            if part in name:
-                total += int(d["traffic"])
-                found = True
-                break
-    return total if found else None
+        if part in by_name:
+            total += by_name[part]
+            found = True
+    if not found:
+        return None, None
+    commit = rec.get("commit")
+    if not commit:
+        try:
+            import subprocess
+            commit = subprocess.run(["git", "-C", here, "log", "-n", "1", "--format=%h", "--", "profiles/hbm_traffic.json"],
+                                    capture_output=True, text=True, timeout=10).stdout.strip() or None
+        except Exception:
+            commit = None
+    return total, "profiles/hbm_traffic.json@%s" % (commit or "unversioned")
 
 
 def run_float(args, ctx, rank, world, dist, torch):
@@ -186,7 +206,8 @@ def run_float(args, ctx, rank, world, dist, torch):
                    "codec": "CodecFloat (sign / exponent / 3 delta-coded mantissa byte planes)", "sharding": "contiguous tile ranges, no collective"},
         "bit_exact": bit_exact, "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": _pmc_traffic(args.workload, dom_name),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": _pmc_traffic(args.workload, dom_name)[0],
+                     "traffic_replayed_from": _pmc_traffic(args.workload, dom_name)[1],
                      "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(dom_ms, 4),
                      "roundtrip_frac": round((2 * alg_bytes) / ((enc_avg + dec_avg) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         "cpu_baseline": cpu_baseline, "host_path": host_path,
@@ -196,26 +217,178 @@ def run_float(args, ctx, rank, world, dist, torch):
         dist.destroy_process_group()
 
 
+class _BorrowedContext:
+    """A context owned by a gf_multi, with the interface DeviceTileBatch / DeviceBuffer / GpuTimer expect."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self):
+        from gridfour_amd import lib
+        return lib().gf_context_stream(self._h)
+
+    def synchronize(self):
+        from gridfour_amd import lib
+        from gridfour_amd._lib import check
+        check(lib().gf_context_synchronize(self._h), "gf_context_synchronize")
+
+    def reserve(self, n_rows, n_cols, n_tiles):
+        from gridfour_amd import lib
+        from gridfour_amd._lib import check
+        check(lib().gf_context_reserve(self._h, n_rows, n_cols, n_tiles), "gf_context_reserve")
+
+
+def _verify_shard(args, batch, n_rows, n_cols, n_tiles, with_oracle):
+    """Per shard: every status OK and every tile survives the round trip; with_oracle: sampled byte parity as well."""
+    lengths = batch.get_lengths()
+    ok = bool((batch.get_enc_status() == 0).all() and (batch.get_dec_status() == 0).all())
+    vals = batch.get_values()
+    ok = ok and bool(np.array_equal(batch.get_decoded(), vals))
+    if with_oracle and ok:
+        import oracle
+        preds = batch.get_predictors()
+        for t in list(range(0, n_tiles, max(1, n_tiles // 64)))[:64]:
+            if args.codec == "lsop":
+                ref, _ = oracle.lsop12_encode(0, n_rows, n_cols, vals[t], False)
+                used = preds[t]
+            else:
+                ref, used = (oracle.codec_canon_encode if args.codec == "canon" else oracle.codec_huffman_encode)(
+                    0, n_rows, n_cols, vals[t])
+            if ref != batch.get_packing(t, int(lengths[t])) or used != preds[t]:
+                ok = False
+                break
+    return ok, int(lengths.astype(np.int64).sum()), vals
+
+
+def _effective_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that shows 256
+    CPUs may be allowed 16 cores' worth of time -- threads beyond that only take turns)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse:
+                quota, period = parse(txt)
+            else:
+                quota, period = txt, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1") and int(period) > 0:
+                n = max(1, min(n, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
+def _cpu_baseline(args, vals, n_rows, n_cols, n_tiles):
+    """The oracle ("port": C restatement of the Java algorithm) on the host's cores, bounded sample of the same workload:
+    one thread (the `value`: the north star's single-thread reference) and every core (native threads inside the oracle)."""
+    import oracle
+    cells = n_rows * n_cols
+    ns = args.cpu_sample_tiles
+    if ns < 0:
+        ns = min(n_tiles, max(64, int(1200e6 / (4 * cells))))   # up to 1.2 GB of tiles: 9-20 s of CPU work on one core
+    if ns <= 0:
+        return None
+    sub = vals[:ns]
+    c0 = time.perf_counter()
+    if args.codec == "lsop":
+        out, ln = oracle.batch_lsop12_encode(0, n_rows, n_cols, sub)
+    elif args.codec == "canon":
+        out, ln, _ = oracle.batch_canon_encode(0, n_rows, n_cols, sub)
+    else:
+        out, ln, _ = oracle.batch_huffman_encode(0, n_rows, n_cols, sub)
+    c1 = time.perf_counter()
+    if args.codec == "lsop":
+        dec = oracle.batch_lsop12_decode(n_rows, n_cols, out, ln)
+    elif args.codec == "canon":
+        dec = oracle.batch_canon_decode(n_rows, n_cols, out, ln)
+    else:
+        dec = oracle.batch_huffman_decode(n_rows, n_cols, out, ln)
+    c2 = time.perf_counter()
+    assert np.array_equal(dec, sub)
+    del out, dec
+    mb = sub.nbytes / 1e6
+    res = {"value": round(mb / (c2 - c0), 2), "unit": "MB/s", "cores": 1, "kind": "port",
+           "sample": "first %d tiles of the same workload (%.0f MB), oracle C restatement of the Java algorithm, 1 thread; "
+                     "encode %.1f MB/s, decode %.1f MB/s" % (ns, mb, mb / (c1 - c0), mb / (c2 - c1))}
+    if args.codec == "huffman":
+        nthr = _effective_cores()
+        enc_s, dec_s = oracle.huffman_roundtrip_threads(nthr, 0, n_rows, n_cols, sub)
+        res["all_cores"] = {"value": round(mb / (enc_s + dec_s), 2), "unit": "MB/s", "cores": nthr,
+                            "sample": "the same %d tiles on %d native threads (pthreads in the oracle, one contiguous share of "
+                                      "the tiles each) = every core this process may use (%d logical CPUs visible, affinity and "
+                                      "cgroup CPU quota applied); encode %.0f MB/s, decode %.0f MB/s" % (
+                                          ns, nthr, os.cpu_count() or 1, mb / enc_s, mb / dec_s)}
+    return res
+
+
+def _host_path(ctx_handle, vals, n_rows, n_cols):
+    """The PCIe-inclusive rate of the host-memory entry points (pageable buffers in and out) on the same tiles; never the
+    headline value, reported beside it."""
+    from gridfour_amd import lib
+    nt, cells = vals.shape
+    cap = nt * cells * 2
+    blob = np.empty(cap, np.uint8)
+    off = np.zeros(nt + 1, np.uint64)
+    st = np.zeros(nt, np.int32)
+    out = np.empty_like(vals)
+    p = lambda a: a.ctypes.data_as(__import__("ctypes").c_void_p)
+    best = [1e9, 1e9]
+    for i in range(3):                                    # the first pass allocates the staging buffers
+        t0 = time.perf_counter()
+        rc = lib().gf_huffman_encode_batch_i32(ctx_handle, 0, n_rows, n_cols, nt, p(vals), p(blob), cap, p(off), None, p(st))
+        t1 = time.perf_counter()
+        assert rc == 0 and (st == 0).all()
+        rc = lib().gf_huffman_decode_batch_i32(ctx_handle, n_rows, n_cols, nt, p(blob), p(off), p(out), p(st))
+        t2 = time.perf_counter()
+        assert rc == 0 and (st == 0).all()
+        if i:
+            best = [min(best[0], t1 - t0), min(best[1], t2 - t1)]
+    assert np.array_equal(out, vals)
+    gb = vals.nbytes / 1e9
+    return {"encode_GBps": round(gb / best[0], 2), "decode_GBps": round(gb / best[1], 2),
+            "roundtrip_GBps": round(gb / (best[0] + best[1]), 2),
+            "note": "gf_huffman_*_batch_i32 on pageable host buffers: chunked, pinned staging, H2D / kernels / D2H overlapped"}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    launcher = "WORLD_SIZE" in os.environ and world > 1
+    if launcher and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # without a launcher --gpus N > 1 runs all N devices from THIS process through the library's multi-context entry points
+    single_multi = (not launcher) and args.gpus > 1
 
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the codec has no CPU path)")
-    # GF_BENCH_BACKEND=gloo is a test hook: it lets several ranks share the one GPU of a test box to exercise the
-    # multi-rank control flow (RCCL refuses two ranks on one device); the judged runs use the default, RCCL
+    # GF_BENCH_BACKEND=gloo / GF_BENCH_SHARE_GPU=1 are test hooks: they let several ranks / shards share the one GPU of a
+    # test box to exercise the multi-GPU control flow (RCCL refuses two ranks on one device); the judged runs use neither
     backend = os.environ.get("GF_BENCH_BACKEND", "nccl")
+    share = os.environ.get("GF_BENCH_SHARE_GPU", "") not in ("", "0")
+    n_dev = torch.cuda.device_count()
     if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
+        local_rank %= n_dev
+    if single_multi and not share and args.gpus > n_dev:
+        raise SystemExit("--gpus %d but only %d device(s) visible" % (args.gpus, n_dev))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -223,42 +396,87 @@ def main():
             dist.init_process_group(backend)
 
     import gridfour_amd
-    from gridfour_amd import DeviceTileBatch, GpuTimer
+    from gridfour_amd import DeviceTileBatch, GpuTimer, lib
+    from gridfour_amd._lib import check
 
     n_rows, n_cols, n_tiles, tiles_per_row, descr = WORKLOADS[args.workload]
     cells = n_rows * n_cols
-    ctx = gridfour_amd.GvrsHipContext(local_rank)
     if (args.codec == "float") != (args.workload == "float256"):
         raise SystemExit("--codec float goes with --workload float256 (and only with it)")
+    if single_multi and args.codec != "huffman":
+        raise SystemExit("the single-process multi-GPU mode runs the north-star codec (CodecHuffman); use a launcher for the others")
     if args.codec == "float":
-        return run_float(args, ctx, rank, world, dist, torch)
-    stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
-    batch = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
-    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3}[args.workload]
-    # rank r owns the contiguous tile range starting at r * n_tiles of the global grid
-    batch.synth_dem(seed, tiles_per_row, tile0=rank * n_tiles)
-    ctx.synchronize()
+        return run_float(args, gridfour_amd.GvrsHipContext(local_rank), rank, world, dist, torch)
 
-    # one HIP-event pair per timed step and kernel, recorded on the stream the kernels run on and
-    # read only after the timed region (no host sync inside it)
-    t_enc = [GpuTimer(ctx) for _ in range(args.steps)]
-    t_dec = [GpuTimer(ctx) for _ in range(args.steps)]
+    # ---- shards: one per GPU.  Under a launcher this process owns shard `rank`; in single-process mode it owns them all ----
+    n_shards = args.gpus if single_multi else 1
+    total_shards = args.gpus if single_multi else world
+    multi = None
+    if single_multi:
+        multi = gridfour_amd.GvrsHipMulti([0 if share else g for g in range(n_shards)])
+        ctxs = [_BorrowedContext(lib().gf_multi_context(multi.handle, g), multi.devices[g]) for g in range(n_shards)]
+    else:
+        ctxs = [gridfour_amd.GvrsHipContext(local_rank)]
+    stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
+    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3}[args.workload]
+    batches = []
+    for g, ctx in enumerate(ctxs):
+        b = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
+        # shard s owns the contiguous tile range starting at s * n_tiles of the global grid (weak scaling)
+        b.synth_dem(seed, tiles_per_row, tile0=(g if single_multi else rank) * n_tiles)
+        ctx.synchronize()
+        batches.append(b)
+
+    # one HIP-event pair per timed step, kernel group and device, recorded on the stream the kernels run on and read only
+    # after the timed region (no host sync inside it)
+    t_enc = [[GpuTimer(ctx) for _ in range(args.steps)] for ctx in ctxs]
+    t_dec = [[GpuTimer(ctx) for _ in range(args.steps)] for ctx in ctxs]
 
     def barrier():
-        if world > 1:
+        if launcher:
             dist.barrier()
         torch.cuda.synchronize()
+        for ctx in ctxs:
+            ctx.synchronize()
 
-    def step(i=None):
-        if i is not None:
-            t_enc[i].start()
-        batch.encode(codec_index=0)
-        if i is not None:
-            t_enc[i].stop()
-            t_dec[i].start()
-        batch.decode()
-        if i is not None:
-            t_dec[i].stop()
+    if single_multi:
+        import ctypes as C
+        G = n_shards
+        arr = lambda ptrs: (C.c_void_p * G)(*ptrs)
+        nT = (C.c_size_t * G)(*([n_tiles] * G))
+        a_vals, a_slots = arr([b.values.ptr for b in batches]), arr([b.slots.ptr for b in batches])
+        a_len, a_pred = arr([b.lengths.ptr for b in batches]), arr([b.predictors.ptr for b in batches])
+        a_est, a_dst = arr([b.enc_status.ptr for b in batches]), arr([b.dec_status.ptr for b in batches])
+        a_dec = arr([b.decoded.ptr for b in batches])
+        blob_bytes = (C.c_size_t * G)(*[n_tiles * b.stride for b in batches])
+
+        def step(i=None):
+            # the library enqueues every device's shard from this thread (launches are asynchronous), no sync in between
+            if i is not None:
+                for g in range(G):
+                    t_enc[g][i].start()
+            check(lib().gf_huffman_encode_batch_i32_multi_dev(multi.handle, 0, n_rows, n_cols, nT, a_vals, a_slots, batches[0].stride,
+                                                              a_len, a_pred, a_est, 0xF), "encode_multi_dev")
+            if i is not None:
+                for g in range(G):
+                    t_enc[g][i].stop()
+                    t_dec[g][i].start()
+            check(lib().gf_huffman_decode_batch_i32_multi_dev(multi.handle, n_rows, n_cols, nT, a_slots, blob_bytes, None,
+                                                              batches[0].stride, a_len, a_dec, a_dst), "decode_multi_dev")
+            if i is not None:
+                for g in range(G):
+                    t_dec[g][i].stop()
+    else:
+        def step(i=None):
+            if i is not None:
+                t_enc[0][i].start()
+            batches[0].encode(codec_index=0)
+            if i is not None:
+                t_enc[0][i].stop()
+                t_dec[0][i].start()
+            batches[0].decode()
+            if i is not None:
+                t_dec[0][i].stop()
 
     for _ in range(args.warmup):
         step()
@@ -269,98 +487,46 @@ def main():
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    enc_ms = [t.elapsed_ms() for t in t_enc]
-    dec_ms = [t.elapsed_ms() for t in t_dec]
-    if world > 1:
+    enc_ms = [np.mean([t.elapsed_ms() for t in tg]) for tg in t_enc]
+    dec_ms = [np.mean([t.elapsed_ms() for t in tg]) for tg in t_dec]
+    if launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---------------- verification (outside the timed region) ----------------
-    lengths = batch.get_lengths()
-    enc_status = batch.get_enc_status()
-    dec_status = batch.get_dec_status()
-    packed_bytes = int(lengths.astype(np.int64).sum())
-    c_per_cell = packed_bytes / float(n_tiles * cells)
-    ok_status = bool((enc_status == 0).all() and (dec_status == 0).all())
-    bit_exact = None
-    cpu_baseline = None
-    if rank == 0 and not args.no_verify:
-        import oracle
-        vals = batch.get_values()
-        roundtrip_ok = bool(np.array_equal(batch.get_decoded(), vals))
-        preds = batch.get_predictors()
-        sample = list(range(0, n_tiles, max(1, n_tiles // 64)))[:64]
-        parity_ok = True
-        for t in sample:
-            if args.codec == "lsop":
-                ref, _ = oracle.lsop12_encode(0, n_rows, n_cols, vals[t], False)
-                used = preds[t]
-            else:
-                ref, used = (oracle.codec_canon_encode if args.codec == "canon" else oracle.codec_huffman_encode)(
-                    0, n_rows, n_cols, vals[t])
-            if ref != batch.get_packing(t, int(lengths[t])) or used != preds[t]:
-                parity_ok = False
-                break
-        bit_exact = bool(roundtrip_ok and parity_ok and ok_status)
+    # ---------------- verification (outside the timed region): EVERY shard, on every rank ----------------
+    ok_all, packed_bytes, vals0 = True, 0, None
+    if not args.no_verify:
+        for g, b in enumerate(batches):
+            ok, pb, vals = _verify_shard(args, b, n_rows, n_cols, n_tiles, with_oracle=(rank == 0 and g == 0))
+            ok_all = ok_all and ok
+            packed_bytes += pb
+            if g == 0:
+                vals0 = vals
+    else:
+        packed_bytes = sum(int(b.get_lengths().astype(np.int64).sum()) for b in batches)
+    if launcher:
+        flag = torch.tensor([1 if ok_all else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # one failed shard anywhere fails the run
+        ok_all = bool(flag.item())
+    bit_exact = None if args.no_verify else ok_all
+    c_per_cell = packed_bytes / float(len(batches) * n_tiles * cells)
 
-        # ---------------- CPU baseline: the oracle ("port"), 1 core, bounded sample ----------------
-        ns = args.cpu_sample_tiles
-        if ns < 0:
-            ns = min(n_tiles, max(64, int(1200e6 / (4 * cells))))   # up to 1.2 GB of tiles: 9-20 s of CPU work on one core
-        if ns > 0 and world == 1:
-            sub = vals[:ns]
-            c0 = time.perf_counter()
-            if args.codec == "lsop":
-                out, ln = oracle.batch_lsop12_encode(0, n_rows, n_cols, sub)
-            elif args.codec == "canon":
-                out, ln, _ = oracle.batch_canon_encode(0, n_rows, n_cols, sub)
-            else:
-                out, ln, _ = oracle.batch_huffman_encode(0, n_rows, n_cols, sub)
-            c1 = time.perf_counter()
-            if args.codec == "lsop":
-                dec = oracle.batch_lsop12_decode(n_rows, n_cols, out, ln)
-            elif args.codec == "canon":
-                dec = oracle.batch_canon_decode(n_rows, n_cols, out, ln)
-            else:
-                dec = oracle.batch_huffman_decode(n_rows, n_cols, out, ln)
-            c2 = time.perf_counter()
-            assert np.array_equal(dec, sub)
-            mb = sub.nbytes / 1e6
-            cpu_baseline = {
-                "value": round(mb / (c2 - c0), 2), "unit": "MB/s", "cores": 1, "kind": "port",
-                "sample": "first %d tiles of the same workload (%.0f MB), oracle C restatement of the Java "
-                          "algorithm, 1 thread; encode %.1f MB/s, decode %.1f MB/s" % (
-                              ns, mb, mb / (c1 - c0), mb / (c2 - c1)),
-            }
-            if args.codec == "huffman" and args.cpu_all_cores:
-                # the same sample on every host core (tiles are independent: one contiguous share per thread;
-                # the oracle's C loops release the GIL inside ctypes)
-                import concurrent.futures as cf
-                nthr = os.cpu_count() or 1
-                shares = [sub[i * ns // nthr:(i + 1) * ns // nthr] for i in range(nthr)]
-                shares = [x for x in shares if len(x)]
-
-                def _roundtrip(x):
-                    o, l, _ = oracle.batch_huffman_encode(0, n_rows, n_cols, x)
-                    return oracle.batch_huffman_decode(n_rows, n_cols, o, l)
-
-                a0 = time.perf_counter()
-                with cf.ThreadPoolExecutor(len(shares)) as ex:
-                    outs = list(ex.map(_roundtrip, shares))
-                a1 = time.perf_counter()
-                assert all(np.array_equal(o, x) for o, x in zip(outs, shares))
-                cpu_baseline["all_cores"] = {"value": round(mb / (a1 - a0), 2), "unit": "MB/s", "cores": len(shares)}
+    cpu_baseline, host_path = None, None
+    if rank == 0 and total_shards == 1 and not args.no_verify:
+        cpu_baseline = _cpu_baseline(args, vals0, n_rows, n_cols, n_tiles)
+        if args.codec == "huffman" and args.cpu_sample_tiles != 0:
+            host_path = _host_path(ctxs[0].handle, vals0, n_rows, n_cols)
 
     if rank != 0:
-        if world > 1:
+        if launcher:
             dist.destroy_process_group()
         return
 
     steps = args.steps
     raw_mb = n_tiles * cells * 4 / 1e6
-    value = raw_mb * world * steps / elapsed
-    enc_avg, dec_avg = float(np.mean(enc_ms)), float(np.mean(dec_ms))
+    value = raw_mb * total_shards * steps / elapsed
+    enc_avg, dec_avg = float(np.max(enc_ms)), float(np.max(dec_ms))      # the slowest device (one device: its average)
     # algorithmic bytes per launch: encode reads 4 B/cell and writes c; decode reads c, writes 4
     alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
     # the decode side of the two Huffman codecs is a per-tile pre-pass kernel followed by the decode kernel: both are inside
@@ -370,12 +536,12 @@ def main():
                 "huffman": "k_huffman_parse_trees+k_huffman_decode"}[args.codec]
     dom_name, dom_ms = (dec_name, dec_avg) if dec_avg >= enc_avg else (enc_name, enc_avg)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = _pmc_traffic(args.workload, dom_name)
+    traffic, traffic_from = _pmc_traffic(args.workload, dom_name)
     out = {
         "metric": METRIC,
         "value": round(value, 1),
         "unit": "MB/s",
-        "n_gpus": world,
+        "n_gpus": total_shards,
         "steps": steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4),
@@ -388,7 +554,9 @@ def main():
                    "tiles_per_gpu": n_tiles, "codec": {"canon": "CodecCanonHuffman (Differencing/Linear/Triangle + canonical Huffman)",
                              "lsop": "LSOP12 (12-coefficient optimal predictor + canonical Huffman container)",
                              "huffman": "CodecHuffman (Differencing/Linear/Triangle + M32 + Huffman)"}[args.codec],
-                   "sharding": "contiguous tile ranges, no collective"},
+                   "sharding": "contiguous tile ranges, no collective",
+                   "processes": "one per GPU (torch.distributed launcher)" if launcher else
+                                ("one process, gf_multi_*_dev over %d contexts" % total_shards if single_multi else "one")},
         "bit_exact": bit_exact,
         "compressed_bytes_per_cell": round(c_per_cell, 4),
         "encode_ms": round(enc_avg, 4),
@@ -397,13 +565,15 @@ def main():
         "decode_MBps": round(raw_mb / (dec_avg * 1e-3), 1),
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_replayed_from": traffic_from,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "avg_launch_ms": round(dom_ms, 4),
                      "roundtrip_frac": round((2 * alg_bytes) / ((enc_avg + dec_avg) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         "cpu_baseline": cpu_baseline,
+        "host_path": host_path,
     }
     print(json.dumps(out))
-    if world > 1:
+    if launcher:
         dist.destroy_process_group()
 
 

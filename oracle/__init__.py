@@ -67,6 +67,8 @@ def lib():
                                                C.c_size_t, u32p, u8p]
         L.gvo_batch_huffman_decode.argtypes = [C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t,
                                                u32p, i32p]
+        L.gvo_huffman_roundtrip_threads.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, i32p, u8p, C.c_size_t, u32p,
+                                                    i32p, C.POINTER(C.c_double)]
         L.gvo_splitmix64.argtypes = [C.c_uint64]
         L.gvo_splitmix64.restype = C.c_uint64
         L.gvo_dem_value.argtypes = [C.c_uint64, C.c_int64, C.c_int64]
@@ -307,6 +309,25 @@ def batch_huffman_decode(n_rows, n_cols, packings, lengths):
     if rc != OK:
         raise IOError("batch_huffman_decode rc=%d" % rc)
     return out
+
+
+def huffman_roundtrip_threads(n_threads, codec_index, n_rows, n_cols, tiles):
+    """CodecHuffman encode + decode of every tile on n_threads NATIVE threads (pthreads inside the oracle, one contiguous
+    share of the tiles each).  Returns (encode seconds, decode seconds); raises if a round trip fails."""
+    v = _i32(tiles).reshape(-1, n_rows * n_cols)
+    nt = v.shape[0]
+    stride = 4 * n_rows * n_cols + 4096
+    out = np.empty((nt, stride), np.uint8)
+    lengths = np.zeros(nt, np.uint32)
+    back = np.empty_like(v)
+    out[:, ::4096] = 0                             # touch every page first: the timed threads must not queue on page faults
+    back[:] = 0
+    sec = (C.c_double * 2)()
+    rc = lib().gvo_huffman_roundtrip_threads(int(n_threads), codec_index, n_rows, n_cols, nt, _p(v, C.c_int32), _p(out, C.c_uint8),
+                                             stride, _p(lengths, C.c_uint32), _p(back, C.c_int32), sec)
+    if rc != OK:
+        raise ValueError("huffman_roundtrip_threads rc=%d" % rc)
+    return float(sec[0]), float(sec[1])
 
 
 # ---- synthetic DEM ----

@@ -8,6 +8,7 @@
  *
  * Reference paths are relative to core/src/main/java/org/gridfour/.
  */
+#define _POSIX_C_SOURCE 200809L   /* pthread barriers, clock_gettime (the all-cores CPU baseline) */
 #include "gvrs_oracle.h"
 
 #include <stdlib.h>
@@ -1006,6 +1007,99 @@ int gvo_batch_huffman_decode(int nRows, int nCols, size_t nTiles,
         if (rc != GVO_OK) return rc;
     }
     return GVO_OK;
+}
+
+/* The CPU baseline on every host core: native threads, one contiguous share of the tiles each (tiles are independent,
+ * gvrs/RasterTile.java:237-241).  Every thread encodes its tiles and decodes them again into scratch of its own and checks
+ * the round trip; seconds[0] / seconds[1] receive the wall time of the encode and of the decode phase (all threads run a
+ * phase together, a barrier in between).  Returns GVO_OK, or the first error / -100 for a round-trip mismatch.           */
+#include <malloc.h>
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    int codecIndex, nRows, nCols;
+    size_t t0, t1, stride;
+    const int32_t *values;
+    uint8_t *out;
+    uint32_t *lengths;
+    int32_t *back;
+    pthread_barrier_t *bar;
+    int rc;
+} gvo_mt_job;
+
+static void *gvo_mt_worker(void *arg)
+{
+    gvo_mt_job *j = (gvo_mt_job *)arg;
+    size_t nCells = (size_t)j->nRows * (size_t)j->nCols;
+    size_t n = j->t1 - j->t0;
+    pthread_barrier_wait(j->bar);                           /* start of the encode phase */
+    int rc = n ? gvo_batch_huffman_encode(j->codecIndex, j->nRows, j->nCols, n, j->values + j->t0 * nCells,
+                                          j->out + j->t0 * j->stride, j->stride, j->lengths + j->t0, NULL) : GVO_OK;
+    pthread_barrier_wait(j->bar);                           /* end of encode = start of decode */
+    if (rc == GVO_OK && n)
+        rc = gvo_batch_huffman_decode(j->nRows, j->nCols, n, j->out + j->t0 * j->stride, j->stride, j->lengths + j->t0,
+                                      j->back + j->t0 * nCells);
+    pthread_barrier_wait(j->bar);                           /* end of the decode phase */
+    if (rc == GVO_OK && n && memcmp(j->back + j->t0 * nCells, j->values + j->t0 * nCells, n * nCells * 4) != 0) rc = -100;
+    j->rc = rc;
+    return NULL;
+}
+
+static double gvo_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int gvo_huffman_roundtrip_threads(int nThreads, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                                  uint8_t *out, size_t stride, uint32_t *lengths, int32_t *back, double *seconds)
+{
+    if (nThreads < 1 || nThreads > 4096) return GVO_ERR_ARG;
+    /* the per-tile work buffers of the restatement are malloc'ed per call; above glibc's mmap threshold every one of them is
+     * an mmap + page faults + munmap, and a few hundred threads then queue on the kernel's address-space lock instead of
+     * computing.  Keep them in the (per-thread) malloc arenas. */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nThreads);
+    gvo_mt_job *job = (gvo_mt_job *)malloc(sizeof(gvo_mt_job) * (size_t)nThreads);
+    pthread_barrier_t bar;
+    if (!th || !job || pthread_barrier_init(&bar, NULL, (unsigned)nThreads + 1u) != 0) {
+        free(th);
+        free(job);
+        return GVO_ERR_ARG;
+    }
+    int started = 0;
+    for (int i = 0; i < nThreads; i++) {
+        gvo_mt_job *j = &job[i];
+        j->codecIndex = codecIndex; j->nRows = nRows; j->nCols = nCols;
+        j->t0 = nTiles * (size_t)i / (size_t)nThreads;
+        j->t1 = nTiles * (size_t)(i + 1) / (size_t)nThreads;
+        j->stride = stride; j->values = values; j->out = out; j->lengths = lengths; j->back = back; j->bar = &bar; j->rc = GVO_OK;
+        if (pthread_create(&th[i], NULL, gvo_mt_worker, j) != 0) break;
+        started++;
+    }
+    int rc = GVO_OK;
+    if (started == nThreads) {
+        pthread_barrier_wait(&bar);
+        double a = gvo_now();
+        pthread_barrier_wait(&bar);
+        double b = gvo_now();
+        pthread_barrier_wait(&bar);
+        double c = gvo_now();
+        if (seconds) { seconds[0] = b - a; seconds[1] = c - b; }
+        for (int i = 0; i < nThreads; i++) pthread_join(th[i], NULL);
+        for (int i = 0; i < nThreads; i++) if (job[i].rc != GVO_OK && rc == GVO_OK) rc = job[i].rc;
+    } else {
+        rc = GVO_ERR_ARG;                                   /* could not start every thread: the started ones wait at the barrier */
+        for (int i = 0; i < started; i++) pthread_cancel(th[i]);
+        for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    }
+    pthread_barrier_destroy(&bar);
+    free(th);
+    free(job);
+    return rc;
 }
 
 /* ------------------------------------------------------------------ */

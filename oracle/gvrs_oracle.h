@@ -149,6 +149,10 @@ int gvo_batch_huffman_encode(int codecIndex, int nRows, int nCols, size_t nTiles
 int gvo_batch_huffman_decode(int nRows, int nCols, size_t nTiles,
                              const uint8_t *packings, size_t stride,
                              const uint32_t *lengths, int32_t *values);
+/* encode + decode of every tile on nThreads native threads (contiguous shares); seconds[2] = wall time of the two phases */
+int gvo_huffman_roundtrip_threads(int nThreads, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                                  uint8_t *out, size_t stride, uint32_t *lengths, int32_t *back, double *seconds);
+
 
 /* ---- deterministic synthetic DEM, integer only ---- */
 uint64_t gvo_splitmix64(uint64_t x);
