@@ -1,0 +1,51 @@
+"""The headline batch sizes of BASELINE.json through the C ABI on the GPU (not only bench.py): the whole ETOPO1-shaped batch
+(configs[2]: 12,960 tiles of 120x150) and a GEBCO-shaped shard (configs[3]: 200x200 tiles) -- size-independent properties
+(every tile survives the round trip, every status OK, sum of packing lengths = length of the compacted blob, compacted blob
+decodes to the same cells) plus sampled byte parity with the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,nt,tpr,seed", [((120, 150), 12960, 144, 2), ((200, 200), 4096, 432, 3)],
+                         ids=["etopo1_12960x120x150", "gebco_4096x200x200"])
+@pytest.mark.parametrize("codec", ["huffman", "canon"])
+def test_full_batch_properties(shape, nt, tpr, seed, codec):
+    import gridfour_amd
+    from gridfour_amd import DeviceBuffer, DeviceTileBatch, lib
+    from gridfour_amd._lib import check
+    n_rows, n_cols = shape
+    cells = n_rows * n_cols
+    ctx = gridfour_amd.GvrsHipContext(0)
+    b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * cells + 1024 + 15) // 16 * 16, codec=codec)
+    b.synth_dem(oracle.DEM_SEED + seed, tpr)
+    b.encode()
+    b.decode()
+    ctx.synchronize()
+    assert (b.get_enc_status() == 0).all() and (b.get_dec_status() == 0).all()
+    vals = b.get_values()
+    assert np.array_equal(b.get_decoded(), vals)                       # every one of the tiles
+    lengths = b.get_lengths().astype(np.int64)
+    preds = b.get_predictors()
+    assert ((preds >= 1) & (preds <= 3)).all() and (lengths > 10).all() and (lengths < 4 * cells).all()
+    # sampled byte parity (the generator itself is pinned by tests/test_gpu_parity.py::test_synth_dem*)
+    enc = oracle.codec_canon_encode if codec == "canon" else oracle.codec_huffman_encode
+    for t in list(range(0, nt, nt // 24))[:24] + [nt - 1]:
+        ref, used = enc(0, n_rows, n_cols, vals[t])
+        assert used == preds[t] and b.get_packing(t, int(lengths[t])) == ref, t
+    # compaction: exclusive scan of the lengths, then the compact blob decodes to the same cells
+    total = int(lengths.sum())
+    d_off, d_blob = DeviceBuffer(ctx, (nt + 1) * 8), DeviceBuffer(ctx, total + 64)
+    check(lib().gf_compact_dev(ctx.handle, None, nt, b.slots.ptr, b.stride, b.lengths.ptr, d_off.ptr, d_blob.ptr, total + 64), "compact")
+    ctx.synchronize()
+    off = d_off.download(np.uint64, nt + 1)
+    assert int(off[nt]) == total and np.array_equal(np.diff(off.astype(np.int64)), lengths)
+    b.decoded.fill(0)
+    fn = lib().gf_canon_decode_batch_i32_dev if codec == "canon" else lib().gf_huffman_decode_batch_i32_dev
+    check(fn(ctx.handle, None, n_rows, n_cols, nt, d_blob.ptr, total + 64, d_off.ptr, 0, b.lengths.ptr, b.decoded.ptr, b.dec_status.ptr),
+          "decode of the compact blob")
+    ctx.synchronize()
+    assert (b.get_dec_status() == 0).all() and np.array_equal(b.get_decoded(), vals)
