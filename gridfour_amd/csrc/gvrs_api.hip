@@ -85,6 +85,7 @@ struct gf_context {
     DevBuf dPlanes;        // CodecFloat plane staging
     DevBuf dResiduals, dCoefs, dStatus2;   // LSOP staging
     DevBuf dM32, dM32Len, dM32Models, dSeeds;   // CodecDeflate staging
+    DevBuf dInflate, dInflOut, dInflMeta;       // GPU inflate: stream descriptors, inflated bytes, produced / status
     struct gf_host_pipe *pipe = nullptr;        // pipelined staging of the host-memory batch entry points (created on first use)
 };
 void gf_host_pipe_destroy(struct gf_host_pipe *p);
@@ -203,6 +204,9 @@ void gf_context_destroy(gf_context *c)
     c->dM32Len.release();
     c->dM32Models.release();
     c->dSeeds.release();
+    c->dInflate.release();
+    c->dInflOut.release();
+    c->dInflMeta.release();
     gf_host_pipe_destroy(c->pipe);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -637,6 +641,43 @@ gf_status gf_float_decode_f32(gf_context *c, int nRows, int nCols, const uint8_t
 }
 
 // ------------------------------------------------------------------ device memory helpers
+
+// zlib streams inflated on the device (gvrs_inflate.hip): stream i = d_in[in_offsets[i] .. + in_lengths[i]) -> at most out_caps[i]
+// bytes at d_out + out_offsets[i].  The four descriptor arrays are HOST arrays (they are packed and uploaded here);
+// d_produced / d_status are device arrays.  Enqueues only (after the small descriptor upload on the same stream).
+gf_status gf_inflate_batch_dev(gf_context *c, void *stream, size_t nStreams, const uint8_t *dIn, const uint64_t *inOffsets,
+                               const uint32_t *inLengths, uint8_t *dOut, const uint64_t *outOffsets, const uint32_t *outCaps,
+                               uint32_t *dProduced, int32_t *dStatus)
+{
+    if (!c || (nStreams && (!dIn || !inOffsets || !inLengths || !dOut || !outOffsets || !outCaps || !dProduced || !dStatus)))
+        return GF_ERR_ARG;
+    if (nStreams == 0) return GF_OK;
+    GF_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    gf_status s = c->dInflate.ensure(nStreams * sizeof(GfInflateStream) + 16);
+    if (s != GF_OK) return s;
+    std::vector<GfInflateStream> desc(nStreams);
+    uint32_t maxCap = 0;
+    for (size_t i = 0; i < nStreams; i++) {
+        desc[i].inOffset = inOffsets[i];
+        desc[i].outOffset = outOffsets[i];
+        desc[i].inLen = inLengths[i];
+        desc[i].outCap = outCaps[i];
+        maxCap = std::max(maxCap, outCaps[i]);
+    }
+    // (pageable source: the copy is staged by the runtime before the call returns)
+    GF_HIP(hipMemcpyAsync(c->dInflate.p, desc.data(), nStreams * sizeof(GfInflateStream), hipMemcpyHostToDevice, st));
+    GfInflateArgs a;
+    a.inBase = dIn;
+    a.outBase = dOut;
+    a.streams = (const GfInflateStream *)c->dInflate.p;
+    a.produced = dProduced;
+    a.status = dStatus;
+    a.nStreams = nStreams;
+    a.window = gf_inflate_window(maxCap);
+    GF_HIP(gf_launch_inflate(a, st));
+    return GF_OK;
+}
 
 // page-locked host memory: the host-memory batch entry points move it over PCIe in place (no staging copy)
 gf_status gf_host_alloc(size_t bytes, void **p)

@@ -1,0 +1,442 @@
+// gvrs_inflate.hip -- RFC 1950 / 1951 (zlib) streams inflated on the GPU, one wave per stream.
+//
+// Replaces the java.util.zip.Inflater calls of the reference's Deflate-carrying decoders
+//   compress/CodecDeflate.java:141-147        one stream of M32 bytes behind the 10-byte header
+//   compress/CodecFloat.java:285-298, 395-458 five byte planes, each a zlib stream behind a 4-byte length
+//   lsop/LsDecoder12.java:127-141             two streams of M32 bytes
+// What an inflater produces is defined by the stream, not by the implementation, so the bytes equal the JDK's (and the
+// host zlib's) by construction; tests/test_gpu_inflate.py holds the kernel to the host's zlib on every block type, on
+// the reference's sample files and on corrupted streams.
+//
+// Decomposition: a deflate stream is one serial chain (every code's position depends on the lengths of all codes before
+// it, every match on the bytes before it), so the parallelism is across streams -- a batch has one to five per tile,
+// thousands per launch.  One wave owns a stream: all 64 lanes run the bit-serial parse in lockstep on wave-uniform state
+// (bit buffer, positions), the lookup tables and the last WINDOW bytes of output live in the wave's slice of LDS, and the
+// lanes work together where there is width: building the tables of a dynamic block, copying matches and stored blocks,
+// flushing the window to HBM with coalesced stores, the Adler-32 of every flushed piece.
+//
+// Result per stream: bytes produced and GF_K_OK or GF_K_ERR_FORMAT -- what one call of Inflater.inflate(byte[]) on the whole
+// input gives (zlib's inflate() with all input and `cap` bytes of room): it stops without error when the room or the input
+// runs out, reports invalid data where zlib does, and checks the Adler-32 when the stream ends inside the room.
+#include <hip/hip_runtime.h>
+
+#include "gvrs_kernels.h"
+
+namespace {
+
+constexpr int INF_WAVES = 4;                       // waves (= streams) per workgroup
+constexpr uint32_t LL_BITS = 10, D_BITS = 9;       // first-level lookup widths; longer codes walk the canonical tables
+constexpr uint32_t FLUSH = 2048;                   // window bytes gathered before they go to HBM
+
+struct __attribute__((packed, aligned(1))) InfWord { uint32_t v; };
+
+// per-wave tables (LDS)
+struct InfTables {
+    uint16_t ll[1 << LL_BITS];                     // sym | len << 9; 0 = no code here / longer than the window
+    uint16_t dd[1 << D_BITS];
+    uint16_t llSym[288], dSym[32];                 // symbols in canonical order (length, symbol)
+    uint16_t llCount[16], dCount[16];              // codes per length
+    uint8_t lens[320];                             // code lengths of the block being set up
+    uint16_t cl[128];                              // the code-length code's table (7 bits)
+    uint32_t red[2];
+};
+
+__constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
+                                       6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// Canonical Huffman tables from n code lengths (RFC 1951 3.2.2), the whole wave: count per length, the symbols in canonical
+// order, and the first-level table (code bits reversed: the stream delivers a code's first bit in the lowest position).
+// Returns 0, or -1 for an over-subscribed or (not allowed) incomplete set -- zlib's inflate_table rules: an incomplete set
+// is accepted only when it consists of a single 1-bit code.
+__device__ int inf_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *symOrder, uint16_t *table, uint32_t tbits,
+                         uint32_t lane)
+{
+    // counts per length
+    if (lane < 16) count[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) cnt[l] = 0;
+    for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const uint32_t L = s < n ? lens[s] : 0u;
+#pragma unroll
+        for (uint32_t l = 1; l < 16; l++) cnt[l] += (uint32_t)__popcll(__ballot(L == l));
+    }
+    // Kraft sum, first code and first position of every length (uniform)
+    uint32_t left = 1, code = 0, offs = 0, nCodes = 0, maxLen = 0;
+    uint32_t first[16], start[16];
+    bool over = false;
+#pragma unroll
+    for (uint32_t l = 1; l < 16; l++) {
+        left <<= 1;
+        if (cnt[l] > left) over = true;
+        left -= over ? 0u : cnt[l];
+        code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
+        first[l] = code;
+        start[l] = offs;
+        offs += cnt[l];
+        nCodes += cnt[l];
+        if (cnt[l]) maxLen = l;
+    }
+    first[0] = start[0] = 0;
+    if (lane < 16) count[lane] = (uint16_t)(lane ? cnt[lane] : 0u);
+    for (uint32_t i = lane; i < (1u << tbits); i += 64) table[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (over) return -1;
+    if (left > 0 && !(nCodes == 1 && maxLen == 1)) return nCodes == 0 ? -2 : -1;    // -2: no codes at all (caller decides)
+    // rank of every symbol among those of its length -> canonical position and code
+    uint32_t seen[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) seen[l] = 0;
+    for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const uint32_t L = s < n ? lens[s] : 0u;
+        uint32_t rank = 0, fst = 0, st = 0;
+#pragma unroll
+        for (uint32_t l = 1; l < 16; l++) {
+            const unsigned long long m = __ballot(L == l);
+            if (L == l) {
+                rank = seen[l] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                fst = first[l];
+                st = start[l];
+            }
+            seen[l] += (uint32_t)__popcll(m);
+        }
+        if (L) {
+            symOrder[st + rank] = (uint16_t)s;
+            if (L <= tbits) {
+                const uint32_t c = fst + rank;
+                const uint32_t r = __brev(c) >> (32u - L);
+                const uint16_t e = (uint16_t)(s | (L << 9));
+                for (uint32_t i = r; i < (1u << tbits); i += 1u << L) table[i] = e;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return 0;
+}
+
+struct InfState {
+    const uint8_t *in;
+    uint32_t inLen, inPos;
+    uint64_t bitbuf;
+    uint32_t bitcnt;
+    bool starved;                                  // a read wanted more bits than the input holds
+};
+
+// make sure `n` (<= 32) bits are buffered; bits behind the input read as zero and raise `starved` when they are consumed
+__device__ __forceinline__ void inf_need(InfState &z, uint32_t n)
+{
+    if (z.bitcnt < n || z.bitcnt <= 32) {
+        if (z.bitcnt <= 32 && z.inPos + 4 <= z.inLen) {
+            const uint32_t w = uni(reinterpret_cast<const InfWord *>(z.in + z.inPos)->v);
+            z.bitbuf |= (uint64_t)w << z.bitcnt;
+            z.bitcnt += 32;
+            z.inPos += 4;
+        } else {
+            while (z.bitcnt <= 56 && z.inPos < z.inLen) {
+                z.bitbuf |= (uint64_t)uni(z.in[z.inPos]) << z.bitcnt;
+                z.bitcnt += 8;
+                z.inPos++;
+            }
+        }
+    }
+}
+__device__ __forceinline__ uint32_t inf_bits(InfState &z, uint32_t n)       // n <= 16
+{
+    inf_need(z, n);
+    if (z.bitcnt < n) { z.starved = true; z.bitcnt = n; }
+    const uint32_t v = (uint32_t)z.bitbuf & ((1u << n) - 1u);
+    z.bitbuf >>= n;
+    z.bitcnt -= n;
+    return v;
+}
+
+// one symbol: first-level table, then the canonical walk for longer codes (puff's loop).  Returns the symbol, -1 for a bit
+// pattern that is no code (incomplete set), -2 when the input ran out inside the code.
+__device__ __forceinline__ int inf_sym(InfState &z, const uint16_t *table, uint32_t tbits, const uint16_t *count, const uint16_t *symOrder)
+{
+    inf_need(z, 15);
+    const uint32_t e = table[(uint32_t)z.bitbuf & ((1u << tbits) - 1u)];
+    if (e) {
+        const uint32_t L = e >> 9;
+        if (L > z.bitcnt) { z.starved = true; return -2; }
+        z.bitbuf >>= L;
+        z.bitcnt -= L;
+        return (int)(e & 511u);
+    }
+    uint32_t code = 0, first = 0, index = 0;
+    uint64_t b = z.bitbuf;
+    for (uint32_t len = 1; len <= 15; len++) {
+        code |= (uint32_t)b & 1u;
+        b >>= 1;
+        const uint32_t c = count[len];
+        if (code < first + c) {
+            if (len > z.bitcnt) { z.starved = true; return -2; }
+            z.bitbuf >>= len;
+            z.bitcnt -= len;
+            return (int)symOrder[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t W = a.window;                                   // power of two
+    uint8_t *mine = ldsDyn + (size_t)wave * (W + sizeof(InfTables));
+    uint8_t *win = mine;
+    InfTables &T = *reinterpret_cast<InfTables *>(mine + W);
+
+    for (size_t sIdx = (size_t)blockIdx.x * INF_WAVES + wave; sIdx < a.nStreams; sIdx += (size_t)gridDim.x * INF_WAVES) {
+        const GfInflateStream S = a.streams[sIdx];
+        uint8_t *__restrict__ out = a.outBase + S.outOffset;
+        int32_t status = GF_K_OK;
+        uint32_t pos = 0, flushed = 0;                             // bytes produced / bytes already in HBM
+        uint32_t s1 = 1, s2 = 0;                                   // Adler-32 of the flushed bytes
+        InfState z;
+        z.in = a.inBase + S.inOffset;
+        z.inLen = S.inLen;
+        z.inPos = 0;
+        z.bitbuf = 0;
+        z.bitcnt = 0;
+        z.starved = false;
+        const uint32_t cap = S.outCap;
+
+        // window -> HBM (and into the checksum): bytes [flushed, upTo)
+        auto flush = [&](uint32_t upTo) {
+            uint32_t sumB = 0;
+            uint64_t sumW = 0;
+            const uint32_t n = upTo - flushed;
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t b = win[(flushed + i) & (W - 1u)];
+                out[flushed + i] = (uint8_t)b;
+                sumB += b;
+                sumW += (uint64_t)(n - i) * b;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                sumB += (uint32_t)__shfl_xor((int)sumB, d, 64);
+                sumW += (uint64_t)__shfl_xor((long long)sumW, d, 64);
+            }
+            // s2 += n * s1 + sum (n - i) b_i ; s1 += sum b_i   (mod 65521)
+            s2 = (uint32_t)(((uint64_t)s2 + (uint64_t)n * s1 + sumW) % 65521u);
+            s1 = (uint32_t)(((uint64_t)s1 + sumB) % 65521u);
+            flushed = upTo;
+        };
+
+        // ---- zlib header (RFC 1950) ----
+        if (S.inLen < 2) {
+            z.starved = true;
+        } else {
+            const uint32_t cmf = inf_bits(z, 8), flg = inf_bits(z, 8);
+            if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 0x20u)) status = GF_K_ERR_FORMAT;
+        }
+        bool done = false;                                         // the stream's last block has ended
+        while (status == GF_K_OK && !z.starved && !done && pos <= cap) {
+            const uint32_t last = inf_bits(z, 1), type = inf_bits(z, 2);
+            if (z.starved) break;
+            if (type == 3u) { status = GF_K_ERR_FORMAT; break; }
+            if (type == 0u) {
+                // stored: to the byte boundary, LEN, ~LEN, bytes
+                const uint32_t drop = z.bitcnt & 7u;
+                z.bitbuf >>= drop;
+                z.bitcnt -= drop;
+                const uint32_t len = inf_bits(z, 16), nlen = inf_bits(z, 16);
+                if (z.starved) break;
+                if ((len ^ 0xffffu) != nlen) { status = GF_K_ERR_FORMAT; break; }
+                // the bit buffer holds whole bytes now: hand them back to the byte position
+                z.inPos -= z.bitcnt >> 3;
+                z.bitbuf = 0;
+                z.bitcnt = 0;
+                uint32_t todo = len;
+                while (todo) {
+                    uint32_t n = min(todo, min(z.inLen - z.inPos, min(cap - pos, FLUSH)));
+                    if (n == 0) break;
+                    for (uint32_t i = lane; i < n; i += 64) win[(pos + i) & (W - 1u)] = z.in[z.inPos + i];
+                    __builtin_amdgcn_wave_barrier();
+                    pos += n;
+                    z.inPos += n;
+                    todo -= n;
+                    if (pos - flushed >= FLUSH) flush(pos);
+                }
+                if (todo) {                                        // room or input ran out inside the block
+                    if (z.inPos >= z.inLen) z.starved = true;
+                    break;
+                }
+                done = last != 0u;
+                continue;
+            }
+            // ---- code tables ----
+            uint32_t nLL, nD;
+            if (type == 1u) {
+                nLL = 288;
+                nD = 32;                                           // 30 and 31 are codes of the fixed set that must not occur
+                for (uint32_t i = lane; i < 288; i += 64) T.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                if (lane < 32) T.lens[288 + lane] = 5;
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                nLL = inf_bits(z, 5) + 257u;
+                nD = inf_bits(z, 5) + 1u;
+                const uint32_t nCL = inf_bits(z, 4) + 4u;
+                if (z.starved) break;
+                if (nLL > 286u || nD > 30u) { status = GF_K_ERR_FORMAT; break; }
+                if (lane < 19) T.lens[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = 0; i < nCL; i++) {
+                    const uint32_t v = inf_bits(z, 3);
+                    if (lane == 0) T.lens[CL_ORDER[i]] = (uint8_t)v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (z.starved) break;
+                // the code-length code: its lengths sit in lens[0..19); tables into cl / (reused) dCount, dSym
+                if (inf_build(T.lens, 19, T.dCount, T.dSym, T.cl, 7, lane) != 0) { status = GF_K_ERR_FORMAT; break; }
+                // the literal/length and distance code lengths, run-length coded (serial)
+                uint32_t idx = 0;
+                bool bad = false;
+                uint32_t prev = 0;
+                __builtin_amdgcn_wave_barrier();
+                // lens[] is both the source of the CL table (already built) and the destination: rebuild from index 0
+                while (idx < nLL + nD) {
+                    const int sym = inf_sym(z, T.cl, 7, T.dCount, T.dSym);
+                    if (sym < 0) { bad = sym == -1; break; }
+                    if (sym < 16) {
+                        if (lane == 0) T.lens[idx] = (uint8_t)sym;
+                        prev = (uint32_t)sym;
+                        idx++;
+                    } else {
+                        uint32_t rep, val = 0;
+                        if (sym == 16) {
+                            if (idx == 0) { bad = true; break; }
+                            val = prev;
+                            rep = 3u + inf_bits(z, 2);
+                        } else if (sym == 17) {
+                            rep = 3u + inf_bits(z, 3);
+                        } else {
+                            rep = 11u + inf_bits(z, 7);
+                        }
+                        if (idx + rep > nLL + nD) { bad = true; break; }
+                        for (uint32_t i = lane; i < rep; i += 64) T.lens[idx + i] = (uint8_t)val;
+                        if (sym != 16) prev = 0;
+                        idx += rep;
+                    }
+                    if (z.starved) break;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (bad) { status = GF_K_ERR_FORMAT; break; }
+                if (z.starved || idx < nLL + nD) { z.starved = true; break; }
+                if (T.lens[256] == 0) { status = GF_K_ERR_FORMAT; break; }              // no end-of-block code
+            }
+            {
+                const int r1 = inf_build(T.lens, nLL, T.llCount, T.llSym, T.ll, LL_BITS, lane);
+                if (r1 != 0) { status = GF_K_ERR_FORMAT; break; }
+                // distance lengths follow the literal/length ones; an empty distance set is legal (literals only)
+                const int r2 = inf_build(T.lens + nLL, nD, T.dCount, T.dSym, T.dd, D_BITS, lane);
+                if (r2 == -1) { status = GF_K_ERR_FORMAT; break; }
+            }
+            // ---- the block's symbols ----
+            for (;;) {
+                if (pos - flushed >= FLUSH) flush(pos);
+                const int sym = inf_sym(z, T.ll, LL_BITS, T.llCount, T.llSym);
+                if (sym < 0) {
+                    if (sym == -1) status = GF_K_ERR_FORMAT;
+                    break;
+                }
+                if (sym < 256) {
+                    if (pos >= cap) { pos = cap + 1; break; }                            // no room: stop here, no error
+                    if (lane == 0) win[pos & (W - 1u)] = (uint8_t)sym;
+                    pos++;
+                    continue;
+                }
+                if (sym == 256) {
+                    done = last != 0u;
+                    break;
+                }
+                if (sym > 285) { status = GF_K_ERR_FORMAT; break; }
+                const uint32_t li = (uint32_t)sym - 257u;
+                const uint32_t len = LEN_BASE[li] + (LEN_EXTRA[li] ? inf_bits(z, LEN_EXTRA[li]) : 0u);
+                const int ds = inf_sym(z, T.dd, D_BITS, T.dCount, T.dSym);
+                if (ds < 0) {
+                    if (ds == -1) status = GF_K_ERR_FORMAT;
+                    break;
+                }
+                if (ds > 29) { status = GF_K_ERR_FORMAT; break; }
+                const uint32_t dist = DIST_BASE[ds] + (DIST_EXTRA[ds] ? inf_bits(z, DIST_EXTRA[ds]) : 0u);
+                if (z.starved) break;
+                if (dist > pos) { status = GF_K_ERR_FORMAT; break; }                     // too far back
+                if (pos >= cap) { pos = cap + 1; break; }
+                // copy `len` bytes from `dist` back; source and destination may overlap (then the pattern repeats): go in
+                // pieces no longer than the distance, each piece with all lanes
+                uint32_t n = min(len, cap - pos);
+                const bool cut = n < len;
+                __builtin_amdgcn_wave_barrier();
+                while (n) {
+                    const uint32_t piece = min(n, min(dist, 64u));
+                    uint32_t b = 0;
+                    if (lane < piece) b = win[(pos - dist + lane) & (W - 1u)];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < piece) win[(pos + lane) & (W - 1u)] = (uint8_t)b;
+                    __builtin_amdgcn_wave_barrier();
+                    pos += piece;
+                    n -= piece;
+                    if (pos - flushed >= W - 512u) flush(pos);                           // (long matches in a small window)
+                }
+                if (cut) { pos = cap + 1; break; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool full = pos > cap;                               // stopped for lack of room
+        if (full) pos = cap;
+        __builtin_amdgcn_wave_barrier();
+        flush(pos);
+        if (status == GF_K_OK && done && !full) {
+            // the stream ended inside the room: its Adler-32 follows, big-endian, at the next byte boundary
+            const uint32_t drop = z.bitcnt & 7u;
+            z.bitbuf >>= drop;
+            z.bitcnt -= drop;
+            z.starved = false;
+            const uint32_t b0 = inf_bits(z, 8), b1 = inf_bits(z, 8), b2 = inf_bits(z, 8), b3 = inf_bits(z, 8);
+            if (!z.starved && ((b0 << 24) | (b1 << 16) | (b2 << 8) | b3) != ((s2 << 16) | s1)) status = GF_K_ERR_FORMAT;
+        }
+        if (lane == 0) {
+            a.produced[sIdx] = pos;
+            a.status[sIdx] = status;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+uint32_t gf_inflate_window(uint32_t maxOut)
+{
+    uint32_t w = 4096;                                             // > FLUSH + the longest match: unflushed bytes never wrap
+    while (w < 32768u && w < maxOut + 64u) w <<= 1;
+    return w;
+}
+
+hipError_t gf_launch_inflate(const GfInflateArgs &a, hipStream_t stream)
+{
+    if (a.nStreams == 0) return hipSuccess;
+    const size_t dyn = (size_t)INF_WAVES * (a.window + sizeof(InfTables));
+    static GfDynLdsOptIn opt;
+    const hipError_t e = gf_opt_in_dyn_lds(k_inflate, dyn, opt);
+    if (e != hipSuccess) return e;
+    const size_t blocks = (a.nStreams + INF_WAVES - 1) / INF_WAVES;
+    const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+    hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), dyn, stream, a);
+    return hipGetLastError();
+}

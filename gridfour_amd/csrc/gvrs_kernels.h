@@ -159,6 +159,25 @@ hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const u
                                   int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
                                   hipStream_t stream, const uint32_t *pre = nullptr);   // pre: records of the first stream's lengths
 
+// zlib streams inflated on the GPU, one wave per stream (gvrs_inflate.hip)
+struct GfInflateStream {
+    uint64_t inOffset;         // the stream (2-byte zlib header first) starts at inBase + inOffset
+    uint64_t outOffset;        // its output goes to outBase + outOffset
+    uint32_t inLen;            // bytes of input that belong to the stream
+    uint32_t outCap;           // room for output (Inflater.inflate(byte[]) semantics: produce at most this much)
+};
+struct GfInflateArgs {
+    const uint8_t *inBase;
+    uint8_t *outBase;
+    const GfInflateStream *streams;
+    uint32_t *produced;        // per stream: bytes written
+    int32_t *status;           // per stream: GF_K_OK or GF_K_ERR_FORMAT (what makes Inflater throw DataFormatException)
+    size_t nStreams;
+    uint32_t window;           // LDS window per wave: gf_inflate_window(largest outCap)
+};
+uint32_t gf_inflate_window(uint32_t maxOut);
+hipError_t gf_launch_inflate(const GfInflateArgs &a, hipStream_t stream);
+
 // predictor -> M32 stage alone (gvrs_encode.hip): per tile up to three candidate M32 streams (CodecDeflate.java:157-199)
 struct GfM32Args {
     const int32_t *values;

@@ -153,6 +153,18 @@ gf_status gf_compact_dev(gf_context *ctx, void *stream, size_t n_tiles, const ui
 gf_status gf_host_alloc(size_t bytes, void **p);
 gf_status gf_host_free(void *p);
 
+/* ---- zlib (RFC 1950 / 1951) streams inflated on the GPU, one wave per stream -------------------------------------------
+ * Replaces the java.util.zip.Inflater calls of the Deflate-carrying decoders (compress/CodecDeflate.java:141-147,
+ * compress/CodecFloat.java:285-298, lsop/LsDecoder12.java:127-141).  Stream i is d_in[in_offsets[i] .. + in_lengths[i]);
+ * at most out_caps[i] bytes go to d_out + out_offsets[i]; d_produced[i] = bytes written, d_status[i] = GF_OK or GF_ERR_FORMAT
+ * -- the outcome of ONE Inflater.inflate(byte[]) call on the whole input: it stops without error when room or input run
+ * out, reports invalid data where zlib does (DataFormatException) and verifies the Adler-32 when the stream ends inside
+ * the room.  The four descriptor arrays are host arrays; d_in, d_out, d_produced, d_status are device memory.       */
+gf_status gf_inflate_batch_dev(gf_context *ctx, void *stream, size_t n_streams, const uint8_t *d_in,
+                               const uint64_t *in_offsets, const uint32_t *in_lengths, uint8_t *d_out,
+                               const uint64_t *out_offsets, const uint32_t *out_caps, uint32_t *d_produced,
+                               int32_t *d_status);
+
 /* ---- several GPUs from one process -----------------------------------------------------------------
  * What gvrs/CodecMaster.java:142-203 / gvrs/RecordManager.java:386-490 would call to use a whole node from one JVM.
  * A gf_multi owns one gf_context per listed device (a device may be listed more than once).  A batch of T tiles shards

@@ -1,0 +1,183 @@
+"""The GPU inflater (gvrs_inflate.hip, one wave per zlib stream) against the host's zlib: what an inflater produces is
+defined by the stream, so every byte must agree -- on every block type (stored, fixed, dynamic), window sizes up to 32 KB,
+long and overlapping matches, truncated room (Inflater.inflate(byte[]) semantics), truncated and corrupted input, and the
+zlib streams inside the reference's own sample files."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inflate(streams, caps):
+    """streams: list of bytes; caps: room per stream.  Returns (outputs, produced, status)."""
+    import gridfour_amd
+    from gridfour_amd import DeviceBuffer, lib
+    from gridfour_amd._lib import check
+    from gridfour_amd.sharding import _ptr
+    ctx = gridfour_amd.GvrsHipContext(0)
+    n = len(streams)
+    in_off = np.zeros(n, np.uint64)
+    in_len = np.array([len(s) for s in streams], np.uint32)
+    pos = 0
+    for i, s in enumerate(streams):
+        in_off[i] = pos
+        pos += (len(s) + 7) // 4 * 4
+    blob = np.zeros(pos + 16, np.uint8)
+    for i, s in enumerate(streams):
+        blob[int(in_off[i]):int(in_off[i]) + len(s)] = np.frombuffer(s, np.uint8)
+    out_cap = np.array(caps, np.uint32)
+    out_off = np.zeros(n, np.uint64)
+    out_off[1:] = np.cumsum((out_cap[:-1].astype(np.uint64) + 15) // 16 * 16)
+    total_out = int(out_off[-1]) + int(out_cap[-1]) + 16
+    d_in, d_out = DeviceBuffer(ctx, blob.size), DeviceBuffer(ctx, total_out)
+    d_prod, d_st = DeviceBuffer(ctx, n * 4 + 16), DeviceBuffer(ctx, n * 4 + 16)
+    d_in.upload(blob)
+    d_out.fill(0xEE)
+    check(lib().gf_inflate_batch_dev(ctx.handle, None, n, d_in.ptr, _ptr(in_off), _ptr(in_len), d_out.ptr, _ptr(out_off), _ptr(out_cap),
+                                     d_prod.ptr, d_st.ptr), "gf_inflate_batch_dev")
+    ctx.synchronize()
+    raw = d_out.download(np.uint8, total_out)
+    prod = d_prod.download(np.uint32, n)
+    st = d_st.download(np.int32, n)
+    outs = [raw[int(out_off[i]):int(out_off[i]) + int(prod[i])].tobytes() for i in range(n)]
+    # nothing may be written behind a stream's room
+    for i in range(n):
+        end = int(out_off[i]) + int(out_cap[i])
+        nxt = int(out_off[i + 1]) if i + 1 < n else total_out
+        assert (raw[end:nxt] == 0xEE).all(), i
+    return outs, prod, st
+
+
+def _host(stream, cap):
+    """one zlib inflate call with all input and `cap` bytes of room"""
+    d = zlib.decompressobj()
+    try:
+        out = d.decompress(stream, cap) if cap else b""
+        return out, 0
+    except zlib.error:
+        return None, -1
+
+
+def _payloads():
+    rng = np.random.default_rng(11)
+    p = []
+    p.append(b"")                                                   # empty
+    p.append(b"a")
+    p.append(b"abcabcabcabc" * 50)
+    p.append(bytes(70000))                                          # one long run: distance 1, maximal lengths
+    p.append(rng.integers(0, 256, 50000, dtype=np.uint8).tobytes())   # incompressible: stored blocks at level 0..9
+    p.append(rng.integers(-4, 5, 40000).astype(np.int8).tobytes())    # residual-like: literals, short codes
+    p.append((rng.geometric(0.02, 30000) % 251).astype(np.uint8).tobytes())   # many symbols, long codes
+    text = b"the quick brown fox jumps over the lazy dog. " * 3000
+    p.append(text[:100000])                                         # matches at many distances (> one window)
+    p.append(bytes(rng.integers(0, 2, 9000, dtype=np.uint8)) + text[:5000] + bytes(3000))
+    big = rng.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    p.append(big + big)                                             # distances beyond 32 KB are impossible: exactly at the window edge
+    return p
+
+
+def test_equals_host_zlib_all_block_types():
+    streams, want = [], []
+    for data in _payloads():
+        for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
+            c = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+            streams.append(c.compress(data) + c.flush())
+            want.append(data)
+    outs, prod, st = _inflate(streams, [len(w) for w in want])
+    for i, w in enumerate(want):
+        assert st[i] == 0 and prod[i] == len(w) and outs[i] == w, (i, st[i], prod[i], len(w))
+
+
+def test_small_windows_and_multiple_blocks():
+    rng = np.random.default_rng(5)
+    data = (rng.integers(0, 40, 120000) % 37).astype(np.uint8).tobytes()
+    streams = []
+    for wbits in (9, 10, 12, 15):
+        c = zlib.compressobj(6, zlib.DEFLATED, wbits)
+        parts = []
+        for i in range(0, len(data), 17000):                        # full flushes: many blocks, stored empties in between
+            parts.append(c.compress(data[i:i + 17000]))
+            parts.append(c.flush(zlib.Z_FULL_FLUSH if i % 2 else zlib.Z_SYNC_FLUSH))
+        parts.append(c.flush())
+        streams.append(b"".join(parts))
+    outs, prod, st = _inflate(streams, [len(data)] * len(streams))
+    for i in range(len(streams)):
+        assert st[i] == 0 and outs[i] == data, i
+
+
+def test_room_and_input_cut_short():
+    rng = np.random.default_rng(8)
+    data = (rng.integers(0, 20, 30000)).astype(np.uint8).tobytes() + b"xyz" * 4000
+    full = zlib.compress(data, 6)
+    streams, caps = [], []
+    for cap in (0, 1, 100, 4095, 4096, 4097, 29999, len(data) - 1, len(data), len(data) + 1000):
+        streams.append(full)
+        caps.append(cap)
+    for cut in (0, 1, 2, 3, 10, len(full) // 2, len(full) - 5, len(full) - 4, len(full) - 1):
+        streams.append(full[:cut])
+        caps.append(len(data))
+    outs, prod, st = _inflate(streams, [max(c, 1) if False else c for c in caps])
+    for i, (s, cap) in enumerate(zip(streams, caps)):
+        want, err = _host(s, cap)
+        assert st[i] == 0 and err == 0, (i, st[i])
+        assert outs[i] == want, (i, cap, len(s), prod[i], len(want))
+
+
+def test_corrupt_streams_are_reported_like_zlib():
+    rng = np.random.default_rng(21)
+    data = (rng.integers(0, 30, 20000)).astype(np.uint8).tobytes() + b"pattern" * 500
+    good = bytearray(zlib.compress(data, 6))
+    streams = []
+    bad_adler = bytearray(good)
+    bad_adler[-1] ^= 0x40
+    streams.append(bytes(bad_adler))                                # checksum
+    streams.append(bytes([0x79, 0x9c]) + bytes(good[2:]))           # method != 8
+    streams.append(bytes([0x78, 0x9d]) + bytes(good[2:]))           # header check
+    streams.append(bytes([0x78, 0xbb]) + bytes(good[2:]))           # preset dictionary
+    streams.append(bytes([0x78, 0x9c, 0x07]) + bytes(20))           # block type 3
+    streams.append(bytes([0x78, 0x9c, 0x01, 0x05, 0x00, 0x00, 0x00]) + b"hello")   # stored: LEN / NLEN mismatch
+    for k in range(24):                                             # bit flips inside the deflate data
+        b = bytearray(good)
+        b[3 + (k * 97) % (len(good) - 8)] ^= 1 << (k % 8)
+        streams.append(bytes(b))
+    outs, prod, st = _inflate(streams, [len(data)] * len(streams))
+    for i, s in enumerate(streams):
+        want, err = _host(s, len(data))
+        if err:
+            assert st[i] == -1, (i, st[i])
+        else:
+            assert st[i] == 0 and outs[i] == want, (i, st[i], prod[i])
+
+
+def test_streams_of_the_reference_sample_files(golden_dir):
+    """every zlib stream inside the tile packings of the reference's compressed sample files (CodecDeflate: one stream
+    behind the 10-byte header; CodecFloat: five behind 4-byte lengths) inflates to what the host's zlib gives"""
+    import os
+    from gvrs_walk import tile_packings
+    streams, want = [], []
+    names = [n for n in sorted(os.listdir(os.path.join(golden_dir, "ref_samples"))) if "Comp" in n and "NoComp" not in n]
+    for name in names:
+        for _, elems in tile_packings(os.path.join(golden_dir, "ref_samples", name), 1).items():
+            for blob in elems:
+                off = 0
+                while off + 2 <= len(blob):
+                    if blob[off] == 0x78 and ((blob[off] << 8) | blob[off + 1]) % 31 == 0:
+                        try:
+                            d = zlib.decompressobj()
+                            out = d.decompress(bytes(blob[off:]))
+                            if d.eof and len(out) > 0:
+                                used = len(blob) - off - len(d.unused_data)
+                                streams.append(bytes(blob[off:off + used]))
+                                want.append(out)
+                                off += used
+                                continue
+                        except zlib.error:
+                            pass
+                    off += 1
+    assert streams, "the sample files hold Deflate packings"
+    outs, prod, st = _inflate(streams, [len(w) for w in want])
+    for i, w in enumerate(want):
+        assert st[i] == 0 and outs[i] == w, i
