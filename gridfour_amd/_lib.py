@@ -101,6 +101,8 @@ SIGNATURES = {
     "gf_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "gf_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "gf_inflate_batch_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gf_deflate_decode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "gf_float_decode_batch_f32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
     "gf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "gf_host_free": (C.c_int, [_vp]),
     "gf_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),

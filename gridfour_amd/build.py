@@ -69,17 +69,22 @@ def _compile_all(lib, extra, verbose):
         # a few compiles at a time: the translation units are independent
         width = max(1, min(4, (os.cpu_count() or 2) // 2))
         running = []
-        for cmd, _ in jobs:
-            if verbose:
-                print(" ".join(cmd))
-            running.append((cmd, subprocess.Popen(cmd)))
-            if len(running) >= width:
+        try:
+            for cmd, _ in jobs:
+                if verbose:
+                    print(" ".join(cmd))
+                running.append((cmd, subprocess.Popen(cmd)))
+                if len(running) >= width:
+                    c, p = running.pop(0)
+                    if p.wait() != 0:
+                        raise subprocess.CalledProcessError(p.returncode, c)
+            while running:
                 c, p = running.pop(0)
                 if p.wait() != 0:
                     raise subprocess.CalledProcessError(p.returncode, c)
-        for c, p in running:
-            if p.wait() != 0:
-                raise subprocess.CalledProcessError(p.returncode, c)
+        finally:
+            for _, p in running:                    # a compile failed: the others finish before their directory goes away
+                p.wait()
         out = os.path.join(tmp, os.path.basename(lib))
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out] + [o for _, o in jobs] + ["-lz", "-lpthread"]
         if verbose:

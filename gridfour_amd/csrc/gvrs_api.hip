@@ -259,7 +259,9 @@ size_t gf_huffman_max_packing(int nRows, int nCols)
 }  // extern "C"
 
 // codec kinds behind the shared batch plumbing
-enum { KIND_HUFFMAN = 0, KIND_CANON = 1, KIND_RAW_M32 = 2 };
+enum { KIND_HUFFMAN = 0, KIND_CANON = 1, KIND_RAW_M32 = 2, KIND_DEFLATE = 3, KIND_FLOAT = 4 };
+static gf_status floatDecodeDev(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob, size_t blobBytes,
+                                const uint64_t *dOffsets, const uint32_t *dLengths, float *dValues, int32_t *dStatus);
 
 static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
                                 size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
@@ -577,48 +579,31 @@ gf_status gf_float_encode_batch_f32(gf_context *c, int codecIndex, int nRows, in
     return GF_OK;
 }
 
+static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                 const uint64_t *offsets, int32_t *values, int32_t *status);
+
+// CodecFloat.decodeFloats :395-458 for a batch: the five zlib streams of every packing are inflated ON THE DEVICE
+// (gvrs_inflate.hip), the planes merged there; the host only moves bytes (chunked, pinned staging).  Without a status array
+// the first failing tile's status is the return value.
 gf_status gf_float_decode_batch_f32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                     const uint64_t *offsets, float *values, int32_t *status)
 {
-    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
-    GF_HIP(hipSetDevice(c->device));
-    const size_t n = (size_t)nRows * (size_t)nCols, nSign = (n + 7) / 8;
-    const size_t stride = roundUp(gf_float_planes_bytes(nRows, nCols), 16);
-    std::vector<uint8_t> planes(nTiles * stride, 0);
-    std::vector<int32_t> tileSt(nTiles, GF_OK);
-    parallelFor(nTiles, [&](size_t t) {
-        const uint8_t *pk = blob + offsets[t];
-        const size_t len = (size_t)(offsets[t + 1] - offsets[t]);
-        int32_t st = GF_OK;
-        size_t off = 2, planeOff = 0;
-        for (int k = 0; k < 5 && st == GF_OK; k++) {
-            const size_t pl = k == 0 ? nSign : n;
-            if (off + 4 > len) { st = GF_ERR_BOUNDS; break; }
-            const uint32_t zn = (uint32_t)pk[off] | ((uint32_t)pk[off + 1] << 8) | ((uint32_t)pk[off + 2] << 16) | ((uint32_t)pk[off + 3] << 24);
-            off += 4;
-            if (off + zn > len) { st = GF_ERR_BOUNDS; break; }
-            uLongf got = (uLongf)pl;
-            const int zr = uncompress(planes.data() + t * stride + planeOff, &got, pk + off, zn);
-            if (zr != Z_OK && zr != Z_BUF_ERROR) st = GF_ERR_FORMAT;      // doInflate :285-298 -> RuntimeException
-            off += zn;
-            planeOff += pl;
-        }
-        tileSt[t] = st;
-    });
-    gf_status overall = GF_OK;
-    for (size_t t = 0; t < nTiles; t++) {
-        if (status) status[t] = tileSt[t];
-        if (tileSt[t] != GF_OK && overall == GF_OK) overall = (gf_status)tileSt[t];
-    }
-    gf_status s;
-    if ((s = c->dValues.ensure(nTiles * n * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dPlanes.ensure(nTiles * stride + 16)) != GF_OK) return s;
-    GF_HIP(hipMemcpyAsync(c->dPlanes.p, planes.data(), nTiles * stride, hipMemcpyHostToDevice, c->stream));
-    s = gf_float_planes_decode_dev(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dPlanes.p, stride, (float *)c->dValues.p);
+    if (status) return decodeBatchHost(KIND_FLOAT, c, nRows, nCols, nTiles, blob, offsets, (int32_t *)values, status);
+    std::vector<int32_t> st(nTiles, GF_OK);
+    const gf_status s = decodeBatchHost(KIND_FLOAT, c, nRows, nCols, nTiles, blob, offsets, (int32_t *)values, st.data());
     if (s != GF_OK) return s;
-    GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * n * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipStreamSynchronize(c->stream));
-    return status ? GF_OK : overall;
+    for (size_t t = 0; t < nTiles; t++)
+        if (st[t] != GF_OK) return (gf_status)st[t];
+    return GF_OK;
+}
+
+gf_status gf_float_decode_batch_f32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
+                                        size_t blobBytes, const uint64_t *dOffsets, const uint32_t *dLengths, float *dValues,
+                                        int32_t *dStatus)
+{
+    if (!c || nRows < 1 || nCols < 1 || !dBlob || !dOffsets || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    return floatDecodeDev(c, stream ? (hipStream_t)stream : c->stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, dLengths, dValues, dStatus);
 }
 
 gf_status gf_float_encode_f32(gf_context *c, int codecIndex, int nRows, int nCols, const float *values, int zlibLevel,
@@ -785,6 +770,83 @@ gf_status gf_timer_elapsed_ms(gf_timer *t, float *ms)
 // ------------------------------------------------------------------ host-memory entry points
 
 }  // extern "C"
+
+// ---- Deflate-carrying containers decoded on the device: walk the packings, inflate (gvrs_inflate.hip), decode ----------
+// The scratch (inflated bytes, stream descriptors, per-stream results) is bounded: batches go through it in chunks of tiles,
+// one after the other in stream order.
+constexpr size_t INFLATE_SCRATCH_BYTES = (size_t)256 << 20;
+
+static gf_status deflateDecodeDev(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
+                                  size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
+                                  int32_t *dValues, int32_t *dStatus)
+{
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    if (cells >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
+    const size_t rawStride = roundUp(10 + 6 * cells, 16);                 // an M32 stream has at most six bytes per cell
+    const size_t chunk = std::max<size_t>(1, std::min(nTiles, INFLATE_SCRATCH_BYTES / rawStride));
+    gf_status s;
+    if ((s = c->dInflOut.ensure(chunk * rawStride + 64)) != GF_OK) return s;
+    if ((s = c->dInflate.ensure(chunk * sizeof(GfInflateStream) + 64)) != GF_OK) return s;
+    if ((s = c->dInflMeta.ensure(chunk * 20 + 256)) != GF_OK) return s;
+    uint8_t *raw = (uint8_t *)c->dInflOut.p;
+    GfInflateStream *desc = (GfInflateStream *)c->dInflate.p;
+    uint32_t *produced = (uint32_t *)c->dInflMeta.p, *rawLengths = produced + chunk;
+    int32_t *inflStatus = (int32_t *)(rawLengths + chunk), *pre = inflStatus + chunk, *decStatus = pre + chunk;
+    for (size_t t0 = 0; t0 < nTiles; t0 += chunk) {
+        const size_t n = std::min(chunk, nTiles - t0);
+        GF_HIP(gf_launch_deflate_streams(dBlob, blobBytes, dOffsets, slotStride, dLengths, t0, n, (uint32_t)cells, raw, rawStride, desc, pre, st));
+        GfInflateArgs a;
+        a.inBase = dBlob;
+        a.outBase = raw;
+        a.streams = desc;
+        a.produced = produced;
+        a.status = inflStatus;
+        a.nStreams = n;
+        a.window = gf_inflate_window((uint32_t)std::min<size_t>(6 * cells, 32768));
+        GF_HIP(gf_launch_inflate(a, st));
+        GF_HIP(gf_launch_deflate_lengths(n, desc, produced, inflStatus, pre, rawLengths, st));
+        s = decodeBatchDev(KIND_RAW_M32, c, st, nRows, nCols, n, raw, chunk * rawStride + 32, nullptr, rawStride, rawLengths,
+                           dValues + t0 * cells, decStatus);
+        if (s != GF_OK) return s;
+        GF_HIP(gf_launch_merge_status(n, pre, decStatus, dStatus + t0, st));
+    }
+    return GF_OK;
+}
+
+static gf_status floatDecodeDev(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob, size_t blobBytes,
+                                const uint64_t *dOffsets, const uint32_t *dLengths, float *dValues, int32_t *dStatus)
+{
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    if (cells >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
+    if (!dOffsets) return GF_ERR_ARG;
+    const size_t planeStride = roundUp(gf_float_planes_bytes(nRows, nCols), 16);
+    const size_t chunk = std::max<size_t>(1, std::min(nTiles, INFLATE_SCRATCH_BYTES / planeStride));
+    gf_status s;
+    if ((s = c->dInflOut.ensure(chunk * planeStride + 64)) != GF_OK) return s;
+    if ((s = c->dInflate.ensure(chunk * 5 * sizeof(GfInflateStream) + 64)) != GF_OK) return s;
+    if ((s = c->dInflMeta.ensure(chunk * (5 * 8 + 4) + 256)) != GF_OK) return s;
+    uint8_t *planes = (uint8_t *)c->dInflOut.p;
+    GfInflateStream *desc = (GfInflateStream *)c->dInflate.p;
+    uint32_t *produced = (uint32_t *)c->dInflMeta.p;
+    int32_t *inflStatus = (int32_t *)(produced + 5 * chunk), *pre = inflStatus + 5 * chunk;
+    for (size_t t0 = 0; t0 < nTiles; t0 += chunk) {
+        const size_t n = std::min(chunk, nTiles - t0);
+        GF_HIP(hipMemsetAsync(planes, 0, n * planeStride, st));           // what a short stream does not reach reads as zero
+        GF_HIP(gf_launch_float_streams(dBlob, blobBytes, dOffsets, dLengths, t0, n, (uint32_t)cells, planeStride, desc, pre, st));
+        GfInflateArgs a;
+        a.inBase = dBlob;
+        a.outBase = planes;
+        a.streams = desc;
+        a.produced = produced;
+        a.status = inflStatus;
+        a.nStreams = 5 * n;
+        a.window = gf_inflate_window((uint32_t)std::min<size_t>(cells, 32768));
+        GF_HIP(gf_launch_inflate(a, st));
+        GF_HIP(gf_launch_float_status(n, pre, inflStatus, dStatus + t0, st));
+        GF_HIP(gf_launch_float_planes_decode(planes, (uint32_t *)dValues + t0 * cells, planeStride, n, nRows, nCols, st));
+    }
+    return GF_OK;
+}
 
 // ---- pipelined staging of the host-memory batch entry points ---------------------------------------------------
 // A batch in host memory is cut into chunks of about HOST_CHUNK_BYTES of cell values.  Each chunk travels through one of
@@ -1127,8 +1189,15 @@ static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, 
         GF_HIP(hipMemcpyAsync(S.dOffsets.p, rel, (n + 1) * 8, hipMemcpyHostToDevice, S.stream));
         GF_HIP(hipMemcpyAsync(S.dLengths.p, len, n * 4, hipMemcpyHostToDevice, S.stream));
         if (k > 0) GF_HIP(hipStreamWaitEvent(S.stream, P->slot[(k - 1) % HOST_SLOTS].evK, 0));   // kernels one chunk at a time
-        s = decodeBatchDev(kind, c, S.stream, nRows, nCols, n, (const uint8_t *)S.dBlob.p, bytes + 32, (const uint64_t *)S.dOffsets.p, 0,
-                           (const uint32_t *)S.dLengths.p, (int32_t *)S.dValues.p, (int32_t *)S.dStatus.p);
+        if (kind == KIND_DEFLATE)
+            s = deflateDecodeDev(c, S.stream, nRows, nCols, n, (const uint8_t *)S.dBlob.p, bytes + 32, (const uint64_t *)S.dOffsets.p, 0,
+                                 (const uint32_t *)S.dLengths.p, (int32_t *)S.dValues.p, (int32_t *)S.dStatus.p);
+        else if (kind == KIND_FLOAT)
+            s = floatDecodeDev(c, S.stream, nRows, nCols, n, (const uint8_t *)S.dBlob.p, bytes + 32, (const uint64_t *)S.dOffsets.p,
+                               (const uint32_t *)S.dLengths.p, (float *)S.dValues.p, (int32_t *)S.dStatus.p);
+        else
+            s = decodeBatchDev(kind, c, S.stream, nRows, nCols, n, (const uint8_t *)S.dBlob.p, bytes + 32, (const uint64_t *)S.dOffsets.p, 0,
+                               (const uint32_t *)S.dLengths.p, (int32_t *)S.dValues.p, (int32_t *)S.dStatus.p);
         if (s != GF_OK) return s;
         GF_HIP(hipEventRecord(S.evK, S.stream));
         GF_HIP(hipMemcpyAsync(pinnedOut ? (void *)(values + t0 * cells) : S.hOut.p, S.dValues.p, n * cells * 4, hipMemcpyDeviceToHost,
@@ -1717,70 +1786,22 @@ gf_status gf_deflate_encode_batch_i32(gf_context *c, int codecIndex, int nRows, 
     return GF_OK;
 }
 
-// CodecDeflate.decode :108-155: the host's zlib inflates the M32 bytes, the GPU turns them into the tile.
+// CodecDeflate.decode :108-155: the zlib stream of every packing is inflated ON THE DEVICE (gvrs_inflate.hip), the M32 bytes
+// go through the decode kernel's raw mode; the host only moves bytes (chunked, pinned staging).
 gf_status gf_deflate_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                       const uint64_t *offsets, int32_t *values, int32_t *status)
 {
-    if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    return decodeBatchHost(KIND_DEFLATE, c, nRows, nCols, nTiles, blob, offsets, values, status);
+}
+
+gf_status gf_deflate_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
+                                          size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
+                                          int32_t *dValues, int32_t *dStatus)
+{
+    if (!c || nRows < 1 || nCols < 1 || !dBlob || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
-    const size_t cells = (size_t)nRows * (size_t)nCols;
-    std::vector<std::vector<uint8_t>> raw(nTiles);
-    std::vector<int32_t> hst(nTiles, GF_OK);
-    parallelFor(nTiles, [&](size_t t) {
-        if (offsets[t + 1] < offsets[t]) { hst[t] = GF_ERR_ARG; return; }
-        const uint8_t *pk = blob + offsets[t];
-        const size_t len = (size_t)(offsets[t + 1] - offsets[t]);
-        if (len < 10) { hst[t] = GF_ERR_BOUNDS; return; }
-        const uint32_t nM32 = getLE32(pk + 6);
-        if ((int32_t)nM32 < 0) { hst[t] = GF_ERR_BOUNDS; return; }      // NegativeArraySizeException
-        if ((uint64_t)nM32 > 6ull * cells) { hst[t] = GF_ERR_FORMAT; return; }
-        raw[t].assign(10 + (size_t)nM32, 0);
-        memcpy(raw[t].data(), pk, 10);
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit(&zs) != Z_OK) { hst[t] = GF_ERR_FORMAT; return; }
-        zs.next_in = (Bytef *)(pk + 10);
-        zs.avail_in = (uInt)(len - 10);
-        zs.next_out = raw[t].data() + 10;
-        zs.avail_out = nM32;
-        const int zr = inflate(&zs, Z_PARTIAL_FLUSH);
-        const size_t got = zs.total_out;
-        inflateEnd(&zs);
-        if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) { hst[t] = GF_ERR_FORMAT; return; }   // DataFormatException
-        if (got == 0) hst[t] = GF_ERR_FORMAT;                           // decode returns null (:147-153)
-    });
-    std::vector<uint64_t> roff(nTiles + 1);
-    uint64_t total = 0;
-    for (size_t t = 0; t < nTiles; t++) {
-        roff[t] = total;
-        if (hst[t] == GF_OK) total += roundUp(raw[t].size(), 4);
-    }
-    roff[nTiles] = total;
-    std::vector<uint8_t> staged(total + 16, 0);
-    std::vector<uint32_t> lengths(nTiles, 0);
-    for (size_t t = 0; t < nTiles; t++)
-        if (hst[t] == GF_OK) { memcpy(staged.data() + roff[t], raw[t].data(), raw[t].size()); lengths[t] = (uint32_t)raw[t].size(); }
-    gf_status s;
-    if ((s = c->dBlob.ensure(total + 32)) != GF_OK) return s;
-    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dLengths.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
-    GF_HIP(hipMemcpyAsync(c->dBlob.p, staged.data(), total + 16, hipMemcpyHostToDevice, c->stream));
-    GF_HIP(hipMemcpyAsync(c->dOffsets.p, roff.data(), (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
-    s = gf_m32_decode_batch_i32_dev(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total + 16,
-                                    (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p, (int32_t *)c->dValues.p,
-                                    (int32_t *)c->dStatus.p);
-    if (s != GF_OK) return s;
-    std::vector<int32_t> st(nTiles);
-    GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipStreamSynchronize(c->stream));
-    for (size_t t = 0; t < nTiles; t++)
-        if (hst[t] != GF_OK) st[t] = hst[t];
-    if (status) memcpy(status, st.data(), nTiles * 4);
-    return GF_OK;
+    return deflateDecodeDev(c, stream ? (hipStream_t)stream : c->stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride,
+                            dLengths, dValues, dStatus);
 }
 
 gf_status gf_deflate_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, uint8_t *out,

@@ -27,6 +27,7 @@ namespace {
 constexpr int INF_WAVES = 4;                       // waves (= streams) per workgroup
 constexpr uint32_t LL_BITS = 10, D_BITS = 9;       // first-level lookup widths; longer codes walk the canonical tables
 constexpr uint32_t FLUSH = 2048;                   // window bytes gathered before they go to HBM
+constexpr uint32_t IN_WORDS = 256;                 // the wave's LDS copy of the compressed input: 1 KB, refilled by all lanes
 
 struct __attribute__((packed, aligned(1))) InfWord { uint32_t v; };
 
@@ -38,7 +39,7 @@ struct InfTables {
     uint16_t llCount[16], dCount[16];              // codes per length
     uint8_t lens[320];                             // code lengths of the block being set up
     uint16_t cl[128];                              // the code-length code's table (7 bits)
-    uint32_t red[2];
+    uint32_t ibuf[IN_WORDS];                       // the compressed input, a piece at a time
 };
 
 __constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -124,29 +125,49 @@ __device__ int inf_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint1
 }
 
 struct InfState {
-    const uint8_t *in;
+    const uint8_t *in;                             // the stream (any byte alignment)
+    const uint32_t *in32;                          // the aligned dword that holds its first byte
+    uint32_t mis;                                  // position of that byte inside the dword
+    uint32_t *ibuf;                                // LDS: dwords [bufWord, bufWord + IN_WORDS) of in32
+    uint32_t bufWord, lastWord;                    // first buffered dword; last dword that holds a byte of the stream
     uint32_t inLen, inPos;
     uint64_t bitbuf;
     uint32_t bitcnt;
     bool starved;                                  // a read wanted more bits than the input holds
 };
 
+// Four bytes of the stream from byte position p, through the LDS copy.  A miss refills the copy with coalesced loads: reading
+// the input dword by dword straight from HBM cost a memory round trip every four bytes of input.
+__device__ __forceinline__ uint32_t inf_load32(InfState &z, uint32_t p)
+{
+    const uint32_t g = z.mis + p, wi = g >> 2;
+    if (wi < z.bufWord || wi + 1u >= z.bufWord + IN_WORDS) {
+        __builtin_amdgcn_wave_barrier();
+        z.bufWord = wi;
+        const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+        for (uint32_t k = 0; k < IN_WORDS / 64u; k++) {
+            const uint32_t w = wi + lane + 64u * k;
+            z.ibuf[lane + 64u * k] = w <= z.lastWord ? z.in32[w] : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t d0 = uni(z.ibuf[wi - z.bufWord]), d1 = uni(z.ibuf[wi - z.bufWord + 1u]);
+    return __builtin_amdgcn_alignbit(d1, d0, (g & 3u) * 8u);
+}
+
 // make sure `n` (<= 32) bits are buffered; bits behind the input read as zero and raise `starved` when they are consumed
 __device__ __forceinline__ void inf_need(InfState &z, uint32_t n)
 {
-    if (z.bitcnt < n || z.bitcnt <= 32) {
-        if (z.bitcnt <= 32 && z.inPos + 4 <= z.inLen) {
-            const uint32_t w = uni(reinterpret_cast<const InfWord *>(z.in + z.inPos)->v);
-            z.bitbuf |= (uint64_t)w << z.bitcnt;
-            z.bitcnt += 32;
-            z.inPos += 4;
-        } else {
-            while (z.bitcnt <= 56 && z.inPos < z.inLen) {
-                z.bitbuf |= (uint64_t)uni(z.in[z.inPos]) << z.bitcnt;
-                z.bitcnt += 8;
-                z.inPos++;
-            }
-        }
+    (void)n;
+    if (z.bitcnt <= 32 && z.inPos < z.inLen) {
+        uint32_t w = inf_load32(z, z.inPos);
+        uint32_t nb = z.inLen - z.inPos;
+        if (nb >= 4u) nb = 4u;
+        else w &= (1u << (8u * nb)) - 1u;
+        z.bitbuf |= (uint64_t)w << z.bitcnt;
+        z.bitcnt += 8u * nb;
+        z.inPos += nb;
     }
 }
 __device__ __forceinline__ uint32_t inf_bits(InfState &z, uint32_t n)       // n <= 16
@@ -209,7 +230,12 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
         uint32_t s1 = 1, s2 = 0;                                   // Adler-32 of the flushed bytes
         InfState z;
         z.in = a.inBase + S.inOffset;
+        z.mis = (uint32_t)(reinterpret_cast<uintptr_t>(z.in) & 3u);
+        z.in32 = reinterpret_cast<const uint32_t *>(z.in - z.mis);
+        z.ibuf = T.ibuf;
+        z.bufWord = 0xF0000000u;                                   // nothing buffered yet
         z.inLen = S.inLen;
+        z.lastWord = S.inLen ? (z.mis + S.inLen - 1u) >> 2 : 0u;
         z.inPos = 0;
         z.bitbuf = 0;
         z.bitcnt = 0;
@@ -419,7 +445,160 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
     }
 }
 
+// ---- containers: where the zlib streams of a packing are, one thread per tile ------------------------------------
+// CodecDeflate (CodecDeflate.java:108-155): 10-byte header (index, predictor, seed LE, nM32 LE), then ONE stream of nM32 bytes.
+// The header goes to the front of the tile's raw container, the stream's output behind it: what k_huffman_decode's rawM32
+// mode reads.  pre[t] = the status the reference's own checks give before inflating (GF_K_OK: go on).
+__global__ void k_deflate_streams(const uint8_t *__restrict__ blob, size_t blobBytes, const uint64_t *__restrict__ offsets,
+                                  size_t slotStride, const uint32_t *__restrict__ lengths, size_t tile0, size_t nTiles, uint32_t cells,
+                                  uint8_t *__restrict__ raw, size_t rawStride, GfInflateStream *__restrict__ desc,
+                                  int32_t *__restrict__ pre)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTiles) return;
+    const size_t t = tile0 + i;
+    const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
+    const uint32_t len = lengths[t];
+    GfInflateStream d;
+    d.inOffset = off + 10;
+    d.outOffset = i * rawStride + 10;
+    d.inLen = 0;
+    d.outCap = 0;
+    int32_t st = GF_K_OK;
+    if (len < 10 || off + len > blobBytes) {
+        st = GF_K_ERR_BOUNDS;
+    } else {
+        const uint8_t *pk = blob + off;
+        const uint32_t nM32 = (uint32_t)pk[6] | ((uint32_t)pk[7] << 8) | ((uint32_t)pk[8] << 16) | ((uint32_t)pk[9] << 24);
+        if ((int32_t)nM32 < 0) st = GF_K_ERR_BOUNDS;                       // NegativeArraySizeException
+        else if ((uint64_t)nM32 > 6ull * cells) st = GF_K_ERR_FORMAT;      // no encoder emits this
+        else {
+            for (int k = 0; k < 10; k++) raw[i * rawStride + k] = pk[k];
+            d.inLen = len - 10;
+            d.outCap = nM32;
+        }
+    }
+    desc[i] = d;
+    pre[i] = st;
+}
+
+// lengths of the raw containers for the decode kernel (0: the tile is out) and the status so far
+__global__ void k_deflate_lengths(size_t nTiles, const GfInflateStream *__restrict__ desc, const uint32_t *__restrict__ produced,
+                                  const int32_t *__restrict__ inflStatus, int32_t *__restrict__ pre, uint32_t *__restrict__ rawLengths)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTiles) return;
+    int32_t st = pre[i];
+    if (st == GF_K_OK && (inflStatus[i] != GF_K_OK || produced[i] == 0)) st = GF_K_ERR_FORMAT;   // DataFormatException / inflate gave nothing
+    pre[i] = st;
+    rawLengths[i] = st == GF_K_OK ? 10u + desc[i].outCap : 0u;
+}
+
+// final status: the container's own where it failed, the decode kernel's otherwise
+__global__ void k_merge_status(size_t nTiles, const int32_t *__restrict__ pre, const int32_t *__restrict__ decoded,
+                               int32_t *__restrict__ status)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTiles) return;
+    status[i] = pre[i] != GF_K_OK ? pre[i] : (decoded ? decoded[i] : GF_K_OK);
+}
+
+// CodecFloat (CodecFloat.java:395-458): two header bytes, then five times [int32 LE n][zlib stream of n bytes]: sign bits,
+// exponent, three mantissa planes.  Five descriptors per tile; pre[t] = GF_K_ERR_BOUNDS where the framing runs off the packing.
+__global__ void k_float_streams(const uint8_t *__restrict__ blob, size_t blobBytes, const uint64_t *__restrict__ offsets,
+                                const uint32_t *__restrict__ lengths, size_t tile0, size_t nTiles, uint32_t cells, size_t planeStride,
+                                GfInflateStream *__restrict__ desc, int32_t *__restrict__ pre)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTiles) return;
+    const size_t t = tile0 + i;
+    const uint64_t off = offsets[t];
+    const uint32_t len = lengths[t];
+    const uint32_t nSign = (cells + 7u) >> 3;
+    int32_t st = off + len > blobBytes ? GF_K_ERR_BOUNDS : GF_K_OK;
+    uint32_t p = 2, planeOff = 0;
+    for (int k = 0; k < 5; k++) {
+        GfInflateStream d;
+        d.inOffset = 0;
+        d.outOffset = i * planeStride + planeOff;
+        d.inLen = 0;
+        d.outCap = 0;
+        const uint32_t pl = k == 0 ? nSign : cells;
+        if (st == GF_K_OK) {
+            if (p + 4u > len) st = GF_K_ERR_BOUNDS;
+            else {
+                const uint8_t *q = blob + off + p;
+                const uint32_t zn = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                p += 4;
+                if ((uint64_t)p + zn > len) st = GF_K_ERR_BOUNDS;
+                else {
+                    d.inOffset = off + p;
+                    d.inLen = zn;
+                    d.outCap = pl;
+                    p += zn;
+                }
+            }
+        }
+        desc[i * 5 + k] = d;
+        planeOff += pl;
+    }
+    pre[i] = st;
+}
+
+__global__ void k_float_status(size_t nTiles, const int32_t *__restrict__ pre, const int32_t *__restrict__ inflStatus,
+                               int32_t *__restrict__ status)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTiles) return;
+    int32_t st = pre[i];
+    for (int k = 0; k < 5 && st == GF_K_OK; k++)
+        if (inflStatus[i * 5 + k] != GF_K_OK) st = GF_K_ERR_FORMAT;            // doInflate :285-298 -> RuntimeException
+    status[i] = st;
+}
+
 }  // namespace
+
+hipError_t gf_launch_deflate_streams(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
+                                     const uint32_t *lengths, size_t tile0, size_t nTiles, uint32_t cells, uint8_t *raw, size_t rawStride,
+                                     GfInflateStream *desc, int32_t *pre, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_deflate_streams, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, stream, blob, blobBytes, offsets, slotStride,
+                       lengths, tile0, nTiles, cells, raw, rawStride, desc, pre);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_deflate_lengths(size_t nTiles, const GfInflateStream *desc, const uint32_t *produced, const int32_t *inflStatus,
+                                     int32_t *pre, uint32_t *rawLengths, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_deflate_lengths, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, stream, nTiles, desc, produced, inflStatus,
+                       pre, rawLengths);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_merge_status(size_t nTiles, const int32_t *pre, const int32_t *decoded, int32_t *status, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_status, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, stream, nTiles, pre, decoded, status);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_float_streams(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, const uint32_t *lengths, size_t tile0,
+                                   size_t nTiles, uint32_t cells, size_t planeStride, GfInflateStream *desc, int32_t *pre, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_float_streams, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, stream, blob, blobBytes, offsets, lengths,
+                       tile0, nTiles, cells, planeStride, desc, pre);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_float_status(size_t nTiles, const int32_t *pre, const int32_t *inflStatus, int32_t *status, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_float_status, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, stream, nTiles, pre, inflStatus, status);
+    return hipGetLastError();
+}
 
 uint32_t gf_inflate_window(uint32_t maxOut)
 {

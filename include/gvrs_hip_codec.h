@@ -165,6 +165,16 @@ gf_status gf_inflate_batch_dev(gf_context *ctx, void *stream, size_t n_streams, 
                                const uint64_t *out_offsets, const uint32_t *out_caps, uint32_t *d_produced,
                                int32_t *d_status);
 
+/* Deflate-carrying packings decoded entirely on the device (container walk, inflate, decode; scratch bounded by chunks):
+ * CodecDeflate (layout as gf_huffman_decode_batch_i32_dev) and CodecFloat (d_offsets required).  The host-memory forms
+ * gf_deflate_decode_batch_i32 / gf_float_decode_batch_f32 run the same kernels behind the pipelined staging.           */
+gf_status gf_deflate_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                          const uint8_t *d_blob, size_t blob_bytes, const uint64_t *d_offsets,
+                                          size_t slot_stride, const uint32_t *d_lengths, int32_t *d_values, int32_t *d_status);
+gf_status gf_float_decode_batch_f32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
+                                        const uint8_t *d_blob, size_t blob_bytes, const uint64_t *d_offsets,
+                                        const uint32_t *d_lengths, float *d_values, int32_t *d_status);
+
 /* ---- several GPUs from one process -----------------------------------------------------------------
  * What gvrs/CodecMaster.java:142-203 / gvrs/RecordManager.java:386-490 would call to use a whole node from one JVM.
  * A gf_multi owns one gf_context per listed device (a device may be listed more than once).  A batch of T tiles shards

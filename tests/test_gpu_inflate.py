@@ -181,3 +181,92 @@ def test_streams_of_the_reference_sample_files(golden_dir):
     outs, prod, st = _inflate(streams, [len(w) for w in want])
     for i, w in enumerate(want):
         assert st[i] == 0 and outs[i] == w, i
+
+
+def _upload_packings(ctx, packs):
+    from gridfour_amd import DeviceBuffer
+    n = len(packs)
+    off = np.zeros(n + 1, np.uint64)
+    pos = 0
+    for i, p in enumerate(packs):
+        off[i] = pos
+        pos += len(p)
+    off[n] = pos
+    blob = np.frombuffer(b"".join(packs) + bytes(32), np.uint8)
+    ln = np.array([len(p) for p in packs], np.uint32)
+    d_blob, d_off, d_len = DeviceBuffer(ctx, blob.size), DeviceBuffer(ctx, off.nbytes), DeviceBuffer(ctx, ln.nbytes + 16)
+    d_blob.upload(blob)
+    d_off.upload(off)
+    d_len.upload(ln)
+    return d_blob, d_off, d_len, pos
+
+
+def test_deflate_packings_decoded_on_the_device():
+    """gf_deflate_decode_batch_i32_dev: container walk, inflate and M32 decode without the host touching a byte; damaged
+    packings get the statuses of the reference's own checks"""
+    import gridfour_amd
+    import oracle
+    from gridfour_amd import DeviceBuffer, lib
+    from gridfour_amd._lib import check
+    n_rows, n_cols, nt = 60, 70, 24
+    tiles = oracle.dem_tiles(oracle.DEM_SEED + 4, n_rows, n_cols, 8, 0, nt).copy()
+    tiles[3, 100:200] = -(2 ** 31)                                   # nulls predictor
+    codec = gridfour_amd.CodecDeflateHip()
+    packs, _, st = codec.encode_batch(0, n_rows, n_cols, tiles)
+    assert (st == 0).all()
+    for t in (0, 3, 11):
+        assert packs[t] == oracle.codec_deflate_encode(0, n_rows, n_cols, tiles[t])[0]
+    packs = [bytes(p) for p in packs]
+    bad = list(packs)
+    b = bytearray(bad[5]); b[-1] ^= 0x10; bad[5] = bytes(b)          # Adler-32 -> DataFormatException -> IOException
+    bad[6] = bad[6][:7]                                              # shorter than the header -> out of bounds
+    b = bytearray(bad[7]); b[9] = 0x80; bad[7] = bytes(b)            # negative nM32 -> NegativeArraySizeException
+    b = bytearray(bad[8]); b[12] ^= 0xFF; bad[8] = bytes(b)          # deflate data damaged
+    ctx = codec.ctx
+    d_blob, d_off, d_len, total = _upload_packings(ctx, bad)
+    d_vals, d_st = DeviceBuffer(ctx, tiles.nbytes), DeviceBuffer(ctx, nt * 4 + 16)
+    check(lib().gf_deflate_decode_batch_i32_dev(ctx.handle, None, n_rows, n_cols, nt, d_blob.ptr, total + 32, d_off.ptr, 0, d_len.ptr,
+                                                d_vals.ptr, d_st.ptr), "gf_deflate_decode_batch_i32_dev")
+    ctx.synchronize()
+    got = d_vals.download(np.int32, tiles.size).reshape(tiles.shape)
+    st = d_st.download(np.int32, nt)
+    for t in range(nt):
+        if t in (5, 8):
+            assert st[t] == -1, (t, st[t])
+        elif t in (6, 7):
+            assert st[t] == -2, (t, st[t])
+        else:
+            assert st[t] == 0 and np.array_equal(got[t], tiles[t]), t
+
+
+def test_float_packings_decoded_on_the_device():
+    import gridfour_amd
+    import oracle
+    from gridfour_amd import DeviceBuffer, lib
+    from gridfour_amd._lib import check
+    n_rows, n_cols, nt = 48, 80, 12
+    ints = oracle.dem_tiles(oracle.DEM_SEED + 6, n_rows, n_cols, 4, 0, nt)
+    vals = (ints.astype(np.float32) * np.float32(0.1)).astype(np.float32)
+    vals[2, 7] = np.nan
+    vals[2, 8] = -0.0
+    codec = gridfour_amd.CodecFloatHip(level=6)
+    packs = [bytes(p) for p in codec.encode_floats_batch(1, n_rows, n_cols, vals)]
+    assert packs[1] == oracle.codec_float_encode(1, n_rows, n_cols, vals[1].view(np.uint32), 6)
+    bad = list(packs)
+    b = bytearray(bad[4]); b[len(b) - 40] ^= 0x55; bad[4] = bytes(b)   # inside the last zlib stream
+    bad[5] = bad[5][:len(bad[5]) // 2]                               # framing runs off the packing
+    ctx = codec.ctx
+    d_blob, d_off, d_len, total = _upload_packings(ctx, bad)
+    d_vals, d_st = DeviceBuffer(ctx, vals.nbytes), DeviceBuffer(ctx, nt * 4 + 16)
+    check(lib().gf_float_decode_batch_f32_dev(ctx.handle, None, n_rows, n_cols, nt, d_blob.ptr, total + 32, d_off.ptr, d_len.ptr,
+                                              d_vals.ptr, d_st.ptr), "gf_float_decode_batch_f32_dev")
+    ctx.synchronize()
+    got = d_vals.download(np.uint32, vals.size).reshape(vals.shape)
+    st = d_st.download(np.int32, nt)
+    for t in range(nt):
+        if t == 4:
+            assert st[t] == -1
+        elif t == 5:
+            assert st[t] == -2
+        else:
+            assert st[t] == 0 and np.array_equal(got[t], vals[t].view(np.uint32)), t
