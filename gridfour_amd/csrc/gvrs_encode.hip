@@ -120,9 +120,11 @@ __device__ __forceinline__ void wave_huff_rounds(GfHuffTree &T, uint32_t (&K)[4]
 #endif
 
 // stream elements [sBegin, sEnd) of `model`, any residual size: the general (slow) packer
-__device__ void pack_generic(int model, const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
-                             const uint64_t *tab, uint32_t elemMaxBits, uint32_t sBegin, uint32_t sEnd,
-                             uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps)
+// (The packers are real calls: the pack state travels by value and comes back as the result -- a reference parameter of
+// a function that is not inlined is a stack object, i.e. scratch memory.)
+__device__ PackState pack_generic(int model, const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
+                                  const uint64_t *tab, uint32_t elemMaxBits, uint32_t sBegin, uint32_t sEnd,
+                                  uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState ps)
 {
     const uint32_t tid = threadIdx.x;
     // elements per chunk such that a chunk can never overflow the window
@@ -173,14 +175,15 @@ __device__ void pack_generic(int model, const uint32_t *__restrict__ tile, uint3
         ps.bitBase += total;
         window_flush(win, out32, ps);
     }
+    return ps;
 }
 
 // the main segment of a model's stream = flat scan over the cells with an emit mask; fast path
 // for residuals whose codes fit the window at CPT cells per thread
 template <int MODEL>
-__device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
-                          const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
-                          PackState &ps, uint32_t cellBegin = 0, uint32_t cellEnd = 0xFFFFFFFFu)
+__device__ PackState pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                               const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                               PackState ps, uint32_t cellBegin = 0, uint32_t cellEnd = 0xFFFFFFFFu)
 {
     // cells [cellBegin, cellEnd): cellBegin a multiple of CPT, cellEnd a multiple of CPT or the end of the tile
     const uint32_t tid = threadIdx.x;
@@ -248,16 +251,21 @@ __device__ void pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32
         ps.bitBase += total;
         window_flush(win, out32, ps);
     }
+    return ps;
 }
 
 // The same segment with wave-private bit windows: every wave packs one contiguous quarter of the cells into its own
 // quarter of the LDS window, starting at bit 0, with a wave-level scan and no workgroup barrier inside the loop; the
 // four bit strings are then shifted into place (they follow one another in the stream) and written out.  Returns
 // false -- nothing written, ps untouched -- when a quarter does not fit its window; the caller then uses pack_flat.
+struct PackStateOk {
+    PackState ps;
+    bool ok;
+};
 template <int MODEL>
-__device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
-                                const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
-                                PackState &ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
+__device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+                                       const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
+                                       PackState ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
 {
     // cells [cellBegin, cellEnd) as for pack_flat; on return the window again holds the partial last word at win[0]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -331,7 +339,10 @@ __device__ bool pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, 
         }
         bits += total;
     }
-    return wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
+    PackStateOk r;
+    r.ok = wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
+    r.ps = ps;
+    return r;
 }
 
 // Two kernels per batch: k_huffman_encode (phases A and B and the selection) and k_huffman_pack (phase C).  Fused into
@@ -545,6 +556,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 // huge tiles: compaction + rank sort on full 32-bit counts, sequential merge on one lane
                 uint32_t *ccnt = &T.cnt[255];    // compacted counts (temp, branch area is free until the merge)
                 uint16_t *csym = T.bq;           // compacted symbols (temp)
+#pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int s = lane + 64 * j;
                     const uint32_t cnt = P.hist[p][s];
@@ -557,6 +569,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 __builtin_amdgcn_wave_barrier();
                 uint32_t rk[4], myc[4];
                 uint16_t mys[4];
+#pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int i = lane + 64 * j;
                     rk[j] = 0;
@@ -573,6 +586,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+#pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int i = lane + 64 * j;
                     if (i < n) { T.cnt[rk[j]] = myc[j]; T.sym[rk[j]] = (uint8_t)mys[j]; }
@@ -704,8 +718,9 @@ __device__ __forceinline__ void pack_flat_ranges(const uint32_t *__restrict__ ti
     const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / capBits + 1u);
     const uint32_t per = (((nCells + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);
     for (uint32_t b = 0; b < nCells; b += per) {
-        if (!pack_flat_waves<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per))
-            pack_flat<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, b, b + per);
+        const PackStateOk r = pack_flat_waves<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
+        if (r.ok) ps = r.ps;
+        else ps = pack_flat<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, b, b + per);
     }
 }
 
@@ -749,14 +764,14 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
         if (nStream > 0 && maxLen > 0) {
             const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
             if (!fast) {
-                pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
+                ps = pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
             } else if (model == 1) {
                 pack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 2) {
-                pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                ps = pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
                 pack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 3) {
-                pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                ps = pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
                 pack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else {
                 pack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
@@ -910,17 +925,17 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
             const uint32_t emb = 48;                                        // six bytes at most per value
             if (nStream > 0) {
                 if (nC < 2) {
-                    pack_generic(model, tile, nR, nC, seed, S.tab, emb, 0u, nStream, S.win, out32, S.waveSum, ps);
+                    ps = pack_generic(model, tile, nR, nC, seed, S.tab, emb, 0u, nStream, S.win, out32, S.waveSum, ps);
                 } else if (model == 1) {
-                    pack_flat<1>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                    ps = pack_flat<1>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
                 } else if (model == 2) {
-                    pack_generic(2, tile, nR, nC, seed, S.tab, emb, 0u, 2u * nR - 1u, S.win, out32, S.waveSum, ps);
-                    pack_flat<2>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                    ps = pack_generic(2, tile, nR, nC, seed, S.tab, emb, 0u, 2u * nR - 1u, S.win, out32, S.waveSum, ps);
+                    ps = pack_flat<2>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
                 } else if (model == 3) {
-                    pack_generic(3, tile, nR, nC, seed, S.tab, emb, 0u, nC - 1u + nR - 1u, S.win, out32, S.waveSum, ps);
-                    pack_flat<3>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                    ps = pack_generic(3, tile, nR, nC, seed, S.tab, emb, 0u, nC - 1u + nR - 1u, S.win, out32, S.waveSum, ps);
+                    ps = pack_flat<3>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
                 } else {
-                    pack_flat<4>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
+                    ps = pack_flat<4>(tile, nC, nCells, seed, S.tab, S.win, out32, S.waveSum, ps);
                 }
             }
             {

@@ -73,28 +73,33 @@ struct Cells8 {
 __device__ __forceinline__ void load_cells8(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells,
                                             uint32_t i0, Cells8 &Q)
 {
+    // every value lands in a scalar first and the struct is filled after the two paths have joined: with the members
+    // assigned inside the branches the compiler kept three of them in a stack slot (12 bytes of scratch per lane)
+    uint32_t c0, c1, c2, c3, c4, c5, c6, c7, u0, u1, u2, u3, u4, u5, u6, u7, wm1, wm2, upm1;
     if (i0 >= nC + 2 && i0 + (CPT - 1) < nCells) {       // interior: every word exists
         const GfU4 a = *reinterpret_cast<const GfU4 *>(tile + i0);
         const GfU4 b = *reinterpret_cast<const GfU4 *>(tile + i0 + 4);
         const GfU4 c = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC));
         const GfU4 d = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC) + 4);
-        Q.wm1 = tile[i0 - 1];
-        Q.wm2 = tile[i0 - 2];
-        Q.upm1 = tile[i0 - nC - 1];
-        Q.cur[0] = a.x; Q.cur[1] = a.y; Q.cur[2] = a.z; Q.cur[3] = a.w;
-        Q.cur[4] = b.x; Q.cur[5] = b.y; Q.cur[6] = b.z; Q.cur[7] = b.w;
-        Q.up[0] = c.x; Q.up[1] = c.y; Q.up[2] = c.z; Q.up[3] = c.w;
-        Q.up[4] = d.x; Q.up[5] = d.y; Q.up[6] = d.z; Q.up[7] = d.w;
+        wm1 = tile[i0 - 1];
+        wm2 = tile[i0 - 2];
+        upm1 = tile[i0 - nC - 1];
+        c0 = a.x; c1 = a.y; c2 = a.z; c3 = a.w; c4 = b.x; c5 = b.y; c6 = b.z; c7 = b.w;
+        u0 = c.x; u1 = c.y; u2 = c.z; u3 = c.w; u4 = d.x; u5 = d.y; u6 = d.z; u7 = d.w;
     } else {
-#pragma unroll
-        for (int j = 0; j < CPT; j++) {
-            Q.cur[j] = i0 + j < nCells ? tile[i0 + j] : 0u;
-            Q.up[j] = (i0 + j >= nC && i0 + j < nCells) ? tile[i0 + j - nC] : 0u;
-        }
-        Q.wm1 = (i0 >= 1 && i0 - 1 < nCells) ? tile[i0 - 1] : 0u;
-        Q.wm2 = (i0 >= 2 && i0 - 2 < nCells) ? tile[i0 - 2] : 0u;
-        Q.upm1 = (i0 >= nC + 1 && i0 - nC - 1 < nCells) ? tile[i0 - nC - 1] : 0u;
+        auto cur = [&](uint32_t j) -> uint32_t { return i0 + j < nCells ? tile[i0 + j] : 0u; };
+        auto up = [&](uint32_t j) -> uint32_t { return (i0 + j >= nC && i0 + j < nCells) ? tile[i0 + j - nC] : 0u; };
+        c0 = cur(0); c1 = cur(1); c2 = cur(2); c3 = cur(3); c4 = cur(4); c5 = cur(5); c6 = cur(6); c7 = cur(7);
+        u0 = up(0); u1 = up(1); u2 = up(2); u3 = up(3); u4 = up(4); u5 = up(5); u6 = up(6); u7 = up(7);
+        wm1 = (i0 >= 1 && i0 - 1 < nCells) ? tile[i0 - 1] : 0u;
+        wm2 = (i0 >= 2 && i0 - 2 < nCells) ? tile[i0 - 2] : 0u;
+        upm1 = (i0 >= nC + 1 && i0 - nC - 1 < nCells) ? tile[i0 - nC - 1] : 0u;
     }
+    Q.cur[0] = c0; Q.cur[1] = c1; Q.cur[2] = c2; Q.cur[3] = c3; Q.cur[4] = c4; Q.cur[5] = c5; Q.cur[6] = c6; Q.cur[7] = c7;
+    Q.up[0] = u0; Q.up[1] = u1; Q.up[2] = u2; Q.up[3] = u3; Q.up[4] = u4; Q.up[5] = u5; Q.up[6] = u6; Q.up[7] = u7;
+    Q.wm1 = wm1;
+    Q.wm2 = wm2;
+    Q.upm1 = upm1;
 }
 
 // Bitonic sort, ascending, of the 64*NREG 32-bit keys held in k[0..NREG) (element e = r*64 + lane).
