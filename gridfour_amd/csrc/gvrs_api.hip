@@ -286,6 +286,7 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
     a.debug = g_encodeDebug;
     a.phaseLimit = g_encPhaseLimit;
     a.packRecs = nullptr;
+    a.retryFlag = kind == KIND_HUFFMAN ? (uint32_t *)c->flags.p + 4 : nullptr;      // (word 0 belongs to the decoder)
     {
         const size_t need = nTiles * (kind == KIND_CANON ? gf_canon_pack_rec_words() : (size_t)GF_PACK_REC_WORDS) * 4 + 16;
         if (c->packRecs.bytes < need) {

@@ -352,6 +352,14 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
 // batch (sweep: 4..8 workgroups per CU each).
 constexpr int ENC_AB_WGS = 6, ENC_PACK_WGS = 8;
 
+constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel leaves this tile to the general one
+
+// Two instantiations of one body.  FAST is what a batch of terrain tiles consists of: no null cells, symbol counts below
+// 2^23 (the in-register sort and the data-parallel tree rounds).  A tile with nulls (its own predictor, seed from a mean,
+// a second histogram pass) is marked GF_K_RETRY and left to the general instantiation, which with a.retryFlag touches only
+// marked tiles and returns at once when there are none.  The general body is twice the size of the fast one and carries the
+// register pressure of the rare paths into every tile's allocation.
+template <bool FAST>
 __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
     __shared__ EncPersist P;
@@ -359,8 +367,14 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    if constexpr (!FAST) {
+        if (a.retryFlag && *a.retryFlag == 0u) return;               // the fast kernel finished every tile
+    }
 
     for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if constexpr (!FAST) {
+            if (a.retryFlag && a.status[t] != GF_K_RETRY) continue;
+        }
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
 
         GF_STAMP(0);
@@ -452,7 +466,17 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
             continue;
         }
 
-        if (anyNull) {
+        if constexpr (FAST) {
+            if (anyNull) {
+                if (tid == 0) {
+                    a.status[t] = GF_K_RETRY;
+                    atomicOr(a.retryFlag, 1u);
+                }
+                __syncthreads();
+                continue;
+            }
+        }
+        if (!FAST && anyNull) {
             // ---- nulls path (rare): seed (PredictorModelDifferencingWithNulls.java:79-105), then one histogram ----
             forcedZeros = 0;
             for (int i = tid; i < 3 * 256 * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
             int n = 0;
             uint32_t nM32 = 0;
             // B1  sort the used symbols by (count asc, symbol asc)
-            if (6ull * nCells < (1ull << 23)) {
+            if (FAST || 6ull * nCells < (1ull << 23)) {
                 // counts < 2^23: one 32-bit key (count << 8 | symbol) per symbol, 256 keys in 4 registers
                 // per lane (element e = r*64 + lane), bitonic network
                 uint32_t key[4];
@@ -960,7 +984,17 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (a.nTiles == 0) return hipSuccess;
     if (!a.packRecs) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
-    hipLaunchKernelGGL(k_huffman_encode, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    const size_t nCells = (size_t)a.nRows * (size_t)a.nCols;
+    if (a.retryFlag && 6ull * nCells < (1ull << 23)) {
+        const hipError_t e = hipMemsetAsync(a.retryFlag, 0, 4, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_huffman_encode<true>, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid < 2048 ? grid : 2048), dim3(ENC_THREADS), 0, stream, a);
+    } else {
+        GfEncodeArgs g = a;
+        g.retryFlag = nullptr;
+        hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid), dim3(ENC_THREADS), 0, stream, g);
+    }
     hipLaunchKernelGGL(k_huffman_pack, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
