@@ -62,9 +62,10 @@ def _compile_all(lib, extra, verbose):
         for s in _sources():
             obj = os.path.join(tmp, os.path.splitext(s)[0] + ".o")
             jobs.append(([hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", obj], obj))
-        # the legacy decoder once more with 512-thread workgroups (large tiles, see gvrs_decode.hip)
+        # the legacy decoder once more with 512-thread workgroups, one Huffman cursor per thread (tiles whose LDS footprint
+        # leaves room for at most two 256-thread workgroups per CU, see gvrs_decode.hip / decodeBatchDev)
         obj = os.path.join(tmp, "gvrs_decode_t512.o")
-        jobs.append(([hipcc] + FLAGS + extra + ["-DGF_DEC_THREADS=512", "-DGF_DEC_VARIANT", "-c",
+        jobs.append(([hipcc] + FLAGS + extra + ["-DGF_DEC_THREADS=512", "-DGF_DEC_VARIANT", "-DGF_DEC_MAXQ=512", "-c",
                                                  os.path.join(CSRC, "gvrs_decode.hip"), "-o", obj], obj))
         # a few compiles at a time: the translation units are independent
         width = max(1, min(4, (os.cpu_count() or 2) // 2))

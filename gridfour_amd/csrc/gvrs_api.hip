@@ -368,9 +368,12 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     } else {
         a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
-        // tiles whose M32 stream leaves LDS for ONE 256-thread workgroup per CU run with 512-thread workgroups (measured:
-        // 256x256 tiles 4.51 -> 2.85 ms; at two workgroups per CU -- 200x200 -- the 512-thread form is the slower one)
-        const bool big = (size_t)a.ldsM32Bytes + 4096 + 14336 > (160 * 1024) / 2;
+        // Occupancy is set by LDS (M32 stream + start bitmap + tables per workgroup).  Where fewer than three 256-thread
+        // workgroups fit a CU, the 512-thread build (one Huffman cursor per thread, twice the waves per tile) is the faster
+        // one: measured on 200x200 tiles (two workgroups per CU either way) 3.92 -> 2.89 ms for 11,664 tiles, on 256x256
+        // tiles 4.51 -> 2.85 ms; at four per CU (120x150) the 256-thread build wins (1.43 vs 1.84 ms).
+        const size_t ldsPerWg = (size_t)a.ldsM32Bytes + std::max<size_t>(2 * (((size_t)a.ldsM32Bytes >> 5) + 2) * 4, 4096) + 14336;
+        const bool big = (160 * 1024) / ldsPerWg < 3;
         if (big) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
         else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     }
