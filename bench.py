@@ -12,6 +12,8 @@ Workloads (BASELINE.json configs)
               (default: the configuration north_star's target is quoted on)
   dem1024     configs[1]: 1024 tiles of 200x200
   gebco_shard configs[3]: one eighth of the GEBCO-shaped grid = 11,664 tiles of 200x200 per GPU
+  float256    configs[4](i):  4,096 tiles of 256x256 float32, --codec float (CodecFloat)
+  float256_lsop configs[4](ii): the same floats as int-coded floats (scale 10), --codec lsop (LSOP12)
 
 Multi-GPU: tiles are independent, so every rank owns a contiguous tile range of the global
 grid and there is no data-path collective; per-GPU work is fixed (weak scaling).  The only
@@ -40,7 +42,10 @@ WORKLOADS = {
     "dem1024": (200, 200, 1024, 32, "1024-tile batch, 200x200 int32 synthetic DEM, all 3 predictors + Huffman"),
     "gebco_shard": (200, 200, 11664, 432, "1/8 shard of the GEBCO_2023-shaped 43200x86400 int32 grid, 200x200 tiles"),
     "float256": (256, 256, 4096, 64, "4096 tiles of 256x256 float32 (DEM x 0.1f), CodecFloat byte-plane stage"),
+    "float256_lsop": (256, 256, 4096, 64, "4096 tiles of 256x256 float32 (DEM x 0.1f) stored as int-coded floats "
+                                          "(scale 10, GvrsElementSpecificationIntCodedFloat), LSOP12"),
 }
+FP64_PEAK_TFLOPS = 78.6       # MI355X vector FP64 (the roof k_lsop_predict's normal equations are priced against)
 
 
 def parse_args():
@@ -266,6 +271,33 @@ def _verify_shard(args, batch, n_rows, n_cols, n_tiles, with_oracle):
     return ok, int(lengths.astype(np.int64).sum()), vals
 
 
+def _lsop_fp64_roofline(ctx, batch, n_rows, n_cols, n_tiles, reps):
+    """k_lsop_predict against the FP64 roof: the normal equations of LsOptimalPredictor12.computeCoefficients
+    (:335-342) are 91 multiply-adds + 13 adds = 195 FP64 flop per interior cell.  The kernel is launched on its own
+    (gf_lsop12_predict_dev, the first half of the encode) and timed with HIP events on the context's stream."""
+    from gridfour_amd import GpuTimer, lib
+    from gridfour_amd._lib import check
+    timers = [GpuTimer(ctx) for _ in range(reps)]
+
+    def launch():
+        check(lib().gf_lsop12_predict_dev(ctx.handle, None, n_rows, n_cols, n_tiles, batch.values.ptr, batch.residuals.ptr,
+                                          batch.res_stride, batch.coefs.ptr, batch.scratch_status.ptr), "gf_lsop12_predict_dev")
+    launch()
+    for t in timers:
+        t.start()
+        launch()
+        t.stop()
+    ctx.synchronize()
+    ms = float(np.mean([t.elapsed_ms() for t in timers]))
+    interior = (n_rows - 2) * (n_cols - 4)
+    flop = 195.0 * interior * n_tiles
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"bound": "fp64", "kernel": "k_lsop_predict", "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP64_PEAK_TFLOPS, 4), "flop_per_launch": int(flop), "avg_launch_ms": round(ms, 4),
+            "note": "195 FP64 flop per interior cell (91 multiply-adds + 13 adds); the kernel also computes the 23-flop FP32 "
+                    "prediction per cell, the 13x13 LU and the initialiser residuals inside the same launch"}
+
+
 def _effective_cores():
     """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that shows 256
     CPUs may be allowed 16 cores' worth of time -- threads beyond that only take turns)."""
@@ -297,7 +329,8 @@ def _cpu_baseline(args, vals, n_rows, n_cols, n_tiles):
     cells = n_rows * n_cols
     ns = args.cpu_sample_tiles
     if ns < 0:
-        ns = min(n_tiles, max(64, int(1200e6 / (4 * cells))))   # up to 1.2 GB of tiles: 9-20 s of CPU work on one core
+        budget = 1200e6 if args.codec == "huffman" else 400e6    # up to 1.2 GB of tiles: 9-20 s of CPU work on one core
+        ns = min(n_tiles, max(64, int(budget / (4 * cells))))
     if ns <= 0:
         return None
     sub = vals[:ns]
@@ -403,6 +436,8 @@ def main():
     cells = n_rows * n_cols
     if (args.codec == "float") != (args.workload == "float256"):
         raise SystemExit("--codec float goes with --workload float256 (and only with it)")
+    if args.workload == "float256_lsop" and args.codec != "lsop":
+        raise SystemExit("--workload float256_lsop is the int-coded-float + LSOP12 configuration: use --codec lsop")
     if single_multi and args.codec != "huffman":
         raise SystemExit("the single-process multi-GPU mode runs the north-star codec (CodecHuffman); use a launcher for the others")
     if args.codec == "float":
@@ -418,13 +453,20 @@ def main():
     else:
         ctxs = [gridfour_amd.GvrsHipContext(local_rank)]
     stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
-    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3}[args.workload]
+    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3, "float256_lsop": 5}[args.workload]
     batches = []
     for g, ctx in enumerate(ctxs):
         b = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
         # shard s owns the contiguous tile range starting at s * n_tiles of the global grid (weak scaling)
         b.synth_dem(seed, tiles_per_row, tile0=(g if single_multi else rank) * n_tiles)
         ctx.synchronize()
+        if args.workload == "float256_lsop":
+            # config 5(ii): the float tiles of config 5(i) (DEM x 0.1f) as the reference stores them in an int-coded-float
+            # element: i = (int) Math.floor((f - offset) * scale + 0.5), float product then double sum, with scale 10 and
+            # offset 0 (GvrsElementIntCodedFloat.java:205); prepared once on the host, outside the timed region
+            f = b.get_values().astype(np.float32) * np.float32(0.1)
+            b.values.upload(np.floor((f * np.float32(10.0)).astype(np.float64) + 0.5).astype(np.int32))
+            del f
         batches.append(b)
 
     # one HIP-event pair per timed step, kernel group and device, recorded on the stream the kernels run on and read only
@@ -572,6 +614,8 @@ def main():
         "cpu_baseline": cpu_baseline,
         "host_path": host_path,
     }
+    if args.codec == "lsop":
+        out["roofline_fp64"] = _lsop_fp64_roofline(ctxs[0], batches[0], n_rows, n_cols, n_tiles, max(3, min(steps, 10)))
     print(json.dumps(out))
     if launcher:
         dist.destroy_process_group()

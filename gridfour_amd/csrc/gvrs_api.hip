@@ -51,6 +51,14 @@ gf_status hipFail(hipError_t e, const char *what)
 
 size_t roundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// offsets[nTiles + 1] of a caller's blob: non-decreasing, every packing shorter than 4 GiB (lengths travel as uint32)
+bool offsetsValid(const uint64_t *offsets, size_t nTiles)
+{
+    for (size_t t = 0; t < nTiles; t++)
+        if (offsets[t + 1] < offsets[t] || offsets[t + 1] - offsets[t] > 0xFFFFFFFFull) return false;
+    return true;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -1500,6 +1508,7 @@ gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t
                                      const uint64_t *offsets, int32_t *values, int32_t *status)
 {
     if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     GF_HIP(hipSetDevice(c->device));
     if (nRows < 6 || nCols < 6) {
         for (size_t t = 0; t < nTiles && status; t++) status[t] = GF_ERR_BOUNDS;
@@ -1895,6 +1904,7 @@ gf_status gf_codec_master_decode_batch_i32(gf_context *c, const int *codecs, int
                                            const uint8_t *blob, const uint64_t *offsets, int32_t *values, int32_t *status)
 {
     if (!c || !codecs || nCodecs < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
+    if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     const size_t cells = (size_t)nRows * (size_t)nCols;
     std::vector<int32_t> st(nTiles, GF_ERR_FORMAT);
     for (int k = 0; k < nCodecs; k++) {
@@ -1980,6 +1990,7 @@ gf_status gf_tile_payload_decode_batch_i32(gf_context *c, const int *codecs, int
                                            const uint8_t *blob, const uint64_t *offsets, int32_t *values, int32_t *status)
 {
     if (!c || !blob || !offsets || !values) return GF_ERR_ARG;
+    if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     const size_t cells = (size_t)nRows * (size_t)nCols, rawBytes = cells * 4;
     std::vector<uint64_t> off(nTiles + 1, 0);
     std::vector<uint8_t> sub;
@@ -2119,6 +2130,7 @@ gf_status gf_tile_record_decode_batch(gf_context *c, const int *codecs, int nCod
                                       int32_t *tileIndices, void *values, int32_t *status)
 {
     if (!c || !blob || !offsets || !values) return GF_ERR_ARG;
+    if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     if (elemType != GF_ELEM_INT && elemType != GF_ELEM_SHORT) return GF_ERR_ARG;
     if (nRows < 1 || nCols < 1) return GF_ERR_ARG;
     const size_t cells = (size_t)nRows * (size_t)nCols, stdSize = elemStandardSize(elemType, cells);
@@ -2195,6 +2207,7 @@ gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t n
                                    gf_codec_stats *stats, int32_t *status)
 {
     if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !stats) return GF_ERR_ARG;
+    if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     GF_HIP(hipSetDevice(c->device));
     const uint64_t total = offsets[nTiles];
     gf_status s;

@@ -288,3 +288,31 @@ def test_device_batch_dem_roundtrip():
     for x in (dres, dco, dsc):
         x.free()
     b.free()
+
+
+def test_config5ii_int_coded_float_256x256():
+    """BASELINE config 5(ii): 256x256 float elevation tiles stored as int-coded floats (scale 10,
+    GvrsElementIntCodedFloat.java:205: (int) Math.floor((f - offset) * scale + 0.5)) through LSOP12, device-resident:
+    every packing equals the oracle's on a sample, every tile survives the round trip."""
+    import gridfour_amd
+    ctx = gridfour_amd.GvrsHipContext(0)
+    nr, nc, nt = 256, 256, 96
+    b = gridfour_amd.DeviceTileBatch(ctx, nr, nc, nt, codec="lsop")
+    b.synth_dem(0x9E3779B97F4A7C15 + 5, 8)
+    ctx.synchronize()
+    f = b.get_values().astype(np.float32) * np.float32(0.1)
+    coded = np.floor((f * np.float32(10.0)).astype(np.float64) + 0.5).astype(np.int32)
+    # a block of larger jitter in some tiles so that the residual streams are not all one-byte codes
+    rng = np.random.default_rng(5)
+    coded[::7, 1000:30000] += rng.integers(-400, 400, 29000).astype(np.int32)
+    b.values.upload(coded)
+    b.encode(codec_index=3)
+    b.decode()
+    ctx.synchronize()
+    assert np.all(b.get_enc_status() == 0) and np.all(b.get_dec_status() == 0)
+    assert np.array_equal(b.get_decoded(), coded)
+    lengths = b.get_lengths()
+    for t in range(0, nt, 5):
+        ref, typ = oracle.lsop12_encode(3, nr, nc, coded[t], False)
+        assert typ == 2 and b.get_packing(t, int(lengths[t])) == ref, t
+    b.free()

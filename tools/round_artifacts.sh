@@ -9,7 +9,11 @@ mkdir -p $OUT
 timeout 1200 python3 -m pytest tests -m gpu -q -rs > $OUT/pytest_gpu.txt 2>&1; tail -5 $OUT/pytest_gpu.txt
 timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
 timeout 600 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench.json
-timeout 600 python3 bench.py --cpu-all-cores 2>/dev/null | tail -1 > $OUT/bench_allcores.json
+timeout 900 python3 tools/host_path_rate.py etopo1 2>/dev/null | tail -1 > $OUT/host_path_etopo1.json
+timeout 900 python3 tools/host_path_rate.py etopo1 2 2>/dev/null | tail -1 > $OUT/host_path_etopo1_multi2.json
+timeout 900 python3 tools/host_path_rate.py gebco_full 2>/dev/null | tail -1 > $OUT/host_path_gebco_full.json
+timeout 900 python3 tools/float_host_rate.py 4096 6 2>/dev/null | tail -1 > $OUT/float_host_path.json
+GF_BENCH_SHARE_GPU=1 timeout 600 python3 bench.py --gpus 2 --cpu-sample-tiles 0 2>/dev/null | tail -1 > $OUT/bench_single_process_2shards_one_gpu.json
 timeout 600 python3 bench.py --codec canon 2>/dev/null | tail -1 > $OUT/bench_canon.json
 timeout 600 python3 bench.py --codec lsop 2>/dev/null | tail -1 > $OUT/bench_lsop.json
 timeout 600 python3 bench.py --workload dem1024 2>/dev/null | tail -1 > $OUT/bench_dem1024.json
