@@ -759,65 +759,68 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs
 }
 
 
-// The same reconstruction with the wavefront's working set in LDS.  A wave owns a tile and walks it in bands of 64
-// rows, one lane per row; lane l is 3 columns behind lane l-1.  Every row keeps its last 16 values in an LDS ring
-// (the rows below read columns c-2..c+2 of the two rows above: at most 8 columns back); the two rows above a band come
-// from full-row LDS buffers that the last two lanes of the previous band filled.  Global memory sees only 16-byte
-// residual loads and 16-byte value stores per lane (one 4-byte access per lane and step is L2-request bound).
-__global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
+// The same reconstruction, one tile per 64-thread workgroup, for global memory that only ever sees whole-row pieces.
+//
+// A wave walks the tile in bands of 64 rows, one lane per row; lane l is 3 columns behind lane l-1 (step s: lane l works
+// on column c = s - 3 l, columns 0 and 1 included: there the "computed" value is the border value, so that every row
+// looks the same to the row below).
+//
+//   * the neighbourhood lives in registers: a lane keeps columns c-2..c+2 of the row above (A) and of the row two above
+//     (B) as two 5-register windows that shift by one per step.  The value entering A is what lane l-1 produced in the
+//     previous step, the value entering B is the middle of lane l-1's own A window -- both arrive with one DPP
+//     wave_shr:1 each; lane 0 takes them from the full-row LDS buffers that lanes 62 / 63 of the previous band filled.
+//   * residuals come in and values go out through one LDS staging ring per row (64 slots, slot = s & 63, a value
+//     overwrites the residual it was made from).  The ring is filled and drained a 32-step ROUND at a time and 16 rows
+//     per 8 steps, cooperatively: a half-wave moves the 32 consecutive residuals / values of one row (128 contiguous
+//     bytes of global memory) per instruction.  Residuals of round R+1 are requested while round R runs and land in the
+//     slots that round R-1's values have just left.
+__device__ __forceinline__ uint32_t lsop_from_lane_above(uint32_t lane0Value, uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0Value, (int)x, 0x138, 0xf, 0xf, false);   // wave_shr:1
+}
+
+__global__ __launch_bounds__(64) void k_lsop_reconstruct(GfLsopReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t reconLds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t wavesPerGrid = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + wave;
+    constexpr uint32_t RS = 65;                            // words per staging ring (64 slots + 1: conflict-free columns)
+    const int lane = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t nInit = lsop_n_init(nR, nC);
-    const uint32_t wI = nC - 4u, nInt = lsop_n_interior(nR, nC);
-    const uint32_t perWave = 64u * 16u + 4u * nC;
-    uint32_t *L = reconLds + (size_t)wave * perWave;
-    const uint32_t RING = 0, ROWS = 64u * 16u;            // word offsets inside L
+    const uint32_t wI = nC - 4u;
+    uint32_t *stage = reconLds;                            // [64][RS]
+    uint32_t *rows = reconLds + 64u * RS;                  // 4 full rows
+    const uint32_t half = (uint32_t)lane >> 5, j32 = (uint32_t)lane & 31u;
 
-    for (size_t t = wid; t < a.nTiles; t += wavesPerGrid) {
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
         if (a.inStatus && a.inStatus[t] != GF_K_OK) {
             if (lane == 0) a.status[t] = a.inStatus[t];
             continue;
         }
         const int32_t *__restrict__ res = a.residuals + t * a.resStride;
         const int32_t *__restrict__ inter = res + nInit;
-        int32_t *v = a.values + t * (size_t)nCells;
+        int32_t *__restrict__ v = a.values + t * (size_t)nCells;
         const uint32_t *cf = a.coefs + t * 16;
         const uint32_t seed = cf[0];
         float u[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) u[i] = __uint_as_float(cf[1 + i]);
-        uint32_t prev0 = ROWS, prev1 = ROWS + nC, next0 = ROWS + 2u * nC, next1 = ROWS + 3u * nC;   // row buffers (offsets)
+        uint32_t prev0 = 0, prev1 = nC, next0 = 2u * nC, next1 = 3u * nC;      // row buffers (offsets into rows[])
 
-        // border cells as prefix sums (LsDecoder12.unpackInitializers :186-221); rows 0 and 1 also go to prev0 / prev1
+        // rows 0 and 1 as prefix sums (LsDecoder12.unpackInitializers :186-221): to global memory and to prev0 / prev1
         {
             uint32_t carry = seed;
-            if (lane == 0) { v[0] = (int32_t)seed; L[prev0] = seed; }
+            if (lane == 0) { v[0] = (int32_t)seed; rows[prev0] = seed; }
             for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
                 const uint32_t c = c0 + lane;
                 const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
-                if (c < nC) { v[c] = (int32_t)incl; L[prev0 + c] = incl; }
+                if (c < nC) { v[c] = (int32_t)incl; rows[prev0 + c] = incl; }
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
-        uint32_t v10 = 0;                                  // v[1][0]
-        {
-            uint32_t carry = seed;
-            for (uint32_t r0 = 1; r0 < nR; r0 += 64) {
-                const uint32_t r = r0 + lane;
-                const uint32_t x = r < nR ? (uint32_t)res[nC - 1 + r - 1] : 0u;
-                const uint32_t incl = gf_wave_incl_scan(x) + carry;
-                if (r < nR) v[(size_t)r * nC] = (int32_t)incl;
-                if (r0 == 1) v10 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 0);
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-        }
-        if (lane == 0) L[prev1] = v10;
-        __builtin_amdgcn_wave_barrier();
-        uint32_t v11 = 0;                                  // v[1][1]
+        const uint32_t v10 = seed + (uint32_t)res[nC - 1u];                    // v[1][0]
+        if (lane == 0) { v[nC] = (int32_t)v10; rows[prev1] = v10; }
+        uint32_t v11 = 0;                                                      // v[1][1]
         {
             uint32_t carry = v10 - seed;
             const uint32_t base = nC - 1u + nR - 1u;
@@ -825,84 +828,97 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
                 const uint32_t c = c0 + lane;
                 const uint32_t x = c < nC ? (uint32_t)res[base + c - 1] : 0u;
                 const uint32_t incl = gf_wave_incl_scan(x) + carry;
-                const uint32_t val = incl + (c < nC ? L[prev0 + c] : 0u);
-                if (c < nC) { v[nC + c] = (int32_t)val; L[prev1 + c] = val; }
+                const uint32_t val = incl + (c < nC ? rows[prev0 + c] : 0u);
+                if (c < nC) { v[nC + c] = (int32_t)val; rows[prev1 + c] = val; }
                 if (c0 == 1) v11 = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // column 0 is read back below
-        __builtin_amdgcn_wave_barrier();
-        {
-            uint32_t carry = v11 - v10;
-            const uint32_t base = 2u * (nC - 1u) + nR - 1u;
-            for (uint32_t r0 = 2; r0 < nR; r0 += 64) {
-                const uint32_t r = r0 + lane;
-                const uint32_t x = r < nR ? (uint32_t)res[base + r - 2] : 0u;
-                const uint32_t incl = gf_wave_incl_scan(x) + carry;
-                if (r < nR) v[(size_t)r * nC + 1] = (int32_t)(incl + (uint32_t)v[(size_t)r * nC]);
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        // columns 0 and 1 of the rows below are running sums too; they are carried from band to band
+        uint32_t carry0 = v10, carry1 = v11 - v10;
+        const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
 
-        // interior and the last two columns (LsDecoder12.unpackInterior :311-383): bands of 64 rows, step = c + 3 * lane
-        const uint32_t tailBase = 2u * (nC - 1u) + nR - 1u + nR - 2u;
         for (uint32_t r0 = 2; r0 < nR; r0 += 64) {
             const uint32_t r = r0 + lane;
             const bool rowValid = r < nR;
-            // where this lane finds the row above (A) and the row two above (B): a ring (mask 15) or a full-row buffer
-            uint32_t baseA, maskA, baseB, maskB;
-            if (lane == 0) { baseA = prev1; maskA = 0xFFFFFFFFu; baseB = prev0; maskB = 0xFFFFFFFFu; }
-            else if (lane == 1) { baseA = RING; maskA = 15u; baseB = prev1; maskB = 0xFFFFFFFFu; }
-            else { baseA = RING + (uint32_t)(lane - 1) * 16u; maskA = 15u; baseB = RING + (uint32_t)(lane - 2) * 16u; maskB = 15u; }
-            const uint32_t own = RING + (uint32_t)lane * 16u;
-            const bool feeds = lane >= 62;                         // rows r0+62, r0+63 are the next band's rows above
-            const uint32_t feedBase = lane == 62 ? next0 : next1;
-            uint32_t z6 = 0, z1 = 0, t0 = 0, t1 = 0;
-            GfU4 cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
-            const uint32_t rowRes = rowValid ? (r - 2u) * wI : 0u;
-            auto loadQuad = [&](uint32_t e) -> GfU4 {              // residuals e .. e+3 of this row (zeros past the stream)
-                GfU4 q = {0, 0, 0, 0};
-                if (rowValid && e < wI) {
-                    const uint32_t i = rowRes + e;
-                    if (i + 3u < nInt) q = *reinterpret_cast<const GfU4 *>(inter + i);
-                    else {
-                        q.x = (uint32_t)inter[i];
-                        if (i + 1u < nInt) q.y = (uint32_t)inter[i + 1];
-                        if (i + 2u < nInt) q.z = (uint32_t)inter[i + 2];
-                    }
+            const uint32_t nBand = min(64u, nR - r0);
+            uint32_t colv0, colv1, t0 = 0, t1 = 0;
+            {
+                const uint32_t x0 = rowValid ? (uint32_t)res[base0 + r - 1u] : 0u;
+                const uint32_t i0 = gf_wave_incl_scan(x0) + carry0;
+                carry0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+                const uint32_t x1 = rowValid ? (uint32_t)res[base1 + r - 2u] : 0u;
+                const uint32_t i1 = gf_wave_incl_scan(x1) + carry1;
+                carry1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+                colv0 = i0;
+                colv1 = i1 + i0;
+                if (rowValid) {
+                    t0 = (uint32_t)res[tailBase + 2u * (r - 2u)];
+                    t1 = (uint32_t)res[tailBase + 2u * (r - 2u) + 1u];
                 }
-                return q;
-            };
-            if (rowValid) {
-                z6 = (uint32_t)v[(size_t)r * nC];
-                z1 = (uint32_t)v[(size_t)r * nC + 1];
-                t0 = (uint32_t)res[tailBase + 2u * (r - 2u)];
-                t1 = (uint32_t)res[tailBase + 2u * (r - 2u) + 1u];
-                L[own + 0] = z6;
-                L[own + 1] = z1;
-                if (feeds) { L[feedBase] = z6; L[feedBase + 1] = z1; }
             }
-            cur = loadQuad(0);
-            nxt = loadQuad(4);
-            uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t rLast = min(r0 + 63u, nR - 1u);
-            const uint32_t sBeg = 3u * 0u + 2u, sEnd = 3u * (rLast - r0) + nC - 1u;        // step = c + 3 * lane
-            for (uint32_t s = sBeg; s <= sEnd; s++) {
-                const int32_t ci = (int32_t)s - 3 * lane;
-                if (rowValid && ci >= 2 && ci <= (int32_t)nC - 1) {
-                    const uint32_t c = (uint32_t)ci;
-                    uint32_t val;
-                    if (c <= nC - 3u) {
-                        const uint32_t a0 = L[baseA + ((c - 2u) & maskA)], a1 = L[baseA + ((c - 1u) & maskA)],
-                                       a2 = L[baseA + (c & maskA)], a3 = L[baseA + ((c + 1u) & maskA)],
-                                       a4 = L[baseA + ((c + 2u) & maskA)];
-                        const uint32_t b0 = L[baseB + ((c - 2u) & maskB)], b1 = L[baseB + ((c - 1u) & maskB)],
-                                       b2 = L[baseB + (c & maskB)], b3 = L[baseB + ((c + 1u) & maskB)],
-                                       b4 = L[baseB + ((c + 2u) & maskB)];
+            const bool feeds = lane >= 62;                                     // rows r0+62, r0+63 are the next band's rows above
+            const uint32_t feedBase = lane == 62 ? next0 : next1;
+            const uint32_t sEnd = 3u * (nBand - 1u) + nC - 1u;
+
+            // cooperative piece k of a 16-row group: row = rowBase + 2k + half, the 32 steps of `round`
+            auto pieceLoad = [&](uint32_t round, uint32_t row) -> uint32_t {   // the residual that (row, step) will consume
+                const int32_t e = (int32_t)(round * 32u + j32) - 3 * (int32_t)row - 2;
+                uint32_t x = 0;
+                if (row < nBand && e >= 0 && e < (int32_t)wI) x = (uint32_t)inter[(size_t)(r0 + row - 2u) * wI + (uint32_t)e];
+                return x;
+            };
+            auto pieceSlot = [&](uint32_t round, uint32_t row) -> uint32_t { return row * RS + ((round & 1u) * 32u + j32); };
+            auto pieceStore = [&](uint32_t round, uint32_t row) {              // the value that (row, step) produced
+                const int32_t c = (int32_t)(round * 32u + j32) - 3 * (int32_t)row;
+                if (row < nBand && c >= 0 && c < (int32_t)nC) v[(size_t)(r0 + row) * nC + (uint32_t)c] = (int32_t)stage[pieceSlot(round, row)];
+            };
+
+            // round 0 is loaded up front
+#pragma unroll 4
+            for (uint32_t k = 0; k < 32; k++) {
+                const uint32_t row = 2u * k + half;
+                stage[pieceSlot(0, row)] = pieceLoad(0, row);
+            }
+
+            // lane 0 starts at column 0 with no steps before it: columns 0 and 1 of the rows above are put into its windows
+            // here (a lane further down starts at column -3 l and has picked them up by the time it reaches column 0)
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = rows[prev1], a4 = rows[prev1 + 1u];
+            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = rows[prev0], b4 = rows[prev0 + 1u], z1 = 0, z6 = 0;
+            uint32_t ld[8];
+            bool pending = false;
+            uint32_t pendRound = 0, pendRow = 0;
+            const uint32_t nRounds = sEnd / 32u + 1u;
+            for (uint32_t round = 0; round < nRounds; round++) {
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t rowBase = 16u * q;
+                    if (pending) {                                             // requested 8 steps ago
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; k++) stage[pieceSlot(pendRound, pendRow + 2u * k + half)] = ld[k];
+                        pending = false;
+                    }
+                    if (round >= 1u) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; k++) pieceStore(round - 1u, rowBase + 2u * k + half);
+                    }
+                    if (round + 1u < nRounds) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; k++) ld[k] = pieceLoad(round + 1u, rowBase + 2u * k + half);
+                        pending = true;
+                        pendRound = round + 1u;
+                        pendRow = rowBase;
+                    }
+                    const uint32_t sFirst = round * 32u + q * 8u;
+                    for (uint32_t s = sFirst; s < sFirst + 8u && s <= sEnd; s++) {
+                        const int32_t c = (int32_t)s - 3 * lane;
+                        // what enters the two windows: column c + 2 of the row above and of the row two above
+                        const uint32_t cc = min(s + 2u, nC - 1u);
+                        const uint32_t na = lsop_from_lane_above(rows[prev1 + cc], z1);
+                        const uint32_t nb = lsop_from_lane_above(rows[prev0 + cc], a2);
+                        a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = na;
+                        b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = nb;
+                        const uint32_t slot = (uint32_t)lane * RS + (s & 63u);
+                        const uint32_t rs = stage[slot];
                         float p = u[0] * (float)(int32_t)z1;
                         p = p + u[1] * (float)(int32_t)a1;
                         p = p + u[2] * (float)(int32_t)a2;
@@ -915,39 +931,27 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct(GfLsopReconArgs a)
                         p = p + u[9] * (float)(int32_t)b2;
                         p = p + u[10] * (float)(int32_t)b3;
                         p = p + u[11] * (float)(int32_t)b4;
-                        const uint32_t e = c - 2u, sl = e & 3u;
-                        const uint32_t rs = sl == 0u ? cur.x : sl == 1u ? cur.y : sl == 2u ? cur.z : cur.w;
-                        val = (uint32_t)lsop_round(p) + rs;
-                        if (sl == 3u) { cur = nxt; nxt = loadQuad(e + 5u); }
-                    } else {
-                        const uint32_t a1 = L[baseA + ((c - 1u) & maskA)], a2 = L[baseA + (c & maskA)];
-                        val = (c == nC - 2u ? t0 : t1) + (z1 + a2 - a1);
-                    }
-                    L[own + (c & 15u)] = val;
-                    if (feeds) L[feedBase + c] = val;
-                    z6 = z1;
-                    z1 = val;
-                    const uint32_t sl = (c - 2u) & 3u;
-                    o0 = sl == 0u ? val : o0;
-                    o1 = sl == 1u ? val : o1;
-                    o2 = sl == 2u ? val : o2;
-                    o3 = sl == 3u ? val : o3;
-                    int32_t *dst = v + (size_t)r * nC + (c - sl);
-                    if (sl == 3u) {
-                        GfU4 q;
-                        q.x = o0; q.y = o1; q.z = o2; q.w = o3;
-                        *reinterpret_cast<GfU4 *>(dst) = q;
-                    } else if (c == nC - 1u) {                     // row end: flush the partial group
-                        dst[0] = (int32_t)o0;
-                        if (sl >= 1u) dst[1] = (int32_t)o1;
-                        if (sl >= 2u) dst[2] = (int32_t)o2;
+                        const uint32_t interior = (uint32_t)lsop_round(p) + rs;                       // LsDecoder12 :311-351
+                        const uint32_t tail = (c == (int32_t)nC - 2 ? t0 : t1) + (z1 + a2 - a1);      // :353-383
+                        const uint32_t border = c == 0 ? colv0 : colv1;
+                        const uint32_t val = c < 2 ? border : (c <= (int32_t)nC - 3 ? interior : tail);
+                        if (rowValid && c >= 0 && c < (int32_t)nC) {
+                            stage[slot] = val;
+                            if (feeds) rows[feedBase + (uint32_t)c] = val;
+                            z6 = z1;
+                            z1 = val;
+                        }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
             }
+            if (pending) {                                                     // (nothing is pending after the last round)
+                pending = false;
+            }
+            // the last round's values
+#pragma unroll 4
+            for (uint32_t k = 0; k < 32; k++) pieceStore(nRounds - 1u, 2u * k + half);
             const uint32_t q0 = prev0, q1 = prev1;
             prev0 = next0; prev1 = next1; next0 = q0; next1 = q1;
-            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) a.status[t] = GF_K_OK;
     }
@@ -986,15 +990,16 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
 {
     if (nTiles == 0) return hipSuccess;
     GfLsopReconArgs a{residuals, resStride, coefs, inStatus, values, status, nTiles, nRows, nCols};
-    const size_t wgs = (nTiles + 3) / 4;
-    const unsigned grid = (unsigned)(wgs < 65536 * 16 ? wgs : 65536 * 16);
-    const size_t dyn = (size_t)4 * (64 * 16 + 4 * (size_t)nCols) * 4;      // per wave: 64 rings of 16 + 4 row buffers
+    const size_t dyn = (64 * 65 + 4 * (size_t)nCols) * 4;                  // 64 staging rings + 4 row buffers
     if (dyn <= 96 * 1024) {
         static GfDynLdsOptIn opt;
         const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct, dyn, opt);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_lsop_reconstruct, dim3(grid), dim3(256), dyn, stream, a);
+        const unsigned grid = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
+        hipLaunchKernelGGL(k_lsop_reconstruct, dim3(grid), dim3(64), dyn, stream, a);
     } else {
+        const size_t wgs = (nTiles + 3) / 4;
+        const unsigned grid = (unsigned)(wgs < 65536 * 16 ? wgs : 65536 * 16);
         hipLaunchKernelGGL(k_lsop_reconstruct_global, dim3(grid), dim3(256), 0, stream, a);   // very wide tiles
     }
     return hipGetLastError();
