@@ -142,6 +142,9 @@ def _diag():
 
 
 def lib_path():
+    variant = os.environ.get("GVRS_HIP_VARIANT", "")          # tools/ only: an experiment build made by build.py --variant
+    if variant:
+        return _build.variant_path(variant)
     return _build.LIB_DIAG if _diag() else _build.LIB
 
 
@@ -152,7 +155,7 @@ def lib():
     global _lib
     if _lib is None:
         path = lib_path()
-        if _build.needs_build(path):
+        if not os.environ.get("GVRS_HIP_VARIANT") and _build.needs_build(path):
             _build.build(diag=_diag())
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():

@@ -96,9 +96,14 @@ def _compile_all(lib, extra, verbose):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def build(force=False, verbose=False, diag=False):
-    """Compiles every HIP source for gfx950 and links gridfour_amd/lib/libgvrs_hip[_diag].so."""
-    lib = LIB_DIAG if diag else LIB
+def variant_path(name):
+    return os.path.join(LIBDIR, "libgvrs_hip_%s.so" % name)
+
+
+def build(force=False, verbose=False, diag=False, variant=None, variant_flags=()):
+    """Compiles every HIP source for gfx950 and links gridfour_amd/lib/libgvrs_hip[_diag].so.
+    variant / variant_flags (tools/ only): an experiment build libgvrs_hip_<variant>.so with extra compiler flags."""
+    lib = variant_path(variant) if variant else (LIB_DIAG if diag else LIB)
     if not force and not needs_build(lib):
         return lib
     os.makedirs(LIBDIR, exist_ok=True)
@@ -107,7 +112,7 @@ def build(force=False, verbose=False, diag=False):
         try:
             # another process may have finished the same build while this one waited for the lock
             if force or needs_build(lib):
-                _compile_all(lib, ["-DGF_DIAG"] if diag else [], verbose)
+                _compile_all(lib, (["-DGF_DIAG"] if diag else []) + list(variant_flags), verbose)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return lib
@@ -115,4 +120,8 @@ def build(force=False, verbose=False, diag=False):
 
 if __name__ == "__main__":
     import sys
-    print(build(force=True, verbose=True, diag="--diag" in sys.argv))
+    if "--variant" in sys.argv:            # python -m gridfour_amd.build --variant NAME -DFLAG ...
+        i = sys.argv.index("--variant")
+        print(build(force=True, verbose=True, diag="--diag" in sys.argv, variant=sys.argv[i + 1], variant_flags=sys.argv[i + 2:]))
+    else:
+        print(build(force=True, verbose=True, diag="--diag" in sys.argv))

@@ -46,6 +46,15 @@ __device__ __forceinline__ int32_t lsop_round(float p)
     return (int32_t)f;
 }
 
+// the same value without branches: v_cvt_i32_f64 saturates and turns NaN into 0 by itself
+__device__ __forceinline__ int32_t lsop_round_sat(float p)
+{
+    const double f = floor((double)p + 0.5);
+    int32_t r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
 // u1*z1 + ... + u12*z12 in float32, left to right (LsOptimalPredictor12.java:254-267)
 __device__ __forceinline__ float lsop_predict12(const float *u, const int32_t *v, uint32_t idx, uint32_t nC)
 {
@@ -779,17 +788,28 @@ __device__ __forceinline__ uint32_t lsop_from_lane_above(uint32_t lane0Value, ui
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0Value, (int)x, 0x138, 0xf, 0xf, false);   // wave_shr:1
 }
 
-__global__ __launch_bounds__(64) void k_lsop_reconstruct(GfLsopReconArgs a)
+#ifndef RECON_WAVES_PER_SIMD
+#define RECON_WAVES_PER_SIMD 4
+#endif
+#ifndef RECON_ROUND
+#define RECON_ROUND 16
+#endif
+template <int ROUND>
+__global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct(GfLsopReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t reconLds[];
-    constexpr uint32_t RS = 65;                            // words per staging ring (64 slots + 1: conflict-free columns)
+    constexpr uint32_t RING = 2u * ROUND;                  // slots per staging ring: two rounds
+    constexpr uint32_t RS = RING + 1u;                     // words per ring (+1: the lanes of a step hit different banks)
+    constexpr uint32_t RPI = 64u / ROUND;                  // rows per cooperative instruction
+    constexpr uint32_t SUBS = ROUND / 8u;                  // 8-step sub-rounds per round
+    constexpr uint32_t SUBROWS = 64u / SUBS;               // rows staged per sub-round
     const int lane = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t nInit = lsop_n_init(nR, nC);
     const uint32_t wI = nC - 4u;
     uint32_t *stage = reconLds;                            // [64][RS]
-    uint32_t *rows = reconLds + 64u * RS;                  // 4 full rows
-    const uint32_t half = (uint32_t)lane >> 5, j32 = (uint32_t)lane & 31u;
+    uint32_t *rows = reconLds + 64u * RS;                  // 2 full rows: the two rows above the band
+    const uint32_t half = (uint32_t)lane / ROUND, j32 = (uint32_t)lane % ROUND;     // row within the instruction, step within the round
 
     for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
         if (a.inStatus && a.inStatus[t] != GF_K_OK) {
@@ -804,7 +824,9 @@ __global__ __launch_bounds__(64) void k_lsop_reconstruct(GfLsopReconArgs a)
         float u[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) u[i] = __uint_as_float(cf[1 + i]);
-        uint32_t prev0 = 0, prev1 = nC, next0 = 2u * nC, next1 = 3u * nC;      // row buffers (offsets into rows[])
+        // the two rows above the band (offsets into rows[]).  Lanes 62 / 63 write the rows above the NEXT band into the same
+        // buffers: they are 186 / 189 columns behind lane 0, which reads (ahead of its own column) what they overwrite later
+        const uint32_t prev0 = 0, prev1 = nC;
 
         // rows 0 and 1 as prefix sums (LsDecoder12.unpackInitializers :186-221): to global memory and to prev0 / prev1
         {
@@ -858,26 +880,26 @@ __global__ __launch_bounds__(64) void k_lsop_reconstruct(GfLsopReconArgs a)
                 }
             }
             const bool feeds = lane >= 62;                                     // rows r0+62, r0+63 are the next band's rows above
-            const uint32_t feedBase = lane == 62 ? next0 : next1;
+            const uint32_t feedBase = lane == 62 ? prev0 : prev1;
             const uint32_t sEnd = 3u * (nBand - 1u) + nC - 1u;
 
-            // cooperative piece k of a 16-row group: row = rowBase + 2k + half, the 32 steps of `round`
+            // cooperative piece k of a group of rows: row = rowBase + RPI k + half, the ROUND steps of `round`
             auto pieceLoad = [&](uint32_t round, uint32_t row) -> uint32_t {   // the residual that (row, step) will consume
-                const int32_t e = (int32_t)(round * 32u + j32) - 3 * (int32_t)row - 2;
+                const int32_t e = (int32_t)(round * ROUND + j32) - 3 * (int32_t)row - 2;
                 uint32_t x = 0;
                 if (row < nBand && e >= 0 && e < (int32_t)wI) x = (uint32_t)inter[(size_t)(r0 + row - 2u) * wI + (uint32_t)e];
                 return x;
             };
-            auto pieceSlot = [&](uint32_t round, uint32_t row) -> uint32_t { return row * RS + ((round & 1u) * 32u + j32); };
+            auto pieceSlot = [&](uint32_t round, uint32_t row) -> uint32_t { return row * RS + ((round & 1u) * ROUND + j32); };
             auto pieceStore = [&](uint32_t round, uint32_t row) {              // the value that (row, step) produced
-                const int32_t c = (int32_t)(round * 32u + j32) - 3 * (int32_t)row;
+                const int32_t c = (int32_t)(round * ROUND + j32) - 3 * (int32_t)row;
                 if (row < nBand && c >= 0 && c < (int32_t)nC) v[(size_t)(r0 + row) * nC + (uint32_t)c] = (int32_t)stage[pieceSlot(round, row)];
             };
 
             // round 0 is loaded up front
 #pragma unroll 4
-            for (uint32_t k = 0; k < 32; k++) {
-                const uint32_t row = 2u * k + half;
+            for (uint32_t k = 0; k < ROUND; k++) {
+                const uint32_t row = RPI * k + half;
                 stage[pieceSlot(0, row)] = pieceLoad(0, row);
             }
 
@@ -888,37 +910,50 @@ __global__ __launch_bounds__(64) void k_lsop_reconstruct(GfLsopReconArgs a)
             uint32_t ld[8];
             bool pending = false;
             uint32_t pendRound = 0, pendRow = 0;
-            const uint32_t nRounds = sEnd / 32u + 1u;
+            const uint32_t nRounds = sEnd / ROUND + 1u;
             for (uint32_t round = 0; round < nRounds; round++) {
-                for (uint32_t q = 0; q < 4; q++) {
-                    const uint32_t rowBase = 16u * q;
+                for (uint32_t q = 0; q < SUBS; q++) {
+                    const uint32_t rowBase = SUBROWS * q;
                     if (pending) {                                             // requested 8 steps ago
 #pragma unroll
-                        for (uint32_t k = 0; k < 8; k++) stage[pieceSlot(pendRound, pendRow + 2u * k + half)] = ld[k];
+                        for (uint32_t k = 0; k < 8; k++) stage[pieceSlot(pendRound, pendRow + RPI * k + half)] = ld[k];
                         pending = false;
                     }
                     if (round >= 1u) {
 #pragma unroll
-                        for (uint32_t k = 0; k < 8; k++) pieceStore(round - 1u, rowBase + 2u * k + half);
+                        for (uint32_t k = 0; k < 8; k++) pieceStore(round - 1u, rowBase + RPI * k + half);
                     }
                     if (round + 1u < nRounds) {
 #pragma unroll
-                        for (uint32_t k = 0; k < 8; k++) ld[k] = pieceLoad(round + 1u, rowBase + 2u * k + half);
+                        for (uint32_t k = 0; k < 8; k++) ld[k] = pieceLoad(round + 1u, rowBase + RPI * k + half);
                         pending = true;
                         pendRound = round + 1u;
                         pendRow = rowBase;
                     }
-                    const uint32_t sFirst = round * 32u + q * 8u;
-                    for (uint32_t s = sFirst; s < sFirst + 8u && s <= sEnd; s++) {
+                    const uint32_t sFirst = round * ROUND + q * 8u;
+                    if (sFirst > sEnd) continue;
+                    // everything the 8 steps read from LDS, up front: column c + 2 of the two rows above lane 0 and the
+                    // lane's own 8 residuals (each slot is read here before the step that overwrites it)
+                    uint32_t ra[8], rb[8], rsv[8];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t cc = min(sFirst + k + 2u, nC - 1u);
+                        ra[k] = rows[prev1 + cc];
+                        rb[k] = rows[prev0 + cc];
+                        rsv[k] = stage[(uint32_t)lane * RS + ((sFirst + k) & (RING - 1u))];
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) asm volatile("" : "+v"(ra[k]), "+v"(rb[k]), "+v"(rsv[k]));   // read here, not at the use
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t s = sFirst + k;
+                        if (s > sEnd) break;
                         const int32_t c = (int32_t)s - 3 * lane;
                         // what enters the two windows: column c + 2 of the row above and of the row two above
-                        const uint32_t cc = min(s + 2u, nC - 1u);
-                        const uint32_t na = lsop_from_lane_above(rows[prev1 + cc], z1);
-                        const uint32_t nb = lsop_from_lane_above(rows[prev0 + cc], a2);
+                        const uint32_t na = lsop_from_lane_above(ra[k], z1);
+                        const uint32_t nb = lsop_from_lane_above(rb[k], a2);
                         a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = na;
                         b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = nb;
-                        const uint32_t slot = (uint32_t)lane * RS + (s & 63u);
-                        const uint32_t rs = stage[slot];
                         float p = u[0] * (float)(int32_t)z1;
                         p = p + u[1] * (float)(int32_t)a1;
                         p = p + u[2] * (float)(int32_t)a2;
@@ -931,16 +966,17 @@ __global__ __launch_bounds__(64) void k_lsop_reconstruct(GfLsopReconArgs a)
                         p = p + u[9] * (float)(int32_t)b2;
                         p = p + u[10] * (float)(int32_t)b3;
                         p = p + u[11] * (float)(int32_t)b4;
-                        const uint32_t interior = (uint32_t)lsop_round(p) + rs;                       // LsDecoder12 :311-351
+                        const uint32_t interior = (uint32_t)lsop_round_sat(p) + rsv[k];               // LsDecoder12 :311-351
                         const uint32_t tail = (c == (int32_t)nC - 2 ? t0 : t1) + (z1 + a2 - a1);      // :353-383
                         const uint32_t border = c == 0 ? colv0 : colv1;
                         const uint32_t val = c < 2 ? border : (c <= (int32_t)nC - 3 ? interior : tail);
-                        if (rowValid && c >= 0 && c < (int32_t)nC) {
-                            stage[slot] = val;
+                        const bool act = rowValid && c >= 0 && c < (int32_t)nC;
+                        if (act) {
+                            stage[(uint32_t)lane * RS + (s & (RING - 1u))] = val;
                             if (feeds) rows[feedBase + (uint32_t)c] = val;
-                            z6 = z1;
-                            z1 = val;
                         }
+                        z6 = act ? z1 : z6;
+                        z1 = act ? val : z1;
                     }
                 }
             }
@@ -949,9 +985,7 @@ __global__ __launch_bounds__(64) void k_lsop_reconstruct(GfLsopReconArgs a)
             }
             // the last round's values
 #pragma unroll 4
-            for (uint32_t k = 0; k < 32; k++) pieceStore(nRounds - 1u, 2u * k + half);
-            const uint32_t q0 = prev0, q1 = prev1;
-            prev0 = next0; prev1 = next1; next0 = q0; next1 = q1;
+            for (uint32_t k = 0; k < ROUND; k++) pieceStore(nRounds - 1u, RPI * k + half);
         }
         if (lane == 0) a.status[t] = GF_K_OK;
     }
@@ -990,13 +1024,13 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
 {
     if (nTiles == 0) return hipSuccess;
     GfLsopReconArgs a{residuals, resStride, coefs, inStatus, values, status, nTiles, nRows, nCols};
-    const size_t dyn = (64 * 65 + 4 * (size_t)nCols) * 4;                  // 64 staging rings + 4 row buffers
+    const size_t dyn = (64 * (2 * RECON_ROUND + 1) + 2 * (size_t)nCols) * 4;      // 64 staging rings + 2 row buffers
     if (dyn <= 96 * 1024) {
         static GfDynLdsOptIn opt;
-        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct, dyn, opt);
+        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct<RECON_ROUND>, dyn, opt);
         if (e != hipSuccess) return e;
         const unsigned grid = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
-        hipLaunchKernelGGL(k_lsop_reconstruct, dim3(grid), dim3(64), dyn, stream, a);
+        hipLaunchKernelGGL(k_lsop_reconstruct<RECON_ROUND>, dim3(grid), dim3(64), dyn, stream, a);
     } else {
         const size_t wgs = (nTiles + 3) / 4;
         const unsigned grid = (unsigned)(wgs < 65536 * 16 ? wgs : 65536 * 16);
