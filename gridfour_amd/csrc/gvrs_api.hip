@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
 #include <zlib.h>
 
 #include "../../include/gvrs_hip_codec.h"
@@ -103,13 +104,41 @@ struct gf_timer {
     hipEvent_t start, stop;
 };
 
-// tiles are independent: the host-side zlib stages run on up to 32 threads
+// Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a container that shows 256 CPUs may
+// be allowed 16 cores' worth of time; more threads than that only take turns and thrash the caches).
+static unsigned hostCores()
+{
+    static const unsigned cached = []() -> unsigned {
+        unsigned n = std::thread::hardware_concurrency();
+        if (n == 0) n = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+            char q[64];
+            long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+                n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, atoll(q) / period));
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            long long quota = -1, period = 0;
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(h, "%lld", &period) != 1) period = 0;
+                fclose(h);
+            }
+            if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, quota / period));
+        }
+        return std::min(n, 256u);
+    }();
+    return cached;
+}
+
+// tiles are independent: the host-side zlib stages run on every core the process may use
 template <class F>
 static void parallelFor(size_t n, F f)
 {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    if (nt > 32) nt = 32;
+    unsigned nt = hostCores();
     if (nt > n) nt = (unsigned)n;
     if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
     std::vector<std::thread> th;
@@ -408,7 +437,9 @@ static gf_status lsopParseLengths(gf_context *c, hipStream_t st, size_t nTiles, 
 // M32; with rawM32 also the host-inflated Deflate ones)
 static gf_status lsopUnpackM32(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
                                size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
-                               int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus, int rawM32)
+                               int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus, int rawM32,
+                               const uint8_t *rawSide = nullptr, size_t rawSideStride = 0, const int32_t *sideStatus = nullptr,
+                               const uint32_t *produced2 = nullptr, const int32_t *inflStatus2 = nullptr)
 {
     if (!c) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
@@ -437,7 +468,64 @@ static gf_status lsopUnpackM32(gf_context *c, hipStream_t st, int nRows, int nCo
     a.nCols = nCols;
     a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
     a.rawM32 = rawM32;
+    a.rawSide = rawSide;
+    a.rawSideStride = rawSideStride;
+    a.sideStatus = sideStatus;
+    a.produced2 = produced2;
+    a.inflStatus2 = inflStatus2;
     GF_HIP(gf_launch_lsop_unpack_m32(a, st, grid));
+    return GF_OK;
+}
+
+
+constexpr size_t INFLATE_SCRATCH_BYTES = (size_t)1 << 30;     // thousands of streams per launch: a stream is one serial chain
+
+// Second entropy pass of the LSOP12 decode with the Deflate containers inflated ON THE DEVICE (LsDecoder12.java:127-141):
+// per chunk of tiles, k_lsop_streams describes the first zlib stream of every Deflate container, k_inflate runs, k_lsop_streams
+// places the second stream behind what the first one consumed, k_inflate runs again, and k_lsop_unpack_m32 reads the M32 bytes
+// of those tiles from the scratch (legacy Huffman containers are decoded as stored in the same launch).
+static gf_status lsopUnpackM32Deflate(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
+                                      size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
+                                      int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus)
+{
+    const size_t nInit = (size_t)4 * nRows + 2 * nCols - 9, nInt = (size_t)(nRows - 2) * (size_t)(nCols - 4);
+    const size_t rawStride = roundUp(6 * (nInit + nInt) + 192, 16);
+    const size_t chunk = std::max<size_t>(1, std::min(nTiles, INFLATE_SCRATCH_BYTES / rawStride));
+    gf_status s;
+    if ((s = c->dInflOut.ensure(chunk * rawStride + 64)) != GF_OK) return s;
+    if ((s = c->dInflate.ensure(chunk * sizeof(GfInflateStream))) != GF_OK) return s;
+    if ((s = c->dInflMeta.ensure(chunk * 7 * 4 + 128)) != GF_OK) return s;
+    uint8_t *raw = (uint8_t *)c->dInflOut.p;
+    GfInflateStream *desc = (GfInflateStream *)c->dInflate.p;
+    uint32_t *produced1 = (uint32_t *)c->dInflMeta.p, *consumed1 = produced1 + chunk, *produced2 = consumed1 + chunk;
+    int32_t *status1 = (int32_t *)(produced2 + chunk), *status2 = status1 + chunk, *side = status2 + chunk;
+    uint32_t *gate = (uint32_t *)(side + chunk);                   // number of Deflate containers in the chunk
+    for (size_t t0 = 0; t0 < nTiles; t0 += chunk) {
+        const size_t n = std::min(chunk, nTiles - t0);
+        GF_HIP(hipMemsetAsync(gate, 0, 4, st));
+        // this chunk's view of the batch
+        const uint8_t *blobC = dOffsets ? dBlob : dBlob + t0 * slotStride;
+        const size_t blobBytesC = dOffsets ? blobBytes : blobBytes - t0 * slotStride;
+        const uint64_t *offC = dOffsets ? dOffsets + t0 : nullptr;
+        for (int pass = 0; pass < 2; pass++) {
+            GF_HIP(gf_launch_lsop_streams(blobC, blobBytesC, offC, slotStride, dLengths + t0, n, (uint32_t)nInit, (uint32_t)nInt, rawStride,
+                                          pass, produced1, status1, consumed1, desc, side, gate, st));
+            GfInflateArgs a{};
+            a.inBase = blobC;
+            a.outBase = raw;
+            a.streams = desc;
+            a.produced = pass ? produced2 : produced1;
+            a.status = pass ? status2 : status1;
+            a.consumed = pass ? nullptr : consumed1;
+            a.gate = gate;
+            a.nStreams = n;
+            a.window = gf_inflate_window(0);
+            GF_HIP(gf_launch_inflate(a, st));
+        }
+        s = lsopUnpackM32(c, st, nRows, nCols, n, blobC, blobBytesC, offC, slotStride, dLengths + t0, dResiduals + t0 * resStride, resStride,
+                          dCoefs + t0 * 16, dScratchStatus + t0, 2, raw, rawStride, side, produced2, status2);
+        if (s != GF_OK) return s;
+    }
     return GF_OK;
 }
 
@@ -664,7 +752,7 @@ gf_status gf_inflate_batch_dev(gf_context *c, void *stream, size_t nStreams, con
     }
     // (pageable source: the copy is staged by the runtime before the call returns)
     GF_HIP(hipMemcpyAsync(c->dInflate.p, desc.data(), nStreams * sizeof(GfInflateStream), hipMemcpyHostToDevice, st));
-    GfInflateArgs a;
+    GfInflateArgs a{};
     a.inBase = dIn;
     a.outBase = dOut;
     a.streams = (const GfInflateStream *)c->dInflate.p;
@@ -786,7 +874,6 @@ gf_status gf_timer_elapsed_ms(gf_timer *t, float *ms)
 // ---- Deflate-carrying containers decoded on the device: walk the packings, inflate (gvrs_inflate.hip), decode ----------
 // The scratch (inflated bytes, stream descriptors, per-stream results) is bounded: batches go through it in chunks of tiles,
 // one after the other in stream order.
-constexpr size_t INFLATE_SCRATCH_BYTES = (size_t)256 << 20;
 
 static gf_status deflateDecodeDev(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
                                   size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
@@ -807,7 +894,7 @@ static gf_status deflateDecodeDev(gf_context *c, hipStream_t st, int nRows, int 
     for (size_t t0 = 0; t0 < nTiles; t0 += chunk) {
         const size_t n = std::min(chunk, nTiles - t0);
         GF_HIP(gf_launch_deflate_streams(dBlob, blobBytes, dOffsets, slotStride, dLengths, t0, n, (uint32_t)cells, raw, rawStride, desc, pre, st));
-        GfInflateArgs a;
+        GfInflateArgs a{};
         a.inBase = dBlob;
         a.outBase = raw;
         a.streams = desc;
@@ -845,7 +932,7 @@ static gf_status floatDecodeDev(gf_context *c, hipStream_t st, int nRows, int nC
         const size_t n = std::min(chunk, nTiles - t0);
         GF_HIP(hipMemsetAsync(planes, 0, n * planeStride, st));           // what a short stream does not reach reads as zero
         GF_HIP(gf_launch_float_streams(dBlob, blobBytes, dOffsets, dLengths, t0, n, (uint32_t)cells, planeStride, desc, pre, st));
-        GfInflateArgs a;
+        GfInflateArgs a{};
         a.inBase = dBlob;
         a.outBase = planes;
         a.streams = desc;
@@ -971,9 +1058,11 @@ static void parallelCopy(void *dst, const void *src, size_t bytes)
     for (auto &x : th) x.join();
 }
 
-static size_t hostChunkTiles(size_t cells, size_t nTiles)
+static size_t hostChunkTiles(size_t cells, size_t nTiles, int kind = KIND_HUFFMAN)
 {
-    const size_t n = std::max<size_t>(1, HOST_CHUNK_BYTES / (cells * 4));
+    // the inflate kernels run one wave per zlib stream and a stream is a serial chain: a chunk has to bring thousands of streams
+    const size_t bytes = kind == KIND_DEFLATE || kind == KIND_FLOAT ? 4 * HOST_CHUNK_BYTES : HOST_CHUNK_BYTES;
+    const size_t n = std::max<size_t>(1, bytes / (cells * 4));
     return std::min(n, std::max<size_t>(nTiles, 1));
 }
 
@@ -1148,7 +1237,7 @@ static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, 
     gf_status s = hostPipe(c, &P);
     if (s != GF_OK) return s;
     const size_t cells = (size_t)nRows * (size_t)nCols;
-    const size_t chunk = hostChunkTiles(cells, nTiles);
+    const size_t chunk = hostChunkTiles(cells, nTiles, kind);
     const size_t nChunks = (nTiles + chunk - 1) / chunk;
     const bool pinnedOut = nTiles && isPinned(values);
     if ((s = gf_context_reserve(c, nRows, nCols, chunk)) != GF_OK) return s;
@@ -1380,8 +1469,8 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
     GF_HIP(gf_launch_lsop_unpack2(dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride, dCoefs,
                                   dScratchStatus, nTiles, nRows, nCols, gf_canon_decode_lds_text(nRows, nCols), grid, st,
                                   (const uint32_t *)c->trees.p));
-    s = lsopUnpackM32(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals,
-                                resStride, dCoefs, dScratchStatus, 0);
+    s = lsopUnpackM32Deflate(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride,
+                             dCoefs, dScratchStatus);
     if (s != GF_OK) return s;
     return gf_lsop12_reconstruct_dev(c, stream, nRows, nCols, nTiles, dResiduals, resStride, dCoefs, dScratchStatus, dValues,
                                      dStatus);
@@ -1501,9 +1590,9 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
     return GF_OK;
 }
 
-// LsDecoder12.decode :94-160 for a batch in host memory.  Every container type is entropy-decoded on the GPU: canonical
-// Huffman (type 2) and legacy Huffman of M32 (type 0, either header revision) as stored; for Deflate containers (type 1)
-// the host's zlib inflates the two streams first and the GPU receives the header followed by the inflated M32 bytes.
+// LsDecoder12.decode :94-160 for a batch in host memory.  Every container type is decoded on the GPU as stored: canonical
+// Huffman (type 2), legacy Huffman of M32 (type 0, either header revision) and Deflate (type 1: the two zlib streams are
+// inflated by k_inflate).  The host only moves bytes.
 gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                      const uint64_t *offsets, int32_t *values, int32_t *status)
 {
@@ -1516,88 +1605,10 @@ gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t
     }
     const size_t cells = (size_t)nRows * (size_t)nCols;
     const size_t nRes = gf_lsop12_residual_count(nRows, nCols), resStride = roundUp(nRes, 4);
-    const size_t nInit = (size_t)4 * nRows + 2 * nCols - 9, nInt = nRes - nInit;
     std::vector<uint32_t> lengths(nTiles);
-    for (size_t t = 0; t < nTiles; t++) {
-        if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
-        lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
-    }
-
-    // Deflate containers: inflate on the host, hand the GPU [header][initialiser M32 bytes][interior M32 bytes]
-    struct Inflated { size_t tile; std::vector<uint8_t> bytes; int32_t st; };
-    std::vector<Inflated> infl;
-    std::vector<uint32_t> hdrLen;
-    for (size_t t = 0; t < nTiles; t++) {
-        const uint8_t *pk = blob + offsets[t];
-        const size_t len = lengths[t];
-        if (len < 3) continue;
-        const bool revised = pk[1] & 0x40;
-        size_t o = revised ? 2 : 1;
-        if (len < o + 1 + 52 + 8 + (revised ? 0 : 1) || pk[o] != 12) continue;      // the GPU reports these
-        int type = revised ? pk[1] & 0x0f : pk[o + 61] & 0x0f;
-        bool checksum = revised ? pk[1] & 0x80 : pk[o + 61] & 0x80;
-        o += 61 + (revised ? 0 : 1) + (checksum ? 4 : 0);
-        if (type == 0 || type == 2 || o > len) continue;
-        infl.push_back(Inflated{t, {}, GF_OK});
-        hdrLen.push_back((uint32_t)o);
-    }
-    parallelFor(infl.size(), [&](size_t i) {
-        Inflated &I = infl[i];
-        const uint8_t *pk = blob + offsets[I.tile];
-        const size_t len = lengths[I.tile], o = hdrLen[i];
-        // the byte counts sit right behind the 12 coefficients in both header revisions
-        const size_t at = ((pk[1] & 0x40) ? 3 : 2) + 52;
-        const uint32_t nMI = getLE32(pk + at), nMX = getLE32(pk + at + 4);
-        if (nMI > 6 * nInit + 64 || nMX > 6 * nInt + 64) { I.st = GF_ERR_FORMAT; return; }
-        I.bytes.resize(o + nMI + nMX);
-        memcpy(I.bytes.data(), pk, o);
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit(&zs) != Z_OK) { I.st = GF_ERR_FORMAT; return; }
-        zs.next_in = (Bytef *)(pk + o); zs.avail_in = (uInt)(len - o);
-        zs.next_out = I.bytes.data() + o; zs.avail_out = nMI;
-        int zr = inflate(&zs, Z_PARTIAL_FLUSH);
-        const size_t used = zs.total_in, got = zs.total_out;
-        inflateEnd(&zs);
-        if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got < nMI) { I.st = GF_ERR_FORMAT; return; }
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit(&zs) != Z_OK) { I.st = GF_ERR_FORMAT; return; }
-        zs.next_in = (Bytef *)(pk + o + used); zs.avail_in = (uInt)(len - o - used);
-        zs.next_out = I.bytes.data() + o + nMI; zs.avail_out = nMX;
-        zr = inflate(&zs, Z_PARTIAL_FLUSH);
-        const size_t got2 = zs.total_out;
-        inflateEnd(&zs);
-        if ((zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) || got2 < nMX) { I.st = GF_ERR_FORMAT; return; }
-    });
+    for (size_t t = 0; t < nTiles; t++) lengths[t] = (uint32_t)(offsets[t + 1] - offsets[t]);
     const uint8_t *gpuBlob = blob;
     const uint64_t *gpuOffsets = offsets;
-    std::vector<uint8_t> blob2;
-    std::vector<uint64_t> offsets2;
-    if (!infl.empty()) {
-        offsets2.resize(nTiles + 1);
-        uint64_t total2 = 0;
-        size_t k = 0;
-        for (size_t t = 0; t < nTiles; t++) {
-            offsets2[t] = total2;
-            if (k < infl.size() && infl[k].tile == t) {
-                if (infl[k].st == GF_OK) lengths[t] = (uint32_t)infl[k].bytes.size();
-                k++;
-            }
-            total2 += lengths[t];
-        }
-        offsets2[nTiles] = total2;
-        blob2.resize(total2 + 4);
-        k = 0;
-        for (size_t t = 0; t < nTiles; t++) {
-            if (k < infl.size() && infl[k].tile == t) {
-                if (infl[k].st == GF_OK) { memcpy(blob2.data() + offsets2[t], infl[k].bytes.data(), lengths[t]); k++; continue; }
-                k++;
-            }
-            memcpy(blob2.data() + offsets2[t], blob + offsets[t], lengths[t]);
-        }
-        gpuBlob = blob2.data();
-        gpuOffsets = offsets2.data();
-    }
     const uint64_t total = gpuOffsets[nTiles];
 
     gf_status s;
@@ -1612,27 +1623,15 @@ gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t
     GF_HIP(hipMemcpyAsync(c->dBlob.p, gpuBlob, total, hipMemcpyHostToDevice, c->stream));
     GF_HIP(hipMemcpyAsync(c->dOffsets.p, gpuOffsets, (nTiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
     GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
-    const unsigned grid = gf_huffman_decode_grid(nTiles);
-    if ((s = lsopParseLengths(c, c->stream, nTiles, (const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
-                              (const uint32_t *)c->dLengths.p)) != GF_OK) return s;
-    GF_HIP(gf_launch_lsop_unpack2((const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
-                                  (const uint32_t *)c->dLengths.p, (int32_t *)c->dResiduals.p, resStride,
-                                  (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p, nTiles, nRows, nCols,
-                                  gf_canon_decode_lds_text(nRows, nCols), grid, c->stream, (const uint32_t *)c->trees.p));
-    s = lsopUnpackM32(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total, (const uint64_t *)c->dOffsets.p, 0,
-                      (const uint32_t *)c->dLengths.p, (int32_t *)c->dResiduals.p, resStride, (uint32_t *)c->dCoefs.p,
-                      (int32_t *)c->dStatus2.p, 1);
-    if (s != GF_OK) return s;
-    s = gf_lsop12_reconstruct_dev(c, c->stream, nRows, nCols, nTiles, (const int32_t *)c->dResiduals.p, resStride,
-                                  (const uint32_t *)c->dCoefs.p, (const int32_t *)c->dStatus2.p, (int32_t *)c->dValues.p,
-                                  (int32_t *)c->dStatus.p);
+    s = gf_lsop12_decode_batch_i32_dev(c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total,
+                                       (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p, (int32_t *)c->dValues.p,
+                                       (int32_t *)c->dStatus.p, (int32_t *)c->dResiduals.p, resStride, (uint32_t *)c->dCoefs.p,
+                                       (int32_t *)c->dStatus2.p);
     if (s != GF_OK) return s;
     std::vector<int32_t> st(nTiles);
     GF_HIP(hipMemcpyAsync(values, c->dValues.p, nTiles * cells * 4, hipMemcpyDeviceToHost, c->stream));
     GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
     GF_HIP(hipStreamSynchronize(c->stream));
-    for (const Inflated &I : infl)
-        if (I.st != GF_OK) st[I.tile] = I.st;                  // the zlib stream itself was damaged
     if (status) memcpy(status, st.data(), nTiles * 4);
     return GF_OK;
 }

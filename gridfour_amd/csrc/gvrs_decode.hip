@@ -1869,9 +1869,15 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
                 if (checksum) o += 4;                                     // value checksum: skipped
                 if (o > len) early = GF_K_ERR_BOUNDS;
                 else if (type == 2) early = GF_K_ERR_UNSUPPORTED;         // canonical text behind a legacy header: never written
-                else if (type != 0 && !a.rawM32) early = GF_K_ERR_UNSUPPORTED;   // Deflate: needs the host's inflate first
+                else if (type != 0 && !a.rawM32) early = GF_K_ERR_UNSUPPORTED;   // Deflate: needs an inflate pass first
                 else if (nMI > 6u * nInit + 64u || nMX > 6u * nInt + 64u) early = GF_K_ERR_FORMAT;   // no encoder emits this
-                else if (type != 0 && (uint64_t)o + nMI + nMX > len) early = GF_K_ERR_BOUNDS;
+                else if (type != 0 && a.rawM32 == 1 && (uint64_t)o + nMI + nMX > len) early = GF_K_ERR_BOUNDS;
+                else if (type != 0 && a.rawM32 == 2) {                    // inflated on the device (k_lsop_streams, k_inflate)
+                    const int32_t sd = a.sideStatus[t];
+                    if (sd < 0) early = sd;
+                    else if (sd != 0) early = GF_K_ERR_UNSUPPORTED;
+                    else if (a.inflStatus2[t] != GF_K_OK || a.produced2[t] < nMX) early = GF_K_ERR_FORMAT;
+                }
             }
         }
         if (early != GF_K_OK) {
@@ -1882,7 +1888,8 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
         if (tid < 13) a.coefs[t * 16 + tid] = le32((pk[1] & 0x40 ? 3u : 2u) + 4u * tid);
 
         uint32_t startBit = o * 8u;                                       // type 0: where the next Huffman segment begins
-        uint32_t rawAt = o;                                               // type 1: where the next M32 stream begins
+        uint32_t rawAt = a.rawM32 == 2 ? 0u : o;                          // type 1: where the next M32 stream begins
+        const uint8_t *__restrict__ rawFrom = a.rawM32 == 2 ? a.rawSide + t * a.rawSideStride : pk;
         int32_t tileStatus = GF_K_OK;
         for (int seg = 0; seg < 2 && tileStatus == GF_K_OK; seg++) {
             const uint32_t nM32 = seg ? nMX : nMI, nVals = seg ? nInt : nInit;
@@ -1902,7 +1909,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
                     wb = bm + (cap >> 5) + 1;
                 }
                 if (type != 0) {
-                    for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = pk[rawAt + i];
+                    for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = rawFrom[rawAt + i];
                     __syncthreads();
                 } else {
                     // the serialised tree: stage the words around it, parse, build the tables

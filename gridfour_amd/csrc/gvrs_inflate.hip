@@ -26,8 +26,8 @@ namespace {
 
 constexpr int INF_WAVES = 4;                       // waves (= streams) per workgroup
 constexpr uint32_t LL_BITS = 10, D_BITS = 9;       // first-level lookup widths; longer codes walk the canonical tables
-constexpr uint32_t FLUSH = 2048;                   // window bytes gathered before they go to HBM
-constexpr uint32_t IN_WORDS = 256;                 // the wave's LDS copy of the compressed input: 1 KB, refilled by all lanes
+constexpr uint32_t FLUSH = 1024;                   // window bytes gathered before they go to HBM
+constexpr uint32_t IN_WORDS = 128;                 // the wave's LDS copy of the compressed input: 512 bytes, refilled by all lanes
 
 struct __attribute__((packed, aligned(1))) InfWord { uint32_t v; };
 
@@ -42,11 +42,6 @@ struct InfTables {
     uint32_t ibuf[IN_WORDS];                       // the compressed input, a piece at a time
 };
 
-__constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
-                                       6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
@@ -185,7 +180,7 @@ __device__ __forceinline__ uint32_t inf_bits(InfState &z, uint32_t n)       // n
 __device__ __forceinline__ int inf_sym(InfState &z, const uint16_t *table, uint32_t tbits, const uint16_t *count, const uint16_t *symOrder)
 {
     inf_need(z, 15);
-    const uint32_t e = table[(uint32_t)z.bitbuf & ((1u << tbits) - 1u)];
+    const uint32_t e = uni(table[(uint32_t)z.bitbuf & ((1u << tbits) - 1u)]);
     if (e) {
         const uint32_t L = e >> 9;
         if (L > z.bitcnt) { z.starved = true; return -2; }
@@ -198,12 +193,12 @@ __device__ __forceinline__ int inf_sym(InfState &z, const uint16_t *table, uint3
     for (uint32_t len = 1; len <= 15; len++) {
         code |= (uint32_t)b & 1u;
         b >>= 1;
-        const uint32_t c = count[len];
+        const uint32_t c = uni(count[len]);
         if (code < first + c) {
             if (len > z.bitcnt) { z.starved = true; return -2; }
             z.bitbuf >>= len;
             z.bitcnt -= len;
-            return (int)symOrder[index + (code - first)];
+            return (int)uni(symOrder[index + (code - first)]);
         }
         index += c;
         first += c;
@@ -216,12 +211,15 @@ __device__ __forceinline__ int inf_sym(InfState &z, const uint16_t *table, uint3
 __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // everything that steers the parse is wave-uniform and is kept in scalar registers: values that come out of LDS or out
+    // of thread ids go through v_readfirstlane (uni) so that the compiler knows
+    const uint32_t lane = threadIdx.x & 63u, wave = uni(threadIdx.x >> 6);
     const uint32_t W = a.window;                                   // power of two
     uint8_t *mine = ldsDyn + (size_t)wave * (W + sizeof(InfTables));
     uint8_t *win = mine;
     InfTables &T = *reinterpret_cast<InfTables *>(mine + W);
 
+    if (a.gate && *a.gate == 0u) return;                           // a batch without a single Deflate container
     for (size_t sIdx = (size_t)blockIdx.x * INF_WAVES + wave; sIdx < a.nStreams; sIdx += (size_t)gridDim.x * INF_WAVES) {
         const GfInflateStream S = a.streams[sIdx];
         uint8_t *__restrict__ out = a.outBase + S.outOffset;
@@ -262,6 +260,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
             s2 = (uint32_t)(((uint64_t)s2 + (uint64_t)n * s1 + sumW) % 65521u);
             s1 = (uint32_t)(((uint64_t)s1 + sumB) % 65521u);
             flushed = upTo;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // far matches read these bytes back (other lanes, L2)
         };
 
         // ---- zlib header (RFC 1950) ----
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
                 __builtin_amdgcn_wave_barrier();
                 if (bad) { status = GF_K_ERR_FORMAT; break; }
                 if (z.starved || idx < nLL + nD) { z.starved = true; break; }
-                if (T.lens[256] == 0) { status = GF_K_ERR_FORMAT; break; }              // no end-of-block code
+                if (uni(T.lens[256]) == 0) { status = GF_K_ERR_FORMAT; break; }         // no end-of-block code
             }
             {
                 const int r1 = inf_build(T.lens, nLL, T.llCount, T.llSym, T.ll, LL_BITS, lane);
@@ -392,15 +391,21 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
                     break;
                 }
                 if (sym > 285) { status = GF_K_ERR_FORMAT; break; }
+                // base value and extra bits of the length / distance codes (RFC 1951 3.2.5) in closed form: the tables in
+                // constant memory cost a memory round trip per match
                 const uint32_t li = (uint32_t)sym - 257u;
-                const uint32_t len = LEN_BASE[li] + (LEN_EXTRA[li] ? inf_bits(z, LEN_EXTRA[li]) : 0u);
+                const uint32_t lx = li < 8u || li == 28u ? 0u : (li - 4u) >> 2;
+                const uint32_t lbase = li < 8u ? li + 3u : li == 28u ? 258u : ((4u + (li & 3u)) << lx) + 3u;
+                const uint32_t len = lbase + (lx ? inf_bits(z, lx) : 0u);
                 const int ds = inf_sym(z, T.dd, D_BITS, T.dCount, T.dSym);
                 if (ds < 0) {
                     if (ds == -1) status = GF_K_ERR_FORMAT;
                     break;
                 }
                 if (ds > 29) { status = GF_K_ERR_FORMAT; break; }
-                const uint32_t dist = DIST_BASE[ds] + (DIST_EXTRA[ds] ? inf_bits(z, DIST_EXTRA[ds]) : 0u);
+                const uint32_t dx = ds < 4 ? 0u : ((uint32_t)ds - 2u) >> 1;
+                const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;
+                const uint32_t dist = dbase + (dx ? inf_bits(z, dx) : 0u);
                 if (z.starved) break;
                 if (dist > pos) { status = GF_K_ERR_FORMAT; break; }                     // too far back
                 if (pos >= cap) { pos = cap + 1; break; }
@@ -409,15 +414,24 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
                 uint32_t n = min(len, cap - pos);
                 const bool cut = n < len;
                 __builtin_amdgcn_wave_barrier();
+                // the LDS window holds the last W bytes; a source further back than that is read from the output in HBM, where
+                // it has been since an earlier flush (at most FLUSH + 258 bytes are ever unflushed)
+                const bool far = dist + 64u > W;
+                // a distance below 64 repeats a pattern: once a piece of D bytes is copied, the last 2 D bytes are the pattern
+                // twice, so the next piece can come from 2 D back -- 1, 2, 4 .. 64 bytes per step instead of `dist` each time
+                uint32_t D = dist;
                 while (n) {
-                    const uint32_t piece = min(n, min(dist, 64u));
+                    const uint32_t piece = min(n, min(D, 64u));
                     uint32_t b = 0;
-                    if (lane < piece) b = win[(pos - dist + lane) & (W - 1u)];
+                    if (lane < piece)
+                        b = far ? (uint32_t)__hip_atomic_load(out + (pos - D + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : (uint32_t)win[(pos - D + lane) & (W - 1u)];
                     __builtin_amdgcn_wave_barrier();
                     if (lane < piece) win[(pos + lane) & (W - 1u)] = (uint8_t)b;
                     __builtin_amdgcn_wave_barrier();
                     pos += piece;
                     n -= piece;
+                    if (D < 64u) D += piece;
                     if (pos - flushed >= W - 512u) flush(pos);                           // (long matches in a small window)
                 }
                 if (cut) { pos = cap + 1; break; }
@@ -440,6 +454,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
         if (lane == 0) {
             a.produced[sIdx] = pos;
             a.status[sIdx] = status;
+            if (a.consumed) a.consumed[sIdx] = z.inPos - (z.bitcnt >> 3);      // Inflater.getTotalIn(): whole bytes not yet looked at stay
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -545,6 +560,72 @@ __global__ void k_float_streams(const uint8_t *__restrict__ blob, size_t blobByt
     pre[i] = st;
 }
 
+// LSOP12 containers that carry Deflate (LsDecoder12.java:127-141): header (either revision, LsHeader.java:131-185) with the
+// byte counts of the two M32 streams, then TWO zlib streams back to back -- the second one begins where the first one's
+// Inflater stopped reading (Inflater.getTotalIn()).  Two passes of one thread per tile around two k_inflate launches:
+// pass 0 describes stream one; pass 1 checks what came out of it and describes stream two.  Both streams of tile i go to
+// raw + i * rawStride: [initialiser M32 bytes][interior M32 bytes].  side[i]: 0 = a Deflate container on its way, 1 = not one
+// (or a header k_lsop_unpack_m32 rejects by itself), < 0 = the status of a failed first stream.
+__global__ void k_lsop_streams(const uint8_t *__restrict__ blob, size_t blobBytes, const uint64_t *__restrict__ offsets, size_t slotStride,
+                               const uint32_t *__restrict__ lengths, size_t nTiles, uint32_t nInit, uint32_t nInt, size_t rawStride,
+                               int pass, const uint32_t *__restrict__ produced, const int32_t *__restrict__ inflStatus,
+                               const uint32_t *__restrict__ consumed, GfInflateStream *__restrict__ desc, int32_t *__restrict__ side,
+                               uint32_t *__restrict__ gate)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTiles) return;
+    if (pass == 1 && *gate == 0u) return;                          // pass 0 found no Deflate container: nothing to place
+    GfInflateStream d;
+    d.inOffset = 0;
+    d.outOffset = i * rawStride;
+    d.inLen = 0;
+    d.outCap = 0;
+    if (pass == 1 && side[i] != 0) {
+        desc[i] = d;
+        return;
+    }
+    const uint64_t off = offsets ? offsets[i] : (uint64_t)i * slotStride;
+    const uint32_t len = lengths[i];
+    const uint8_t *__restrict__ pk = blob + off;
+    auto le32 = [&](uint32_t o) -> uint32_t {
+        return (uint32_t)pk[o] | ((uint32_t)pk[o + 1] << 8) | ((uint32_t)pk[o + 2] << 16) | ((uint32_t)pk[o + 3] << 24);
+    };
+    int32_t sd = 1;
+    uint32_t o = 1, type = 0, nMI = 0, nMX = 0;
+    if (len >= 3 && off + len <= blobBytes) {
+        const bool revised = pk[1] & 0x40;
+        bool checksum = false;
+        if (revised) { type = pk[1] & 0x0fu; checksum = pk[1] & 0x80; o = 2; }
+        if (len >= o + 1u + 52u + 8u + (revised ? 0u : 1u) && pk[o] == 12) {
+            o += 53;
+            nMI = le32(o);
+            nMX = le32(o + 4);
+            o += 8;
+            if (!revised) { type = pk[o] & 0x0fu; checksum = pk[o] & 0x80; o++; }
+            if (checksum) o += 4;
+            if (o <= len && type != 0 && type != 2 && nMI <= 6u * nInit + 64u && nMX <= 6u * nInt + 64u) sd = 0;
+        }
+    }
+    if (sd == 0) {
+        if (pass == 0) {
+            d.inOffset = off + o;
+            d.inLen = len - o;
+            d.outCap = nMI;
+        } else if (inflStatus[i] != GF_K_OK || produced[i] < nMI) {
+            sd = GF_K_ERR_FORMAT;                                  // what makes the first Inflater.inflate call fail or fall short
+        } else {
+            const uint32_t used = min(consumed[i], len - o);
+            d.inOffset = off + o + used;
+            d.outOffset = i * rawStride + nMI;
+            d.inLen = len - o - used;
+            d.outCap = nMX;
+        }
+    }
+    desc[i] = d;
+    side[i] = sd;
+    if (pass == 0 && sd == 0) atomicAdd(gate, 1u);
+}
+
 __global__ void k_float_status(size_t nTiles, const int32_t *__restrict__ pre, const int32_t *__restrict__ inflStatus,
                                int32_t *__restrict__ status)
 {
@@ -593,6 +674,17 @@ hipError_t gf_launch_float_streams(const uint8_t *blob, size_t blobBytes, const 
     return hipGetLastError();
 }
 
+hipError_t gf_launch_lsop_streams(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride, const uint32_t *lengths,
+                                  size_t nTiles, uint32_t nInit, uint32_t nInt, size_t rawStride, int pass, const uint32_t *produced,
+                                  const int32_t *inflStatus, const uint32_t *consumed, GfInflateStream *desc, int32_t *side, uint32_t *gate,
+                                  hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lsop_streams, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, stream, blob, blobBytes, offsets, slotStride,
+                       lengths, nTiles, nInit, nInt, rawStride, pass, produced, inflStatus, consumed, desc, side, gate);
+    return hipGetLastError();
+}
+
 hipError_t gf_launch_float_status(size_t nTiles, const int32_t *pre, const int32_t *inflStatus, int32_t *status, hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
@@ -602,9 +694,8 @@ hipError_t gf_launch_float_status(size_t nTiles, const int32_t *pre, const int32
 
 uint32_t gf_inflate_window(uint32_t maxOut)
 {
-    uint32_t w = 4096;                                             // > FLUSH + the longest match: unflushed bytes never wrap
-    while (w < 32768u && w < maxOut + 64u) w <<= 1;
-    return w;
+    (void)maxOut;
+    return 2048;                // > FLUSH + the longest match + 512: unflushed bytes never wrap; older bytes are read back from HBM
 }
 
 hipError_t gf_launch_inflate(const GfInflateArgs &a, hipStream_t stream)
@@ -615,7 +706,7 @@ hipError_t gf_launch_inflate(const GfInflateArgs &a, hipStream_t stream)
     const hipError_t e = gf_opt_in_dyn_lds(k_inflate, dyn, opt);
     if (e != hipSuccess) return e;
     const size_t blocks = (a.nStreams + INF_WAVES - 1) / INF_WAVES;
-    const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+    const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
     hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), dyn, stream, a);
     return hipGetLastError();
 }

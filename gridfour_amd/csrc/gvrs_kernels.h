@@ -109,6 +109,12 @@ struct GfLsopM32Args {
     int nRows, nCols;
     uint32_t ldsM32Bytes;
     int rawM32;                // 1: type-1 containers hold the inflated M32 bytes of both streams behind the header
+                               // 2: the inflated M32 bytes of tile t are at rawSide + t * rawSideStride (device inflate)
+    const uint8_t *rawSide;
+    size_t rawSideStride;
+    const int32_t *sideStatus;     // mode 2, per tile (k_lsop_streams): 0 = inflated, < 0 = the first stream's failure
+    const uint32_t *produced2;     // mode 2: bytes the second stream gave
+    const int32_t *inflStatus2;    // mode 2: the second stream's status
 };
 
 hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream, unsigned grid);
@@ -176,6 +182,8 @@ struct GfInflateArgs {
     int32_t *status;           // per stream: GF_K_OK or GF_K_ERR_FORMAT (what makes Inflater throw DataFormatException)
     size_t nStreams;
     uint32_t window;           // LDS window per wave: gf_inflate_window(largest outCap)
+    uint32_t *consumed;        // may be null; per stream: bytes of input used (Inflater.getTotalIn()): where a following stream starts
+    const uint32_t *gate;      // may be null; a device word: zero = no stream of this launch has any input, every wave leaves at once
 };
 uint32_t gf_inflate_window(uint32_t maxOut);
 hipError_t gf_launch_inflate(const GfInflateArgs &a, hipStream_t stream);
@@ -188,6 +196,10 @@ hipError_t gf_launch_deflate_lengths(size_t nTiles, const GfInflateStream *desc,
 hipError_t gf_launch_merge_status(size_t nTiles, const int32_t *pre, const int32_t *decoded, int32_t *status, hipStream_t stream);
 hipError_t gf_launch_float_streams(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, const uint32_t *lengths, size_t tile0,
                                    size_t nTiles, uint32_t cells, size_t planeStride, GfInflateStream *desc, int32_t *pre, hipStream_t stream);
+hipError_t gf_launch_lsop_streams(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride, const uint32_t *lengths,
+                                  size_t nTiles, uint32_t nInit, uint32_t nInt, size_t rawStride, int pass, const uint32_t *produced,
+                                  const int32_t *inflStatus, const uint32_t *consumed, GfInflateStream *desc, int32_t *side, uint32_t *gate,
+                                  hipStream_t stream);
 hipError_t gf_launch_float_status(size_t nTiles, const int32_t *pre, const int32_t *inflStatus, int32_t *status, hipStream_t stream);
 
 // predictor -> M32 stage alone (gvrs_encode.hip): per tile up to three candidate M32 streams (CodecDeflate.java:157-199)

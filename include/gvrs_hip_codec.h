@@ -276,8 +276,10 @@ gf_status gf_deflate_decode_i32(gf_context *ctx, int n_rows, int n_cols, const u
  * in one bit store (compression type 2).  The Deflate alternative (type 1, LsEncoder12.java:180-216) is produced by the
  * host entry points with the host's zlib when deflate_enabled != 0 (the reference's default).  Decoding accepts every
  * container the reference's decoder does (LsDecoder12.java:107-150), with either header revision: type 2 and type 0
- * (legacy Huffman of the two M32 streams, what Sample14_LSOP.gvrs holds) entirely on the GPU; type 1 after the host's
- * zlib inflated its two streams (host entry points only: the _dev form reports GF_ERR_UNSUPPORTED for it).           */
+ * (legacy Huffman of the two M32 streams, what Sample14_LSOP.gvrs holds) and type 1 (two zlib streams, inflated on the
+ * device: the second one starts where the first Inflater stopped reading) -- all of them entirely on the GPU, in the host
+ * and the _dev forms alike.  The _dev decode allocates inflate scratch inside the context on first use (not capture-safe
+ * until it has run once for the shape).                                                                             */
 size_t gf_lsop12_residual_count(int n_rows, int n_cols);
 size_t gf_lsop12_max_packing(int n_rows, int n_cols);
 /* LsOptimalPredictor12.encode: tile -> coefficients + residual streams (d_status: GF_OK / GF_DECLINED per tile) */

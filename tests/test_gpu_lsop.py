@@ -226,8 +226,8 @@ def test_legacy_container_damage_is_reported(codec, sample14):
 
 
 def test_device_resident_legacy_containers(sample14):
-    """gf_lsop12_decode_batch_i32_dev on packings already in HBM: type 0 is decoded entirely on the device; a Deflate
-    container there (no inflate on the device) is reported unsupported."""
+    """gf_lsop12_decode_batch_i32_dev on packings already in HBM: every container type (legacy Huffman, canonical, Deflate)
+    is decoded entirely on the device."""
     import gridfour_amd
     from gridfour_amd import DeviceBuffer, lib
     ctx = gridfour_amd.GvrsHipContext(0)
@@ -257,7 +257,7 @@ def test_device_resident_legacy_containers(sample14):
     got = dval.download(np.int32, nt * nr * nc).reshape(nt, -1)
     for k in (0, 1, 3):
         assert st[k] == 0 and np.array_equal(got[k], v), (k, st[k])
-    assert st[2] == (-7 if typ1 == 1 else 0)
+    assert st[2] == 0 and np.array_equal(got[2], v)          # Deflate containers are inflated on the device too
 
 
 def test_device_batch_dem_roundtrip():
@@ -316,3 +316,35 @@ def test_config5ii_int_coded_float_256x256():
         ref, typ = oracle.lsop12_encode(3, nr, nc, coded[t], False)
         assert typ == 2 and b.get_packing(t, int(lengths[t])) == ref, t
     b.free()
+
+
+def test_deflate_container_damage_matches_the_oracle(codec):
+    """Deflate (type 1) containers are inflated on the device, the second zlib stream behind what the first one consumed.
+    Truncated and bit-flipped containers: whenever the oracle (host zlib, as java.util.zip.Inflater) decodes one, the device
+    decodes it to the same cells; whenever the oracle rejects one, the device does not report success with other cells."""
+    nr, nc = 64, 80
+    y, x = np.mgrid[0:nr, 0:nc]
+    v = (3 * x + 5 * y + 40 * ((x // 16 + y // 16) % 2)).astype(np.int32).ravel()      # a plane with steps: long runs of equal residuals
+    defl, typ = oracle.lsop12_encode(1, nr, nc, v, True)
+    assert typ == 1, "the Deflate container should win on this tile"
+    rng = np.random.default_rng(23)
+    packs = [defl] + [defl[:n] for n in (60, 71, 72, 80, len(defl) // 2, len(defl) - 5, len(defl) - 1)]
+    for k in range(60):
+        b = bytearray(defl)
+        for _ in range(1 + k % 3):
+            b[int(rng.integers(63, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        packs.append(bytes(b))
+    vals, st = codec.decode_batch(nr, nc, packs)
+    assert st[0] == 0 and np.array_equal(vals[0], v)
+    n_ok = 0
+    for k, pk in enumerate(packs):
+        try:
+            ref = oracle.lsop12_decode(nr, nc, pk)
+        except Exception:
+            ref = None
+        if ref is not None:
+            assert st[k] == 0 and np.array_equal(vals[k], ref), (k, st[k])
+            n_ok += 1
+        else:
+            assert st[k] != 0, k
+    assert n_ok >= 1
