@@ -354,7 +354,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         gf_status s = c->workspace.ensure((size_t)grid * wsStride);
         if (s != GF_OK) return s;
     }
-    GfDecodeArgs a;
+    GfDecodeArgs a{};
     a.blob = dBlob;
     a.blobBytes = blobBytes;
     a.offsets = dOffsets;
@@ -401,6 +401,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     if (kind == KIND_CANON) {
         a.ldsM32Bytes = 0;
         a.ldsTextBytes = gf_canon_decode_lds_text(nRows, nCols);
+        a.ldsStageBytes = gf_canon_decode_lds_stage(nRows, nCols);
         GF_HIP(gf_launch_canon_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     } else {
         a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);

@@ -40,6 +40,11 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
     const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
     const uint32_t capWords = a.ldsTextBytes >> 2;
+    // the byte stage of phase 2 (CdCellSink): the sync arrays qe / qc are dead by then, the rest sits behind the text copy
+    uint8_t *const stageA = reinterpret_cast<uint8_t *>(S.qe);
+    uint8_t *const stageB = reinterpret_cast<uint8_t *>(cdLdsText + capWords);
+    const uint32_t stageCapA = (uint32_t)(2 * sizeof(S.qe)), stageCap = stageCapA + a.ldsStageBytes;
+    static_assert(offsetof(CanonDec, qc) == offsetof(CanonDec, qe) + sizeof(S.qe), "qe and qc form one stretch of LDS");
 
     for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
         const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
@@ -84,11 +89,12 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
         const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
         const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
 #ifdef GF_DIAG
-        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, !(a.phaseLimit & 0x100)};
+        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, !(a.phaseLimit & 0x100),
+                              stageA, stageB, stageCapA, stageCap, 0u};
         uint32_t *stamps = a.debug ? a.debug + t * 16 : nullptr;
         if (stamps && tid == 0) stamps[0] = (uint32_t)__builtin_amdgcn_s_memtime();
 #else
-        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, true};
+        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, true, stageA, stageB, stageCapA, stageCap, 0u};
         constexpr uint32_t *stamps = nullptr;
 #endif
         uint32_t endPos, nValues;
@@ -269,10 +275,23 @@ uint32_t gf_canon_decode_lds_text(int nRows, int nCols)
     return (uint32_t)((want + 31) & ~(size_t)31);
 }
 
+uint32_t gf_canon_decode_lds_stage(int nRows, int nCols)
+{
+    // what is left of a quarter of the CU's LDS (four workgroups per CU) behind the tables and the text copy, and never
+    // more than a half of the stream could use
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const size_t used = sizeof(CanonDec) + gf_canon_decode_lds_text(nRows, nCols) + 512;
+    const size_t quarter = 40 * 1024;
+    size_t room = quarter > used ? quarter - used : 0;
+    const size_t want = cells > 2 * sizeof(((CanonDec *)nullptr)->qe) ? cells - 2 * sizeof(((CanonDec *)nullptr)->qe) : 0;
+    if (room > want) room = want;
+    return (uint32_t)(room & ~(size_t)31);
+}
+
 hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid)
 {
     if (a.nTiles == 0) return hipSuccess;
-    const size_t dyn = a.ldsTextBytes;
+    const size_t dyn = (size_t)a.ldsTextBytes + a.ldsStageBytes;
     static GfDynLdsOptIn opt;
     {
         const hipError_t e = gf_opt_in_dyn_lds(k_canon_decode, dyn, opt);

@@ -221,6 +221,8 @@ __device__ __forceinline__ void cd_run(const CanonDec &S, const Text &T, CdCur<T
 struct CdArraySink {                      // value k -> dst[k], k < n
     int32_t *dst;
     uint32_t n;
+    static constexpr bool kStaged = false;
+    __device__ __forceinline__ void put(uint32_t k, uint32_t v) const { one(k, v); }
     __device__ __forceinline__ void one(uint32_t k, uint32_t v) const { if (k < n) dst[k] = (int32_t)v; }
     __device__ __forceinline__ void quad(uint32_t k0, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const
     {
@@ -240,6 +242,35 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
     __device__ __forceinline__ uint32_t cell(uint32_t k) const { return stream_cell_fast(model, nR, nC, k, magic, useMagic); }
     bool enabled;                         // false: diagnostic ablation (no stores)
     __device__ __forceinline__ void one(uint32_t k, uint32_t v) const { if (k < nStream && enabled) o[cell(k)] = v; }
+    // Staging (decode phase 2): a thread walks its own stretch of the stream, so the 64 lanes of a store instruction hit 64
+    // different lines, four bytes each -- measured, that multiplies the HBM write traffic by four.  Values of -127..127 (one
+    // byte; nearly all of them) are parked in LDS instead, a byte each, and expand() writes them out afterwards with
+    // neighbouring lanes on neighbouring cells; the rare others (and whatever does not fit the stage) go straight to their
+    // cell and leave the mark 0x80.  The stream is staged in two halves (subsequences 0..255, then 256..511).
+    static constexpr bool kStaged = true;
+    uint8_t *stA, *stB;                   // the stage: capA bytes at stA, then cap - capA bytes at stB (cap == 0: no staging)
+    uint32_t capA, cap;
+    uint32_t halfBase;                    // stream position of the half being decoded
+    __device__ __forceinline__ uint8_t *slot(uint32_t rel) const { return rel < capA ? stA + rel : stB + (rel - capA); }
+    __device__ __forceinline__ void put(uint32_t k, uint32_t v) const
+    {
+        if (k >= nStream || !enabled) return;
+        const uint32_t rel = k - halfBase;
+        const bool small = v + 127u <= 254u;
+        if (rel < cap) {
+            *slot(rel) = small ? (uint8_t)v : (uint8_t)0x80;
+            if (small) return;
+        }
+        o[cell(k)] = v;
+    }
+    __device__ __forceinline__ void expand(uint32_t count) const        // the whole workgroup, between two barriers
+    {
+        const uint32_t n = min(count, cap);
+        for (uint32_t rel = threadIdx.x; rel < n; rel += DEC_THREADS) {
+            const uint32_t b = *slot(rel), k = halfBase + rel;
+            if (b != 0x80u && k < nStream && enabled) o[cell(k)] = (uint32_t)(int32_t)(int8_t)b;
+        }
+    }
     __device__ __forceinline__ void quad(uint32_t k0, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const
     {
         if (k0 + 3u < nStream) {
@@ -461,7 +492,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     int32_t tileStatus = GF_K_OK;
     if (qStar == 0xFFFFFFFFu || S.qe[qStar] != CD_END_EOT) tileStatus = GF_K_ERR_BOUNDS;   // no end-of-text: read past the data
     // exclusive prefix sum of the counts over the chain
-    uint32_t base[2];
+    uint32_t base[2], firstHalf = 0;              // firstHalf: values of subsequences 0..DEC_THREADS-1 (uniform)
     {
         uint32_t running = 0;
 #pragma unroll
@@ -471,6 +502,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
             uint32_t tot;
             base[j] = running + block_excl_scan(c, S.waveSum, &tot);
             running += tot;
+            if (j == 0) firstHalf = tot;
         }
         if (tid == 0) S.carry = running;
     }
@@ -487,6 +519,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const uint32_t q = tid + j * DEC_THREADS;
+        if constexpr (Sink::kStaged) sink.halfBase = j == 0 ? 0u : min(firstHalf, nValues);
         if (q < Q && q <= qStar) {
             const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
             const uint32_t bound = Bn == endBit ? 0xFFFFFFF0u : Bn;
@@ -500,7 +533,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
                 if (cd_e_pair(e) && cur.pos + cd_e_len(e) < bound) {
                     // two plain values in the window: the first one is complete (a value follows it, not an escape)
                     started = true;
-                    sink.one(k, cd_e_sym(e) - 128u);
+                    sink.put(k, cd_e_sym(e) - 128u);
                     k++;
                     cur.advance(T, cd_e_len(e));
                     w = cur.window();
@@ -526,9 +559,14 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
                     else if (tk.sym != 260u) break;
                     cur.advance(T, tk.bits);
                 }
-                sink.one(k, v);
+                sink.put(k, v);
                 k++;
             }
+        }
+        if constexpr (Sink::kStaged) {             // this half's small values wait in LDS: out with them, whole lines at a time
+            __syncthreads();
+            sink.expand(j == 0 ? min(firstHalf, nValues) : nValues - min(firstHalf, nValues));
+            __syncthreads();
         }
     }
     // a text shorter than its reader expects leaves zeros (fresh int[] in Java)

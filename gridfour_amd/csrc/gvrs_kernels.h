@@ -74,6 +74,7 @@ struct GfDecodeArgs {
     int nRows, nCols;
     uint32_t ldsM32Bytes;      // capacity of the in-LDS M32 buffer
     uint32_t ldsTextBytes;     // capacity of the in-LDS copy of the packing (multiple of 16)
+    uint32_t ldsStageBytes;    // k_canon_decode: bytes of value staging behind the text copy (gf_canon_decode_lds_stage)
     int phaseLimit;            // diagnostic: stop after phase 0/1/2 (value 1/2/3); 0 = run everything
     uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
     int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
@@ -138,6 +139,7 @@ hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
 size_t gf_canon_pack_rec_words();      // words per tile of GfEncodeArgs::packRecs for the canonical encoder
 hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 uint32_t gf_canon_decode_lds_text(int nRows, int nCols);
+uint32_t gf_canon_decode_lds_stage(int nRows, int nCols);
 
 // status (optional): tiles whose status is not GF_K_OK take no room in the blob
 hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStride,
