@@ -10,7 +10,7 @@ from ._lib import (GvrsHipError, OK, DECLINED, OVERFLOW, ERR_FORMAT, ERR_BOUNDS,
                    ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, PM_ALL, lib, lib_path)
 from .codec import (CodecMasterHip, STANDARD_CODEC_LIST, CodecHuffmanHip, CodecDeflateHip, CodecCanonHuffmanHip, CodecFloatHip, LsCodecHip, GvrsHipContext, DeviceBuffer, DeviceTileBatch, GpuTimer,  # noqa: F401
                     INT4_NULL_CODE)
-from .sharding import shard_range, GvrsHipMulti, PinnedArray  # noqa: F401
+from .sharding import shard_range, GvrsHipMulti, PinnedArray, TileReadAhead  # noqa: F401
 
 __all__ = ["CodecHuffmanHip", "CodecCanonHuffmanHip", "CodecDeflateHip", "CodecFloatHip", "LsCodecHip", "GvrsHipContext", "GvrsHipError", "INT4_NULL_CODE", "lib", "lib_path",
-           "shard_range", "GvrsHipMulti", "PinnedArray"]
+           "shard_range", "GvrsHipMulti", "PinnedArray", "TileReadAhead"]

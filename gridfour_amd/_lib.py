@@ -105,6 +105,12 @@ SIGNATURES = {
     "gf_float_decode_batch_f32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
     "gf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "gf_host_free": (C.c_int, [_vp]),
+    "gf_readahead_create": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(_vp)]),
+    "gf_readahead_destroy": (None, [_vp]),
+    "gf_readahead_submit": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
+    "gf_readahead_pending": (C.c_int, [_vp]),
+    "gf_readahead_take": (C.c_int, [_vp, C.c_int32, C.c_size_t, _vp, _vp, _vp, C.POINTER(C.c_size_t)]),
+    "gf_readahead_counters": (None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gf_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     "gf_multi_destroy": (None, [_vp]),
     "gf_multi_count": (C.c_int, [_vp]),

@@ -24,7 +24,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvrs_hip.so")
 LIB_DIAG = os.path.join(LIBDIR, "libgvrs_hip_diag.so")
 SOURCES = ["gvrs_api.hip", "gvrs_multi.hip", "gvrs_encode.hip", "gvrs_decode.hip", "gvrs_aux.hip", "gvrs_float.hip",
-           "gvrs_canon_encode.hip", "gvrs_canon_decode.hip", "gvrs_lsop.hip", "gvrs_lsop_decode.hip", "gvrs_inflate.hip"]
+           "gvrs_canon_encode.hip", "gvrs_canon_decode.hip", "gvrs_lsop.hip", "gvrs_lsop_decode.hip", "gvrs_inflate.hip",
+           "gvrs_readahead.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 

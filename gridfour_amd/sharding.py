@@ -120,3 +120,50 @@ class GvrsHipMulti:
             self.close()
         except Exception:
             pass
+
+
+class TileReadAhead:
+    """gf_readahead: the tile cache's reading assistant (gvrs/TileDecompressionAssistant.java) as an N-tile prefetch queue.
+    submit() copies a tile's element bytes and returns; a background thread inside the library decodes whatever is queued as
+    one GPU batch; take() is getTilesWithWaitForIndex."""
+
+    def __init__(self, n_rows, n_cols, codecs=(1, 2, 0, 3), device=0, max_batch=1024):
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.cells = self.n_rows * self.n_cols
+        cd = (C.c_int * len(codecs))(*[int(c) for c in codecs])
+        self._h = C.c_void_p()
+        check(lib().gf_readahead_create(int(device), cd, len(codecs), self.n_rows, self.n_cols, int(max_batch), C.byref(self._h)),
+              "gf_readahead_create")
+
+    def submit(self, tile_index, packing):
+        b = np.frombuffer(bytes(packing), dtype=np.uint8)
+        check(lib().gf_readahead_submit(self._h, int(tile_index), _ptr(b) if b.size else None, b.size), "gf_readahead_submit")
+
+    def pending(self):
+        return int(lib().gf_readahead_pending(self._h))
+
+    def take(self, wait_index, max_tiles=64):
+        """Returns {tile_index: (values int32[cells], status)} of up to max_tiles finished tiles, wait_index first."""
+        idx = np.zeros(max_tiles, np.int32)
+        st = np.zeros(max_tiles, np.int32)
+        vals = np.empty((max_tiles, self.cells), np.int32)
+        n = C.c_size_t(0)
+        check(lib().gf_readahead_take(self._h, int(wait_index), max_tiles, _ptr(idx), _ptr(vals), _ptr(st), C.byref(n)),
+              "gf_readahead_take")
+        return {int(idx[i]): (vals[i].copy(), int(st[i])) for i in range(n.value)}
+
+    def counters(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        lib().gf_readahead_counters(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().gf_readahead_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

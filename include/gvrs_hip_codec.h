@@ -341,6 +341,27 @@ gf_status gf_tile_payload_decode_batch_i32(gf_context *ctx, const int *codecs, i
                                            size_t n_tiles, const uint8_t *blob, const uint64_t *offsets, int32_t *values,
                                            int32_t *status);
 
+/* ---- read-ahead: gvrs/TileDecompressionAssistant.java:60-230 and its caller gvrs/RasterTileCache.java:339-426
+ * as an N-tile prefetch queue.  The reference's assistant decodes ONE predicted tile on a background thread; this one takes
+ * everything that is queued when it wakes up (at most max_batch tiles) and decodes it as one GPU batch through
+ * gf_tile_payload_decode_batch_i32, on a context of its own on `device` (the application thread may use its own context
+ * at the same time, as the reference's main thread uses its own CodecMaster).
+ *   gf_readahead_submit   submitDecompression: `packing` = the element bytes RecordManager.readTilePacking returns (a
+ *                         CodecMaster packing, or 4*cells raw little-endian bytes); copied, returns at once
+ *   gf_readahead_pending  getPendingTaskCount: queued + in progress
+ *   gf_readahead_take     getTilesWithWaitForIndex: waits while wait_index is queued or in progress, then hands over up to
+ *                         max_tiles finished tiles (indices[i], values + i*cells, status[i]); the tile waited for comes first.
+ *                         Tiles that do not fit stay for the next call.  A wait_index that was never submitted does not wait. */
+typedef struct gf_readahead gf_readahead;
+gf_status gf_readahead_create(int device, const int *codecs, int n_codecs, int n_rows, int n_cols, size_t max_batch,
+                              gf_readahead **ra);
+void gf_readahead_destroy(gf_readahead *ra);
+gf_status gf_readahead_submit(gf_readahead *ra, int32_t tile_index, const uint8_t *packing, size_t len);
+int gf_readahead_pending(gf_readahead *ra);
+gf_status gf_readahead_take(gf_readahead *ra, int32_t wait_index, size_t max_tiles, int32_t *indices, int32_t *values,
+                            int32_t *status, size_t *n_out);
+void gf_readahead_counters(gf_readahead *ra, uint64_t *n_batches, uint64_t *n_tiles);   /* GPU batches run, tiles decoded */
+
 /* ---- ICompressionDecoder.analyze for CodecHuffman (compress/CodecHuffman.java:172-234, compress/CodecStats.java:49-290):
  * the per-predictor statistics the reference gathers by decoding every packing on the CPU, from a GPU pass that
  * Huffman-decodes the batch and histograms the M32 bytes.  stats[0..4] by predictor code (None, Differencing, Linear,
