@@ -80,6 +80,8 @@ SIGNATURES = {
     "gf_tile_payload_encode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp]),
     "gf_tile_payload_decode_batch_i32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
     "gf_huffman_analyze_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_huffman_analyze_batch_h2": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp, _vp]),
+    "gf_codec_stats_h2": (C.c_double, [_vp]),
     "gf_tile_record_max_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "gf_crc32c": (C.c_uint32, [_vp, C.c_size_t]),
     "gf_tile_record_encode_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_int,

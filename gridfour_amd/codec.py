@@ -136,9 +136,21 @@ class CodecHuffmanHip:
         offsets[1:] = np.cumsum([len(p) for p in packings])
         blob = np.frombuffer(b"".join(packings) + b"\0" * 16, dtype=np.uint8)
         status = np.zeros(nt, np.int32)
-        check(lib().gf_huffman_analyze_batch(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets), _ptr(self._stats),
-                                             _ptr(status)), "gf_huffman_analyze_batch")
+        if getattr(self, "_pairs", None) is None:
+            self._pairs = np.zeros((6, 65536), np.int64)          # sB of the six CodecStats (CodecStats.java:64)
+        check(lib().gf_huffman_analyze_batch_h2(self.ctx.handle, nRows, nCols, nt, _ptr(blob), _ptr(offsets), _ptr(self._stats),
+                                                _ptr(self._pairs), _ptr(status)), "gf_huffman_analyze_batch_h2")
         return status
+
+    def pair_counts(self):
+        """sB[(prior << 8) | value] of the six CodecStats (five predictors, all)."""
+        p = getattr(self, "_pairs", None)
+        return None if p is None else p.copy()
+
+    def getH2(self, k=5):
+        """CodecStats.getH2 of record k (0..4 by predictor code, 5 = all predictors)."""
+        p = getattr(self, "_pairs", None)
+        return 0.0 if p is None else float(lib().gf_codec_stats_h2(_ptr(np.ascontiguousarray(p[k]))))
 
     def analysis_data(self):
         """The accumulated sums, one record per predictor code 0..4 and one for all (CodecStats fields)."""
@@ -164,6 +176,7 @@ class CodecHuffmanHip:
 
     def clearAnalysisData(self):
         self._stats = None
+        self._pairs = None
 
     # ---- batched forms (host memory) ----
     def encode_batch(self, codecIndex, nRows, nCols, tiles):

@@ -340,7 +340,8 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
 
 static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
                                 const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets, size_t slotStride,
-                                const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus, uint32_t *analysis = nullptr)
+                                const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus, uint32_t *analysis = nullptr,
+                                uint32_t *pairCounts = nullptr)
 {
     if (!c || nRows < 1 || nCols < 1 || !dBlob || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
@@ -371,6 +372,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     a.debug = g_decodeDebug;
     a.rawM32 = kind == KIND_RAW_M32 ? 1 : 0;
     a.analysis = analysis;
+    a.pairCounts = pairCounts;
     a.trees = nullptr;
     a.retryFlag = nullptr;
     if (kind == KIND_HUFFMAN) {
@@ -2202,9 +2204,9 @@ gf_status gf_tile_record_decode_batch(gf_context *c, const int *codecs, int nCod
 // the 256-bin histogram of the M32 bytes; the sums of CodecStats.addToCounts / addCountsForM32 (compress/CodecStats.java:
 // 100-141) are then accumulated here in tile order.  stats[p], p = 0..4 by predictor code (PredictorModelType ordinal),
 // stats[5] = "All Predictors"; counts ADD to what stats already holds (clearAnalysisData = zero the array).  The pair
-// counts behind CodecStats.getH2 (not part of reportAnalysisData) are not collected.
-gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob, const uint64_t *offsets,
-                                   gf_codec_stats *stats, int32_t *status)
+// counts behind CodecStats.getH2 (sA / sB) come from the same pass when the caller hands in tables for them.
+static gf_status analyzeBatch(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob, const uint64_t *offsets,
+                              gf_codec_stats *stats, int64_t *pairCounts, int32_t *status)
 {
     if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !stats) return GF_ERR_ARG;
     if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
@@ -2217,6 +2219,13 @@ gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t n
     if ((s = c->dOffsets.ensure((nTiles + 1) * 8 + 16)) != GF_OK) return s;
     if ((s = c->dResiduals.ensure(nTiles * GF_ANALYSIS_WORDS * 4 + 16)) != GF_OK) return s;
     if ((s = c->dValues.ensure(16)) != GF_OK) return s;
+    uint32_t *dPairs = nullptr;
+    const size_t pairWords = (size_t)GF_PAIR_TABLES * 65536;
+    if (pairCounts) {
+        if ((s = c->dCoefs.ensure(pairWords * 4)) != GF_OK) return s;
+        dPairs = (uint32_t *)c->dCoefs.p;
+        GF_HIP(hipMemsetAsync(dPairs, 0, pairWords * 4, c->stream));
+    }
     std::vector<uint32_t> lengths(nTiles);
     for (size_t t = 0; t < nTiles; t++) {
         if (offsets[t + 1] < offsets[t]) return GF_ERR_ARG;
@@ -2227,8 +2236,13 @@ gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t n
     GF_HIP(hipMemcpyAsync(c->dLengths.p, lengths.data(), nTiles * 4, hipMemcpyHostToDevice, c->stream));
     s = decodeBatchDev(KIND_HUFFMAN, c, c->stream, nRows, nCols, nTiles, (const uint8_t *)c->dBlob.p, total,
                        (const uint64_t *)c->dOffsets.p, 0, (const uint32_t *)c->dLengths.p, (int32_t *)c->dValues.p,
-                       (int32_t *)c->dStatus.p, (uint32_t *)c->dResiduals.p);
+                       (int32_t *)c->dStatus.p, (uint32_t *)c->dResiduals.p, dPairs);
     if (s != GF_OK) return s;
+    std::vector<uint32_t> pairs;
+    if (pairCounts) {
+        pairs.resize(pairWords);
+        GF_HIP(hipMemcpyAsync(pairs.data(), dPairs, pairWords * 4, hipMemcpyDeviceToHost, c->stream));
+    }
     std::vector<uint32_t> rec(nTiles * GF_ANALYSIS_WORDS);
     std::vector<int32_t> st(nTiles);
     GF_HIP(hipMemcpyAsync(rec.data(), c->dResiduals.p, rec.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2267,7 +2281,57 @@ gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t n
             }
         }
     }
+    if (pairCounts) {
+        // sB of the predictor's CodecStats and of "All Predictors" (CodecHuffman.java:186-196 feeds both)
+        for (int m = 0; m < GF_PAIR_TABLES; m++)
+            for (size_t i = 0; i < 65536; i++) {
+                const int64_t n = pairs[(size_t)m * 65536 + i];
+                pairCounts[(size_t)m * 65536 + i] += n;
+                pairCounts[(size_t)5 * 65536 + i] += n;
+            }
+    }
     return GF_OK;
+}
+
+gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob, const uint64_t *offsets,
+                                   gf_codec_stats *stats, int32_t *status)
+{
+    return analyzeBatch(c, nRows, nCols, nTiles, blob, offsets, stats, nullptr, status);
+}
+
+gf_status gf_huffman_analyze_batch_h2(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                      const uint64_t *offsets, gf_codec_stats *stats, int64_t *pairCounts, int32_t *status)
+{
+    if (!pairCounts) return GF_ERR_ARG;
+    return analyzeBatch(c, nRows, nCols, nTiles, blob, offsets, stats, pairCounts, status);
+}
+
+// CodecStats.getH2 (CodecStats.java:157-190) from one table of pair counts: sA[v] is the column sum of sB
+double gf_codec_stats_h2(const int64_t *sB)
+{
+    if (!sB) return 0.0;
+    std::vector<int64_t> sA(256, 0);
+    int64_t k = 0;
+    for (int p = 0; p < 256; p++)
+        for (int v = 0; v < 256; v++) sA[v] += sB[p * 256 + v];
+    for (int i = 0; i < 256; i++) k += sA[i];
+    if (k == 0) return 0.0;
+    double h2 = 0;
+    for (int i = 0; i < 256; i++) {
+        if (sA[i] > 0) {
+            const double pI = (double)sA[i] / (double)k;
+            int64_t n = 0;
+            for (int j = i * 256; j < i * 256 + 256; j++) n += sB[j];
+            double sumJ = 0;
+            for (int j = i * 256; j < i * 256 + 256; j++)
+                if (sB[j] > 0) {
+                    const double pJ = (double)sB[j] / (double)n;
+                    sumJ += pJ * std::log(pJ);
+                }
+            h2 += pI * sumJ;
+        }
+    }
+    return -h2;
 }
 
 }  // extern "C"

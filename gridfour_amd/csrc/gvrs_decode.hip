@@ -1766,6 +1766,10 @@ __global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDe
                 for (uint32_t i = tid; i < 256; i += DEC_THREADS) hist[i] = 0;
                 __syncthreads();
                 for (uint32_t i = tid; i < nM32; i += DEC_THREADS) atomicAdd(&hist[m32[i]], 1u);
+                if (a.pairCounts && nM32 >= 2u) {                        // sB[(prior << 8) | value]++ (CodecStats.java:150-156)
+                    uint32_t *pc = a.pairCounts + (size_t)(model >= 0 && model < GF_PAIR_TABLES ? model : 0) * 65536u;
+                    for (uint32_t i = tid + 1u; i < nM32; i += DEC_THREADS) atomicAdd(&pc[((uint32_t)m32[i - 1u] << 8) | m32[i]], 1u);
+                }
                 __syncthreads();
                 uint32_t *rec = a.analysis + t * GF_ANALYSIS_WORDS;
                 if (tid == 0) {

@@ -84,8 +84,11 @@ struct GfDecodeArgs {
                                // the launch only)
     uint32_t *analysis;        // non-null: CodecHuffman.analyze mode -- per tile GF_ANALYSIS_WORDS words (predictor, nM32,
                                // bits in tree, packing bytes - 10, 256-bin histogram of the M32 bytes); no values are written
+    uint32_t *pairCounts;      // analyze mode, may be null: GF_PAIR_TABLES x 65536 counters, [predictor][prior << 8 | value] of
+                               // neighbouring M32 bytes (CodecStats.addCountsForM32 :150-156), added to with atomics
 };
 constexpr int GF_ANALYSIS_WORDS = 260;
+constexpr int GF_PAIR_TABLES = 5;               // one 65536-bin table of byte pairs per predictor code (CodecStats.sB)
 // per-tile record of the tree pre-pass: 8 header words (status, leaves, bit position of the first code, longest code,
 // single-symbol value or -1, 3 spare), then 256 x (path bits uint64), 256 x code length, 256 x symbol
 constexpr int GF_TREE_REC_WORDS = 8 + 512 + 64 + 64;

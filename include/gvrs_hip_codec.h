@@ -380,6 +380,12 @@ typedef struct gf_codec_stats {
 } gf_codec_stats;
 gf_status gf_huffman_analyze_batch(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
                                    const uint64_t *offsets, gf_codec_stats *stats, int32_t *status);
+/* The same pass with the pair counts behind CodecStats.getH2 (CodecStats.java:63-64, 150-190): pair_counts = six tables of
+ * 65536 int64, table k = sB of stats[k], entry (prior << 8) | value counts neighbouring M32 bytes; the call ADDS to them
+ * (sA is the column sum of sB).  gf_codec_stats_h2(table) = getH2() of that CodecStats (natural logarithm, as there).   */
+gf_status gf_huffman_analyze_batch_h2(gf_context *ctx, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                      const uint64_t *offsets, gf_codec_stats *stats, int64_t *pair_counts, int32_t *status);
+double gf_codec_stats_h2(const int64_t *pair_table);
 
 /* ---- tile records (gvrs/RecordManager.java:153-204, 217-262, 386-520; gvrs/TileElementInt.java:196-219,
  * gvrs/TileElementShort.java:211-250; util/GridfourCRC32C.java): what RecordManager.writeTile appends to the file for a

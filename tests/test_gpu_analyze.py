@@ -72,6 +72,60 @@ def test_analysis_sums_match_the_oracle():
     assert "Tiles Compressed:  0" in out.getvalue()
 
 
+def _expected_h2(packings, k):
+    """CodecStats.addCountsForM32 :150-156 and getH2 :157-190 restated: pair counts of neighbouring M32 bytes, then the
+    conditional entropy (natural logarithm) the reference computes from them."""
+    sA = np.zeros(256, np.int64)
+    sB = np.zeros(65536, np.int64)
+    for pk in packings:
+        if k != 5 and pk[1] != k:
+            continue
+        n_m32 = struct.unpack_from("<i", pk, 6)[0]
+        m32, _ = oracle.huffman_decode(pk[10:], n_m32, 0)
+        b = np.frombuffer(m32[:n_m32], np.uint8).astype(np.int64)
+        if n_m32 < 2:
+            continue
+        np.add.at(sA, b[1:], 1)
+        np.add.at(sB, (b[:-1] << 8) | b[1:], 1)
+    total = int(sA.sum())
+    if total == 0:
+        return 0.0, sB
+    h2 = 0.0
+    for i in range(256):
+        if sA[i] > 0:
+            p_i = sA[i] / float(total)
+            row = sB[i * 256:(i + 1) * 256]
+            n = float(row.sum())
+            s = sum((c / n) * math.log(c / n) for c in row if c > 0)
+            h2 += p_i * s
+    return -h2, sB
+
+
+def test_h2_pair_counts_match_the_oracle():
+    """The sA / sB tables of CodecStats (the pair counts behind getH2) from the GPU pass, per predictor and for all."""
+    import gridfour_amd
+    codec = gridfour_amd.CodecHuffmanHip()
+    nr, nc = 60, 90
+    tiles = [make_tile(k, nr, nc, seed=s) for s, k in enumerate(["smooth", "ramp", "noise8", "noise16", "steps", "sparse_big", "smooth",
+                                                                   "noise8", "steps"])]
+    with_nulls = make_tile("smooth", nr, nc, seed=41).copy()
+    with_nulls.reshape(nr, nc)[5:15, 20:60] = NULL
+    tiles.append(with_nulls)
+    packs, preds, st = codec.encode_batch(0, nr, nc, np.stack(tiles))
+    packs = [p for p in packs if p is not None]
+    codec.clearAnalysisData()
+    assert (codec.analyze_batch(nr, nc, packs[:4]) == 0).all()
+    assert (codec.analyze_batch(nr, nc, packs[4:]) == 0).all()          # a second batch accumulates
+    got = codec.pair_counts()
+    for k in range(6):
+        want_h2, want_sB = _expected_h2(packs, k)
+        assert np.array_equal(got[k], want_sB), k
+        assert codec.getH2(k) == pytest.approx(want_h2, rel=1e-12, abs=1e-12)
+    assert codec.getH2(5) > 0.0
+    codec.clearAnalysisData()
+    assert codec.getH2(5) == 0.0
+
+
 def test_analysis_rejects_damaged_packings():
     import gridfour_amd
     codec = gridfour_amd.CodecHuffmanHip()
