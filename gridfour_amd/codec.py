@@ -111,6 +111,8 @@ class CodecHuffmanHip:
         st = self._fn("decode_i32")(self.ctx.handle, nRows, nColumns, _ptr(p), p.size, _ptr(out))
         if st in (_lib.ERR_FORMAT, _lib.ERR_BOUNDS):
             raise IOError(lib().gf_status_string(st).decode())
+        if st == _lib.DECLINED:                      # CodecDeflate.decode: the inflater gave nothing -> null (:143-154)
+            return None
         check(st, self._PREFIX + "_decode_i32")
         return out
 

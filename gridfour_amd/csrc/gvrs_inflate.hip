@@ -504,7 +504,8 @@ __global__ void k_deflate_lengths(size_t nTiles, const GfInflateStream *__restri
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nTiles) return;
     int32_t st = pre[i];
-    if (st == GF_K_OK && (inflStatus[i] != GF_K_OK || produced[i] == 0)) st = GF_K_ERR_FORMAT;   // DataFormatException / inflate gave nothing
+    if (st == GF_K_OK && inflStatus[i] != GF_K_OK) st = GF_K_ERR_FORMAT;        // DataFormatException -> IOException
+    else if (st == GF_K_OK && produced[i] == 0) st = GF_K_DECLINED;             // inflate gave nothing: decode returns null (:143-154)
     pre[i] = st;
     rawLengths[i] = st == GF_K_OK ? 10u + desc[i].outCap : 0u;
 }

@@ -7,6 +7,9 @@
 // One gf_context per adapter instance; CodecHolder creates one instance per codec
 // (gvrs/CodecHolder.java:208-234) and the decoder may be called from two threads
 // (gvrs/TileDecompressionAssistant.java:68-73), hence the mutex around context use.
+// Java arrays are copied to and from native buffers with Get/Set<Type>ArrayRegion OUTSIDE the lock: no JNI critical region
+// is ever open while this code waits for the mutex, copies over PCIe, launches kernels or synchronises a stream (the JNI
+// specification forbids blocking inside GetPrimitiveArrayCritical regions).
 #include <jni.h>
 
 #include <mutex>
@@ -23,6 +26,43 @@ void throwIo(JNIEnv *env, const char *msg)
 {
     jclass c = env->FindClass("java/io/IOException");
     if (c) env->ThrowNew(c, msg);
+}
+// the handle of a native method: null (a create that failed, a closed adapter) raises IllegalStateException
+Handle *handleOf(JNIEnv *env, jlong handle)
+{
+    Handle *h = (Handle *)(intptr_t)handle;
+    if (!h || !h->ctx) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, "the native HIP codec is not open");
+        return nullptr;
+    }
+    return h;
+}
+std::vector<int32_t> intsOf(JNIEnv *env, jintArray a)
+{
+    const jsize n = a ? env->GetArrayLength(a) : 0;
+    std::vector<int32_t> v((size_t)n + 1);
+    if (n) env->GetIntArrayRegion(a, 0, n, (jint *)v.data());
+    return v;
+}
+std::vector<uint8_t> bytesOf(JNIEnv *env, jbyteArray a)
+{
+    const jsize n = a ? env->GetArrayLength(a) : 0;
+    std::vector<uint8_t> v((size_t)n + 16);          // the decoders read whole words
+    if (n) env->GetByteArrayRegion(a, 0, n, (jbyte *)v.data());
+    return v;
+}
+// cells of a tile batch: int[] (GF_ELEM_INT) or short[] (GF_ELEM_SHORT)
+std::vector<uint8_t> cellsOf(JNIEnv *env, jobject cells, int elemType)
+{
+    const jsize n = env->GetArrayLength((jarray)cells);
+    const size_t w = elemType == GF_ELEM_SHORT ? 2 : 4;
+    std::vector<uint8_t> v((size_t)n * w + 16);
+    if (n) {
+        if (elemType == GF_ELEM_SHORT) env->GetShortArrayRegion((jshortArray)cells, 0, n, (jshort *)v.data());
+        else env->GetIntArrayRegion((jintArray)cells, 0, n, (jint *)v.data());
+    }
+    return v;
 }
 }  // namespace
 
@@ -52,16 +92,16 @@ JNIEXPORT void JNICALL Java_org_gridfour_hip_CodecHuffmanHip_destroyNative(JNIEn
 JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_encodeNative(JNIEnv *env, jclass, jlong handle, jint codecIndex,
                                                                                jint nRows, jint nCols, jintArray values)
 {
-    Handle *h = (Handle *)(intptr_t)handle;
+    Handle *h = handleOf(env, handle);
+    if (!h) return nullptr;
     const size_t cap = gf_huffman_max_packing(nRows, nCols);
     jbyte *out = new jbyte[cap];
     size_t n = 0;
     gf_status s;
+    const std::vector<int32_t> v = intsOf(env, values);
     {
         std::lock_guard<std::mutex> g(h->lock);
-        jint *v = (jint *)env->GetPrimitiveArrayCritical(values, nullptr);
-        s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
-        env->ReleasePrimitiveArrayCritical(values, v, JNI_ABORT);
+        s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, v.data(), (uint8_t *)out, cap, &n);
     }
     jbyteArray result = nullptr;
     if (s == GF_OK) {
@@ -82,23 +122,22 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_encodeNative(
 JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(JNIEnv *env, jclass, jlong handle, jint nRows,
                                                                               jint nCols, jbyteArray packing)
 {
-    Handle *h = (Handle *)(intptr_t)handle;
+    Handle *h = handleOf(env, handle);
+    if (!h) return nullptr;
     const jsize len = env->GetArrayLength(packing);
-    jintArray result = env->NewIntArray(nRows * nCols);
-    if (!result) return nullptr;
+    const std::vector<uint8_t> p = bytesOf(env, packing);
+    std::vector<int32_t> o((size_t)nRows * (size_t)nCols + 1);
     gf_status s;
     {
         std::lock_guard<std::mutex> g(h->lock);
-        jbyte *p = (jbyte *)env->GetPrimitiveArrayCritical(packing, nullptr);
-        jint *o = (jint *)env->GetPrimitiveArrayCritical(result, nullptr);
-        s = gf_huffman_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
-        env->ReleasePrimitiveArrayCritical(result, o, 0);
-        env->ReleasePrimitiveArrayCritical(packing, p, JNI_ABORT);
+        s = gf_huffman_decode_i32(h->ctx, nRows, nCols, p.data(), (size_t)len, o.data());
     }
     if (s != GF_OK) {
         throwIo(env, gf_status_string(s));
         return nullptr;
     }
+    jintArray result = env->NewIntArray(nRows * nCols);
+    if (result) env->SetIntArrayRegion(result, 0, nRows * nCols, (const jint *)o.data());
     return result;
 }
 
@@ -119,21 +158,22 @@ JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_destroy(JNIEnv *env,
 JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_encode(JNIEnv *env, jclass, jlong handle, jint kind,
                                                                          jint codecIndex, jint nRows, jint nCols, jintArray values)
 {
-    Handle *h = (Handle *)(intptr_t)handle;
+    Handle *h = handleOf(env, handle);
+    if (!h) return nullptr;
     const size_t cap = kind == 0 ? gf_huffman_max_packing(nRows, nCols)
                      : kind == 1 ? gf_canon_max_packing(nRows, nCols)
                      : kind == 4 ? gf_m32_max_stream(nRows, nCols) + 256 : gf_lsop12_max_packing(nRows, nCols) + 64;
     jbyte *out = new jbyte[cap];
     size_t n = 0;
     gf_status s;
+    const std::vector<int32_t> vals = intsOf(env, values);
+    const int32_t *v = vals.data();
     {
         std::lock_guard<std::mutex> g(h->lock);
-        jint *v = (jint *)env->GetPrimitiveArrayCritical(values, nullptr);
-        if (kind == 0) s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
-        else if (kind == 1) s = gf_canon_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
-        else if (kind == 4) s = gf_deflate_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, (uint8_t *)out, cap, &n);
-        else s = gf_lsop12_encode_i32(h->ctx, codecIndex, nRows, nCols, (const int32_t *)v, kind == 3, (uint8_t *)out, cap, &n);
-        env->ReleasePrimitiveArrayCritical(values, v, JNI_ABORT);
+        if (kind == 0) s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, v, (uint8_t *)out, cap, &n);
+        else if (kind == 1) s = gf_canon_encode_i32(h->ctx, codecIndex, nRows, nCols, v, (uint8_t *)out, cap, &n);
+        else if (kind == 4) s = gf_deflate_encode_i32(h->ctx, codecIndex, nRows, nCols, v, (uint8_t *)out, cap, &n);
+        else s = gf_lsop12_encode_i32(h->ctx, codecIndex, nRows, nCols, v, kind == 3, (uint8_t *)out, cap, &n);
     }
     jbyteArray result = nullptr;
     if (s == GF_OK) {
@@ -156,26 +196,28 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_encode(JNIEnv 
 JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_HipCodecNative_decode(JNIEnv *env, jclass, jlong handle, jint kind, jint nRows,
                                                                         jint nCols, jbyteArray packing)
 {
-    Handle *h = (Handle *)(intptr_t)handle;
+    Handle *h = handleOf(env, handle);
+    if (!h) return nullptr;
     const jsize len = env->GetArrayLength(packing);
-    jintArray result = env->NewIntArray(nRows * nCols);
-    if (!result) return nullptr;
+    const std::vector<uint8_t> pk = bytesOf(env, packing);
+    const uint8_t *p = pk.data();
+    std::vector<int32_t> out((size_t)nRows * (size_t)nCols + 1);
+    int32_t *o = out.data();
     gf_status s;
     {
         std::lock_guard<std::mutex> g(h->lock);
-        jbyte *p = (jbyte *)env->GetPrimitiveArrayCritical(packing, nullptr);
-        jint *o = (jint *)env->GetPrimitiveArrayCritical(result, nullptr);
-        if (kind == 0) s = gf_huffman_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
-        else if (kind == 1) s = gf_canon_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
-        else if (kind == 4) s = gf_deflate_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
-        else s = gf_lsop12_decode_i32(h->ctx, nRows, nCols, (const uint8_t *)p, (size_t)len, (int32_t *)o);
-        env->ReleasePrimitiveArrayCritical(result, o, 0);
-        env->ReleasePrimitiveArrayCritical(packing, p, JNI_ABORT);
+        if (kind == 0) s = gf_huffman_decode_i32(h->ctx, nRows, nCols, p, (size_t)len, o);
+        else if (kind == 1) s = gf_canon_decode_i32(h->ctx, nRows, nCols, p, (size_t)len, o);
+        else if (kind == 4) s = gf_deflate_decode_i32(h->ctx, nRows, nCols, p, (size_t)len, o);
+        else s = gf_lsop12_decode_i32(h->ctx, nRows, nCols, p, (size_t)len, o);
     }
+    if (s == GF_DECLINED) return nullptr;          // CodecDeflate.decode: the inflater gave nothing -> null (CodecDeflate.java:143-154)
     if (s != GF_OK) {
         throwIo(env, gf_status_string(s));
         return nullptr;
     }
+    jintArray result = env->NewIntArray(nRows * nCols);
+    if (result) env->SetIntArrayRegion(result, 0, nRows * nCols, (const jint *)o);
     return result;
 }
 
@@ -186,7 +228,8 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_tileRecords(JN
                                                                               jintArray tileIndices, jobject cells, jboolean checksums,
                                                                               jlongArray recordOffsets)
 {
-    Handle *h = (Handle *)(intptr_t)handle;
+    Handle *h = handleOf(env, handle);
+    if (!h) return nullptr;
     const jsize nTiles = env->GetArrayLength(tileIndices), nCodecs = env->GetArrayLength(codecKinds);
     if (env->GetArrayLength(recordOffsets) < nTiles + 1) return nullptr;
     const size_t cap = (size_t)nTiles * gf_tile_record_max_bytes(elemType, nRows, nCols);
@@ -197,12 +240,11 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_tileRecords(JN
     std::vector<int32_t> idx((size_t)nTiles + 1);
     env->GetIntArrayRegion(tileIndices, 0, nTiles, (jint *)idx.data());
     gf_status s;
+    const std::vector<uint8_t> v = cellsOf(env, cells, elemType);
     {
         std::lock_guard<std::mutex> g(h->lock);
-        void *v = env->GetPrimitiveArrayCritical((jarray)cells, nullptr);
-        s = gf_tile_record_encode_batch(h->ctx, kinds.data(), nCodecs, elemType, fillValue, nRows, nCols, (size_t)nTiles, idx.data(), v,
-                                        checksums ? 1 : 0, blob.data(), cap, offsets.data(), nullptr);
-        env->ReleasePrimitiveArrayCritical((jarray)cells, v, JNI_ABORT);
+        s = gf_tile_record_encode_batch(h->ctx, kinds.data(), nCodecs, elemType, fillValue, nRows, nCols, (size_t)nTiles, idx.data(),
+                                        v.data(), checksums ? 1 : 0, blob.data(), cap, offsets.data(), nullptr);
     }
     if (s != GF_OK) {
         jclass c = env->FindClass("java/io/IOException");
@@ -222,29 +264,43 @@ JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_tilesFromRecords(JNI
                                                                              jlongArray recordOffsets, jboolean verifyChecksums,
                                                                              jintArray tileIndices, jobject cells, jintArray status)
 {
-    Handle *h = (Handle *)(intptr_t)handle;
+    Handle *h = handleOf(env, handle);
+    if (!h) return;
     const jsize nTiles = env->GetArrayLength(tileIndices), nCodecs = env->GetArrayLength(codecKinds);
     std::vector<int> kinds((size_t)nCodecs + 1);
     env->GetIntArrayRegion(codecKinds, 0, nCodecs, (jint *)kinds.data());
+    if (env->GetArrayLength(recordOffsets) < nTiles + 1 || env->GetArrayLength(status) < nTiles) {
+        jclass c = env->FindClass("java/lang/IllegalArgumentException");
+        if (c) env->ThrowNew(c, "recordOffsets needs nTiles + 1 entries, status nTiles");
+        return;
+    }
     std::vector<uint64_t> offsets((size_t)nTiles + 1);
     env->GetLongArrayRegion(recordOffsets, 0, nTiles + 1, (jlong *)offsets.data());
     std::vector<int32_t> idx((size_t)nTiles + 1), st((size_t)nTiles + 1);
     const jsize len = env->GetArrayLength(records);
     std::vector<uint8_t> blob((size_t)len + 16);
     env->GetByteArrayRegion(records, 0, len, (jbyte *)blob.data());
+    // the library checks that the offsets are monotone and inside the record bytes (GF_ERR_ARG otherwise)
+    if (offsets[(size_t)nTiles] > (uint64_t)len) {
+        jclass c = env->FindClass("java/lang/IllegalArgumentException");
+        if (c) env->ThrowNew(c, "recordOffsets run past the record bytes");
+        return;
+    }
     gf_status s;
+    const jsize nCells = env->GetArrayLength((jarray)cells);
+    std::vector<uint8_t> v((size_t)nCells * (elemType == GF_ELEM_SHORT ? 2 : 4) + 16);
     {
         std::lock_guard<std::mutex> g(h->lock);
-        void *v = env->GetPrimitiveArrayCritical((jarray)cells, nullptr);
         s = gf_tile_record_decode_batch(h->ctx, kinds.data(), nCodecs, elemType, nRows, nCols, (size_t)nTiles, blob.data(), offsets.data(),
-                                        verifyChecksums ? 1 : 0, idx.data(), v, st.data());
-        env->ReleasePrimitiveArrayCritical((jarray)cells, v, 0);
+                                        verifyChecksums ? 1 : 0, idx.data(), v.data(), st.data());
     }
     if (s != GF_OK) {
         jclass c = env->FindClass("java/io/IOException");
         if (c) env->ThrowNew(c, gf_last_error());
         return;
     }
+    if (elemType == GF_ELEM_SHORT) env->SetShortArrayRegion((jshortArray)cells, 0, nCells, (const jshort *)v.data());
+    else env->SetIntArrayRegion((jintArray)cells, 0, nCells, (const jint *)v.data());
     env->SetIntArrayRegion(tileIndices, 0, nTiles, (const jint *)idx.data());
     env->SetIntArrayRegion(status, 0, nTiles, (const jint *)st.data());
 }

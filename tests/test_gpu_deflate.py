@@ -159,3 +159,18 @@ def test_tile_payloads_equal_the_fixture_records(golden_dir):
     assert payloads[0] == struct.pack("<i", 10000) + noise.astype("<i4").tobytes()
     back, st = master.tiles_from_payloads(50, 50, payloads)
     assert (st == 0).all() and np.array_equal(back[0], noise) and np.array_equal(back[1], nulls)
+
+
+def test_decode_returns_null_when_the_inflater_gives_nothing(codec):
+    """CodecDeflate.decode :139-154: `int test = inflater.inflate(codeM32s); if (test > 0) {...} return null;` -- a packing
+    whose stream inflates to nothing (here: nM32 = 0, so there is no room) is null, not an exception; a stream that is no
+    deflate data is the IOException that wraps DataFormatException."""
+    import zlib
+    packing = bytes([2, 1]) + struct.pack("<i", 1234) + struct.pack("<i", 0) + zlib.compress(b"", 6)
+    assert codec.decode(8, 8, packing) is None
+    rc = oracle.lib().gvo_codec_deflate_decode(8, 8, oracle._p(oracle._u8(packing), oracle.C.c_uint8), len(packing),
+                                               oracle._p(np.zeros(64, np.int32), oracle.C.c_int32))
+    assert rc == oracle.DECLINED
+    not_deflate = bytes([2, 1]) + struct.pack("<i", 1234) + struct.pack("<i", 63) + bytes([0x78, 0x9C, 0xFF, 0xFF, 0xFF, 0xFF])
+    with pytest.raises(IOError):
+        codec.decode(8, 8, not_deflate)
