@@ -350,7 +350,10 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
 // the calls into the packers saving and restoring two dozen registers); apart, they run at six workgroups per CU
 // (80 VGPRs) resp. eight (64 VGPRs, with the wave-private windows of pack_flat_waves): 1.63 -> 1.40 ms on the ETOPO1-shaped
 // batch (sweep: 4..8 workgroups per CU each).
-constexpr int ENC_AB_WGS = 6, ENC_PACK_WGS = 8;
+#ifndef GF_ENC_PACK_WGS
+#define GF_ENC_PACK_WGS 8        // sweep: 8 -> 1.137 ms (15 spilled registers: 0.65 GB of scratch traffic), 5 -> 1.208 ms, no spills
+#endif
+constexpr int ENC_AB_WGS = 6, ENC_PACK_WGS = GF_ENC_PACK_WGS;
 
 constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel leaves this tile to the general one
 
