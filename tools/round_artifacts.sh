@@ -8,6 +8,10 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $OUT
 timeout 1200 python3 -m pytest tests -m gpu -q -rs > $OUT/pytest_gpu.txt 2>&1; tail -5 $OUT/pytest_gpu.txt
 timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
+# HBM traffic first (shipping library, all three integer codecs): the bench lines below replay it
+bash tools/pmc_hbm.sh $OUT/hbm etopo1 "huffman canon lsop" > $OUT/pmc_hbm.txt 2>&1
+cp $OUT/hbm/hbm_traffic.json $OUT/hbm_traffic.json 2>/dev/null && cp $OUT/hbm_traffic.json profiles/hbm_traffic.json
+rm -rf $OUT/hbm/FETCH_SIZE $OUT/hbm/WRITE_SIZE
 timeout 600 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench.json
 timeout 900 python3 tools/host_path_rate.py etopo1 2>/dev/null | tail -1 > $OUT/host_path_etopo1.json
 timeout 900 python3 tools/host_path_rate.py etopo1 2 2>/dev/null | tail -1 > $OUT/host_path_etopo1_multi2.json
@@ -19,6 +23,9 @@ timeout 600 python3 bench.py --codec lsop 2>/dev/null | tail -1 > $OUT/bench_lso
 timeout 600 python3 bench.py --workload dem1024 2>/dev/null | tail -1 > $OUT/bench_dem1024.json
 timeout 600 python3 bench.py --workload gebco_shard --cpu-sample-tiles 0 2>/dev/null | tail -1 > $OUT/bench_gebco_shard.json
 timeout 600 python3 bench.py --codec float --workload float256 2>/dev/null | tail -1 > $OUT/bench_float256.json
+timeout 900 python3 bench.py --codec lsop --workload float256_lsop 2>/dev/null | tail -1 > $OUT/bench_float256_lsop.json
+timeout 300 python3 tools/lsop_recon_time.py 2>/dev/null | tail -1 > $OUT/lsop_kernels_etopo1.json
+timeout 300 python3 tools/lsop_recon_time.py 256 256 4096 2>/dev/null | tail -1 > $OUT/lsop_kernels_256x256.json
 for c in "" canon lsop; do
   rm -rf $OUT/prof$c
   if [ -z "$c" ]; then
@@ -32,7 +39,18 @@ for c in "" canon lsop; do
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proff -- python3 bench.py --codec float --workload float256 --cpu-sample-tiles 0 > /dev/null 2>> $OUT/rocprof.log
 f=$(find $OUT/proff -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_float.csv; rm -rf $OUT/proff
-bash tools/pmc_hbm.sh $OUT/hbm etopo1 > $OUT/pmc_hbm.txt 2>&1
-cp $OUT/hbm/hbm_traffic.json $OUT/hbm_traffic.json 2>/dev/null
-rm -rf $OUT/hbm/FETCH_SIZE $OUT/hbm/WRITE_SIZE
+# the counters' calibration: 1 GiB read / written once with 4-, 8- and 16-byte accesses
+if [ -x tools/bin/fetch_calib ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/calib; rocprofv3 --pmc $c --output-format csv -d $OUT/calib -- tools/bin/fetch_calib > /dev/null 2>&1
+    python3 - <<PY >> $OUT/counter_calibration.txt
+import csv, glob
+for f in glob.glob("$OUT/calib/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == "$c" and "fillBuffer" not in row["Kernel_Name"]:
+            print("$c", row["Kernel_Name"].split("(")[0], "counter x 1024 / bytes moved =", round(float(row["Counter_Value"]) * 1024 / 2**30, 4))
+PY
+  done
+  rm -rf $OUT/calib
+fi
 head -c 600 $OUT/bench.json; echo; head -5 $OUT/kernel_stats.csv
