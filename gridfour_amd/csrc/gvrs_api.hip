@@ -906,7 +906,7 @@ static gf_status deflateDecodeDev(gf_context *c, hipStream_t st, int nRows, int 
         a.nStreams = n;
         a.window = gf_inflate_window((uint32_t)std::min<size_t>(6 * cells, 32768));
         GF_HIP(gf_launch_inflate(a, st));
-        GF_HIP(gf_launch_deflate_lengths(n, desc, produced, inflStatus, pre, rawLengths, st));
+        GF_HIP(gf_launch_deflate_lengths(n, desc, produced, inflStatus, pre, rawLengths, raw, st));
         s = decodeBatchDev(KIND_RAW_M32, c, st, nRows, nCols, n, raw, chunk * rawStride + 32, nullptr, rawStride, rawLengths,
                            dValues + t0 * cells, decStatus);
         if (s != GF_OK) return s;

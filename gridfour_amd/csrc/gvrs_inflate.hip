@@ -407,8 +407,11 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
                 const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;
                 const uint32_t dist = dbase + (dx ? inf_bits(z, dx) : 0u);
                 if (z.starved) break;
-                if (dist > pos) { status = GF_K_ERR_FORMAT; break; }                     // too far back
+                // zlib looks at the room before it looks at the distance (inflate.c, state MATCH: `if (left == 0) goto inf_leave`
+                // comes first, "invalid distance too far back" after it): a match that arrives when the room is used up ends the
+                // call without an error whatever its distance says
                 if (pos >= cap) { pos = cap + 1; break; }
+                if (dist > pos) { status = GF_K_ERR_FORMAT; break; }                     // too far back
                 // copy `len` bytes from `dist` back; source and destination may overlap (then the pattern repeats): go in
                 // pieces no longer than the distance, each piece with all lanes
                 uint32_t n = min(len, cap - pos);
@@ -499,11 +502,18 @@ __global__ void k_deflate_streams(const uint8_t *__restrict__ blob, size_t blobB
 
 // lengths of the raw containers for the decode kernel (0: the tile is out) and the status so far
 __global__ void k_deflate_lengths(size_t nTiles, const GfInflateStream *__restrict__ desc, const uint32_t *__restrict__ produced,
-                                  const int32_t *__restrict__ inflStatus, int32_t *__restrict__ pre, uint32_t *__restrict__ rawLengths)
+                                  const int32_t *__restrict__ inflStatus, int32_t *__restrict__ pre, uint32_t *__restrict__ rawLengths,
+                                  uint8_t *__restrict__ rawBase)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nTiles) return;
     int32_t st = pre[i];
+    // A stream that ends early (damaged input) fills only part of codeM32s; the rest of the Java array is zero
+    // (new byte[nM32], CodecDeflate.java:139) and the predictor may read it.  Rare, so one thread clears it.
+    if (st == GF_K_OK && inflStatus[i] == GF_K_OK && produced[i] > 0u && produced[i] < desc[i].outCap) {
+        uint8_t *p = rawBase + desc[i].outOffset;
+        for (uint32_t k = produced[i]; k < desc[i].outCap; k++) p[k] = 0;
+    }
     if (st == GF_K_OK && inflStatus[i] != GF_K_OK) st = GF_K_ERR_FORMAT;        // DataFormatException -> IOException
     else if (st == GF_K_OK && produced[i] == 0) st = GF_K_DECLINED;             // inflate gave nothing: decode returns null (:143-154)
     pre[i] = st;
@@ -651,11 +661,11 @@ hipError_t gf_launch_deflate_streams(const uint8_t *blob, size_t blobBytes, cons
 }
 
 hipError_t gf_launch_deflate_lengths(size_t nTiles, const GfInflateStream *desc, const uint32_t *produced, const int32_t *inflStatus,
-                                     int32_t *pre, uint32_t *rawLengths, hipStream_t stream)
+                                     int32_t *pre, uint32_t *rawLengths, uint8_t *rawBase, hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_deflate_lengths, dim3((unsigned)((nTiles + 255) / 256)), dim3(256), 0, stream, nTiles, desc, produced, inflStatus,
-                       pre, rawLengths);
+                       pre, rawLengths, rawBase);
     return hipGetLastError();
 }
 

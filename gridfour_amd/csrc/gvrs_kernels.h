@@ -197,7 +197,7 @@ hipError_t gf_launch_deflate_streams(const uint8_t *blob, size_t blobBytes, cons
                                      const uint32_t *lengths, size_t tile0, size_t nTiles, uint32_t cells, uint8_t *raw, size_t rawStride,
                                      GfInflateStream *desc, int32_t *pre, hipStream_t stream);
 hipError_t gf_launch_deflate_lengths(size_t nTiles, const GfInflateStream *desc, const uint32_t *produced, const int32_t *inflStatus,
-                                     int32_t *pre, uint32_t *rawLengths, hipStream_t stream);
+                                     int32_t *pre, uint32_t *rawLengths, uint8_t *rawBase, hipStream_t stream);
 hipError_t gf_launch_merge_status(size_t nTiles, const int32_t *pre, const int32_t *decoded, int32_t *status, hipStream_t stream);
 hipError_t gf_launch_float_streams(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, const uint32_t *lengths, size_t tile0,
                                    size_t nTiles, uint32_t cells, size_t planeStride, GfInflateStream *desc, int32_t *pre, hipStream_t stream);

@@ -380,7 +380,18 @@ int gvo_predictor_encode(int model, int nRows, int nCols, const int32_t *values,
 int gvo_predictor_decode(int model, int32_t seed, int nRows, int nCols,
                          const uint8_t *m32, size_t nM32, int32_t *values)
 {
-    (void)nM32; /* the reference performs no bounds checks on the M32 buffer */
+    /* The reference's predictors read codeM32s through CodecM32.decode without a check of their own (:327-356), but the
+     * array is exactly nM32 bytes long (new byte[nM32], CodecHuffman.java:143 / CodecDeflate.java:139): a stream that
+     * holds fewer values than the predictor reads ends in the JVM's ArrayIndexOutOfBoundsException.  The C buffers here
+     * are padded, so that case is found by walking the values the predictor will read. */
+    if (model >= 1 && model <= 4 && nRows > 0 && nCols > 0) {
+        const size_t need = (size_t)nRows * (size_t)nCols - (model == GVO_PM_DIFFERENCING_NULLS ? 0 : 1);
+        size_t p = 0;
+        for (size_t k = 0; k < need; k++) {
+            (void)gvo_m32_decode(m32, &p);
+            if (p > nM32) return GVO_ERR_BOUNDS;
+        }
+    }
     switch (model) {
     case GVO_PM_DIFFERENCING: pm_differencing_decode(seed, nRows, nCols, m32, values); return GVO_OK;
     case GVO_PM_LINEAR: pm_linear_decode(seed, nRows, nCols, m32, values); return GVO_OK;

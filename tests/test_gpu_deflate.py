@@ -174,3 +174,77 @@ def test_decode_returns_null_when_the_inflater_gives_nothing(codec):
     not_deflate = bytes([2, 1]) + struct.pack("<i", 1234) + struct.pack("<i", 63) + bytes([0x78, 0x9C, 0xFF, 0xFF, 0xFF, 0xFF])
     with pytest.raises(IOError):
         codec.decode(8, 8, not_deflate)
+
+
+def test_every_single_bit_flip_matches_the_oracle(codec):
+    """Every one-bit damage of a CodecDeflate packing, all in one batch: where the oracle (the host's zlib driven as
+    java.util.zip.Inflater drives it) still decodes, the device decodes to the same cells; where the oracle returns null
+    (nothing inflated) so does the device; where the oracle throws, the device reports an error."""
+    nr, nc = 12, 40
+    v = make_tile("smooth", nr, nc, seed=5)
+    good = codec.encode(2, nr, nc, v)
+    assert good is not None
+    packs = []
+    for i in range(1, len(good)):                     # (byte 0 is the codec index, not looked at by decode)
+        for b in range(8):
+            x = bytearray(good)
+            x[i] ^= 1 << b
+            packs.append(bytes(x))
+    vals, st = codec.decode_batch(nr, nc, packs)
+    n_ok = n_null = n_err = 0
+    for k, pk in enumerate(packs):
+        out = np.zeros(nr * nc, np.int32)
+        rc = oracle.lib().gvo_codec_deflate_decode(nr, nc, oracle._p(oracle._u8(pk), oracle.C.c_uint8), len(pk),
+                                                   oracle._p(out, oracle.C.c_int32))
+        where = (k // 8 + 1, k % 8)
+        n_m32 = struct.unpack_from("<I", pk, 6)[0]
+        if n_m32 > 6 * nr * nc:
+            # documented deviation (DESIGN.md 2): a byte count no encoder can produce (more than six bytes per cell) is
+            # rejected up front instead of sizing buffers by it
+            assert st[k] < 0, (where, int(st[k]))
+            continue
+        if rc == oracle.OK:
+            assert st[k] == 0 and np.array_equal(vals[k], out), (where, int(st[k]))
+            n_ok += 1
+        elif rc == oracle.DECLINED:
+            assert st[k] == 1, (where, int(st[k]))
+            n_null += 1
+        else:
+            assert st[k] < 0, (where, int(st[k]), rc)
+            n_err += 1
+    assert n_ok > 0 and n_err > 0
+
+
+def test_stream_that_ends_early_leaves_zeros_like_a_fresh_java_array(codec):
+    """Found by tools/soak.py: one flipped bit makes the zlib stream run out of input after 3,253 of 16,824 bytes.
+    Inflater.inflate returns what it has, the rest of `new byte[nM32]` is zero, and the predictor reads on into it
+    (CodecDeflate.java:139-148) -- the device must see zeros there too, not what an earlier tile left in its scratch."""
+    import base64
+    pk = base64.b64decode("BwE87f//uEEAAHic7cQxDQAACAOwG9UL8uYKDfzt0XS2E9u2bZu2bdu2bdu2bdu2bdu2bdu2bdu2bT8/jzft9Q==")
+    nr, nc = 79, 71
+    want = oracle.codec_deflate_decode(nr, nc, pk)
+    filler = codec.encode(1, nr, nc, make_tile("noise16", nr, nc, seed=3))      # leaves non-zero bytes in the scratch first
+    vals, st = codec.decode_batch(nr, nc, [filler, filler, filler])
+    assert (st == 0).all()
+    for _ in range(2):
+        vals, st = codec.decode_batch(nr, nc, [pk, pk, filler, pk])
+        assert list(st) == [0, 0, 0, 0]
+        for k in (0, 1, 3):
+            assert np.array_equal(vals[k], want), k
+
+
+def test_match_behind_the_room_is_not_looked_at():
+    """Found by tools/soak.py: the last-block bit of a stored block flipped, so zlib goes on into the Adler-32 bytes as if
+    they were another block; they happen to spell a match whose distance reaches before the start of the output.  zlib only
+    validates a distance when it has room to copy (inflate.c, state MATCH), and the room is exactly used up: Inflater.inflate
+    returns the 228 bytes without an exception, and so must the device."""
+    import base64
+    import gridfour_amd
+    pk = base64.b64decode("BwLen+ry5AAAAHicAOQAG/+BhOWO+UOBhIGTnF6Bgs2thUF/g+C400+BhuThzVR/i4eCD4GF09XabYGD78eKJ3/v1rVJgYC0wfghf4Ll8+BU"
+                          "gYOi9OQOgYPo/NwNgYK59qRdf4bO/p08gYHG5qRMgYTww/sFf4HRgbt7f4Twt+4KgYSfsMVEgYaByY4AgYPhjIIVgYbLptpGgYK2hJp3"
+                          "gYOu9+EygYbh2osNgYb2kqYgf4Hfzv0wf+XMt12BqLSlSX+FgY+NM3+T5YUrgYCbuZNBf4X0qORMf4Lfkrg0gZXksTWBgt/11wh/heaQ"
+                          "9yCBhejemQYbuoUw")
+    codec = gridfour_amd.CodecDeflateHip()
+    want = oracle.codec_deflate_decode(10, 4, pk)
+    vals, st = codec.decode_batch(10, 4, [pk])
+    assert st[0] == 0 and np.array_equal(vals[0], want)
