@@ -944,6 +944,7 @@ static gf_status floatDecodeDev(gf_context *c, hipStream_t st, int nRows, int nC
         a.nStreams = 5 * n;
         a.window = gf_inflate_window((uint32_t)std::min<size_t>(cells, 32768));
         GF_HIP(gf_launch_inflate(a, st));
+        GF_HIP(gf_launch_float_short_planes(n, pre, inflStatus, produced, planes, planeStride, nRows, nCols, st));
         GF_HIP(gf_launch_float_status(n, pre, inflStatus, dStatus + t0, st));
         GF_HIP(gf_launch_float_planes_decode(planes, (uint32_t *)dValues + t0 * cells, planeStride, n, nRows, nCols, st));
     }

@@ -685,6 +685,64 @@ hipError_t gf_launch_float_streams(const uint8_t *blob, size_t blobBytes, const 
     return hipGetLastError();
 }
 
+// CodecFloat.decodeFloats uses ONE scratch array for its five planes (CodecFloat.java:397, 409-446) and decodes the mantissa
+// deltas in place: behind a stream that ends early -- damaged input; no exception, doInflate only looks at the sign of the
+// count -- a plane keeps what the plane before it left there (delta-DECODED bytes behind the mantissa planes).  The plane
+// buffer here has a region per plane, zeroed before the inflate; for the rare tile with a short plane this kernel (one
+// thread per tile) writes into each short plane's tail what the Java array would hold, so that the plane merge that follows
+// sees the reference's bytes.
+__global__ void k_float_short_planes(size_t nTiles, const int32_t *__restrict__ pre, const int32_t *__restrict__ inflStatus,
+                                     const uint32_t *__restrict__ produced, uint8_t *__restrict__ planes, size_t planeStride, int nRows,
+                                     int nCols)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTiles || pre[t] != GF_K_OK) return;
+    const uint32_t n = (uint32_t)nRows * (uint32_t)nCols, nSign = (n + 7u) >> 3;
+    bool any = false;
+    for (int p = 0; p < 5; p++) {
+        if (inflStatus[t * 5 + p] != GF_K_OK) return;                 // the tile fails anyway
+        if (p > 0 && produced[t * 5 + p] < n) any = true;
+    }
+    if (!any) return;
+    uint8_t *P0 = planes + t * planeStride, *P1 = P0 + nSign;
+    // plane 1 (exponent) behind its end: the sign bytes, then the zeros of the fresh array
+    for (uint32_t i = produced[t * 5 + 1]; i < n; i++) P1[i] = i < nSign ? P0[i] : (uint8_t)0;
+    // planes 2..4 behind their ends: what decodeDeltas left of the plane before (plane 2: the exponent bytes as they are)
+    for (int p = 2; p < 5; p++) {
+        uint8_t *cur = P1 + (size_t)(p - 1) * n;
+        const uint8_t *prev = cur - n;
+        const uint32_t got = produced[t * 5 + p];
+        if (got >= n) continue;
+        if (p == 2) {
+            for (uint32_t i = got; i < n; i++) cur[i] = prev[i];
+        } else {
+            // decodeDeltas :315-326 over the previous plane, keeping only the tail
+            int prior = 0;
+            uint32_t k = 0;
+            for (int r = 0; r < nRows; r++) {
+                int first = 0;
+                for (int c = 0; c < nCols; c++, k++) {
+                    prior += (int8_t)prev[k];
+                    const uint8_t d = (uint8_t)prior;
+                    prior = (int8_t)d;
+                    if (c == 0) first = (int8_t)d;
+                    if (k >= got) cur[k] = d;
+                }
+                prior = first;
+            }
+        }
+    }
+}
+
+hipError_t gf_launch_float_short_planes(size_t nTiles, const int32_t *pre, const int32_t *inflStatus, const uint32_t *produced,
+                                        uint8_t *planes, size_t planeStride, int nRows, int nCols, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_float_short_planes, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, nTiles, pre, inflStatus, produced,
+                       planes, planeStride, nRows, nCols);
+    return hipGetLastError();
+}
+
 hipError_t gf_launch_lsop_streams(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride, const uint32_t *lengths,
                                   size_t nTiles, uint32_t nInit, uint32_t nInt, size_t rawStride, int pass, const uint32_t *produced,
                                   const int32_t *inflStatus, const uint32_t *consumed, GfInflateStream *desc, int32_t *side, uint32_t *gate,

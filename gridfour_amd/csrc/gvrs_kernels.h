@@ -205,6 +205,8 @@ hipError_t gf_launch_lsop_streams(const uint8_t *blob, size_t blobBytes, const u
                                   size_t nTiles, uint32_t nInit, uint32_t nInt, size_t rawStride, int pass, const uint32_t *produced,
                                   const int32_t *inflStatus, const uint32_t *consumed, GfInflateStream *desc, int32_t *side, uint32_t *gate,
                                   hipStream_t stream);
+hipError_t gf_launch_float_short_planes(size_t nTiles, const int32_t *pre, const int32_t *inflStatus, const uint32_t *produced,
+                                        uint8_t *planes, size_t planeStride, int nRows, int nCols, hipStream_t stream);
 hipError_t gf_launch_float_status(size_t nTiles, const int32_t *pre, const int32_t *inflStatus, int32_t *status, hipStream_t stream);
 
 // predictor -> M32 stage alone (gvrs_encode.hip): per tile up to three candidate M32 streams (CodecDeflate.java:157-199)

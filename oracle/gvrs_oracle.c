@@ -961,12 +961,17 @@ int gvo_codec_float_encode(int codecIndex, int nRows, int nCols,
 int gvo_codec_float_decode(int nRows, int nCols, const uint8_t *packing,
                            size_t len, uint32_t *rawBits)
 {
+    /* CodecFloat.decodeFloats :395-458, statement by statement: ONE scratch array serves all five planes
+     * (`byte[] scratch = new byte[nCellsInTile]`), every doInflate writes only as many bytes as its stream gives, and
+     * decodeDeltas works in place -- so behind a stream that ends early (damaged input) a plane keeps what the plane
+     * before it left there (its delta-DECODED bytes for the mantissa planes), not zeros. */
     size_t n = (size_t)nRows * (size_t)nCols;
     size_t nSign = (n + 7) / 8;
-    uint8_t *planes = (uint8_t *)calloc(nSign + 4 * n, 1);
-    if (!planes) return GVO_ERR_ARG;
-    size_t off = 2, planeOff = 0;
+    uint8_t *scratch = (uint8_t *)calloc(n + 8, 1);
+    if (!scratch) return GVO_ERR_ARG;
+    size_t off = 2;
     int rc = GVO_OK;
+    for (size_t i = 0; i < n; i++) rawBits[i] = 0;
     for (int p = 0; p < 5; p++) {
         size_t pl = p == 0 ? nSign : n;
         if (off + 4 > len) { rc = GVO_ERR_BOUNDS; break; }
@@ -975,13 +980,21 @@ int gvo_codec_float_decode(int nRows, int nCols, const uint8_t *packing,
         off += 4;
         if (off + zn > len) { rc = GVO_ERR_BOUNDS; break; }
         size_t got = 0;
-        rc = zinflate(packing + off, zn, planes + planeOff, pl, &got);
+        rc = zinflate(packing + off, zn, scratch, pl, &got);
         if (rc != GVO_OK) break;
         off += zn;
-        planeOff += pl;
+        if (p >= 2) float_decode_deltas(scratch, nRows, nCols);
+        for (size_t i = 0; i < n; i++) {
+            switch (p) {
+            case 0: rawBits[i] = (uint32_t)((scratch[i >> 3] >> (i & 7)) & 1) << 31; break;
+            case 1: rawBits[i] |= (uint32_t)scratch[i] << 23; break;
+            case 2: rawBits[i] |= (uint32_t)(scratch[i] & 0x7f) << 16; break;
+            case 3: rawBits[i] |= (uint32_t)scratch[i] << 8; break;
+            default: rawBits[i] |= (uint32_t)scratch[i]; break;
+            }
+        }
     }
-    if (rc == GVO_OK) rc = gvo_float_planes_decode(nRows, nCols, planes, rawBits);
-    free(planes);
+    free(scratch);
     return rc;
 }
 

@@ -83,3 +83,71 @@ def test_reference_sample06(fcodec, golden_dir):
     assert fcodec.encode(0, 2, 2, np.zeros(4, np.int32)) is None
     with pytest.raises(IOError):
         fcodec.decodeFloats(50, 50, packing[:40])
+
+
+def test_every_single_bit_flip_matches_the_oracle(fcodec):
+    """Every one-bit damage of a CodecFloat packing (two header bytes, five length-prefixed zlib streams) in one batch: the
+    device accepts exactly what the oracle (host zlib driven as java.util.zip.Inflater) accepts, with the same floats."""
+    nr, nc = 9, 14
+    rng = np.random.default_rng(77)
+    f = (np.sin(np.arange(nr * nc) / 5.0) * 300.0 + rng.standard_normal(nr * nc)).astype(np.float32)
+    good = fcodec.encodeFloats(3, nr, nc, f)
+    packs = []
+    for i in range(2, len(good)):                      # (bytes 0 and 1 are not looked at by decodeFloats)
+        for b in range(8):
+            x = bytearray(good)
+            x[i] ^= 1 << b
+            packs.append(bytes(x))
+    vals, st = fcodec.decode_floats_batch(nr, nc, packs)
+    n_ok = n_err = 0
+    for k, pk in enumerate(packs):
+        where = (k // 8 + 2, k % 8)
+        try:
+            want = oracle.codec_float_decode(nr, nc, pk)
+        except IOError:
+            want = None
+        if want is None:
+            assert st[k] != 0, where
+            n_err += 1
+        else:
+            assert st[k] == 0 and np.array_equal(vals[k].view(np.uint32), want), (where, int(st[k]))
+            n_ok += 1
+    assert n_ok > 0 and n_err > 0
+
+
+def test_short_plane_keeps_what_the_plane_before_left(fcodec):
+    """CodecFloat.decodeFloats inflates all five planes into ONE scratch array and decodes the mantissa deltas in place
+    (CodecFloat.java:397-446): a plane whose stream gives fewer bytes than the tile has cells -- no exception in the
+    reference -- continues with what the previous plane left behind.  Packings rebuilt with deliberately short (but valid)
+    zlib streams for one plane each; device = oracle (which restates the method statement by statement)."""
+    import zlib
+    nr, nc = 10, 16
+    n = nr * nc
+    rng = np.random.default_rng(9)
+    f = (np.cos(np.arange(n) / 7.0) * 1000.0 + rng.standard_normal(n) * 3).astype(np.float32)
+    good = fcodec.encodeFloats(3, nr, nc, f)
+    # split into its five streams
+    streams, off = [], 2
+    for _ in range(5):
+        zn = struct.unpack_from("<I", good, off)[0]
+        streams.append(good[off + 4:off + 4 + zn])
+        off += 4 + zn
+    planes = [zlib.decompress(s) for s in streams]
+    packs = []
+    for p in range(5):
+        for keep in (0, 1, len(planes[p]) // 3, len(planes[p]) - 1):
+            ss = list(streams)
+            ss[p] = zlib.compress(planes[p][:keep], 6)
+            packs.append(good[:2] + b"".join(struct.pack("<I", len(s)) + s for s in ss))
+    # two planes short at once
+    ss = list(streams)
+    ss[2] = zlib.compress(planes[2][:40], 6)
+    ss[4] = zlib.compress(planes[4][:7], 6)
+    packs.append(good[:2] + b"".join(struct.pack("<I", len(s)) + s for s in ss))
+    vals, st = fcodec.decode_floats_batch(nr, nc, packs)
+    differs = 0
+    for k, pk in enumerate(packs):
+        want = oracle.codec_float_decode(nr, nc, pk)
+        assert st[k] == 0 and np.array_equal(vals[k].view(np.uint32), want), k
+        differs += int(not np.array_equal(want, f.view(np.uint32)))
+    assert differs >= len(packs) - 6

@@ -348,3 +348,34 @@ def test_deflate_container_damage_matches_the_oracle(codec):
         else:
             assert st[k] != 0, k
     assert n_ok >= 1
+
+
+def test_every_single_bit_flip_of_a_deflate_container_matches_the_oracle(codec):
+    """Every one-bit damage of an LSOP12 Deflate container (header, two chained zlib streams), in one batch, against the
+    oracle's verdict and cells."""
+    nr, nc = 20, 24
+    y, x = np.mgrid[0:nr, 0:nc]
+    v = (3 * x + 5 * y + 40 * ((x // 8 + y // 8) % 2)).astype(np.int32).ravel()
+    defl, typ = oracle.lsop12_encode(1, nr, nc, v, True)
+    assert typ == 1
+    packs = []
+    for i in range(1, len(defl)):
+        for b in range(8):
+            z = bytearray(defl)
+            z[i] ^= 1 << b
+            packs.append(bytes(z))
+    vals, st = codec.decode_batch(nr, nc, packs)
+    n_ok = n_err = 0
+    for k, pk in enumerate(packs):
+        where = (k // 8 + 1, k % 8)
+        try:
+            want = oracle.lsop12_decode(nr, nc, pk)
+        except Exception:
+            want = None
+        if want is None:
+            assert st[k] != 0, where
+            n_err += 1
+        else:
+            assert st[k] == 0 and np.array_equal(vals[k], want), (where, int(st[k]))
+            n_ok += 1
+    assert n_ok > 0 and n_err > 0
