@@ -94,6 +94,11 @@ struct DecShared {
     uint32_t chainEnd;                         // position after the last needed symbol
     uint32_t chainTotal;
     uint32_t dense;                            // M32 stream too dense in multi-byte values for local start resolution
+    // An INCOMPLETE tree (damaged input: the leaf count was reached while branch nodes still waited for children;
+    // HuffmanDecoder.decodeTree :87-120 returns it as it is): skipLen = length of the LAST leaf's path (0: the tree is
+    // complete), skipLo/Hi = that path.  Every 0 step on it is a branch whose right child was never read; the reference's
+    // decode loop :179-185 finds 0 in such a child slot, lands on the root again and goes on without a symbol.
+    uint32_t skipLen, skipLo, skipHi;
 };
 
 #include "gvrs_decode_common.h"
@@ -835,6 +840,8 @@ __device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, 
     const uint32_t nLeaves = take(8) + 1;
     const uint32_t rootBit = take(1);
     uint32_t nShort = 0, nSub = 0, maxLen = 1;
+    uint32_t skipLen = 0;
+    unsigned long long skipPath = 0;
     if (rootBit == 1) {
         uniformSym = (int32_t)take(8);
     } else {
@@ -872,6 +879,10 @@ __device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, 
             uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
             z = min(z, have);
             if (z) {
+                // decodeTree's arrays: stack = new int[nLeaves + 1] (a branch of code length l is pushed at index l) and
+                // nodeIndex = new int[6 nLeaves] (three ints per node, the root included): damage that asks for more ends in
+                // ArrayIndexOutOfBoundsException there
+                if (L - 1u + z > nLeaves || records + z > 2u * nLeaves - 1u) { st = GF_K_ERR_BOUNDS; break; }
                 if (L - 1u + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }   // see DESIGN.md (unsupported depth)
                 if (L <= (uint32_t)LUT_BITS && L + z > (uint32_t)LUT_BITS) {
                     // a branch at depth LUT_BITS on this path: codes below it continue into a second-level table,
@@ -889,6 +900,7 @@ __device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, 
                 if (have == 0u || !(buf & 1ull)) continue;           // the run continues beyond the buffered bits
                 refill();
             }
+            if (records + 1u > 2u * nLeaves - 1u) { st = GF_K_ERR_BOUNDS; break; }      // nodeIndex is full (see above)
             const uint32_t rec = take(9);
             const uint32_t sym = rec >> 1;
             const uint32_t clen = L;
@@ -910,11 +922,18 @@ __device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, 
             L -= t1;
         }
         if (leaves & 63u) flush(leaves & ~63u, leaves & 63u);
-        // all leaves read: the tree must be complete (every open branch is on its right child)
-        if (st == GF_K_OK && !complete) st = GF_K_ERR_FORMAT;
+        // all leaves read.  An incomplete tree (some open branch still on its left child) is what the reference's decoder
+        // walks with a fall-back to the root: huffman_serial_skips
+        if (st == GF_K_OK && !complete && leaves == nLeaves) {
+            skipLen = L;
+            skipPath = __brevll(c) >> (64u - L);
+        }
     }
     if (st == GF_K_OK && bp > totalBits) st = GF_K_ERR_BOUNDS;   // read past end of data
     if (writer) {
+        S.skipLen = skipLen;
+        S.skipLo = (uint32_t)skipPath;
+        S.skipHi = (uint32_t)(skipPath >> 32);
         S.uniformSym = uniformSym;
         S.textStart = bp;
         S.parseStatus = st;
@@ -1523,6 +1542,76 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     return S.chainEnd > nM32 ? GF_K_ERR_BOUNDS : GF_K_OK;       // last value truncated
 }
 
+// The Huffman text of a tile whose serialised tree is INCOMPLETE (DecShared::skipLen), decoded the way the reference walks
+// it (HuffmanDecoder.decode :179-185 over the node table of decodeTree :87-120): a step onto a child that was never read
+// finds 0 in the table, which is the root's own slot, so the walk starts over at the root WITHOUT a symbol.  The missing
+// children are the right children of the branches on the last leaf's path that were left by their left child: the codes
+// (path prefix, then 1 where the path has 0).  No encoder writes such a tree; this is the decode of a damaged packing, done
+// by one wave, a symbol at a time: the lanes hold the leaves (four each) and every step of the walk is one ballot.
+// Ends with a barrier; returns the status (same in all threads); S.chainEnd = bit after the last symbol.
+template <class M32Ptr>
+__device__ int32_t huffman_serial_skips(DecShared &S, const uint32_t *__restrict__ base32, uint32_t nW, uint32_t sh0, uint32_t textStart,
+                                        uint32_t endBit, uint32_t nM32, M32Ptr m32)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < 64u) {
+        const uint32_t nLeaves = S.nLeaves;
+        unsigned long long lc[4];
+        uint32_t ll[4], ls[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t i = lane + 64u * j;
+            lc[j] = i < nLeaves ? S.leafCode[i] : 0ull;
+            ll[j] = i < nLeaves ? (uint32_t)S.leafLen[i] : 0xFFu;
+            ls[j] = i < nLeaves ? (uint32_t)S.leafSym[i] : 0u;
+        }
+        const uint32_t skipLen = GF_UNI(S.skipLen);
+        const unsigned long long skipPath = ((unsigned long long)GF_UNI(S.skipHi) << 32) | GF_UNI(S.skipLo);
+        uint32_t pos = textStart, k = 0;
+        int32_t st = GF_K_OK;
+        while (k < nM32) {
+            unsigned long long cur = 0;                              // path so far, first step in bit 0
+            uint32_t len = 0;
+            bool emitted = false, restart = false;
+            while (!emitted && !restart) {
+                if (pos >= endBit || len >= 64u) { st = GF_K_ERR_BOUNDS; break; }   // the bits end inside a code
+                const uint32_t g = pos + sh0, wi = g >> 5;
+                const uint32_t w = wi < nW ? GF_UNI(base32[wi]) : 0u;
+                const uint32_t b = (w >> (g & 31u)) & 1u;
+                pos++;
+                cur |= (unsigned long long)b << len;
+                len++;
+                bool hit = false;
+                uint32_t sym = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (ll[j] == len && lc[j] == cur) { hit = true; sym = ls[j]; }
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    const uint32_t who = (uint32_t)__builtin_ctzll(m);
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)who);
+                    if (lane == 0u) m32[k] = (uint8_t)v;
+                    k++;
+                    emitted = true;
+                } else if (len <= skipLen && b == 1u && ((skipPath >> (len - 1u)) & 1ull) == 0ull &&
+                           ((cur ^ skipPath) & ((1ull << (len - 1u)) - 1ull)) == 0ull) {
+                    restart = true;                                  // a child that was never read: back to the root
+                }
+            }
+            if (st != GF_K_OK) break;
+        }
+        if (lane == 0u) {
+            S.chainEnd = pos;
+            S.chainTotal = k;
+            S.parseStatus = st;
+        }
+    }
+    __syncthreads();
+    const int32_t st = S.parseStatus;
+    __syncthreads();
+    return st;
+}
+
 // Diagnostics (cycle stamps per phase, phase ablation, warm-up sweep) exist only in the -DGF_DIAG build that tools/ use
 // (gridfour_amd/build.py: libgvrs_hip_diag.so); the shipping kernels carry none of it.
 #ifdef GF_DIAG
@@ -1617,7 +1706,7 @@ __global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDe
 
         GF_DSTAMP(1);
         if (!FAST && a.rawM32) {
-            if (tid == 0) { S.parseStatus = len < 10ull + nM32 ? GF_K_ERR_BOUNDS : GF_K_OK; S.uniformSym = -1; S.textStart = 80; }
+            if (tid == 0) { S.parseStatus = len < 10ull + nM32 ? GF_K_ERR_BOUNDS : GF_K_OK; S.uniformSym = -1; S.textStart = 80; S.skipLen = 0; }
         } else if (FAST || a.trees) {
             // the tree was walked by k_huffman_parse_trees: fetch the leaf records, then mark the first-level entries
             // whose codes continue in a second-level table (one per distinct LUT_BITS-bit prefix among the longer codes,
@@ -1649,6 +1738,9 @@ __global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDe
             if (tid == 0) {
                 const uint32_t maxLen = rec[3];
                 S.uniformSym = (int32_t)rec[4];
+                S.skipLen = rec[5];
+                S.skipLo = rec[6];
+                S.skipHi = rec[7];
                 S.textStart = rec[2];
                 S.parseStatus = (int32_t)rec[0];
                 S.nLeaves = nLeaves;
@@ -1670,7 +1762,7 @@ __global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDe
         if constexpr (FAST) {
             // the fast Huffman passes want the packing (plus padding) in the M32 buffer and codes of at most 32 bits
             const uint32_t pkWords = (((uint32_t)(off * 8ull) & 31u) + len * 8u + 31u) >> 5;
-            if (S.maxLen > 32u || (pkWords + FAST_TEXT_PAD) * 4u > a.ldsM32Bytes) {
+            if (S.maxLen > 32u || S.skipLen != 0u || (pkWords + FAST_TEXT_PAD) * 4u > a.ldsM32Bytes) {
                 if (tid == 0) {
                     a.status[t] = GF_K_RETRY;
                     atomicOr(a.retryFlag, 1u);
@@ -1723,6 +1815,11 @@ __global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDe
                 const uint8_t sym = (uint8_t)S.uniformSym;
                 for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
                 __syncthreads();
+            } else if (!FAST && S.skipLen != 0u) {
+                // an incomplete tree (damaged input): the reference's walk, symbol by symbol, by one wave
+                const uint64_t baseWord = (off * 8ull) >> 5;
+                tileStatus = huffman_serial_skips(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
+                                                  (uint32_t)(off * 8ull) & 31u, S.textStart, len * 8u, nM32, m32);
             } else {
                 build_lut(S, lut2);
                 GF_DSTAMP(3);
@@ -1931,6 +2028,14 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
                         for (uint32_t i = tid; i < nM32; i += DEC_THREADS) m32[i] = sym;
                         if (tid == 0) S.chainEnd = S.textStart;          // no text (HuffmanDecoder.java:170-177)
                         __syncthreads();
+                    } else if (S.skipLen != 0u) {
+                        // an incomplete tree (damaged input): the reference's walk, symbol by symbol (huffman_serial_skips)
+                        const uint64_t baseWord = (off * 8ull) >> 5;
+                        const int32_t st = huffman_serial_skips(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
+                                                                (uint32_t)(off * 8ull) & 31u, S.textStart, len * 8u, nM32, m32);
+                        if (st != GF_K_OK) return st;
+                        if (nM32 == 0 && tid == 0) S.chainEnd = S.textStart;
+                        __syncthreads();
                     } else {
                         // second-level table: always in LDS, in the area the in-LDS bitmap uses later (as in k_huffman_decode)
                         uint16_t *lut2 = reinterpret_cast<uint16_t *>(ldsDyn + a.ldsM32Bytes);
@@ -2017,6 +2122,8 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     const uint32_t nLeaves = take(8) + 1;
     const uint32_t rootBit = take(1);
     uint32_t maxLen = 1;
+    uint32_t skipLen = 0;
+    unsigned long long skipPath = 0;
     if (rootBit == 1) {
         uniformSym = (int32_t)take(8);
     } else {
@@ -2030,6 +2137,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             uint32_t z = buf ? (uint32_t)__builtin_ctzll(buf) : 64u;
             z = min(z, have);
             if (z) {
+                if (L - 1u + z > nLeaves || records + z > 2u * nLeaves - 1u) { st = GF_K_ERR_BOUNDS; break; }   // as parse_tree_wave
                 if (L - 1u + z > MAX_DEPTH) { st = GF_K_ERR_FORMAT; break; }
                 c <<= z;
                 L += z;
@@ -2040,6 +2148,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
                 if (have == 0u || !(buf & 1ull)) continue;
                 refill();
             }
+            if (records + 1u > 2u * nLeaves - 1u) { st = GF_K_ERR_BOUNDS; break; }
             const uint32_t r9 = take(9);
             records++;
             codes[leaves] = __brevll(c) >> (64u - L);
@@ -2053,7 +2162,10 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             c = (c >> t1) | 1ull;
             L -= t1;
         }
-        if (st == GF_K_OK && !complete) st = GF_K_ERR_FORMAT;
+        if (st == GF_K_OK && !complete && leaves == nLeaves) {       // incomplete tree: see DecShared::skipLen
+            skipLen = L;
+            skipPath = __brevll(c) >> (64u - L);
+        }
     }
     if (st == GF_K_OK && bp > len * 8u) st = GF_K_ERR_BOUNDS;
     rec[0] = (uint32_t)st;
@@ -2061,6 +2173,9 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     rec[2] = bp;
     rec[3] = maxLen;
     rec[4] = (uint32_t)uniformSym;
+    rec[5] = skipLen;
+    rec[6] = (uint32_t)skipPath;
+    rec[7] = (uint32_t)(skipPath >> 32);
 }
 
 #endif  // GF_DEC_VARIANT

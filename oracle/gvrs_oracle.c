@@ -601,6 +601,7 @@ int gvo_huffman_decode(const uint8_t *bits, size_t nBitsTotal, size_t *bitPos,
         if (r.overrun) return GVO_ERR_BOUNDS;
         if (bit == 1) {
             nLeafsDecoded++;
+            if (nodeIndexCount + 3 > nLeafsToDecode * 6) return GVO_ERR_BOUNDS; /* nodeIndex AIOOBE (a leaf's three slots) */
             nodeIndex[nodeIndexCount++] = (int)br_bits(&r, 8);
             nodeIndex[nodeIndexCount++] = 0;
             nodeIndex[nodeIndexCount++] = 0;
