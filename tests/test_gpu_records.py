@@ -133,3 +133,41 @@ def test_short_fill_value_maps_to_null_code():
     assert packing == want and used[0] == want_used
     _, got, st = master.tiles_from_records(nr, nc, recs, element="short")
     assert st[0] == 0 and np.array_equal(got[0], np.where(v == -9999, -32768, v).ravel())
+
+
+@pytest.mark.parametrize("verify", [True, False], ids=["crc", "nocrc"])
+def test_every_single_bit_flip_of_a_record(verify):
+    """Every one-bit damage of one tile record among three, all variants in ONE batch call.  With the CRC-32C verified every
+    flip is caught (a CRC detects all single-bit errors); without it the framing is on its own -- record size, type,
+    element length and packing bytes all get damaged: nothing may crash, the neighbours decode untouched, a record the
+    framing still accepts keeps its tile index unless the flip was in the index itself."""
+    import gridfour_amd
+    master = gridfour_amd.CodecMasterHip()
+    nr, nc = 10, 14
+    tiles = np.stack([make_tile("smooth", nr, nc, seed=21), make_tile("steps", nr, nc, seed=22), make_tile("ramp", nr, nc, seed=23)])
+    idx = [11, 12, 13]
+    recs, used = master.tile_records(nr, nc, idx, tiles, element="int", checksums=True)
+    victim = recs[1]
+    batch, where = [], []
+    for i in range(len(victim)):
+        for b in range(8):
+            x = bytearray(victim)
+            x[i] ^= 1 << b
+            batch += [recs[0], bytes(x), recs[2]]
+            where.append((i, b))
+    got_idx, got, st = master.tiles_from_records(nr, nc, batch, element="int", verify_checksums=verify)
+    st = st.reshape(-1, 3)
+    got = got.reshape(-1, 3, nr * nc)
+    got_idx = got_idx.reshape(-1, 3)
+    assert (st[:, 0] == 0).all() and (st[:, 2] == 0).all()
+    assert (got[:, 0] == tiles[0]).all() and (got[:, 2] == tiles[2]).all()
+    assert (got_idx[:, 0] == 11).all() and (got_idx[:, 2] == 13).all()
+    if verify:
+        assert (st[:, 1] != 0).all()
+    else:
+        accepted = st[:, 1] == 0
+        assert accepted.any() and (~accepted).any()
+        for k in np.nonzero(accepted)[0]:
+            i, b = where[k]
+            if not 8 <= i < 12:                        # (bytes 8..11 hold the tile index)
+                assert got_idx[k, 1] == 12, (i, b)
