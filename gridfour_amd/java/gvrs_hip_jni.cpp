@@ -305,4 +305,149 @@ JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_tilesFromRecords(JNI
     env->SetIntArrayRegion(status, 0, nTiles, (const jint *)st.data());
 }
 
+// ---- read-ahead: org.gridfour.hip.HipReadAhead over gf_readahead_* ----
+JNIEXPORT jlong JNICALL Java_org_gridfour_hip_HipCodecNative_readaheadCreate(JNIEnv *env, jclass, jint device, jintArray codecKinds,
+                                                                           jint nRows, jint nCols, jint maxBatch)
+{
+    const std::vector<int32_t> kinds = intsOf(env, codecKinds);
+    const jsize nCodecs = codecKinds ? env->GetArrayLength(codecKinds) : 0;
+    gf_readahead *ra = nullptr;
+    if (gf_readahead_create(device, (const int *)kinds.data(), nCodecs, nRows, nCols, maxBatch > 0 ? (size_t)maxBatch : 1, &ra) != GF_OK) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, gf_last_error());
+        return 0;
+    }
+    return (jlong)(intptr_t)ra;
+}
+
+JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_readaheadDestroy(JNIEnv *, jclass, jlong ra)
+{
+    gf_readahead_destroy((gf_readahead *)(intptr_t)ra);            // (joins the worker; null is a no-op)
+}
+
+JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_readaheadSubmit(JNIEnv *env, jclass, jlong ra, jint tileIndex,
+                                                                          jbyteArray packing)
+{
+    if (!ra || !packing) return;
+    const jsize len = env->GetArrayLength(packing);
+    const std::vector<uint8_t> p = bytesOf(env, packing);
+    gf_readahead_submit((gf_readahead *)(intptr_t)ra, tileIndex, p.data(), (size_t)len);    // the library copies the bytes
+}
+
+JNIEXPORT jint JNICALL Java_org_gridfour_hip_HipCodecNative_readaheadPending(JNIEnv *, jclass, jlong ra)
+{
+    return ra ? gf_readahead_pending((gf_readahead *)(intptr_t)ra) : 0;
+}
+
+JNIEXPORT jint JNICALL Java_org_gridfour_hip_HipCodecNative_readaheadTake(JNIEnv *env, jclass, jlong ra, jint waitIndex,
+                                                                        jintArray indices, jintArray cells, jintArray status)
+{
+    if (!ra) return 0;
+    const jsize maxTiles = env->GetArrayLength(indices), nCells = env->GetArrayLength(cells);
+    if (maxTiles == 0) return 0;
+    // (the wait happens here, in native code, with no Java array pinned)
+    std::vector<int32_t> idx((size_t)maxTiles), st((size_t)maxTiles), v((size_t)nCells + 1);
+    size_t n = 0;
+    const gf_status s = gf_readahead_take((gf_readahead *)(intptr_t)ra, waitIndex, (size_t)maxTiles, idx.data(), v.data(), st.data(), &n);
+    if (s != GF_OK) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, gf_status_string(s));
+        return 0;
+    }
+    if (n) {
+        const size_t per = (size_t)nCells / (size_t)maxTiles;        // the caller sized cells for maxTiles tiles
+        env->SetIntArrayRegion(indices, 0, (jsize)n, (const jint *)idx.data());
+        env->SetIntArrayRegion(status, 0, (jsize)n, (const jint *)st.data());
+        env->SetIntArrayRegion(cells, 0, (jsize)(n * per), (const jint *)v.data());
+    }
+    return (jint)n;
+}
+
+// ---- several GPUs from one JVM: org.gridfour.hip.HipMultiGpu over gf_multi_* ----
+JNIEXPORT jlong JNICALL Java_org_gridfour_hip_HipCodecNative_multiCreate(JNIEnv *env, jclass, jintArray devices)
+{
+    const std::vector<int32_t> dev = intsOf(env, devices);
+    gf_multi *m = nullptr;
+    if (gf_multi_create((const int *)dev.data(), devices ? env->GetArrayLength(devices) : 0, &m) != GF_OK) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, gf_last_error());
+        return 0;
+    }
+    return (jlong)(intptr_t)m;
+}
+
+JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_multiDestroy(JNIEnv *, jclass, jlong multi)
+{
+    gf_multi_destroy((gf_multi *)(intptr_t)multi);
+}
+
+JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_multiHuffmanEncode(JNIEnv *env, jclass, jlong multi, jint codecIndex,
+                                                                                   jint nRows, jint nCols, jintArray cells,
+                                                                                   jlongArray offsets, jbyteArray predictors,
+                                                                                   jintArray status)
+{
+    if (!multi) return nullptr;
+    const size_t per = (size_t)nRows * (size_t)nCols;
+    const jsize nCells = env->GetArrayLength(cells);
+    const size_t nTiles = per ? (size_t)nCells / per : 0;
+    if (env->GetArrayLength(offsets) < (jsize)nTiles + 1) return nullptr;
+    const std::vector<int32_t> v = intsOf(env, cells);
+    std::vector<uint64_t> off(nTiles + 1);
+    std::vector<uint8_t> pred(nTiles + 1);
+    std::vector<int32_t> st(nTiles + 1);
+    size_t cap = nTiles * per + 4096;                                // a byte per cell holds terrain packings; grown on demand
+    std::vector<uint8_t> blob;
+    gf_status s;
+    for (;;) {
+        blob.resize(cap);
+        s = gf_huffman_encode_batch_i32_multi((gf_multi *)(intptr_t)multi, codecIndex, nRows, nCols, nTiles, v.data(), blob.data(), cap,
+                                              off.data(), pred.data(), st.data());
+        if (s != GF_ERR_CAPACITY) break;
+        cap = (size_t)off[nTiles] + 64;                              // the call reports the size it needs
+    }
+    if (s != GF_OK) {
+        throwIo(env, gf_status_string(s));
+        return nullptr;
+    }
+    env->SetLongArrayRegion(offsets, 0, (jsize)nTiles + 1, (const jlong *)off.data());
+    if (predictors) env->SetByteArrayRegion(predictors, 0, (jsize)nTiles, (const jbyte *)pred.data());
+    if (status) env->SetIntArrayRegion(status, 0, (jsize)nTiles, (const jint *)st.data());
+    jbyteArray result = env->NewByteArray((jsize)off[nTiles]);
+    if (result) env->SetByteArrayRegion(result, 0, (jsize)off[nTiles], (const jbyte *)blob.data());
+    return result;
+}
+
+JNIEXPORT void JNICALL Java_org_gridfour_hip_HipCodecNative_multiHuffmanDecode(JNIEnv *env, jclass, jlong multi, jint nRows, jint nCols,
+                                                                             jbyteArray blob, jlongArray offsets, jintArray cells,
+                                                                             jintArray status)
+{
+    if (!multi) return;
+    const size_t per = (size_t)nRows * (size_t)nCols;
+    const jsize nOff = env->GetArrayLength(offsets);
+    if (nOff < 1) return;
+    const size_t nTiles = (size_t)nOff - 1;
+    if ((size_t)env->GetArrayLength(cells) < nTiles * per) {
+        jclass c = env->FindClass("java/lang/IllegalArgumentException");
+        if (c) env->ThrowNew(c, "cells must hold nTiles x nRows x nCols values");
+        return;
+    }
+    std::vector<uint64_t> off((size_t)nOff);
+    env->GetLongArrayRegion(offsets, 0, nOff, (jlong *)off.data());
+    const std::vector<uint8_t> b = bytesOf(env, blob);
+    if (off[nTiles] > (uint64_t)env->GetArrayLength(blob)) {
+        jclass c = env->FindClass("java/lang/IllegalArgumentException");
+        if (c) env->ThrowNew(c, "offsets run past the packings");
+        return;
+    }
+    std::vector<int32_t> v(nTiles * per + 1), st(nTiles + 1);
+    const gf_status s = gf_huffman_decode_batch_i32_multi((gf_multi *)(intptr_t)multi, nRows, nCols, nTiles, b.data(), off.data(),
+                                                          v.data(), st.data());
+    if (s != GF_OK) {
+        throwIo(env, gf_status_string(s));
+        return;
+    }
+    env->SetIntArrayRegion(cells, 0, (jsize)(nTiles * per), (const jint *)v.data());
+    if (status) env->SetIntArrayRegion(status, 0, (jsize)nTiles, (const jint *)st.data());
+}
+
 }  // extern "C"

@@ -33,6 +33,26 @@ final class HipCodecNative {
   static native void tilesFromRecords(long handle, int[] codecKinds, int elemType, int nRows, int nCols, byte[] records,
     long[] recordOffsets, boolean verifyChecksums, int[] tileIndices, Object cells, int[] status) throws IOException;
 
+  // ---- read-ahead (gf_readahead_*): gvrs/TileDecompressionAssistant.java as an N-tile prefetch queue ----
+  static native long readaheadCreate(int device, int[] codecKinds, int nRows, int nCols, int maxBatch);
+  static native void readaheadDestroy(long ra);
+  static native void readaheadSubmit(long ra, int tileIndex, byte[] packing);
+  static native int readaheadPending(long ra);
+  /**
+   * Waits while waitIndex is queued or being decoded, then hands over up to indices.length finished tiles: returns
+   * their number n, fills indices[0..n), status[0..n) and cells[i * nRows * nCols ...] (the tile waited for comes first).
+   */
+  static native int readaheadTake(long ra, int waitIndex, int[] indices, int[] cells, int[] status);
+
+  // ---- several GPUs from one JVM (gf_multi_*): contiguous tile ranges per device, no exchange between devices ----
+  static native long multiCreate(int[] devices);
+  static native void multiDestroy(long multi);
+  /** CodecHuffman.encode of nTiles tiles (cells: nTiles x nRows x nCols) over all devices; offsets receives nTiles + 1. */
+  static native byte[] multiHuffmanEncode(long multi, int codecIndex, int nRows, int nCols, int[] cells, long[] offsets,
+    byte[] predictors, int[] status) throws IOException;
+  static native void multiHuffmanDecode(long multi, int nRows, int nCols, byte[] blob, long[] offsets, int[] cells,
+    int[] status) throws IOException;
+
   private HipCodecNative() {
   }
 }
