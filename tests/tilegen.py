@@ -1,4 +1,6 @@
 """Seeded tile generators shared by the CPU and GPU tests."""
+import zlib
+
 import numpy as np
 
 NULL = -(2 ** 31)
@@ -7,7 +9,8 @@ KINDS = ["ramp", "smooth", "noise8", "noise16", "noise32", "uniform", "extremes"
 
 
 def make_tile(kind, n_rows, n_cols, seed=0):
-    rng = np.random.default_rng((hash(kind) & 0xFFFF) * 7919 + n_rows * 131 + n_cols + seed)
+    # (a stable hash of the kind: Python's own string hash changes from process to process)
+    rng = np.random.default_rng((zlib.crc32(kind.encode()) & 0xFFFF) * 7919 + n_rows * 131 + n_cols + seed)
     n = n_rows * n_cols
     if kind == "ramp":
         return (np.arange(n, dtype=np.int64) - 1).astype(np.int32)
