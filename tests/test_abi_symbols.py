@@ -79,3 +79,27 @@ def test_crc32c_known_answers(golden_dir):
     (size,) = struct.unpack_from("<i", data, 16)
     rec = data[16:16 + size]
     assert lib().gf_crc32c(C.c_char_p(rec[:size - 4]), size - 4) == struct.unpack_from("<I", rec, size - 4)[0]
+
+
+def test_handle_entry_points_reject_bad_arguments_without_a_device():
+    """gf_readahead_* / gf_multi_* / gf_host_alloc with null handles and bad arguments: an error code, never a crash;
+    creating them without a device fails loudly (no CPU fallback behind them either)."""
+    L = _lib.lib()
+    n = C.c_size_t(0)
+    assert L.gf_readahead_submit(None, 1, None, 0) == _lib.ERR_ARG
+    assert L.gf_readahead_pending(None) == 0
+    assert L.gf_readahead_take(None, 0, 0, None, None, None, C.byref(n)) == _lib.ERR_ARG
+    L.gf_readahead_destroy(None)
+    L.gf_multi_destroy(None)
+    assert L.gf_multi_count(None) == 0
+    h = C.c_void_p()
+    assert L.gf_readahead_create(0, None, 3, 10, 10, 16, C.byref(h)) == _lib.ERR_ARG          # a codec count without a list
+    assert L.gf_readahead_create(0, None, 0, 0, 10, 16, C.byref(h)) == _lib.ERR_ARG
+    assert L.gf_multi_create(None, 2, C.byref(h)) == _lib.ERR_ARG
+    if L.gf_device_count() == 0:
+        assert L.gf_readahead_create(0, None, 0, 10, 10, 16, C.byref(h)) != _lib.OK and not h.value
+        dev = (C.c_int * 1)(0)
+        assert L.gf_multi_create(dev, 1, C.byref(h)) != _lib.OK and not h.value
+    t0, t1 = C.c_size_t(7), C.c_size_t(7)
+    L.gf_multi_partition(10, 0, 0, C.byref(t0), C.byref(t1))                                  # no shards: an empty range
+    assert (t0.value, t1.value) == (0, 0)
