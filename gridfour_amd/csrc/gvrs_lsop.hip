@@ -179,6 +179,66 @@ __device__ __forceinline__ void lsop_gram_wave(const int32_t *__restrict__ v, ui
     }
 }
 
+// The same sums with the tile's rows passing through a four-row ring in LDS: a row is loaded from HBM once, by the whole
+// workgroup and coalesced, one row ahead of its use, and the 13 neighbours of a cell are LDS reads.  (Read straight from
+// global memory, every one of the four waves issues 13 scattered loads per cell group: 2.71 -> 2.45 ms for the kernel on the
+// ETOPO1-shaped batch, 3.39 -> 2.51 ms on 256x256 tiles; two rows per barrier with the cells of the pair dealt flat to the
+// lanes measured the same.)  Wave w still owns the pairs [26 w, 26 w + 26); one barrier per row.
+template <int W>
+__device__ __forceinline__ void lsop_gram_fma(const double *z, double *acc)
+{
+#pragma unroll
+    for (int q = 0; q < 26; q++) acc[q] = __fma_rn(z[PAIRS.i[W * 26 + q]], z[PAIRS.j[W * 26 + q]], acc[q]);   // exact: see the guard
+}
+
+constexpr uint32_t LSOP_RING_MAXC = 256;         // widest row the ring path takes (one prefetch register per thread)
+
+// Every wave of the workgroup runs this loop (each its own instantiation: only the 26 pairs differ) with the same trip
+// counts, so the barriers inside match up.
+template <int W>
+__device__ __forceinline__ void lsop_gram_rows(const int32_t *__restrict__ v, int32_t *ring, uint32_t nR, uint32_t nC, double *G, int tid)
+{
+    const int lane = tid & 63;
+    double acc[26];
+#pragma unroll
+    for (int q = 0; q < 26; q++) acc[q] = 0.0;
+    for (uint32_t i = (uint32_t)tid; i < 3u * nC; i += 256u) ring[i] = v[i];          // rows 0..2 -> slots 0..2
+    __syncthreads();
+    for (uint32_t r = 2; r < nR; r++) {
+        const bool more = r + 1u < nR && (uint32_t)tid < nC;
+        const int32_t pre = more ? v[(size_t)(r + 1u) * nC + (uint32_t)tid] : 0;
+        const int32_t *r0 = ring + (r & 3u) * nC, *r1 = ring + ((r - 1u) & 3u) * nC, *r2 = ring + ((r - 2u) & 3u) * nC;
+#pragma unroll 1
+        for (uint32_t c = 2u + (uint32_t)lane; c < nC - 2u; c += 64u) {
+            double z[14];
+            z[0] = (double)r0[c];
+            z[1] = (double)r0[c - 1];
+            z[2] = (double)r1[c - 1];
+            z[3] = (double)r1[c];
+            z[4] = (double)r1[c + 1];
+            z[5] = (double)r1[c + 2];
+            z[6] = (double)r0[c - 2];
+            z[7] = (double)r1[c - 2];
+            z[8] = (double)r2[c - 2];
+            z[9] = (double)r2[c - 1];
+            z[10] = (double)r2[c];
+            z[11] = (double)r2[c + 1];
+            z[12] = (double)r2[c + 2];
+            z[13] = 1.0;
+            lsop_gram_fma<W>(z, acc);
+        }
+        if (more) ring[((r + 1u) & 3u) * nC + (uint32_t)tid] = pre;     // the slot of row r - 3
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 26; q++) {
+        double a = acc[q];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) G[W * 26 + q] = a;
+    }
+}
+
 __device__ __forceinline__ double lsop_bcast(double x, int k)           // value of lane k (k wave-uniform)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), k), hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
@@ -264,6 +324,7 @@ struct GfLsopPredictArgs {
 __global__ __launch_bounds__(256, 4) void k_lsop_predict(GfLsopPredictArgs a)
 {
     __shared__ LsopShared S;
+    extern __shared__ __attribute__((aligned(16))) int32_t lsopRing[];      // four rows of the tile (lsop_gram_rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t nInit = lsop_n_init(nR, nC), nInt = lsop_n_interior(nR, nC);
@@ -301,10 +362,18 @@ __global__ __launch_bounds__(256, 4) void k_lsop_predict(GfLsopPredictArgs a)
             // Exact sums: lanes split the cells, the four waves split the 104 accumulators (26 each), FMA.
             // (v_mfma_f64_16x16x4_f64 was measured here: 64-cycle issue for 1024 MACs of which 416 are needed --
             //  6.7 ms against 3.7 ms for this form; FP64 MFMA has the vector rate on gfx950, so padding loses.)
-            if (wave == 0) lsop_gram_wave<0>(v, nC, nInt, S.G, lane);
-            else if (wave == 1) lsop_gram_wave<1>(v, nC, nInt, S.G, lane);
-            else if (wave == 2) lsop_gram_wave<2>(v, nC, nInt, S.G, lane);
-            else lsop_gram_wave<3>(v, nC, nInt, S.G, lane);
+            if (nC <= LSOP_RING_MAXC) {
+                const int w = (int)GF_UNI(wave);                    // (a scalar: each wave runs ONE of the four loops)
+                if (w == 0) lsop_gram_rows<0>(v, lsopRing, nR, nC, S.G, tid);
+                else if (w == 1) lsop_gram_rows<1>(v, lsopRing, nR, nC, S.G, tid);
+                else if (w == 2) lsop_gram_rows<2>(v, lsopRing, nR, nC, S.G, tid);
+                else lsop_gram_rows<3>(v, lsopRing, nR, nC, S.G, tid);
+            } else {
+                if (wave == 0) lsop_gram_wave<0>(v, nC, nInt, S.G, lane);
+                else if (wave == 1) lsop_gram_wave<1>(v, nC, nInt, S.G, lane);
+                else if (wave == 2) lsop_gram_wave<2>(v, nC, nInt, S.G, lane);
+                else lsop_gram_wave<3>(v, nC, nInt, S.G, lane);
+            }
         } else if (tid < 104) {
             // inexact sums: one accumulator per thread, the reference's scan order, multiply and add rounded separately
             const int pi = PAIRS.i[tid], pj = PAIRS.j[tid];
@@ -1003,7 +1072,8 @@ hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, siz
     if (nTiles == 0) return hipSuccess;
     GfLsopPredictArgs a{values, residuals, resStride, coefs, status, nTiles, nRows, nCols};
     const unsigned grid = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
-    hipLaunchKernelGGL(k_lsop_predict, dim3(grid), dim3(256), 0, stream, a);
+    const size_t dyn = (size_t)nCols <= LSOP_RING_MAXC ? (size_t)4 * (size_t)nCols * 4 : 0;
+    hipLaunchKernelGGL(k_lsop_predict, dim3(grid), dim3(256), dyn, stream, a);
     return hipGetLastError();
 }
 
