@@ -268,7 +268,9 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
                                        PackState ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
 {
     // cells [cellBegin, cellEnd) as for pack_flat; on return the window again holds the partial last word at win[0]
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (the wave index as a SCALAR: what derives from it -- the wave's cell range, its window, the loop bounds -- then lives in
+    // scalar registers and the loop is a scalar loop; as `tid >> 6` the compiler has to treat all of it as per-lane values)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = GF_UNI(tid >> 6);
     cellEnd = min(cellEnd, nCells);
     const uint32_t carryWord = wave_windows_begin(win, waveSum);
     const uint32_t quarter = (((cellEnd - cellBegin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
