@@ -46,7 +46,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
     const uint32_t stageCapA = (uint32_t)(2 * sizeof(S.qe)), stageCap = stageCapA + a.ldsStageBytes;
     static_assert(offsetof(CanonDec, qc) == offsetof(CanonDec, qe) + sizeof(S.qe), "qe and qc form one stretch of LDS");
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
         const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
         const uint32_t len = a.lengths[t];
         uint32_t *o = reinterpret_cast<uint32_t *>(a.values) + t * (size_t)nCells;
@@ -297,7 +297,8 @@ hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, uns
         const hipError_t e = gf_opt_in_dyn_lds(k_canon_decode, dyn, opt);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_canon_decode, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    (void)grid;
+    hipLaunchKernelGGL(k_canon_decode, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();
 }
 

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
 
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncod
     const int tid = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
         // declined, overflow: nothing to write; a uniform tile (exactly the 6 header bytes) was written by k_canon_encode
         if (a.status[t] != GF_K_OK || a.lengths[t] <= 6u) continue;
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
@@ -578,10 +578,10 @@ __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncod
 hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream)
 {
     if (a.nTiles == 0) return hipSuccess;
-    const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
+    const dim3 grid = gf_tile_grid(a.nTiles);
     if (!a.packRecs) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_canon_encode, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
-    hipLaunchKernelGGL(k_canon_pack, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_canon_encode, grid, dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_canon_pack, grid, dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

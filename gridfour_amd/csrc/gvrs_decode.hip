@@ -1656,7 +1656,8 @@ __global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDe
         if (a.retryFlag && *a.retryFlag == 0u) return;               // the fast kernel decoded every tile
     }
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_TILES(t, a.nTiles, MODE == DEC_FAST) {                     // the fast kernel: one tile per workgroup, no loop (it never
+                                                                      // touches the per-workgroup workspace)
         if constexpr (MODE == DEC_GENERAL) {
             if (a.retryFlag && a.status[t] != GF_K_RETRY) continue;
         }
@@ -2239,7 +2240,7 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         // when nothing is marked)
         if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST>, dyn, optF)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(a.retryFlag, 0, 4, stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+        hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, a);
     }
     hipLaunchKernelGGL(k_huffman_decode<DEC_GENERAL>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();

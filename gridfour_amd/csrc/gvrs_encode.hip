@@ -376,7 +376,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
         if (a.retryFlag && *a.retryFlag == 0u) return;               // the fast kernel finished every tile
     }
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_TILES(t, a.nTiles, FAST) {                                     // the fast kernel: one tile per workgroup, no loop
         if constexpr (!FAST) {
             if (a.retryFlag && a.status[t] != GF_K_RETRY) continue;
         }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
     const int tid = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
         if (a.status[t] != GF_K_OK) continue;                             // declined, overflow: nothing to write
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     S.tab[tid] = (8ull << 56) | (uint64_t)tid;
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
         if (tid == 0) { S.flags = 0; S.sumStart = 0; S.nStart = 0; }
         __syncthreads();
@@ -993,21 +993,20 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (a.retryFlag && 6ull * nCells < (1ull << 23)) {
         const hipError_t e = hipMemsetAsync(a.retryFlag, 0, 4, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_huffman_encode<true>, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(k_huffman_encode<true>, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
         hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid < 2048 ? grid : 2048), dim3(ENC_THREADS), 0, stream, a);
     } else {
         GfEncodeArgs g = a;
         g.retryFlag = nullptr;
         hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid), dim3(ENC_THREADS), 0, stream, g);
     }
-    hipLaunchKernelGGL(k_huffman_pack, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_huffman_pack, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t gf_launch_m32_streams(const GfM32Args &a, hipStream_t stream)
 {
     if (a.nTiles == 0) return hipSuccess;
-    const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
-    hipLaunchKernelGGL(k_m32_streams, dim3(grid), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_m32_streams, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_encode(const uint3
     const uint32_t nC = (uint32_t)nCols, n = (uint32_t)nRows * nC;
     const uint32_t nSign = (n + 7u) >> 3;
     const int lane = threadIdx.x & 63;
-    for (size_t t = blockIdx.x; t < nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, nTiles) {                                           // no tile loop: see gvrs_kernels.h
         const uint32_t *__restrict__ c = raw + t * (size_t)n;
         uint8_t *pSign = planes + t * planeStride;
         uint8_t *pExp = pSign + nSign, *pM1 = pExp + n, *pM2 = pM1 + n, *pM3 = pM2 + n;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_decode(const uint8
     const uint32_t nR = (uint32_t)nRows, nC = (uint32_t)nCols, n = nR * nC;
     const uint32_t nSign = (n + 7u) >> 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (size_t t = blockIdx.x; t < nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, nTiles) {                                           // no tile loop: see gvrs_kernels.h
         const uint8_t *pSign = planes + t * planeStride;
         const uint8_t *pExp = pSign + nSign, *pM1 = pExp + n, *pM2 = pM1 + n, *pM3 = pM2 + n;
         uint32_t *o = raw + t * (size_t)n;
@@ -212,8 +212,7 @@ hipError_t gf_launch_float_planes_encode(const uint32_t *raw, uint8_t *planes, s
                                          int nCols, hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
-    const unsigned grid = (unsigned)(nTiles < 16384 ? nTiles : 16384);
-    hipLaunchKernelGGL(k_float_planes_encode, dim3(grid), dim3(FLT_THREADS), 0, stream, raw, planes, planeStride, nTiles, nRows, nCols);
+    hipLaunchKernelGGL(k_float_planes_encode, gf_tile_grid(nTiles), dim3(FLT_THREADS), 0, stream, raw, planes, planeStride, nTiles, nRows, nCols);
     return hipGetLastError();
 }
 
@@ -221,7 +220,6 @@ hipError_t gf_launch_float_planes_decode(const uint8_t *planes, uint32_t *raw, s
                                          int nCols, hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
-    const unsigned grid = (unsigned)(nTiles < 16384 ? nTiles : 16384);
-    hipLaunchKernelGGL(k_float_planes_decode, dim3(grid), dim3(FLT_THREADS), 0, stream, planes, raw, planeStride, nTiles, nRows, nCols);
+    hipLaunchKernelGGL(k_float_planes_decode, gf_tile_grid(nTiles), dim3(FLT_THREADS), 0, stream, planes, raw, planeStride, nTiles, nRows, nCols);
     return hipGetLastError();
 }

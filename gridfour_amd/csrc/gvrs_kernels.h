@@ -17,6 +17,23 @@
 #define GF_K_ERR_ARG (-4)
 #define GF_K_ERR_UNSUPPORTED (-7)
 
+// One tile per workgroup and NO tile loop in the kernel.  A persistent grid-stride loop over tiles invites the compiler to hoist
+// every thread-index and tile-shape term out of it; at the kernels' register caps those dozens of hoisted values are then
+// spilled (VGPRs to scratch -- stored and reloaded once per tile, i.e. HBM traffic; SGPRs into lanes of reserved VGPRs).
+// Measured on the bench batch: k_huffman_decode<fast> 118 -> 86 VGPRs, 72 -> 11 spilled SGPRs, 1.43 -> 1.31 ms;
+// k_huffman_pack 14 -> 6 spilled VGPRs.  GF_FOR_WG_TILE is a `for` that runs at most once (so `continue` / `break` keep
+// their meaning); gf_tile_grid spreads the tiles over x and y so that any tile count fits one launch.
+#define GF_FOR_WG_TILE(t, nTiles) \
+    for (size_t t = (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x; t < (size_t)(nTiles); t = ~(size_t)0)
+// the same with the choice left to a template parameter: a persistent grid-stride loop (1-D grid) when ONESHOT is false
+#define GF_FOR_TILES(t, nTiles, ONESHOT) \
+    for (size_t t = (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x; t < (size_t)(nTiles); t = (ONESHOT) ? ~(size_t)0 : t + gridDim.x)
+inline dim3 gf_tile_grid(size_t nTiles)
+{
+    const size_t gx = nTiles < (1u << 20) ? (nTiles ? nTiles : 1) : (1u << 20), gy = (nTiles + gx - 1) / gx;
+    return dim3((unsigned)gx, (unsigned)(gy ? gy : 1), 1);
+}
+
 // Dynamic LDS beyond the default limit must be opted into, per kernel and PER DEVICE (hipFuncSetAttribute acts on the
 // current device's copy of the function).  One GfDynLdsOptIn per kernel remembers the largest size asked for on each
 // device; contexts on different devices and threads of one process share it safely.

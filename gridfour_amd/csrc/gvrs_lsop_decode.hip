@@ -45,7 +45,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArg
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
     const uint32_t capWords = a.ldsTextBytes >> 2;
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
         const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
         const uint32_t len = a.lengths[t];
         const uint8_t *__restrict__ pk = a.blob + off;
@@ -111,6 +111,7 @@ hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const u
         const hipError_t e = gf_opt_in_dyn_lds(k_lsop_unpack2, ldsTextBytes, opt);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_lsop_unpack2, dim3(grid), dim3(DEC_THREADS), ldsTextBytes, stream, a);
+    (void)grid;
+    hipLaunchKernelGGL(k_lsop_unpack2, gf_tile_grid(nTiles), dim3(DEC_THREADS), ldsTextBytes, stream, a);
     return hipGetLastError();
 }
