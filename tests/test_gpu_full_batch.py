@@ -49,3 +49,36 @@ def test_full_batch_properties(shape, nt, tpr, seed, codec):
           "decode of the compact blob")
     ctx.synchronize()
     assert (b.get_dec_status() == 0).all() and np.array_equal(b.get_decoded(), vals)
+
+
+@pytest.mark.parametrize("codec", ["huffman", "canon", "lsop"])
+def test_more_than_2_20_tiles(codec):
+    """More tiles than one grid row holds (gf_tile_grid: 2^20 workgroups in x, the rest in y): every tile survives the round
+    trip, the tiles either side of the x/y seam and the last one match the oracle byte for byte."""
+    import gridfour_amd
+    from gridfour_amd import DeviceTileBatch
+    n_rows, n_cols = (8, 9) if codec == "lsop" else (4, 5)             # LSOP12 declines tiles below 6 x 6
+    nt = (1 << 20) + 4099
+    cells = n_rows * n_cols
+    ctx = gridfour_amd.GvrsHipContext(0)
+    b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(8 * cells + 1024 + 15) // 16 * 16, codec=codec)
+    b.synth_dem(oracle.DEM_SEED + 11, 1 << 10)
+    b.encode()
+    b.decode()
+    ctx.synchronize()
+    es, ds = b.get_enc_status(), b.get_dec_status()
+    ok = es == 0
+    assert ((es == 0) | (es == 1)).all() and ok.sum() > nt // 2            # tiny tiles: some packings are declined (status 1)
+    assert (ds[ok] == 0).all()
+    vals, dec = b.get_values(), b.get_decoded()
+    assert np.array_equal(dec[ok], vals[ok])
+    lengths = b.get_lengths()
+    enc = {"huffman": lambda v: oracle.codec_huffman_encode(0, n_rows, n_cols, v)[0],
+           "canon": lambda v: oracle.codec_canon_encode(0, n_rows, n_cols, v)[0],
+           "lsop": lambda v: oracle.lsop12_encode(0, n_rows, n_cols, v, False)[0]}[codec]
+    for t in [0, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, nt - 1]:
+        ref = enc(vals[t])
+        if ref is None:
+            assert es[t] == 1, t
+        else:
+            assert es[t] == 0 and b.get_packing(t, int(lengths[t])) == ref, t
