@@ -3,6 +3,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ["GVRS_HIP_DIAG"] = "1"           # the diagnostic flavour of the library carries the stamps
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
