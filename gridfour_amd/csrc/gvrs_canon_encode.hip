@@ -107,6 +107,37 @@ __device__ void cpack_generic(int model, const uint32_t *__restrict__ tile, uint
     }
 }
 
+// the short head of a Linear / Triangle stream in the fast case, one element per thread and chunk, inlined (pack_head of
+// gvrs_encode.hip: a call into cpack_generic costs every tile the callee's register saves in scratch memory)
+template <int MODEL>
+__device__ __forceinline__ void cpack_head(const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
+                                           const uint32_t *tab, uint32_t sEnd, uint32_t *win, uint32_t *__restrict__ out32,
+                                           uint32_t *waveSum, PackState &ps)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t chunk = 0; chunk < sEnd; chunk += ENC_THREADS) {
+        const uint32_t s = chunk + tid;
+        uint32_t x = 0, myBits = 0;
+        if (s < sEnd) {
+            const uint32_t idx = gf_stream_cell(MODEL, nR, nC, s);
+            const uint32_t r = idx / nC, c = idx - r * nC;
+            x = cell_residual(MODEL, tile, nC, idx, r, c, seed);
+            myBits = cn_value_bits(tab, x);
+        }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
+        if (myBits) {
+            BitSink sink;
+            sink.init(win, ps.bitBase + excl - ps.wordBase * 32u);
+            cn_value_emit(sink, tab, x);
+            sink.finish();
+        }
+        __syncthreads();
+        ps.bitBase += total;
+        window_flush(win, out32, ps);
+    }
+}
+
 // the main segment of a model's stream = flat scan over the cells with an emit mask
 template <int MODEL>
 __device__ void cpack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
@@ -252,7 +283,13 @@ __device__ __forceinline__ void cpack_flat_ranges(const uint32_t *__restrict__ t
 
 // workgroups per CU: the histogram + table kernel is capped at four by its 34 KB of LDS (sweep 4..6: 1.81 / 2.00 / 2.00 ms),
 // the pack kernel runs six (80 VGPRs; eight, at 64 VGPRs, cost 0.3 ms with the wave-private windows)
-constexpr int CN_AB_WGS = 4, CN_PACK_WGS = 6;
+#ifndef GF_CN_AB_WGS
+#define GF_CN_AB_WGS 4
+#endif
+#ifndef GF_CN_PACK_WGS
+#define GF_CN_PACK_WGS 6
+#endif
+constexpr int CN_AB_WGS = GF_CN_AB_WGS, CN_PACK_WGS = GF_CN_PACK_WGS;
 
 __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncodeArgs a)
 {
@@ -543,10 +580,10 @@ __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncod
             } else if (model == 1) {
                 cpack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 2) {
-                cpack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                cpack_head<2>(tile, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
                 cpack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 3) {
-                cpack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                cpack_head<3>(tile, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
                 cpack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else {
                 cpack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);

@@ -178,6 +178,45 @@ __device__ PackState pack_generic(int model, const uint32_t *__restrict__ tile, 
     return ps;
 }
 
+// the short head of a Linear / Triangle stream (first column and first row(s): nR + nC elements or so) in the fast case,
+// one element per thread and chunk, INLINED: as a call into pack_generic it cost every tile the callee's register saves --
+// twelve VGPRs per lane stored to and reloaded from scratch, a third of a gigabyte per launch on the bench batch.
+// Requires 256 * elemMaxBits <= window bits (implied by the kernels' `fast` condition).
+template <int MODEL>
+__device__ __forceinline__ PackState pack_head(const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
+                                               const uint64_t *tab, uint32_t sEnd, uint32_t *win, uint32_t *__restrict__ out32,
+                                               uint32_t *waveSum, PackState ps)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t chunk = 0; chunk < sEnd; chunk += ENC_THREADS) {
+        const uint32_t s = chunk + tid;
+        uint32_t x = 0, myBits = 0;
+        int n = 0;
+        if (s < sEnd) {
+            const uint32_t idx = gf_stream_cell(MODEL, nR, nC, s);
+            const uint32_t r = idx / nC, c = idx - r * nC;
+            x = cell_residual(MODEL, tile, nC, idx, r, c, seed);
+            n = gf_m32_len(x);
+            for (int k = 0; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
+        }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
+        if (myBits) {
+            BitSink sink;
+            sink.init(win, ps.bitBase + excl - ps.wordBase * 32u);
+            for (int k = 0; k < n; k++) {
+                const uint64_t cl = tab[gf_m32_byte(x, n, k)];
+                sink.put(cl & 0x00ffffffffffffffull, (uint32_t)(cl >> 56));
+            }
+            sink.finish();
+        }
+        __syncthreads();
+        ps.bitBase += total;
+        window_flush(win, out32, ps);
+    }
+    return ps;
+}
+
 // the main segment of a model's stream = flat scan over the cells with an emit mask; fast path
 // for residuals whose codes fit the window at CPT cells per thread
 template <int MODEL>
@@ -797,10 +836,10 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
             } else if (model == 1) {
                 pack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 2) {
-                ps = pack_generic(2, tile, nR, nC, seed, tab, elemMaxBits, 0u, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                ps = pack_head<2>(tile, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
                 pack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else if (model == 3) {
-                ps = pack_generic(3, tile, nR, nC, seed, tab, elemMaxBits, 0u, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                ps = pack_head<3>(tile, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
                 pack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
             } else {
                 pack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);

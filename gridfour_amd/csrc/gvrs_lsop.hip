@@ -321,7 +321,13 @@ struct GfLsopPredictArgs {
     int nRows, nCols;
 };
 
-__global__ __launch_bounds__(256, 4) void k_lsop_predict(GfLsopPredictArgs a)
+#ifndef GF_LSOP_PREDICT_WGS
+#define GF_LSOP_PREDICT_WGS 4
+#endif
+#ifndef GF_LSOP_PACK2_WGS
+#define GF_LSOP_PACK2_WGS 4
+#endif
+__global__ __launch_bounds__(256, GF_LSOP_PREDICT_WGS) void k_lsop_predict(GfLsopPredictArgs a)
 {
     __shared__ LsopShared S;
     extern __shared__ __attribute__((aligned(16))) int32_t lsopRing[];      // four rows of the tile (lsop_gram_rows)
@@ -592,7 +598,7 @@ struct GfPack2Args {
 
 constexpr uint32_t LSOP_HEADER_BYTES = 55;     // LsHeader.packHeader :219-222 for the canonical container: 7 + 12*4
 
-__global__ __launch_bounds__(ENC_THREADS, 4) void k_canon_pack2(GfPack2Args a)
+__global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(GfPack2Args a)
 {
     __shared__ Pack2Persist P;
     __shared__ Pack2Union S;
