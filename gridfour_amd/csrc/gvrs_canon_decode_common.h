@@ -404,10 +404,30 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
         __syncthreads();
         return st;
     }
-    for (uint32_t e = tid; e < (1u << CD_LUT_BITS); e += DEC_THREADS) {
-        uint32_t cl;
-        const uint32_t sym = cd_search(S.first, S.count, S.offset, S.symByOrder, __brev(e), 1, CD_LUT_BITS, &cl);
-        S.lut[e] = cl ? cd_entry(sym, cl) : 0;
+    {
+        // The lookup table without a search per entry.  Canonical codes tile the code space in order of length: read most
+        // significant bit first over CD_LUT_BITS bits, the codes of length l are the indices [B(l-1), B(l)) with
+        // B(l) = (first[l] + count[l]) << (CD_LUT_BITS - l) = first[l + 1] << (CD_LUT_BITS - l - 1), B(0) = 0.  The bounds
+        // and offset[l] - first[l] are wave-uniform, so the length of an entry is CD_LUT_BITS compare + select pairs on
+        // scalar operands -- same entries as cd_search (the smallest length whose range holds the index), which read
+        // first[] / count[] from LDS in a dependent loop for each of the eight entries of a thread.
+        uint32_t bound[CD_LUT_BITS + 1], adj[CD_LUT_BITS + 1];
+#pragma unroll
+        for (int l = 1; l <= CD_LUT_BITS; l++) {
+            bound[l] = GF_UNI((S.first[l] + S.count[l]) << (CD_LUT_BITS - l));
+            adj[l] = GF_UNI(S.offset[l] - S.first[l]);
+        }
+        for (uint32_t e = tid; e < (1u << CD_LUT_BITS); e += DEC_THREADS) {
+            const uint32_t m = __brev(e) >> (32 - CD_LUT_BITS);
+            uint32_t cl = 0, at = 0;
+#pragma unroll
+            for (int l = CD_LUT_BITS; l >= 1; l--) {
+                const bool in = m < bound[l];                       // bound[] never decreases: the last hit is the smallest l
+                cl = in ? (uint32_t)l : cl;
+                at = in ? adj[l] + (m >> (CD_LUT_BITS - l)) : at;
+            }
+            S.lut[e] = cl ? cd_entry(S.symByOrder[at], cl) : 0;
+        }
     }
     __syncthreads();
     for (uint32_t x = tid; x < (1u << CD_LUT_BITS); x += DEC_THREADS) {     // pair up plain values that share a window

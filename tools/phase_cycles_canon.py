@@ -1,5 +1,6 @@
 """Per-phase shader-clock cycles of k_canon_decode per tile (s_memtime stamps; diagnostic)."""
 import ctypes as C, os, sys
+os.environ["GVRS_HIP_DIAG"] = "1"           # the diagnostic flavour of the library carries the stamps
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gridfour_amd
