@@ -163,8 +163,35 @@ __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, u
             }
         }
     } else {
-        // PredictorModelDifferencingWithNulls.java:137-166: column 0 first (row starts depend on the
-        // first cell of the previous row), then every row on its own
+        // PredictorModelDifferencingWithNulls.java:137-166.  Inside a row the flag follows the RESIDUAL just decoded (null code or
+        // not), at a row start it follows the VALUE of the previous row's first cell (:162-163) -- and a sum may come out as
+        // the null code, Integer.MIN_VALUE, without any null residual (damaged input only: the encoder never sees that value
+        // in a valid cell).  So nothing here may ask a value whether "it was null":
+        //   pass 1, a thread per row: everything behind the row's first null residual (from column 1 on when (r,0) itself is
+        //           null) -- restarts from the seed, independent of column 0; the stretch before it stays as residuals;
+        //   pass 2, wave 0: the column-0 chain over the rows.  Where a sum comes out as the null code, the row's first stretch
+        //           is finished right there, continuing from that sum as the reference does;
+        //   pass 3, a thread per row: the first stretch of the rows whose first VALUE is not the null code (the others are
+        //           complete: a null residual has no first stretch, the rare other case was finished in pass 2).
+        for (uint32_t r = tid; r < nR; r += DEC_THREADS) {
+            uint32_t *row = o + (size_t)r * nC;
+            uint32_t c = 1;
+            if (row[0] != GF_NULL_CODE)
+                while (c < nC && row[c] != GF_NULL_CODE) c++;
+            uint32_t prior = seed;
+            bool nullFlag = true;
+            for (; c < nC; c++) {
+                const uint32_t test = row[c];
+                if (test == GF_NULL_CODE) {
+                    nullFlag = true;
+                } else {
+                    if (nullFlag) { nullFlag = false; prior = seed; }
+                    prior += test;
+                    row[c] = prior;
+                }
+            }
+        }
+        __syncthreads();
         if (wave == 0) {
             // wave-uniform scalar loop (all lanes hold the same state; lane 0 stores)
             uint32_t prior = seed;
@@ -174,7 +201,17 @@ __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, u
                 uint32_t first = GF_NULL_CODE;
                 if (test != GF_NULL_CODE) {
                     first = (nullFlag ? seed : prior) + test;
-                    if (lane == 0) o[(size_t)r * nC] = first;
+                    if (lane == 0) {
+                        uint32_t *row = o + (size_t)r * nC;
+                        row[0] = first;
+                        if (first == GF_NULL_CODE) {
+                            uint32_t p = first;
+                            for (uint32_t c = 1; c < nC && row[c] != GF_NULL_CODE; c++) {
+                                p += row[c];
+                                row[c] = p;
+                            }
+                        }
+                    }
                 }
                 // row start of the next row: prior = first cell of this row, flag by VALUE (:162-163)
                 prior = first;
@@ -185,17 +222,12 @@ __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, u
         for (uint32_t r = tid; r < nR; r += DEC_THREADS) {
             uint32_t *row = o + (size_t)r * nC;
             uint32_t prior = row[0];
-            // inside a row the flag follows the residual just decoded; (r,0) was null iff its value is
-            bool nullFlag = prior == GF_NULL_CODE;
+            if (prior == GF_NULL_CODE) continue;
             for (uint32_t c = 1; c < nC; c++) {
                 const uint32_t test = row[c];
-                if (test == GF_NULL_CODE) {
-                    nullFlag = true;
-                } else {
-                    if (nullFlag) { nullFlag = false; prior = seed; }
-                    prior += test;
-                    row[c] = prior;
-                }
+                if (test == GF_NULL_CODE) break;
+                prior += test;
+                row[c] = prior;
             }
         }
     }

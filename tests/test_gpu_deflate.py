@@ -248,3 +248,47 @@ def test_match_behind_the_room_is_not_looked_at():
     want = oracle.codec_deflate_decode(10, 4, pk)
     vals, st = codec.decode_batch(10, 4, [pk])
     assert st[0] == 0 and np.array_equal(vals[0], want)
+
+
+def _nulls_packings(n_rows, n_cols, seed, residuals):
+    """CodecDeflate and CodecHuffman packings of predictor 4 (DifferencingWithNulls) around a hand-made residual stream."""
+    import zlib
+    m32 = oracle.m32_encode_seq(np.asarray(residuals, np.int64).astype(np.int32))
+    head = bytes([0, 4]) + struct.pack("<iI", seed, len(m32))
+    return head + zlib.compress(m32, 6), oracle.huffman_encode(np.frombuffer(m32, np.uint8), 80, head)[0]
+
+
+def test_a_sum_that_comes_out_as_the_null_code_is_not_a_null():
+    """PredictorModelDifferencingWithNulls.decode (:137-166): inside a row the null flag follows the RESIDUAL, at a row start
+    the VALUE of the previous row's first cell.  A sum can come out as Integer.MIN_VALUE -- the null code -- without a null
+    residual (damaged or hand-made input only; found by tools/soak.py, seed 424242).  The row goes on from that sum; the
+    next row then starts from the seed."""
+    import gridfour_amd
+    ctx = gridfour_amd.GvrsHipContext(0)
+    null, imin = int(NULL), -2**31
+    nr, nc, seed = 6, 5, 5
+    wrap = lambda x: (x + 2**31) % 2**32 - 2**31
+    res = np.array([[wrap(imin - seed), 7, null, 3, 4],        # (0,0): seed + r = MIN_VALUE; (0,1) continues from it
+                    [wrap(imin - seed), 1, 2, 3, 4],           # row start: prior MIN_VALUE counts as null -> seed again -> MIN_VALUE again
+                    [9, wrap(imin - seed - 9), 2, null, 1],    # the null-code sum in the middle of a row
+                    [null, 4, 5, 6, 7],                        # a real null first
+                    [wrap(imin - seed), null, null, 8, 9],     # nulls straight after the sum
+                    [1, 2, 3, 4, 5]], np.int64)
+    cases = [(nr, nc, seed, res.ravel())]
+    rng = np.random.default_rng(77)
+    for _ in range(6):                                          # every row starts with such a sum, random rest, odd shapes
+        r, c, s = int(rng.integers(1, 40)), int(rng.integers(1, 9)), int(rng.integers(-1000, 1000))
+        x = rng.integers(-300, 300, (r, c)).astype(np.int64)
+        x[rng.random((r, c)) < 0.15] = null
+        x[:, 0] = wrap(imin - s)
+        if c > 2:
+            x[::3, 1] = 11                                      # a plain value after the sum
+        cases.append((r, c, s, x.ravel()))
+    for r, c, s, x in cases:
+        pk_deflate, pk_huffman = _nulls_packings(r, c, s, x)
+        for codec, dec, pk in ((gridfour_amd.CodecDeflateHip(context=ctx), oracle.codec_deflate_decode, pk_deflate),
+                               (gridfour_amd.CodecHuffmanHip(context=ctx), oracle.codec_huffman_decode, pk_huffman)):
+            ref = dec(r, c, pk)
+            assert (ref[::c] == imin).sum() >= 1                # the case is in there
+            vals, st = codec.decode_batch(r, c, [pk, pk])
+            assert st[0] == 0 and st[1] == 0 and np.array_equal(vals[0], ref) and np.array_equal(vals[1], ref), (r, c, s)
