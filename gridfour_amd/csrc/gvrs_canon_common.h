@@ -63,12 +63,33 @@ struct CanonScratch {
     uint32_t metaTab[CN_META + 4];       // (len << 16) | bit-reversed code
     uint8_t mtokCode[CN_META + 4], mtokRun[CN_META + 4];
     uint32_t blc[16];
-    // package-merge (rare): one level's items and the next level's package counts
+};
+
+// Scratch of the package-merge (codes that would be longer than CN_MAXLEN bits: rare): one level's items and the next level's
+// package counts.  ONE per workgroup, shared by the waves that build the code tables side by side and taken under a lock
+// (cn_pm_acquire): a scratch per tree cost the canonical encoder 8.8 KB of LDS, i.e. its fifth workgroup per CU.
+struct CanonPM {
     uint32_t pmM[2 * CN_SYMS];           // bit 31 = package, low bits = count
     uint32_t pmPC[CN_SYMS];
     uint32_t pmMask[CN_MAXLEN][(2 * CN_SYMS + 31) / 32];
     uint32_t pmB[CN_MAXLEN];
 };
+
+// the lock word lives outside the scratch unions (zeroed with the per-tile state); one wave at a time holds it
+__device__ __forceinline__ void cn_pm_acquire(uint32_t *lock, int lane)
+{
+    if (lane == 0) {
+        while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+}
+__device__ __forceinline__ void cn_pm_release(uint32_t *lock, int lane)
+{
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) atomicExch(lock, 0u);
+}
 
 // Tree by data-parallel rounds (see wave_huff_rounds in gvrs_encode.hip for why this reproduces the
 // reference's linked-list merge).  K: live nodes in list order, key = count << 10 | tie, NREG*64 slots,
@@ -118,28 +139,29 @@ __device__ __forceinline__ void cn_rounds(uint16_t *parent, uint32_t (&K)[8], in
 // looking at the first n items: a base item among them gets one more bit, the packages among them decide
 // n for the level above.  Base items keep their order in every level, so "the base items among the first
 // n" is a prefix [0, b_d) and the length of leaf i is the number of levels with i < b_d.
-__device__ __forceinline__ void cn_package_merge(CanonScratch &S, int nb, uint8_t *lenSorted, int lane)
+__device__ __forceinline__ void cn_package_merge(CanonScratch &S, CanonPM &M, uint32_t *pmLock, int nb, uint8_t *lenSorted, int lane)
 {
+    cn_pm_acquire(pmLock, lane);
     const uint32_t unb = (uint32_t)nb;
     uint32_t nPair = 0;                                  // packages feeding the current level
     for (int d = 0; d < CN_MAXLEN; d++) {
         const uint32_t len = unb + nPair;
         const uint32_t words = (len + 31u) >> 5;
-        for (uint32_t w = (uint32_t)lane; w < words; w += 64) S.pmMask[d][w] = 0;
+        for (uint32_t w = (uint32_t)lane; w < words; w += 64) M.pmMask[d][w] = 0;
         __builtin_amdgcn_wave_barrier();
         // base item i goes behind the packages with a smaller count; package j behind the base items with count <= its own
         for (uint32_t i = (uint32_t)lane; i < unb; i += 64) {
             const uint32_t c = S.cntOf[i];
             uint32_t lo = 0, hi = nPair;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S.pmPC[mid] < c) lo = mid + 1; else hi = mid; }
-            S.pmM[i + lo] = c;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (M.pmPC[mid] < c) lo = mid + 1; else hi = mid; }
+            M.pmM[i + lo] = c;
         }
         for (uint32_t j = (uint32_t)lane; j < nPair; j += 64) {
-            const uint32_t c = S.pmPC[j];
+            const uint32_t c = M.pmPC[j];
             uint32_t lo = 0, hi = unb;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S.cntOf[mid] <= c) lo = mid + 1; else hi = mid; }
-            S.pmM[j + lo] = c | 0x80000000u;
-            atomicOr(&S.pmMask[d][(j + lo) >> 5], 1u << ((j + lo) & 31u));
+            M.pmM[j + lo] = c | 0x80000000u;
+            atomicOr(&M.pmMask[d][(j + lo) >> 5], 1u << ((j + lo) & 31u));
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t nNext = len >> 1;
@@ -147,13 +169,13 @@ __device__ __forceinline__ void cn_package_merge(CanonScratch &S, int nb, uint8_
 #pragma unroll
         for (int q = 0; q < (CN_SYMS + 63) / 64; q++) {
             const uint32_t j = (uint32_t)(q * 64 + lane);
-            pc[q] = j < nNext ? (S.pmM[2 * j] & 0x7fffffffu) + (S.pmM[2 * j + 1] & 0x7fffffffu) : 0u;
+            pc[q] = j < nNext ? (M.pmM[2 * j] & 0x7fffffffu) + (M.pmM[2 * j + 1] & 0x7fffffffu) : 0u;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < (CN_SYMS + 63) / 64; q++) {
             const uint32_t j = (uint32_t)(q * 64 + lane);
-            if (j < nNext) S.pmPC[j] = pc[q];
+            if (j < nNext) M.pmPC[j] = pc[q];
         }
         nPair = nNext;
         __builtin_amdgcn_wave_barrier();
@@ -164,31 +186,32 @@ __device__ __forceinline__ void cn_package_merge(CanonScratch &S, int nb, uint8_
         uint32_t merged = 0;
         for (uint32_t w0 = 0; w0 < (n + 31u) >> 5; w0 += 64) {
             const uint32_t w = w0 + (uint32_t)lane;
-            uint32_t m = (w << 5) < n ? S.pmMask[d][w] : 0u;
+            uint32_t m = (w << 5) < n ? M.pmMask[d][w] : 0u;
             if ((w << 5) < n && n - (w << 5) < 32u) m &= (1u << (n - (w << 5))) - 1u;
             uint32_t pcnt = (uint32_t)__popc(m);
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) pcnt += gf_lane_xor(pcnt, o);
             merged += pcnt;
         }
-        if (lane == 0) S.pmB[d] = n - merged;
+        if (lane == 0) M.pmB[d] = n - merged;
         n = 2u * merged;
     }
     __builtin_amdgcn_wave_barrier();
     for (uint32_t i = (uint32_t)lane; i < unb; i += 64) {
         uint32_t bits = 0;
-        for (int d = 0; d < CN_MAXLEN; d++) bits += i < S.pmB[d] ? 1u : 0u;
+        for (int d = 0; d < CN_MAXLEN; d++) bits += i < M.pmB[d] ? 1u : 0u;
         lenSorted[i] = (uint8_t)bits;
     }
     __builtin_amdgcn_wave_barrier();
+    cn_pm_release(pmLock, lane);
 }
 
 // Code lengths of an alphabet of nSym (<= 64*NREG) symbols from counts cnt[] (LDS) into lenOut[sym].
 // Returns the number of used symbols; *maxLenOut = longest code.  At least two symbols must be used
 // (the callers guarantee it: the end-of-text symbol always counts 1).
 template <int NREG>
-__device__ __forceinline__ int cn_code_lengths(CanonScratch &S, const uint32_t *cnt, int nSym, uint8_t *lenOut, int lane,
-                                               uint32_t *maxLenOut)
+__device__ __forceinline__ int cn_code_lengths(CanonScratch &S, CanonPM &M, uint32_t *pmLock, const uint32_t *cnt, int nSym,
+                                               uint8_t *lenOut, int lane, uint32_t *maxLenOut)
 {
     uint32_t K[8];
     int n = 0;
@@ -239,9 +262,13 @@ __device__ __forceinline__ int cn_code_lengths(CanonScratch &S, const uint32_t *
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) maxLen = max(maxLen, gf_lane_xor(maxLen, o));
+#ifdef GF_CN_FORCE_PM                                                 // stress build of the shared package-merge scratch (tools/)
+    if (n >= 2) {
+#else
     if (maxLen > (uint32_t)CN_MAXLEN) {                              // TreeBuilder.java:173-178
+#endif
         uint8_t *lenSorted = reinterpret_cast<uint8_t *>(S.parent);  // the tree is no longer needed
-        cn_package_merge(S, n, lenSorted, lane);
+        cn_package_merge(S, M, pmLock, n, lenSorted, lane);
         maxLen = 0;
 #pragma unroll
         for (int r = 0; r < NREG; r++) {
@@ -386,12 +413,12 @@ struct CanonBuilt {
 // Everything CanonicalHuffman.encode :191-200 + buildCodeLengthTree :285-343 decide, for one stream, by
 // one wave.  hist[CN_HIST]: symbol counts INCLUDING the end-of-text count of 1; nGap: values hit by the
 // -8333608 quirk.  img must be zeroed (CN_IMG_WORDS).  tab[CN_SYMS] receives the code table.
-__device__ __forceinline__ CanonBuilt cn_build(CanonScratch &S, const uint32_t *hist, uint32_t nGap, uint32_t *tab,
-                                               uint32_t *img, int lane)
+__device__ __forceinline__ CanonBuilt cn_build(CanonScratch &S, CanonPM &M, uint32_t *pmLock, const uint32_t *hist, uint32_t nGap,
+                                               uint32_t *tab, uint32_t *img, int lane)
 {
     CanonBuilt B;
     uint32_t maxLen, metaMax;
-    cn_code_lengths<8>(S, hist, CN_SYMS, S.len, lane, &maxLen);
+    cn_code_lengths<8>(S, M, pmLock, hist, CN_SYMS, S.len, lane, &maxLen);
     cn_assign_codes<8>(S, S.len, CN_SYMS, tab, lane);
     const int nTok = cn_rle(S, S.len, CN_SYMS, S.tokCode, S.tokRun, lane);
     // meta alphabet: token codes + end-of-text (count 1, never written)  :289-297
@@ -399,7 +426,7 @@ __device__ __forceinline__ CanonBuilt cn_build(CanonScratch &S, const uint32_t *
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < nTok; i += 64) atomicAdd(&S.metaCnt[S.tokCode[i]], 1u);
     __builtin_amdgcn_wave_barrier();
-    cn_code_lengths<1>(S, S.metaCnt, CN_META, S.metaLen, lane, &metaMax);
+    cn_code_lengths<1>(S, M, pmLock, S.metaCnt, CN_META, S.metaLen, lane, &metaMax);
     cn_assign_codes<1>(S, S.metaLen, CN_META, S.metaTab, lane);
     const int nMtok = cn_rle(S, S.metaLen, CN_META, S.mtokCode, S.mtokRun, lane);
     // image: reserved bit 0 (:306), raw 5-bit meta tokens (LengthEncoder.java:169-195), coded text-length tokens (:322-342)

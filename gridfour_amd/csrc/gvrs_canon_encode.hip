@@ -46,11 +46,16 @@ struct CanonPersist {
     uint32_t waveSum[ENC_WAVES];
     unsigned long long sumStart;
     uint32_t nStart;
+    uint32_t pmLock;                            // cn_pm_acquire
 };
 
+struct CanonTrees {
+    CanonScratch tree[3];
+    CanonPM pm;                                 // shared: see CanonPM
+};
 union CanonUnion {
     uint32_t histR[3][CN_HIST * HIST_R];        // phase A
-    CanonScratch tree[3];                       // phase B
+    CanonTrees b;                               // phase B
 };
 
 // upper bound of the bits one value can take given the longest code and the largest escape kind
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
 
         // ---------------- phase A: null / uniform scan + three histograms ----------------
         for (int i = tid; i < 3 * CN_HIST * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
-        if (tid == 0) { P.flags = 0; P.sumStart = 0; P.nStart = 0; }
+        if (tid == 0) { P.flags = 0; P.sumStart = 0; P.nStart = 0; P.pmLock = 0; }
         if (tid < 3) { P.maxKind[tid] = 0; P.model[tid] = 0; P.nGap[tid] = 0; }
         __syncthreads();
 
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
         // ---------------- phase B: code tables of the candidates, one wave each ----------------
         if (wave < 3 && P.model[wave] != 0) {
             const int p = wave;
-            const CanonBuilt B = cn_build(S.tree[p], P.hist[p], P.nGap[p], P.tab[p], P.img[p], lane);
+            const CanonBuilt B = cn_build(S.b.tree[p], S.b.pm, &P.pmLock, P.hist[p], P.nGap[p], P.tab[p], P.img[p], lane);
             if (lane == 0) {
                 P.imgBits[p] = B.imgBits;
                 P.maxLen[p] = B.maxLen;

@@ -456,11 +456,16 @@ struct Pack2Persist {
     uint32_t maxKind[2];
     uint32_t nGap[2];
     uint32_t waveSum[ENC_WAVES];
+    uint32_t pmLock;                            // cn_pm_acquire
 };
 
+struct Pack2Trees {
+    CanonScratch tree[2];
+    CanonPM pm;                                 // shared: see CanonPM
+};
 union Pack2Union {
     uint32_t histR[2][CN_HIST * HIST_R];
-    CanonScratch tree[2];
+    Pack2Trees b;
     uint32_t win[WIN_WORDS + WIN_SLACK];
 };
 
@@ -615,6 +620,7 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
 
         for (int i = tid; i < 2 * CN_HIST * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
         if (tid < 2) { P.maxKind[tid] = 0; P.nGap[tid] = 0; }
+        if (tid == 0) P.pmLock = 0;
         __syncthreads();
         const uint32_t rep = (uint32_t)lane & (HIST_R - 1);
         for (int sidx = 0; sidx < 2; sidx++) {
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
         for (int i = tid; i < 2 * CN_IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
         __syncthreads();
         if (wave < 2) {
-            const CanonBuilt B = cn_build(S.tree[wave], P.hist[wave], P.nGap[wave], P.tab[wave], P.img[wave], lane);
+            const CanonBuilt B = cn_build(S.b.tree[wave], S.b.pm, &P.pmLock, P.hist[wave], P.nGap[wave], P.tab[wave], P.img[wave], lane);
             if (lane == 0) { P.imgBits[wave] = B.imgBits; P.maxLen[wave] = B.maxLen; P.textBits[wave] = B.textBits; }
         }
         __syncthreads();

@@ -82,3 +82,29 @@ def test_more_than_2_20_tiles(codec):
             assert es[t] == 1, t
         else:
             assert es[t] == 0 and b.get_packing(t, int(lengths[t])) == ref, t
+
+
+def test_more_than_2_20_tiles_float_planes():
+    """The CodecFloat plane stage on more tiles than one grid row holds: planes of the tiles either side of the seam and of the
+    last tile equal the oracle's, every tile comes back bit for bit."""
+    import gridfour_amd
+    from gridfour_amd import DeviceBuffer, lib
+    from gridfour_amd._lib import check
+    n_rows, n_cols, nt = 3, 5, (1 << 20) + 777
+    cells = n_rows * n_cols
+    ctx = gridfour_amd.GvrsHipContext(0)
+    rng = np.random.default_rng(5)
+    vals = (rng.standard_normal((nt, cells)) * 1000).astype(np.float32)
+    vals[rng.random((nt, cells)) < 0.01] = np.nan
+    pstride = int(lib().gf_float_planes_bytes(n_rows, n_cols))
+    d_in, d_planes, d_out = DeviceBuffer(ctx, nt * cells * 4), DeviceBuffer(ctx, nt * pstride), DeviceBuffer(ctx, nt * cells * 4)
+    d_in.upload(vals)
+    d_out.fill(0)
+    check(lib().gf_float_planes_encode_dev(ctx.handle, None, n_rows, n_cols, nt, d_in.ptr, d_planes.ptr, pstride), "enc")
+    check(lib().gf_float_planes_decode_dev(ctx.handle, None, n_rows, n_cols, nt, d_planes.ptr, pstride, d_out.ptr), "dec")
+    ctx.synchronize()
+    back = d_out.download(np.uint32, nt * cells).reshape(nt, cells)
+    assert np.array_equal(back, vals.view(np.uint32))
+    planes = d_planes.download(np.uint8, nt * pstride).reshape(nt, pstride)
+    for t in [0, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, nt - 1]:
+        assert planes[t].tobytes() == bytes(oracle.float_planes_encode(n_rows, n_cols, vals[t].view(np.uint32))), t
