@@ -1471,7 +1471,7 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
     gf_status s = lsopParseLengths(c, st, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths);
     if (s != GF_OK) return s;
     GF_HIP(gf_launch_lsop_unpack2(dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride, dCoefs,
-                                  dScratchStatus, nTiles, nRows, nCols, gf_canon_decode_lds_text(nRows, nCols), grid, st,
+                                  dScratchStatus, nTiles, nRows, nCols, gf_lsop_unpack_lds_text(nRows, nCols), grid, st,
                                   (const uint32_t *)c->trees.p));
     s = lsopUnpackM32Deflate(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride,
                              dCoefs, dScratchStatus);

@@ -266,23 +266,34 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
 
 }  // namespace
 
+// LDS per workgroup that still lets FIVE workgroups run on a CU.  Measured (k_lsop_unpack2, same tables): 32,240 bytes run
+// four to a CU, 31,744 five -- LDS is handed out in steps coarser than 512 bytes (1,280 fits both findings).
+static constexpr size_t CD_FIFTH = 31 * 1024, CD_QUARTER = 40 * 1024;
+
 uint32_t gf_canon_decode_lds_text(int nRows, int nCols)
 {
-    // LDS copy of a packing: typical terrain packs to 0.5-1 byte per cell; larger packings are read in place
+    // LDS copy of a packing: typical terrain packs to 0.5-1 byte per cell; larger packings are read in place.  Since the tile loop
+    // went the kernel needs 75 VGPRs and LDS alone decides how many workgroups a CU holds: where the usual size lands just above
+    // a fifth of the CU's LDS (ETOPO1-shaped tiles: 18.5 KB of tables + 14.5 KB of text) the copy is trimmed to what lets five
+    // in, as long as that leaves half a byte per cell -- decode of the bench batch 2.29 -> 2.06 ms, although the value stage then
+    // shrinks to the 4 KB of the dead sync arrays (a larger stage instead of text measured the same, 2.06 / 2.10 ms)
     size_t cells = (size_t)nRows * (size_t)nCols;
     size_t want = cells - cells / 4 + 1024;
     if (want > 96 * 1024) want = 96 * 1024;
-    return (uint32_t)((want + 31) & ~(size_t)31);
+    want = (want + 31) & ~(size_t)31;
+    const size_t room = (CD_FIFTH - sizeof(CanonDec)) & ~(size_t)31;
+    if (want > room && room >= cells / 2 + 1024) want = room;
+    return (uint32_t)want;
 }
 
 uint32_t gf_canon_decode_lds_stage(int nRows, int nCols)
 {
-    // what is left of a quarter of the CU's LDS (four workgroups per CU) behind the tables and the text copy, and never
-    // more than a half of the stream could use
+    // what is left of a fifth resp. a quarter of the CU's LDS (the tier the tables and the text copy fall into) and never more
+    // than a half of the stream could use
     const size_t cells = (size_t)nRows * (size_t)nCols;
-    const size_t used = sizeof(CanonDec) + gf_canon_decode_lds_text(nRows, nCols) + 512;
-    const size_t quarter = 40 * 1024;
-    size_t room = quarter > used ? quarter - used : 0;
+    const size_t base = sizeof(CanonDec) + gf_canon_decode_lds_text(nRows, nCols);
+    const size_t budget = base <= CD_FIFTH ? CD_FIFTH : CD_QUARTER - 512;
+    size_t room = budget > base ? budget - base : 0;
     const size_t want = cells > 2 * sizeof(((CanonDec *)nullptr)->qe) ? cells - 2 * sizeof(((CanonDec *)nullptr)->qe) : 0;
     if (room > want) room = want;
     return (uint32_t)(room & ~(size_t)31);

@@ -159,6 +159,7 @@ hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
 size_t gf_canon_pack_rec_words();      // words per tile of GfEncodeArgs::packRecs for the canonical encoder
 hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 uint32_t gf_canon_decode_lds_text(int nRows, int nCols);
+uint32_t gf_lsop_unpack_lds_text(int nRows, int nCols);      // the same for k_lsop_unpack2 (trimmed where that gains a workgroup per CU)
 uint32_t gf_canon_decode_lds_stage(int nRows, int nCols);
 
 // status (optional): tiles whose status is not GF_K_OK take no room in the blob

@@ -98,6 +98,27 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArg
 
 }  // namespace
 
+uint32_t gf_lsop_unpack_lds_text(int nRows, int nCols)
+{
+    // LDS copy of the packing, as in the canonical decoder (3/4 byte per cell + 1 KB; larger packings are read in place) -- but
+    // this kernel has no value stage behind it, and at 46 VGPRs the LDS alone decides how many workgroups a CU holds: where the
+    // usual size lands just above a fifth of the CU's LDS (ETOPO1-shaped tiles: 18.5 KB of tables + 14.5 KB of text = 33 KB)
+    // the copy is trimmed to what still lets five workgroups in, as long as that leaves half a byte per cell: LSOP12 decode of
+    // the ETOPO1-shaped batch 3.73 -> 3.38 ms
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    size_t want = cells - cells / 4 + 1024;
+    if (want > 96 * 1024) want = 96 * 1024;
+    want = (want + 31) & ~(size_t)31;
+    // measured on the bench batch: 32,240 bytes per workgroup still run four to a CU (3.73 ms per decode), 31,744 and less
+    // five (3.38 ms) -- LDS is handed out in steps coarser than the 512 bytes assumed at first (1,280 fits both findings)
+    const size_t fifth = 31 * 1024;
+    if (fifth > sizeof(CanonDec)) {
+        const size_t room = (fifth - sizeof(CanonDec)) & ~(size_t)31;
+        if (room < want && room >= cells / 2 + 1024) want = room;
+    }
+    return (uint32_t)want;
+}
+
 hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                   const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
                                   int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
