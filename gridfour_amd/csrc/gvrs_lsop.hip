@@ -325,7 +325,7 @@ struct GfLsopPredictArgs {
 #define GF_LSOP_PREDICT_WGS 4
 #endif
 #ifndef GF_LSOP_PACK2_WGS
-#define GF_LSOP_PACK2_WGS 4
+#define GF_LSOP_PACK2_WGS 7      // sweep 4 / 6 / 7 workgroups per CU (22 KB of LDS: 7 at most): LSOP12 encode 3.46 / 3.33 / 3.28 ms
 #endif
 __global__ __launch_bounds__(256, GF_LSOP_PREDICT_WGS) void k_lsop_predict(GfLsopPredictArgs a)
 {
