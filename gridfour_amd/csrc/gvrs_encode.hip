@@ -28,6 +28,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gvrs_kernels.h"
 #include "gvrs_encode_layout.h"
 
@@ -36,11 +38,28 @@ namespace {
 #include "gvrs_encode_common.h"
 
 
-union EncScratch {
+// (the diagnostic flavour dumps the trees in the full layout from both kernels)
+#ifdef GF_DIAG
+template <bool FAST> using EncTree = GfHuffTree;
+#else
+template <bool FAST> using EncTree = std::conditional_t<FAST, GfHuffTreeSlim, GfHuffTree>;
+#endif
+template <bool FAST>
+union EncScratchT {
     uint32_t histR[3][256 * HIST_R];            // phase A
-    GfHuffTree tree[3];                         // phase B
+    EncTree<FAST> tree[3];                      // phase B
 };
 
+
+// reduced histogram of predictor slot p (see EncPersist)
+__device__ __forceinline__ uint32_t *enc_hist(EncPersist &P, int p)
+{
+#ifdef GF_ENC_HIST_SEPARATE
+    return P.hist[p];
+#else
+    return reinterpret_cast<uint32_t *>(P.tab[p]);
+#endif
+}
 
 // first M32 byte of residual x and whether it is the whole encoding (CodecM32.java:257-283)
 __device__ __forceinline__ uint32_t m32_first_byte(uint32_t x, bool *single)
@@ -60,7 +79,8 @@ __device__ __forceinline__ uint32_t m32_first_byte(uint32_t x, bool *single)
 // round -- then re-sorts.  tie: leaf = 256 + sorted index, branch k = 254 - k, so that newer
 // branches precede older ones and leaves of equal count (:175-193).  ~15 rounds instead of
 // ~150 dependent merges.  Writes T.parent / T.left / T.nl.  Needs total count < 2^23.
-__device__ __forceinline__ void wave_huff_rounds(GfHuffTree &T, uint32_t (&K)[4], int n, int lane)
+template <class Tree>
+__device__ __forceinline__ void wave_huff_rounds(Tree &T, uint32_t (&K)[4], int n, int lane)
 {
     uint32_t L = (uint32_t)n, kbase = 0;
     const uint32_t un = (uint32_t)n;
@@ -407,7 +427,7 @@ template <bool FAST>
 __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
     __shared__ EncPersist P;
-    __shared__ EncScratch S;
+    __shared__ EncScratchT<FAST> S;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 #pragma unroll
             for (int k = 0; k < HIST_R; k++) s += h[k];
             if ((i & 255) == 0 && s >= forcedZeros) s -= forcedZeros;
-            P.hist[i >> 8][i & 255] = s;
+            enc_hist(P, i >> 8)[i & 255] = s;
         }
         for (int i = tid; i < 3 * IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
         __syncthreads();                         // histR dead from here: S.tree may be written
@@ -588,7 +608,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
         // ---------------- phase B: the three Huffman trees, one wave each ----------------
         if (wave < 3 && P.model[wave] != 0) {
             const int p = wave;
-            GfHuffTree &T = S.tree[p];
+            EncTree<FAST> &T = S.tree[p];
             int n = 0;
             uint32_t nM32 = 0;
             // B1  sort the used symbols by (count asc, symbol asc)
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 uint32_t key[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const uint32_t cnt = P.hist[p][r * 64 + lane];
+                    const uint32_t cnt = enc_hist(P, p)[r * 64 + lane];
                     key[r] = cnt ? ((cnt << 8) | (uint32_t)(r * 64 + lane)) : 0xFFFFFFFFu;
                     n += __popcll(__ballot(cnt != 0));
                     nM32 += cnt;
@@ -620,14 +640,14 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 GF_STAMP(3);
                 // B2  tree by data-parallel rounds
                 wave_huff_rounds(T, key, n, lane);
-            } else {
+            } else if constexpr (!FAST) {
                 // huge tiles: compaction + rank sort on full 32-bit counts, sequential merge on one lane
                 uint32_t *ccnt = &T.cnt[255];    // compacted counts (temp, branch area is free until the merge)
                 uint16_t *csym = T.bq;           // compacted symbols (temp)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int s = lane + 64 * j;
-                    const uint32_t cnt = P.hist[p][s];
+                    const uint32_t cnt = enc_hist(P, p)[s];
                     const unsigned long long m = __ballot(cnt != 0);
                     const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
                     if (cnt != 0) { ccnt[pos] = cnt; csym[pos] = (uint16_t)s; }

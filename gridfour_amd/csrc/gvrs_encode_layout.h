@@ -8,8 +8,17 @@
 #define GF_ENC_WAVES (GF_ENC_THREADS / 64)
 #define GF_IMG_WORDS 84                 // 80 header bits + 8 + 2559 tree bits -> 83 words
 
+// GF_ENC_HIST_SEPARATE: the reduced histograms as an array of their own -- the layout of the diagnostic flavour's dump
+// (tools/, tests/csrc/host_harness.cpp).  In the shipping kernels histogram p lies over the first half of tab[p]: the wave that
+// builds tree p reads its histogram before anything else and writes its code table last, and the 3 KB saved are what lets
+// eight workgroups of k_huffman_encode<fast> share a CU's LDS (enc_hist() in gvrs_encode.hip).
+#if defined(GF_DIAG) || defined(GF_ENC_LAYOUT_FULL)
+#define GF_ENC_HIST_SEPARATE 1
+#endif
 struct EncPersist {
+#ifdef GF_ENC_HIST_SEPARATE
     uint32_t hist[3][256];                      // reduced histograms
+#endif
     uint64_t tab[3][256];                       // (len << 56) | code per symbol
     uint32_t img[3][GF_IMG_WORDS];                 // packing header + serialised tree
     uint64_t totalBits[3];

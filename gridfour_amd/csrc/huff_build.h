@@ -33,6 +33,18 @@ struct GfHuffTree {
     int n;                 // number of leaves (distinct symbols)
 };
 
+// The fast encoder's tree (k_huffman_encode<true>): at most 256 leaves sorted in registers, the tree built by data-parallel
+// rounds (wave_huff_rounds) -- no branch counts, no branch queue, i.e. 3.8 instead of 5.4 KB per tree; three of them fit under
+// the 12 KB the histogram replicas need anyway, which is what lets eight workgroups of that kernel share a CU's LDS.
+struct GfHuffTreeSlim {
+    uint32_t cnt[256];     // counts of the sorted leaves
+    uint16_t parent[511];
+    uint16_t left[255];
+    uint16_t nl[511];
+    uint8_t sym[256];
+    int n;
+};
+
 // GF_UNI(x): on the device the merge is executed by EVERY lane of one wave with identical
 // (wave-uniform) state; readfirstlane tells the compiler so, which turns the whole loop
 // into scalar code with scalar branches (no exec-mask juggling; hipcc 7.2 miscompiles the
@@ -143,7 +155,8 @@ GF_HD void gf_huff_merge(GfHuffTree &T, int n, bool writer) { gf_huff_merge_t<tr
 // HuffmanEncoder.java:198-213 appends them).  *pos = bit offset of the leaf's
 // "1 + 8-bit symbol" record inside the pre-order tree serialisation
 // (:221-294), counted from the root's bit.  Returns the code length.
-GF_HD int gf_huff_leaf_code(const GfHuffTree &T, int i, uint64_t *code, uint32_t *pos)
+template <class Tree>
+GF_HD int gf_huff_leaf_code(const Tree &T, int i, uint64_t *code, uint32_t *pos)
 {
     const int n = T.n;
     const int root = 2 * n - 2;

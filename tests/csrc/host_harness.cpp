@@ -63,6 +63,7 @@ uint32_t hh_m32_byte(uint32_t x, int n, int k) { return gf_m32_byte(x, n, k); }
 }
 
 // layout of the encode kernel's debug dump (gvrs_encode_layout.h)
+#define GF_ENC_LAYOUT_FULL 1          // the dump comes from the diagnostic flavour of the library
 #include "../../gridfour_amd/csrc/gvrs_encode_layout.h"
 #include <cstddef>
 extern "C" {
