@@ -124,6 +124,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
 // cd_decode_stream; bit positions are relative to the packing (the stream starts at bit 48).
 struct __attribute__((packed, aligned(1))) CdPackedWord { uint32_t v; };
 
+template <unsigned perWave>                                 // as k_huffman_parse_trees
 __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__restrict__ blob, size_t blobBytes,
                                                             const uint64_t *__restrict__ offsets, size_t slotStride,
                                                             const uint32_t *__restrict__ lengths, uint32_t *__restrict__ recs,
@@ -131,16 +132,16 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
 {
     __shared__ uint8_t sMetaLen[CN_META * 64], sOrder[CN_META * 64];   // per-lane columns
     const uint32_t lane = threadIdx.x;
-    const size_t t0 = (size_t)blockIdx.x * 64;
+    const size_t t0 = (size_t)blockIdx.x * perWave;          // perWave lanes walk a tile each: gf_prepass_tiles_per_wave
     // records start out zero: only non-zero lengths are stored below
     {
-        const size_t n = min((size_t)64, nTiles - t0) * GF_CANON_REC_WORDS;
+        const size_t n = min((size_t)perWave, nTiles - t0) * GF_CANON_REC_WORDS;
         uint32_t *r0 = recs + t0 * GF_CANON_REC_WORDS;
         for (size_t i = lane; i < n; i += 64) r0[i] = 0;
         __threadfence_block();
     }
     const size_t t = t0 + lane;
-    if (t >= nTiles) return;
+    if (lane >= perWave || t >= nTiles) return;
     const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
     const uint32_t len = lengths[t];
     uint32_t *rec = recs + t * GF_CANON_REC_WORDS;
@@ -318,7 +319,11 @@ hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, 
                                          hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_canon_parse_lengths, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
-                       slotStride, lengths, recs, nTiles, lsopContainer);
+    if (gf_prepass_tiles_per_wave(nTiles) == 1u)
+        hipLaunchKernelGGL(k_canon_parse_lengths<1>, dim3((unsigned)nTiles), dim3(64), 0, stream, blob, blobBytes, offsets, slotStride,
+                           lengths, recs, nTiles, lsopContainer);
+    else
+        hipLaunchKernelGGL(k_canon_parse_lengths<64>, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
+                           slotStride, lengths, recs, nTiles, lsopContainer);
     return hipGetLastError();
 }

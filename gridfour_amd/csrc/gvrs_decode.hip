@@ -2076,12 +2076,15 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
 // is serial per tree (about a hundred leaves, a hundred instructions each); as a scalar loop inside the decode kernel it
 // kept three of a workgroup's four waves idle for a sixth of the tile time.  Here 64 trees advance per wave instruction
 // and the decode kernel starts from the leaf records.  Same walk, same checks and statuses as parse_tree_wave.
+template <unsigned perWave>                                 // lanes of a wave that walk a tree each: gf_prepass_tiles_per_wave (as
+                                                            // a constant: with one lane the compiler makes the walk scalar code)
 __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__restrict__ blob, size_t blobBytes,
                                                             const uint64_t *__restrict__ offsets, size_t slotStride,
                                                             const uint32_t *__restrict__ lengths, uint32_t *__restrict__ trees,
                                                             size_t nTiles)
 {
-    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x >= perWave) return;
+    const size_t t = (size_t)blockIdx.x * perWave + threadIdx.x;
     if (t >= nTiles) return;
     const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
     const uint32_t len = lengths[t];
@@ -2262,8 +2265,12 @@ hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, 
                                          const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_huffman_parse_trees, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
-                       slotStride, lengths, trees, nTiles);
+    if (gf_prepass_tiles_per_wave(nTiles) == 1u)
+        hipLaunchKernelGGL(k_huffman_parse_trees<1>, dim3((unsigned)nTiles), dim3(64), 0, stream, blob, blobBytes, offsets, slotStride,
+                           lengths, trees, nTiles);
+    else
+        hipLaunchKernelGGL(k_huffman_parse_trees<64>, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
+                           slotStride, lengths, trees, nTiles);
     return hipGetLastError();
 }
 #endif  // GF_DEC_VARIANT
