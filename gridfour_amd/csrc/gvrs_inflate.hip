@@ -268,7 +268,10 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
             z.starved = true;
         } else {
             const uint32_t cmf = inf_bits(z, 8), flg = inf_bits(z, 8);
-            if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 0x20u)) status = GF_K_ERR_FORMAT;
+            if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u) status = GF_K_ERR_FORMAT;
+            // a header that asks for a preset dictionary is no error: zlib returns Z_NEED_DICT, Inflater.inflate 0 bytes with
+            // needsDictionary() set -- nothing is inflated
+            else if (flg & 0x20u) z.starved = true;
         }
         bool done = false;                                         // the stream's last block has ended
         while (status == GF_K_OK && !z.starved && !done && pos <= cap) {
@@ -343,15 +346,16 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
                         prev = (uint32_t)sym;
                         idx++;
                     } else {
+                        // zlib asks for the code AND its extra bits before it looks at either (inflate.c, CODELENS: NEEDBITS(here.bits
+                        // + 2 / 3 / 7)): a stream that ends inside them waits for input, it is not "invalid bit length repeat"
                         uint32_t rep, val = 0;
+                        if (sym == 16) rep = 3u + inf_bits(z, 2);
+                        else if (sym == 17) rep = 3u + inf_bits(z, 3);
+                        else rep = 11u + inf_bits(z, 7);
+                        if (z.starved) break;
                         if (sym == 16) {
                             if (idx == 0) { bad = true; break; }
                             val = prev;
-                            rep = 3u + inf_bits(z, 2);
-                        } else if (sym == 17) {
-                            rep = 3u + inf_bits(z, 3);
-                        } else {
-                            rep = 11u + inf_bits(z, 7);
                         }
                         if (idx + rep > nLL + nD) { bad = true; break; }
                         for (uint32_t i = lane; i < rep; i += 64) T.lens[idx + i] = (uint8_t)val;

@@ -40,7 +40,11 @@ inline dim3 gf_tile_grid(size_t nTiles)
 // trees.  Small batches therefore give every tile a wave of its own -- an instantiation with ONE active lane, which the compiler
 // turns into scalar code (with 2 or 4 lanes, or the lane count as a kernel argument, half the gain is lost): decode of the
 // 1,024-tile batch 0.339 -> 0.300 ms; on the 12,960-tile batch the same costs 0.07 ms, 16 or 8 tiles per wave 0.01-0.02 ms.
-inline unsigned gf_prepass_tiles_per_wave(size_t nTiles) { return nTiles <= 2048 ? 1u : 64u; }
+#ifndef GF_PREPASS_ONE_LANE_MAX
+#define GF_PREPASS_ONE_LANE_MAX 4096      // 120x150 tiles, decode ms with a lane / a wave per tile: 2,048 tiles 0.308 / 0.280, 3,000
+                                          // 0.403 / 0.386, 4,096 0.511 / 0.502, 6,000 0.703 / 0.710, 8,192 0.904 / 0.920
+#endif
+inline unsigned gf_prepass_tiles_per_wave(size_t nTiles) { return nTiles <= GF_PREPASS_ONE_LANE_MAX ? 1u : 64u; }
 
 // Dynamic LDS beyond the default limit must be opted into, per kernel and PER DEVICE (hipFuncSetAttribute acts on the
 // current device's copy of the function).  One GfDynLdsOptIn per kernel remembers the largest size asked for on each

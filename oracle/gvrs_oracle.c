@@ -773,7 +773,9 @@ static int zinflate(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_
     int zr = inflate(&s, Z_FINISH);
     *outLen = s.total_out;
     inflateEnd(&s);
-    if (zr == Z_STREAM_END || zr == Z_BUF_ERROR || zr == Z_OK) return GVO_OK;
+    /* Z_NEED_DICT (a header with the preset-dictionary flag): java.util.zip.Inflater.inflate returns 0 with needsDictionary()
+       set -- nothing inflated, no DataFormatException (Inflater.c: case Z_NEED_DICT) */
+    if (zr == Z_STREAM_END || zr == Z_BUF_ERROR || zr == Z_OK || zr == Z_NEED_DICT) return GVO_OK;
     return GVO_ERR_FORMAT;
 }
 

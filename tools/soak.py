@@ -91,10 +91,12 @@ def main():
                         ok_ref = 0
                     except IOError as ex:
                         ref, ok_ref = None, (1 if "rc=1" in str(ex) else -1)
-                    if ok_ref == 0 and not (st[0] == 0 and np.array_equal(vals[0], ref)):
+                    verdict_differs = (ok_ref == 1 and st[0] != 1) or (ok_ref == -1 and st[0] >= 0)
+                    if verdict_differs or (ok_ref == 0 and not (st[0] == 0 and np.array_equal(vals[0], ref))):
                         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)       # the case, for a look on the CPU
                         np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail.npz"), bad=np.frombuffer(bytes(bad), np.uint8),
-                                 good=np.frombuffer(good[0], np.uint8), shape=np.array([nr, nc]), gpu=vals[0], ref=ref)
+                                 good=np.frombuffer(good[0], np.uint8), shape=np.array([nr, nc]), gpu=vals[0],
+                                 ref=ref if ref is not None else np.zeros(0, np.int32), verdicts=np.array([ok_ref, int(st[0])]))
                     if ok_ref == 0:
                         assert st[0] == 0 and np.array_equal(vals[0], ref), (tag, name, "damaged accepted by the oracle", st[0])
                     elif ok_ref == 1:
