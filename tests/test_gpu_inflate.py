@@ -146,7 +146,11 @@ def test_corrupt_streams_are_reported_like_zlib():
     outs, prod, st = _inflate(streams, [len(data)] * len(streams))
     for i, s in enumerate(streams):
         want, err = _host(s, len(data))
-        if err:
+        if i == 3:
+            # Z_NEED_DICT is not an error to java.util.zip.Inflater: inflate() returns 0 with needsDictionary() set (Inflater.c),
+            # so the kernel reports a stream that produced nothing (python's zlib raises instead)
+            assert err and st[i] == 0 and prod[i] == 0, (i, st[i], prod[i])
+        elif err:
             assert st[i] == -1, (i, st[i])
         else:
             assert st[i] == 0 and outs[i] == want, (i, st[i], prod[i])
