@@ -401,6 +401,8 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
                 const uint32_t lx = li < 8u || li == 28u ? 0u : (li - 4u) >> 2;
                 const uint32_t lbase = li < 8u ? li + 3u : li == 28u ? 258u : ((4u + (li & 3u)) << lx) + 3u;
                 const uint32_t len = lbase + (lx ? inf_bits(z, lx) : 0u);
+                if (z.starved) break;                              // (before the distance code is looked at: on zero-padded bits an
+                                                                   // empty or one-code distance set would read as "invalid distance code")
                 const int ds = inf_sym(z, T.dd, D_BITS, T.dCount, T.dSym);
                 if (ds < 0) {
                     if (ds == -1) status = GF_K_ERR_FORMAT;

@@ -274,3 +274,36 @@ def test_float_packings_decoded_on_the_device():
             assert st[t] == -2
         else:
             assert st[t] == 0 and np.array_equal(got[t], vals[t].view(np.uint32)), t
+
+
+def test_damaged_and_cut_short_at_once():
+    """A bit flipped near the end of the input AND the input cut short behind it, in every combination over the tail of three
+    small streams (literals only, i.e. an empty distance set; fixed codes; ordinary dynamic codes): where zlib merely runs out
+    of input -- inside a code, inside extra bits, inside a header -- it reports what it has and no error, and an error only
+    where a complete field is invalid.  (Found this way of looking by tools/soak.py: a stream that ended inside the extra bits
+    of a code-length repeat code had been called invalid.)"""
+    rng = np.random.default_rng(8)
+    texts = [rng.integers(0, 256, 150).astype(np.uint8).tobytes(),                       # no matches: empty distance set
+             b"abcabcabd" * 4,                                                           # short: fixed codes
+             (rng.integers(0, 6, 400).astype(np.uint8).tobytes() + b"xyz" * 40)]         # dynamic codes, matches
+    streams, caps = [], []
+    for text in texts:
+        good = zlib.compress(text, 9)
+        tail = min(len(good) - 3, 28)
+        for cut in range(len(good) - tail, len(good) + 1):
+            for byte in range(max(2, cut - 12), cut):
+                for bit in range(8):
+                    b = bytearray(good[:cut])
+                    b[byte] ^= 1 << bit
+                    streams.append(bytes(b))
+                    caps.append(len(text) + 64)
+    outs, prod, st = _inflate(streams, caps)
+    n_err = 0
+    for i, s in enumerate(streams):
+        want, err = _host(s, caps[i])
+        if err:
+            n_err += 1
+            assert st[i] == -1, (i, st[i], prod[i])
+        else:
+            assert st[i] == 0 and outs[i] == want, (i, st[i], prod[i], len(want))
+    assert 0 < n_err < len(streams)
