@@ -408,12 +408,21 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     } else {
         a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
-        // Occupancy is set by LDS (M32 stream + start bitmap + tables per workgroup).  Where fewer than three 256-thread
-        // workgroups fit a CU, the 512-thread build (one Huffman cursor per thread, twice the waves per tile) is the faster
-        // one: measured on 200x200 tiles (two workgroups per CU either way) 3.92 -> 2.89 ms for 11,664 tiles, on 256x256
-        // tiles 4.51 -> 2.85 ms; at four per CU (120x150) the 256-thread build wins (1.43 vs 1.84 ms).
-        const size_t ldsPerWg = (size_t)a.ldsM32Bytes + std::max<size_t>(2 * (((size_t)a.ldsM32Bytes >> 5) + 2) * 4, 4096) + 14336;
-        const bool big = (160 * 1024) / ldsPerWg < 3;
+        // Occupancy is set by LDS (M32 stream + start bitmap + tables per workgroup), handed out in 1,280-byte steps, and the kernel
+        // gains from every wave a CU can hold (tools/occupancy_sweep.sh).  Two builds of the same source: 256 threads (two Huffman
+        // cursors per thread in lockstep, the leaner one per wave) and 512 threads (one cursor per thread, 64 VGPRs, up to four
+        // workgroups = all 32 wave slots of a CU).  The 512-thread build is the faster one where it holds at least 1.5 times the waves:
+        // measured 120x150 (16 against 32 waves) 1.37 -> 1.19 ms per 12,960 tiles, 100x120 1.59 -> 1.36, 200x200 (8 / 16) 3.92 -> 2.89;
+        // 70x100 (24 / 32) 1.62 against 1.81 and 32x32 2.63 against 3.45: the 256-thread build stays.
+        auto wgsPerCu = [](size_t lds, size_t cap) {
+            const size_t step = 1280, n = (160 * 1024) / ((lds + step - 1) / step * step);
+            return n < cap ? n : cap;
+        };
+        const size_t waves256 = 4 * wgsPerCu(gf_huffman_decode_lds_per_wg(a), 8), waves512 = 8 * wgsPerCu(gf_huffman_decode_lds_per_wg_t512(a), 4);
+        bool big = 2 * waves512 >= 3 * waves256;
+#ifdef GF_DEC_LDS_PAD_ENV
+        if (const char *e = getenv("GF_DEC_FORCE_T512")) big = atoi(e) != 0;   // experiment builds only (tools/occupancy_sweep.sh)
+#endif
         if (big) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
         else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     }

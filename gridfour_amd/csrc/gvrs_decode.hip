@@ -58,9 +58,16 @@ constexpr int LUT_BITS = 10;                    // first-level window: most symb
 #define GF_DEC_MAXQ (2 * GF_DEC_THREADS)
 #endif
 constexpr int MAXQ = GF_DEC_MAXQ;                // subsequences per chain: two per thread (advanced in lockstep) or one
+// second argument of __launch_bounds__: waves per SIMD the register allocation must leave room for.  The 512-thread build is
+// held to 64 VGPRs (it needs 49): four of its workgroups fill a CU's 32 wave slots where the LDS footprint allows four
+// (tiles up to about 120x150) -- round 3: k_huffman_decode on the ETOPO1-shaped batch 1.22 -> 1.07 ms against the 256-thread
+// build at four workgroups (16 waves) per CU; tools/occupancy_sweep.sh: the 256-thread build gains 14 % from a fifth and
+// 8 % from a sixth workgroup per CU, which LDS does not allow it at this tile size.
 #ifndef GF_DEC_WGS
-#define GF_DEC_WGS (GF_DEC_THREADS == 256 ? 4 : 2)
+#define GF_DEC_WGS (GF_DEC_THREADS == 256 ? 4 : 8)
 #endif
+// the general and the analysis instantiations (several times the code, 128 VGPRs): 16 waves per CU in either build
+#define GF_DEC_WGS_GENERAL (GF_DEC_THREADS == 256 ? 4 : 4)
 constexpr int HEAD_WORDS = 88;                 // 10 header + 1 + ceil(2559/8) tree bytes = 332 -> 83 words, + slack
 constexpr int MAX_DEPTH = 63;                  // code length limit of the register tree parser
 
@@ -1408,14 +1415,40 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
                 const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
                 if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
                 if (c < nC) {
+                    // The column recurrence is one add per row; what a row costs is the latency of its LDS reads.  FIN_ROWS rows go
+                    // together: every read is issued before the first sum (a row at a time, each iteration waited for its own three
+                    // reads: 14 rows of a 2,048-value chunk were half of the chunk's time).  The ring position of a row's first
+                    // element advances by W per row (wave-uniform); a thread of column 0 reads its column-0 value in place of the
+                    // ring entry -- same array, so one read instruction serves both kinds of lane.
+                    constexpr uint32_t FIN_ROWS = 4;
                     uint32_t cp = u == 0 ? colPrev0 : colPrev1;
-                    for (uint32_t row = rowsDone; row < rowsNew; row++) {
-                        const uint32_t r = row + 1u, tS = row * W;
-                        uint32_t v;
-                        if (c == 0u) v = rowA[r];
-                        else v = cp + rowB[r] + ring[ringIdx(tS + c - 1u)] - ring[ringIdx(tS + RING - 1u)];
-                        cp = v;
-                        o[(size_t)r * nC + c] = v;
+                    uint32_t base = ringIdx(rowsDone * W);                 // ring position of the row's first element
+                    uint32_t *op = o + (size_t)(rowsDone + 1u) * nC + c;
+                    for (uint32_t row = rowsDone; row < rowsNew; row += FIN_ROWS) {
+                        uint32_t a[FIN_ROWS], k[FIN_ROWS];
+                        uint32_t b = base;
+#pragma unroll
+                        for (uint32_t j = 0; j < FIN_ROWS; j++) {
+                            const uint32_t r = min(row + j, rowsNew - 1u) + 1u;          // rows beyond the last: read it again
+                            if (j > 0u && row + j < rowsNew) {
+                                b += W;
+                                b = b >= RING ? b - RING : b;
+                            }
+                            uint32_t e = b + c - 1u;
+                            e = e >= RING ? e - RING : e;
+                            a[j] = scr[c == 0u ? RING + r : e];                          // rowA[r] for column 0
+                            k[j] = rowB[r] - ring[b ? b - 1u : RING - 1u];               // column-0 residual - F before the row
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < FIN_ROWS; j++) {
+                            if (row + j < rowsNew) {
+                                cp = c == 0u ? a[j] : cp + k[j] + a[j];
+                                op[(size_t)j * nC] = cp;
+                            }
+                        }
+                        op += (size_t)FIN_ROWS * nC;
+                        base = b + W;
+                        base = base >= RING ? base - RING : base;
                     }
                     if (u == 0) colPrev0 = cp;
                     else colPrev1 = cp;
@@ -1641,7 +1674,7 @@ constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel lea
 enum { DEC_GENERAL = 0, DEC_ANALYZE = 1, DEC_FAST = 2 };
 
 template <int MODE>
-__global__ __launch_bounds__(DEC_THREADS, GF_DEC_WGS) void k_huffman_decode(GfDecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GENERAL) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
@@ -2204,7 +2237,13 @@ static size_t decodeDynLds(uint32_t ldsM32Bytes, uint32_t ldsTextBytes)
 {
     // the bitmap + rank area doubles as the second-level lookup table (L2_ENTRIES uint16) during phase 1
     const size_t bm = 2 * ((size_t)(ldsM32Bytes >> 5) + 2) * 4;
-    return (size_t)ldsM32Bytes + (bm > 2 * L2_ENTRIES ? bm : 2 * L2_ENTRIES) + ldsTextBytes;
+    size_t pad = 0;
+#ifdef GF_DEC_LDS_PAD_ENV
+    // experiment builds only (python -m gridfour_amd.build --variant NAME -DGF_DEC_LDS_PAD_ENV): unused dynamic LDS that takes
+    // workgroups off a CU -- the occupancy sensitivity of the kernel on one tile shape (tools/occupancy_sweep.sh)
+    if (const char *e = getenv("GF_DEC_LDS_PAD")) pad = (size_t)atol(e);
+#endif
+    return (size_t)ldsM32Bytes + (bm > 2 * L2_ENTRIES ? bm : 2 * L2_ENTRIES) + ldsTextBytes + pad;
 }
 
 #ifndef GF_DEC_VARIANT
@@ -2225,6 +2264,16 @@ unsigned gf_huffman_decode_grid(size_t nTiles)
 }
 
 #endif
+
+// LDS bytes of one workgroup of this build for the launch a describes (static + dynamic): decodeBatchDev weighs the two builds
+#ifdef GF_DEC_VARIANT
+size_t gf_huffman_decode_lds_per_wg_t512(const GfDecodeArgs &a)
+#else
+size_t gf_huffman_decode_lds_per_wg(const GfDecodeArgs &a)
+#endif
+{
+    return sizeof(DecShared) + decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
+}
 
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid)
 {
