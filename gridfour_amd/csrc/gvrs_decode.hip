@@ -468,6 +468,8 @@ __device__ int32_t huffman_to_m32(DecShared &S, HuffCursorT<TextPtr> cur, uint32
 struct FastHuff {
     const DecShared *S;
     const uint16_t *lut2;
+    const unsigned long long *leafCodeG;           // the leaves' path bits in the tile's tree record (global memory): the LDS copy
+                                                   // is given up after build_lut -- the count table of pass 1 lies over it
     uint32_t l2bits, nSub;
 };
 
@@ -487,7 +489,7 @@ __device__ __forceinline__ uint32_t fh_resolve(const FastHuff &H, uint32_t e, ui
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t cl = H.S->leafLen[i];
             const uint64_t mask = cl >= 64 ? ~0ull : ((1ull << cl) - 1ull);
-            if (cl > LUT_BITS && (t & mask) == H.S->leafCode[i]) {
+            if (cl > LUT_BITS && (t & mask) == H.leafCodeG[i]) {
                 e16 = (cl << 8) | H.S->leafSym[i];
                 break;
             }
@@ -497,31 +499,33 @@ __device__ __forceinline__ uint32_t fh_resolve(const FastHuff &H, uint32_t e, ui
     return lut_single(e16 & 0xffu, e16 >> 8);
 }
 
-struct LCur {                                      // pass 1: text in LDS
-    uint32_t pos, sh, wi, w0, w1, w2, wn;
-};
-__device__ __forceinline__ void lcur_seek(LCur &c, const uint32_t *txt, uint32_t sh0, uint32_t p)
+// Pass 1 only needs to know WHERE codes start and HOW MANY there are, not which symbols they are: its table gives, for the ten
+// text bits at a code start, the bits and the number of ALL the codes that lie completely inside them (bits 0-3 / 4-7: up to
+// ten one-bit codes) next to the length of the first one (bits 8-13); bit 15: the first code is longer than the window.  On
+// terrain data a step consumes about eight bits whatever the code lengths are (the two-symbol table of pass 2 gives two
+// codes at most: three bits per step where the residuals are small).  256 x 8 bytes: the table lies over DecShared::leafCode.
+constexpr uint32_t CNT_LONG = 0x8000u;
+__device__ __forceinline__ void build_count_table(DecShared &S, uint16_t *cnt16)
 {
-    const uint32_t a = p + sh0;
-    c.pos = p;
-    c.wi = a >> 5;
-    c.sh = a & 31u;
-    c.w0 = txt[c.wi];
-    c.w1 = txt[c.wi + 1];
-    c.w2 = txt[c.wi + 2];
-    c.wn = txt[c.wi + 3];
-}
-__device__ __forceinline__ void lcur_advance(LCur &c, const uint32_t *txt, uint32_t len)      // len <= 32
-{
-    c.pos += len;
-    const uint32_t sh = c.sh + len;
-    const bool ge = sh >= 32u;
-    c.w0 = ge ? c.w1 : c.w0;
-    c.w1 = ge ? c.w2 : c.w1;
-    c.w2 = ge ? c.wn : c.w2;
-    c.wi += ge ? 1u : 0u;
-    c.sh = sh & 31u;
-    c.wn = txt[c.wi + 3];
+    for (uint32_t x = threadIdx.x; x < (1u << LUT_BITS); x += DEC_THREADS) {
+        const uint32_t e = S.lut[x];
+        uint32_t v = CNT_LONG;
+        if (!(e & 0x80000000u)) {
+            const uint32_t l1 = (e >> 16) & 63u;
+            uint32_t pos = l1, ns = 1u;
+            for (;;) {
+                // the bits behind the codes found so far, zero-extended: an entry whose code fits the bits that are left was
+                // decided by those bits alone (prefix code)
+                const uint32_t e2 = S.lut[x >> pos];
+                const uint32_t l = (e2 >> 16) & 63u;
+                if ((e2 & 0x80000000u) || pos + l > (uint32_t)LUT_BITS) break;
+                pos += l;
+                ns++;
+            }
+            v = (l1 << 8) | (ns << 4) | pos;
+        }
+        cnt16[x] = (uint16_t)v;
+    }
 }
 
 constexpr uint32_t FAST_TEXT_PAD = 8;              // zero words behind the LDS copy of the text
@@ -533,9 +537,16 @@ constexpr int NCUR = MAXQ / DEC_THREADS;           // cursors per thread: subseq
 // step), yet a round costs every wave that owns one of them a full pass.  So from round 2 on the subsequences to redo are
 // listed and dealt out to the lanes of as few waves as possible (wave 0 takes the first 64 * NCUR of them); the other
 // waves go straight to the barrier.  Rounds repeat until no start moves.
+//
+// A step (round 3): the cursor is ONE register, the bit address of the next code inside the LDS copy of the text.  The two text
+// words at it are read afresh (one ds_read2_b32), the window formed by v_alignbit, the count table answers with all the codes
+// inside the window.  Codes are taken one at a time only within ten bits of a border (the warm-up's end, the subsequence's
+// end: the first code at or behind a border belongs to the other side) and where the first code is longer than the window.
+// With 32 waves on a CU the two dependent LDS round trips per step are covered by the other waves; what the kernel is short of
+// is issue slots (PMC, profiles/r03_*: VALU 60 %, scalar unit 70 % busy), and the step is 28 instructions instead of 42.
 template <int OWNER>
-__device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint32_t *txt, uint32_t sh0, uint32_t start, uint32_t end,
-                               uint32_t unit, uint32_t Q, uint32_t warm, uint32_t *dbg)
+__device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *cnt16, const uint32_t *txt, uint32_t sh0, uint32_t start,
+                               uint32_t end, uint32_t unit, uint32_t Q, uint32_t warm, uint32_t *dbg)
 {
     const uint32_t tid = threadIdx.x;
     uint16_t *list = reinterpret_cast<uint16_t *>(S.qdirty);      // subsequences to redo (the flags themselves are not used here)
@@ -549,68 +560,85 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint32_t *t
     // one round: cursor i of this thread decodes subsequence qv[i] (>= Q: none)
     auto runRound = [&](const bool first, const uint32_t (&qv)[NCUR]) {
         bool d[NCUR];
-        uint32_t b[NCUR], lim[NCUR], sPos[NCUR], cnt[NCUR];
-        LCur c[NCUR];
+        uint32_t bA[NCUR], limA[NCUR], a[NCUR], sPos[NCUR], cnt[NCUR];       // positions as bit addresses in txt (+ sh0)
 #pragma unroll
         for (int i = 0; i < NCUR; i++) {
             const uint32_t q = qv[i];
             d[i] = q < Q;
-            b[i] = start + q * unit;                                            // boundary
-            lim[i] = min(end, b[i] + unit);
+            const uint32_t b = d[i] ? start + q * unit : end;                   // boundary
+            bA[i] = b + sh0;
+            limA[i] = min(end, b + unit) + sh0;
             // first round: from a warm-up stretch in front of the boundary (the first position reached at or beyond the
             // boundary is the start); later rounds: from the predecessor's end
             uint32_t p;
-            if (first) p = (q > 0 && b[i] - start >= warm) ? b[i] - warm : (q > 0 ? start : b[i]);
+            if (first) p = (q > 0 && b - start >= warm) ? b - warm : (q > 0 ? start : b);
             else p = d[i] ? S.qe[q - 1u] : end;                                 // listed subsequences have q > 0
-            lcur_seek(c[i], txt, sh0, d[i] ? p : end);
-            sPos[i] = p;
+            a[i] = (d[i] ? p : end) + sh0;
             cnt[i] = 0;
         }
-        for (;;) {
-            bool r[NCUR], any = false;
+        // one step of every cursor towards its border: the codes of the window, or ONE code within ten bits of the border and
+        // where the first code is longer than the window.  The loops are wave-uniform (no exec-mask bookkeeping: a cursor that
+        // has arrived adds zero), and the warm-up is a loop of its own: it counts nothing and has no second border to watch.
+        auto step = [&](const uint32_t (&border)[NCUR], auto counting) {
+            uint32_t x[NCUR], e[NCUR], l1[NCUR], anyLong = 0;
 #pragma unroll
             for (int i = 0; i < NCUR; i++) {
-                r[i] = d[i] && c[i].pos < lim[i];
-                any = any || r[i];
-            }
-            if (!any) break;
-            uint32_t x[NCUR], e[NCUR], anyLong = 0;
-#pragma unroll
-            for (int i = 0; i < NCUR; i++) {
-                x[i] = __builtin_amdgcn_alignbit(c[i].w1, c[i].w0, c[i].sh);
-                e[i] = S.lut[x[i] & ((1u << LUT_BITS) - 1u)];
+                const uint32_t wi = a[i] >> 5;
+                x[i] = __builtin_amdgcn_alignbit(txt[wi + 1u], txt[wi], a[i]);  // the shift takes the low five bits of a
+                e[i] = cnt16[x[i] & ((1u << LUT_BITS) - 1u)];
                 anyLong |= e[i];
             }
-            if (anyLong & 0x80000000u) {
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) l1[i] = (e[i] >> 8) & 63u;
+            if (__any((anyLong & CNT_LONG) != 0u)) {
 #pragma unroll
                 for (int i = 0; i < NCUR; i++)
-                    if (e[i] & 0x80000000u) e[i] = fh_resolve(H, e[i], x[i], c[i].w0, c[i].w1, c[i].w2, c[i].sh);
+                    if (e[i] & CNT_LONG) {
+                        const uint32_t wi = a[i] >> 5;
+                        const uint32_t e32 = fh_resolve(H, S.lut[x[i] & ((1u << LUT_BITS) - 1u)], x[i], txt[wi], txt[wi + 1u], txt[wi + 2u],
+                                                        a[i] & 31u);
+                        l1[i] = (e32 >> 16) & 63u;
+                    }
             }
 #pragma unroll
             for (int i = 0; i < NCUR; i++) {
-                const bool m = c[i].pos >= b[i];                                // past the warm-up
-                const uint32_t cl = m ? lim[i] : b[i];                          // a pair must not straddle these
-                const uint32_t a1 = (e[i] >> 16) & 63u, t2 = e[i] >> 22;
-                const bool two = t2 != a1 && c[i].pos + a1 < cl;
-                cnt[i] += (r[i] && m) ? (two ? 2u : 1u) : 0u;
-                lcur_advance(c[i], txt, r[i] ? (two ? t2 : a1) : 0u);
-                sPos[i] = (!m && c[i].pos >= b[i]) ? c[i].pos : sPos[i];
+                const bool live = a[i] < border[i];
+                const bool single = (e[i] & CNT_LONG) || a[i] + (uint32_t)LUT_BITS > border[i];
+                if constexpr (decltype(counting)::value) cnt[i] += live ? (single ? 1u : ((e[i] >> 4) & 15u)) : 0u;
+                a[i] += live ? (single ? l1[i] : (e[i] & 15u)) : 0u;
             }
-        }
+        };
+        auto anyBefore = [&](const uint32_t (&border)[NCUR]) {
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) any = any || a[i] < border[i];
+            return __any(any) != 0;
+        };
+        while (anyBefore(bA)) step(bA, std::false_type{});
+#pragma unroll
+        for (int i = 0; i < NCUR; i++) sPos[i] = a[i] - sh0;                    // the first code at or beyond the boundary
+        while (anyBefore(limA)) step(limA, std::true_type{});
 #pragma unroll
         for (int i = 0; i < NCUR; i++)
-            if (d[i]) { S.qs[qv[i]] = sPos[i]; S.qe[qv[i]] = c[i].pos; S.qn[qv[i]] = cnt[i]; }
+            if (d[i]) { S.qs[qv[i]] = sPos[i]; S.qe[qv[i]] = a[i] - sh0; S.qn[qv[i]] = cnt[i]; }
     };
+#ifdef GF_DIAG
+    const uint32_t tBegin = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     {
         uint32_t qv[NCUR];
 #pragma unroll
         for (int i = 0; i < NCUR; i++) qv[i] = tid + i * DEC_THREADS;
         runRound(true, qv);
     }
+#ifdef GF_DIAG
+    if (dbg && tid == 0) dbg[1] = (uint32_t)__builtin_amdgcn_s_memtime() - tBegin;      // round 1, wave 0
+#endif
     for (uint32_t round = 1;; round++) {
         __syncthreads();                                                        // the round's starts and ends are in place
 #ifdef GF_DIAG
         rounds++;
+        if (dbg && tid == 0 && round == 1) dbg[3] = (uint32_t)__builtin_amdgcn_s_memtime() - tBegin;   // ... all waves
 #endif
         if (tid == 0) S.nRedo[(round + 1u) & 1u] = 0;                           // the next round's counter (last read before this barrier)
 #pragma unroll
@@ -650,7 +678,7 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint32_t *t
     }
     if (tid == 0) S.chainTotal = tot;
 #ifdef GF_DIAG
-    if (dbg && tid == 0) dbg[0] = rounds;
+    if (dbg && tid == 0) { dbg[0] = rounds; dbg[4] = (uint32_t)__builtin_amdgcn_s_memtime() - tBegin; }   // the whole pass
 #endif
     __syncthreads();
 }
@@ -701,8 +729,9 @@ constexpr uint32_t RCUR_BUDGET = 256u - 31u - 96u;
 
 template <int OWNER>
 __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict__ base32, uint32_t nW, uint32_t sh0,
-                                       uint32_t *txt, uint32_t pkWords, const uint16_t *lut2, uint32_t textStart, uint32_t endBit,
-                                       uint32_t nM32, uint8_t *m32, uint32_t *dbg, const uint32_t warmBits)
+                                       uint32_t *txt, uint32_t pkWords, const uint16_t *lut2, const unsigned long long *leafCodeG,
+                                       uint32_t textStart, uint32_t endBit, uint32_t nM32, uint8_t *m32, uint32_t *dbg,
+                                       const uint32_t warmBits)
 {
     const uint32_t tid = threadIdx.x;
     int32_t status = GF_K_OK;
@@ -713,8 +742,13 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
     FastHuff H;
     H.S = &S;
     H.lut2 = lut2;
+    H.leafCodeG = leafCodeG;
     H.l2bits = S.l2bits;
     H.nSub = S.nSub;
+    // the count table of pass 1, over the leaves' path bits (build_lut, which read them, ended with a barrier)
+    uint16_t *cnt16 = reinterpret_cast<uint16_t *>(S.leafCode);
+    static_assert(sizeof(S.leafCode) >= (sizeof(uint16_t) << LUT_BITS), "count table does not fit over leafCode");
+    build_count_table(S, cnt16);
     // the packing into LDS (txt = the M32 buffer, not yet in use), zero words behind it
 #ifdef GF_DIAG
     const uint32_t tStage = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -724,7 +758,7 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
 #ifdef GF_DIAG
     if (dbg && tid == 0) dbg[2] = (uint32_t)__builtin_amdgcn_s_memtime() - tStage;
 #endif
-    fast_sync_pass<OWNER>(S, H, txt, sh0, textStart, endBit, unit, Q, warmBits, dbg);
+    fast_sync_pass<OWNER>(S, H, cnt16, txt, sh0, textStart, endBit, unit, Q, warmBits, dbg);
 #ifdef GF_DIAG
     if (dbg && tid == 0) dbg[-7] = (uint32_t)__builtin_amdgcn_s_memtime();      // stamp 4
 #else
@@ -1038,59 +1072,81 @@ __device__ __forceinline__ void m32_mark_starts(DecShared &S, M32Ptr m32, uint32
     cur.base = 0;
     cur.d0 = cur.d1 = cur.d2 = 0;
     const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
-    const uint32_t nDw = (nM32 + 3u) >> 2;
-    // bitmap of the bytes that start a value
-    for (uint32_t w = tid; w < bmWords; w += DEC_THREADS) bm[w] = 0;
     if (tid == 0) { S.chainEnd = 0; S.dense = 0; }
     __syncthreads();
-    // Local resolution, one dword of the stream per thread and step: a byte is certainly a value
-    // start when none of the five bytes before it can be an introducer (0x7f / 0x81) -- no value
-    // is longer than 6 bytes.  Where introducer candidates are near, walk the few values from
-    // the nearest certain start ("anchor").  No chain, no rounds; only a stream that is dense in
-    // multi-byte values (no anchor within 11 bytes) falls back to the chain resolution.
+    // Local resolution, 32 bytes of the stream (one bitmap word) per thread, by bit operations on masks -- no walk over the bytes.
+    // I: bytes that may be an introducer (0x7f / 0x81), H: bytes with the continuation bit.  A true introducer at p makes p+1 a
+    // payload byte, and p+2 .. p+5 as long as the bytes before them carry the continuation bit (CodecM32.java:327-356: at most
+    // five payload bytes): cover(T) below, a handful of shifts for all 64 positions of the window at once.  Which candidates
+    // are true introducers depends on the starts (T = S & I) and the starts on them (S = ~cover(T)): iterate from "every
+    // candidate is one" -- the iterates close in on the solution from both sides and settle from the left, one nested
+    // candidate at least per turn; on terrain data candidates stand alone and the second turn confirms the first.  The window
+    // is the thread's word and the word before it, entered at an anchor: a byte with no candidate among the five before it is
+    // certainly a start (no value is longer than six bytes).  No anchor in the 27 bytes before the word, or no fixed point
+    // after eight turns (a stream dense in multi-byte values): the chain resolution below.
+    // (Round 2 walked the values from an anchor per DWORD, a divergent loop over a byte cursor that some lane of every wave was in:
+    // with the value decode below about half of the kernel's instructions.)
     {
-        // 0x80 in every byte that may be an introducer (false positives are harmless)
+        // 0x80 in every byte that may be an introducer
         auto cand = [](uint32_t x) -> uint32_t {
             const uint32_t p = x ^ 0x7F7F7F7Fu, q = x ^ 0x81818181u;
             return (((p - 0x01010101u) & ~p) | ((q - 0x01010101u) & ~q)) & 0x80808080u;
         };
-        auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits
-            return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
+        auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits (the partial products do not collide)
+            return (((f >> 7) * 0x00204081u) >> 21) & 0xfu;
         };
-        for (uint32_t dw = tid; dw < nDw; dw += DEC_THREADS) {
-            const uint32_t i0 = dw << 2;
-            uint32_t d0 = m32w[dw];
-            if (i0 + 4 > nM32) d0 &= (1u << ((nM32 - i0) * 8u)) - 1u;
-            const uint32_t dm1 = dw >= 1 ? m32w[dw - 1] : 0u, dm2 = dw >= 2 ? m32w[dw - 2] : 0u;
-            const uint32_t c0 = cand(d0), cm1 = cand(dm1), cm2 = cand(dm2);
-            const uint32_t validNib = i0 + 4 <= nM32 ? 0xFu : ((1u << (nM32 - i0)) - 1u);
-            uint32_t nib;
-            if (!((cm1 | (cm2 & 0x80000000u)) | c0)) {
-                nib = validNib;                         // four single-byte values
-            } else {
-                const uint32_t dm3 = dw >= 3 ? m32w[dw - 3] : 0u, dm4 = dw >= 4 ? m32w[dw - 4] : 0u;
-                // candidate bit b <-> byte i0 - 16 + b
-                const uint32_t C = nib4(cand(dm4)) | (nib4(cand(dm3)) << 4) | (nib4(cm2) << 8) | (nib4(cm1) << 12) |
-                                   (nib4(c0) << 16);
-                const uint32_t U = C | (C << 1) | (C << 2) | (C << 3) | (C << 4);   // bit m: a candidate in bytes m-4..m
-                // position index j (byte i0-16+j) is a certain start iff U bit j-1 is clear; want the largest j <= 16
-                const uint32_t safe = ~U & 0xFFF0u;                                  // j-1 in 4..15
-                nib = 0;
-                if (!safe) {
-                    S.dense = 1;
-                } else {
-                    const uint32_t j = 32u - (uint32_t)__builtin_clz(safe);          // (j-1)+1
-                    const uint32_t anchor = i0 + j >= 16u ? i0 + j - 16u : 0u;
-                    M32Cursor c = cur;
-                    c.seek(anchor);
-                    const uint32_t stop = min(i0 + 4u, nM32);
-                    while (c.pos < stop) {
-                        if (c.pos >= i0) nib |= 1u << (c.pos - i0);
-                        c.next();
+        const uint32_t turns = (bmWords + DEC_THREADS - 1u) / DEC_THREADS;
+        for (uint32_t turn = 0; turn < turns; turn++) {
+            const uint32_t w = turn * DEC_THREADS + tid;
+            if (w < bmWords) {
+                uint32_t I = 0, H = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t d = m32w[8u * w + j];
+                    I |= nib4(cand(d)) << (4u * j);
+                    H |= nib4(d & 0x80808080u) << (4u * j);
+                }
+                const uint32_t left = nM32 - 32u * w, valid = left >= 32u ? 0xFFFFFFFFu : (1u << left) - 1u;   // stale bytes beyond nM32
+                bm[w] = I & valid;
+                wb[w] = H & valid;
+            }
+        }
+        __syncthreads();
+        // the masks give way to the starts word by word; a word needs its left neighbour's masks: last turn first
+        for (uint32_t turn = turns; turn-- > 0u;) {
+            const uint32_t w = turn * DEC_THREADS + tid;
+            uint32_t starts = 0;
+            if (w < bmWords) {
+                unsigned long long I64 = ((unsigned long long)bm[w] << 32) | (w ? bm[w - 1u] : 0u);
+                const unsigned long long H64 = ((unsigned long long)wb[w] << 32) | (w ? wb[w - 1u] : 0u);
+                const unsigned long long U = I64 | (I64 << 1) | (I64 << 2) | (I64 << 3) | (I64 << 4);   // bit m: a candidate in m-4..m
+                // bit j: no candidate in j-5..j-1; positions 0..4 of the window do not see all of their five (the word before the
+                // first one is empty: byte 0 of the stream is an anchor)
+                const unsigned long long anchors = ~(U << 1) & ~0x1Full & 0x1FFFFFFFFull;               // up to my first byte (bit 32)
+                bool settled = false;
+                unsigned long long Sx = 0;
+                if (anchors) {
+                    I64 &= ~0ull << (63u - (uint32_t)__builtin_clzll(anchors));
+                    unsigned long long T = I64;
+                    for (int it = 0; it < 8 && !settled; it++) {
+                        unsigned long long c = T << 1, cover = c;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            c = (c & H64) << 1;
+                            cover |= c;
+                        }
+                        Sx = ~cover;
+                        const unsigned long long Tn = Sx & I64;
+                        settled = Tn == T;
+                        T = Tn;
                     }
                 }
+                if (!settled) S.dense = 1;
+                const uint32_t left = nM32 - 32u * w, valid = left >= 32u ? 0xFFFFFFFFu : (1u << left) - 1u;
+                starts = (uint32_t)(Sx >> 32) & valid;
             }
-            if (nib) atomicOr(&bm[i0 >> 5], nib << (i0 & 31u));
+            __syncthreads();                            // every mask of this turn has been read
+            if (w < bmWords) bm[w] = starts;
         }
     }
     __syncthreads();
@@ -1307,6 +1363,9 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     const uint32_t nValues = S.carry;
     if (nValues < nStream) return GF_K_ERR_BOUNDS;               // predictor reads past codeM32s
     GF_TSTAMP(6);
+#ifdef GF_DIAG
+    if ((diagFlags & 0xffu) == 4u) return GF_K_OK;               // diagnostic: instruction counts of the parts (tools/pmc_phases_dec.sh)
+#endif
 
     uint32_t *scr = reinterpret_cast<uint32_t *>(&S);
     const uint32_t RING = plan.ring;
@@ -1374,6 +1433,12 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     // (the scan barrier of the first chunk orders these stores before the first reads)
 
     GF_TSTAMP(7);
+#ifdef GF_DIAG
+    if ((diagFlags & 0xffu) == 5u) return GF_K_OK;
+    const bool skipRows = (diagFlags & 0x40000u) != 0u;          // ... the chunk loop without the rows finished from the ring
+#else
+    constexpr bool skipRows = false;
+#endif
     uint32_t carry1 = 0, carry2 = 0, rowsDone = 0;
     const uint32_t nIter = (nDw + DEC_THREADS - 1u) / DEC_THREADS;
     // Stage 2 of chunk i runs AFTER the scan barrier of chunk i + 1: that barrier also publishes chunk i's ring entries, so a
@@ -1410,97 +1475,109 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
                 o[cell] = v;
             }
         } else {
+            // Triangle: v(r,c) = v(r-1,c) + K(r) + F(r,c), K(r) = column-0 residual of the row - F before its first interior element.
+            // Column 0 needs no case of its own: its ring entry "c - 1" is the F before the row, so the same sum gives
+            // v(r-1,0) + residual (wrap-around sums are associative).  The column recurrence is one add per row; what a row costs
+            // is its bookkeeping, so that is pared down to a running ring position per lane (add, wrap), one LDS read, one
+            // v_readlane for K -- the K of up to 64 rows are computed side by side in the lanes first -- one three-operand add
+            // and the store.  FIN_ROWS rows go together with every LDS read issued before the first sum.
+            // (Round 2 finished a row per iteration and waited for its three reads each time; two of them were the wave-uniform
+            // row constants, fetched by every lane, behind a dozen scalar instructions of ring arithmetic per row.)
+            constexpr uint32_t FIN_ROWS = 4;
+            const uint32_t waveCol0 = tid & ~63u;
+            for (uint32_t rb = rowsDone; rb < rowsNew; rb += 64u) {
+                const uint32_t nb = min(64u, rowsNew - rb);
+                uint32_t Kl = 0;
+                if (waveCol0 < nC || (nC > (uint32_t)DEC_THREADS && waveCol0 + DEC_THREADS < nC)) {      // the wave holds a column
+                    const uint32_t j = min(lane, nb - 1u), bj = ringIdx((rb + j) * W);
+                    Kl = rowB[rb + j + 1u] - ring[bj ? bj - 1u : RING - 1u];
+                }
+                const uint32_t b0 = ringIdx(rb * W), bm1 = b0 ? b0 - 1u : RING - 1u;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
-                if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
-                if (c < nC) {
-                    // The column recurrence is one add per row; what a row costs is the latency of its LDS reads.  FIN_ROWS rows go
-                    // together: every read is issued before the first sum (a row at a time, each iteration waited for its own three
-                    // reads: 14 rows of a 2,048-value chunk were half of the chunk's time).  The ring position of a row's first
-                    // element advances by W per row (wave-uniform); a thread of column 0 reads its column-0 value in place of the
-                    // ring entry -- same array, so one read instruction serves both kinds of lane.
-                    constexpr uint32_t FIN_ROWS = 4;
-                    uint32_t cp = u == 0 ? colPrev0 : colPrev1;
-                    uint32_t base = ringIdx(rowsDone * W);                 // ring position of the row's first element
-                    uint32_t *op = o + (size_t)(rowsDone + 1u) * nC + c;
-                    for (uint32_t row = rowsDone; row < rowsNew; row += FIN_ROWS) {
-                        uint32_t a[FIN_ROWS], k[FIN_ROWS];
-                        uint32_t b = base;
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
+                    if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
+                    if (c < nC) {
+                        uint32_t cp = u == 0 ? colPrev0 : colPrev1;
+                        uint32_t e = bm1 + c;                                   // ring position of the row's entry c - 1
+                        e = min(e, e - RING);
+                        uint32_t cell = (rb + 1u) * nC + c;
+                        for (uint32_t j0 = 0; j0 < nb; j0 += FIN_ROWS) {
+                            uint32_t a[FIN_ROWS];
 #pragma unroll
-                        for (uint32_t j = 0; j < FIN_ROWS; j++) {
-                            const uint32_t r = min(row + j, rowsNew - 1u) + 1u;          // rows beyond the last: read it again
-                            if (j > 0u && row + j < rowsNew) {
-                                b += W;
-                                b = b >= RING ? b - RING : b;
+                            for (uint32_t j = 0; j < FIN_ROWS; j++) {
+                                a[j] = ring[e];
+                                if (j0 + j + 1u < nb) {                          // (rows beyond the last: the last one again)
+                                    e += W;
+                                    e = min(e, e - RING);
+                                }
                             }
-                            uint32_t e = b + c - 1u;
-                            e = e >= RING ? e - RING : e;
-                            a[j] = scr[c == 0u ? RING + r : e];                          // rowA[r] for column 0
-                            k[j] = rowB[r] - ring[b ? b - 1u : RING - 1u];               // column-0 residual - F before the row
-                        }
 #pragma unroll
-                        for (uint32_t j = 0; j < FIN_ROWS; j++) {
-                            if (row + j < rowsNew) {
-                                cp = c == 0u ? a[j] : cp + k[j] + a[j];
-                                op[(size_t)j * nC] = cp;
+                            for (uint32_t j = 0; j < FIN_ROWS; j++) {
+                                if (j0 + j < nb) {
+                                    cp += (uint32_t)__builtin_amdgcn_readlane((int)Kl, (int)(j0 + j)) + a[j];
+                                    o[cell] = cp;
+                                    cell += nC;
+                                }
                             }
                         }
-                        op += (size_t)FIN_ROWS * nC;
-                        base = b + W;
-                        base = base >= RING ? base - RING : base;
+                        if (u == 0) colPrev0 = cp;
+                        else colPrev1 = cp;
                     }
-                    if (u == 0) colPrev0 = cp;
-                    else colPrev1 = cp;
                 }
             }
         }
         rowsDone = rowsNew;
     };
+#ifdef GF_DIAG
+    // wave 0's cycles in the parts of the chunk loop, summed over the chunks (diagFlags bit 17; they go where the stamps of the
+    // synchronisation pass are otherwise)
+    uint32_t tcA = 0, tcB = 0, tcC = 0, tcD = 0, tcLast = (uint32_t)__builtin_amdgcn_s_memtime();
+#define GF_CSTAMP(acc) do { const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); acc += n_ - tcLast; tcLast = n_; } while (0)
+#else
+#define GF_CSTAMP(acc) do { } while (0)
+#endif
     for (uint32_t it = 0; it < nIter; it++) {
         const uint32_t dw = it * DEC_THREADS + tid;
         // ---- decode: up to four values, slot j = the value that starts at byte j of the thread's dword ----
+        // Every byte is taken as a one-byte value first (a slot that starts no value is masked out below); the slots whose byte is
+        // an introducer or the null code -- a few per cent on terrain data, but some lane of every wave has one -- are then
+        // redone one at a time: the loop runs as often as the wave's worst dword has such bytes, once as a rule.
         uint32_t bits = 0, k = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0;
         if (dw < nDw) {
             const uint32_t i0 = dw << 2;
             const uint32_t word = bm[i0 >> 5];
             bits = (word >> (i0 & 31u)) & 0xfu;
-            if (bits) {
-                k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
-                uint32_t d0 = m32w[dw];
-                const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
-                const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) &
-                                         0x80808080u;
-                if (bits == 0xfu && !special) {
-                    v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu);
-                    v1 = (uint32_t)((int32_t)(d0 << 16) >> 24);
-                    v2 = (uint32_t)((int32_t)(d0 << 8) >> 24);
-                    v3 = (uint32_t)((int32_t)d0 >> 24);
-                } else {
-                    uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
-                    if (i0 + 12 > nM32) {
-                        const uint32_t valid = nM32 - i0;        // 1..11 bytes
-                        if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
-                        if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
-                        d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
-                    }
-                    uint32_t kk = k;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        if ((bits >> j) & 1u) {
-                            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
-                            const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
-                            uint32_t vlen;
-                            const uint32_t val = m32_value(lo, hi, &vlen);
-                            if (j == 0) v0 = val;
-                            else if (j == 1) v1 = val;
-                            else if (j == 2) v2 = val;
-                            else v3 = val;
-                            if (kk == nStream - 1u) S.chainEnd = i0 + j + vlen;
-                            kk++;
-                        }
-                    }
+            k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
+            uint32_t d0 = m32w[dw];
+            v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu);
+            v1 = (uint32_t)((int32_t)(d0 << 16) >> 24);
+            v2 = (uint32_t)((int32_t)(d0 << 8) >> 24);
+            v3 = (uint32_t)((int32_t)d0 >> 24);
+            const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
+            const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) & 0x80808080u;
+            uint32_t redo = bits & ((((special >> 7) * 0x00204081u) >> 21) & 0xfu);
+            if (redo) {
+                uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
+                if (i0 + 12 > nM32) {
+                    const uint32_t valid = nM32 - i0;        // 1..11 bytes
+                    if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
+                    if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
+                    d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
                 }
+                do {
+                    const uint32_t j = (uint32_t)__builtin_ctz(redo);
+                    redo &= redo - 1u;
+                    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
+                    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
+                    uint32_t vlen;
+                    const uint32_t val = m32_value(lo, hi, &vlen);
+                    v0 = j == 0u ? val : v0;
+                    v1 = j == 1u ? val : v1;
+                    v2 = j == 2u ? val : v2;
+                    v3 = j == 3u ? val : v3;
+                    if (k + (uint32_t)__popc(bits & ((1u << j) - 1u)) == nStream - 1u) S.chainEnd = i0 + j + vlen;
+                } while (redo);
             }
         }
         // stream index of every slot; a slot counts if it holds an interior element of the stream
@@ -1522,7 +1599,9 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
             if (lane == 63u) { wt[DEC_WAVES + wave] = inclN; wt[2 * DEC_WAVES + wave] = inclQ; }
         }
         if (lane == 63u) wt[wave] = incl1;
+        GF_CSTAMP(tcA);
         __syncthreads();
+        GF_CSTAMP(tcB);
         uint32_t base1 = carry1, base2 = carry2;                 // F1 / F2 before this wave's first element
         {
             uint32_t c1 = carry1, c2 = carry2;
@@ -1560,16 +1639,22 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
             if (ok3) ring[ringIdx(t3)] = F3;
         }
         if (!plan.endBarrier) {
-            if (it > 0u) finishRows(it - 1u);
+            GF_CSTAMP(tcC);
+            if (it > 0u && !skipRows) finishRows(it - 1u);
         } else {
             __syncthreads();
-            finishRows(it);
+            GF_CSTAMP(tcC);
+            if (!skipRows) finishRows(it);
             __syncthreads();
         }
+        GF_CSTAMP(tcD);
     }
+#ifdef GF_DIAG
+    if (stamps && tid == 0 && (diagFlags & 0x20000u)) { stamps[12] = tcA; stamps[13] = tcB; stamps[14] = tcC; stamps[15] = tcD; }
+#endif
     if (!plan.endBarrier) {
         __syncthreads();
-        finishRows(nIter - 1u);
+        if (!skipRows) finishRows(nIter - 1u);
     }
     __syncthreads();
     return S.chainEnd > nM32 ? GF_K_ERR_BOUNDS : GF_K_OK;       // last value truncated
@@ -1863,8 +1948,9 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 const uint32_t pkWords = (sh0 + endBit + 31u) >> 5;          // words that hold the packing
                 if constexpr (FAST) {
                     tileStatus = huffman_to_m32_fast<MODE>(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
-                                                           sh0, reinterpret_cast<uint32_t *>(ldsDyn), pkWords, lut2, textStart,
-                                                           endBit, nM32, m32, dbg, warmBits);
+                                                           sh0, reinterpret_cast<uint32_t *>(ldsDyn), pkWords, lut2,
+                                                           reinterpret_cast<const unsigned long long *>(a.trees + t * GF_TREE_REC_WORDS + 8),
+                                                           textStart, endBit, nM32, m32, dbg, warmBits);
                 } else if (pkWords * 4u <= a.ldsTextBytes) {
                     // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
                     uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + bmArea);
@@ -2131,12 +2217,30 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     const uint8_t *__restrict__ pk = blob + off;
     // the walk sees what parse_tree_wave sees: the packing's bytes, zero beyond its end and beyond the staged head
     const uint32_t visible = min(len, (uint32_t)(HEAD_WORDS * 4));
-    auto ld32 = [&](uint32_t i) -> uint32_t {                // bytes i .. i+3 of the packing, little-endian
+    auto ldGlobal = [&](uint32_t i) -> uint32_t {            // bytes i .. i+3 of the packing, little-endian
         if (i + 4u <= visible) return reinterpret_cast<const PackedWord *>(pk + i)->v;
         uint32_t w = 0;
         for (uint32_t k = 0; k < 4; k++)
             if (i + k < visible) w |= (uint32_t)pk[i + k] << (8u * k);
         return w;
+    };
+    // A lane per tile reads its tree a dword at a time as the walk consumes it: 80-odd DEPENDENT global loads per tile, a
+    // microsecond each -- the whole 0.07 ms of the kernel on the bench batch.  So every lane first brings its serialised tree
+    // (bytes 10 .. 351 of the packing at most) into a stretch of LDS of its own with all loads in flight together (odd
+    // stride: the lanes' words fall into different banks), and the walk reads from there.
+    constexpr uint32_t TREE_WORDS = (HEAD_WORDS * 4 - 10 + 3) / 4, TREE_STRIDE = TREE_WORDS | 1u;
+    __shared__ uint32_t stage[perWave == 1 ? 1 : 64 * TREE_STRIDE];
+    if constexpr (perWave != 1) {
+        uint32_t *mine = stage + threadIdx.x * TREE_STRIDE;
+#pragma unroll 8
+        for (uint32_t j = 0; j < TREE_WORDS; j++) mine[j] = 10u + 4u * j < visible ? ldGlobal(10u + 4u * j) : 0u;
+    }
+    auto ld32 = [&](uint32_t i) -> uint32_t {                // i = 10 + 4 j
+        if constexpr (perWave == 1) return ldGlobal(i);
+        else {
+            const uint32_t j = (i - 10u) >> 2;
+            return j < TREE_WORDS ? stage[threadIdx.x * TREE_STRIDE + j] : 0u;
+        }
     };
     uint64_t buf = ((uint64_t)ld32(14) << 32) | ld32(10);    // packing bit 80 = byte 10
     uint32_t have = 64, next = 18, bp = 80;

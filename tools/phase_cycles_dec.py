@@ -40,12 +40,14 @@ def main():
              "8 values (+ inverse when fused)", "9 -", "10 end"]
     for i in (1, 2, 3, 4, 5, 6, 7, 8, 10):
         print("  after %-34s median %9d  p90 %9d" % (names[i], np.median(rel[:, i]), np.percentile(rel[:, i], 90)))
-    for i, nme in ((12, "chunk loop: decode + wave scans"), (13, "chunk loop: barrier"), (14, "chunk loop: bases + ring writes"),
-                   (15, "chunk loop: rows finished from the ring")):
-        print("  %-40s median %9d  p90 %9d   (wave 0, summed over the chunks)" % (nme, np.median(st[:, i]), np.percentile(st[:, i], 90)))
-    print("  huffman sync: rounds median %d p90 %d max %d; first round cycles median %d; text staging cycles median %d; steps of wave 0 in round 1 median %d p90 %d" % (
-        np.median(st[:, 11]), np.percentile(st[:, 11], 90), st[:, 11].max(), np.median(st[:, 12]), np.median(st[:, 13]),
-        np.median(st[:, 14]), np.percentile(st[:, 14], 90)))
+    print("  huffman sync pass: rounds median %d p90 %d max %d" % (np.median(st[:, 11]), np.percentile(st[:, 11], 90), st[:, 11].max()))
+    for i, nme in ((13, "text staged in LDS (+ count table)"), (12, "round 1, wave 0"), (14, "round 1, all waves (first barrier)"),
+                   (15, "whole pass (rounds + prefix sums)")):
+        print("    %-40s median %9d  p90 %9d" % (nme, np.median(st[:, i]), np.percentile(st[:, i], 90)))
+    if warm & 0x20000:
+        print("  chunk loop, wave 0, summed over the chunks (instead of the sync stamps above):")
+        for i, nme in ((12, "decode + wave scans"), (13, "scan barrier"), (14, "bases + ring writes (+ barrier)"), (15, "rows finished (+ barrier)")):
+            print("    %-40s median %9d  p90 %9d" % (nme, np.median(st[:, i]), np.percentile(st[:, i], 90)))
     pred = b.get_predictors()
     if True:
         print("  predictors chosen:", {int(k): int(v) for k, v in zip(*np.unique(pred, return_counts=True))})
