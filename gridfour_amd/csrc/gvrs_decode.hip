@@ -1381,9 +1381,80 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     const uint32_t magicW = (uint32_t)(((1ull << 32) + W - 1u) / W);
     const uint32_t magicC = (uint32_t)(((1ull << 32) + nC - 1u) / nC);
 
+    // Up to four values of one dword of the stream: slot j = the value that starts at byte j (bits: the dword's start flags, k: rank
+    // of its first start).  Every byte is taken as a one-byte value first (a slot that starts no value is masked out by its
+    // flag); the slots whose byte is an introducer or the null code -- a few per cent on terrain data, but some lane of every
+    // wave has one -- are then redone one at a time: the loop runs as often as the wave's worst dword has such bytes, once as a rule.
+    auto decodeDword = [&](const uint32_t dw, uint32_t &bits, uint32_t &k, uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3) {
+        const uint32_t i0 = dw << 2;
+        const uint32_t word = bm[i0 >> 5];
+        bits = (word >> (i0 & 31u)) & 0xfu;
+        k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
+        uint32_t d0 = m32w[dw];
+        v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu);
+        v1 = (uint32_t)((int32_t)(d0 << 16) >> 24);
+        v2 = (uint32_t)((int32_t)(d0 << 8) >> 24);
+        v3 = (uint32_t)((int32_t)d0 >> 24);
+        const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
+        const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) & 0x80808080u;
+        uint32_t redo = bits & ((((special >> 7) * 0x00204081u) >> 21) & 0xfu);
+        if (redo) {
+            uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
+            if (i0 + 12 > nM32) {
+                const uint32_t valid = nM32 - i0;        // 1..11 bytes
+                if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
+                if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
+                d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
+            }
+            do {
+                const uint32_t j = (uint32_t)__builtin_ctz(redo);
+                redo &= redo - 1u;
+                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
+                const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
+                uint32_t vlen;
+                const uint32_t val = m32_value(lo, hi, &vlen);
+                v0 = j == 0u ? val : v0;
+                v1 = j == 1u ? val : v1;
+                v2 = j == 2u ? val : v2;
+                v3 = j == 3u ? val : v3;
+                if (k + (uint32_t)__popc(bits & ((1u << j) - 1u)) == nStream - 1u) S.chainEnd = i0 + j + vlen;
+            } while (redo);
+        }
+    };
+
     // ---- borders: per-row constants (and row 0 of Triangle) ----
+    // Linear and Triangle emit their border residuals FIRST (2 nR - 1, nC + nR - 2 elements): the head of the stream is decoded a
+    // dword per thread like any chunk, and every border value goes to its place in LDS by its rank -- row 0 of Triangle into the
+    // (still unused) ring, the column-0 / column-1 residuals into the row arrays.  (Round 2 fetched each of them through
+    // m32_select, a gallop and a bisection per value: 5 K of the kernel's 90 K instructions per tile.)  Differencing has its
+    // column 0 spread over the stream and keeps the selects.
     uint32_t colPrev0 = 0, colPrev1 = 0;
     {
+        if (model != 1) {
+            for (uint32_t base = 0; base < nDw; base += DEC_THREADS) {
+                // values before this turn's first byte (wave-uniform); the turns end where the border does
+                const uint32_t kBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb[base >> 3]);
+                if (kBase >= nB) break;
+                const uint32_t dw = base + tid;
+                if (dw < nDw) {
+                    uint32_t bits, k, v[4];
+                    decodeDword(dw, bits, k, v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if (((bits >> j) & 1u) && k < nB) {
+                            if (model == 3) {
+                                if (k < nC - 1u) ring[k + 1u] = v[j];              // cell (0, k + 1)
+                                else rowB[k - (nC - 2u)] = v[j];                   // cell (r, 0), r = k - (nC - 2)
+                            } else if (k == 0u) rowB[0] = v[j];                    // Linear: cell (0, 1)
+                            else if ((k - 1u) & 1u) rowB[1u + ((k - 1u) >> 1)] = v[j];   // cell (r, 1)
+                            else rowA[1u + ((k - 1u) >> 1)] = v[j];                // cell (r, 0)
+                        }
+                        k += (bits >> j) & 1u;
+                    }
+                }
+            }
+            __syncthreads();
+        }
         uint32_t vlen;
         if (model == 3) {
             // row 0: stream elements 0 .. nC-2 are cells (0,1) .. (0,nC-1), each relative to its left neighbour
@@ -1392,7 +1463,7 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
             for (int u = 0; u < 2; u++) {
                 const uint32_t c = tid + (uint32_t)u * DEC_THREADS;
                 if (u == 1 && nC <= (uint32_t)DEC_THREADS) break;
-                const uint32_t x = (c >= 1u && c < nC) ? m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, c - 1u), &vlen) : 0u;
+                const uint32_t x = (c >= 1u && c < nC) ? ring[c] : 0u;
                 uint32_t tot;
                 const uint32_t v = carry + block_excl_scan(x, S.waveSum, &tot) + x;
                 if (c < nC) o[c] = v;
@@ -1404,28 +1475,14 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
         uint32_t carry = seed;
         for (uint32_t rb = 0; rb < nR; rb += DEC_THREADS) {
             const uint32_t r = rb + tid;
-            uint32_t x0 = 0, x1 = 0;
-            if (r < nR) {
-                if (model == 1) {
-                    if (r >= 1u) x0 = m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, r * nC - 1u), &vlen);
-                } else if (model == 3) {
-                    if (r >= 1u) x0 = m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, nC - 2u + r), &vlen);
-                } else {
-                    // Linear: element 0 is cell (0,1); elements 2r-1, 2r are cells (r,0), (r,1)
-                    uint32_t p = m32_select(bm, wb, bmWords, r >= 1u ? 2u * r - 1u : 0u);
-                    if (r >= 1u) {
-                        x0 = m32_value_at(m32, nM32, p, &vlen);
-                        p += vlen;
-                    }
-                    x1 = m32_value_at(m32, nM32, p, &vlen);
-                }
+            uint32_t x0 = 0;
+            if (r >= 1u && r < nR) {
+                if (model == 1) x0 = m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, r * nC - 1u), &vlen);
+                else x0 = model == 3 ? rowB[r] : rowA[r];
             }
             uint32_t tot;
             const uint32_t cv = carry + block_excl_scan(x0, S.waveSum, &tot) + x0;
-            if (r < nR) {
-                rowA[r] = cv;                                    // column 0
-                rowB[r] = model == 3 ? x0 : x1;                  // Triangle: column-0 residual; Linear: v(r,1) - v(r,0)
-            }
+            if (r < nR) rowA[r] = cv;                            // column 0 (rowB: Triangle column-0 residual, Linear v(r,1) - v(r,0))
             carry += tot;
         }
         if (tid == 0) ring[model == 1 ? 0u : RING - 1u] = 0u;     // F before the first interior element
@@ -1540,46 +1597,8 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     for (uint32_t it = 0; it < nIter; it++) {
         const uint32_t dw = it * DEC_THREADS + tid;
         // ---- decode: up to four values, slot j = the value that starts at byte j of the thread's dword ----
-        // Every byte is taken as a one-byte value first (a slot that starts no value is masked out below); the slots whose byte is
-        // an introducer or the null code -- a few per cent on terrain data, but some lane of every wave has one -- are then
-        // redone one at a time: the loop runs as often as the wave's worst dword has such bytes, once as a rule.
         uint32_t bits = 0, k = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-        if (dw < nDw) {
-            const uint32_t i0 = dw << 2;
-            const uint32_t word = bm[i0 >> 5];
-            bits = (word >> (i0 & 31u)) & 0xfu;
-            k = wb[i0 >> 5] + (uint32_t)__popc(word & ((1u << (i0 & 31u)) - 1u));
-            uint32_t d0 = m32w[dw];
-            v0 = (uint32_t)(int32_t)(int8_t)(d0 & 0xffu);
-            v1 = (uint32_t)((int32_t)(d0 << 16) >> 24);
-            v2 = (uint32_t)((int32_t)(d0 << 8) >> 24);
-            v3 = (uint32_t)((int32_t)d0 >> 24);
-            const uint32_t p7 = d0 ^ 0x7F7F7F7Fu, p1 = d0 ^ 0x81818181u, p0 = d0 ^ 0x80808080u;
-            const uint32_t special = (((p7 - 0x01010101u) & ~p7) | ((p1 - 0x01010101u) & ~p1) | ((p0 - 0x01010101u) & ~p0)) & 0x80808080u;
-            uint32_t redo = bits & ((((special >> 7) * 0x00204081u) >> 21) & 0xfu);
-            if (redo) {
-                uint32_t d1 = dw + 1 < nDw ? m32w[dw + 1] : 0u, d2 = dw + 2 < nDw ? m32w[dw + 2] : 0u;
-                if (i0 + 12 > nM32) {
-                    const uint32_t valid = nM32 - i0;        // 1..11 bytes
-                    if (valid < 4) d0 &= (1u << (valid * 8u)) - 1u;
-                    if (valid < 8) d1 &= valid > 4 ? (1u << ((valid - 4u) * 8u)) - 1u : 0u;
-                    d2 &= valid > 8 ? (1u << ((valid - 8u) * 8u)) - 1u : 0u;
-                }
-                do {
-                    const uint32_t j = (uint32_t)__builtin_ctz(redo);
-                    redo &= redo - 1u;
-                    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 8u * j);
-                    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 8u * j);
-                    uint32_t vlen;
-                    const uint32_t val = m32_value(lo, hi, &vlen);
-                    v0 = j == 0u ? val : v0;
-                    v1 = j == 1u ? val : v1;
-                    v2 = j == 2u ? val : v2;
-                    v3 = j == 3u ? val : v3;
-                    if (k + (uint32_t)__popc(bits & ((1u << j) - 1u)) == nStream - 1u) S.chainEnd = i0 + j + vlen;
-                } while (redo);
-            }
-        }
+        if (dw < nDw) decodeDword(dw, bits, k, v0, v1, v2, v3);
         // stream index of every slot; a slot counts if it holds an interior element of the stream
         const uint32_t b0 = bits & 1u, b1 = (bits >> 1) & 1u, b2 = (bits >> 2) & 1u, b3 = (bits >> 3) & 1u;
         const uint32_t t0 = k + tOff, t1 = t0 + b0, t2 = t1 + b1, t3 = t2 + b2;
@@ -1603,16 +1622,27 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
         __syncthreads();
         GF_CSTAMP(tcB);
         uint32_t base1 = carry1, base2 = carry2;                 // F1 / F2 before this wave's first element
-        {
+        if (model == 2) {
             uint32_t c1 = carry1, c2 = carry2;
 #pragma unroll
             for (uint32_t w = 0; w < (uint32_t)DEC_WAVES; w++) {
                 if (w == wave) { base1 = c1; base2 = c2; }
-                if (model == 2) c2 += wt[DEC_WAVES + w] * c1 + wt[2 * DEC_WAVES + w];
+                c2 += wt[DEC_WAVES + w] * c1 + wt[2 * DEC_WAVES + w];
                 c1 += wt[w];
             }
             carry1 = c1;
             carry2 = c2;
+        } else {
+            // the waves' totals side by side in the first lanes of every wave, summed up by three DPP steps, picked by v_readlane
+            // (one LDS read instead of a read and an add per wave)
+            static_assert(DEC_WAVES <= 8, "three row_shr steps cover eight totals");
+            int x = (int)wt[lane & (uint32_t)(DEC_WAVES - 1)];
+            x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+            x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+            x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+            const uint32_t waveU = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+            base1 = carry1 + (waveU ? (uint32_t)__builtin_amdgcn_readlane(x, (int)waveU - 1) : 0u);
+            carry1 += (uint32_t)__builtin_amdgcn_readlane(x, DEC_WAVES - 1);
         }
         {
             const uint32_t e1 = base1 + (incl1 - f3);            // F1 before this thread's first slot
