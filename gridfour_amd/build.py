@@ -65,9 +65,10 @@ def _compile_all(lib, extra, verbose):
             jobs.append(([hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", obj], obj))
         # the legacy decoder once more with 512-thread workgroups, one Huffman cursor per thread (tiles whose LDS footprint
         # leaves room for at most two 256-thread workgroups per CU, see gvrs_decode.hip / decodeBatchDev)
-        obj = os.path.join(tmp, "gvrs_decode_t512.o")
-        jobs.append(([hipcc] + FLAGS + extra + ["-DGF_DEC_THREADS=512", "-DGF_DEC_VARIANT", "-DGF_DEC_MAXQ=512", "-c",
-                                                 os.path.join(CSRC, "gvrs_decode.hip"), "-o", obj], obj))
+        for threads in (512, 1024):
+            obj = os.path.join(tmp, "gvrs_decode_t%d.o" % threads)
+            jobs.append(([hipcc] + FLAGS + extra + ["-DGF_DEC_THREADS=%d" % threads, "-DGF_DEC_VARIANT", "-DGF_DEC_MAXQ=%d" % threads, "-c",
+                                                     os.path.join(CSRC, "gvrs_decode.hip"), "-o", obj], obj))
         # a few compiles at a time: the translation units are independent
         width = max(1, min(4, (os.cpu_count() or 2) // 2))
         running = []

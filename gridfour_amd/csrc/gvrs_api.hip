@@ -418,12 +418,16 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
             const size_t step = 1280, n = (160 * 1024) / ((lds + step - 1) / step * step);
             return n < cap ? n : cap;
         };
-        const size_t waves256 = 4 * wgsPerCu(gf_huffman_decode_lds_per_wg(a), 8), waves512 = 8 * wgsPerCu(gf_huffman_decode_lds_per_wg_t512(a), 4);
-        bool big = 2 * waves512 >= 3 * waves256;
+        const size_t waves256 = 4 * wgsPerCu(gf_huffman_decode_lds_per_wg(a), 8), waves512 = 8 * wgsPerCu(gf_huffman_decode_lds_per_wg_t512(a), 4),
+                     waves1024 = 16 * wgsPerCu(gf_huffman_decode_lds_per_wg_t1024(a), 2);
+        int threads = 2 * waves512 >= 3 * waves256 ? 512 : 256;
+        // 1024 threads where that doubles the waves again (tiles of 160x160 and more: two workgroups of 512 at most on a CU)
+        if (threads == 512 && waves1024 >= 2 * waves512) threads = 1024;
 #ifdef GF_DEC_LDS_PAD_ENV
-        if (const char *e = getenv("GF_DEC_FORCE_T512")) big = atoi(e) != 0;   // experiment builds only (tools/occupancy_sweep.sh)
+        if (const char *e = getenv("GF_DEC_FORCE_THREADS")) threads = atoi(e);   // experiment builds only (tools/occupancy_sweep.sh)
 #endif
-        if (big) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
+        if (threads == 1024) GF_HIP(gf_launch_huffman_decode_t1024(a, stream ? (hipStream_t)stream : c->stream, grid));
+        else if (threads == 512) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
         else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     }
     return GF_OK;

@@ -42,14 +42,18 @@
 namespace {
 
 constexpr int GF_K_SKIP = 0x7fff0001;           // internal: a diagnostic phase limit ended the tile early
-// The file is compiled twice: as is (256 threads per workgroup), and with -DGF_DEC_THREADS=512 -DGF_DEC_VARIANT for tiles
-// whose M32 stream leaves room for only one 256-thread workgroup per CU (>= ~57 K cells, e.g. 256x256): twice the waves
-// per tile there.  The variant object exports gf_launch_huffman_decode_t512 only.
+// The file is compiled three times: as is (256 threads per workgroup, two Huffman cursors per thread), and with
+// -DGF_DEC_THREADS=512 / 1024 -DGF_DEC_VARIANT -DGF_DEC_MAXQ=512 / 1024 (one cursor per thread) for the tile sizes whose LDS
+// footprint lets those builds put more waves on a CU (decodeBatchDev weighs them).  A variant object exports
+// gf_launch_huffman_decode_t<threads> and gf_huffman_decode_lds_per_wg_t<threads> only.
 #ifndef GF_DEC_THREADS
 #define GF_DEC_THREADS 256
 #endif
 #ifdef GF_DEC_VARIANT
-#define gf_launch_huffman_decode gf_launch_huffman_decode_t512
+#define GF_DEC_CAT2(a, b) a##b
+#define GF_DEC_CAT(a, b) GF_DEC_CAT2(a, b)
+#define gf_launch_huffman_decode GF_DEC_CAT(gf_launch_huffman_decode_t, GF_DEC_THREADS)
+#define gf_huffman_decode_lds_per_wg GF_DEC_CAT(gf_huffman_decode_lds_per_wg_t, GF_DEC_THREADS)
 #endif
 constexpr int DEC_THREADS = GF_DEC_THREADS;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
@@ -1282,22 +1286,23 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
 // in LDS (the decode tables of phase 1 are dead by now: the ring and three per-row arrays alias them); the rows a chunk
 // completes are then finished from the ring -- lane = consecutive cells of a row, so every store instruction writes
 // whole contiguous lines -- and for Triangle the column recurrence is carried in a register per column.
-constexpr uint32_t SCR_WORDS = offsetof(DecShared, qdirty) / 4;   // lut .. qn: free after phase 1
+constexpr uint32_t SCR_WORDS = offsetof(DecShared, waveSum) / 4;  // lut .. head: free after phase 1 (the header fields are in registers)
 constexpr uint32_t FUSED_CHUNK = 4u * DEC_THREADS;                // values a chunk can hold at most
 
 struct FusedPlan {
     uint32_t ring;          // ring entries (0 = tile shape not eligible)
     bool endBarrier;        // the ring is too short to overlap the next chunk's writes with this chunk's reads
 };
-__device__ __forceinline__ FusedPlan fused_plan(uint32_t nR, uint32_t nC)
+__device__ __forceinline__ FusedPlan fused_plan(uint32_t nR, uint32_t nC, int model)
 {
     FusedPlan p;
     p.ring = 0;
     p.endBarrier = false;
     // nC <= 2 * DEC_THREADS: two column registers per thread (Triangle); the products behind the reciprocal divisions stay
-    // below 2^32 by a wide margin at these sizes
-    if (nR < 2u || nC < 4u || nC > 2u * DEC_THREADS || nR > 4096u || 3u * nR + nC + FUSED_CHUNK + 1u > SCR_WORDS) return p;
-    const uint32_t avail = SCR_WORDS - 3u * nR;
+    // below 2^32 by a wide margin at these sizes.  Row arrays behind the ring: two, a third one for Linear
+    const uint32_t rowWords = (model == 2 ? 3u : 2u) * nR;
+    if (nR < 2u || nC < 4u || nC > 2u * DEC_THREADS || nR > 4096u || rowWords + nC + FUSED_CHUNK + 1u > SCR_WORDS) return p;
+    const uint32_t avail = SCR_WORDS - rowWords;
     p.ring = avail;
     p.endBarrier = avail < 2u * FUSED_CHUNK + nC;
     return p;
@@ -1635,11 +1640,12 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
         } else {
             // the waves' totals side by side in the first lanes of every wave, summed up by three DPP steps, picked by v_readlane
             // (one LDS read instead of a read and an add per wave)
-            static_assert(DEC_WAVES <= 8, "three row_shr steps cover eight totals");
+            static_assert(DEC_WAVES <= 16, "row_shr steps stay inside a row of sixteen lanes");
             int x = (int)wt[lane & (uint32_t)(DEC_WAVES - 1)];
             x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
             x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
             x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+            if (DEC_WAVES > 8) x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
             const uint32_t waveU = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
             base1 = carry1 + (waveU ? (uint32_t)__builtin_amdgcn_readlane(x, (int)waveU - 1) : 0u);
             carry1 += (uint32_t)__builtin_amdgcn_readlane(x, DEC_WAVES - 1);
@@ -1840,7 +1846,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         else if ((uint64_t)nM32 > 6ull * nCells) early = GF_K_ERR_FORMAT; // no encoder emits this
         else if ((model == 2 && nC < 2)) early = GF_K_ERR_BOUNDS;       // PredictorModelLinear.java:80 output[1]
         else if (nM32 < nStream) early = GF_K_ERR_BOUNDS;               // M32 reads run off codeM32s
-        const FusedPlan plan = fused_plan(nR, nC);
+        const FusedPlan plan = fused_plan(nR, nC, model);
         if constexpr (FAST) {
             if (early == GF_K_OK && (nM32 > a.ldsM32Bytes || model > 3 || !plan.ring)) {
                 early = GF_K_RETRY;
@@ -2360,7 +2366,8 @@ uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols)
     size_t cells = (size_t)nRows * (size_t)nCols;
     size_t want = cells + cells / 8 + 512;
     if (want < 8192) want = 8192;
-    if (want > 65536) want = 65536;             // with bitmap, rank bases, text and the static part: < 160 KB
+    if (want > 98304) want = 98304;             // with bitmap, rank bases and the static part of the 1024-thread build: 144 KB of the
+                                                // CU's 160 (256x256 tiles: 74 KB of stream, one workgroup of 16 waves per CU)
     return (uint32_t)((want + 31) & ~(size_t)31);
 }
 
@@ -2400,11 +2407,7 @@ unsigned gf_huffman_decode_grid(size_t nTiles)
 #endif
 
 // LDS bytes of one workgroup of this build for the launch a describes (static + dynamic): decodeBatchDev weighs the two builds
-#ifdef GF_DEC_VARIANT
-size_t gf_huffman_decode_lds_per_wg_t512(const GfDecodeArgs &a)
-#else
 size_t gf_huffman_decode_lds_per_wg(const GfDecodeArgs &a)
-#endif
 {
     return sizeof(DecShared) + decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
 }

@@ -155,8 +155,10 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 hipError_t gf_launch_huffman_decode_t512(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);   // 512-thread workgroups
+hipError_t gf_launch_huffman_decode_t1024(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);  // 1024-thread workgroups
 size_t gf_huffman_decode_lds_per_wg(const GfDecodeArgs &a);           // LDS bytes per workgroup, 256-thread build
 size_t gf_huffman_decode_lds_per_wg_t512(const GfDecodeArgs &a);      // ... 512-thread build
+size_t gf_huffman_decode_lds_per_wg_t1024(const GfDecodeArgs &a);     // ... 1024-thread build
 unsigned gf_huffman_decode_grid(size_t nTiles);
 uint32_t gf_huffman_decode_lds_m32(int nRows, int nCols);
 uint32_t gf_huffman_decode_lds_text(int nRows, int nCols);
