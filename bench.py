@@ -41,10 +41,17 @@ WORKLOADS = {
     "etopo1": (120, 150, 12960, 144, "ETOPO1-shaped 10800x21600 int32 grid, 120x150 tiles, full encode+decode roundtrip"),
     "dem1024": (200, 200, 1024, 32, "1024-tile batch, 200x200 int32 synthetic DEM, all 3 predictors + Huffman"),
     "gebco_shard": (200, 200, 11664, 432, "1/8 shard of the GEBCO_2023-shaped 43200x86400 int32 grid, 200x200 tiles"),
+    # strong scaling: the WHOLE GEBCO-shaped grid (93,312 tiles, 14.9 GB of cells) cut into --gpus contiguous shares
+    "gebco_full": (200, 200, 93312, 432, "GEBCO_2023-shaped 43200x86400 int32 grid, 200x200 tiles, all 93,312 tiles divided over the GPUs"),
+    # "a variant with 5 % INT4_NULL_CODE ocean-mask blocks to exercise a6" (PredictorModelDifferencingWithNulls)
+    "etopo1_nulls": (120, 150, 12960, 144, "ETOPO1-shaped grid as etopo1 with an ocean mask: 5 % of its 16x16 blocks are null "
+                                           "(nearly every tile takes PredictorModelDifferencingWithNulls)"),
     "float256": (256, 256, 4096, 64, "4096 tiles of 256x256 float32 (DEM x 0.1f), CodecFloat byte-plane stage"),
     "float256_lsop": (256, 256, 4096, 64, "4096 tiles of 256x256 float32 (DEM x 0.1f) stored as int-coded floats "
                                           "(scale 10, GvrsElementSpecificationIntCodedFloat), LSOP12"),
 }
+MASK_PER_MILLE = {"etopo1_nulls": 50}
+STRONG = {"gebco_full"}       # workloads whose tile count is the whole job's (divided over the GPUs); the others are per GPU
 FP64_PEAK_TFLOPS = 78.6       # MI355X vector FP64 (the roof k_lsop_predict's normal equations are priced against)
 
 
@@ -275,6 +282,22 @@ def _verify_shard(args, batch, n_rows, n_cols, n_tiles, with_oracle):
     return ok, int(lengths.astype(np.int64).sum()), vals
 
 
+def _entropy(vals, n_rows, n_cols):
+    """"report the generated data's zero-order entropy and c".  Zero-order (memoryless) entropy of the row
+    differences of a sample of the generated tiles, in bits per cell, next to the share of null cells: what an ideal
+    order-0 coder of Differencing residuals would need, to hold against compressed_bytes_per_cell * 8."""
+    t = np.asarray(vals).reshape(-1, n_rows, n_cols)
+    t = t[:: max(1, len(t) // 64)][:64].astype(np.int64)
+    null = t == -2 ** 31
+    d = (t[:, :, 1:] - t[:, :, :-1])[~(null[:, :, 1:] | null[:, :, :-1])]
+    if d.size == 0:
+        return None
+    _, counts = np.unique(d, return_counts=True)
+    p = counts / counts.sum()
+    return {"bits_per_cell": round(float(-(p * np.log2(p)).sum()), 4), "of": "row differences of 64 sampled tiles (null cells left out)",
+            "null_cell_share": round(float(null.mean()), 4)}
+
+
 def _lsop_fp64_roofline(ctx, batch, n_rows, n_cols, n_tiles, reps):
     """k_lsop_predict against the FP64 roof: the normal equations of LsOptimalPredictor12.computeCoefficients
     (:335-342) are 91 multiply-adds + 13 adds = 195 FP64 flop per interior cell.  The kernel is launched on its own
@@ -437,6 +460,8 @@ def main():
     from gridfour_amd._lib import check
 
     n_rows, n_cols, n_tiles, tiles_per_row, descr = WORKLOADS[args.workload]
+    if args.workload in STRONG:
+        n_tiles //= args.gpus                                 # strong scaling: contiguous shares of one grid
     cells = n_rows * n_cols
     if (args.codec == "float") != (args.workload == "float256"):
         raise SystemExit("--codec float goes with --workload float256 (and only with it)")
@@ -457,12 +482,12 @@ def main():
     else:
         ctxs = [gridfour_amd.GvrsHipContext(local_rank)]
     stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
-    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "gebco_shard": 3, "float256_lsop": 5}[args.workload]
+    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "etopo1_nulls": 2, "gebco_shard": 3, "gebco_full": 3, "float256_lsop": 5}[args.workload]
     batches = []
     for g, ctx in enumerate(ctxs):
         b = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
         # shard s owns the contiguous tile range starting at s * n_tiles of the global grid (weak scaling)
-        b.synth_dem(seed, tiles_per_row, tile0=(g if single_multi else rank) * n_tiles)
+        b.synth_dem(seed, tiles_per_row, tile0=(g if single_multi else rank) * n_tiles, mask_per_mille=MASK_PER_MILLE.get(args.workload, 0))
         ctx.synchronize()
         if args.workload == "float256_lsop":
             # config 5(ii): the float tiles of config 5(i) (DEM x 0.1f) as the reference stores them in an int-coded-float
@@ -567,6 +592,19 @@ def main():
         ok_all = bool(flag.item())
     bit_exact = None if args.no_verify else ok_all
     c_per_cell = packed_bytes / float(len(batches) * n_tiles * cells)
+    # which device every shard ran on (the record of an N-GPU run shows N distinct devices without RCCL introspection)
+    def dev_record(shard, index):
+        p = torch.cuda.get_device_properties(index)
+        return {"shard": shard, "device": index, "name": p.name, "uuid": str(getattr(p, "uuid", "")),
+                "gf_device_count": int(lib().gf_device_count())}
+    if single_multi:
+        devices = [dev_record(g, multi.devices[g]) for g in range(n_shards)]
+    else:
+        devices = [dev_record(rank, local_rank)]
+        if launcher:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, devices[0])
+            devices = gathered
 
     cpu_baseline, host_path = None, None
     if rank == 0 and total_shards == 1 and not args.no_verify:
@@ -602,7 +640,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.workload in STRONG else "weak",
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
@@ -615,6 +653,8 @@ def main():
                                 ("one process, gf_multi_*_dev over %d contexts" % total_shards if single_multi else "one")},
         "bit_exact": bit_exact,
         "compressed_bytes_per_cell": round(c_per_cell, 4),
+        "zero_order_entropy": _entropy(vals0, n_rows, n_cols) if vals0 is not None else None,
+        "devices": devices,
         "encode_ms": round(enc_avg, 4),
         "decode_ms": round(dec_avg, 4),
         "encode_MBps": round(raw_mb / (enc_avg * 1e-3), 1),

@@ -609,6 +609,16 @@ gf_status gf_synth_dem_dev(gf_context *c, void *stream, uint64_t seed, int nRows
     return GF_OK;
 }
 
+gf_status gf_synth_dem_masked_dev(gf_context *c, void *stream, uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                                  int64_t tile0, size_t nTiles, int maskPerMille, int32_t *dValues)
+{
+    if (!c || nRows < 1 || nCols < 1 || tilesPerRow < 1 || !dValues || maskPerMille < 0 || maskPerMille > 1000) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    GF_HIP(gf_launch_synth_dem(seed, nRows, nCols, tilesPerRow, tile0, nTiles, dValues,
+                               stream ? (hipStream_t)stream : c->stream, maskPerMille));
+    return GF_OK;
+}
+
 
 // ------------------------------------------------------------------ CodecFloat
 

@@ -110,8 +110,16 @@ __device__ int32_t dem_value(uint64_t seed, int64_t gx, int64_t gy)
     return (int32_t)sum;
 }
 
+// ocean mask of the nulls workload: 16 x 16 blocks of the grid, maskPerMille / 1000 of them null
+__device__ __forceinline__ bool dem_masked(uint64_t seed, int64_t gx, int64_t gy, int maskPerMille)
+{
+    const uint64_t h = splitmix64(seed ^ 0x3300000000000000ULL ^ ((((uint64_t)gy >> 4) & 0xFFFFFFFULL) << 28) ^
+                                  (((uint64_t)gx >> 4) & 0xFFFFFFFULL));
+    return (int)((h >> 33) % 1000u) < maskPerMille;
+}
+
 __global__ __launch_bounds__(256) void k_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
-                                                   int64_t tile0, size_t nTiles, int32_t *__restrict__ values)
+                                                   int64_t tile0, size_t nTiles, int maskPerMille, int32_t *__restrict__ values)
 {
     const size_t nCells = (size_t)nRows * (size_t)nCols;
     const size_t total = nTiles * nCells;
@@ -121,7 +129,8 @@ __global__ __launch_bounds__(256) void k_synth_dem(uint64_t seed, int nRows, int
         const int r = (int)(k / (uint32_t)nCols), c = (int)(k - (uint32_t)r * (uint32_t)nCols);
         const int64_t tile = tile0 + (int64_t)t;
         const int64_t tr = tile / tilesPerRow, tc = tile % tilesPerRow;
-        values[g] = dem_value(seed, tc * nCols + c, tr * nRows + r);
+        const int64_t gx = tc * nCols + c, gy = tr * nRows + r;
+        values[g] = maskPerMille > 0 && dem_masked(seed, gx, gy, maskPerMille) ? (int32_t)0x80000000u : dem_value(seed, gx, gy);
     }
 }
 
@@ -140,10 +149,10 @@ hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStr
 }
 
 hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow, int64_t tile0,
-                               size_t nTiles, int32_t *values, hipStream_t stream)
+                               size_t nTiles, int32_t *values, hipStream_t stream, int maskPerMille)
 {
     if (nTiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_synth_dem, dim3(4096), dim3(256), 0, stream, seed, nRows, nCols, tilesPerRow, tile0, nTiles,
-                       values);
+                       maskPerMille, values);
     return hipGetLastError();
 }

@@ -1289,6 +1289,40 @@ __device__ __forceinline__ int32_t m32_to_values(DecShared &S, M32Ptr m32, uint3
 constexpr uint32_t SCR_WORDS = offsetof(DecShared, waveSum) / 4;  // lut .. head: free after phase 1 (the header fields are in registers)
 constexpr uint32_t FUSED_CHUNK = 4u * DEC_THREADS;                // values a chunk can hold at most
 
+// Segmented inclusive scan over the wave (DPP): s = sum of the lane's segment up to the lane, f != 0 = a segment head lies at or
+// before the lane inside the scanned range (its value is the head's: heads hand their mark down their segment).  A lane that
+// has a head of its own takes nothing from the left.
+__device__ __forceinline__ void gf_wave_seg_incl_scan(uint32_t &s, uint32_t &f)
+{
+#define GF_SEG_STEP(ctrl, rowmask, bc)                                                          \
+    {                                                                                           \
+        const uint32_t ps = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, ctrl, rowmask, 0xf, bc); \
+        const uint32_t pf = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, ctrl, rowmask, 0xf, bc); \
+        const bool open = f == 0u;                                                              \
+        s += open ? ps : 0u;                                                                    \
+        f = open ? pf : f;                                                                      \
+    }
+    GF_SEG_STEP(0x111, 0xf, true)      // row_shr:1
+    GF_SEG_STEP(0x112, 0xf, true)      // row_shr:2
+    GF_SEG_STEP(0x114, 0xf, true)      // row_shr:4
+    GF_SEG_STEP(0x118, 0xf, true)      // row_shr:8
+    GF_SEG_STEP(0x142, 0xa, false)     // row_bcast:15 -> rows 1, 3
+    GF_SEG_STEP(0x143, 0xc, false)     // row_bcast:31 -> rows 2, 3
+#undef GF_SEG_STEP
+}
+// (s, f) of the lane before (lane 0: nothing)
+__device__ __forceinline__ void gf_wave_shr1(uint32_t &s, uint32_t &f)
+{
+    s = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    f = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x138, 0xf, 0xf, false);
+}
+// a then b of one sequence
+__device__ __forceinline__ void gf_seg_combine(uint32_t as, uint32_t af, uint32_t bs, uint32_t bf, uint32_t &rs, uint32_t &rf)
+{
+    rs = bf ? bs : as + bs;
+    rf = bf ? bf : af;
+}
+
 struct FusedPlan {
     uint32_t ring;          // ring entries (0 = tile shape not eligible)
     bool endBarrier;        // the ring is too short to overlap the next chunk's writes with this chunk's reads
@@ -1301,6 +1335,11 @@ __device__ __forceinline__ FusedPlan fused_plan(uint32_t nR, uint32_t nC, int mo
     // nC <= 2 * DEC_THREADS: two column registers per thread (Triangle); the products behind the reciprocal divisions stay
     // below 2^32 by a wide margin at these sizes.  Row arrays behind the ring: two, a third one for Linear
     const uint32_t rowWords = (model == 2 ? 3u : 2u) * nR;
+    if (model == 4) {
+        // the nulls predictor keeps no ring (m32_to_tile_nulls): two row arrays and the scan's wave totals
+        if (nR >= 1u && nC >= 2u && 2u * nR + 4u * DEC_WAVES <= SCR_WORDS) p.ring = 1u;
+        return p;
+    }
     if (nR < 2u || nC < 4u || nC > 2u * DEC_THREADS || nR > 4096u || rowWords + nC + FUSED_CHUNK + 1u > SCR_WORDS) return p;
     const uint32_t avail = SCR_WORDS - rowWords;
     p.ring = avail;
@@ -1426,6 +1465,124 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
             } while (redo);
         }
     };
+
+    if (model == 4) {
+        // ---- PredictorModelDifferencingWithNulls.decode (:137-166), fused: one store per cell, no second pass over the tile ----
+        // The stream holds every cell in row-major order; a value is the sum of the residuals since the last RESTART plus what
+        // the restart starts from: behind a null residual the seed; at a row's first cell the first cell of the row before --
+        // unless that VALUE is the null code (:162-163), then the seed again (row 0: the seed).  So: a segmented scan in stream
+        // order.  Elements: null residual = head (kind 1: the seed follows), sum 0; first cell of a row = head (kind 3: the row's
+        // base follows), sum = its residual; others = no head.  Heads hand their kind down their segment, so every cell knows
+        // what its sum is to be added to; the row bases B(r) come from the column-0 chain, which is worked out first (its
+        // residuals are elements r nC of the stream: m32_select).  A sum may come out as the null code without any null residual
+        // (damaged input only); inside a row that changes nothing (the flag follows the residual there), on the column-0 chain
+        // it restarts the NEXT row from the seed: the chain is checked for it and redone the reference's way, serially, then.
+        uint32_t *x0 = scr, *rowBase = scr + nR, *wtot = scr + 2u * nR;              // column-0 residuals, B(r), wave totals of the scan
+        constexpr uint32_t K_NULL = 1u, K_ROW = 3u;
+        for (uint32_t r = tid; r < nR; r += DEC_THREADS) {
+            uint32_t vlen;
+            x0[r] = m32_value_at(m32, nM32, m32_select(bm, wb, bmWords, r * nC), &vlen);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // C(r) = value of cell (r, 0); B(r) = what row r starts from
+            uint32_t cs = 0, cf = 0;                                                  // carry: sum and kind of the running segment
+            bool odd = false;
+            for (uint32_t rb = 0; rb < nR; rb += 64u) {
+                const uint32_t r = rb + lane;
+                const uint32_t x = r < nR ? x0[r] : GF_NULL_CODE;
+                const bool isNull = x == GF_NULL_CODE;
+                uint32_t es = isNull ? 0u : x, ef = isNull ? K_NULL : 0u;
+                gf_wave_seg_incl_scan(es, ef);
+                uint32_t is, ifl;
+                gf_seg_combine(cs, cf, es, ef, is, ifl);                             // inclusive, with the rows before
+                // C(r): a segment of the chain starts from the seed (the rows before the first null included: carry kind 0)
+                const uint32_t C = isNull ? GF_NULL_CODE : seed + is;
+                odd = odd || (!isNull && C == GF_NULL_CODE && r < nR);
+                // B(r + 1) = C(r) unless that is the null code
+                if (r + 1u < nR) rowBase[r + 1u] = C == GF_NULL_CODE ? seed : C;
+                cs = (uint32_t)__builtin_amdgcn_readlane((int)is, 63);
+                cf = (uint32_t)__builtin_amdgcn_readlane((int)ifl, 63);
+            }
+            if (lane == 0) rowBase[0] = seed;
+            if (__any(odd)) {
+                // a sum hit the null code: the reference's loop over the rows, one lane
+                if (lane == 0) {
+                    uint32_t prior = seed;
+                    bool nullFlag = true;
+                    for (uint32_t r = 0; r < nR; r++) {
+                        rowBase[r] = nullFlag ? seed : prior;
+                        const uint32_t x = x0[r];
+                        prior = x == GF_NULL_CODE ? GF_NULL_CODE : rowBase[r] + x;
+                        nullFlag = prior == GF_NULL_CODE;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t carryS = 0, carryF = 0;
+        const uint32_t nIterN = (nDw + DEC_THREADS - 1u) / DEC_THREADS;
+        for (uint32_t it = 0; it < nIterN; it++) {
+            const uint32_t dw = it * DEC_THREADS + tid;
+            uint32_t bits = 0, k = 0, v[4] = {0, 0, 0, 0};
+            if (dw < nDw) decodeDword(dw, bits, k, v[0], v[1], v[2], v[3]);
+            // the thread's elements in order: position, row / column, element of the scan; local inclusive scan
+            uint32_t t[4], ls[4], lf[4];
+            bool ok[4], nul[4];
+            uint32_t kk = k, rs = 0, rf = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[j] = kk;
+                ok[j] = ((bits >> j) & 1u) && kk < nStream;
+                kk += (bits >> j) & 1u;
+                nul[j] = v[j] == GF_NULL_CODE;
+                const uint32_t r = __umulhi(t[j], magicC), c = t[j] - r * nC;
+                const uint32_t es = ok[j] && !nul[j] ? v[j] : 0u;
+                const uint32_t ef = !ok[j] ? 0u : nul[j] ? K_NULL : c == 0u ? K_ROW : 0u;
+                gf_seg_combine(rs, rf, es, ef, rs, rf);
+                ls[j] = rs;
+                lf[j] = rf;
+            }
+            uint32_t ws = rs, wf = rf;
+            gf_wave_seg_incl_scan(ws, wf);
+            uint32_t *wt = wtot + (it & 1u) * (2u * DEC_WAVES);                      // double-buffered by chunk parity
+            if (lane == 63u) { wt[wave] = ws; wt[DEC_WAVES + wave] = wf; }
+            gf_wave_shr1(ws, wf);                                                    // exclusive: what lies before the thread in its wave
+            __syncthreads();
+            uint32_t bs = carryS, bf = carryF;                                       // ... before the wave
+            {
+                uint32_t cs = carryS, cf = carryF;
+#pragma unroll
+                for (uint32_t w = 0; w < (uint32_t)DEC_WAVES; w++) {
+                    if (w == wave) { bs = cs; bf = cf; }
+                    gf_seg_combine(cs, cf, wt[w], wt[DEC_WAVES + w], cs, cf);
+                }
+                carryS = cs;
+                carryF = cf;
+            }
+            gf_seg_combine(bs, bf, ws, wf, bs, bf);                                  // before the thread
+            uint32_t out[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t fs, ff;
+                gf_seg_combine(bs, bf, ls[j], lf[j], fs, ff);
+                const uint32_t r = __umulhi(t[j], magicC);
+                const uint32_t base = ff == K_ROW ? rowBase[min(r, nR - 1u)] : seed;
+                out[j] = nul[j] ? GF_NULL_CODE : base + fs;
+            }
+            if (bits == 0xfu && t[3] < nStream) {
+                GfU4 q;
+                q.x = out[0]; q.y = out[1]; q.z = out[2]; q.w = out[3];
+                *reinterpret_cast<GfU4 *>(o + t[0]) = q;                             // four cells in a row: lanes side by side
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (ok[j]) o[t[j]] = out[j];
+            }
+        }
+        __syncthreads();
+        return S.chainEnd > nM32 ? GF_K_ERR_BOUNDS : GF_K_OK;                        // last value truncated
+    }
 
     // ---- borders: per-row constants (and row 0 of Triangle) ----
     // Linear and Triangle emit their border residuals FIRST (2 nR - 1, nC + nR - 2 elements): the head of the stream is decoded a
@@ -1848,7 +2005,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         else if (nM32 < nStream) early = GF_K_ERR_BOUNDS;               // M32 reads run off codeM32s
         const FusedPlan plan = fused_plan(nR, nC, model);
         if constexpr (FAST) {
-            if (early == GF_K_OK && (nM32 > a.ldsM32Bytes || model > 3 || !plan.ring)) {
+            if (early == GF_K_OK && (nM32 > a.ldsM32Bytes || !plan.ring)) {
                 early = GF_K_RETRY;
                 if (tid == 0) atomicOr(a.retryFlag, 1u);
             }

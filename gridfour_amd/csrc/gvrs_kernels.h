@@ -183,7 +183,7 @@ hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStr
                              const uint32_t *lengths, uint64_t *offsets, uint8_t *blob,
                              size_t blobCap, hipStream_t stream, const int32_t *status = nullptr);
 hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
-                               int64_t tile0, size_t nTiles, int32_t *values, hipStream_t stream);
+                               int64_t tile0, size_t nTiles, int32_t *values, hipStream_t stream, int maskPerMille = 0);
 
 // CodecFloat byte planes (gvrs_float.hip); plane buffer of a tile = ceil(n/8) + 4n bytes at planeStride
 hipError_t gf_launch_float_planes_encode(const uint32_t *raw, uint8_t *planes, size_t planeStride, size_t nTiles, int nRows,

@@ -436,6 +436,12 @@ gf_status gf_float_decode_f32(gf_context *ctx, int n_rows, int n_cols, const uin
 gf_status gf_synth_dem_dev(gf_context *ctx, void *stream, uint64_t seed, int n_rows, int n_cols,
                            int64_t tiles_per_row, int64_t tile0, size_t n_tiles,
                            int32_t *d_values);
+/* the nulls workload of SURVEY.md section 8d: the same grid with an "ocean mask" -- mask_per_mille / 1000 of its
+ * 16 x 16 blocks hold GF_INT4_NULL_CODE, so that nearly every tile takes PredictorModelDifferencingWithNulls
+ * (compress/CodecHuffman.java:73-98, PredictorModelDifferencingWithNulls.java:66-166)                            */
+gf_status gf_synth_dem_masked_dev(gf_context *ctx, void *stream, uint64_t seed, int n_rows, int n_cols,
+                                  int64_t tiles_per_row, int64_t tile0, size_t n_tiles, int mask_per_mille,
+                                  int32_t *d_values);
 
 /* ---- thin device-memory helpers so that non-HIP hosts (JNI, ctypes) can
  *      stage data without linking the HIP runtime themselves --------------- */

@@ -1174,6 +1174,33 @@ int32_t gvo_dem_value(uint64_t seed, int64_t gx, int64_t gy)
     return (int32_t)sum;
 }
 
+/* ocean mask of the nulls workload ("a variant with 5 % INT4_NULL_CODE ocean-mask blocks"): the grid is
+ * cut into 16 x 16 blocks; a block is masked out entirely when its hash falls below maskPerMille / 1000 */
+int gvo_dem_masked(uint64_t seed, int64_t gx, int64_t gy, int maskPerMille)
+{
+    if (maskPerMille <= 0) return 0;
+    uint64_t h = gvo_splitmix64(seed ^ 0x3300000000000000ULL ^
+                                ((((uint64_t)gy >> 4) & 0xFFFFFFFULL) << 28) ^ (((uint64_t)gx >> 4) & 0xFFFFFFFULL));
+    return (int)((h >> 33) % 1000u) < maskPerMille;
+}
+
+void gvo_dem_fill_tiles_masked(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                               int64_t tile0, int64_t nTiles, int maskPerMille, int32_t *values)
+{
+    size_t nCells = (size_t)nRows * (size_t)nCols;
+    for (int64_t t = 0; t < nTiles; t++) {
+        int64_t tile = tile0 + t;
+        int64_t tr = tile / tilesPerRow, tc = tile % tilesPerRow;
+        int32_t *v = values + (size_t)t * nCells;
+        for (int r = 0; r < nRows; r++) {
+            for (int c = 0; c < nCols; c++) {
+                int64_t gx = tc * nCols + c, gy = tr * nRows + r;
+                v[(size_t)r * nCols + c] = gvo_dem_masked(seed, gx, gy, maskPerMille) ? (int32_t)0x80000000u : gvo_dem_value(seed, gx, gy);
+            }
+        }
+    }
+}
+
 void gvo_dem_fill_tiles(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                         int64_t tile0, int64_t nTiles, int32_t *values)
 {

@@ -162,6 +162,9 @@ int32_t gvo_dem_value(uint64_t seed, int64_t gx, int64_t gy);
  * of a grid cut into nRows x nCols tiles), starting at tile index tile0.     */
 void gvo_dem_fill_tiles(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                         int64_t tile0, int64_t nTiles, int32_t *values);
+/* the same with an ocean mask: 16 x 16 blocks of GF null codes, maskPerMille / 1000 of the blocks */
+void gvo_dem_fill_tiles_masked(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                               int64_t tile0, int64_t nTiles, int maskPerMille, int32_t *values);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,31 @@ def test_synth_dem_matches_oracle(codec):
     b.free()
 
 
+def test_synth_dem_masked_matches_oracle(codec):
+    """The nulls workload: 5 % of the grid's 16 x 16 blocks are null; generator == oracle, and the tiles take the
+    nulls predictor through the batch path with the oracle's bytes."""
+    from gridfour_amd import DeviceTileBatch
+    b = DeviceTileBatch(codec.ctx, 120, 150, 8)
+    b.synth_dem(oracle.DEM_SEED + 2, 144, tile0=141, mask_per_mille=50)
+    codec.ctx.synchronize()
+    ref = oracle.dem_tiles(oracle.DEM_SEED + 2, 120, 150, 144, 141, 8, mask_per_mille=50)
+    vals = b.get_values()
+    assert np.array_equal(vals, ref)
+    frac = float((ref == np.int32(-2 ** 31)).mean())
+    assert 0.01 < frac < 0.12
+    b.encode(codec_index=0)
+    b.decode()
+    codec.ctx.synchronize()
+    assert (b.get_enc_status() == 0).all() and (b.get_dec_status() == 0).all()
+    assert np.array_equal(b.get_decoded(), vals)
+    preds, lengths = b.get_predictors(), b.get_lengths()
+    assert (preds == 4).sum() >= 6                               # nearly every tile has a masked block
+    for t in range(8):
+        want, used = oracle.codec_huffman_encode(0, 120, 150, ref[t])
+        assert preds[t] == used and b.get_packing(t) == want
+    b.free()
+
+
 def test_batch_dem_roundtrip_and_sampled_parity(codec):
     """Config-2 shape at reduced count: 256 tiles of 200x200, all three predictors + Huffman."""
     from gridfour_amd import DeviceTileBatch
