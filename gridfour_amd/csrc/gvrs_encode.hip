@@ -471,6 +471,15 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 Cells8 Q;
                 load_cells8(tile, nC, nCells, i0, Q);
                 uint32_t c = c0;
+                // a tile with a null cell takes the nulls predictor alone, with a histogram of its own (below): once a lane of the wave
+                // has seen one, the three histograms of this pass are not needed any more -- only the scan for valid cells goes on
+                // (wave-local: a wave's lanes cover 512 consecutive cells per turn, so a block of nulls reaches every wave within a turn or two)
+                if (__any((myFlags & 1u) != 0u)) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (i0 + j < nCells) myFlags |= Q.cur[j] == GF_NULL_CODE ? 1u : 2u;
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     const uint32_t idx = i0 + j;
@@ -530,6 +539,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
             continue;
         }
 
+#ifdef GF_ENC_NULLS_RETRY
         if constexpr (FAST) {
             if (anyNull) {
                 if (tid == 0) {
@@ -540,20 +550,51 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 continue;
             }
         }
-        if (!FAST && anyNull) {
-            // ---- nulls path (rare): seed (PredictorModelDifferencingWithNulls.java:79-105), then one histogram ----
+#endif
+        if (anyNull) {
+            // ---- nulls path: seed (PredictorModelDifferencingWithNulls.java:79-105), then one histogram ----
+            // A cell's residual is v - prior, prior = left neighbour (column 0: the first cell of the row above), and the seed in
+            // prior's place where prior is null (cell (0,0) included): only those "start" cells need the seed, which is the rounded
+            // mean of exactly their values (:79-96).  So one pass over the tile (eight cells per thread as in phase A) sums the
+            // start cells and counts everything else -- null cells as the byte 0x80 -- and a second one adds the start cells.
             forcedZeros = 0;
             for (int i = tid; i < 3 * 256 * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
+            __syncthreads();
+            uint32_t *const h0 = &S.histR[0][rep];
+            auto addHist0 = [&](uint32_t x) -> uint32_t {
+                bool single;
+                const uint32_t b0 = m32_first_byte(x, &single);
+                atomicAdd(h0 + b0 * HIST_R, 1u);
+                uint32_t n = 1;
+                if (!single) {
+                    n = (uint32_t)gf_m32_len(x);
+                    for (uint32_t k = 1; k < n; k++) atomicAdd(h0 + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
+                }
+                return n;
+            };
             long long mySum = 0;
-            uint32_t myCnt = 0;
-            for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
-                const uint32_t v = tile[idx];
-                if (v == GF_NULL_CODE) continue;
-                const uint32_t r = idx / nC, c = idx - r * nC;
-                bool flag;
-                if (c > 0) flag = tile[idx - 1] == GF_NULL_CODE;
-                else flag = r == 0 ? true : tile[idx - nC] == GF_NULL_CODE;
-                if (flag) { mySum += (int32_t)v; myCnt++; }
+            uint32_t myCnt = 0, maxN = 1;
+            {
+                uint32_t c0 = ((uint32_t)tid * CPT) % nC;
+                const uint32_t cStep = STEP_CELLS % nC;
+                for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
+                    Cells8 Q;
+                    load_cells8(tile, nC, nCells, i0, Q);
+                    uint32_t c = c0;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t idx = i0 + j, v = Q.cur[j];
+                        const uint32_t prior = c > 0 ? (j > 0 ? Q.cur[j - 1] : Q.wm1) : Q.up[j];
+                        if (idx < nCells) {
+                            if (v == GF_NULL_CODE) addHist0(GF_NULL_CODE);
+                            else if (idx == 0 || prior == GF_NULL_CODE) { mySum += (int32_t)v; myCnt++; }
+                            else maxN = max(maxN, addHist0(v - prior));
+                        }
+                        if (++c == nC) c = 0;
+                    }
+                    c0 += cStep;
+                    if (c0 >= nC) c0 -= nC;
+                }
             }
             if (myCnt) {
                 atomicAdd(&P.sumStart, (unsigned long long)mySum);
@@ -575,13 +616,23 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
             }
             __syncthreads();
             const uint32_t seed = P.seed;
-            uint32_t maxN = 1;
-            for (uint32_t idx = tid; idx < nCells; idx += ENC_THREADS) {
-                const uint32_t r = idx / nC, c = idx - r * nC;
-                const uint32_t x = cell_residual(4, tile, nC, idx, r, c, seed);
-                const int n = gf_m32_len(x);
-                maxN = max(maxN, (uint32_t)n);
-                for (int k = 0; k < n; k++) atomicAdd(&S.histR[0][gf_m32_byte(x, n, k) * HIST_R + rep], 1u);
+            if (myCnt) {                                     // the threads that met start cells meet them again
+                uint32_t c0 = ((uint32_t)tid * CPT) % nC;
+                const uint32_t cStep = STEP_CELLS % nC;
+                for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
+                    Cells8 Q;
+                    load_cells8(tile, nC, nCells, i0, Q);
+                    uint32_t c = c0;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t idx = i0 + j, v = Q.cur[j];
+                        const uint32_t prior = c > 0 ? (j > 0 ? Q.cur[j - 1] : Q.wm1) : Q.up[j];
+                        if (idx < nCells && v != GF_NULL_CODE && (idx == 0 || prior == GF_NULL_CODE)) maxN = max(maxN, addHist0(v - seed));
+                        if (++c == nC) c = 0;
+                    }
+                    c0 += cStep;
+                    if (c0 >= nC) c0 -= nC;
+                }
             }
             atomicMax(&P.maxN[0], maxN);
             __syncthreads();
