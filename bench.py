@@ -112,7 +112,42 @@ def _pmc_traffic(workload, kernel):
     return total, "profiles/hbm_traffic.json@%s" % (commit or "unversioned")
 
 
-def run_float(args, ctx, rank, world, dist, torch):
+CLOCK_HZ = 2.4e9              # MI355X_MICROARCH.md: max engine clock; 256 CUs x 4 SIMDs
+
+
+def _issue_roofline(workload, kernel, n_tiles, launch_ms):
+    """Second bound next to the HBM one: the instruction-issue floor of the dominant kernel.  Wave-instructions per tile (VALU + SALU,
+    rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of the SHIPPING library, tools/pmc_issue.sh -> profiles/issue_counts.json,
+    replayed here like the HBM traffic: counters cannot be collected inside the timed process) x tiles / (256 CUs x 4 SIMDs x
+    clock): the time the launch would take if every SIMD issued one of these instructions per cycle and nothing ever waited.
+    tools/valu_rate.hip measures what a SIMD really sustains on this instruction mix (profiles/r03_*/valu_rate.txt: 2.6 cycles
+    per integer add / xor, 3.6-3.8 per compare + select pair member at two or more waves): that, not one per cycle, is the wall
+    the decode kernel runs at 60-70 % of."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        rec = json.load(open(os.path.join(here, "profiles", "issue_counts.json")))
+    except (OSError, ValueError):
+        return None
+    if rec.get("workload") != workload:
+        return None
+    valu = salu = 0.0
+    found = []
+    for part in kernel.split("+"):
+        for name, d in rec.get("kernels", {}).items():
+            if name.split("<")[0].strip() == part:
+                valu += d.get("insts_valu", 0.0)
+                salu += d.get("insts_salu", 0.0)
+                found.append(name)
+    if not found:
+        return None
+    floor_ms = (valu + salu) * n_tiles / (256 * 4 * CLOCK_HZ) * 1e3
+    return {"bound": "issue", "kernel": "+".join(found), "valu_per_tile": round(valu, 1), "salu_per_tile": round(salu, 1),
+            "floor_ms": round(floor_ms, 4), "avg_launch_ms": round(launch_ms, 4), "frac_of_issue_floor": round(floor_ms / launch_ms, 4),
+            "assumes": "one VALU or SALU wave-instruction per cycle and SIMD, 256 CUs x 4 SIMDs at 2.4 GHz",
+            "counts_replayed_from": "profiles/issue_counts.json@%s" % (rec.get("commit") or "unversioned")}
+
+
+def run_float(args, ctxs, rank, world, dist, torch, single_multi=False):
     """BASELINE config 5(i): CodecFloat.  The GPU stage is the five byte planes (split + delta on encode, running sums +
     merge on decode, CodecFloat.java:328-458); the Deflate stage is the host's zlib and is timed separately, on a sample,
     through the host entry points.  One step = planes-encode then planes-decode of every tile, device-resident."""
@@ -121,51 +156,60 @@ def run_float(args, ctx, rank, world, dist, torch):
     from gridfour_amd._lib import check
     n_rows, n_cols, n_tiles, tiles_per_row, descr = WORKLOADS[args.workload]
     cells = n_rows * n_cols
-    # floats = integer DEM x 0.1f: generated on the device as int32, converted on the host once
-    gen = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=16)
-    gen.synth_dem(0x9E3779B97F4A7C15 + 5, tiles_per_row, tile0=rank * n_tiles)
-    ctx.synchronize()
-    vals = (gen.get_values().astype(np.float32) * np.float32(0.1)).reshape(n_tiles, cells)
-    del gen
+    n_shards = len(ctxs)
+    total_shards = n_shards if single_multi else world
     pstride = int(lib().gf_float_planes_bytes(n_rows, n_cols))
     pstride = (pstride + 15) // 16 * 16
-    d_in, d_planes, d_out = (DeviceBuffer(ctx, vals.nbytes), DeviceBuffer(ctx, n_tiles * pstride),
-                             DeviceBuffer(ctx, vals.nbytes))
-    d_in.upload(vals)
-    t_enc = [GpuTimer(ctx) for _ in range(args.steps)]
-    t_dec = [GpuTimer(ctx) for _ in range(args.steps)]
+    shards = []                                        # one per device this process drives: (ctx, values, in, planes, out, timers)
+    for g, ctx in enumerate(ctxs):
+        # floats = integer DEM x 0.1f: generated on the device as int32, converted on the host once
+        gen = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=16)
+        gen.synth_dem(0x9E3779B97F4A7C15 + 5, tiles_per_row, tile0=(g if single_multi else rank) * n_tiles)
+        ctx.synchronize()
+        v = (gen.get_values().astype(np.float32) * np.float32(0.1)).reshape(n_tiles, cells)
+        del gen
+        d_in, d_planes, d_out = DeviceBuffer(ctx, v.nbytes), DeviceBuffer(ctx, n_tiles * pstride), DeviceBuffer(ctx, v.nbytes)
+        d_in.upload(v)
+        shards.append((ctx, v, d_in, d_planes, d_out, [GpuTimer(ctx) for _ in range(args.steps)], [GpuTimer(ctx) for _ in range(args.steps)]))
+    ctx, vals, d_in, d_planes, d_out = shards[0][:5]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.synchronize()
+        for sh in shards:
+            sh[0].synchronize()
 
     def step(i=None):
-        if i is not None:
-            t_enc[i].start()
-        check(lib().gf_float_planes_encode_dev(ctx.handle, None, n_rows, n_cols, n_tiles, d_in.ptr, d_planes.ptr, pstride), "enc")
-        if i is not None:
-            t_enc[i].stop()
-            t_dec[i].start()
-        check(lib().gf_float_planes_decode_dev(ctx.handle, None, n_rows, n_cols, n_tiles, d_planes.ptr, pstride, d_out.ptr), "dec")
-        if i is not None:
-            t_dec[i].stop()
+        # every device's shard is enqueued from this thread (the launches are asynchronous), no sync in between
+        for c, _, din, dpl, dout, te, td in shards:
+            if i is not None:
+                te[i].start()
+            check(lib().gf_float_planes_encode_dev(c.handle, None, n_rows, n_cols, n_tiles, din.ptr, dpl.ptr, pstride), "enc")
+            if i is not None:
+                te[i].stop()
+        for c, _, din, dpl, dout, te, td in shards:
+            if i is not None:
+                td[i].start()
+            check(lib().gf_float_planes_decode_dev(c.handle, None, n_rows, n_cols, n_tiles, dpl.ptr, pstride, dout.ptr), "dec")
+            if i is not None:
+                td[i].stop()
 
     for _ in range(args.warmup):
         step()
     # the timers' events are recorded once outside the timed region: the first record of an event is slower than the rest
-    for tm in t_enc + t_dec:
-        tm.start()
-        tm.stop()
+    for sh in shards:
+        for tm in sh[5] + sh[6]:
+            tm.start()
+            tm.stop()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    enc_avg = float(np.mean([t.elapsed_ms() for t in t_enc]))
-    dec_avg = float(np.mean([t.elapsed_ms() for t in t_dec]))
+    enc_avg = float(max(np.mean([t.elapsed_ms() for t in sh[5]]) for sh in shards))      # the slowest device
+    dec_avg = float(max(np.mean([t.elapsed_ms() for t in sh[6]]) for sh in shards))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -177,15 +221,17 @@ def run_float(args, ctx, rank, world, dist, torch):
     bit_exact, cpu_baseline, host_path = None, None, None
     if not args.no_verify:
         import oracle
-        back = d_out.download(np.uint32, n_tiles * cells).reshape(n_tiles, cells)
-        roundtrip_ok = bool(np.array_equal(back, vals.view(np.uint32)))
+        roundtrip_ok = True
+        for sh in shards:                              # every shard's round trip
+            back = sh[4].download(np.uint32, n_tiles * cells).reshape(n_tiles, cells)
+            roundtrip_ok = roundtrip_ok and bool(np.array_equal(back, sh[1].view(np.uint32)))
         planes = d_planes.download(np.uint8, n_tiles * pstride).reshape(n_tiles, pstride)
         nb = int(lib().gf_float_planes_bytes(n_rows, n_cols))
         parity_ok = all(planes[t, :nb].tobytes() == bytes(oracle.float_planes_encode(n_rows, n_cols, vals[t].view(np.uint32)))
                         for t in range(0, n_tiles, max(1, n_tiles // 16)))
         bit_exact = bool(roundtrip_ok and parity_ok)
         ns = args.cpu_sample_tiles if args.cpu_sample_tiles >= 0 else min(n_tiles, 400)    # ~10 s: zlib level 9 dominates
-        if ns > 0 and world == 1:
+        if ns > 0 and total_shards == 1:
             sub = vals[:ns]
             mb = sub.nbytes / 1e6
             c0 = time.perf_counter()
@@ -215,11 +261,12 @@ def run_float(args, ctx, rank, world, dist, torch):
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     out = {
         "metric": "CodecFloat plane stage encode+decode MB/s on float32 tiles (GPU stage; Deflate on the host's zlib)",
-        "value": round(raw_mb * world * steps / elapsed, 1), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "value": round(raw_mb * total_shards * steps / elapsed, 1), "unit": "MB/s", "n_gpus": total_shards, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, descr), "tile_rows": n_rows, "tile_cols": n_cols, "tiles_per_gpu": n_tiles,
-                   "codec": "CodecFloat (sign / exponent / 3 delta-coded mantissa byte planes)", "sharding": "contiguous tile ranges, no collective"},
+                   "codec": "CodecFloat (sign / exponent / 3 delta-coded mantissa byte planes)", "sharding": "contiguous tile ranges, no collective",
+                   "processes": ("one process, %d contexts" % n_shards) if single_multi else ("one per GPU (torch.distributed launcher)" if world > 1 else "one")},
         "bit_exact": bit_exact, "encode_ms": round(enc_avg, 4), "decode_ms": round(dec_avg, 4),
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": _pmc_traffic(args.workload, dom_name)[0],
@@ -467,10 +514,12 @@ def main():
         raise SystemExit("--codec float goes with --workload float256 (and only with it)")
     if args.workload == "float256_lsop" and args.codec != "lsop":
         raise SystemExit("--workload float256_lsop is the int-coded-float + LSOP12 configuration: use --codec lsop")
-    if single_multi and args.codec != "huffman":
-        raise SystemExit("the single-process multi-GPU mode runs the north-star codec (CodecHuffman); use a launcher for the others")
     if args.codec == "float":
-        return run_float(args, gridfour_amd.GvrsHipContext(local_rank), rank, world, dist, torch)
+        if single_multi:
+            multi = gridfour_amd.GvrsHipMulti([0 if share else g for g in range(args.gpus)])
+            fctx = [_BorrowedContext(lib().gf_multi_context(multi.handle, g), multi.devices[g]) for g in range(args.gpus)]
+            return run_float(args, fctx, rank, world, dist, torch, single_multi=True)
+        return run_float(args, [gridfour_amd.GvrsHipContext(local_rank)], rank, world, dist, torch)
 
     # ---- shards: one per GPU.  Under a launcher this process owns shard `rank`; in single-process mode it owns them all ----
     n_shards = args.gpus if single_multi else 1
@@ -510,7 +559,23 @@ def main():
         for ctx in ctxs:
             ctx.synchronize()
 
-    if single_multi:
+    if single_multi and args.codec != "huffman":
+        # CodecCanonHuffman / LSOP12 from one process: every shard's kernels are enqueued on its own context's stream from this
+        # thread, one device after the other (what gf_*_multi_dev do inside the library), no sync in between
+        def step(i=None):
+            for g, b in enumerate(batches):
+                if i is not None:
+                    t_enc[g][i].start()
+                b.encode(codec_index=0)
+                if i is not None:
+                    t_enc[g][i].stop()
+            for g, b in enumerate(batches):
+                if i is not None:
+                    t_dec[g][i].start()
+                b.decode()
+                if i is not None:
+                    t_dec[g][i].stop()
+    elif single_multi:
         import ctypes as C
         G = n_shards
         arr = lambda ptrs: (C.c_void_p * G)(*ptrs)
@@ -668,6 +733,7 @@ def main():
         "cpu_baseline": cpu_baseline,
         "host_path": host_path,
     }
+    out["roofline_issue"] = _issue_roofline(args.workload, dom_name, n_tiles, dom_ms)
     if args.codec == "lsop":
         out["roofline_fp64"] = _lsop_fp64_roofline(ctxs[0], batches[0], n_rows, n_cols, n_tiles, max(3, min(steps, 10)))
     print(json.dumps(out))

@@ -125,6 +125,15 @@ SIGNATURES = {
     "gf_huffman_decode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
     "gf_canon_encode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "gf_canon_decode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_deflate_encode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "gf_deflate_decode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_lsop12_encode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "gf_lsop12_decode_batch_i32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_float_encode_batch_f32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "gf_float_decode_batch_f32_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, _vp]),
+    "gf_canon_encode_batch_i32_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp,
+                                                      C.c_int]),
+    "gf_canon_decode_batch_i32_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "gf_huffman_encode_batch_i32_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp,
                                                         C.c_int]),
     "gf_huffman_decode_batch_i32_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),

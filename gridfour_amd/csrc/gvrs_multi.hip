@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -99,11 +100,13 @@ gf_status gf_multi_synchronize(gf_multi *m)
 
 namespace {
 
-typedef gf_status (*EncodeHostFn)(gf_context *, int, int, int, size_t, const int32_t *, uint8_t *, size_t, uint64_t *, uint8_t *,
-                                  int32_t *);
-typedef gf_status (*DecodeHostFn)(gf_context *, int, int, size_t, const uint8_t *, const uint64_t *, int32_t *, int32_t *);
+// the host-memory batch entry point of a codec, as a callable: (context, codec index, rows, columns, tiles, cells, blob, capacity,
+// offsets, per-tile byte (predictor / container type) or null, status or null); cells are 32-bit words (int32 or float32)
+typedef std::function<gf_status(gf_context *, int, int, int, size_t, const int32_t *, uint8_t *, size_t, uint64_t *, uint8_t *, int32_t *)>
+    EncodeHostFn;
+typedef std::function<gf_status(gf_context *, int, int, size_t, const uint8_t *, const uint64_t *, int32_t *, int32_t *)> DecodeHostFn;
 
-gf_status encodeMulti(EncodeHostFn fn, gf_multi *m, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+gf_status encodeMulti(const EncodeHostFn &fn, gf_multi *m, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
                       uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *predictors, int32_t *status)
 {
     if (!m || nRows < 1 || nCols < 1 || (!values && nTiles) || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
@@ -131,7 +134,7 @@ gf_status encodeMulti(EncodeHostFn fn, gf_multi *m, int codecIndex, int nRows, i
                     free(m->part[g]);
                     m->part[g] = (uint8_t *)malloc(cap);
                     m->partCap[g] = m->part[g] ? cap : 0;
-                    if (!m->part[g]) { p.st = GF_ERR_CAPACITY; return; }
+                    if (!m->part[g]) { p.st = GF_ERR_HIP; return; }       // out of host memory: not the "grow the blob" status
                 }
                 p.st = fn(m->ctx[g], codecIndex, nRows, nCols, n, values + p.t0 * cells, m->part[g], m->partCap[g], p.off.data(),
                           predictors ? predictors + p.t0 : nullptr, status ? status + p.t0 : nullptr);
@@ -164,7 +167,7 @@ gf_status encodeMulti(EncodeHostFn fn, gf_multi *m, int codecIndex, int nRows, i
     return GF_OK;
 }
 
-gf_status decodeMulti(DecodeHostFn fn, gf_multi *m, int nRows, int nCols, size_t nTiles, const uint8_t *blob, const uint64_t *offsets,
+gf_status decodeMulti(const DecodeHostFn &fn, gf_multi *m, int nRows, int nCols, size_t nTiles, const uint8_t *blob, const uint64_t *offsets,
                       int32_t *values, int32_t *status)
 {
     if (!m || nRows < 1 || nCols < 1 || !blob || !offsets || (!values && nTiles)) return GF_ERR_ARG;
@@ -220,6 +223,57 @@ gf_status gf_canon_decode_batch_i32_multi(gf_multi *m, int nRows, int nCols, siz
     return decodeMulti(gf_canon_decode_batch_i32, m, nRows, nCols, nTiles, blob, offsets, values, status);
 }
 
+gf_status gf_deflate_encode_batch_i32_multi(gf_multi *m, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                                            uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *predictors, int32_t *status)
+{
+    return encodeMulti(gf_deflate_encode_batch_i32, m, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, predictors, status);
+}
+
+gf_status gf_deflate_decode_batch_i32_multi(gf_multi *m, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                            const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    return decodeMulti(gf_deflate_decode_batch_i32, m, nRows, nCols, nTiles, blob, offsets, values, status);
+}
+
+// LSOP12 (BASELINE config 5-ii sharded): types = the container each tile ended up in, as gf_lsop12_encode_batch_i32 reports it
+gf_status gf_lsop12_encode_batch_i32_multi(gf_multi *m, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                                           int deflateEnabled, uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *types,
+                                           int32_t *status)
+{
+    const EncodeHostFn fn = [deflateEnabled](gf_context *c, int ci, int nr, int nc, size_t n, const int32_t *v, uint8_t *b, size_t cap,
+                                             uint64_t *off, uint8_t *ty, int32_t *st) {
+        return gf_lsop12_encode_batch_i32(c, ci, nr, nc, n, v, deflateEnabled, b, cap, off, ty, st);
+    };
+    return encodeMulti(fn, m, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, types, status);
+}
+
+gf_status gf_lsop12_decode_batch_i32_multi(gf_multi *m, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                           const uint64_t *offsets, int32_t *values, int32_t *status)
+{
+    return decodeMulti(gf_lsop12_decode_batch_i32, m, nRows, nCols, nTiles, blob, offsets, values, status);
+}
+
+// CodecFloat (BASELINE config 5-i sharded): float32 cells; no per-tile byte, no encode status (CodecFloat never declines)
+gf_status gf_float_encode_batch_f32_multi(gf_multi *m, int codecIndex, int nRows, int nCols, size_t nTiles, const float *values,
+                                          int zlibLevel, uint8_t *blob, size_t blobCap, uint64_t *offsets)
+{
+    const EncodeHostFn fn = [zlibLevel](gf_context *c, int ci, int nr, int nc, size_t n, const int32_t *v, uint8_t *b, size_t cap,
+                                        uint64_t *off, uint8_t *, int32_t *) {
+        return gf_float_encode_batch_f32(c, ci, nr, nc, n, reinterpret_cast<const float *>(v), zlibLevel, b, cap, off);
+    };
+    return encodeMulti(fn, m, codecIndex, nRows, nCols, nTiles, reinterpret_cast<const int32_t *>(values), blob, blobCap, offsets,
+                       nullptr, nullptr);
+}
+
+gf_status gf_float_decode_batch_f32_multi(gf_multi *m, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
+                                          const uint64_t *offsets, float *values, int32_t *status)
+{
+    const DecodeHostFn fn = [](gf_context *c, int nr, int nc, size_t n, const uint8_t *b, const uint64_t *off, int32_t *v, int32_t *st) {
+        return gf_float_decode_batch_f32(c, nr, nc, n, b, off, reinterpret_cast<float *>(v), st);
+    };
+    return decodeMulti(fn, m, nRows, nCols, nTiles, blob, offsets, reinterpret_cast<int32_t *>(values), status);
+}
+
 // Device-resident shards: shard g lives on context g's device.  Every array argument has gf_multi_count(m) entries; the
 // calls only enqueue (one stream per device) and return -- gf_multi_synchronize waits.
 gf_status gf_huffman_encode_batch_i32_multi_dev(gf_multi *m, int codecIndex, int nRows, int nCols, const size_t *nTiles,
@@ -246,6 +300,35 @@ gf_status gf_huffman_decode_batch_i32_multi_dev(gf_multi *m, int nRows, int nCol
         const gf_status s = gf_huffman_decode_batch_i32_dev(m->ctx[g], nullptr, nRows, nCols, nTiles[g], dBlob[g], blobBytes[g],
                                                             dOffsets ? dOffsets[g] : nullptr, slotStride, dLengths[g], dValues[g],
                                                             dStatus[g]);
+        if (s != GF_OK) return s;
+    }
+    return GF_OK;
+}
+
+gf_status gf_canon_encode_batch_i32_multi_dev(gf_multi *m, int codecIndex, int nRows, int nCols, const size_t *nTiles,
+                                              const int32_t *const *dValues, uint8_t *const *dOut, size_t slotStride,
+                                              uint32_t *const *dLengths, uint8_t *const *dPredictors, int32_t *const *dStatus,
+                                              int predictorMask)
+{
+    if (!m || !nTiles || !dValues || !dOut || !dLengths || !dStatus) return GF_ERR_ARG;
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        const gf_status s = gf_canon_encode_batch_i32_dev(m->ctx[g], nullptr, codecIndex, nRows, nCols, nTiles[g], dValues[g], dOut[g],
+                                                          slotStride, dLengths[g], dPredictors ? dPredictors[g] : nullptr, dStatus[g],
+                                                          predictorMask);
+        if (s != GF_OK) return s;
+    }
+    return GF_OK;
+}
+
+gf_status gf_canon_decode_batch_i32_multi_dev(gf_multi *m, int nRows, int nCols, const size_t *nTiles, const uint8_t *const *dBlob,
+                                              const size_t *blobBytes, const uint64_t *const *dOffsets, size_t slotStride,
+                                              const uint32_t *const *dLengths, int32_t *const *dValues, int32_t *const *dStatus)
+{
+    if (!m || !nTiles || !dBlob || !blobBytes || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        const gf_status s = gf_canon_decode_batch_i32_dev(m->ctx[g], nullptr, nRows, nCols, nTiles[g], dBlob[g], blobBytes[g],
+                                                          dOffsets ? dOffsets[g] : nullptr, slotStride, dLengths[g], dValues[g],
+                                                          dStatus[g]);
         if (s != GF_OK) return s;
     }
     return GF_OK;

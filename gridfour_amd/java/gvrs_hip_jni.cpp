@@ -221,6 +221,65 @@ JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_HipCodecNative_decode(JNIEnv *
     return result;
 }
 
+// byte[] encodeFloats(long handle, int codecIndex, int nRows, int nCols, float[] values, int level): ICompressionEncoder.encodeFloats
+// as CodecFloat implements it (compress/CodecFloat.java:328-369, ICompressionEncoder.java:76-91)
+JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_encodeFloats(JNIEnv *env, jclass, jlong handle, jint codecIndex,
+                                                                               jint nRows, jint nCols, jfloatArray values, jint level)
+{
+    Handle *h = handleOf(env, handle);
+    if (!h) return nullptr;
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    if (!values || (size_t)env->GetArrayLength(values) < cells) {
+        jclass c = env->FindClass("java/lang/ArrayIndexOutOfBoundsException");   // values[k] beyond the array in the reference's loops
+        if (c) env->ThrowNew(c, "fewer values than nRows * nCols");
+        return nullptr;
+    }
+    std::vector<float> v(cells + 1);
+    if (cells) env->GetFloatArrayRegion(values, 0, (jsize)cells, (jfloat *)v.data());
+    // 2 header bytes + five planes, each a length and a zlib stream (stored blocks at worst: a few bytes per 16 KB more)
+    const size_t cap = 5 * cells + 4096;
+    std::vector<uint8_t> out(cap);
+    size_t n = 0;
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        s = gf_float_encode_f32(h->ctx, codecIndex, nRows, nCols, v.data(), level, out.data(), cap, &n);
+    }
+    if (s != GF_OK) {
+        jclass c = env->FindClass("java/lang/IllegalStateException");
+        if (c) env->ThrowNew(c, gf_status_string(s));
+        return nullptr;
+    }
+    jbyteArray result = env->NewByteArray((jsize)n);
+    if (result) env->SetByteArrayRegion(result, 0, (jsize)n, (const jbyte *)out.data());
+    return result;
+}
+
+// float[] decodeFloats(long handle, int nRows, int nColumns, byte[] packing): ICompressionDecoder.decodeFloats as CodecFloat
+// implements it (compress/CodecFloat.java:371-458); a stream the inflater rejects is CodecFloat's IOException
+JNIEXPORT jfloatArray JNICALL Java_org_gridfour_hip_HipCodecNative_decodeFloats(JNIEnv *env, jclass, jlong handle, jint nRows,
+                                                                                jint nCols, jbyteArray packing)
+{
+    Handle *h = handleOf(env, handle);
+    if (!h) return nullptr;
+    const jsize len = env->GetArrayLength(packing);
+    const std::vector<uint8_t> pk = bytesOf(env, packing);
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    std::vector<float> out(cells + 1);
+    gf_status s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        s = gf_float_decode_f32(h->ctx, nRows, nCols, pk.data(), (size_t)len, out.data());
+    }
+    if (s != GF_OK) {
+        throwIo(env, gf_status_string(s));
+        return nullptr;
+    }
+    jfloatArray result = env->NewFloatArray((jsize)cells);
+    if (result) env->SetFloatArrayRegion(result, 0, (jsize)cells, (const jfloat *)out.data());
+    return result;
+}
+
 // byte[] tileRecords(long handle, int[] codecKinds, int elemType, int fillValue, int nRows, int nCols, int[] tileIndices,
 //                    Object cells, boolean checksums, long[] recordOffsets)
 JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_tileRecords(JNIEnv *env, jclass, jlong handle, jintArray codecKinds,
@@ -398,12 +457,12 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_multiHuffmanEn
     size_t cap = nTiles * per + 4096;                                // a byte per cell holds terrain packings; grown on demand
     std::vector<uint8_t> blob;
     gf_status s;
-    for (;;) {
+    for (int attempt = 0; attempt < 2; attempt++) {                  // one regrow at most: the call reports the size it needs
         blob.resize(cap);
         s = gf_huffman_encode_batch_i32_multi((gf_multi *)(intptr_t)multi, codecIndex, nRows, nCols, nTiles, v.data(), blob.data(), cap,
                                               off.data(), pred.data(), st.data());
-        if (s != GF_ERR_CAPACITY) break;
-        cap = (size_t)off[nTiles] + 64;                              // the call reports the size it needs
+        if (s != GF_ERR_CAPACITY || off[nTiles] == 0) break;
+        cap = (size_t)off[nTiles] + 64;
     }
     if (s != GF_OK) {
         throwIo(env, gf_status_string(s));

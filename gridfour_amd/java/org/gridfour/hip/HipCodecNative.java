@@ -17,6 +17,10 @@ final class HipCodecNative {
   static native byte[] encode(long handle, int kind, int codecIndex, int nRows, int nCols, int[] values);
   static native int[] decode(long handle, int kind, int nRows, int nColumns, byte[] packing) throws IOException;
 
+  /** CodecFloat.encodeFloats / decodeFloats (gf_float_encode_f32 / gf_float_decode_f32); level: zlib's, 9 in the current source. */
+  static native byte[] encodeFloats(long handle, int codecIndex, int nRows, int nCols, float[] values, int level);
+  static native float[] decodeFloats(long handle, int nRows, int nColumns, byte[] packing) throws IOException;
+
   /**
    * All dirty tiles of a flush in one call (RecordManager.writeTile framing, gf_tile_record_encode_batch):
    * codecKinds lists the file's codecs in CodecMaster order (GF_CODEC_* of the C header; empty when compression

@@ -80,22 +80,38 @@ class GvrsHipMulti:
     def synchronize(self):
         check(lib().gf_multi_synchronize(self._h), "gf_multi_synchronize")
 
-    def encode_batch(self, codecIndex, nRows, nCols, tiles, codec="huffman"):
-        """Host memory in, (blob uint8, offsets uint64[n+1], predictors, status) out -- the arrays of the C call."""
-        v = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, nRows * nCols)
+    def encode_batch(self, codecIndex, nRows, nCols, tiles, codec="huffman", deflate_enabled=True, level=9):
+        """Host memory in, (blob uint8, offsets uint64[n+1], predictors, status) out -- the arrays of the C call.
+        codec: huffman, canon, deflate, lsop12 (predictors = container types; deflate_enabled as LsEncoder12), float (float32
+        cells, zlib level; no per-tile byte, no status: those come back as zeros)."""
+        cells = nRows * nCols
+        is_float = codec == "float"
+        v = np.ascontiguousarray(tiles, dtype=np.float32 if is_float else np.int32).reshape(-1, cells)
         nt = v.shape[0]
-        fn = getattr(lib(), "gf_%s_encode_batch_i32_multi" % codec)
-        cap = nt * int(lib().gf_huffman_default_stride(nRows, nCols)) // 2 + 4096
+        name = "gf_float_encode_batch_f32_multi" if is_float else "gf_%s_encode_batch_i32_multi" % codec
+        fn = getattr(lib(), name)
+        if is_float:
+            cap = nt * (5 * cells + 4096)
+        elif codec == "lsop12":
+            cap = nt * (int(lib().gf_lsop12_max_packing(nRows, nCols)) // 2 + 256) + 4096
+        else:
+            cap = nt * int(lib().gf_huffman_default_stride(nRows, nCols)) // 2 + 4096
         offsets = np.zeros(nt + 1, np.uint64)
         preds = np.zeros(nt, np.uint8)
         status = np.zeros(nt, np.int32)
-        while True:
+        for attempt in range(2):                              # one regrow at most: a second GF_ERR_CAPACITY is an error
             blob = np.empty(cap, np.uint8)
-            st = fn(self._h, codecIndex, nRows, nCols, nt, _ptr(v), _ptr(blob), cap, _ptr(offsets), _ptr(preds), _ptr(status))
-            if st == _lib.ERR_CAPACITY:
+            if is_float:
+                st = fn(self._h, codecIndex, nRows, nCols, nt, _ptr(v), int(level), _ptr(blob), cap, _ptr(offsets))
+            elif codec == "lsop12":
+                st = fn(self._h, codecIndex, nRows, nCols, nt, _ptr(v), 1 if deflate_enabled else 0, _ptr(blob), cap, _ptr(offsets),
+                        _ptr(preds), _ptr(status))
+            else:
+                st = fn(self._h, codecIndex, nRows, nCols, nt, _ptr(v), _ptr(blob), cap, _ptr(offsets), _ptr(preds), _ptr(status))
+            if st == _lib.ERR_CAPACITY and attempt == 0 and int(offsets[nt]) > 0:
                 cap = int(offsets[nt]) + 64
                 continue
-            check(st, "gf_%s_encode_batch_i32_multi" % codec)
+            check(st, name)
             return blob[:int(offsets[nt])], offsets, preds, status
 
     def decode_batch(self, nRows, nCols, blob, offsets, codec="huffman"):
@@ -104,10 +120,11 @@ class GvrsHipMulti:
         if b.size < int(offsets[nt]) + 16:
             b = np.concatenate([b, np.zeros(16, np.uint8)])
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
-        out = np.empty((nt, nRows * nCols), np.int32)
+        is_float = codec == "float"
+        out = np.empty((nt, nRows * nCols), np.float32 if is_float else np.int32)
         status = np.zeros(nt, np.int32)
-        check(getattr(lib(), "gf_%s_decode_batch_i32_multi" % codec)(self._h, nRows, nCols, nt, _ptr(b), _ptr(off), _ptr(out),
-                                                                      _ptr(status)), "gf_%s_decode_batch_i32_multi" % codec)
+        name = "gf_float_decode_batch_f32_multi" if is_float else "gf_%s_decode_batch_i32_multi" % codec
+        check(getattr(lib(), name)(self._h, nRows, nCols, nt, _ptr(b), _ptr(off), _ptr(out), _ptr(status)), name)
         return out, status
 
     def close(self):

@@ -204,6 +204,32 @@ gf_status gf_canon_encode_batch_i32_multi(gf_multi *multi, int codec_index, int 
                                           uint8_t *predictors, int32_t *status);
 gf_status gf_canon_decode_batch_i32_multi(gf_multi *multi, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
                                           const uint64_t *offsets, int32_t *values, int32_t *status);
+/* the same partition for the other codecs (CodecDeflate; LSOP12 -- BASELINE config 5(ii) sharded; CodecFloat -- config 5(i)):
+ * arguments as the single-context entry points of the same name without _multi                                          */
+gf_status gf_deflate_encode_batch_i32_multi(gf_multi *multi, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                            const int32_t *values, uint8_t *blob, size_t blob_cap, uint64_t *offsets,
+                                            uint8_t *predictors, int32_t *status);
+gf_status gf_deflate_decode_batch_i32_multi(gf_multi *multi, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                            const uint64_t *offsets, int32_t *values, int32_t *status);
+gf_status gf_lsop12_encode_batch_i32_multi(gf_multi *multi, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                           const int32_t *values, int deflate_enabled, uint8_t *blob, size_t blob_cap,
+                                           uint64_t *offsets, uint8_t *types, int32_t *status);
+gf_status gf_lsop12_decode_batch_i32_multi(gf_multi *multi, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                           const uint64_t *offsets, int32_t *values, int32_t *status);
+gf_status gf_float_encode_batch_f32_multi(gf_multi *multi, int codec_index, int n_rows, int n_cols, size_t n_tiles,
+                                          const float *values, int zlib_level, uint8_t *blob, size_t blob_cap,
+                                          uint64_t *offsets);
+gf_status gf_float_decode_batch_f32_multi(gf_multi *multi, int n_rows, int n_cols, size_t n_tiles, const uint8_t *blob,
+                                          const uint64_t *offsets, float *values, int32_t *status);
+gf_status gf_canon_encode_batch_i32_multi_dev(gf_multi *multi, int codec_index, int n_rows, int n_cols,
+                                              const size_t *n_tiles, const int32_t *const *d_values, uint8_t *const *d_out,
+                                              size_t slot_stride, uint32_t *const *d_lengths, uint8_t *const *d_predictors,
+                                              int32_t *const *d_status, int predictor_mask);
+gf_status gf_canon_decode_batch_i32_multi_dev(gf_multi *multi, int n_rows, int n_cols, const size_t *n_tiles,
+                                              const uint8_t *const *d_blob, const size_t *blob_bytes,
+                                              const uint64_t *const *d_offsets, size_t slot_stride,
+                                              const uint32_t *const *d_lengths, int32_t *const *d_values,
+                                              int32_t *const *d_status);
 gf_status gf_huffman_encode_batch_i32_multi_dev(gf_multi *multi, int codec_index, int n_rows, int n_cols,
                                                 const size_t *n_tiles, const int32_t *const *d_values, uint8_t *const *d_out,
                                                 size_t slot_stride, uint32_t *const *d_lengths, uint8_t *const *d_predictors,

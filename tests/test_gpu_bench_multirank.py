@@ -61,3 +61,19 @@ def test_default_line_has_baselines_and_host_path():
     assert 1 <= cb["all_cores"]["cores"] <= os.cpu_count() and cb["all_cores"]["value"] > cb["value"] * 0.5
     assert d["host_path"]["roundtrip_GBps"] > 0
     assert "traffic_replayed_from" in d["roofline"]
+
+
+@pytest.mark.parametrize("codec,workload", [("canon", "dem1024"), ("lsop", "dem1024"), ("float", "float256")])
+def test_single_process_multi_gpu_mode_other_codecs(codec, workload):
+    """The same for CodecCanonHuffman, LSOP12 and CodecFloat (BASELINE config 5): `--gpus 2` without a launcher."""
+    env = dict(os.environ, GF_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+           "--codec", codec, "--cpu-sample-tiles", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["value"] > 0
+    if codec != "float":
+        assert len(d["devices"]) == 2

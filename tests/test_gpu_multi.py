@@ -141,3 +141,48 @@ def test_host_pipeline_many_chunks_overflow_and_pinned():
     small = np.empty(1000, np.uint8)
     rc = lib().gf_huffman_encode_batch_i32(codec.ctx.handle, 0, n_rows, n_cols, nt, _ptr(tiles), _ptr(small), 1000, _ptr(off3), None, None)
     assert rc == -3 and np.array_equal(off3, off)
+
+
+@pytest.mark.parametrize("shards,nt", [(2, 9), (3, 5)])
+def test_multi_deflate_lsop_float_equal_single_context(shards, nt):
+    """gf_{deflate,lsop12}_*_batch_i32_multi and gf_float_*_batch_f32_multi (BASELINE config 5 sharded inside the library):
+    the bytes of a batch cut over several contexts are those of one context, and decode back to the cells."""
+    import gridfour_amd
+    from gridfour_amd import lib
+    from gridfour_amd.sharding import _ptr
+    n_rows, n_cols = 24, 40
+    tiles = _batch(n_rows, n_cols, nt, seed=7)
+    m = gridfour_amd.GvrsHipMulti([0] * shards)
+    ctx = gridfour_amd.GvrsHipContext(0)
+    cells = n_rows * n_cols
+
+    # CodecDeflate
+    blob1, off1, pred1, st1 = _single("deflate", n_rows, n_cols, tiles)
+    blob, off, pred, st = m.encode_batch(1, n_rows, n_cols, tiles, codec="deflate")
+    assert np.array_equal(off, off1) and np.array_equal(pred, pred1) and np.array_equal(st, st1) and blob.tobytes() == blob1.tobytes()
+    vals, dst = m.decode_batch(n_rows, n_cols, blob, off, codec="deflate")
+    assert (dst == 0).all() and np.array_equal(vals, tiles)
+
+    # LSOP12, the reference's default (Deflate alternative on) and without it
+    for deflate in (True, False):
+        cap = nt * (int(lib().gf_lsop12_max_packing(n_rows, n_cols)) + 64)
+        b1, o1 = np.empty(cap, np.uint8), np.zeros(nt + 1, np.uint64)
+        ty1, s1 = np.zeros(nt, np.uint8), np.zeros(nt, np.int32)
+        rc = lib().gf_lsop12_encode_batch_i32(ctx.handle, 2, n_rows, n_cols, nt, _ptr(tiles), 1 if deflate else 0, _ptr(b1), cap, _ptr(o1),
+                                              _ptr(ty1), _ptr(s1))
+        assert rc == 0, rc
+        blob, off, ty, st = m.encode_batch(2, n_rows, n_cols, tiles, codec="lsop12", deflate_enabled=deflate)
+        assert np.array_equal(off, o1) and np.array_equal(ty, ty1) and np.array_equal(st, s1)
+        assert blob.tobytes() == b1[:int(o1[nt])].tobytes()
+        vals, dst = m.decode_batch(n_rows, n_cols, blob, off, codec="lsop12")
+        assert (dst == 0).all() and np.array_equal(vals, tiles)
+
+    # CodecFloat
+    f = (tiles.astype(np.float32) * np.float32(0.1)).reshape(nt, cells)
+    flt = gridfour_amd.CodecFloatHip(context=ctx, level=6)
+    packs = flt.encode_floats_batch(3, n_rows, n_cols, f)
+    blob, off, _, _ = m.encode_batch(3, n_rows, n_cols, f, codec="float", level=6)
+    assert [bytes(blob[int(off[t]):int(off[t + 1])]) for t in range(nt)] == packs
+    vals, dst = m.decode_batch(n_rows, n_cols, blob, off, codec="float")
+    assert (dst == 0).all() and np.array_equal(vals.view(np.uint32), f.view(np.uint32))
+    m.close()

@@ -42,3 +42,18 @@ def test_every_native_method_has_its_jni_function():
     assert not extra, extra
     wrong = {k: (natives[k], jni[k]) for k in natives if natives[k] != jni[k]}
     assert not wrong, wrong
+
+
+def test_every_standard_codec_has_an_adapter():
+    """The codecs a GvrsFileSpecification registers by default (GvrsFileSpecification.java:227-229: GvrsHuffman,
+    GvrsDeflate, GvrsFloat, and the LSOP / canonical-Huffman ones added by their modules) each have an adapter class
+    that implements both plug-in interfaces; the float one answers as CodecFloat does (CodecFloat.java:116-125, 461-468)."""
+    pkg_dir = os.path.join(JAVA, "org", "gridfour", "hip")
+    for cls in ("CodecHuffmanHip", "CodecDeflateHip", "CodecFloatHip", "CodecCanonHuffmanHip", "LsCodecHip"):
+        src = open(os.path.join(pkg_dir, cls + ".java")).read()
+        assert re.search(r"class\s+%s\s+implements\s+ICompressionEncoder\s*,\s*ICompressionDecoder" % cls, src), cls
+        assert re.search(r"public\s+%s\s*\(\s*\)" % cls, src), cls            # CodecHolder needs a public no-argument constructor
+    f = open(os.path.join(pkg_dir, "CodecFloatHip.java")).read()
+    assert re.search(r"implementsFloatingPointEncoding\(\)\s*\{\s*return true;", f)
+    assert re.search(r"implementsIntegerEncoding\(\)\s*\{\s*return false;", f)
+    assert "HipCodecNative.encodeFloats(" in f and "HipCodecNative.decodeFloats(" in f

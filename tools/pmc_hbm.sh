@@ -21,7 +21,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[re.sub(r"\(anonymous namespace\)::", "", row["Kernel_Name"]).split("(")[0]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
             res[k][c] = v[-1]          # last (warm) dispatch
-out = {"workload": "$WL", "unit": "bytes per launch", "correction": "FETCH_SIZE KB x1024 x2 (gfx950 half-count), WRITE_SIZE KB x1024", "kernels": {}}
+import os
+out = {"workload": "$WL", "commit": os.environ.get("GF_COMMIT", ""), "unit": "bytes per launch", "correction": "FETCH_SIZE KB x1024 x2 (gfx950 half-count), WRITE_SIZE KB x1024", "kernels": {}}
 for k, d in res.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         out["kernels"][k] = {"fetch_size_kb_raw": d["FETCH_SIZE"], "write_size_kb_raw": d["WRITE_SIZE"],
