@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -655,6 +656,35 @@ static bool zDeflate(const uint8_t *in, size_t n, int level, std::vector<uint8_t
     out.resize(cap);
     if (compress2(out.data(), &cap, in, (uLong)n, level) != Z_OK) return false;
     out.resize(cap);
+    return true;
+}
+
+// The same stream, given up as soon as it is longer than `limit` bytes (returns false then, as on a zlib error): the caller only
+// wants it if it is no longer than that.  Feeding the whole input with Z_FINISH and draining the output in pieces gives the bytes
+// of compress2 -- what comes out of deflate() does not depend on how much room each call is given.
+static bool zDeflateUpTo(const uint8_t *in, size_t n, int level, size_t limit, std::vector<uint8_t> &out)
+{
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit(&zs, level) != Z_OK) return false;
+    const size_t bound = (size_t)compressBound((uLong)n) + 64;
+    out.resize(bound);
+    zs.next_in = const_cast<Bytef *>(in);
+    zs.avail_in = (uInt)n;
+    size_t done = 0;
+    int rc = Z_OK;
+    while (rc == Z_OK) {
+        const size_t room = std::min<size_t>(bound - done, 2048);
+        zs.next_out = out.data() + done;
+        zs.avail_out = (uInt)room;
+        rc = deflate(&zs, Z_FINISH);
+        done += room - zs.avail_out;
+        if (done > limit && rc != Z_STREAM_END) { deflateEnd(&zs); return false; }
+        if (room == 0) break;
+    }
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || done > limit) return false;
+    out.resize(done);
     return true;
 }
 
@@ -1729,88 +1759,154 @@ gf_status gf_m32_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, in
 
 // CodecDeflate.encode :157-199 + compress :201-228 for a batch in host memory: the candidate M32 streams come from the GPU,
 // java.util.zip.Deflater(6) is the host's zlib, the strictly shortest packing wins (earlier predictor on ties).
+//
+// The cost is zlib's: three candidate streams per tile at level 6 (tools/codec_master_rate.py: 60 MB/s of M32 bytes per core,
+// 0.9 ms per 120x150 tile and core).  What can be done around it is done (round 3): the batch goes through in chunks, the GPU
+// stage of chunk k + 1 (upload, k_m32_streams, download) overlapping the host threads' zlib of chunk k; a candidate is given
+// up the moment its stream is longer than the shortest packing known for the tile -- the predictors' candidates among each
+// other (Triangle first: it is the shortest on terrain, the ties of :195 are kept by comparing against the right side), and
+// under gf_codec_master_encode_batch_i32 the packings of the list's other codecs (notLongerThan): a candidate that cannot win
+// needs no bytes.  Results are byte-identical to running every stream to its end.
+static gf_status deflateEncodeBatchHost(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
+                                        const uint32_t *notLongerThan,      // per tile or null: packings longer than this are of no use
+                                        std::vector<std::vector<uint8_t>> &packs, std::vector<uint8_t> &chosen, std::vector<int32_t> &st)
+{
+    GF_HIP(hipSetDevice(c->device));
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    const size_t sub = gf_m32_default_stride(nRows, nCols), maxSub = gf_m32_max_stream(nRows, nCols);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(nTiles, (size_t)(64u << 20) / (cells * 4)));
+    gf_status s;
+    if ((s = c->dValues.ensure(chunk * cells * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dM32.ensure(chunk * 3 * sub + 16)) != GF_OK) return s;
+    if ((s = c->dM32Len.ensure(chunk * 12 + 16)) != GF_OK) return s;
+    if ((s = c->dM32Models.ensure(chunk * 3 + 16)) != GF_OK) return s;
+    if ((s = c->dSeeds.ensure(chunk * 4 + 16)) != GF_OK) return s;
+    if ((s = c->dStatus.ensure(chunk * 4 + 16)) != GF_OK) return s;
+    packs.assign(nTiles, {});
+    chosen.assign(nTiles, 0);
+    st.assign(nTiles, GF_OK);
+    struct Stage {                                                       // what a chunk brings back from the GPU
+        std::unique_ptr<uint8_t[]> streams;
+        std::vector<uint8_t> models;
+        std::vector<uint32_t> lens, seeds;
+        std::vector<std::vector<uint8_t>> big;                           // tiles whose streams did not fit the default sub-slot
+        size_t t0 = 0, n = 0;
+    } stage[2];
+    for (Stage &g : stage) g.streams.reset(new uint8_t[chunk * 3 * sub]);
+    auto gpuStage = [&](Stage &g, size_t t0, size_t n) -> gf_status {
+        g.t0 = t0;
+        g.n = n;
+        g.models.resize(n * 3);
+        g.lens.resize(n * 3);
+        g.seeds.resize(n);
+        g.big.assign(n, {});
+        GF_HIP(hipMemcpyAsync(c->dValues.p, values + t0 * cells, n * cells * 4, hipMemcpyHostToDevice, c->stream));
+        gf_status r = gf_m32_encode_batch_i32_dev(c, c->stream, nRows, nCols, n, (const int32_t *)c->dValues.p, (uint8_t *)c->dM32.p, sub,
+                                                  (uint32_t *)c->dM32Len.p, (uint8_t *)c->dM32Models.p, (uint32_t *)c->dSeeds.p,
+                                                  (int32_t *)c->dStatus.p);
+        if (r != GF_OK) return r;
+        GF_HIP(hipMemcpyAsync(g.streams.get(), c->dM32.p, n * 3 * sub, hipMemcpyDeviceToHost, c->stream));
+        GF_HIP(hipMemcpyAsync(g.lens.data(), c->dM32Len.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+        GF_HIP(hipMemcpyAsync(g.models.data(), c->dM32Models.p, n * 3, hipMemcpyDeviceToHost, c->stream));
+        GF_HIP(hipMemcpyAsync(g.seeds.data(), c->dSeeds.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+        GF_HIP(hipMemcpyAsync(st.data() + t0, c->dStatus.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+        GF_HIP(hipStreamSynchronize(c->stream));
+        // tiles with a stream longer than the default sub-slot: once more, one at a time, into worst-case slots
+        for (size_t i = 0; i < n; i++) {
+            if (st[t0 + i] != GF_OVERFLOW) continue;
+            DevBuf slot, meta;
+            if ((r = slot.ensure(3 * maxSub)) != GF_OK) return r;
+            if ((r = meta.ensure(64)) != GF_OK) { slot.release(); return r; }
+            uint8_t *m = (uint8_t *)meta.p;
+            r = gf_m32_encode_batch_i32_dev(c, c->stream, nRows, nCols, 1, (const int32_t *)c->dValues.p + i * cells, (uint8_t *)slot.p,
+                                            maxSub, (uint32_t *)m, m + 16, (uint32_t *)(m + 32), (int32_t *)(m + 48));
+            g.big[i].resize(3 * maxSub);
+            hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+            if (r == GF_OK) {
+                e1 = hipMemcpyAsync(g.big[i].data(), slot.p, 3 * maxSub, hipMemcpyDeviceToHost, c->stream);
+                e2 = hipMemcpyAsync(&st[t0 + i], m + 48, 4, hipMemcpyDeviceToHost, c->stream);
+                e3 = hipStreamSynchronize(c->stream);
+            }
+            slot.release();
+            meta.release();
+            if (r != GF_OK) return r;
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return hipFail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3, "m32 overflow tile");
+        }
+        return GF_OK;
+    };
+    auto zlibStage = [&](const Stage &g) {
+        parallelFor(g.n, [&](size_t i) {
+            const size_t t = g.t0 + i;
+            if (st[t] != GF_OK) return;
+            const bool isBig = !g.big[i].empty();
+            const size_t stride = isBig ? maxSub : sub;
+            const uint8_t *base = isBig ? g.big[i].data() : g.streams.get() + i * 3 * sub;
+            // packing length of the candidate kept so far per predictor slot (0: none); the winner is the FIRST shortest in the
+            // order Differencing, Linear, Triangle (:195: a later one must be strictly shorter)
+            size_t have[3] = {0, 0, 0};
+            std::vector<uint8_t> z[3];
+            static const int order[3] = {2, 0, 1};                           // Triangle first, then the reference's order
+            for (int oi = 0; oi < 3; oi++) {
+                const int p = order[oi];
+                const uint32_t n = g.lens[i * 3 + p];
+                const int model = g.models[i * 3 + p];
+                if (model == 0 || n == 0) continue;                          // mCodeLength > 0 (:189)
+                // longest packing this candidate is still of use with: against an EARLIER slot it must be strictly shorter,
+                // against a LATER one no longer
+                size_t cap = notLongerThan ? (size_t)notLongerThan[t] : ~(size_t)0;
+                for (int q = 0; q < 3; q++)
+                    if (have[q]) cap = std::min(cap, q < p ? have[q] - 1 : have[q]);
+                if (cap < 11) continue;
+                const size_t limit = std::min<size_t>(cap - 10, (size_t)n + 118);   // Deflater wrote into byte[nM32 + 128] from offset 10 (:204-205)
+                if (!zDeflateUpTo(base + p * stride, n, 6, limit, z[p])) {
+                    // given up: longer than the limit.  The reference's buffer cuts a stream at nM32 + 118 bytes; a candidate that
+                    // long is kept at that length there -- run it to the end where that cut is the reason
+                    if (limit == (size_t)n + 118 && zDeflate(base + p * stride, n, 6, z[p])) z[p].resize(limit);
+                    else continue;
+                }
+                if (z[p].empty()) continue;
+                have[p] = z[p].size() + 10;
+            }
+            int win = -1;
+            for (int p = 0; p < 3; p++)
+                if (have[p] && (win < 0 || have[p] < have[win])) win = p;
+            if (win < 0) { st[t] = GF_DECLINED; return; }
+            std::vector<uint8_t> &pk = packs[t];
+            pk.resize(have[win]);
+            pk[0] = (uint8_t)codecIndex;
+            pk[1] = g.models[i * 3 + win];
+            putLE32(&pk[2], g.seeds[i]);
+            putLE32(&pk[6], g.lens[i * 3 + win]);
+            memcpy(&pk[10], z[win].data(), z[win].size());
+            chosen[t] = g.models[i * 3 + win];
+        });
+    };
+    // chunk k's zlib runs on the host's threads while this thread drives the GPU stage of chunk k + 1
+    std::thread worker;
+    gf_status result = GF_OK;
+    int cur = 0;
+    for (size_t t0 = 0; t0 < nTiles && result == GF_OK; t0 += chunk) {
+        const size_t n = std::min(chunk, nTiles - t0);
+        result = gpuStage(stage[cur], t0, n);
+        if (worker.joinable()) worker.join();
+        if (result != GF_OK) break;
+        Stage *g = &stage[cur];
+        worker = std::thread([&, g]() { zlibStage(*g); });
+        cur ^= 1;
+    }
+    if (worker.joinable()) worker.join();
+    return result;
+}
+
 gf_status gf_deflate_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
                                       uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *predictors, int32_t *status)
 {
     if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
-    GF_HIP(hipSetDevice(c->device));
-    const size_t cells = (size_t)nRows * (size_t)nCols;
-    size_t sub = gf_m32_default_stride(nRows, nCols);
-    gf_status s;
-    if ((s = c->dValues.ensure(nTiles * cells * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dM32.ensure(nTiles * 3 * sub + 16)) != GF_OK) return s;
-    if ((s = c->dM32Len.ensure(nTiles * 12 + 16)) != GF_OK) return s;
-    if ((s = c->dM32Models.ensure(nTiles * 3 + 16)) != GF_OK) return s;
-    if ((s = c->dSeeds.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    if ((s = c->dStatus.ensure(nTiles * 4 + 16)) != GF_OK) return s;
-    GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
-    s = gf_m32_encode_batch_i32_dev(c, c->stream, nRows, nCols, nTiles, (const int32_t *)c->dValues.p, (uint8_t *)c->dM32.p, sub,
-                                    (uint32_t *)c->dM32Len.p, (uint8_t *)c->dM32Models.p, (uint32_t *)c->dSeeds.p,
-                                    (int32_t *)c->dStatus.p);
+    std::vector<std::vector<uint8_t>> packs;
+    std::vector<uint8_t> chosen;
+    std::vector<int32_t> st;
+    gf_status s = deflateEncodeBatchHost(c, codecIndex, nRows, nCols, nTiles, values, nullptr, packs, chosen, st);
     if (s != GF_OK) return s;
-    std::vector<uint8_t> streams(nTiles * 3 * sub), models(nTiles * 3);
-    std::vector<uint32_t> lens(nTiles * 3), seeds(nTiles);
-    std::vector<int32_t> st(nTiles);
-    GF_HIP(hipMemcpyAsync(streams.data(), c->dM32.p, nTiles * 3 * sub, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipMemcpyAsync(lens.data(), c->dM32Len.p, nTiles * 12, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipMemcpyAsync(models.data(), c->dM32Models.p, nTiles * 3, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipMemcpyAsync(seeds.data(), c->dSeeds.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipMemcpyAsync(st.data(), c->dStatus.p, nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-    GF_HIP(hipStreamSynchronize(c->stream));
-
-    // tiles with a stream longer than the default sub-slot: once more, one at a time, into worst-case slots
-    std::vector<std::vector<uint8_t>> big(nTiles);
-    for (size_t t = 0; t < nTiles; t++) {
-        if (st[t] != GF_OVERFLOW) continue;
-        const size_t maxSub = gf_m32_max_stream(nRows, nCols);
-        DevBuf slot, meta;
-        if ((s = slot.ensure(3 * maxSub)) != GF_OK) return s;
-        if ((s = meta.ensure(64)) != GF_OK) { slot.release(); return s; }
-        uint8_t *m = (uint8_t *)meta.p;
-        s = gf_m32_encode_batch_i32_dev(c, c->stream, nRows, nCols, 1, (const int32_t *)c->dValues.p + t * cells, (uint8_t *)slot.p,
-                                        maxSub, (uint32_t *)m, m + 16, (uint32_t *)(m + 32), (int32_t *)(m + 48));
-        big[t].resize(3 * maxSub);
-        hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
-        if (s == GF_OK) {
-            e1 = hipMemcpyAsync(big[t].data(), slot.p, 3 * maxSub, hipMemcpyDeviceToHost, c->stream);
-            e2 = hipMemcpyAsync(&st[t], m + 48, 4, hipMemcpyDeviceToHost, c->stream);
-            e3 = hipStreamSynchronize(c->stream);
-        }
-        slot.release();
-        meta.release();
-        if (s != GF_OK) return s;
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return hipFail(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3, "m32 overflow tile");
-    }
-
-    std::vector<std::vector<uint8_t>> packs(nTiles);
-    std::vector<uint8_t> chosen(nTiles, 0);
-    parallelFor(nTiles, [&](size_t t) {
-        if (st[t] != GF_OK) return;
-        const bool isBig = !big[t].empty();
-        const size_t stride = isBig ? gf_m32_max_stream(nRows, nCols) : sub;
-        const uint8_t *base = isBig ? big[t].data() : streams.data() + t * 3 * sub;
-        std::vector<uint8_t> z;
-        for (int p = 0; p < 3; p++) {
-            const uint32_t n = lens[t * 3 + p];
-            const int model = models[t * 3 + p];
-            if (model == 0 || n == 0) continue;                          // mCodeLength > 0 (:189)
-            if (!zDeflate(base + p * stride, n, 6, z)) continue;
-            size_t dN = z.size();
-            if (dN > (size_t)n + 118) dN = (size_t)n + 118;             // Deflater wrote into byte[nM32 + 128] from offset 10 (:204-205)
-            if (dN == 0) continue;
-            if (packs[t].empty() || dN + 10 < packs[t].size()) {        // strictly shorter (:195)
-                std::vector<uint8_t> &pk = packs[t];
-                pk.resize(dN + 10);
-                pk[0] = (uint8_t)codecIndex;
-                pk[1] = (uint8_t)model;
-                putLE32(&pk[2], seeds[t]);
-                putLE32(&pk[6], n);
-                memcpy(&pk[10], z.data(), dN);
-                chosen[t] = (uint8_t)model;
-            }
-        }
-        if (packs[t].empty()) st[t] = GF_DECLINED;
-    });
     uint64_t total = 0;
     for (size_t t = 0; t < nTiles; t++) {
         offsets[t] = total;
@@ -1876,52 +1972,91 @@ gf_status gf_codec_master_encode_batch_i32(gf_context *c, const int *codecs, int
 {
     if (!c || !codecs || nCodecs < 1 || nCodecs > 255 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     const size_t cells = (size_t)nRows * (size_t)nCols;
-    std::vector<std::vector<uint8_t>> best(nTiles);
+    for (int k = 0; k < nCodecs; k++)
+        if (codecs[k] < GF_CODEC_NONE || codecs[k] > GF_CODEC_LSOP12) return GF_ERR_ARG;
+    // per codec of the list: its packings (Deflate: one vector per tile; the others: one blob + offsets) and statuses
+    struct Entry {
+        std::unique_ptr<uint8_t[]> blob;
+        std::vector<uint64_t> off;
+        std::vector<std::vector<uint8_t>> packs;
+        std::vector<int32_t> st;
+        bool ran = false;
+    };
+    std::vector<Entry> e(nCodecs);
+    auto lenOf = [&](int k, size_t t) -> size_t {
+        const Entry &x = e[k];
+        if (!x.ran || x.st[t] != GF_OK) return 0;
+        return codecs[k] == GF_CODEC_DEFLATE ? x.packs[t].size() : (size_t)(x.off[t + 1] - x.off[t]);
+    };
+    // The GPU codecs first, CodecDeflate last: its three zlib streams per tile are the expensive part of the list, and a stream
+    // that is already longer than what another codec of the list made of the tile cannot win (:161-164: the shortest packing
+    // wins, the earlier codec on ties) -- deflateEncodeBatchHost gives such candidates up early.
+    for (int pass = 0; pass < 2; pass++) {
+        for (int k = 0; k < nCodecs; k++) {
+            const int kind = codecs[k];
+            if (kind == GF_CODEC_NONE || (kind == GF_CODEC_DEFLATE) != (pass == 1)) continue;
+            Entry &x = e[k];
+            x.st.assign(nTiles, GF_OK);
+            gf_status s = GF_OK;
+            if (kind == GF_CODEC_DEFLATE) {
+                // what a Deflate packing may measure at most to be of use: strictly less than the codecs before it, no more than those behind
+                std::vector<uint32_t> bound(nTiles, 0xFFFFFFFFu);
+                for (size_t t = 0; t < nTiles; t++)
+                    for (int j = 0; j < nCodecs; j++) {
+                        const size_t len = j == k ? 0 : lenOf(j, t);
+                        if (len) bound[t] = (uint32_t)std::min<size_t>(bound[t], j < k ? len - 1 : len);
+                    }
+                std::vector<uint8_t> chosen;
+                s = deflateEncodeBatchHost(c, k, nRows, nCols, nTiles, values, bound.data(), x.packs, chosen, x.st);
+            } else {
+                x.off.assign(nTiles + 1, 0);
+                size_t cap = nTiles * (cells + 1024) + 64;                       // a byte per cell holds terrain packings; grown once if not
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    x.blob.reset(new uint8_t[cap]);
+                    switch (kind) {
+                    case GF_CODEC_HUFFMAN: s = gf_huffman_encode_batch_i32(c, k, nRows, nCols, nTiles, values, x.blob.get(), cap, x.off.data(), nullptr, x.st.data()); break;
+                    case GF_CODEC_CANON_HUFFMAN: s = gf_canon_encode_batch_i32(c, k, nRows, nCols, nTiles, values, x.blob.get(), cap, x.off.data(), nullptr, x.st.data()); break;
+                    default: s = gf_lsop12_encode_batch_i32(c, k, nRows, nCols, nTiles, values, 1, x.blob.get(), cap, x.off.data(), nullptr, x.st.data()); break;
+                    }
+                    if (s != GF_ERR_CAPACITY) break;
+                    cap = (size_t)x.off[nTiles] + 64;
+                }
+            }
+            if (s != GF_OK) return s;
+            x.ran = true;
+        }
+    }
+    // per tile the first shortest packing in list order; a tile no codec packed reports the first encoder error (the Java
+    // encoder threw) or "declined"
     std::vector<int32_t> bestSt(nTiles, GF_DECLINED);
     std::vector<uint8_t> used(nTiles, 0xff);
-    std::vector<uint8_t> tmp;
-    std::vector<uint64_t> off(nTiles + 1);
-    std::vector<int32_t> st(nTiles);
-    for (int k = 0; k < nCodecs; k++) {
-        const int kind = codecs[k];
-        if (kind == GF_CODEC_NONE) continue;
-        size_t cap = nTiles * (4 * cells + 1024) + 64;
-        gf_status s = GF_OK;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            tmp.resize(cap);
-            switch (kind) {
-            case GF_CODEC_HUFFMAN: s = gf_huffman_encode_batch_i32(c, k, nRows, nCols, nTiles, values, tmp.data(), cap, off.data(), nullptr, st.data()); break;
-            case GF_CODEC_DEFLATE: s = gf_deflate_encode_batch_i32(c, k, nRows, nCols, nTiles, values, tmp.data(), cap, off.data(), nullptr, st.data()); break;
-            case GF_CODEC_CANON_HUFFMAN: s = gf_canon_encode_batch_i32(c, k, nRows, nCols, nTiles, values, tmp.data(), cap, off.data(), nullptr, st.data()); break;
-            case GF_CODEC_LSOP12: s = gf_lsop12_encode_batch_i32(c, k, nRows, nCols, nTiles, values, 1, tmp.data(), cap, off.data(), nullptr, st.data()); break;
-            default: return GF_ERR_ARG;
-            }
-            if (s != GF_ERR_CAPACITY) break;
-            cap = (size_t)off[nTiles] + 64;
-        }
-        if (s != GF_OK) return s;
-        for (size_t t = 0; t < nTiles; t++) {
-            if (st[t] < 0) { if (bestSt[t] >= 0 && best[t].empty()) bestSt[t] = st[t]; continue; }   // the Java encoder threw
-            if (st[t] != GF_OK) continue;
-            const size_t len = (size_t)(off[t + 1] - off[t]);
-            if (best[t].empty() || len < best[t].size()) {                               // strictly shorter (:161-164)
-                best[t].assign(tmp.begin() + (ptrdiff_t)off[t], tmp.begin() + (ptrdiff_t)off[t + 1]);
+    uint64_t total = 0;
+    for (size_t t = 0; t < nTiles; t++) {
+        size_t bestLen = 0;
+        for (int k = 0; k < nCodecs; k++) {
+            if (!e[k].ran) continue;
+            const int32_t stK = e[k].st[t];
+            if (stK < 0) { if (used[t] == 0xff && bestSt[t] >= 0) bestSt[t] = stK; continue; }
+            const size_t len = lenOf(k, t);
+            if (len && (used[t] == 0xff || len < bestLen)) {                     // strictly shorter (:161-164)
+                bestLen = len;
                 used[t] = (uint8_t)k;
                 bestSt[t] = GF_OK;
             }
         }
-    }
-    uint64_t total = 0;
-    for (size_t t = 0; t < nTiles; t++) {
         offsets[t] = total;
-        if (bestSt[t] == GF_OK) total += best[t].size();
+        total += bestLen;
     }
     offsets[nTiles] = total;
     if (status) memcpy(status, bestSt.data(), nTiles * 4);
     if (codecUsed) memcpy(codecUsed, used.data(), nTiles);
     if (total > blobCap) return GF_ERR_CAPACITY;
-    for (size_t t = 0; t < nTiles; t++)
-        if (bestSt[t] == GF_OK) memcpy(blob + offsets[t], best[t].data(), best[t].size());
+    parallelFor(nTiles, [&](size_t t) {
+        if (bestSt[t] != GF_OK) return;
+        const int k = used[t];
+        const uint8_t *src = codecs[k] == GF_CODEC_DEFLATE ? e[k].packs[t].data() : e[k].blob.get() + e[k].off[t];
+        memcpy(blob + offsets[t], src, (size_t)(offsets[t + 1] - offsets[t]));
+    });
     return GF_OK;
 }
 

@@ -10,8 +10,8 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape,nt,tpr,seed", [((120, 150), 12960, 144, 2), ((200, 200), 4096, 432, 3)],
-                         ids=["etopo1_12960x120x150", "gebco_4096x200x200"])
+@pytest.mark.parametrize("shape,nt,tpr,seed", [((120, 150), 12960, 144, 2), ((200, 200), 4096, 432, 3), ((200, 200), 11664, 432, 3)],
+                         ids=["etopo1_12960x120x150", "gebco_4096x200x200", "gebco_shard_11664x200x200"])
 @pytest.mark.parametrize("codec", ["huffman", "canon"])
 def test_full_batch_properties(shape, nt, tpr, seed, codec):
     import gridfour_amd
@@ -108,3 +108,42 @@ def test_more_than_2_20_tiles_float_planes():
     planes = d_planes.download(np.uint8, nt * pstride).reshape(nt, pstride)
     for t in [0, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, nt - 1]:
         assert planes[t].tobytes() == bytes(oracle.float_planes_encode(n_rows, n_cols, vals[t].view(np.uint32))), t
+
+
+def test_whole_gebco_grid_through_one_context():
+    """BASELINE configs[3] at its full size on ONE GPU: the 93,312 tiles of the GEBCO_2023-shaped grid (14.9 GB of cells),
+    generated on the device in pieces, through gf_huffman_{encode,decode}_batch_i32 on host memory -- chunked, pipelined
+    staging inside the library, device memory bounded by the chunk.  Every status OK, every tile back bit for bit, the
+    offsets consistent, sampled packings equal to the oracle's (what tools/host_path_rate.py gebco_full times)."""
+    import gridfour_amd
+    from gridfour_amd import DeviceTileBatch, lib
+    from gridfour_amd.sharding import _ptr
+    n_rows, n_cols, nt, tpr = 200, 200, 93312, 432
+    cells = n_rows * n_cols
+    ctx = gridfour_amd.GvrsHipContext(0)
+    vals = np.empty((nt, cells), np.int32)
+    piece = 7776
+    for t0 in range(0, nt, piece):
+        n = min(piece, nt - t0)
+        b = DeviceTileBatch(ctx, n_rows, n_cols, n)
+        b.synth_dem(oracle.DEM_SEED + 3, tpr, tile0=t0)
+        ctx.synchronize()
+        vals[t0:t0 + n] = b.get_values()
+        b.free()
+    cap = nt * cells                                                      # a byte per cell: DEM packings are ~0.55
+    blob = np.empty(cap, np.uint8)
+    off = np.zeros(nt + 1, np.uint64)
+    pred = np.zeros(nt, np.uint8)
+    st = np.zeros(nt, np.int32)
+    assert lib().gf_huffman_encode_batch_i32(ctx.handle, 0, n_rows, n_cols, nt, _ptr(vals), _ptr(blob), cap, _ptr(off), _ptr(pred), _ptr(st)) == 0
+    assert (st == 0).all() and ((pred >= 1) & (pred <= 3)).all()
+    lengths = np.diff(off.astype(np.int64))
+    assert off[0] == 0 and (lengths > 10).all() and (lengths < 4 * cells).all()
+    for t in [0, 1, nt // 3, nt // 2, nt - 2, nt - 1]:
+        ref, used = oracle.codec_huffman_encode(0, n_rows, n_cols, vals[t])
+        assert used == pred[t] and blob[int(off[t]):int(off[t + 1])].tobytes() == ref, t
+    out = np.empty_like(vals)
+    assert lib().gf_huffman_decode_batch_i32(ctx.handle, n_rows, n_cols, nt, _ptr(blob), _ptr(off), _ptr(out), _ptr(st)) == 0
+    assert (st == 0).all()
+    for t0 in range(0, nt, piece):                                        # compared in pieces: no third 15 GB array
+        assert np.array_equal(out[t0:t0 + piece], vals[t0:t0 + piece]), t0
