@@ -440,6 +440,47 @@ def _cpu_baseline(args, vals, n_rows, n_cols, n_tiles):
     return res
 
 
+def _lsop_default_container(ctx_handle, vals, n_rows, n_cols, sample):
+    """LsEncoder12's DEFAULT configuration (lsop/LsEncoder12.java:78, 180-216: deflateEnabled = true -- the Deflate container is built
+    next to the canonical-Huffman one and the smaller is kept), which needs the host's zlib and therefore goes through the
+    host-memory entry points: gf_lsop12_{encode,decode}_batch_i32 with deflate_enabled = 1 on the first `sample` tiles,
+    PCIe-inclusive, checked against the oracle's default-configuration packings.  The device-resident line above times the
+    canonical container alone (deflate_enabled = 0)."""
+    import oracle
+    from gridfour_amd import lib
+    nt = min(sample, vals.shape[0])
+    v = np.ascontiguousarray(vals[:nt])
+    cells = v.shape[1]
+    cap = nt * (int(lib().gf_lsop12_max_packing(n_rows, n_cols)) + 64)
+    blob, off = np.empty(cap, np.uint8), np.zeros(nt + 1, np.uint64)
+    types, st = np.zeros(nt, np.uint8), np.zeros(nt, np.int32)
+    out = np.empty_like(v)
+    p = lambda a: a.ctypes.data_as(__import__("ctypes").c_void_p)
+    best = {}
+    for de in (1, 0):
+        b = [1e9, 1e9]
+        for i in range(2):
+            t0 = time.perf_counter()
+            rc = lib().gf_lsop12_encode_batch_i32(ctx_handle, 0, n_rows, n_cols, nt, p(v), de, p(blob), cap, p(off), p(types), p(st))
+            t1 = time.perf_counter()
+            assert rc == 0 and (st == 0).all()
+            rc = lib().gf_lsop12_decode_batch_i32(ctx_handle, n_rows, n_cols, nt, p(blob), p(off), p(out), p(st))
+            t2 = time.perf_counter()
+            assert rc == 0 and (st == 0).all() and np.array_equal(out, v)
+            b = [min(b[0], t1 - t0), min(b[1], t2 - t1)]
+        gb = v.nbytes / 1e9
+        rec = {"encode_GBps": round(gb / b[0], 3), "decode_GBps": round(gb / b[1], 3), "bytes_per_cell": round(int(off[nt]) / (nt * cells), 4),
+               "container_types": {int(a): int(n) for a, n in zip(*np.unique(types, return_counts=True))}}
+        if de:
+            ok = all(blob[int(off[t]):int(off[t + 1])].tobytes() == oracle.lsop12_encode(0, n_rows, n_cols, v[t], True)[0]
+                     for t in range(0, nt, max(1, nt // 16)))
+            rec["equals_oracle_packings"] = bool(ok)
+        best["deflate_enabled" if de else "deflate_disabled"] = rec
+    best["sample_tiles"] = nt
+    best["note"] = "host-memory entry points (PCIe-inclusive); deflate_enabled = the reference's default: zlib level 6 on the host's threads"
+    return best
+
+
 def _host_path(ctx_handle, vals, n_rows, n_cols):
     """The PCIe-inclusive rate of the host-memory entry points (pageable buffers in and out) on the same tiles; never the
     headline value, reported beside it."""
@@ -734,6 +775,8 @@ def main():
         "host_path": host_path,
     }
     out["roofline_issue"] = _issue_roofline(args.workload, dom_name, n_tiles, dom_ms)
+    if args.codec == "lsop" and vals0 is not None and args.cpu_sample_tiles != 0:
+        out["default_container"] = _lsop_default_container(ctxs[0].handle, vals0, n_rows, n_cols, 2048)
     if args.codec == "lsop":
         out["roofline_fp64"] = _lsop_fp64_roofline(ctxs[0], batches[0], n_rows, n_cols, n_tiles, max(3, min(steps, 10)))
     print(json.dumps(out))

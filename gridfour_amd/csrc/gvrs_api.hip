@@ -495,6 +495,7 @@ static gf_status lsopUnpackM32(gf_context *c, hipStream_t st, int nRows, int nCo
 }
 
 
+constexpr size_t LSOP_INFLATE_SCRATCH_BYTES = (size_t)384 << 20;   // LSOP12's Deflate containers (rare: see lsopUnpackM32Deflate)
 constexpr size_t INFLATE_SCRATCH_BYTES = (size_t)1 << 30;     // thousands of streams per launch: a stream is one serial chain
 
 // Second entropy pass of the LSOP12 decode with the Deflate containers inflated ON THE DEVICE (LsDecoder12.java:127-141):
@@ -507,7 +508,10 @@ static gf_status lsopUnpackM32Deflate(gf_context *c, hipStream_t st, int nRows, 
 {
     const size_t nInit = (size_t)4 * nRows + 2 * nCols - 9, nInt = (size_t)(nRows - 2) * (size_t)(nCols - 4);
     const size_t rawStride = roundUp(6 * (nInit + nInt) + 192, 16);
-    const size_t chunk = std::max<size_t>(1, std::min(nTiles, INFLATE_SCRATCH_BYTES / rawStride));
+    // The scratch of the Deflate containers: LSOP_INFLATE_SCRATCH_BYTES, not a share of HBM per tile of the batch -- the default
+    // encoder output is the canonical container and pays these gated launches for nothing (the full gigabyte of the CodecDeflate /
+    // CodecFloat paths made a gigabyte of every context -- read-ahead, gf_multi shards -- that ever decoded an LSOP tile)
+    const size_t chunk = std::max<size_t>(1, std::min(nTiles, LSOP_INFLATE_SCRATCH_BYTES / rawStride));
     gf_status s;
     if ((s = c->dInflOut.ensure(chunk * rawStride + 64)) != GF_OK) return s;
     if ((s = c->dInflate.ensure(chunk * sizeof(GfInflateStream))) != GF_OK) return s;
