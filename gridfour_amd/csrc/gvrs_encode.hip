@@ -657,7 +657,59 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 
         GF_STAMP(2);
         // ---------------- phase B: the three Huffman trees, one wave each ----------------
-        if (wave < 3 && P.model[wave] != 0) {
+        // Only the shortest packing is written (CodecHuffman.java:106-119), so a tree is built only for a predictor that can
+        // still win.  No prefix code spends fewer bits on a text than its zero-order entropy (Shannon), the header and the
+        // serialised tree are known from the number of distinct symbols: a LOWER BOUND of every candidate's packing comes
+        // from its histogram alone (a logarithm per symbol).  The candidate with the smallest bound builds its tree first;
+        // once its exact size is known the others build theirs only if their bound does not already lose against it (the
+        // earlier predictor wins ties, :107).  On terrain the Triangle residuals undercut the others by a tenth of the
+        // packing: two of the three trees -- a third of the kernel's instructions -- are not built.  (Fast kernel only.)
+        int firstP = -1;
+        if constexpr (FAST) {
+            if (wave < 3 && P.model[wave] != 0) {
+                const int p = wave;
+                double sumCLogC = 0.0;
+                uint32_t n = 0, N = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t cnt = enc_hist(P, p)[r * 64 + lane];
+                    n += cnt != 0;
+                    N += cnt;
+                    if (cnt > 1) sumCLogC += (double)cnt * (double)__log2f((float)cnt);
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    n += gf_lane_xor(n, d);
+                    N += gf_lane_xor(N, d);
+                    sumCLogC += __shfl_xor(sumCLogC, d, 64);
+                }
+                if (lane == 0) {
+                    // bits: 80 of header, the tree (n == 1: 17; else 8 + 10 n - 1), the text >= N log2 N - sum c log2 c, less a
+                    // margin for the single-precision logarithms (2^-22 relative on sums of at most N log2 N) and the cast
+                    double text = n > 1 ? (double)N * (double)__log2f((float)N) - sumCLogC : 0.0;
+                    text -= 64.0 + (double)N * (1.0 / 4096.0);
+                    const double bits = 80.0 + (n == 1 ? 17.0 : 8.0 + 10.0 * (double)n - 1.0) + (text > 0.0 ? text : 0.0);
+                    P.lbBytes[p] = (uint32_t)(bits * 0.125);                // floor: a lower bound stays one
+                }
+            }
+            __syncthreads();
+            for (int p = 0; p < 3; p++)
+                if (P.model[p] != 0 && (firstP < 0 || P.lbBytes[p] < P.lbBytes[firstP])) firstP = p;
+        }
+        for (int stage = 0; stage < (FAST ? 2 : 1); stage++) {
+        bool mine = wave < 3 && P.model[wave] != 0;
+        if constexpr (FAST) {
+            mine = mine && (stage == 0 ? wave == firstP : wave != firstP);
+            if (mine && stage == 1) {
+                const uint64_t firstBytes = (P.totalBits[firstP] + 7) >> 3;
+                const bool lost = wave < firstP ? (uint64_t)P.lbBytes[wave] > firstBytes : (uint64_t)P.lbBytes[wave] >= firstBytes;
+                if (lost) {
+                    if (lane == 0) P.model[wave] = 0;                         // not a candidate any more
+                    mine = false;
+                }
+            }
+        }
+        if (mine) {
             const int p = wave;
             EncTree<FAST> &T = S.tree[p];
             int n = 0;
@@ -787,6 +839,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
             }
         }
         __syncthreads();
+        }                                        // stage
         GF_STAMP(5);
 #ifdef GF_DIAG
         if (a.debug) {                           // dump of the on-chip state

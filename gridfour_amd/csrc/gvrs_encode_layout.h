@@ -32,6 +32,7 @@ struct EncPersist {
     uint32_t waveSum[GF_ENC_WAVES];
     unsigned long long sumStart;                // nulls predictor seed
     uint32_t nStart;
+    uint32_t lbBytes[3];                        // fast kernel: lower bound of a predictor's packing (header + tree + entropy of its text)
 };
 
 
