@@ -24,14 +24,17 @@
 
 namespace {
 
-constexpr int DEC_THREADS = 256;
+#ifndef GF_CD_THREADS
+#define GF_CD_THREADS 256
+#endif
+constexpr int DEC_THREADS = GF_CD_THREADS;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 
 #include "gvrs_decode_common.h"
 
 #include "gvrs_canon_decode_common.h"
 
-__global__ __launch_bounds__(DEC_THREADS, 4) void k_canon_decode(GfDecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_canon_decode(GfDecodeArgs a)
 {
     __shared__ CanonDec S;
 
@@ -283,7 +286,7 @@ uint32_t gf_canon_decode_lds_text(int nRows, int nCols)
     if (want > 96 * 1024) want = 96 * 1024;
     want = (want + 31) & ~(size_t)31;
     const size_t room = (CD_FIFTH - sizeof(CanonDec)) & ~(size_t)31;
-    if (want > room && room >= cells / 2 + 1024) want = room;
+    if (DEC_THREADS == 256 && want > room && room >= cells / 2 + 1024) want = room;   // (the 512-thread build: four workgroups of a quarter each)
     return (uint32_t)want;
 }
 
@@ -293,7 +296,7 @@ uint32_t gf_canon_decode_lds_stage(int nRows, int nCols)
     // than a half of the stream could use
     const size_t cells = (size_t)nRows * (size_t)nCols;
     const size_t base = sizeof(CanonDec) + gf_canon_decode_lds_text(nRows, nCols);
-    const size_t budget = base <= CD_FIFTH ? CD_FIFTH : CD_QUARTER - 512;
+    const size_t budget = DEC_THREADS == 256 && base <= CD_FIFTH ? CD_FIFTH : CD_QUARTER - 512;
     size_t room = budget > base ? budget - base : 0;
     const size_t want = cells > 2 * sizeof(((CanonDec *)nullptr)->qe) ? cells - 2 * sizeof(((CanonDec *)nullptr)->qe) : 0;
     if (room > want) room = want;

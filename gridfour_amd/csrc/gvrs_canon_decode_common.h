@@ -8,6 +8,7 @@ constexpr int CN_NULL = 256, CN_ESC1 = 257, CN_ESC2 = 258, CN_EOT = 259;
 constexpr int CN_META = 20;
 constexpr int CD_LUT_BITS = 11;
 constexpr int CD_MAXQ = 512;
+constexpr int CD_NCUR = CD_MAXQ / DEC_THREADS > 0 ? CD_MAXQ / DEC_THREADS : 1;   // subsequences per thread: tid, tid + DEC_THREADS, ...
 constexpr uint32_t CD_WARM = 128;
 constexpr uint32_t CD_END_EOT = 0xFFFFFFFFu;     // subsequence ended on the end-of-text symbol
 constexpr uint32_t CD_END_BAD = 0xFFFFFFFEu;     // subsequence ran into an invalid code / the end of the data
@@ -473,15 +474,15 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     __syncthreads();
     for (uint32_t round = 0; round < (uint32_t)CD_MAXQ; round++) {
         if (tid == 0) S.changed = 0;
-        uint32_t want[2];
+        uint32_t want[CD_NCUR];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < CD_NCUR; j++) {
             const uint32_t q = tid + j * DEC_THREADS;
             want[j] = (q >= 1 && q < Q) ? S.qe[q - 1] : 0u;
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < CD_NCUR; j++) {
             const uint32_t q = tid + j * DEC_THREADS;
             if (q >= 1 && q < Q && want[j] < CD_END_BAD && want[j] != S.qs[q]) {
                 const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
@@ -512,11 +513,11 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     int32_t tileStatus = GF_K_OK;
     if (qStar == 0xFFFFFFFFu || S.qe[qStar] != CD_END_EOT) tileStatus = GF_K_ERR_BOUNDS;   // no end-of-text: read past the data
     // exclusive prefix sum of the counts over the chain
-    uint32_t base[2], firstHalf = 0;              // firstHalf: values of subsequences 0..DEC_THREADS-1 (uniform)
+    uint32_t base[CD_NCUR], firstHalf = 0;              // firstHalf: values of subsequences 0..DEC_THREADS-1 (uniform)
     {
         uint32_t running = 0;
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < CD_NCUR; j++) {
             const uint32_t q = tid + j * DEC_THREADS;
             const uint32_t c = (q < Q && q <= qStar) ? S.qc[q] : 0u;
             uint32_t tot;
@@ -537,7 +538,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     CD_STAMP(4);                                  // counted
     // ---------------- phase 2: values to their sink ----------------
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < CD_NCUR; j++) {
         const uint32_t q = tid + j * DEC_THREADS;
         if constexpr (Sink::kStaged) sink.halfBase = j == 0 ? 0u : min(firstHalf, nValues);
         if (q < Q && q <= qStar) {

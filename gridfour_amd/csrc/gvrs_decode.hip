@@ -1091,11 +1091,12 @@ __device__ __forceinline__ void m32_mark_starts(DecShared &S, M32Ptr m32, uint32
     // (Round 2 walked the values from an anchor per DWORD, a divergent loop over a byte cursor that some lane of every wave was in:
     // with the value decode below about half of the kernel's instructions.)
     {
-        // 0x80 in every byte that may be an introducer
-        auto cand = [](uint32_t x) -> uint32_t {
-            const uint32_t p = x ^ 0x7F7F7F7Fu, q = x ^ 0x81818181u;
-            return (((p - 0x01010101u) & ~p) | ((q - 0x01010101u) & ~q)) & 0x80808080u;
-        };
+        // 0x80 in every byte that IS 0x7f or 0x81 -- exactly: the masks decide which bytes a value covers, so the usual
+        // (v - 0x01010101) & ~v test will not do here (its borrow marks a 0x01 byte above a zero byte: 0x80 behind 0x81, 0x7e
+        // behind 0x7f; tools/soak.py, seed 30031003, found the packing that has 0x81 0x80 behind a six-byte value).  Per byte:
+        // (v & 0x7f) + 0x7f carries into bit 7 iff the low seven bits are not all zero; or v: bit 7 set iff the byte is not zero
+        auto isZero = [](uint32_t v) -> uint32_t { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+        auto cand = [&](uint32_t x) -> uint32_t { return isZero(x ^ 0x7F7F7F7Fu) | isZero(x ^ 0x81818181u); };
         auto nib4 = [](uint32_t f) -> uint32_t {      // 0x80-per-byte flags -> 4 bits (the partial products do not collide)
             return (((f >> 7) * 0x00204081u) >> 21) & 0xfu;
         };

@@ -68,13 +68,13 @@ __device__ __forceinline__ uint32_t row_scan_segment(uint32_t x, uint32_t carry,
     return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 
-constexpr int ROW_BATCH = 8;                    // rows a wave keeps in flight in the row scans
+constexpr int ROW_BATCH = DEC_THREADS > 256 ? 4 : 8;   // rows a wave keeps in flight in the row scans (the builds with more waves per tile are held to 64 VGPRs)
 
 // Predictor inverse in place (residuals at their cells -> values), int32 wrap-around prefix sums:
 // PredictorModelDifferencing.java:145-167, PredictorModelLinear.java:66-101, PredictorModelTriangle.java:62-98,
 // PredictorModelDifferencingWithNulls.java:137-166 (and the decodeInt twins).  Whole workgroup; o[0] need not
 // hold the seed.  stamp (optional) receives a cycle stamp after the column-0 chain.
-constexpr int COL_BATCH = 16;                   // rows of a column in flight in the Triangle column sums
+constexpr int COL_BATCH = DEC_THREADS > 256 ? 8 : 16;  // rows of a column in flight in the Triangle column sums
 
 __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, uint32_t *o, uint32_t nR, uint32_t nC,
                                                      uint32_t *stamp)

@@ -321,3 +321,52 @@ def test_a_header_that_asks_for_a_preset_dictionary_inflates_nothing(codec):
             oracle.codec_deflate_decode(5, 10, pk)
         _, st = codec.decode_batch(5, 10, [pk, pk])
         assert st[0] == 1 and st[1] == 1
+
+
+def test_introducer_candidates_are_told_exactly():
+    """tools/soak.py, seed 30031003 (round 3): a damaged CodecDeflate packing whose M32 bytes hold a six-byte value that ends in
+    0x81 (five continuation bytes: CodecM32.java:335-356 returns the bits read so far) with the null code 0x80 right behind it.
+    The value starts are worked out from byte masks (m32_mark_starts); the usual zero-byte test marks a 0x01 above a zero byte
+    too, so 0x80 behind 0x81 looked like an introducer and swallowed the two values behind it.  The saved packing, and
+    hand-made streams with the byte pairs that test gets wrong (0x81 0x80, 0x7f 0x7e) at every alignment."""
+    import os
+    import zlib
+    import gridfour_amd
+    ctx = gridfour_amd.GvrsHipContext(0)
+    codec = gridfour_amd.CodecDeflateHip(context=ctx)
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak", "soak_r03_30031003_case1694.npz"))
+    nr, nc = map(int, d["shape"])
+    bad = bytes(d["bad"])
+    vals, st = codec.decode_batch(nr, nc, [bad])
+    assert st[0] == 0 and np.array_equal(vals[0], oracle.codec_deflate_decode(nr, nc, bad))
+    # hand-made: model 4 (every cell in the stream), values of one byte around the pattern
+    nr, nc = 9, 16
+    rng = np.random.default_rng(3)
+    packs = []
+    for pattern in (bytes([0x7f, 0x81, 0xaa, 0x81, 0xec, 0x81, 0x80, 0xe5, 0x21, 0xd0]),      # the soak's
+                    bytes([0x81, 0xff, 0xff, 0xff, 0xff, 0x7f, 0x7e, 0x05]),                  # ... 0x7f (a payload byte) 0x7e (a start)
+                    bytes([0x7f, 0x81, 0x81, 0x81, 0x81, 0x81, 0x80, 0x80, 0x01]),
+                    bytes([0x81, 0xff, 0xff, 0xff, 0xff, 0x81, 0x80, 0x7f, 0x7e])):
+        for shift in range(8):
+            body = bytearray(rng.integers(0, 100, nr * nc + 32).astype(np.uint8))             # plain one-byte values
+            at = 40 + shift
+            body[at:at + len(pattern)] = pattern
+            # as many bytes as the stream needs values for (the pattern shortens the count: pad generously, then cut by parsing)
+            m32 = bytes(body)
+            n_vals, i = 0, 0
+            while n_vals < nr * nc and i < len(m32):
+                b = m32[i]
+                i += 1
+                if b in (0x7f, 0x81):
+                    for _ in range(5):
+                        x = m32[i]
+                        i += 1
+                        if not x & 0x80:
+                            break
+                n_vals += 1
+            m32 = m32[:i]
+            packs.append(bytes([3, 4]) + (5).to_bytes(4, "little", signed=True) + len(m32).to_bytes(4, "little") + zlib.compress(m32, 6))
+    vals, st = codec.decode_batch(nr, nc, packs)
+    for k, pk in enumerate(packs):
+        ref = oracle.codec_deflate_decode(nr, nc, pk)
+        assert st[k] == 0 and np.array_equal(vals[k], ref), k
