@@ -69,6 +69,9 @@ def _compile_all(lib, extra, verbose):
             obj = os.path.join(tmp, "gvrs_decode_t%d.o" % threads)
             jobs.append(([hipcc] + FLAGS + extra + ["-DGF_DEC_THREADS=%d" % threads, "-DGF_DEC_VARIANT", "-DGF_DEC_MAXQ=%d" % threads, "-c",
                                                      os.path.join(CSRC, "gvrs_decode.hip"), "-o", obj], obj))
+        # ... and the canonical decoder with 512-thread workgroups
+        obj = os.path.join(tmp, "gvrs_canon_decode_t512.o")
+        jobs.append(([hipcc] + FLAGS + extra + ["-DGF_CD_THREADS=512", "-DGF_CD_VARIANT", "-c", os.path.join(CSRC, "gvrs_canon_decode.hip"), "-o", obj], obj))
         # a few compiles at a time: the translation units are independent
         width = max(1, min(4, (os.cpu_count() or 2) // 2))
         running = []

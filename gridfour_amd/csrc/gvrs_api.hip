@@ -402,10 +402,20 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         a.trees = (const uint32_t *)c->trees.p;
     }
     if (kind == KIND_CANON) {
+        // two builds as for the legacy decoder below: 256 threads (up to five workgroups per CU) or 512 (four = 32 waves)
         a.ldsM32Bytes = 0;
+        GfDecodeArgs b = a;
         a.ldsTextBytes = gf_canon_decode_lds_text(nRows, nCols);
         a.ldsStageBytes = gf_canon_decode_lds_stage(nRows, nCols);
-        GF_HIP(gf_launch_canon_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
+        b.ldsTextBytes = gf_canon_decode_lds_text_t512(nRows, nCols);
+        b.ldsStageBytes = gf_canon_decode_lds_stage_t512(nRows, nCols);
+        auto wgsPerCu = [](size_t lds, size_t cap) {
+            const size_t step = 1280, n = (160 * 1024) / ((lds + step - 1) / step * step);
+            return n < cap ? n : cap;
+        };
+        const size_t waves256 = 4 * wgsPerCu(gf_canon_decode_lds_per_wg(a), 8), waves512 = 8 * wgsPerCu(gf_canon_decode_lds_per_wg_t512(b), 4);
+        if (2 * waves512 >= 3 * waves256) GF_HIP(gf_launch_canon_decode_t512(b, stream ? (hipStream_t)stream : c->stream, grid));
+        else GF_HIP(gf_launch_canon_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     } else {
         a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);

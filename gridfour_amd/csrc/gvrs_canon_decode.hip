@@ -24,8 +24,17 @@
 
 namespace {
 
+// Compiled twice: as is (256 threads per workgroup, two subsequences per thread) and with -DGF_CD_THREADS=512 -DGF_CD_VARIANT
+// (one per thread, 64 VGPRs, four workgroups = all 32 wave slots of a CU where the LDS footprint allows four); the variant
+// object exports gf_launch_canon_decode_t512 and the LDS sizes of that build only.  decodeBatchDev weighs the two.
 #ifndef GF_CD_THREADS
 #define GF_CD_THREADS 256
+#endif
+#ifdef GF_CD_VARIANT
+#define gf_launch_canon_decode gf_launch_canon_decode_t512
+#define gf_canon_decode_lds_text gf_canon_decode_lds_text_t512
+#define gf_canon_decode_lds_stage gf_canon_decode_lds_stage_t512
+#define gf_canon_decode_lds_per_wg gf_canon_decode_lds_per_wg_t512
 #endif
 constexpr int DEC_THREADS = GF_CD_THREADS;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
@@ -102,7 +111,9 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
 #endif
         uint32_t endPos, nValues;
         const uint32_t *pre = a.trees ? a.trees + t * GF_CANON_REC_WORDS : nullptr;
-        const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias)
+        // the token table of the synchronisation pass: in the value stage behind the text, which is idle until phase 2
+        uint16_t *const tok = a.ldsStageBytes >= (sizeof(uint16_t) << CD_LUT_BITS) ? reinterpret_cast<uint16_t *>(stageB) : nullptr;
+        const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias, tok)
                                      : cd_decode_stream(S, TG, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias);
         if (st != GF_K_OK) {
             if (tid == 0) a.status[t] = st;
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
     }
 }
 
+#ifndef GF_CD_VARIANT
 // ---------------------------------------------------------------------------------------------------------------
 // Code-length pre-pass of the canonical decoder, ONE LANE PER TILE: LengthEncoder.readEncodedLengths (:197-236) and
 // CanonHuffTreeDecoder.decodeTree (:133-177) are a serial walk over some three hundred tokens; inside the decode kernel
@@ -268,6 +280,8 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
     rec[2] = nonZero;
 }
 
+#endif  // GF_CD_VARIANT
+
 }  // namespace
 
 // LDS per workgroup that still lets FIVE workgroups run on a CU.  Measured (k_lsop_unpack2, same tables): 32,240 bytes run
@@ -317,6 +331,10 @@ hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, uns
     return hipGetLastError();
 }
 
+// static + dynamic LDS of one workgroup of this build for the launch a describes
+size_t gf_canon_decode_lds_per_wg(const GfDecodeArgs &a) { return sizeof(CanonDec) + (size_t)a.ldsTextBytes + a.ldsStageBytes; }
+
+#ifndef GF_CD_VARIANT
 hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                          const uint32_t *lengths, uint32_t *recs, size_t nTiles, int lsopContainer,
                                          hipStream_t stream)
@@ -330,3 +348,4 @@ hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, 
                            slotStride, lengths, recs, nTiles, lsopContainer);
     return hipGetLastError();
 }
+#endif  // GF_CD_VARIANT

@@ -3,6 +3,8 @@
 // gvrs_decode_common.h.  See gvrs_canon_decode.hip for the phases.
 #pragma once
 
+#include <type_traits>
+
 constexpr int CN_SYMS = 260;
 constexpr int CN_NULL = 256, CN_ESC1 = 257, CN_ESC2 = 258, CN_EOT = 259;
 constexpr int CN_META = 20;
@@ -218,6 +220,60 @@ __device__ __forceinline__ void cd_run(const CanonDec &S, const Text &T, CdCur<T
     *cntOut = cnt;
 }
 
+// ---- token table of the synchronisation pass (round 3) ----
+// Pass 1 only needs to know where tokens start and how many VALUES start on the way (a value = a symbol 0..256; the escapes
+// behind it, with their raw bits, and the spare symbol 260 belong to it).  Over the CD_LUT_BITS-bit window at a token start the
+// table gives: nb = bits of ALL the tokens whose CODE lies inside the window, raw bits of escapes included (so nb may reach
+// past the window), ns = values among them; l1 / c1 = the same for the first token alone; CD_TOK_STOP: the first token is the
+// end-of-text symbol, longer than the window or no code at all -- the caller takes that one through cd_entry_of.
+// 16 bits: nb (5) | ns << 5 (4) | l1 << 9 (5) | c1 << 14 | stop << 15.
+constexpr uint32_t CD_TOK_STOP = 0x8000u;
+__device__ __forceinline__ void cd_build_tokens(const CanonDec &S, uint16_t *tok)
+{
+    for (uint32_t x = threadIdx.x; x < (1u << CD_LUT_BITS); x += DEC_THREADS) {
+        uint32_t pos = 0, ns = 0, l1 = 0, c1 = 0, v = CD_TOK_STOP;
+        while (pos < (uint32_t)CD_LUT_BITS) {
+            const uint32_t e = S.lut[x >> pos];                     // the bits behind the tokens so far, zero-extended
+            const uint32_t cl = cd_e_len(e), sym = cd_e_sym(e);
+            if (!e || pos + cl > (uint32_t)CD_LUT_BITS || sym == (uint32_t)CN_EOT) break;   // not decided by the window's bits / the end
+            const uint32_t bits = cl + cd_e_extra(e);
+            if (pos == 0) { l1 = bits; c1 = sym <= (uint32_t)CN_NULL ? 1u : 0u; }
+            ns += sym <= (uint32_t)CN_NULL ? 1u : 0u;
+            pos += bits;
+        }
+        if (l1) v = min(pos, 31u) | (ns << 5) | (l1 << 9) | (c1 << 14);
+        tok[x] = (uint16_t)v;
+    }
+}
+
+// cd_run with the token table: same end, count and end-of-text position.  a = bit position in the LDS text.
+__device__ __forceinline__ void cd_run_tok(const CanonDec &S, const uint16_t *tok, uint32_t a, uint32_t bound, uint32_t endBit,
+                                           uint32_t *endOut, uint32_t *cntOut, uint32_t *eotEnd)
+{
+    const uint32_t border = min(bound, endBit);                     // no token of a group may start at or behind it
+    uint32_t cnt = 0, end;
+    for (;;) {
+        if (a >= bound) { end = a; break; }
+        if (a >= endBit) { end = CD_END_BAD; break; }
+        const uint32_t i = a >> 5;
+        const uint32_t w = __builtin_amdgcn_alignbit(cdLdsText[i + 1u], cdLdsText[i], a);
+        const uint32_t t = tok[w & ((1u << CD_LUT_BITS) - 1u)];
+        if (t & CD_TOK_STOP) {
+            const CdTok tk = cd_token_from(cd_entry_of(S, w), w);
+            if (tk.sym == 0xFFFFu) { end = CD_END_BAD; break; }
+            if (tk.sym == (uint32_t)CN_EOT) { end = CD_END_EOT; *eotEnd = a + tk.bits; break; }
+            cnt += tk.sym <= (uint32_t)CN_NULL ? 1u : 0u;
+            a += tk.bits;
+            continue;
+        }
+        const bool single = a + (uint32_t)CD_LUT_BITS > border;
+        cnt += single ? (t >> 14) & 1u : (t >> 5) & 15u;
+        a += single ? (t >> 9) & 31u : t & 31u;
+    }
+    *endOut = end;
+    *cntOut = cnt;
+}
+
 // value sinks of cd_decode_stream: one(k, v) and quad(k0, four values), k0 a multiple of 4
 struct CdArraySink {                      // value k -> dst[k], k < n
     int32_t *dst;
@@ -295,8 +351,9 @@ template <class Text, class Sink>
 __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, uint32_t startBit, uint32_t endBit,
                                                     uint32_t maxValues, uint32_t fillTo, Sink sink, uint32_t *endPos,
                                                     uint32_t *nValuesOut, uint32_t *stamps = nullptr,
-                                                    const uint32_t *pre = nullptr, uint32_t preBase = 0)
+                                                    const uint32_t *pre = nullptr, uint32_t preBase = 0, uint16_t *tok = nullptr)
 {
+    // tok: 4 KB of LDS for the token table of the synchronisation pass (LDS text only), or null: the cursor walk
 #define CD_STAMP(i)                                                                        \
     do {                                                                                   \
         if (stamps && threadIdx.x == 0) stamps[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
@@ -441,6 +498,12 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
         }
     }
     __syncthreads();
+    constexpr bool kLdsText = std::is_same<Text, CdTextLds>::value;
+    if (!kLdsText) tok = nullptr;
+    if (tok) {
+        cd_build_tokens(S, tok);
+        __syncthreads();
+    }
 
     CD_STAMP(2);                                  // tables + LUT done
     // ---------------- phase 1: synchronise the subsequences, count their values ----------------
@@ -448,6 +511,32 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     const uint32_t span = endBit > T0 ? endBit - T0 : 1u;
     const uint32_t unit = max(128u, ((span + CD_MAXQ - 1) / CD_MAXQ + 31u) & ~31u);
     const uint32_t Q = (span + unit - 1) / unit;
+    if (tok) {
+        for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
+            const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
+            uint32_t a = Bq;
+            if (q > 0) {                                        // warm-up: walk in from 128 bits before the boundary
+                a = Bq - T0 > CD_WARM ? Bq - CD_WARM : T0;
+                while (a < Bq) {
+                    const uint32_t i = a >> 5;
+                    const uint32_t w = __builtin_amdgcn_alignbit(cdLdsText[i + 1u], cdLdsText[i], a);
+                    const uint32_t t = tok[w & ((1u << CD_LUT_BITS) - 1u)];
+                    if (t & CD_TOK_STOP) {
+                        const CdTok tk = cd_token_from(cd_entry_of(S, w), w);
+                        if (tk.sym == 0xFFFFu || tk.sym == (uint32_t)CN_EOT) { a = Bq; break; }
+                        a += tk.bits;
+                        continue;
+                    }
+                    a += a + (uint32_t)CD_LUT_BITS > Bq ? (t >> 9) & 31u : t & 31u;   // one token at a time close to the boundary
+                }
+            }
+            uint32_t e, c;
+            cd_run_tok(S, tok, a, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+            S.qs[q] = a;
+            S.qe[q] = e;
+            S.qc[q] = c;
+        }
+    } else
     for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
         const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
         CdCur<Text> cur;
@@ -489,6 +578,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
                 uint32_t e, c;
                 // a value's escapes may carry the previous subsequence past this one's end: then it is empty
                 if (want[j] >= Bn && Bn != endBit) { e = want[j]; c = 0; }
+                else if (tok) cd_run_tok(S, tok, want[j], Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
                 else {
                     CdCur<Text> cur;
                     cur.seek(T, want[j]);

@@ -175,6 +175,12 @@ hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
 size_t gf_canon_pack_rec_words();      // words per tile of GfEncodeArgs::packRecs for the canonical encoder
 hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 uint32_t gf_canon_decode_lds_text(int nRows, int nCols);
+// the 512-thread build of the canonical decoder (gvrs_canon_decode.hip compiled with -DGF_CD_THREADS=512 -DGF_CD_VARIANT)
+hipError_t gf_launch_canon_decode_t512(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
+uint32_t gf_canon_decode_lds_text_t512(int nRows, int nCols);
+uint32_t gf_canon_decode_lds_stage_t512(int nRows, int nCols);
+size_t gf_canon_decode_lds_per_wg(const GfDecodeArgs &a);
+size_t gf_canon_decode_lds_per_wg_t512(const GfDecodeArgs &a);
 uint32_t gf_lsop_unpack_lds_text(int nRows, int nCols);      // the same for k_lsop_unpack2 (trimmed where that gains a workgroup per CU)
 uint32_t gf_canon_decode_lds_stage(int nRows, int nCols);
 

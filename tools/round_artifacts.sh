@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the judged artifacts of a round on the GPU box: full GPU test suite, smoke, bench lines of every codec,
 # rocprofv3 kernel statistics of the default bench command, HBM traffic (PMC passes).
-# usage: tools/round_artifacts.sh <tag>        (writes gpurun_out/<tag>/)
+# usage: GF_COMMIT=<hash> tools/round_artifacts.sh <tag>        (writes gpurun_out/<tag>/; the hash goes into the replayed PMC files)
 TAG=${1:-r01_vX}
 OUT=gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -9,10 +9,18 @@ mkdir -p $OUT
 timeout 1200 python3 -m pytest tests -m gpu -q -rs > $OUT/pytest_gpu.txt 2>&1; tail -5 $OUT/pytest_gpu.txt
 timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
 # HBM traffic first (shipping library, all three integer codecs): the bench lines below replay it
-bash tools/pmc_hbm.sh $OUT/hbm etopo1 "huffman canon lsop" > $OUT/pmc_hbm.txt 2>&1
+GF_COMMIT=$GF_COMMIT bash tools/pmc_hbm.sh $OUT/hbm etopo1 "huffman canon lsop" > $OUT/pmc_hbm.txt 2>&1
 cp $OUT/hbm/hbm_traffic.json $OUT/hbm_traffic.json 2>/dev/null && cp $OUT/hbm_traffic.json profiles/hbm_traffic.json
 rm -rf $OUT/hbm/FETCH_SIZE $OUT/hbm/WRITE_SIZE
+# instruction counts of the shipping kernels (bench.py's roofline_issue replays them), and why the fraction is what it is
+GF_COMMIT=$GF_COMMIT bash tools/pmc_issue.sh $OUT/issue_counts.json etopo1 "huffman canon lsop" > $OUT/pmc_issue.txt 2>&1
+cp $OUT/issue_counts.json profiles/issue_counts.json 2>/dev/null
+bash tools/pmc_why.sh $OUT both > $OUT/pmc_why.log 2>&1
+bash tools/pmc_phases_dec.sh > $OUT/pmc_phases_dec.txt 2>&1
+[ -x tools/bin/valu_rate ] && tools/bin/valu_rate > $OUT/valu_rate.txt 2>&1
 timeout 600 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench.json
+timeout 600 python3 bench.py --workload etopo1_nulls --cpu-sample-tiles 0 2>/dev/null | tail -1 > $OUT/bench_etopo1_nulls.json
+timeout 900 python3 tools/codec_master_rate.py 2>/dev/null | tail -1 > $OUT/codec_master_rate.json
 timeout 900 python3 tools/host_path_rate.py etopo1 2>/dev/null | tail -1 > $OUT/host_path_etopo1.json
 timeout 900 python3 tools/host_path_rate.py etopo1 2 2>/dev/null | tail -1 > $OUT/host_path_etopo1_multi2.json
 timeout 900 python3 tools/host_path_rate.py gebco_full 2>/dev/null | tail -1 > $OUT/host_path_gebco_full.json
@@ -26,6 +34,8 @@ timeout 600 python3 bench.py --codec float --workload float256 2>/dev/null | tai
 timeout 900 python3 bench.py --codec lsop --workload float256_lsop 2>/dev/null | tail -1 > $OUT/bench_float256_lsop.json
 timeout 300 python3 tools/lsop_recon_time.py 2>/dev/null | tail -1 > $OUT/lsop_kernels_etopo1.json
 timeout 300 python3 tools/lsop_recon_time.py 256 256 4096 2>/dev/null | tail -1 > $OUT/lsop_kernels_256x256.json
+rm -rf $OUT/profn; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profn -- python3 bench.py --workload etopo1_nulls --cpu-sample-tiles 0 > /dev/null 2>> $OUT/rocprof.log
+f=$(find $OUT/profn -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_etopo1_nulls.csv; rm -rf $OUT/profn
 for c in "" canon lsop; do
   rm -rf $OUT/prof$c
   if [ -z "$c" ]; then
