@@ -2411,30 +2411,14 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     const uint8_t *__restrict__ pk = blob + off;
     // the walk sees what parse_tree_wave sees: the packing's bytes, zero beyond its end and beyond the staged head
     const uint32_t visible = min(len, (uint32_t)(HEAD_WORDS * 4));
-    auto ldGlobal = [&](uint32_t i) -> uint32_t {            // bytes i .. i+3 of the packing, little-endian
+    // (staging a tile's serialised tree in LDS first -- all loads in flight, the walk reading from there -- was tried in rounds
+    // 2 and 3 and changes nothing: 0.08 ms either way, the walk is bound by its dependent instruction chain at one wave per CU)
+    auto ld32 = [&](uint32_t i) -> uint32_t {                // bytes i .. i+3 of the packing, little-endian
         if (i + 4u <= visible) return reinterpret_cast<const PackedWord *>(pk + i)->v;
         uint32_t w = 0;
         for (uint32_t k = 0; k < 4; k++)
             if (i + k < visible) w |= (uint32_t)pk[i + k] << (8u * k);
         return w;
-    };
-    // A lane per tile reads its tree a dword at a time as the walk consumes it: 80-odd DEPENDENT global loads per tile, a
-    // microsecond each -- the whole 0.07 ms of the kernel on the bench batch.  So every lane first brings its serialised tree
-    // (bytes 10 .. 351 of the packing at most) into a stretch of LDS of its own with all loads in flight together (odd
-    // stride: the lanes' words fall into different banks), and the walk reads from there.
-    constexpr uint32_t TREE_WORDS = (HEAD_WORDS * 4 - 10 + 3) / 4, TREE_STRIDE = TREE_WORDS | 1u;
-    __shared__ uint32_t stage[perWave == 1 ? 1 : 64 * TREE_STRIDE];
-    if constexpr (perWave != 1) {
-        uint32_t *mine = stage + threadIdx.x * TREE_STRIDE;
-#pragma unroll 8
-        for (uint32_t j = 0; j < TREE_WORDS; j++) mine[j] = 10u + 4u * j < visible ? ldGlobal(10u + 4u * j) : 0u;
-    }
-    auto ld32 = [&](uint32_t i) -> uint32_t {                // i = 10 + 4 j
-        if constexpr (perWave == 1) return ldGlobal(i);
-        else {
-            const uint32_t j = (i - 10u) >> 2;
-            return j < TREE_WORDS ? stage[threadIdx.x * TREE_STRIDE + j] : 0u;
-        }
     };
     uint64_t buf = ((uint64_t)ld32(14) << 32) | ld32(10);    // packing bit 80 = byte 10
     uint32_t have = 64, next = 18, bp = 80;
