@@ -12,7 +12,10 @@
 
 namespace {
 
-constexpr int DEC_THREADS = 256;
+// 512 threads, one subsequence of a stream per thread, 64 VGPRs (round 3): four workgroups = all 32 wave slots of a CU where the
+// LDS footprint allows four (18.5 KB of tables + the text + 4 KB of token table: ETOPO1-shaped tiles 37 KB); with 256 threads
+// the kernel ran five workgroups = 20 waves per CU
+constexpr int DEC_THREADS = 512;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 
 #include "gvrs_decode_common.h"
@@ -34,7 +37,7 @@ struct GfLsopUnpackArgs {
     const uint32_t *pre;       // code-length records of the first stream (k_canon_parse_lengths), or null
 };
 
-__global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArgs a)
+__global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArgs a)
 {
     __shared__ CanonDec S;
 
@@ -84,11 +87,12 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack2(GfLsopUnpackArg
         uint32_t pos = bias + hdr * 8u, nv;
         const CdArraySink sink0{res, nInit};
         const uint32_t *pre = a.pre ? a.pre + t * GF_CANON_REC_WORDS : nullptr;
-        int32_t st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias)
+        uint16_t *const tok = reinterpret_cast<uint16_t *>(cdLdsText + capWords);      // token table of the synchronisation passes
+        int32_t st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias, tok)
                                : cd_decode_stream(S, TG, pos, endBit, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias);
         if (st == GF_K_OK) {
             const CdArraySink sink1{res + nInit, nInt};
-            st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv)
+            st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv, nullptr, nullptr, 0, tok)
                            : cd_decode_stream(S, TG, pos, endBit, nInt, nInt, sink1, &pos, &nv);
         }
         if (tid == 0) a.status[t] = st;
@@ -109,11 +113,11 @@ uint32_t gf_lsop_unpack_lds_text(int nRows, int nCols)
     size_t want = cells - cells / 4 + 1024;
     if (want > 96 * 1024) want = 96 * 1024;
     want = (want + 31) & ~(size_t)31;
-    // measured on the bench batch: 32,240 bytes per workgroup still run four to a CU (3.73 ms per decode), 31,744 and less
-    // five (3.38 ms) -- LDS is handed out in steps coarser than the 512 bytes assumed at first (1,280 fits both findings)
-    const size_t fifth = 31 * 1024;
-    if (fifth > sizeof(CanonDec)) {
-        const size_t room = (fifth - sizeof(CanonDec)) & ~(size_t)31;
+    // round 3 (512 threads): a quarter of the CU's LDS per workgroup is the tier to stay in -- tables + text + the 4 KB token table
+    // <= 40,448 bytes where half a byte per cell + 1 KB of text still fit (ETOPO1-shaped tiles: 37 KB, nothing to trim)
+    const size_t quarter = 40 * 1024 - 512, fixed = sizeof(CanonDec) + (sizeof(uint16_t) << CD_LUT_BITS);
+    if (quarter > fixed) {
+        const size_t room = (quarter - fixed) & ~(size_t)31;
         if (room < want && room >= cells / 2 + 1024) want = room;
     }
     return (uint32_t)want;
@@ -129,10 +133,10 @@ hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const u
                        ldsTextBytes, pre};
     static GfDynLdsOptIn opt;
     {
-        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_unpack2, ldsTextBytes, opt);
+        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_unpack2, ldsTextBytes + (sizeof(uint16_t) << CD_LUT_BITS), opt);
         if (e != hipSuccess) return e;
     }
     (void)grid;
-    hipLaunchKernelGGL(k_lsop_unpack2, gf_tile_grid(nTiles), dim3(DEC_THREADS), ldsTextBytes, stream, a);
+    hipLaunchKernelGGL(k_lsop_unpack2, gf_tile_grid(nTiles), dim3(DEC_THREADS), ldsTextBytes + (sizeof(uint16_t) << CD_LUT_BITS), stream, a);
     return hipGetLastError();
 }
