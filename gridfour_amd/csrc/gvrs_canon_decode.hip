@@ -53,9 +53,13 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
     const uint32_t capWords = a.ldsTextBytes >> 2;
     // the byte stage of phase 2 (CdCellSink): the sync arrays qe / qc are dead by then, the rest sits behind the text copy
-    uint8_t *const stageA = reinterpret_cast<uint8_t *>(S.qe);
+    // (one subsequence per thread: every thread has its start in a register before the first value is staged, so all four
+    // sync arrays serve as stage; two per thread: the starts of the second half are still needed, qe / qc only)
+    uint8_t *const stageA = reinterpret_cast<uint8_t *>(CD_NCUR == 1 ? S.qs : S.qe);
     uint8_t *const stageB = reinterpret_cast<uint8_t *>(cdLdsText + capWords);
-    const uint32_t stageCapA = (uint32_t)(2 * sizeof(S.qe)), stageCap = stageCapA + a.ldsStageBytes;
+    const uint32_t stageCapA = (uint32_t)((CD_NCUR == 1 ? 4 : 2) * sizeof(S.qe)), stageCap = stageCapA + a.ldsStageBytes;
+    static_assert(offsetof(CanonDec, qe) == offsetof(CanonDec, qs) + sizeof(S.qs) && offsetof(CanonDec, qx) == offsetof(CanonDec, qc) + sizeof(S.qc),
+                  "qs .. qx form one stretch of LDS");
     static_assert(offsetof(CanonDec, qc) == offsetof(CanonDec, qe) + sizeof(S.qe), "qe and qc form one stretch of LDS");
 
     GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
@@ -312,7 +316,8 @@ uint32_t gf_canon_decode_lds_stage(int nRows, int nCols)
     const size_t base = sizeof(CanonDec) + gf_canon_decode_lds_text(nRows, nCols);
     const size_t budget = DEC_THREADS == 256 && base <= CD_FIFTH ? CD_FIFTH : CD_QUARTER - 512;
     size_t room = budget > base ? budget - base : 0;
-    const size_t want = cells > 2 * sizeof(((CanonDec *)nullptr)->qe) ? cells - 2 * sizeof(((CanonDec *)nullptr)->qe) : 0;
+    const size_t inArrays = (DEC_THREADS == 256 ? 2 : 4) * sizeof(((CanonDec *)nullptr)->qe);      // the part of the stage over the sync arrays
+    const size_t want = cells > inArrays ? cells - inArrays : 0;
     if (room > want) room = want;
     return (uint32_t)(room & ~(size_t)31);
 }

@@ -561,38 +561,51 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
         S.qc[q] = c;
     }
     __syncthreads();
-    for (uint32_t round = 0; round < (uint32_t)CD_MAXQ; round++) {
-        if (tid == 0) S.changed = 0;
-        uint32_t want[CD_NCUR];
+    // Fix-up rounds: a subsequence whose start differs from its predecessor's end is decoded again from that end.  There are a
+    // handful per tile, so they are LISTED (with the end they start from, as it stood when the round began) and dealt out to
+    // the first lanes of wave 0 -- a wave that owned one of them used to run a whole pass for it while every other wave waited
+    // at the barrier all the same.  The list (64 entries; what does not fit shows up again next round) lies over the meta
+    // tables of phase 0.
+    {
+        constexpr uint32_t LIST_CAP = 64;
+        uint32_t *listW = reinterpret_cast<uint32_t *>(S.metaLut);                    // 64 x 4 bytes
+        uint16_t *listQ = reinterpret_cast<uint16_t *>(S.metaLut) + 2 * LIST_CAP;     // 64 x 2 bytes behind them
+        static_assert(sizeof(S.metaLut) >= LIST_CAP * 6, "redo list does not fit over metaLut");
+        for (uint32_t round = 0; round < (uint32_t)CD_MAXQ * 8u; round++) {
+            if (tid == 0) S.changed = 0;
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < CD_NCUR; j++) {
-            const uint32_t q = tid + j * DEC_THREADS;
-            want[j] = (q >= 1 && q < Q) ? S.qe[q - 1] : 0u;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < CD_NCUR; j++) {
-            const uint32_t q = tid + j * DEC_THREADS;
-            if (q >= 1 && q < Q && want[j] < CD_END_BAD && want[j] != S.qs[q]) {
+            for (int j = 0; j < CD_NCUR; j++) {
+                const uint32_t q = tid + j * DEC_THREADS;
+                if (q >= 1 && q < Q) {
+                    const uint32_t want = S.qe[q - 1];
+                    if (want < CD_END_BAD && want != S.qs[q]) {
+                        const uint32_t slot = atomicAdd(&S.changed, 1u);
+                        if (slot < LIST_CAP) { listW[slot] = want; listQ[slot] = (uint16_t)q; }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nList = min(S.changed, LIST_CAP);
+            if (nList == 0) break;
+            if ((uint32_t)tid < nList) {
+                const uint32_t q = listQ[tid], want = listW[tid];
                 const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
                 uint32_t e, c;
                 // a value's escapes may carry the previous subsequence past this one's end: then it is empty
-                if (want[j] >= Bn && Bn != endBit) { e = want[j]; c = 0; }
-                else if (tok) cd_run_tok(S, tok, want[j], Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+                if (want >= Bn && Bn != endBit) { e = want; c = 0; }
+                else if (tok) cd_run_tok(S, tok, want, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
                 else {
                     CdCur<Text> cur;
-                    cur.seek(T, want[j]);
+                    cur.seek(T, want);
                     cd_run(S, T, cur, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
                 }
-                S.qs[q] = want[j];
+                S.qs[q] = want;
                 S.qe[q] = e;
                 S.qc[q] = c;
-                S.changed = 1;
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (!S.changed) break;
-        __syncthreads();
     }
     CD_STAMP(3);                                  // synchronised
     // the true chain ends at the first subsequence that met the end-of-text symbol (or an error)
@@ -627,6 +640,13 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
 
     CD_STAMP(4);                                  // counted
     // ---------------- phase 2: values to their sink ----------------
+    // (a staged sink may lie over the sync arrays: with one subsequence per thread over all four of them -- what phase 2 needs
+    // of them goes into registers first)
+    const uint32_t eotEnd = S.qx[qStar];
+    uint32_t myStart[CD_NCUR];
+#pragma unroll
+    for (int j = 0; j < CD_NCUR; j++) myStart[j] = tid + j * DEC_THREADS < Q ? S.qs[tid + j * DEC_THREADS] : 0u;
+    if (CD_NCUR == 1) __syncthreads();
 #pragma unroll
     for (int j = 0; j < CD_NCUR; j++) {
         const uint32_t q = tid + j * DEC_THREADS;
@@ -637,7 +657,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
             uint32_t k = base[j];
             bool started = q != 0;                                // q == 0: an escape before any value is text[-1]
             CdCur<Text> cur;
-            cur.seek(T, S.qs[q]);
+            cur.seek(T, CD_NCUR == 1 ? myStart[j] : S.qs[q]);
             uint32_t w = cur.window();
             uint32_t e = cd_entry_of(S, w);                       // e is always the entry at the cursor
             while (cur.pos < bound) {
@@ -690,7 +710,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     }
 
     CD_STAMP(5);                                  // values written
-    *endPos = S.qx[qStar];
+    *endPos = eotEnd;
     *nValuesOut = nValues;
     __syncthreads();
     return GF_K_OK;
