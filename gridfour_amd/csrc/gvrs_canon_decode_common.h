@@ -651,47 +651,52 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     for (int j = 0; j < CD_NCUR; j++) {
         const uint32_t q = tid + j * DEC_THREADS;
         if constexpr (Sink::kStaged) sink.halfBase = j == 0 ? 0u : min(firstHalf, nValues);
-        if (q < Q && q <= qStar) {
+        {
+            // One TOKEN per turn of a wave-uniform loop, everything by selects (round 3).  A value is PENDING from its symbol on until
+            // the next token shows that no escape extends it any further (CanonicalHuffman.java:489-511): a plain symbol or the end
+            // flushes it.  A subsequence owns the values whose symbol starts before its end; the escapes of its last value may carry
+            // it past that end, and the escapes at its own start belong to the subsequence before (q == 0: an escape before any
+            // value is text[-1]).  Two plain values that share a lookup go out together, the second one becomes the pending one.
+            // (The loop used to be three nested per-lane loops -- values, escapes, pairs -- around a register cursor: the scalar
+            // unit spent more instructions on their exec masks than the SIMDs on the values: 54 K SALU + 16 K branches per tile.)
+            const bool mine = q < Q && q <= qStar;
             const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
             const uint32_t bound = Bn == endBit ? 0xFFFFFFF0u : Bn;
-            uint32_t k = base[j];
-            bool started = q != 0;                                // q == 0: an escape before any value is text[-1]
-            CdCur<Text> cur;
-            cur.seek(T, CD_NCUR == 1 ? myStart[j] : S.qs[q]);
-            uint32_t w = cur.window();
-            uint32_t e = cd_entry_of(S, w);                       // e is always the entry at the cursor
-            while (cur.pos < bound) {
-                if (cd_e_pair(e) && cur.pos + cd_e_len(e) < bound) {
-                    // two plain values in the window: the first one is complete (a value follows it, not an escape)
-                    started = true;
-                    sink.put(k, cd_e_sym(e) - 128u);
+            uint32_t k = base[j], a = mine ? (CD_NCUR == 1 ? myStart[j] : S.qs[q]) : 0u, v = 0;
+            bool fin = !mine, pend = false, started = q != 0;
+            while (__any(!fin)) {
+                const uint32_t w = cd_peek(T, a);
+                const uint32_t e = cd_entry_of(S, w);
+                const bool inside = a < bound;
+                const bool live = !fin && (inside || pend);
+                const bool bad = e == 0x7FFFFFFFu;
+                const uint32_t sym = cd_e_sym(e), cl = cd_e_len(e), extra = cd_e_extra(e);
+                const bool isPlain = !bad && sym <= (uint32_t)CN_NULL, isEnd = bad || sym == (uint32_t)CN_EOT;
+                const bool isEsc = !bad && (sym == (uint32_t)CN_ESC1 || sym == (uint32_t)CN_ESC2);
+                const bool takePlain = live && isPlain && inside;
+                const bool stop = live && (isEnd || (isPlain && !inside));
+                const bool takeEsc = live && !isPlain && !isEnd;                 // an escape or the spare symbol 260
+                if (pend && (takePlain || stop)) {
+                    sink.put(k, v);
                     k++;
-                    cur.advance(T, cd_e_len(e));
-                    w = cur.window();
-                    e = cd_entry(cd_e_sym2(e), cd_e_len12(e) - cd_e_len(e));
                 }
-                CdTok tk = cd_token_from(e, w);
-                if (tk.sym == (uint32_t)CN_EOT || tk.sym == 0xFFFFu) break;
-                cur.advance(T, tk.bits);
-                if (tk.sym > (uint32_t)CN_NULL) {                 // escape belonging to the previous value, or spare symbol 260
-                    if (!started && tk.sym != 260u) S.runStatus = GF_K_ERR_BOUNDS;
-                    w = cur.window();
-                    e = cd_entry_of(S, w);
-                    continue;
+                const bool takePair = takePlain && cd_e_pair(e) && a + cl < bound;
+                if (takePair) {
+                    sink.put(k, sym - 128u);                                      // complete: a value follows it, not an escape
+                    k++;
                 }
-                started = true;
-                uint32_t v = tk.sym == (uint32_t)CN_NULL ? GF_NULL_CODE : tk.sym - 128u;
-                for (;;) {                                        // the escapes that extend this value (:495-504)
-                    w = cur.window();
-                    e = cd_entry_of(S, w);
-                    tk = cd_token_from(e, w);
-                    if (tk.sym == (uint32_t)CN_ESC2) v = (v << 2) | tk.raw;
-                    else if (tk.sym == (uint32_t)CN_ESC1) v = (v << 8) | tk.raw;
-                    else if (tk.sym != 260u) break;
-                    cur.advance(T, tk.bits);
+                if (takeEsc) {
+                    const uint32_t raw = (w >> cl) & ((1u << extra) - 1u);
+                    if (pend && isEsc) v = sym == (uint32_t)CN_ESC2 ? (v << 2) | raw : (v << 8) | raw;
+                    if (!pend && !started && sym != 260u) S.runStatus = GF_K_ERR_BOUNDS;
                 }
-                sink.put(k, v);
-                k++;
+                if (takePlain) {
+                    v = takePair ? cd_e_sym2(e) - 128u : sym == (uint32_t)CN_NULL ? GF_NULL_CODE : sym - 128u;
+                    started = true;
+                }
+                pend = (pend || takePlain) && !stop;
+                a += takePlain ? (takePair ? cd_e_len12(e) : cl) : takeEsc ? cl + extra : 0u;
+                fin = fin || stop || !live;
             }
         }
         if constexpr (Sink::kStaged) {             // this half's small values wait in LDS: out with them, whole lines at a time
