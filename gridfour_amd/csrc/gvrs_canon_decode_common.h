@@ -246,29 +246,37 @@ __device__ __forceinline__ void cd_build_tokens(const CanonDec &S, uint16_t *tok
     }
 }
 
-// cd_run with the token table: same end, count and end-of-text position.  a = bit position in the LDS text.
-__device__ __forceinline__ void cd_run_tok(const CanonDec &S, const uint16_t *tok, uint32_t a, uint32_t bound, uint32_t endBit,
+// cd_run with the token table: same end, count and end-of-text position.  a = bit position in the LDS text.  The loop is
+// wave-uniform (a lane that has arrived adds nothing); run == false: the lane takes no part.
+__device__ __forceinline__ void cd_run_tok(const CanonDec &S, const uint16_t *tok, uint32_t a, uint32_t bound, uint32_t endBit, bool run,
                                            uint32_t *endOut, uint32_t *cntOut, uint32_t *eotEnd)
 {
     const uint32_t border = min(bound, endBit);                     // no token of a group may start at or behind it
-    uint32_t cnt = 0, end;
-    for (;;) {
-        if (a >= bound) { end = a; break; }
-        if (a >= endBit) { end = CD_END_BAD; break; }
+    uint32_t cnt = 0, end = 0;
+    bool going = run;
+    while (__any(going)) {
         const uint32_t i = a >> 5;
         const uint32_t w = __builtin_amdgcn_alignbit(cdLdsText[i + 1u], cdLdsText[i], a);
         const uint32_t t = tok[w & ((1u << CD_LUT_BITS) - 1u)];
-        if (t & CD_TOK_STOP) {
+        const bool arrived = a >= bound, out = !arrived && a >= endBit;
+        uint32_t nb = 0, nv = 0;
+        bool stopNow = going && (arrived || out);
+        uint32_t endIf = arrived ? a : CD_END_BAD;
+        if (going && !arrived && !out && (t & CD_TOK_STOP)) {       // end of text, a code longer than the window, no code at all
             const CdTok tk = cd_token_from(cd_entry_of(S, w), w);
-            if (tk.sym == 0xFFFFu) { end = CD_END_BAD; break; }
-            if (tk.sym == (uint32_t)CN_EOT) { end = CD_END_EOT; *eotEnd = a + tk.bits; break; }
-            cnt += tk.sym <= (uint32_t)CN_NULL ? 1u : 0u;
-            a += tk.bits;
-            continue;
+            if (tk.sym == 0xFFFFu) { stopNow = true; endIf = CD_END_BAD; }
+            else if (tk.sym == (uint32_t)CN_EOT) { stopNow = true; endIf = CD_END_EOT; *eotEnd = a + tk.bits; }
+            else { nb = tk.bits; nv = tk.sym <= (uint32_t)CN_NULL ? 1u : 0u; }
+        } else {
+            const bool single = a + (uint32_t)CD_LUT_BITS > border;
+            nv = single ? (t >> 14) & 1u : (t >> 5) & 15u;
+            nb = single ? (t >> 9) & 31u : t & 31u;
         }
-        const bool single = a + (uint32_t)CD_LUT_BITS > border;
-        cnt += single ? (t >> 14) & 1u : (t >> 5) & 15u;
-        a += single ? (t >> 9) & 31u : t & 31u;
+        const bool step = going && !stopNow;
+        cnt += step ? nv : 0u;
+        a += step ? nb : 0u;
+        end = stopNow ? endIf : end;
+        going = step;
     }
     *endOut = end;
     *cntOut = cnt;
@@ -512,29 +520,34 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     const uint32_t unit = max(128u, ((span + CD_MAXQ - 1) / CD_MAXQ + 31u) & ~31u);
     const uint32_t Q = (span + unit - 1) / unit;
     if (tok) {
-        for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
+        for (uint32_t q0 = 0; q0 < Q; q0 += DEC_THREADS) {      // (wave-uniform loops: every lane of a wave takes every turn)
+            const uint32_t q = q0 + tid;
+            const bool mine = q < Q;
             const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
             uint32_t a = Bq;
-            if (q > 0) {                                        // warm-up: walk in from 128 bits before the boundary
-                a = Bq - T0 > CD_WARM ? Bq - CD_WARM : T0;
-                while (a < Bq) {
-                    const uint32_t i = a >> 5;
-                    const uint32_t w = __builtin_amdgcn_alignbit(cdLdsText[i + 1u], cdLdsText[i], a);
-                    const uint32_t t = tok[w & ((1u << CD_LUT_BITS) - 1u)];
-                    if (t & CD_TOK_STOP) {
-                        const CdTok tk = cd_token_from(cd_entry_of(S, w), w);
-                        if (tk.sym == 0xFFFFu || tk.sym == (uint32_t)CN_EOT) { a = Bq; break; }
-                        a += tk.bits;
-                        continue;
-                    }
-                    a += a + (uint32_t)CD_LUT_BITS > Bq ? (t >> 9) & 31u : t & 31u;   // one token at a time close to the boundary
+            if (mine && q > 0) a = Bq - T0 > CD_WARM ? Bq - CD_WARM : T0;      // warm-up: walk in from 128 bits before the boundary
+            bool warm = mine && a < Bq;
+            while (__any(warm)) {
+                const uint32_t i = a >> 5;
+                const uint32_t w = __builtin_amdgcn_alignbit(cdLdsText[i + 1u], cdLdsText[i], a);
+                const uint32_t t = tok[w & ((1u << CD_LUT_BITS) - 1u)];
+                uint32_t nb = a + (uint32_t)CD_LUT_BITS > Bq ? (t >> 9) & 31u : t & 31u;   // one token at a time close to the boundary
+                bool jump = false;
+                if (warm && (t & CD_TOK_STOP)) {
+                    const CdTok tk = cd_token_from(cd_entry_of(S, w), w);
+                    jump = tk.sym == 0xFFFFu || tk.sym == (uint32_t)CN_EOT;
+                    nb = tk.bits;
                 }
+                a = !warm ? a : jump ? Bq : a + nb;
+                warm = warm && a < Bq;
             }
             uint32_t e, c;
-            cd_run_tok(S, tok, a, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
-            S.qs[q] = a;
-            S.qe[q] = e;
-            S.qc[q] = c;
+            cd_run_tok(S, tok, a, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, mine, &e, &c, &S.qx[mine ? q : 0]);
+            if (mine) {
+                S.qs[q] = a;
+                S.qe[q] = e;
+                S.qc[q] = c;
+            }
         }
     } else
     for (uint32_t q = tid; q < Q; q += DEC_THREADS) {
@@ -594,7 +607,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
                 uint32_t e, c;
                 // a value's escapes may carry the previous subsequence past this one's end: then it is empty
                 if (want >= Bn && Bn != endBit) { e = want; c = 0; }
-                else if (tok) cd_run_tok(S, tok, want, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, &e, &c, &S.qx[q]);
+                else if (tok) cd_run_tok(S, tok, want, Bn == endBit ? 0xFFFFFFF0u : Bn, endBit, true, &e, &c, &S.qx[q]);
                 else {
                     CdCur<Text> cur;
                     cur.seek(T, want);
