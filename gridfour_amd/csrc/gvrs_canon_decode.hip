@@ -101,23 +101,26 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
 
         // ---------------- phases 0-2: the canonical-Huffman stream, values to their cells ----------------
         const uint32_t nStream = gf_stream_len(model, nR, nC);
-        const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
-        const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
-        const uint32_t magic = (uint32_t)(((1ull << 32) + wMain - 1) / wMain);
 #ifdef GF_DIAG
-        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, !(a.phaseLimit & 0x100),
+        const CdCellSink sink{o, GfCellMap::make(model, nR, nC), nStream, !(a.phaseLimit & 0x100),
                               stageA, stageB, stageCapA, stageCap, 0u};
         uint32_t *stamps = a.debug ? a.debug + t * 16 : nullptr;
         if (stamps && tid == 0) stamps[0] = (uint32_t)__builtin_amdgcn_s_memtime();
 #else
-        const CdCellSink sink{o, model, nR, nC, nStream, magic, useMagic && wMain > 1, true, stageA, stageB, stageCapA, stageCap, 0u};
+        const CdCellSink sink{o, GfCellMap::make(model, nR, nC), nStream, true,
+                              stageA, stageB, stageCapA, stageCap, 0u};
         constexpr uint32_t *stamps = nullptr;
 #endif
         uint32_t endPos, nValues;
         const uint32_t *pre = a.trees ? a.trees + t * GF_CANON_REC_WORDS : nullptr;
         // the token table of the synchronisation pass: in the value stage behind the text, which is idle until phase 2
         uint16_t *const tok = a.ldsStageBytes >= (sizeof(uint16_t) << CD_LUT_BITS) ? reinterpret_cast<uint16_t *>(stageB) : nullptr;
-        const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias, tok)
+#ifdef GF_DIAG
+        const int diagLimit = a.phaseLimit & 0xff;
+#else
+        constexpr int diagLimit = 0;
+#endif
+        const int32_t st = textInLds ? cd_decode_stream(S, TL, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias, tok, diagLimit)
                                      : cd_decode_stream(S, TG, bias + 48u, endBit, nCells, nStream, sink, &endPos, &nValues, stamps, pre, bias);
         if (st != GF_K_OK) {
             if (tid == 0) a.status[t] = st;

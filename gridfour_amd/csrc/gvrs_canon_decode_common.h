@@ -287,7 +287,7 @@ struct CdArraySink {                      // value k -> dst[k], k < n
     int32_t *dst;
     uint32_t n;
     static constexpr bool kStaged = false;
-    __device__ __forceinline__ void put(uint32_t k, uint32_t v) const { one(k, v); }
+    __device__ __forceinline__ void put(uint32_t k, uint32_t v, bool on = true) const { if (on) one(k, v); }
     __device__ __forceinline__ void one(uint32_t k, uint32_t v) const { if (k < n) dst[k] = (int32_t)v; }
     __device__ __forceinline__ void quad(uint32_t k0, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const
     {
@@ -301,10 +301,9 @@ struct CdArraySink {                      // value k -> dst[k], k < n
 
 struct CdCellSink {                       // value k of a predictor's stream -> its cell of the tile
     uint32_t *o;
-    int model;
-    uint32_t nR, nC, nStream, magic;
-    bool useMagic;
-    __device__ __forceinline__ uint32_t cell(uint32_t k) const { return stream_cell_fast(model, nR, nC, k, magic, useMagic); }
+    GfCellMap map;                        // (worked out once per tile: no model dispatch per value)
+    uint32_t nStream;
+    __device__ __forceinline__ uint32_t cell(uint32_t k) const { return map(k); }
     bool enabled;                         // false: diagnostic ablation (no stores)
     __device__ __forceinline__ void one(uint32_t k, uint32_t v) const { if (k < nStream && enabled) o[cell(k)] = v; }
     // Staging (decode phase 2): a thread walks its own stretch of the stream, so the 64 lanes of a store instruction hit 64
@@ -317,16 +316,14 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
     uint32_t capA, cap;
     uint32_t halfBase;                    // stream position of the half being decoded
     __device__ __forceinline__ uint8_t *slot(uint32_t rel) const { return rel < capA ? stA + rel : stB + (rel - capA); }
-    __device__ __forceinline__ void put(uint32_t k, uint32_t v) const
+    __device__ __forceinline__ void put(uint32_t k, uint32_t v, bool on = true) const
     {
-        if (k >= nStream || !enabled) return;
+        // (two flat predicated stores: nested, the conditions cost the scalar unit more than the stores cost the SIMDs)
         const uint32_t rel = k - halfBase;
-        const bool small = v + 127u <= 254u;
-        if (rel < cap) {
-            *slot(rel) = small ? (uint8_t)v : (uint8_t)0x80;
-            if (small) return;
-        }
-        o[cell(k)] = v;
+        const bool ok = on && k < nStream && enabled;
+        const bool small = v + 127u <= 254u, staged = rel < cap;
+        if (ok && staged) *slot(rel) = small ? (uint8_t)v : (uint8_t)0x80;
+        if (ok && !(staged && small)) o[cell(k)] = v;
     }
     __device__ __forceinline__ void expand(uint32_t count) const        // the whole workgroup, between two barriers
     {
@@ -359,8 +356,10 @@ template <class Text, class Sink>
 __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, uint32_t startBit, uint32_t endBit,
                                                     uint32_t maxValues, uint32_t fillTo, Sink sink, uint32_t *endPos,
                                                     uint32_t *nValuesOut, uint32_t *stamps = nullptr,
-                                                    const uint32_t *pre = nullptr, uint32_t preBase = 0, uint16_t *tok = nullptr)
+                                                    const uint32_t *pre = nullptr, uint32_t preBase = 0, uint16_t *tok = nullptr,
+                                                    int diagLimit = 0)
 {
+    // diagLimit (diagnostic build only): return early after the tables (1), the synchronisation pass (2), the value pass (3)
     // tok: 4 KB of LDS for the token table of the synchronisation pass (LDS text only), or null: the cursor walk
 #define CD_STAMP(i)                                                                        \
     do {                                                                                   \
@@ -514,6 +513,9 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     }
 
     CD_STAMP(2);                                  // tables + LUT done
+#ifdef GF_DIAG
+    if (diagLimit == 1) { __syncthreads(); return GF_K_ERR_UNSUPPORTED; }
+#endif
     // ---------------- phase 1: synchronise the subsequences, count their values ----------------
     const uint32_t T0 = S.textStart;
     const uint32_t span = endBit > T0 ? endBit - T0 : 1u;
@@ -621,6 +623,9 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
         }
     }
     CD_STAMP(3);                                  // synchronised
+#ifdef GF_DIAG
+    if (diagLimit == 2) { __syncthreads(); return GF_K_ERR_UNSUPPORTED; }
+#endif
     // the true chain ends at the first subsequence that met the end-of-text symbol (or an error)
     for (uint32_t q = tid; q < Q; q += DEC_THREADS)
         if (S.qe[q] >= CD_END_BAD) atomicMin(&S.qStar, q);
@@ -689,15 +694,12 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
                 const bool takePlain = live && isPlain && inside;
                 const bool stop = live && (isEnd || (isPlain && !inside));
                 const bool takeEsc = live && !isPlain && !isEnd;                 // an escape or the spare symbol 260
-                if (pend && (takePlain || stop)) {
-                    sink.put(k, v);
-                    k++;
-                }
+                const bool flush = pend && (takePlain || stop);
+                sink.put(k, v, flush);
+                k += flush ? 1u : 0u;
                 const bool takePair = takePlain && cd_e_pair(e) && a + cl < bound;
-                if (takePair) {
-                    sink.put(k, sym - 128u);                                      // complete: a value follows it, not an escape
-                    k++;
-                }
+                sink.put(k, sym - 128u, takePair);                                // complete: a value follows it, not an escape
+                k += takePair ? 1u : 0u;
                 if (takeEsc) {
                     const uint32_t raw = (w >> cl) & ((1u << extra) - 1u);
                     if (pend && isEsc) v = sym == (uint32_t)CN_ESC2 ? (v << 2) | raw : (v << 8) | raw;
@@ -728,6 +730,9 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     }
 
     CD_STAMP(5);                                  // values written
+#ifdef GF_DIAG
+    if (diagLimit == 3) { __syncthreads(); return GF_K_ERR_UNSUPPORTED; }
+#endif
     *endPos = eotEnd;
     *nValuesOut = nValues;
     __syncthreads();

@@ -1053,10 +1053,8 @@ __device__ __forceinline__ void build_lut(DecShared &S, Lut2Ptr lut2)
 // workgroup: value k goes to o[map(k)].  bm / wb: start bitmap and its rank bases (same memory space as m32).
 // Returns GF_K_OK, or GF_K_ERR_BOUNDS where the reference's reads run off the stream.
 struct CellMapPredictor {
-    int model;
-    uint32_t nR, nC, magic;
-    bool fast;
-    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return stream_cell_fast(model, nR, nC, k, magic, fast); }
+    GfCellMap map;
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return map(k); }
 };
 struct CellMapIdentity {
     __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return k; }
@@ -2207,9 +2205,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 }
                 if constexpr (!FAST) {
                     // ---------------- phase 2: M32 bytes -> residuals at their cells ----------------
-                    const bool useMagic = (uint64_t)nCells * nC < (1ull << 32);
-                    const uint32_t wMain = model == 2 ? (nC > 2 ? nC - 2u : 1u) : (nC > 1 ? nC - 1u : 1u);
-                    const CellMapPredictor map{model, nR, nC, (uint32_t)(((1ull << 32) + wMain - 1) / wMain), useMagic && wMain > 1};
+                    const CellMapPredictor map{GfCellMap::make(model, nR, nC)};
                     tileStatus = m32_to_values(S, m32, nM32, bm, wb, nStream, map, o);
                 }
                 return tileStatus;

@@ -28,37 +28,49 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *waveSu
     return base + incl - v;
 }
 
-__device__ __forceinline__ uint32_t stream_cell_fast(int model, uint32_t nR, uint32_t nC, uint32_t k, uint32_t magic,
-                                                     bool useMagic)
-{
-    // cell of stream element k; the row/column split of the main segment uses a multiply-high
-    // reciprocal (exact while t * w < 2^32) instead of an integer division
-    uint32_t t, w, rowBase, colBase;
-    if (model == 1) return k + 1u;
-    if (model == 4) return k;
-    if (model == 2) {
-        if (k == 0) return 1u;
-        const uint32_t seedLen = 2u * nR - 1u;
-        if (k < seedLen) {
-            const uint32_t u = k - 1u;
-            return (1u + (u >> 1)) * nC + (u & 1u);
-        }
-        t = k - seedLen;
-        w = nC - 2u;
-        rowBase = 0u;
-        colBase = 2u;
-    } else {
-        if (k < nC - 1u) return k + 1u;
-        t = k - (nC - 1u);
-        if (t < nR - 1u) return (t + 1u) * nC;
-        t -= nR - 1u;
-        w = nC - 1u;
-        rowBase = 1u;
-        colBase = 1u;
+// Cell of stream element k of a predictor's stream (PredictorModel*.java: the order the encoder walks the tile in), as ONE
+// formula whose parameters are worked out once per tile (wave-uniform, in SGPRs) -- so the per-value code has no branch on the
+// model and none on "border or interior": written as a switch over the model with per-lane ifs inside, the mapping cost ~50
+// scalar instructions per call for its exec masks and its dispatch, in the value loops of the canonical decoders (round 3).
+//   k <  hA         : k + hAdd                    (row 0 of Triangle / Differencing / the identity; element 0 of Linear)
+//   k <  nHead      : u = k - hA:  (1 + (u >> sh)) * nC + (u & msk)
+//                     (Linear: elements 2r-1, 2r are cells (r,0), (r,1);  Triangle: column 0 from row 1 on)
+//   else            : t = k - nHead, r = t / w:   base + t + r * colBase      (= (r + rowBase) * nC + colBase + t - r * w,
+//                     w = nC - colBase cells of a row in the interior, colBase = 2 for Linear, 1 for Triangle)
+// t / w is a multiply-high by a 33-bit reciprocal (Granlund & Montgomery: m = floor(2^32 (2^s - w) / w) + 1, s = ceil(log2 w);
+// q = mulhi(t, m); r = (((t - q) >> min(s, 1)) + q) >> max(s - 1, 0)): exact for every 32-bit t, no division fallback.
+struct GfCellMap {
+    uint32_t nC, hA, hAdd, nHead, sh, msk, base, colBase, m, s1, s2;
+    __device__ __forceinline__ static GfCellMap make(int model, uint32_t nR, uint32_t nC)
+    {
+        GfCellMap c;
+        const bool linear = model == 2, tri = model == 3;
+        c.nC = nC;
+        c.hAdd = model == 4 ? 0u : 1u;
+        c.hA = linear ? 1u : tri ? nC - 1u : 0xFFFFFFFFu;
+        c.nHead = linear ? 2u * nR - 1u : tri ? nC + nR - 2u : 0xFFFFFFFFu;
+        c.sh = linear ? 1u : 0u;
+        c.msk = linear ? 1u : 0u;
+        c.colBase = linear ? 2u : 1u;
+        c.base = (linear ? 0u : nC) + c.colBase;
+        const uint32_t w = nC > c.colBase ? nC - c.colBase : 1u;
+        const uint32_t s = w > 1u ? 32u - (uint32_t)__builtin_clz(w - 1u) : 0u;
+        c.m = (uint32_t)(((uint64_t)((1ull << s) - w) << 32) / w) + 1u;
+        c.s1 = s ? 1u : 0u;
+        c.s2 = s - c.s1;
+        return c;
     }
-    const uint32_t r = useMagic ? __umulhi(t, magic) : t / w;
-    return (r + rowBase) * nC + colBase + (t - r * w);
-}
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const
+    {
+        const uint32_t u = k - hA;
+        const uint32_t border = (1u + (u >> sh)) * nC + (u & msk);
+        const uint32_t t = k - nHead;                            // (of no meaning before the interior)
+        const uint32_t q = __umulhi(t, m);
+        const uint32_t r = (((t - q) >> s1) + q) >> s2;
+        const uint32_t interior = base + t + r * colBase;
+        return k < hA ? k + hAdd : k < nHead ? border : interior;
+    }
+};
 
 // wave-wide inclusive scan of one row segment with carry; returns the new carry
 __device__ __forceinline__ uint32_t row_scan_segment(uint32_t x, uint32_t carry, int lane, uint32_t *outv)
