@@ -101,14 +101,17 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
 
         // ---------------- phases 0-2: the canonical-Huffman stream, values to their cells ----------------
         const uint32_t nStream = gf_stream_len(model, nR, nC);
+        // Triangle tiles of the one-subsequence-per-thread build: the staged residuals become the tile in one go (cd_fused_triangle)
 #ifdef GF_DIAG
+        const bool fuse = cd_fuse_eligible(model, nR, nC, stageCap) && !(a.phaseLimit & 0x300);
         const CdCellSink sink{o, GfCellMap::make(model, nR, nC), nStream, !(a.phaseLimit & 0x100),
-                              stageA, stageB, stageCapA, stageCap, 0u};
+                              stageA, stageB, stageCapA, stageCap, 0u, fuse};
         uint32_t *stamps = a.debug ? a.debug + t * 16 : nullptr;
         if (stamps && tid == 0) stamps[0] = (uint32_t)__builtin_amdgcn_s_memtime();
 #else
+        const bool fuse = cd_fuse_eligible(model, nR, nC, stageCap);
         const CdCellSink sink{o, GfCellMap::make(model, nR, nC), nStream, true,
-                              stageA, stageB, stageCapA, stageCap, 0u};
+                              stageA, stageB, stageCapA, stageCap, 0u, fuse};
         constexpr uint32_t *stamps = nullptr;
 #endif
         uint32_t endPos, nValues;
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
         }
 
         // ---------------- phase 3: predictor inverse ----------------
-        gf_predictor_inverse(model, seed, o, nR, nC, nullptr);
+        if (fuse) cd_fused_triangle(S, sink, seed, nR, nC, o);
+        else gf_predictor_inverse(model, seed, o, nR, nC, nullptr);
 #ifdef GF_DIAG
         if (stamps && tid == 0) stamps[6] = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif

@@ -315,6 +315,7 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
     uint8_t *stA, *stB;                   // the stage: capA bytes at stA, then cap - capA bytes at stB (cap == 0: no staging)
     uint32_t capA, cap;
     uint32_t halfBase;                    // stream position of the half being decoded
+    bool fuse;                            // the staged values stay where they are: cd_fused_triangle() turns them into the tile
     __device__ __forceinline__ uint8_t *slot(uint32_t rel) const { return rel < capA ? stA + rel : stB + (rel - capA); }
     __device__ __forceinline__ void put(uint32_t k, uint32_t v, bool on = true) const
     {
@@ -347,6 +348,116 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
         one(k0, a); one(k0 + 1u, b); one(k0 + 2u, c); one(k0 + 3u, d);
     }
 };
+
+// The Triangle predictor's inverse (PredictorModelTriangle.java:62-98) straight from the staged residuals (round 3): the value
+// pass left every small residual of the stream as a byte in LDS (the others, and what the stage had no room for, at their cells
+// in the tile, marked 0x80 in the stage), so the tile is written ONCE, whole rows by neighbouring lanes -- expand() + the in-place
+// inverse wrote the residuals, read them back and wrote the values: 4.5 GB of HBM traffic per 0.93 GB of tiles on the
+// ETOPO1-shaped batch (profiles/hbm_traffic.json, round 3 v1), at a rate where that traffic is no longer free.
+//   out[i][j] = res[i][j] + out[i][j-1] + out[i-1][j] - out[i-1][j-1]   (int32, wrapping)   unrolls to
+//   out[i][j] = out[0][j] + out[i][0] - seed + SUM(r = 1..i) SUM(m = 1..j) res[r][m]:
+// row 0 and column 0 are running sums of their residuals from the seed; the double sum is a row-wise prefix sum (DPP scan over
+// the lanes of a wave, a carry between the 64-column segments) accumulated down the rows (a register per segment).  The rows are
+// dealt out in DEC_WAVES blocks, a wave each; the sums of the blocks above a wave's own come from a cheaper pre-pass (column
+// sums per block, then ONE row-wise prefix sum per block) through LDS.  Row 0 and column 0 take part as rows / columns of
+// zero residuals, so every wave stores whole rows.  Scratch: the lookup table (dead after the value pass).
+constexpr int CD_FUSE_NSEG = 4;                                   // 64-column segments a lane keeps sums for: nC <= 256
+__device__ __forceinline__ bool cd_fuse_eligible(int model, uint32_t nR, uint32_t nC, uint32_t stageCap)
+{
+    return CD_NCUR == 1 && DEC_WAVES >= 2 && model == 3 && nR >= 2u && nC >= 2u && nC <= 64u * CD_FUSE_NSEG && stageCap > 0u &&
+           (uint32_t)(DEC_WAVES + 1) * nC + nR <= (1u << CD_LUT_BITS);
+}
+__device__ __forceinline__ void cd_fused_triangle(CanonDec &S, const CdCellSink &sink, uint32_t seed, uint32_t nR, uint32_t nC,
+                                                  uint32_t *__restrict__ o)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t *row0 = S.lut, *col0 = row0 + nC, *T = col0 + nR;    // out[0][*], out[*][0], block sums [DEC_WAVES][nC]
+    const uint32_t W = nC - 1u, H = nR - 1u, nHead = W + H;
+    // residual of stream element k, whose cell is `cell`
+    auto res = [&](uint32_t k, uint32_t cell) -> uint32_t {
+        const uint32_t b = *sink.slot(min(k, sink.cap - 1u));
+        uint32_t v = (uint32_t)(int32_t)(int8_t)b;
+        if (b == 0x80u || k >= sink.cap) v = o[cell];             // (rare) wider than a byte, or beyond the stage
+        return v;
+    };
+    // ---- the borders: running sums from the seed (wave 0: row 0, wave 1: column 0)
+    if (wave < 2u) {
+        const uint32_t n = wave == 0u ? W : H, k0 = wave == 0u ? 0u : W;
+        uint32_t *dst = wave == 0u ? row0 : col0;
+        uint32_t carry = seed;
+        for (uint32_t c = 0; c < n; c += 64u) {
+            const uint32_t e = c + lane;
+            uint32_t v = 0;
+            if (e < n) v = res(k0 + e, wave == 0u ? e + 1u : (e + 1u) * nC);
+            v = gf_wave_incl_scan(v) + carry;
+            if (e < n) dst[e + 1u] = v;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+        }
+        if (lane == 0u) dst[0] = seed;
+    }
+    // ---- pre-pass: T[b][j] = SUM(rows r of block b) SUM(m = 1..j) res[r][m]
+    const uint32_t RB = (nR + DEC_WAVES - 1u) / DEC_WAVES;
+    const uint32_t r0 = min(nR, wave * RB), r1 = min(nR, r0 + RB);
+    {
+        uint32_t cs[CD_FUSE_NSEG];
+#pragma unroll
+        for (int s = 0; s < CD_FUSE_NSEG; s++) cs[s] = 0;
+        for (uint32_t r = max(r0, 1u); r < r1; r++) {
+            const uint32_t kRow = nHead + (r - 1u) * W - 1u, cRow = r * nC;
+#pragma unroll
+            for (int s = 0; s < CD_FUSE_NSEG; s++) {
+                const uint32_t j = (uint32_t)s * 64u + lane;
+                if ((uint32_t)s * 64u < nC) {
+                    uint32_t v = 0;
+                    if (j >= 1u && j < nC) v = res(kRow + j, cRow + j);
+                    cs[s] += v;
+                }
+            }
+        }
+        uint32_t carry = 0;
+#pragma unroll
+        for (int s = 0; s < CD_FUSE_NSEG; s++) {
+            const uint32_t j = (uint32_t)s * 64u + lane;
+            if ((uint32_t)s * 64u < nC) {
+                const uint32_t v = gf_wave_incl_scan(cs[s]) + carry;
+                if (j < nC) T[wave * nC + j] = v;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the tile, row by row
+    uint32_t colBase[CD_FUSE_NSEG], acc[CD_FUSE_NSEG];
+#pragma unroll
+    for (int s = 0; s < CD_FUSE_NSEG; s++) {
+        const uint32_t j = (uint32_t)s * 64u + lane;
+        uint32_t b = 0;
+        if (j < nC) {
+            b = row0[j] - seed;
+            for (uint32_t w = 0; w < wave; w++) b += T[w * nC + j];
+        }
+        colBase[s] = b;
+        acc[s] = 0;
+    }
+    for (uint32_t r = r0; r < r1; r++) {
+        const uint32_t kRow = nHead + (r - 1u) * W - 1u, cRow = r * nC;
+        const uint32_t left = col0[r];
+        uint32_t carry = 0;
+#pragma unroll
+        for (int s = 0; s < CD_FUSE_NSEG; s++) {
+            const uint32_t j = (uint32_t)s * 64u + lane;
+            if ((uint32_t)s * 64u < nC) {
+                uint32_t v = 0;
+                if (r >= 1u && j >= 1u && j < nC) v = res(kRow + j, cRow + j);
+                v = gf_wave_incl_scan(v) + carry;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+                acc[s] += v;
+                if (j < nC) o[cRow + j] = colBase[s] + left + acc[s];
+            }
+        }
+    }
+    __syncthreads();
+}
 
 // One canonical-Huffman stream (CanonicalHuffman.decode :441-519) starting at bit startBit of T, by the whole
 // workgroup: code tables, subsequence synchronisation, then every value k handed to sink(k, value); values the
@@ -716,12 +827,17 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
         }
         if constexpr (Sink::kStaged) {             // this half's small values wait in LDS: out with them, whole lines at a time
             __syncthreads();
-            sink.expand(j == 0 ? min(firstHalf, nValues) : nValues - min(firstHalf, nValues));
+            if (!sink.fuse) sink.expand(j == 0 ? min(firstHalf, nValues) : nValues - min(firstHalf, nValues));
             __syncthreads();
         }
     }
     // a text shorter than its reader expects leaves zeros (fresh int[] in Java)
-    for (uint32_t k = nValues + tid; k < fillTo; k += DEC_THREADS) sink.one(k, 0u);
+    for (uint32_t k = nValues + tid; k < fillTo; k += DEC_THREADS) {
+        if constexpr (Sink::kStaged) {
+            if (sink.fuse) sink.put(k, 0u);                       // (one subsequence per thread: halfBase is 0)
+            else sink.one(k, 0u);
+        } else sink.one(k, 0u);
+    }
     __syncthreads();
     {
         const int32_t st = S.runStatus;

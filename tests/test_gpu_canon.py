@@ -163,3 +163,33 @@ def test_device_batch_dem_roundtrip_and_sampled_parity():
         assert preds[t] == used and lengths[t] == len(ref)
         assert b.get_packing(t, int(lengths[t])) == ref
     b.free()
+
+
+@pytest.mark.parametrize("shape", [(120, 150), (200, 200), (100, 256), (90, 257), (64, 193), (129, 128), (2, 8000), (300, 64), (500, 40)],
+                         ids=lambda s: "%dx%d" % s)
+def test_triangle_packings_every_kind(codec, shape):
+    """Packings the oracle made with the Triangle predictor alone, through the decoder: the 512-thread build turns the staged
+    residuals of such tiles into the tile in one go (cd_fused_triangle) -- small residuals from the LDS stage, wide ones and
+    whatever the stage has no room for read back from their cells; shapes either side of its limits (256 columns, the scratch
+    of (waves + 1) rows) take the two-step path."""
+    n_rows, n_cols = shape
+    tiles = [make_tile(k, n_rows, n_cols) for k in KINDS]
+    tiles.append(add_nulls(make_tile("smooth", n_rows, n_cols), n_rows, n_cols, 0.05, blocks=False))
+    rng = np.random.default_rng(n_rows * 1000 + n_cols)
+    v = rng.integers(-2, 3, n_rows * n_cols).cumsum().astype(np.int64)      # small residuals, a few wide ones, int32 wrap-around
+    idx = rng.integers(0, v.size, 40)
+    v[idx] += rng.integers(-2_000_000_000, 2_000_000_000, idx.size)
+    tiles.append((v & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+    packs = []
+    for v in tiles:
+        p, used = oracle.codec_canon_encode(3, n_rows, n_cols, v, predictor_mask=1 << 2)
+        if p is not None:
+            assert used in (0, 3)                                  # (0: the uniform tile's six-byte packing)
+            packs.append(p)
+    assert len(packs) >= 6
+    vals, st = codec.decode_batch(n_rows, n_cols, packs)
+    for k, p in enumerate(packs):
+        assert st[k] == 0, (k, st[k])
+        want = oracle.codec_canon_decode(n_rows, n_cols, p)
+        bad = np.nonzero(vals[k] != want)[0]
+        assert bad.size == 0, (k, bad.size, int(bad[0]), int(vals[k][bad[0]]), int(want[bad[0]]))
