@@ -353,24 +353,28 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
 // pass left every small residual of the stream as a byte in LDS (the others, and what the stage had no room for, at their cells
 // in the tile, marked 0x80 in the stage), so the tile is written ONCE, whole rows by neighbouring lanes -- expand() + the in-place
 // inverse wrote the residuals, read them back and wrote the values: 4.5 GB of HBM traffic per 0.93 GB of tiles on the
-// ETOPO1-shaped batch (profiles/hbm_traffic.json, round 3 v1), at a rate where that traffic is no longer free.
+// ETOPO1-shaped batch (profiles/hbm_traffic.json, round 3 v1).
 //   out[i][j] = res[i][j] + out[i][j-1] + out[i-1][j] - out[i-1][j-1]   (int32, wrapping)   unrolls to
 //   out[i][j] = out[0][j] + out[i][0] - seed + SUM(r = 1..i) SUM(m = 1..j) res[r][m]:
-// row 0 and column 0 are running sums of their residuals from the seed; the double sum is a row-wise prefix sum (DPP scan over
-// the lanes of a wave, a carry between the 64-column segments) accumulated down the rows (a register per segment).  The rows are
-// dealt out in DEC_WAVES blocks, a wave each; the sums of the blocks above a wave's own come from a cheaper pre-pass (column
-// sums per block, then ONE row-wise prefix sum per block) through LDS.  Row 0 and column 0 take part as rows / columns of
-// zero residuals, so every wave stores whole rows.  Scratch: the lookup table (dead after the value pass).
-constexpr int CD_FUSE_NSEG = 4;                                   // 64-column segments a lane keeps sums for: nC <= 256
+// row 0 and column 0 are running sums of their residuals from the seed; the double sum is a row-wise prefix sum accumulated
+// down the rows.  A lane owns FOUR neighbouring columns (nC <= 256: a wave spans a row): one 4-byte read of the stage, a prefix
+// over its four values, a DPP scan over the lanes' sums, four accumulators that run down the rows, one 16-byte store.  The rows
+// are dealt out in DEC_WAVES blocks, a wave each; the sums of the blocks above a wave's own come from a pre-pass -- column sums
+// per block (the four bytes added up as two pairs of 16-bit fields), then ONE row-wise prefix sum per block -- through LDS.
+// Row 0 and column 0 take part as rows / columns of zero residuals, so every wave stores whole rows.  Scratch: the lookup
+// table (dead after the value pass).  (First version, a lane per column in 64-column segments: 14 K vector instructions per
+// ETOPO1-shaped tile, as many as expand() + the inverse it replaced; this one: half of that.)
 __device__ __forceinline__ bool cd_fuse_eligible(int model, uint32_t nR, uint32_t nC, uint32_t stageCap)
 {
-    return CD_NCUR == 1 && DEC_WAVES >= 2 && model == 3 && nR >= 2u && nC >= 2u && nC <= 64u * CD_FUSE_NSEG && stageCap > 0u &&
+    return CD_NCUR == 1 && DEC_WAVES >= 2 && model == 3 && nR >= 2u && nC >= 2u && nC <= 256u && stageCap >= 8u &&
+           (nR + DEC_WAVES - 1u) / DEC_WAVES <= 255u &&                       // rows per block: the 16-bit column sums of the pre-pass
            (uint32_t)(DEC_WAVES + 1) * nC + nR <= (1u << CD_LUT_BITS);
 }
 __device__ __forceinline__ void cd_fused_triangle(CanonDec &S, const CdCellSink &sink, uint32_t seed, uint32_t nR, uint32_t nC,
                                                   uint32_t *__restrict__ o)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = gf_wave_id();                           // (in an SGPR: the row loops and their addresses are scalar)
     uint32_t *row0 = S.lut, *col0 = row0 + nC, *T = col0 + nR;    // out[0][*], out[*][0], block sums [DEC_WAVES][nC]
     const uint32_t W = nC - 1u, H = nR - 1u, nHead = W + H;
     // residual of stream element k, whose cell is `cell`
@@ -395,65 +399,111 @@ __device__ __forceinline__ void cd_fused_triangle(CanonDec &S, const CdCellSink 
         }
         if (lane == 0u) dst[0] = seed;
     }
+    const uint32_t *stAw = reinterpret_cast<const uint32_t *>(sink.stA), *stBw = reinterpret_cast<const uint32_t *>(sink.stB);
+    const uint32_t j0 = 4u * lane;                                // the lane's columns: j0 .. j0 + 3
+    // the staged bytes of stream elements p0 + j0 .. + 3 (p0 wave-uniform); markers where the stage does not hold the four in
+    // one piece (res() sorts those out)
+    auto fetch4 = [&](uint32_t p0) -> uint32_t {
+        const uint32_t pEnd = p0 + 4u * 63u + 3u;                 // the last byte any lane asks for
+        uint32_t x;
+        if (pEnd < sink.capA || (p0 >= sink.capA && pEnd < sink.cap)) {         // (wave-uniform) one part of the stage holds them all
+            const bool inA = pEnd < sink.capA;
+            const uint32_t *w = inA ? stAw : stBw;
+            const uint32_t off = (inA ? p0 : p0 - sink.capA) + j0;
+            x = __builtin_amdgcn_alignbyte(w[(off >> 2) + 1u], w[off >> 2], off & 3u);
+        } else {
+            const uint32_t p = p0 + j0;
+            const bool inA = p + 3u < sink.capA, inB = p >= sink.capA && p + 3u < sink.cap;
+            const uint32_t *w = inA ? stAw : stBw;
+            const uint32_t off = inA ? p : inB ? p - sink.capA : 0u;
+            x = __builtin_amdgcn_alignbyte(w[(off >> 2) + 1u], w[off >> 2], off & 3u);
+            x = (inA || inB) ? x : 0x80808080u;
+        }
+        return x;
+    };
+    auto hasMarker = [](uint32_t x) -> bool {                     // some byte is 0x80
+        const uint32_t y = x ^ 0x80808080u;
+        return ((y - 0x01010101u) & ~y & 0x80808080u) != 0u;
+    };
     // ---- pre-pass: T[b][j] = SUM(rows r of block b) SUM(m = 1..j) res[r][m]
     const uint32_t RB = (nR + DEC_WAVES - 1u) / DEC_WAVES;
     const uint32_t r0 = min(nR, wave * RB), r1 = min(nR, r0 + RB);
     {
-        uint32_t cs[CD_FUSE_NSEG];
+        uint32_t ev = 0, od = 0, corr[4] = {0u, 0u, 0u, 0u};      // bytes + 128 of columns j0, j0 + 2 / j0 + 1, j0 + 3 as 16-bit fields
+        const uint32_t rFirst = max(r0, 1u);
+        for (uint32_t r = rFirst; r < r1; r++) {
+            const uint32_t kRow = nHead + (r - 1u) * W - 1u, cRow = r * nC;     // element of (r, j): kRow + j
+            const uint32_t x = fetch4(kRow);
+            if (hasMarker(x)) {                                   // (rare) the marker counts as -128 below
 #pragma unroll
-        for (int s = 0; s < CD_FUSE_NSEG; s++) cs[s] = 0;
-        for (uint32_t r = max(r0, 1u); r < r1; r++) {
-            const uint32_t kRow = nHead + (r - 1u) * W - 1u, cRow = r * nC;
-#pragma unroll
-            for (int s = 0; s < CD_FUSE_NSEG; s++) {
-                const uint32_t j = (uint32_t)s * 64u + lane;
-                if ((uint32_t)s * 64u < nC) {
-                    uint32_t v = 0;
-                    if (j >= 1u && j < nC) v = res(kRow + j, cRow + j);
-                    cs[s] += v;
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t j = j0 + (uint32_t)i;
+                    if (((x >> (8 * i)) & 0xffu) == 0x80u && j >= 1u && j < nC) corr[i] += res(kRow + j, cRow + j) + 128u;
                 }
             }
+            const uint32_t y = x ^ 0x80808080u;
+            ev += y & 0x00FF00FFu;
+            od += (y >> 8) & 0x00FF00FFu;
         }
-        uint32_t carry = 0;
-#pragma unroll
-        for (int s = 0; s < CD_FUSE_NSEG; s++) {
-            const uint32_t j = (uint32_t)s * 64u + lane;
-            if ((uint32_t)s * 64u < nC) {
-                const uint32_t v = gf_wave_incl_scan(cs[s]) + carry;
-                if (j < nC) T[wave * nC + j] = v;
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-            }
-        }
+        const uint32_t bias = r1 > rFirst ? 128u * (r1 - rFirst) : 0u;
+        uint32_t c0 = (ev & 0xFFFFu) - bias + corr[0], c1 = (od & 0xFFFFu) - bias + corr[1];
+        const uint32_t c2 = (ev >> 16) - bias + corr[2], c3 = (od >> 16) - bias + corr[3];
+        if (lane == 0u) c0 = 0;                                   // column 0 has no residuals (the byte there is someone else's)
+        const uint32_t p1 = c0 + c1, p2 = p1 + c2, p3 = p2 + c3;
+        const uint32_t ex = gf_wave_incl_scan(p3) - p3;
+        uint32_t *Tw = T + wave * nC + j0;
+        if (j0 < nC) Tw[0] = ex + c0;
+        if (j0 + 1u < nC) Tw[1] = ex + p1;
+        if (j0 + 2u < nC) Tw[2] = ex + p2;
+        if (j0 + 3u < nC) Tw[3] = ex + p3;
     }
     __syncthreads();
-    // ---- the tile, row by row
-    uint32_t colBase[CD_FUSE_NSEG], acc[CD_FUSE_NSEG];
+    // ---- the tile, row by row: acc = out[0][j] - seed + the double sum down to the row
+    uint32_t acc[4];
 #pragma unroll
-    for (int s = 0; s < CD_FUSE_NSEG; s++) {
-        const uint32_t j = (uint32_t)s * 64u + lane;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t j = j0 + (uint32_t)i;
         uint32_t b = 0;
         if (j < nC) {
             b = row0[j] - seed;
             for (uint32_t w = 0; w < wave; w++) b += T[w * nC + j];
         }
-        colBase[s] = b;
-        acc[s] = 0;
+        acc[i] = b;
     }
     for (uint32_t r = r0; r < r1; r++) {
-        const uint32_t kRow = nHead + (r - 1u) * W - 1u, cRow = r * nC;
+        const uint32_t cRow = r * nC;
         const uint32_t left = col0[r];
-        uint32_t carry = 0;
-#pragma unroll
-        for (int s = 0; s < CD_FUSE_NSEG; s++) {
-            const uint32_t j = (uint32_t)s * 64u + lane;
-            if ((uint32_t)s * 64u < nC) {
-                uint32_t v = 0;
-                if (r >= 1u && j >= 1u && j < nC) v = res(kRow + j, cRow + j);
-                v = gf_wave_incl_scan(v) + carry;
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-                acc[s] += v;
-                if (j < nC) o[cRow + j] = colBase[s] + left + acc[s];
+        uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (r >= 1u) {
+            const uint32_t kRow = nHead + (r - 1u) * W - 1u;
+            const uint32_t x = fetch4(kRow);
+            v0 = (uint32_t)(int32_t)(int8_t)x;
+            v1 = (uint32_t)(int32_t)(int8_t)(x >> 8);
+            v2 = (uint32_t)(int32_t)(int8_t)(x >> 16);
+            v3 = (uint32_t)((int32_t)x >> 24);
+            if (hasMarker(x)) {                                   // (rare)
+                if ((x & 0xffu) == 0x80u && j0 >= 1u && j0 < nC) v0 = res(kRow + j0, cRow + j0);
+                if (((x >> 8) & 0xffu) == 0x80u && j0 + 1u < nC) v1 = res(kRow + j0 + 1u, cRow + j0 + 1u);
+                if (((x >> 16) & 0xffu) == 0x80u && j0 + 2u < nC) v2 = res(kRow + j0 + 2u, cRow + j0 + 2u);
+                if ((x >> 24) == 0x80u && j0 + 3u < nC) v3 = res(kRow + j0 + 3u, cRow + j0 + 3u);
             }
+            if (lane == 0u) v0 = 0;
+        }
+        const uint32_t p1 = v0 + v1, p2 = p1 + v2, p3 = p2 + v3;
+        const uint32_t ex = gf_wave_incl_scan(p3) - p3;
+        acc[0] += ex + v0;
+        acc[1] += ex + p1;
+        acc[2] += ex + p2;
+        acc[3] += ex + p3;
+        uint32_t *dst = o + cRow + j0;
+        if (j0 + 3u < nC) {
+            GfU4 q;
+            q.x = acc[0] + left; q.y = acc[1] + left; q.z = acc[2] + left; q.w = acc[3] + left;
+            *reinterpret_cast<GfU4 *>(dst) = q;
+        } else {
+            if (j0 < nC) dst[0] = acc[0] + left;
+            if (j0 + 1u < nC) dst[1] = acc[1] + left;
+            if (j0 + 2u < nC) dst[2] = acc[2] + left;
         }
     }
     __syncthreads();
@@ -476,7 +526,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     do {                                                                                   \
         if (stamps && threadIdx.x == 0) stamps[i] = (uint32_t)__builtin_amdgcn_s_memtime(); \
     } while (0)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     if (tid == 0) { S.parseStatus = GF_K_OK; S.runStatus = GF_K_OK; S.qStar = 0xFFFFFFFFu; S.carry = 0; }
     __syncthreads();
     // ---------------- phase 0: code tables ----------------

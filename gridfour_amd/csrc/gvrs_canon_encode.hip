@@ -211,7 +211,7 @@ __device__ bool cpack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC,
                                  const uint32_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                  PackState &ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = gf_wave_id();
     cellEnd = min(cellEnd, nCells);
     const uint32_t carryWord = wave_windows_begin(win, waveSum);
     const uint32_t quarter = (((cellEnd - cellBegin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
     __shared__ CanonPersist P;
     __shared__ CanonUnion S;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
 
     GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h

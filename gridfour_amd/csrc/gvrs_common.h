@@ -132,6 +132,18 @@ __device__ __forceinline__ uint32_t gf_lane_xor(uint32_t v, int j)
 #endif
 }
 
+// The wave's index inside its workgroup as a SCALAR (v_readfirstlane): written `threadIdx.x >> 6` the compiler has to treat it,
+// and every loop bound, address and branch that derives from it, as per-lane values -- vector registers and exec-mask loops
+// where scalar registers and scalar branches do (seen in the ISA of the canonical decoder's row loops, round 3).
+__device__ __forceinline__ uint32_t gf_wave_id()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    return 0;                                                                                      // host pass of hipcc: never executed
+#endif
+}
+
 // Wave64 inclusive prefix sum with DPP row shifts/broadcasts: 6 VALU steps, no LDS crossbar
 // (a __shfl_up ladder costs 6 dependent ds_bpermute round trips).
 __device__ __forceinline__ uint32_t gf_wave_incl_scan(uint32_t v)

@@ -659,7 +659,7 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *c
         uint32_t qv[NCUR];
 #pragma unroll
         for (int i = 0; i < NCUR; i++) {
-            const uint32_t slot = (tid >> 6) * (64u * NCUR) + (uint32_t)i * 64u + (tid & 63u);
+            const uint32_t slot = gf_wave_id() * (64u * NCUR) + (uint32_t)i * 64u + (tid & 63u);
             qv[i] = slot < nList ? list[slot] : 0xFFFFFFFFu;
         }
         runRound(false, qv);
@@ -1399,7 +1399,7 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
 #else
 #define GF_TSTAMP(i) do { (void)stamps; } while (0)
 #endif
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = gf_wave_id();
     const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
     const uint32_t nDw = (nM32 + 3u) >> 2, bmWords = (nM32 + 31u) >> 5;
     m32_mark_starts(S, m32, nM32, bm, wb);
@@ -1958,7 +1958,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
     constexpr bool ANALYZE = MODE == DEC_ANALYZE;
     constexpr bool FAST = MODE == DEC_FAST;
 
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
@@ -2245,7 +2245,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void k_lsop_unpack_m32(GfLsopM32Arg
     __shared__ DecShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
 
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t nInit = 4u * nR + 2u * nC - 9u, nInt = (nR - 2u) * (nC - 4u);
     const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);

@@ -12,7 +12,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 // exclusive scan over the workgroup (two barriers); *total = sum over all threads
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *waveSum, uint32_t *total)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (int)gf_wave_id();
     const uint32_t incl = wave_incl_scan(v, lane);
     if (lane == 63) waveSum[wave] = incl;
     __syncthreads();
@@ -91,7 +91,7 @@ constexpr int COL_BATCH = DEC_THREADS > 256 ? 8 : 16;  // rows of a column in fl
 __device__ __forceinline__ void gf_predictor_inverse(int model, uint32_t seed, uint32_t *o, uint32_t nR, uint32_t nC,
                                                      uint32_t *stamp)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     if (model != 4) {
         // Triangle: column sums of the interior residuals first (needs row 0 still as residuals)
         if (model == 3) {

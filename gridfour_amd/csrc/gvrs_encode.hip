@@ -429,7 +429,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
     __shared__ EncPersist P;
     __shared__ EncScratchT<FAST> S;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     if constexpr (!FAST) {
         if (a.retryFlag && *a.retryFlag == 0u) return;               // the fast kernel finished every tile

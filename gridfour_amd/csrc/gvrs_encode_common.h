@@ -22,7 +22,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 // exclusive scan over the workgroup; *total = sum over all threads
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *waveSum, uint32_t *total)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (int)gf_wave_id();
     uint32_t incl = wave_incl_scan(v, lane);
     if (lane == 63) waveSum[wave] = incl;
     __syncthreads();
@@ -248,7 +248,7 @@ __device__ __forceinline__ uint32_t wave_windows_begin(uint32_t *win, uint32_t *
 __device__ __forceinline__ bool wave_windows_end(uint32_t *win, uint32_t *waveSum, uint32_t carryWord, uint32_t bits, bool fits,
                                                  uint32_t *__restrict__ out32, uint32_t slotWords, PackState &ps)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = gf_wave_id();
     if (lane == 0 && fits) waveSum[wave] = bits;
     __syncthreads();
     uint32_t L[ENC_WAVES];

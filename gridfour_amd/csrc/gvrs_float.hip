@@ -72,7 +72,7 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_encode(const uint3
             continue;
         }
         // any shape: whole waves walk 64 consecutive cells so that one ballot yields 8 sign bytes
-        for (uint32_t base = (threadIdx.x >> 6) * 64u; base < n; base += FLT_THREADS) {
+        for (uint32_t base = gf_wave_id() * 64u; base < n; base += FLT_THREADS) {
             const uint32_t i = base + lane;
             const bool in = i < n;
             const uint32_t v = in ? c[i] : 0u;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(FLT_THREADS) void k_float_planes_decode(const uint8
     __shared__ uint32_t col0[3][1024];          // decoded first cells of the rows (three mantissa planes), by chunk
     const uint32_t nR = (uint32_t)nRows, nC = (uint32_t)nCols, n = nR * nC;
     const uint32_t nSign = (n + 7u) >> 3;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (int)gf_wave_id();
     GF_FOR_WG_TILE(t, nTiles) {                                           // no tile loop: see gvrs_kernels.h
         const uint8_t *pSign = planes + t * planeStride;
         const uint8_t *pExp = pSign + nSign, *pM1 = pExp + n, *pM2 = pM1 + n, *pM3 = pM2 + n;

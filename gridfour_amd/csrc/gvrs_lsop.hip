@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT_WGS) void k_lsop_predict(GfLso
 {
     __shared__ LsopShared S;
     extern __shared__ __attribute__((aligned(16))) int32_t lsopRing[];      // four rows of the tile (lsop_gram_rows)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t nInit = lsop_n_init(nR, nC), nInt = lsop_n_interior(nR, nC);
 
@@ -483,7 +483,7 @@ __device__ bool p2_pack_array_waves(const int32_t *__restrict__ arr, uint32_t be
                                     uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps,
                                     uint32_t slotWords)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = gf_wave_id();
     const uint32_t carryWord = wave_windows_begin(win, waveSum);
     const uint32_t quarter = (((end - begin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
     const uint32_t segBegin = min(end, begin + wave * quarter), segEnd = min(end, segBegin + quarter);
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
 {
     __shared__ Pack2Persist P;
     __shared__ Pack2Union S;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
 
     GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
         if (a.inStatus[t] != GF_K_OK) {
@@ -747,7 +747,7 @@ struct GfLsopReconArgs {
 __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const size_t wavesPerGrid = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t wavesPerGrid = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t nInit = lsop_n_init(nR, nC);
     const uint32_t wI = nC - 4u;
