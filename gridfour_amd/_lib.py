@@ -113,6 +113,7 @@ SIGNATURES = {
     "gf_readahead_submit": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     "gf_readahead_pending": (C.c_int, [_vp]),
     "gf_readahead_take": (C.c_int, [_vp, C.c_int32, C.c_size_t, _vp, _vp, _vp, C.POINTER(C.c_size_t)]),
+    "gf_readahead_cells": (C.c_size_t, [_vp]),
     "gf_readahead_counters": (None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gf_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     "gf_multi_destroy": (None, [_vp]),

@@ -180,6 +180,8 @@ const char *gf_status_string(int s)
 }
 
 const char *gf_last_error(void) { return g_lastError.c_str(); }
+// (library-internal: gvrs_multi.hip hands the text of a failing shard's thread to the thread that called gf_*_multi)
+void gf_internal_set_last_error(const char *text) { g_lastError = text ? text : ""; }
 
 int gf_device_count(void)
 {

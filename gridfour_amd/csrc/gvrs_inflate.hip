@@ -49,9 +49,10 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin
 // Canonical Huffman tables from n code lengths (RFC 1951 3.2.2), the whole wave: count per length, the symbols in canonical
 // order, and the first-level table (code bits reversed: the stream delivers a code's first bit in the lowest position).
 // Returns 0, or -1 for an over-subscribed or (not allowed) incomplete set -- zlib's inflate_table rules: an incomplete set
-// is accepted only when it consists of a single 1-bit code.
+// is accepted only when it consists of a single 1-bit code, and never for the code-length code (clTable: `left > 0 && (type ==
+// CODES || max != 1)`, inftrees.c); -2: no code at all (the caller does what zlib does with its invalid-code marker table).
 __device__ int inf_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *symOrder, uint16_t *table, uint32_t tbits,
-                         uint32_t lane)
+                         uint32_t lane, bool clTable = false)
 {
     // counts per length
     if (lane < 16) count[lane] = 0;
@@ -86,7 +87,7 @@ __device__ int inf_build(const uint8_t *lens, uint32_t n, uint16_t *count, uint1
     for (uint32_t i = lane; i < (1u << tbits); i += 64) table[i] = 0;
     __builtin_amdgcn_wave_barrier();
     if (over) return -1;
-    if (left > 0 && !(nCodes == 1 && maxLen == 1)) return nCodes == 0 ? -2 : -1;    // -2: no codes at all (caller decides)
+    if (left > 0 && (clTable || !(nCodes == 1 && maxLen == 1))) return nCodes == 0 ? -2 : -1;    // -2: no codes at all (caller decides)
     // rank of every symbol among those of its length -> canonical position and code
     uint32_t seen[16];
 #pragma unroll
@@ -331,7 +332,17 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(GfInflateArgs a)
                 __builtin_amdgcn_wave_barrier();
                 if (z.starved) break;
                 // the code-length code: its lengths sit in lens[0..19); tables into cl / (reused) dCount, dSym
-                if (inf_build(T.lens, 19, T.dCount, T.dSym, T.cl, 7, lane) != 0) { status = GF_K_ERR_FORMAT; break; }
+                const int rcl = inf_build(T.lens, 19, T.dCount, T.dSym, T.cl, 7, lane, true);
+                if (rcl == -2) {
+                    // No code-length code at all: zlib's table for that is two invalid-code markers of one bit and value 0, and
+                    // CODELENS takes `val < 16` before it looks at the marker -- every length reads as 0, a bit each; the block
+                    // then fails on its missing end-of-block code, unless the input runs out first (no error then)
+                    for (uint32_t i = 0; i < nLL + nD && !z.starved; i++) (void)inf_bits(z, 1);
+                    if (z.starved) break;
+                    status = GF_K_ERR_FORMAT;
+                    break;
+                }
+                if (rcl != 0) { status = GF_K_ERR_FORMAT; break; }
                 // the literal/length and distance code lengths, run-length coded (serial)
                 uint32_t idx = 0;
                 bool bad = false;

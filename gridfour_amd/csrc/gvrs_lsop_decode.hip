@@ -88,8 +88,23 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
         const CdArraySink sink0{res, nInit};
         const uint32_t *pre = a.pre ? a.pre + t * GF_CANON_REC_WORDS : nullptr;
         uint16_t *const tok = reinterpret_cast<uint16_t *>(cdLdsText + capWords);      // token table of the synchronisation passes
-        int32_t st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias, tok)
-                               : cd_decode_stream(S, TG, pos, endBit, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias);
+        // The first stream ends where its end-of-text symbol says, which nobody knows beforehand: synchronising "to the end of
+        // the text" meant the whole packing, i.e. a full pass over the SECOND stream's bits with the first stream's code
+        // (a seventh of the kernel's instructions, round 3).  So the first attempt looks at 16 bits per initialiser + 1 Kbit
+        // only; a stream that is longer (no end-of-text symbol inside: any failure of the short attempt) is decoded again
+        // with the whole packing in view -- same values, same status as before either way.
+        const uint32_t pos0 = pos;
+        const uint32_t endShort = min(endBit, pos0 + 16u * nInit + 1024u);
+        int32_t st = GF_K_OK;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const uint32_t e = attempt == 0 ? endShort : endBit;
+            pos = pos0;
+            st = textInLds ? cd_decode_stream(S, TL, pos0, e, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias, tok)
+                           : cd_decode_stream(S, TG, pos0, e, nInit, nInit, sink0, &pos, &nv, nullptr, pre, bias);
+            st = (int32_t)GF_UNI((uint32_t)st);                   // (the same in every thread: a scalar, so that this is a scalar loop)
+            pos = GF_UNI(pos);
+            if (st == GF_K_OK || e == endBit) break;
+        }
         if (st == GF_K_OK) {
             const CdArraySink sink1{res + nInit, nInt};
             st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv, nullptr, nullptr, 0, tok)

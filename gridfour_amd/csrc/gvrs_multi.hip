@@ -15,10 +15,14 @@
 #include <cstring>
 #include <new>
 #include <functional>
+#include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/gvrs_hip_codec.h"
+
+// gf_last_error() is per thread: the text of a failing shard's thread is handed to the thread that called gf_*_multi (gvrs_api.hip)
+extern "C" void gf_internal_set_last_error(const char *text);
 
 struct gf_multi {
     std::vector<gf_context *> ctx;
@@ -117,6 +121,7 @@ gf_status encodeMulti(const EncodeHostFn &fn, gf_multi *m, int codecIndex, int n
         size_t t0 = 0, t1 = 0;
         std::vector<uint64_t> off;
         gf_status st = GF_OK;
+        std::string err;                          // gf_last_error() of the shard's thread (the text is per thread)
     };
     std::vector<Part> part(G);
     std::vector<std::thread> th;
@@ -134,13 +139,18 @@ gf_status encodeMulti(const EncodeHostFn &fn, gf_multi *m, int codecIndex, int n
                     free(m->part[g]);
                     m->part[g] = (uint8_t *)malloc(cap);
                     m->partCap[g] = m->part[g] ? cap : 0;
-                    if (!m->part[g]) { p.st = GF_ERR_HIP; return; }       // out of host memory: not the "grow the blob" status
+                    if (!m->part[g]) {                                    // out of host memory: not the "grow the blob" status
+                        p.st = GF_ERR_HIP;
+                        p.err = "gf_multi: no host memory for a shard's staging buffer";
+                        return;
+                    }
                 }
                 p.st = fn(m->ctx[g], codecIndex, nRows, nCols, n, values + p.t0 * cells, m->part[g], m->partCap[g], p.off.data(),
                           predictors ? predictors + p.t0 : nullptr, status ? status + p.t0 : nullptr);
                 if (p.st != GF_ERR_CAPACITY) break;
                 cap = (size_t)p.off[n] + 64;
             }
+            if (p.st != GF_OK) p.err = gf_last_error();
         });
     }
     for (auto &t : th) t.join();
@@ -150,7 +160,10 @@ gf_status encodeMulti(const EncodeHostFn &fn, gf_multi *m, int codecIndex, int n
     offsets[0] = 0;
     for (int g = 0; g < G; g++) {
         const Part &p = part[g];
-        if (p.st != GF_OK && r == GF_OK) r = p.st;
+        if (p.st != GF_OK && r == GF_OK) {
+            r = p.st;
+            gf_internal_set_last_error(p.err.c_str());            // the failing shard's text, for the caller's thread
+        }
         const size_t n = p.t1 - p.t0;
         for (size_t t = 0; t < n; t++) offsets[p.t0 + t + 1] = total + p.off[t + 1];
         total += n ? p.off[n] : 0;
@@ -176,6 +189,7 @@ gf_status decodeMulti(const DecodeHostFn &fn, gf_multi *m, int nRows, int nCols,
     const int G = (int)m->ctx.size();
     const size_t cells = (size_t)nRows * (size_t)nCols;
     std::vector<gf_status> st(G, GF_OK);
+    std::vector<std::string> err(G);
     std::vector<std::thread> th;
     for (int g = 0; g < G; g++) {
         th.emplace_back([&, g]() {
@@ -187,11 +201,15 @@ gf_status decodeMulti(const DecodeHostFn &fn, gf_multi *m, int nRows, int nCols,
             std::vector<uint64_t> rel(n + 1);
             for (size_t t = 0; t <= n; t++) rel[t] = offsets[t0 + t] - offsets[t0];
             st[g] = fn(m->ctx[g], nRows, nCols, n, blob + offsets[t0], rel.data(), values + t0 * cells, status ? status + t0 : nullptr);
+            if (st[g] != GF_OK) err[g] = gf_last_error();
         });
     }
     for (auto &t : th) t.join();
     for (int g = 0; g < G; g++)
-        if (st[g] != GF_OK) return st[g];
+        if (st[g] != GF_OK) {
+            gf_internal_set_last_error(err[g].c_str());
+            return st[g];
+        }
     return GF_OK;
 }
 

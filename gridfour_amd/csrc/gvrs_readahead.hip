@@ -12,6 +12,7 @@
 // Same roles as the reference's methods:
 //   gf_readahead_submit      submitDecompression   (the packing is copied; the call returns at once)
 //   gf_readahead_pending     getPendingTaskCount   (queued + in progress)
+//   gf_readahead_cells       cells of a tile (what a taker must have room for, per tile)
 //   gf_readahead_take        getTilesWithWaitForIndex: waits while wait_index is queued or in progress, then hands over
 //                            finished tiles
 // The assistant owns a context of its own on the cache's device (the reference's assistant owns its own CodecMaster,
@@ -207,6 +208,11 @@ gf_status gf_readahead_take(gf_readahead *ra, int32_t wait_index, size_t max_til
     const gf_status e = ra->workerError;
     ra->workerError = GF_OK;
     return e;
+}
+
+size_t gf_readahead_cells(gf_readahead *ra)
+{
+    return ra ? (size_t)ra->nRows * (size_t)ra->nCols : 0;
 }
 
 void gf_readahead_counters(gf_readahead *ra, uint64_t *n_batches, uint64_t *n_tiles)

@@ -404,8 +404,16 @@ JNIEXPORT jint JNICALL Java_org_gridfour_hip_HipCodecNative_readaheadTake(JNIEnv
     if (!ra) return 0;
     const jsize maxTiles = env->GetArrayLength(indices), nCells = env->GetArrayLength(cells);
     if (maxTiles == 0) return 0;
+    // gf_readahead_take writes `per` ints for every tile it hands over: the arrays must have room for maxTiles of them (a direct
+    // call of this static native with a shorter array would otherwise run over the native buffer)
+    const size_t per = gf_readahead_cells((gf_readahead *)(intptr_t)ra);
+    if ((size_t)nCells < (size_t)maxTiles * per || env->GetArrayLength(status) < maxTiles) {
+        jclass c = env->FindClass("java/lang/IllegalArgumentException");
+        if (c) env->ThrowNew(c, "readaheadTake: cells needs indices.length * nRows * nCols ints, status indices.length");
+        return 0;
+    }
     // (the wait happens here, in native code, with no Java array pinned)
-    std::vector<int32_t> idx((size_t)maxTiles), st((size_t)maxTiles), v((size_t)nCells + 1);
+    std::vector<int32_t> idx((size_t)maxTiles), st((size_t)maxTiles), v((size_t)maxTiles * per + 1);
     size_t n = 0;
     const gf_status s = gf_readahead_take((gf_readahead *)(intptr_t)ra, waitIndex, (size_t)maxTiles, idx.data(), v.data(), st.data(), &n);
     if (s != GF_OK) {
@@ -414,7 +422,6 @@ JNIEXPORT jint JNICALL Java_org_gridfour_hip_HipCodecNative_readaheadTake(JNIEnv
         return 0;
     }
     if (n) {
-        const size_t per = (size_t)nCells / (size_t)maxTiles;        // the caller sized cells for maxTiles tiles
         env->SetIntArrayRegion(indices, 0, (jsize)n, (const jint *)idx.data());
         env->SetIntArrayRegion(status, 0, (jsize)n, (const jint *)st.data());
         env->SetIntArrayRegion(cells, 0, (jsize)(n * per), (const jint *)v.data());

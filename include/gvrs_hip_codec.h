@@ -159,7 +159,13 @@ gf_status gf_host_free(void *p);
  * at most out_caps[i] bytes go to d_out + out_offsets[i]; d_produced[i] = bytes written, d_status[i] = GF_OK or GF_ERR_FORMAT
  * -- the outcome of ONE Inflater.inflate(byte[]) call on the whole input: it stops without error when room or input run
  * out, reports invalid data where zlib does (DataFormatException) and verifies the Adler-32 when the stream ends inside
- * the room.  The four descriptor arrays are host arrays; d_in, d_out, d_produced, d_status are device memory.       */
+ * the room.  The four descriptor arrays are host arrays; d_in, d_out, d_produced, d_status are device memory.
+ * Unlike the other _dev entry points this one ALLOCATES and BLOCKS: it uploads the descriptor arrays (a context-owned device
+ * buffer that grows on demand: hipMalloc on first use and when n_streams grows; a pageable-memory copy that the host waits
+ * for), so it is not capture-safe and is not covered by gf_context_reserve.  d_in must be 4-byte aligned and readable up to
+ * the end of the aligned dword that holds the last byte of every stream: the kernel reads whole aligned dwords, i.e. up to
+ * three bytes before a stream's first and after its last byte are touched (never used) -- leave 4 bytes of padding behind
+ * the last stream of an allocation.                                                                                     */
 gf_status gf_inflate_batch_dev(gf_context *ctx, void *stream, size_t n_streams, const uint8_t *d_in,
                                const uint64_t *in_offsets, const uint32_t *in_lengths, uint8_t *d_out,
                                const uint64_t *out_offsets, const uint32_t *out_caps, uint32_t *d_produced,
@@ -386,6 +392,7 @@ gf_status gf_readahead_submit(gf_readahead *ra, int32_t tile_index, const uint8_
 int gf_readahead_pending(gf_readahead *ra);
 gf_status gf_readahead_take(gf_readahead *ra, int32_t wait_index, size_t max_tiles, int32_t *indices, int32_t *values,
                             int32_t *status, size_t *n_out);
+size_t gf_readahead_cells(gf_readahead *ra);   /* n_rows * n_cols: gf_readahead_take writes that many ints per tile handed over */
 void gf_readahead_counters(gf_readahead *ra, uint64_t *n_batches, uint64_t *n_tiles);   /* GPU batches run, tiles decoded */
 
 /* ---- ICompressionDecoder.analyze for CodecHuffman (compress/CodecHuffman.java:172-234, compress/CodecStats.java:49-290):

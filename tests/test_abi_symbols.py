@@ -88,6 +88,7 @@ def test_handle_entry_points_reject_bad_arguments_without_a_device():
     n = C.c_size_t(0)
     assert L.gf_readahead_submit(None, 1, None, 0) == _lib.ERR_ARG
     assert L.gf_readahead_pending(None) == 0
+    assert L.gf_readahead_cells(None) == 0
     assert L.gf_readahead_take(None, 0, 0, None, None, None, C.byref(n)) == _lib.ERR_ARG
     L.gf_readahead_destroy(None)
     L.gf_multi_destroy(None)

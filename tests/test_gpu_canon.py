@@ -193,3 +193,27 @@ def test_triangle_packings_every_kind(codec, shape):
         want = oracle.codec_canon_decode(n_rows, n_cols, p)
         bad = np.nonzero(vals[k] != want)[0]
         assert bad.size == 0, (k, bad.size, int(bad[0]), int(vals[k][bad[0]]), int(want[bad[0]]))
+
+
+def test_saved_soak_case_quirk_stream(codec, golden_dir):
+    """tools/soak.py, seed 30031004 case 9894 (3 x 6, residuals of ~1e8 under Differencing): the packing the encoder writes for
+    one of its tiles holds a residual inside the gap between CanonicalHuffman.java:258 and :395 -- the reference cannot read it
+    back; the library writes the same bytes and refuses them with the same status as the oracle."""
+    import os
+    d = np.load(os.path.join(golden_dir, "soak", "soak_r03_30031004_case9894.npz"))
+    tiles, (n_rows, n_cols) = d["tiles"], map(int, d["shape"])
+    n_rows, n_cols = int(d["shape"][0]), int(d["shape"][1])
+    packs, _, status = codec.encode_batch(7, n_rows, n_cols, tiles)
+    refs = [oracle.codec_canon_encode(7, n_rows, n_cols, v)[0] for v in tiles]
+    assert [p for p in packs] == refs and (np.asarray(status) == 0).all()
+    vals, st = codec.decode_batch(n_rows, n_cols, refs)
+    n_bad = 0
+    for k, p in enumerate(refs):
+        try:
+            want = oracle.codec_canon_decode(n_rows, n_cols, p)
+        except IOError as ex:
+            n_bad += 1
+            assert st[k] == (-2 if "rc=-2" in str(ex) else -1), (k, st[k], str(ex))
+            continue
+        assert st[k] == 0 and np.array_equal(vals[k], want), k
+    assert n_bad == 1

@@ -307,3 +307,47 @@ def test_damaged_and_cut_short_at_once():
         else:
             assert st[i] == 0 and outs[i] == want, (i, st[i], prod[i], len(want))
     assert 0 < n_err < len(streams)
+
+
+def _bits_to_bytes(bits):
+    out = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        out[i >> 3] |= b << (i & 7)
+    return bytes(out)
+
+
+def test_code_length_code_sets_as_zlib():
+    """Dynamic-block headers whose code-length code is degenerate, whole and cut short at every byte: no code at all (zlib reads
+    every length as 0, a bit each, and fails on the missing end-of-block code -- or just runs out of input), a single one-bit
+    code (incomplete: rejected for this table even though a one-code distance set is allowed), and the complete two-code set
+    for comparison.  (inftrees.c: `left > 0 && (type == CODES || max != 1)`.)"""
+    def header(cl_lens, hlit=0, hdist=0):
+        bits = [1, 0, 1]                                           # BFINAL, BTYPE = 2 (dynamic), LSB first
+        bits += [(hlit >> i) & 1 for i in range(5)] + [(hdist >> i) & 1 for i in range(5)]
+        hclen = len(cl_lens) - 4
+        bits += [(hclen >> i) & 1 for i in range(4)]
+        for v in cl_lens:
+            bits += [(v >> i) & 1 for i in range(3)]
+        return bits
+    rng = np.random.default_rng(3)
+    tails = [list(rng.integers(0, 2, 400)), [0] * 400, [1] * 400]
+    heads = [header([0] * 19), header([0] * 4), header([1] + [0] * 18), header([0, 0, 0, 1] + [0] * 15),      # none; one 1-bit code
+             header([1, 1] + [0] * 17), header([0] * 3 + [1] + [0] * 10 + [1] + [0] * 4, hlit=3, hdist=2)]     # complete sets
+    streams, caps = [], []
+    for h in heads:
+        for t in tails:
+            raw = _bits_to_bytes(h + t)
+            z = b"\x78\x9c" + raw
+            for cut in list(range(3, 16)) + [len(z) // 2, len(z)]:
+                streams.append(z[:cut])
+                caps.append(4096)
+    outs, prod, st = _inflate(streams, caps)
+    n_err = 0
+    for i, s in enumerate(streams):
+        want, err = _host(s, caps[i])
+        if err:
+            n_err += 1
+            assert st[i] == -1, (i, st[i], prod[i], s[:8].hex(), len(s))
+        else:
+            assert st[i] == 0 and outs[i] == want, (i, st[i], prod[i], len(want), s[:8].hex(), len(s))
+    assert 0 < n_err < len(streams)

@@ -2,7 +2,10 @@
 """Randomised parity soak: random tile shapes, data kinds and seeds through every codec of the library against the oracle
 (encode bytes, chosen predictor / container type, decode, error statuses) for a wall-clock budget.  Not part of the test
 suite (tests/test_gpu_random_shapes.py is the fixed sample of it); prints the failing case's seed and stops.
-    python tools/soak.py [seconds] [seed]"""
+    python tools/soak.py [seconds] [seed]
+    python tools/soak.py replay <seed> <case> [out.npz]     the tiles of one case of a run, WITHOUT a GPU: the same loop with the
+                                                            oracle standing in for the library (the random draws depend on
+                                                            the oracle's packings only), saved for tests/ or a closer look"""
 import os
 import sys
 import time
@@ -25,16 +28,62 @@ def expect(fn, *args):
         return None, (-2 if "rc=-2" in str(ex) else -4)
 
 
+class _Dry:
+    """the oracle behind the library's batch interface (replay mode)"""
+    def __init__(self, enc=None, dec=None):
+        self.enc, self.dec = enc, dec
+
+    def encode_batch(self, ci, nr, nc, tiles):
+        packs, status = [], []
+        for v in tiles:
+            if self.enc is None:                                   # LSOP12
+                ref, typ = oracle.lsop12_encode(ci, nr, nc, v, True)
+                err = 0
+            else:
+                ref, err = expect(self.enc, ci, nr, nc, v)
+                typ = 0
+            packs.append(ref)
+            status.append(err if err else (1 if ref is None else 0))
+        if self.enc is None:
+            return packs, [oracle.lsop12_encode(ci, nr, nc, v, True)[1] for v in tiles], status
+        return packs, None, status
+
+    def decode_batch(self, nr, nc, packs):
+        vals, st = [], []
+        for p in packs:
+            try:
+                vals.append((self.dec or oracle.lsop12_decode)(nr, nc, p))
+                st.append(0)
+            except IOError as ex:
+                vals.append(np.zeros(nr * nc, np.int32))
+                st.append(1 if "rc=1" in str(ex) else -1)
+        return vals, np.array(st)
+
+    def encode_floats_batch(self, ci, nr, nc, f):
+        return [oracle.codec_float_encode(ci, nr, nc, f[t].view(np.uint32), 6) for t in range(f.shape[0])]
+
+    def decode_floats_batch(self, nr, nc, pk):
+        return np.stack([oracle.codec_float_decode(nr, nc, p) for p in pk]).view(np.float32), np.zeros(len(pk), np.int32)
+
+
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    replay = len(sys.argv) > 3 and sys.argv[1] == "replay"
+    budget = 1e9 if replay else float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    stop_at = int(sys.argv[3]) if replay else -1
     rng = np.random.default_rng(seed)
-    ctx = gridfour_amd.GvrsHipContext(0)
-    fams = [("huffman", gridfour_amd.CodecHuffmanHip(context=ctx), oracle.codec_huffman_encode, oracle.codec_huffman_decode),
-            ("canon", gridfour_amd.CodecCanonHuffmanHip(context=ctx), oracle.codec_canon_encode, oracle.codec_canon_decode),
-            ("deflate", gridfour_amd.CodecDeflateHip(context=ctx), oracle.codec_deflate_encode, oracle.codec_deflate_decode)]
-    lsop = gridfour_amd.LsCodecHip(context=ctx, deflate_enabled=True)
-    fl = gridfour_amd.CodecFloatHip(context=ctx, level=6)
+    if replay:
+        fams = [("huffman", _Dry(oracle.codec_huffman_encode, oracle.codec_huffman_decode), oracle.codec_huffman_encode, oracle.codec_huffman_decode),
+                ("canon", _Dry(oracle.codec_canon_encode, oracle.codec_canon_decode), oracle.codec_canon_encode, oracle.codec_canon_decode),
+                ("deflate", _Dry(oracle.codec_deflate_encode, oracle.codec_deflate_decode), oracle.codec_deflate_encode, oracle.codec_deflate_decode)]
+        lsop = fl = _Dry()
+    else:
+        ctx = gridfour_amd.GvrsHipContext(0)
+        fams = [("huffman", gridfour_amd.CodecHuffmanHip(context=ctx), oracle.codec_huffman_encode, oracle.codec_huffman_decode),
+                ("canon", gridfour_amd.CodecCanonHuffmanHip(context=ctx), oracle.codec_canon_encode, oracle.codec_canon_decode),
+                ("deflate", gridfour_amd.CodecDeflateHip(context=ctx), oracle.codec_deflate_encode, oracle.codec_deflate_decode)]
+        lsop = gridfour_amd.LsCodecHip(context=ctx, deflate_enabled=True)
+        fl = gridfour_amd.CodecFloatHip(context=ctx, level=6)
     t0 = time.time()
     n_cases = n_tiles = 0
     while time.time() - t0 < budget:
@@ -62,6 +111,11 @@ def main():
             tiles.append(t)
         tiles = np.stack(tiles)
         tag = "seed %d case %d shape %dx%d" % (seed, n_cases, nr, nc)
+        if n_cases == stop_at:
+            out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "gpurun_out", "soak_case.npz")
+            np.savez(out, tiles=tiles, shape=np.array([nr, nc]), seed=np.array([seed, n_cases]))
+            print("saved", tag, "->", out)
+            return
         for name, codec, enc, dec in fams:
             packs, _, status = codec.encode_batch(7, nr, nc, tiles)
             good, idx = [], []
@@ -78,7 +132,14 @@ def main():
             if good:
                 vals, st = codec.decode_batch(nr, nc, good)
                 for k, t in enumerate(idx):
-                    assert st[k] == 0 and np.array_equal(vals[k], dec(nr, nc, good[k])), (tag, name, "decode", t, st[k])
+                    try:
+                        want = dec(nr, nc, good[k])
+                    except IOError:
+                        # (canon: a residual inside the -8388608 .. -8333608 gap of CanonicalHuffman.java:258 / :395 -- the
+                        # reference cannot read back what it wrote, and neither may the library; seed 30031004 case 9894)
+                        assert st[k] != 0, (tag, name, "undecodable stream accepted", t)
+                        continue
+                    assert st[k] == 0 and np.array_equal(vals[k], want), (tag, name, "decode", t, st[k])
                 # a damaged copy must not hang or crash and, when accepted, must decode as the oracle decodes it
                 bad = bytearray(good[0])
                 bad[int(rng.integers(1, len(bad)))] ^= 1 << int(rng.integers(0, 8))
