@@ -899,9 +899,10 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 
 
 // the flat scan of a tile through the wave-private windows, in as many cell ranges as its bit count asks for (a wave's
-// share of a range must fit its quarter of the window); a range that does not fit after all goes through pack_flat
+// share of a range must fit its quarter of the window); false: a range did not fit after all -- the tile is left to
+// k_huffman_pack_rare, which packs it again from its first bit
 template <int MODEL>
-__device__ __forceinline__ void pack_flat_ranges(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
+__device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                                  const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                                  PackState &ps, uint32_t slotWords, uint32_t textBits)
 {
@@ -911,9 +912,10 @@ __device__ __forceinline__ void pack_flat_ranges(const uint32_t *__restrict__ ti
     const uint32_t per = (((nCells + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);
     for (uint32_t b = 0; b < nCells; b += per) {
         const PackStateOk r = pack_flat_waves<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
-        if (r.ok) ps = r.ps;
-        else ps = pack_flat<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, b, b + per);
+        if (!r.ok) return false;
+        ps = r.ps;
     }
+    return true;
 }
 
 // k_huffman_pack: phase C of the encoder as its own kernel (see GfEncodeArgs::packRecs)
@@ -922,20 +924,22 @@ struct PackShared {
     uint32_t waveSum[ENC_WAVES];
 };
 
-__global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEncodeArgs a)
+// The packer proper has no calls and no stack: tiles whose codes do not fit the wave windows (a value of more than
+// (WIN_WORDS - 2) * 32 / STEP_CELLS bits, a single column, a range that overran its window after all) are marked in word 6 of
+// their record and packed by k_huffman_pack_rare behind it, through the general scans (pack_generic / pack_flat: calls with
+// frames, 128 bytes of scratch per lane -- which the packer of every tile used to carry for them).
+template <bool RARE>
+__device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackShared &P, uint32_t *win)
 {
-    __shared__ PackShared P;
-    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
-
     const int tid = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
-
-    GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
+    GF_FOR_TILES(t, a.nTiles, !RARE) {                                    // the packer: no tile loop (see gvrs_kernels.h)
         if (a.status[t] != GF_K_OK) continue;                             // declined, overflow: nothing to write
+        uint32_t *rec = a.packRecs + t * (size_t)GF_PACK_REC_WORDS;
+        if (RARE && rec[6] != 1u) continue;                               // (the same word in every thread)
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
-        GF_STAMP(6);
-        const uint32_t *rec = a.packRecs + t * (size_t)GF_PACK_REC_WORDS;
+        if (!RARE) GF_STAMP(6);
         const int model = (int)rec[0];
         const uint32_t treeEnd = rec[1], seed = rec[2], maxN = rec[3], maxLen = rec[4], textBits = rec[5];
         const uint32_t imgWords = (treeEnd + 31u) >> 5;
@@ -949,36 +953,70 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
         const uint32_t nStream = gf_stream_len(model, nR, nC);
         const uint64_t *tab = P.tab;
         const uint32_t elemMaxBits = max(1u, maxN * maxLen);
+        const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
         PackState ps;
         ps.bitBase = treeEnd;
         ps.wordBase = 0;
         window_flush(win, out32, ps);            // header + tree image
+        bool done = true;
         if (nStream > 0 && maxLen > 0) {
             const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
-            if (!fast) {
-                ps = pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
-            } else if (model == 1) {
-                pack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
-            } else if (model == 2) {
-                ps = pack_head<2>(tile, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
-                pack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
-            } else if (model == 3) {
-                ps = pack_head<3>(tile, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
-                pack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
+            if constexpr (RARE) {
+                if (!fast) {
+                    ps = pack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
+                } else if (model == 1) {
+                    ps = pack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                } else if (model == 2) {
+                    ps = pack_head<2>(tile, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                    ps = pack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                } else if (model == 3) {
+                    ps = pack_head<3>(tile, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                    ps = pack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                } else {
+                    ps = pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
+                }
             } else {
-                pack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
+                if (!fast) {
+                    done = false;
+                } else if (model == 1) {
+                    done = pack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                } else if (model == 2) {
+                    ps = pack_head<2>(tile, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                    done = pack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                } else if (model == 3) {
+                    ps = pack_head<3>(tile, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                    done = pack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                } else {
+                    done = pack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                }
             }
         }
-        GF_STAMP(7);
-        {
+        if (!RARE) {
+            GF_STAMP(7);
+            if (tid == 0) rec[6] = done ? 0u : 1u;
+        }
+        if (done) {
             const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
             const uint32_t remWords = (remBits + 31u) >> 5;
-            const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
             for (uint32_t j = tid; j < remWords; j += ENC_THREADS)
                 if (ps.wordBase + j < slotWords) out32[ps.wordBase + j] = win[j];
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEncodeArgs a)
+{
+    __shared__ PackShared P;
+    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+    huffman_pack_tiles<false>(a, P, win);
+}
+
+__global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_pack_rare(GfEncodeArgs a)
+{
+    __shared__ PackShared P;
+    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+    huffman_pack_tiles<true>(a, P, win);
 }
 
 
@@ -1164,6 +1202,7 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
         hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid), dim3(ENC_THREADS), 0, stream, g);
     }
     hipLaunchKernelGGL(k_huffman_pack, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_huffman_pack_rare, dim3(grid < 1024 ? grid : 1024), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -268,3 +268,26 @@ def test_tree_tie_breaking_on_device(codec):
         codec.ctx.synchronize()
         assert b.get_dec_status()[0] == 0 and np.array_equal(b.get_decoded()[0], v)
         b.free()
+
+
+@pytest.mark.parametrize("shape", [(120, 150), (200, 200), (64, 64)], ids=lambda s: "%dx%d" % s)
+def test_bits_crowded_into_part_of_the_tile(codec, shape):
+    """The packer deals a tile's cells out to its waves by count, with room for a quarter more bits than the average share: tiles
+    whose bits crowd into one stretch of the cells (noise in the first, a middle or the last rows, flat elsewhere; every other
+    row; long codes in a corner) overrun a wave's window and are packed again by k_huffman_pack_rare -- same bytes as the
+    oracle's either way."""
+    n_rows, n_cols = shape
+    rng = np.random.default_rng(n_rows + n_cols)
+    tiles = []
+    for lo, hi in ((0, n_rows // 5), (n_rows // 2, n_rows // 2 + n_rows // 6), (n_rows - n_rows // 7, n_rows), (0, n_rows)):
+        for amp in (200, 30000):
+            v = np.full((n_rows, n_cols), 1000, np.int64)
+            v[lo:hi] += rng.integers(-amp, amp, (hi - lo, n_cols))
+            tiles.append(v.ravel().astype(np.int32))
+    v = np.full((n_rows, n_cols), 7, np.int64)
+    v[::2] += rng.integers(-90, 90, (len(range(0, n_rows, 2)), n_cols))
+    tiles.append(v.ravel().astype(np.int32))
+    v = rng.integers(-2, 3, (n_rows, n_cols)).astype(np.int64)
+    v[: n_rows // 8, : n_cols // 3] = rng.integers(-2_000_000_000, 2_000_000_000, (n_rows // 8, n_cols // 3))
+    tiles.append(v.ravel().astype(np.int32))
+    _check_tiles(codec, n_rows, n_cols, np.stack(tiles))
