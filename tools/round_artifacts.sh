@@ -17,6 +17,7 @@ GF_COMMIT=$GF_COMMIT bash tools/pmc_issue.sh $OUT/issue_counts.json etopo1 "huff
 cp $OUT/issue_counts.json profiles/issue_counts.json 2>/dev/null
 bash tools/pmc_why.sh $OUT both > $OUT/pmc_why.log 2>&1
 bash tools/pmc_phases_dec.sh > $OUT/pmc_phases_dec.txt 2>&1
+bash tools/pmc_phases_canon.sh > $OUT/pmc_phases_canon.txt 2>&1
 [ -x tools/bin/valu_rate ] && tools/bin/valu_rate > $OUT/valu_rate.txt 2>&1
 timeout 600 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench.json
 timeout 600 python3 bench.py --workload etopo1_nulls --cpu-sample-tiles 0 2>/dev/null | tail -1 > $OUT/bench_etopo1_nulls.json
