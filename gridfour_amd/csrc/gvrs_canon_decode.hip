@@ -56,8 +56,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
     // (one subsequence per thread: every thread has its start in a register before the first value is staged, so all four
     // sync arrays serve as stage; two per thread: the starts of the second half are still needed, qe / qc only)
     uint8_t *const stageA = reinterpret_cast<uint8_t *>(CD_NCUR == 1 ? S.qs : S.qe);
-    uint8_t *const stageB = reinterpret_cast<uint8_t *>(cdLdsText + capWords);
-    const uint32_t stageCapA = (uint32_t)((CD_NCUR == 1 ? 4 : 2) * sizeof(S.qe)), stageCap = stageCapA + a.ldsStageBytes;
+    const uint32_t stageCapA = (uint32_t)((CD_NCUR == 1 ? 4 : 2) * sizeof(S.qe));
     static_assert(offsetof(CanonDec, qe) == offsetof(CanonDec, qs) + sizeof(S.qs) && offsetof(CanonDec, qx) == offsetof(CanonDec, qc) + sizeof(S.qc),
                   "qs .. qx form one stretch of LDS");
     static_assert(offsetof(CanonDec, qc) == offsetof(CanonDec, qe) + sizeof(S.qe), "qe and qc form one stretch of LDS");
@@ -102,6 +101,9 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
         // ---------------- phases 0-2: the canonical-Huffman stream, values to their cells ----------------
         const uint32_t nStream = gf_stream_len(model, nR, nC);
         // Triangle tiles of the one-subsequence-per-thread build: the staged residuals become the tile in one go (cd_fused_triangle)
+        // (the stage behind the sync arrays: what this packing leaves of the text buffer, then the bytes behind it)
+        uint8_t *const stageB = reinterpret_cast<uint8_t *>(cdLdsText + (textInLds ? needWords : 0u));
+        const uint32_t stageCap = stageCapA + (capWords - (textInLds ? needWords : 0u)) * 4u + a.ldsStageBytes;
 #ifdef GF_DIAG
         const bool fuse = cd_fuse_eligible(model, nR, nC, stageCap) && !(a.phaseLimit & 0x300);
         const CdCellSink sink{o, GfCellMap::make(model, nR, nC), nStream, !(a.phaseLimit & 0x100),
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
         uint32_t endPos, nValues;
         const uint32_t *pre = a.trees ? a.trees + t * GF_CANON_REC_WORDS : nullptr;
         // the token table of the synchronisation pass: in the value stage behind the text, which is idle until phase 2
-        uint16_t *const tok = a.ldsStageBytes >= (sizeof(uint16_t) << CD_LUT_BITS) ? reinterpret_cast<uint16_t *>(stageB) : nullptr;
+        uint16_t *const tok = a.ldsStageBytes >= (sizeof(uint16_t) << CD_LUT_BITS) ? reinterpret_cast<uint16_t *>(cdLdsText + capWords) : nullptr;
 #ifdef GF_DIAG
         const int diagLimit = a.phaseLimit & 0xff;
 #else

@@ -993,7 +993,10 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
         }
         if (!RARE) {
             GF_STAMP(7);
-            if (tid == 0) rec[6] = done ? 0u : 1u;
+            if (tid == 0) {
+                rec[6] = done ? 0u : 1u;
+                if (!done && a.retryFlag) atomicAdd(a.retryFlag + 1, 1u);  // (word 1: tiles left to k_huffman_pack_rare)
+            }
         }
         if (done) {
             const uint32_t remBits = ps.bitBase - ps.wordBase * 32u;
@@ -1016,6 +1019,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_pack_rare(GfEncodeAr
 {
     __shared__ PackShared P;
     __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+    if (a.retryFlag && a.retryFlag[1] == 0u) return;                      // the packer finished every tile
     huffman_pack_tiles<true>(a, P, win);
 }
 
@@ -1191,9 +1195,11 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (!a.packRecs) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
     const size_t nCells = (size_t)a.nRows * (size_t)a.nCols;
-    if (a.retryFlag && 6ull * nCells < (1ull << 23)) {
-        const hipError_t e = hipMemsetAsync(a.retryFlag, 0, 4, stream);
+    if (a.retryFlag) {                                                    // word 0: tiles for k_huffman_encode<false>, word 1: for k_huffman_pack_rare
+        const hipError_t e = hipMemsetAsync(a.retryFlag, 0, 8, stream);
         if (e != hipSuccess) return e;
+    }
+    if (a.retryFlag && 6ull * nCells < (1ull << 23)) {
         hipLaunchKernelGGL(k_huffman_encode<true>, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
         hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid < 2048 ? grid : 2048), dim3(ENC_THREADS), 0, stream, a);
     } else {

@@ -81,7 +81,7 @@ struct GfEncodeArgs {
     int predictorMask;
     uint32_t *debug;           // optional diagnostic dump (GF_ENC_DEBUG_WORDS per tile), normally null
     int phaseLimit;            // diagnostic: stop after phase A (1) / B (2); 0 = run everything
-    uint32_t *retryFlag;       // CodecHuffman: one device word; the fast encode kernel ORs 1 into it for every tile it leaves to
+    uint32_t *retryFlag;       // CodecHuffman: two device words (the second one counts the tiles k_huffman_pack leaves to k_huffman_pack_rare); the fast encode kernel ORs 1 into the first for every tile it leaves to
                                // the general kernel (status GF_K_RETRY inside the launch only); null: general kernel only
     uint32_t *packRecs;        // non-null (CodecHuffman only): k_huffman_encode stops after the selection and leaves per tile
                                // GF_PACK_REC_WORDS words (model, tree end bit, seed, maxN, maxLen, tree image, code table)

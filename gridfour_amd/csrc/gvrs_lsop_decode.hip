@@ -106,7 +106,16 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
             if (st == GF_K_OK || e == endBit) break;
         }
         if (st == GF_K_OK) {
-            const CdArraySink sink1{res + nInit, nInt};
+            // the interior residuals go through the byte stage of the canonical decoder (round 3): a thread walks its own stretch
+            // of the stream, so its 4-byte stores hit 64 different lines per instruction -- 3.7 GB of HBM writes for 0.93 GB of
+            // residuals on the ETOPO1-shaped batch (profiles/hbm_traffic.json).  The stage lies over the four sync arrays (one
+            // subsequence per thread: dead by then), the token table and the unused end of the text buffer; what does not fit goes straight out
+            // ... and the part of the text buffer this packing does not fill (the buffer is sized for 3/4 byte per cell)
+            const uint32_t usedWords = textInLds ? min(needWords, capWords) : 0u;
+            const CdCellSink sink1{reinterpret_cast<uint32_t *>(res + nInit), GfCellMap::make(4, 1u, 2u), nInt, true,
+                                   reinterpret_cast<uint8_t *>(S.qs), reinterpret_cast<uint8_t *>(cdLdsText + usedWords),
+                                   (uint32_t)(4 * sizeof(S.qe)), (uint32_t)(4 * sizeof(S.qe)) + (capWords - usedWords) * 4u + 4096u, 0u, false};
+            static_assert(CD_NCUR == 1, "the stage over all four sync arrays needs one subsequence per thread");
             st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv, nullptr, nullptr, 0, tok)
                            : cd_decode_stream(S, TG, pos, endBit, nInt, nInt, sink1, &pos, &nv);
         }
