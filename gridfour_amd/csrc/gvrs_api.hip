@@ -416,10 +416,14 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
             return n < cap ? n : cap;
         };
         const size_t waves256 = 4 * wgsPerCu(gf_canon_decode_lds_per_wg(a), 8), waves512 = 8 * wgsPerCu(gf_canon_decode_lds_per_wg_t512(b), 4);
-        // ... where the tile is large enough to give every thread a subsequence (at least 128 bits each: 70x100 tiles have 230
-        // of them and run 2.50 ms per 33,000 tiles with 256 threads against 2.81 with 512; 120x150: 2.07 against 1.88,
-        // 200x200: 5.13 against 4.60)
-        if (2 * waves512 >= 3 * waves256 && (size_t)nRows * (size_t)nCols >= 12000)
+        // ... where the tile is large enough to give most threads a subsequence (at least 128 bits each).  With the fused Triangle
+        // inverse and the whole stream staged (late round 3) the 512-thread build wins from about 7,000 cells on: 90x120 tiles
+        // 1.69 -> 1.37 ms per 16,000 tiles, 100x110 1.74 -> 1.40, 70x100 2.24 -> 2.22 per 33,000, 64x64 the same either way
+        // (before those two: 70x100 2.50 with 256 threads against 2.81 with 512, and the bound was 12,000 cells)
+#ifndef GF_CANON_T512_MIN_CELLS
+#define GF_CANON_T512_MIN_CELLS 7000
+#endif
+        if (2 * waves512 >= 3 * waves256 && (size_t)nRows * (size_t)nCols >= GF_CANON_T512_MIN_CELLS)
             GF_HIP(gf_launch_canon_decode_t512(b, stream ? (hipStream_t)stream : c->stream, grid));
         else GF_HIP(gf_launch_canon_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
     } else {

@@ -12,7 +12,7 @@ b.synth_dem(0x9E3779B97F4A7C15 + 2, 144)
 L = lib(); L.gf_internal_set_phase_limits.argtypes = [C.c_int, C.c_int]
 b.encode(); ctx.synchronize()
 vals = b.get_values()
-for warm in (128, 64, 96, 112, 144, 160, 192, 224, 255, 128):
+for warm in [int(x) for x in sys.argv[1:]] or (128, 64, 96, 112, 144, 160, 192, 224, 255, 128):
     L.gf_internal_set_phase_limits(0, warm << 8)
     for _ in range(2): b.decode()
     tm = GpuTimer(ctx); tm.start()
