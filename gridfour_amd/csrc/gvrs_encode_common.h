@@ -248,7 +248,10 @@ __device__ __forceinline__ uint32_t wave_windows_begin(uint32_t *win, uint32_t *
 __device__ __forceinline__ bool wave_windows_end(uint32_t *win, uint32_t *waveSum, uint32_t carryWord, uint32_t bits, bool fits,
                                                  uint32_t *__restrict__ out32, uint32_t slotWords, PackState &ps)
 {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = gf_wave_id();
+    // (the thread index worked out afresh -- lane by mbcnt, wave from the scalar -- instead of kept alive across the caller's
+    // scan loop, where the register allocator had no room for it at 64 VGPRs and parked it in scratch)
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wave = gf_wave_id();
+    const uint32_t tid = wave * 64u + lane;
     if (lane == 0 && fits) waveSum[wave] = bits;
     __syncthreads();
     uint32_t L[ENC_WAVES];
