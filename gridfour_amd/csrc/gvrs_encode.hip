@@ -381,30 +381,17 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
         const uint32_t incl = gf_wave_incl_scan(myBits);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (bits + total > capBits) { fits = false; break; }         // wave-uniform
-        // The usual lane -- eight one-byte values whose codes make two groups of four of at most 32 bits each -- joins its codes
-        // in registers (a tree of 32-bit shifts and ORs, no branch) and ORs the 64 bits into the window as three words.  The
-        // bit sink below took a branch or two per code (a word filled up? the first word, shared with the lane before?): the
-        // scalar unit spent more instructions on those than the SIMDs on the codes (round 3: 317 scalar + 75 branch
-        // instructions per wave and step).  Same bits at the same places either way.
+        // the usual lane -- eight one-byte values whose codes make two groups of four of at most 32 bits each -- joins its codes
+        // in registers (GF_JOIN8_OR, gvrs_encode_common.h); the others go through the bit sink
 #define GF_LN(j) ((uint32_t)(cl[j] >> 56))
 #define GF_CD(j) ((uint32_t)cl[j])
         const uint32_t n01 = GF_LN(0) + GF_LN(1), n45 = GF_LN(4) + GF_LN(5);
         const uint32_t n0 = n01 + GF_LN(2) + GF_LN(3), n1 = n45 + GF_LN(6) + GF_LN(7);
-        const bool simple = multi == 0u && n0 <= 32u && n1 <= 32u;
         static_assert(CPT == 8, "the register path joins eight codes");
-        if (simple) {
-            // (a shift count of 32 only ever meets a zero operand: the codes behind a group that is full have no bits)
-            const uint32_t p01 = GF_CD(0) | (GF_CD(1) << (GF_LN(0) & 31u)), p23 = GF_CD(2) | (GF_CD(3) << (GF_LN(2) & 31u));
-            const uint32_t p45 = GF_CD(4) | (GF_CD(5) << (GF_LN(4) & 31u)), p67 = GF_CD(6) | (GF_CD(7) << (GF_LN(6) & 31u));
-            const uint32_t q0 = p01 | (p23 << (n01 & 31u)), q1 = p45 | (p67 << (n45 & 31u));
+        if (multi == 0u && n0 <= 32u && n1 <= 32u) {
+            GF_JOIN8_OR(wwin, bits + incl - myBits, GF_CD, GF_LN, n01, n45, n0);
 #undef GF_LN
 #undef GF_CD
-            const uint32_t lo = q0 | (n0 < 32u ? q1 << n0 : 0u);
-            const uint32_t hi = n0 ? q1 >> ((32u - n0) & 31u) : 0u;
-            const uint32_t pbit = bits + incl - myBits, w = pbit >> 5, o = pbit & 31u, ro = (32u - o) & 31u;
-            atomicOr(&wwin[w], lo << o);
-            atomicOr(&wwin[w + 1u], o ? (lo >> ro) | (hi << o) : hi);
-            atomicOr(&wwin[w + 2u], o ? hi >> ro : 0u);              // (the window keeps two words behind what a wave may fill)
         } else if (myBits) {
             BitSink sink;
             sink.init(wwin, bits + incl - myBits);

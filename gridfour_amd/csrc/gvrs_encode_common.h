@@ -179,6 +179,25 @@ struct BitSink {
     }
 };
 
+// Eight (code, length) pairs whose two groups of four are at most 32 bits each, joined in registers (a tree of 32-bit shifts
+// and ORs, no branch) and ORed into a zeroed bit window at bit position pbit as three words.  What the packers' usual lane does
+// instead of eight BitSink::put calls with a branch or two each (a word filled up? the first word, shared with the lane
+// before?) -- the scalar unit spent more instructions on those than the SIMDs on the codes (round 3).  Same bits at the same
+// places.  A shift count of 32 only ever meets a zero operand: the codes behind a group that is full have no bits.  The window
+// keeps two words behind what a wave may fill (WAVE_WIN_BITS).
+#define GF_JOIN8_OR(wwin, pbit, CD, LN, n01, n45, n0)                                                              \
+    do {                                                                                                            \
+        const uint32_t p01_ = CD(0) | (CD(1) << (LN(0) & 31u)), p23_ = CD(2) | (CD(3) << (LN(2) & 31u));            \
+        const uint32_t p45_ = CD(4) | (CD(5) << (LN(4) & 31u)), p67_ = CD(6) | (CD(7) << (LN(6) & 31u));            \
+        const uint32_t q0_ = p01_ | (p23_ << ((n01) & 31u)), q1_ = p45_ | (p67_ << ((n45) & 31u));                  \
+        const uint32_t lo_ = q0_ | ((n0) < 32u ? q1_ << (n0) : 0u);                                                 \
+        const uint32_t hi_ = (n0) ? q1_ >> ((32u - (n0)) & 31u) : 0u;                                               \
+        const uint32_t w_ = (pbit) >> 5, o_ = (pbit) & 31u, ro_ = (32u - o_) & 31u;                                 \
+        atomicOr(&(wwin)[w_], lo_ << o_);                                                                           \
+        atomicOr(&(wwin)[w_ + 1u], o_ ? (lo_ >> ro_) | (hi_ << o_) : hi_);                                          \
+        atomicOr(&(wwin)[w_ + 2u], o_ ? hi_ >> ro_ : 0u);                                                           \
+    } while (0)
+
 // residual and emit mask of cell j of a Cells8 block for one model (flat-scan form)
 template <int MODEL>
 __device__ __forceinline__ uint32_t flat_residual(const Cells8 &Q, int j, uint32_t idx, uint32_t c, uint32_t nC,

@@ -514,7 +514,18 @@ __device__ bool p2_pack_array_waves(const int32_t *__restrict__ arr, uint32_t be
         const uint32_t incl = gf_wave_incl_scan(myBits);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (bits + total > WAVE_WIN_BITS) { fits = false; break; }   // wave-uniform
-        if (myBits) {
+        // the usual lane (eight values inside a byte, two groups of four codes of at most 32 bits each) joins its codes in
+        // registers (GF_JOIN8_OR, gvrs_encode_common.h); the others go through the bit sink
+#define GF_LN(j) (cl[j] >> 16)
+#define GF_CD(j) (cl[j] & 0xffffu)
+        const uint32_t n01 = GF_LN(0) + GF_LN(1), n45 = GF_LN(4) + GF_LN(5);
+        const uint32_t n0 = n01 + GF_LN(2) + GF_LN(3), n1 = n45 + GF_LN(6) + GF_LN(7);
+        static_assert(CPT == 8, "the register path joins eight codes");
+        if (wide == 0u && n0 <= 32u && n1 <= 32u) {
+            GF_JOIN8_OR(wwin, bits + incl - myBits, GF_CD, GF_LN, n01, n45, n0);
+#undef GF_LN
+#undef GF_CD
+        } else if (myBits) {
             BitSink sink;
             sink.init(wwin, bits + incl - myBits);
 #pragma unroll
