@@ -1597,7 +1597,11 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
                 const uint32_t kBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb[base >> 3]);
                 if (kBase >= nB) break;
                 const uint32_t dw = base + tid;
-                if (dw < nDw) {
+                // (a wave whose first byte already lies behind the border has nothing to pick up: on an ETOPO1-shaped tile the
+                // border is the first 300 bytes of the stream, i.e. the dwords of two of the eight waves)
+                const uint32_t dwWave = base + wave * 64u;
+                const bool waveIn = dwWave < nDw && (uint32_t)__builtin_amdgcn_readfirstlane((int)wb[min(dwWave >> 3, bmWords - 1u)]) < nB;
+                if (waveIn && dw < nDw) {
                     uint32_t bits, k, v[4];
                     decodeDword(dw, bits, k, v[0], v[1], v[2], v[3]);
 #pragma unroll
