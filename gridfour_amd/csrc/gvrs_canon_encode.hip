@@ -47,6 +47,7 @@ struct CanonPersist {
     unsigned long long sumStart;
     uint32_t nStart;
     uint32_t pmLock;                            // cn_pm_acquire
+    uint32_t lbBytes[3];                        // lower bound of a candidate's packing from its histogram alone (phase B)
 };
 
 struct CanonTrees {
@@ -297,10 +298,11 @@ __device__ __forceinline__ void cpack_flat_ranges(const uint32_t *__restrict__ t
     }
 }
 
-// workgroups per CU: the histogram + table kernel is capped at four by its 34 KB of LDS (sweep 4..6: 1.81 / 2.00 / 2.00 ms),
+// workgroups per CU: the histogram + table kernel runs six (25.8 KB of LDS since the package-merge scratch is shared; with the
+// two-turn phase B of round 3 the bound has to say so: left at four the compiler took 110 VGPRs, 1.03 against 1.23 ms),
 // the pack kernel runs six (80 VGPRs; eight, at 64 VGPRs, cost 0.3 ms with the wave-private windows)
 #ifndef GF_CN_AB_WGS
-#define GF_CN_AB_WGS 4
+#define GF_CN_AB_WGS 6
 #endif
 #ifndef GF_CN_PACK_WGS
 #define GF_CN_PACK_WGS 7        // sweep 6 / 7 / 8 after the head packer was inlined: encode 1.277 / 1.259 / 1.273 ms
@@ -482,16 +484,67 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
         __syncthreads();                         // histR dead from here: S.tree may be written
 
         // ---------------- phase B: code tables of the candidates, one wave each ----------------
-        if (wave < 3 && P.model[wave] != 0) {
-            const int p = wave;
-            const CanonBuilt B = cn_build(S.b.tree[p], S.b.pm, &P.pmLock, P.hist[p], P.nGap[p], P.tab[p], P.img[p], lane);
-            if (lane == 0) {
-                P.imgBits[p] = B.imgBits;
-                P.maxLen[p] = B.maxLen;
-                P.totalBits[p] = 48ull + B.imgBits + B.textBits;
+        // Only the shortest packing is written (CodecCanonHuffman.java:126-140), so code tables are built only for a predictor that
+        // can still win -- the rule of the legacy encoder (gvrs_encode.hip, phase B), round 3.  No prefix code, length-limited or
+        // not, spends fewer bits on a text than its zero-order entropy; the raw bits of the escapes are known from the counts:
+        // 48 + N H + 2 n(ESC2) + 8 n(ESC1) bits (the serialised tables counted as nothing) is a LOWER BOUND of a candidate's
+        // packing from its histogram alone.  The candidate with the smallest bound builds first; the others only if their bound
+        // does not already lose against its exact size (the earlier predictor wins ties, :133).  A tile with a value inside the
+        // -8333608 quirk (nGap: its correction can shorten the text) builds all three as before.
+        const bool prune = P.nGap[0] == 0u && P.nGap[1] == 0u && P.nGap[2] == 0u;
+        int firstP = -1;
+        if (prune) {
+            if (wave < 3 && P.model[wave] != 0) {
+                const int p = wave;
+                double sumCLogC = 0.0;
+                uint32_t N = 0;
+                for (int e = lane; e < CN_SYMS; e += 64) {
+                    const uint32_t cnt = P.hist[p][e];
+                    N += cnt;
+                    if (cnt > 1) sumCLogC += (double)cnt * (double)__log2f((float)cnt);
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    N += gf_lane_xor(N, d);
+                    sumCLogC += __shfl_xor(sumCLogC, d, 64);
+                }
+                if (lane == 0) {
+                    // (less a margin for the single-precision logarithms: 2^-22 relative on sums of at most N log2 N, and the cast)
+                    double text = (double)N * (double)__log2f((float)N) - sumCLogC;
+                    text -= 64.0 + (double)N * (1.0 / 4096.0);
+                    const double bits = 48.0 + (text > 0.0 ? text : 0.0) + 2.0 * (double)P.hist[p][CN_ESC2] + 8.0 * (double)P.hist[p][CN_ESC1];
+                    P.lbBytes[p] = (uint32_t)(bits * 0.125);                  // floor: a lower bound stays one
+                }
             }
+            __syncthreads();
+            for (int p = 0; p < 3; p++)
+                if (P.model[p] != 0 && (firstP < 0 || P.lbBytes[p] < P.lbBytes[firstP])) firstP = p;
         }
-        __syncthreads();
+#pragma unroll 1
+        for (int stage = 0; stage < 2; stage++) {
+            bool mine = wave < 3 && P.model[wave] != 0;
+            if (prune) {
+                mine = mine && (stage == 0 ? wave == firstP : wave != firstP);
+                if (mine && stage == 1) {
+                    const uint64_t firstBytes = (P.totalBits[firstP] + 7) >> 3;
+                    const bool lost = wave < firstP ? (uint64_t)P.lbBytes[wave] > firstBytes : (uint64_t)P.lbBytes[wave] >= firstBytes;
+                    if (lost) {
+                        if (lane == 0) P.model[wave] = 0;                     // not a candidate any more
+                        mine = false;
+                    }
+                }
+            } else if (stage == 1) mine = false;                              // (all of them were built in the first turn)
+            if (mine) {
+                const int p = wave;
+                const CanonBuilt B = cn_build(S.b.tree[p], S.b.pm, &P.pmLock, P.hist[p], P.nGap[p], P.tab[p], P.img[p], lane);
+                if (lane == 0) {
+                    P.imgBits[p] = B.imgBits;
+                    P.maxLen[p] = B.maxLen;
+                    P.totalBits[p] = 48ull + B.imgBits + B.textBits;
+                }
+            }
+            __syncthreads();
+        }
 
         // ---------------- phase C: pick the shortest, pack it ----------------
         int best = -1;
