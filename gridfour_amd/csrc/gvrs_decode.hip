@@ -735,7 +735,7 @@ template <int OWNER>
 __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict__ base32, uint32_t nW, uint32_t sh0,
                                        uint32_t *txt, uint32_t pkWords, const uint16_t *lut2, const unsigned long long *leafCodeG,
                                        uint32_t textStart, uint32_t endBit, uint32_t nM32, uint8_t *m32, uint32_t *dbg,
-                                       const uint32_t warmBits)
+                                       const uint32_t warmBits, const int diagLimit = 0)
 {
     const uint32_t tid = threadIdx.x;
     int32_t status = GF_K_OK;
@@ -762,8 +762,12 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
 #ifdef GF_DIAG
     if (dbg && tid == 0) dbg[2] = (uint32_t)__builtin_amdgcn_s_memtime() - tStage;
 #endif
+#ifdef GF_DIAG
+    if (diagLimit == 7) return GF_K_SKIP;                                        // (count table built, text staged)
+#endif
     fast_sync_pass<OWNER>(S, H, cnt16, txt, sh0, textStart, endBit, unit, Q, warmBits, dbg);
 #ifdef GF_DIAG
+    if (diagLimit == 8) return GF_K_SKIP;                                        // (+ synchronisation pass)
     if (dbg && tid == 0) dbg[-7] = (uint32_t)__builtin_amdgcn_s_memtime();      // stamp 4
 #else
     (void)dbg;
@@ -2138,6 +2142,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             } else {
                 build_lut(S, lut2);
                 GF_DSTAMP(3);
+                GF_DPHASE_LIMIT(6, return (int32_t)GF_K_SKIP);            // (diagnostic: header + tree records + lookup tables)
                 const uint32_t textStart = S.textStart, endBit = len * 8u;
                 const uint64_t baseWord = (off * 8ull) >> 5;
                 const uint32_t sh0 = (uint32_t)(off * 8ull) & 31u;
@@ -2146,7 +2151,11 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                     tileStatus = huffman_to_m32_fast<MODE>(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
                                                            sh0, reinterpret_cast<uint32_t *>(ldsDyn), pkWords, lut2,
                                                            reinterpret_cast<const unsigned long long *>(a.trees + t * GF_TREE_REC_WORDS + 8),
+#ifdef GF_DIAG
+                                                           textStart, endBit, nM32, m32, dbg, warmBits, a.phaseLimit & 0xff);
+#else
                                                            textStart, endBit, nM32, m32, dbg, warmBits);
+#endif
                 } else if (pkWords * 4u <= a.ldsTextBytes) {
                     // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
                     uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes + bmArea);
