@@ -1085,6 +1085,259 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct(G
     }
 }
 
+
+// The same wavefront as ONE pipeline down the tile (round 3) instead of a fill and a drain per band of 64 rows: lane l takes rows
+// 2 + l, 2 + 64 + l, ... one after the other, and starts the next one P = max(nC, 192) steps (rounded up to a round) after the
+// last -- as soon as lane 63 is three columns into the row above it.  A band costs P steps instead of 189 + nC: 501 instead of
+// 648 for the 120 x 150 tiles of the ETOPO1-shaped batch, 1,213 instead of 1,780 for 256 x 256.  Everything a step does is the band
+// kernel's; what changes is bookkeeping: a lane's column wraps at P (its row index goes up by 64), the per-row constants of the
+// next rows are worked out by the whole wave when lane 0 starts a row and taken over by a lane when it gets there, lane 0 alone
+// re-arms its windows from the two row buffers, and the staging pieces tell rows apart by whether a step lies before or behind a
+// row's start inside the current period.  For tiles of more than one band and at least 16 columns (the launcher decides).
+template <int ROUND>
+__global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_pipe(GfLsopReconArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t reconLds[];
+    constexpr uint32_t RING = 2u * ROUND;
+    constexpr uint32_t RS = RING + 1u;
+    constexpr uint32_t RPI = 64u / ROUND;
+    constexpr uint32_t SUBS = ROUND / 8u;
+    constexpr uint32_t SUBROWS = 64u / SUBS;
+    const int lane = threadIdx.x;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    const uint32_t nInit = lsop_n_init(nR, nC);
+    const uint32_t wI = nC - 4u;
+    uint32_t *stage = reconLds;
+    uint32_t *rows = reconLds + 64u * RS;
+    const uint32_t half = (uint32_t)lane / ROUND, j32 = (uint32_t)lane % ROUND;
+    const uint32_t nPh = (nR - 2u + 63u) / 64u;                              // rows per lane
+    // steps between a lane's rows: lane 63 starts its row 189 steps into a period, and lane 0 reads column c + 2 of that row for
+    // the eight steps of a group at once, from the row buffers: 189 + 2 + 8 <= P
+    const uint32_t P = ((max(nC, 208u) + ROUND - 1u) / ROUND) * ROUND;
+    const uint32_t nLast = nR - 2u - 64u * (nPh - 1u);
+    const uint32_t sEnd = (nPh - 1u) * P + 3u * (nLast - 1u) + nC - 1u;       // the last step that produces a value
+    const uint32_t nRounds = sEnd / ROUND + 1u;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if (a.inStatus && a.inStatus[t] != GF_K_OK) {
+            if (lane == 0) a.status[t] = a.inStatus[t];
+            continue;
+        }
+        const int32_t *__restrict__ res = a.residuals + t * a.resStride;
+        const int32_t *__restrict__ inter = res + nInit;
+        int32_t *__restrict__ v = a.values + t * (size_t)nCells;
+        const uint32_t *cf = a.coefs + t * 16;
+        const uint32_t seed = cf[0];
+        float u[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) u[i] = __uint_as_float(cf[1 + i]);
+        const uint32_t prev0 = 0, prev1 = nC;
+
+        // rows 0 and 1 as in the band kernel
+        {
+            uint32_t carry = seed;
+            if (lane == 0) { v[0] = (int32_t)seed; rows[prev0] = seed; }
+            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                if (c < nC) { v[c] = (int32_t)incl; rows[prev0 + c] = incl; }
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        const uint32_t v10 = seed + (uint32_t)res[nC - 1u];
+        if (lane == 0) { v[nC] = (int32_t)v10; rows[prev1] = v10; }
+        uint32_t v11 = 0;
+        {
+            uint32_t carry = v10 - seed;
+            const uint32_t base = nC - 1u + nR - 1u;
+            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const uint32_t x = c < nC ? (uint32_t)res[base + c - 1] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                const uint32_t val = incl + (c < nC ? rows[prev0 + c] : 0u);
+                if (c < nC) { v[nC + c] = (int32_t)val; rows[prev1 + c] = val; }
+                if (c0 == 1) v11 = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        uint32_t carry0 = v10, carry1 = v11 - v10;
+        const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
+
+        // (row, step) of a staging piece -> the row of the tile and its column: step S belongs to period pg = S / P (the same for a
+        // whole round: P is a multiple of ROUND); row `row` starts 3 row steps into a period, what lies before that is the end of
+        // its row of the period before
+        uint32_t relOf[3] = {0u, 0u, ROUND % P}, pgOf[3] = {0u, 0u, ROUND / P};      // first step mod P / period of rounds round - 1, round, round + 1
+        auto pieceRC = [&](uint32_t round, uint32_t rel, uint32_t pg, uint32_t row, uint32_t &r, int32_t &c) {
+            (void)round;
+            const int32_t tq = (int32_t)(rel + j32) - 3 * (int32_t)row;
+            const bool before = tq < 0;
+            c = before ? tq + (int32_t)P : tq;
+            const int32_t ph = (int32_t)pg - (before ? 1 : 0);
+            r = ph >= 0 ? 2u + 64u * (uint32_t)ph + row : 0xFFFFFFFFu;
+        };
+        auto pieceLoad = [&](uint32_t round, uint32_t rel, uint32_t pg, uint32_t row) -> uint32_t {
+            uint32_t r;
+            int32_t c;
+            pieceRC(round, rel, pg, row, r, c);
+            const int32_t e = c - 2;
+            uint32_t x = 0;
+            if (r < nR && e >= 0 && e < (int32_t)wI) x = (uint32_t)inter[(size_t)(r - 2u) * wI + (uint32_t)e];
+            return x;
+        };
+        auto pieceSlot = [&](uint32_t round, uint32_t row) -> uint32_t { return row * RS + ((round & 1u) * ROUND + j32); };
+        auto pieceStore = [&](uint32_t round, uint32_t rel, uint32_t pg, uint32_t row) {
+            uint32_t r;
+            int32_t c;
+            pieceRC(round, rel, pg, row, r, c);
+            if (r < nR && c < (int32_t)nC) v[(size_t)r * nC + (uint32_t)c] = (int32_t)stage[pieceSlot(round, row)];
+        };
+
+#pragma unroll 4
+        for (uint32_t k = 0; k < ROUND; k++) {
+            const uint32_t row = RPI * k + half;
+            stage[pieceSlot(0, row)] = pieceLoad(0, 0u, 0u, row);
+        }
+
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = rows[prev1], a4 = rows[prev1 + 1u];
+        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = rows[prev0], b4 = rows[prev0 + 1u], z1 = 0, z6 = 0;
+        uint32_t colv0 = 0, colv1 = 0, t0 = 0, t1 = 0;            // of the lane's current row
+        uint32_t pc0 = 0, pc1 = 0, pt0 = 0, pt1 = 0;              // of its next one (taken over when the lane gets there)
+        int32_t cBase = -3 * lane;                                // the lane's column at the next step (wraps at P)
+        uint32_t ph = 0;                                          // its row: 2 + 64 ph + lane
+        uint32_t nextStart = 0, pn = 0;                           // lane 0 starts row 2 + 64 pn at step nextStart
+        const bool feeds = lane >= 62;
+        const uint32_t feedBase = lane == 62 ? prev0 : prev1;
+        uint32_t ld[8];
+        bool pending = false;
+        uint32_t pendRound = 0, pendRow = 0;
+        for (uint32_t round = 0; round < nRounds; round++) {
+            for (uint32_t q = 0; q < SUBS; q++) {
+                const uint32_t rowBase = SUBROWS * q;
+                const uint32_t sFirst = round * ROUND + q * 8u;
+                // a lane whose column 0 lies in these eight steps takes over the border values of its next row (nothing of the
+                // row it is finishing needs them); its tail residuals one group later (the row's own tail is behind it then)
+                {
+                    const bool wrapSoon = (cBase <= 0 && cBase + 8 > 0) || cBase + 8 > (int32_t)P;
+                    colv0 = wrapSoon ? pc0 : colv0;
+                    colv1 = wrapSoon ? pc1 : colv1;
+                    const bool justWrapped = cBase >= 0 && cBase < 8;
+                    t0 = justWrapped ? pt0 : t0;
+                    t1 = justWrapped ? pt1 : t1;
+                }
+                if (sFirst == nextStart && pn < nPh) {                        // lane 0 starts a row: the next rows' constants
+                    const uint32_t r = 2u + 64u * pn + (uint32_t)lane;
+                    const bool rowValidN = r < nR;
+                    const uint32_t x0 = rowValidN ? (uint32_t)res[base0 + r - 1u] : 0u;
+                    const uint32_t i0 = gf_wave_incl_scan(x0) + carry0;
+                    carry0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+                    const uint32_t x1 = rowValidN ? (uint32_t)res[base1 + r - 2u] : 0u;
+                    const uint32_t i1 = gf_wave_incl_scan(x1) + carry1;
+                    carry1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+                    pc0 = i0;
+                    pc1 = i1 + i0;
+                    pt0 = rowValidN ? (uint32_t)res[tailBase + 2u * (r - 2u)] : 0u;
+                    pt1 = rowValidN ? (uint32_t)res[tailBase + 2u * (r - 2u) + 1u] : 0u;
+                    if (pn == 0u) { colv0 = pc0; colv1 = pc1; t0 = pt0; t1 = pt1; }
+                    else {
+                        // the lanes that reach their column 0 within this group (0, 1, 2) start rows of THIS period: the take-over
+                        // above handed them the constants of the period before
+                        const bool wrapSoon = (cBase <= 0 && cBase + 8 > 0) || cBase + 8 > (int32_t)P;
+                        colv0 = wrapSoon ? pc0 : colv0;
+                        colv1 = wrapSoon ? pc1 : colv1;
+                        if (lane == 0) {
+                            // its windows: columns 0 and 1 of the two rows above.  (Only these: lane 1 is three columns behind
+                            // on its old row and still takes lane 0's last value and the middle of its window at this step.)
+                            a3 = rows[prev1]; a4 = rows[prev1 + 1u];
+                            b3 = rows[prev0]; b4 = rows[prev0 + 1u];
+                            t0 = pt0; t1 = pt1;                               // (its old row ended nC steps into the period before)
+                        }
+                    }
+                    pn++;
+                    nextStart += P;
+                }
+                if (pending) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) stage[pieceSlot(pendRound, pendRow + RPI * k + half)] = ld[k];
+                    pending = false;
+                }
+                if (round >= 1u) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) pieceStore(round - 1u, relOf[0], pgOf[0], rowBase + RPI * k + half);
+                }
+                if (round + 1u < nRounds) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) ld[k] = pieceLoad(round + 1u, relOf[2], pgOf[2], rowBase + RPI * k + half);
+                    pending = true;
+                    pendRound = round + 1u;
+                    pendRow = rowBase;
+                }
+                if (sFirst <= sEnd) {
+                    // lane 0's column in this group (its windows take column c + 2 of the two rows above from the row buffers)
+                    const uint32_t c00 = sFirst - (nextStart - P);
+                    uint32_t ra[8], rb[8], rsv[8];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t cc = min(c00 + k + 2u, nC - 1u);
+                        ra[k] = rows[prev1 + cc];
+                        rb[k] = rows[prev0 + cc];
+                        rsv[k] = stage[(uint32_t)lane * RS + ((sFirst + k) & (RING - 1u))];
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) asm volatile("" : "+v"(ra[k]), "+v"(rb[k]), "+v"(rsv[k]));
+                    const bool validCur = 2u + 64u * ph + (uint32_t)lane < nR, validNext = 2u + 64u * (ph + 1u) + (uint32_t)lane < nR;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t s = sFirst + k;
+                        if (s > sEnd) break;
+                        const int32_t cw = cBase + (int32_t)k;
+                        const bool wrapped = cw >= (int32_t)P;
+                        const int32_t c = wrapped ? cw - (int32_t)P : cw;
+                        const bool rowValid = wrapped ? validNext : validCur;
+                        const uint32_t na = lsop_from_lane_above(ra[k], z1);
+                        const uint32_t nb = lsop_from_lane_above(rb[k], a2);
+                        a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = na;
+                        b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = nb;
+                        float p = u[0] * (float)(int32_t)z1;
+                        p = p + u[1] * (float)(int32_t)a1;
+                        p = p + u[2] * (float)(int32_t)a2;
+                        p = p + u[3] * (float)(int32_t)a3;
+                        p = p + u[4] * (float)(int32_t)a4;
+                        p = p + u[5] * (float)(int32_t)z6;
+                        p = p + u[6] * (float)(int32_t)a0;
+                        p = p + u[7] * (float)(int32_t)b0;
+                        p = p + u[8] * (float)(int32_t)b1;
+                        p = p + u[9] * (float)(int32_t)b2;
+                        p = p + u[10] * (float)(int32_t)b3;
+                        p = p + u[11] * (float)(int32_t)b4;
+                        const uint32_t interior = (uint32_t)lsop_round_sat(p) + rsv[k];
+                        const uint32_t tail = (c == (int32_t)nC - 2 ? t0 : t1) + (z1 + a2 - a1);
+                        const uint32_t border = c == 0 ? colv0 : colv1;
+                        const uint32_t val = c < 2 ? border : (c <= (int32_t)nC - 3 ? interior : tail);
+                        const bool act = rowValid && c >= 0 && c < (int32_t)nC;
+                        if (act) {
+                            stage[(uint32_t)lane * RS + (s & (RING - 1u))] = val;
+                            if (feeds) rows[feedBase + (uint32_t)c] = val;
+                        }
+                        z6 = act ? z1 : z6;
+                        z1 = act ? val : z1;
+                    }
+                }
+                cBase += 8;
+                if (cBase >= (int32_t)P) { cBase -= (int32_t)P; ph++; }
+            }
+            relOf[0] = relOf[1]; pgOf[0] = pgOf[1];
+            relOf[1] = relOf[2]; pgOf[1] = pgOf[2];
+            relOf[2] += ROUND;
+            if (relOf[2] >= P) { relOf[2] -= P; pgOf[2]++; }
+        }
+        // (after the loop relOf[1] / pgOf[1] belong to round nRounds, relOf[0] / pgOf[0] to the last round)
+#pragma unroll 4
+        for (uint32_t k = 0; k < ROUND; k++) pieceStore(nRounds - 1u, relOf[0], pgOf[0], RPI * k + half);
+        if (lane == 0) a.status[t] = GF_K_OK;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1123,7 +1376,12 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
         const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct<RECON_ROUND>, dyn, opt);
         if (e != hipSuccess) return e;
         const unsigned grid = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
-        hipLaunchKernelGGL(k_lsop_reconstruct<RECON_ROUND>, dim3(grid), dim3(64), dyn, stream, a);
+        if (nRows > 66 && nCols >= 16) {                        // more than one band of 64 rows: one pipeline down the tile
+            static GfDynLdsOptIn optPipe;
+            const hipError_t e2 = gf_opt_in_dyn_lds(k_lsop_reconstruct_pipe<RECON_ROUND>, dyn, optPipe);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(k_lsop_reconstruct_pipe<RECON_ROUND>, dim3(grid), dim3(64), dyn, stream, a);
+        } else hipLaunchKernelGGL(k_lsop_reconstruct<RECON_ROUND>, dim3(grid), dim3(64), dyn, stream, a);
     } else {
         const size_t wgs = (nTiles + 3) / 4;
         const unsigned grid = (unsigned)(wgs < 65536 * 16 ? wgs : 65536 * 16);
