@@ -464,18 +464,6 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
         uint32_t myFlags = 0, maxN1 = 1, maxN2 = 1, maxN3 = 1;
         {
             uint32_t *const h0 = &S.histR[0][rep], *const h1 = &S.histR[1][rep], *const h2 = &S.histR[2][rep];
-            // all M32 bytes of residual x into histogram h; returns the byte count
-            auto addHist = [&](uint32_t *h, uint32_t x) -> uint32_t {
-                bool single;
-                const uint32_t b0 = m32_first_byte(x, &single);
-                atomicAdd(h + b0 * HIST_R, 1u);
-                uint32_t n = 1;
-                if (!single) {
-                    n = (uint32_t)gf_m32_len(x);
-                    for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
-                }
-                return n;
-            };
             uint32_t c0 = ((uint32_t)tid * CPT) % nC;
             const uint32_t cStep = STEP_CELLS % nC;
             for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
@@ -508,9 +496,22 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                     const uint32_t d1 = counted ? d : 0u;
                     const uint32_t d2 = counted ? (c >= 2 ? v - (2u * W - WW) : d) : 0u;
                     const uint32_t d3 = counted ? ((idx >= nC && c > 0) ? v - (W + N - NW) : d) : 0u;
-                    maxN1 = max(maxN1, addHist(h0, d1));
-                    maxN2 = max(maxN2, addHist(h1, d2));
-                    if (triOk) maxN3 = max(maxN3, addHist(h2, d3));
+                    // the first M32 byte of the three residuals without a branch; the continuation bytes of values that have any
+                    // behind ONE branch per cell (three, one per predictor, cost the scalar unit more than the cell cost the SIMDs)
+                    bool s1, s2, s3 = true;
+                    atomicAdd(h0 + m32_first_byte(d1, &s1) * HIST_R, 1u);
+                    atomicAdd(h1 + m32_first_byte(d2, &s2) * HIST_R, 1u);
+                    if (triOk) atomicAdd(h2 + m32_first_byte(d3, &s3) * HIST_R, 1u);
+                    if (!(s1 && s2 && s3)) {
+                        auto rest = [&](uint32_t *h, uint32_t x) -> uint32_t {
+                            const uint32_t n = (uint32_t)gf_m32_len(x);
+                            for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
+                            return n;
+                        };
+                        if (!s1) maxN1 = max(maxN1, rest(h0, d1));
+                        if (!s2) maxN2 = max(maxN2, rest(h1, d2));
+                        if (!s3) maxN3 = max(maxN3, rest(h2, d3));
+                    }
                     if (++c == nC) c = 0;
                 }
                 c0 += cStep;
