@@ -75,6 +75,9 @@ constexpr int MAXQ = GF_DEC_MAXQ;                // subsequences per chain: two 
 constexpr int HEAD_WORDS = 88;                 // 10 header + 1 + ceil(2559/8) tree bytes = 332 -> 83 words, + slack
 constexpr int MAX_DEPTH = 63;                  // code length limit of the register tree parser
 
+constexpr uint32_t GF_TREE_HAS_INTRODUCER = 0x100u;   // word 3 of a tree record, above the longest code length: some leaf is 0x7f / 0x81
+constexpr uint32_t GF_TREE_HAS_NULL = 0x200u;         // ... some leaf is 0x80 (the null code)
+
 constexpr int L2_MAX_BITS = 8;                 // second-level LUT: up to 8 more bits (codes of 11..18 bits)
 constexpr int L2_ENTRIES = 2048;               // shared by all second-level tables: 2048 >> l2bits tables of
                                                // 2^l2bits entries, l2bits = min(8, longest code - 11) per tile
@@ -110,6 +113,7 @@ struct DecShared {
     // complete), skipLo/Hi = that path.  Every 0 step on it is a branch whose right child was never read; the reference's
     // decode loop :179-185 finds 0 in such a child slot, lands on the root again and goes on without a symbol.
     uint32_t skipLen, skipLo, skipHi;
+    uint32_t symKinds;                         // GF_TREE_HAS_* of the tree record (fast kernel only)
 };
 
 #include "gvrs_decode_common.h"
@@ -1860,6 +1864,198 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
     return S.chainEnd > nM32 ? GF_K_ERR_BOUNDS : GF_K_OK;       // last value truncated
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The byte path (round 4): phases 2 + 3 for a tile whose tree holds NO introducer (0x7f / 0x81) and no null code (0x80).
+//
+// Every M32 value of such a text is one byte (CodecM32.java:327-356: a value is longer only behind an introducer), so byte j of
+// the Huffman output IS element j of the predictor's stream, sign-extended -- no start marks, no ranks, no redo of special
+// slots, and the element of cell (r, c) sits at an address known in closed form.  The pre-pass tells (GF_TREE_HAS_*, from the
+// leaves it walks anyway); all of a terrain batch's tiles qualify, a tile with a steep step in it takes m32_to_tile as before.
+// With the addresses known the inverse predictors (PredictorModelDifferencing.java:145-167, PredictorModelLinear.java:66-101,
+// PredictorModelTriangle.java:62-98) need no stream-order scan and no ring either.  They are evaluated ROW BY ROW: a lane owns
+// four neighbouring columns (nC <= 256: a wave spans a row) -- two LDS words and a v_alignbyte give it its four residual bytes,
+// a prefix over the four, a DPP scan over the lanes' sums, one 16-byte store -- and the waves own blocks of rows:
+//   Differencing  v(r,c) = C(r) + SUM(j = 1..c) res(r,j)                                C(r) = column 0, a running sum from the seed
+//   Linear        v(r,c) = C(r) + c d1(r) + SUM(k = 2..c) SUM(j = 2..k) res(r,j)        d1(r) = v(r,1) - v(r,0): a double prefix sum
+//   Triangle      v(r,c) = C(r) + SUM(i = 0..r) SUM(j = 1..c) res(i,j)                  four accumulators running down the rows; what
+//                 the blocks above a wave's own add up to comes from a pre-pass over the bytes (column sums per block as pairs
+//                 of 16-bit fields, then one row-wise prefix sum per block), through LDS
+// Stream layouts (the order the encoders emit, see gf_stream_cell): Differencing -- cell i is byte i - 1; Linear -- byte 0 is
+// (0,1), bytes 2r - 1 / 2r are (r,0) / (r,1), the interior of row r starts at 2 nR - 1 + r (nC - 2); Triangle -- row 0, then
+// column 0, then the interior of row r >= 1 at nC + nR - 2 + (r - 1)(nC - 1).
+// Scratch (over the dead decode tables): C(r), d1(r), the block sums.
+constexpr uint32_t BYTE_MAX_COLS = 256;
+__device__ __forceinline__ bool byte_path_eligible(int model, uint32_t nR, uint32_t nC, uint32_t ldsM32Bytes)
+{
+    const uint32_t RB = (nR + DEC_WAVES - 1u) / DEC_WAVES;
+    // (a lane's four bytes may end three bytes behind the stream, and the word behind them is read too)
+    return model >= 1 && model <= 3 && nR >= 2u && nC >= 4u && nC <= BYTE_MAX_COLS && RB <= 255u && nR * nC + 8u <= ldsM32Bytes &&
+           ((2u * nR + 3u) & ~3u) + (model == 3 ? (uint32_t)DEC_WAVES * ((nC + 3u) & ~3u) : 0u) <= SCR_WORDS;
+}
+
+template <int MODEL>
+__device__ __forceinline__ void m32_bytes_rows(DecShared &S, const uint8_t *m32, const uint32_t seed, const uint32_t nR, const uint32_t nC,
+                                               uint32_t *__restrict__ o)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = gf_wave_id();
+    uint32_t *scr = reinterpret_cast<uint32_t *>(&S);
+    uint32_t *col0 = scr, *d1s = scr + nR, *T = scr + ((2u * nR + 3u) & ~3u);
+    const uint32_t TS = (nC + 3u) & ~3u;
+    const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
+    const uint32_t j0 = 4u * lane;                                // the lane's columns: j0 .. j0 + 3
+    const uint32_t jf = j0 < nC ? j0 : 0u;                        // (lanes without a column read lane 0's bytes: nothing behind the stream)
+    auto sx = [](uint32_t b) -> uint32_t { return (uint32_t)(int32_t)(int8_t)b; };
+    // ---- per-row constants: C(r), a running sum of the column-0 residuals, by the last wave (it has no pre-pass to do below),
+    // d1(r) by the one before it
+    if (wave == (uint32_t)DEC_WAVES - 1u) {
+        uint32_t carry = seed;
+        for (uint32_t rb = 0; rb < nR; rb += 64u) {
+            const uint32_t r = rb + lane;
+            uint32_t x = 0;
+            if (r >= 1u && r < nR) x = sx(m32[MODEL == 3 ? nC - 2u + r : MODEL == 1 ? r * nC - 1u : 2u * r - 1u]);
+            const uint32_t v = gf_wave_incl_scan(x) + carry;
+            if (r < nR) col0[r] = v;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+        }
+    } else if (MODEL == 2 && wave == (uint32_t)DEC_WAVES - 2u) {
+        for (uint32_t r = lane; r < nR; r += 64u) d1s[r] = sx(m32[2u * r]);
+    }
+    // the rows of this wave, and where the bytes of a row lie: byte rowAt(r) + c belongs to cell (r, c) from column 1 on (Linear: 2)
+    const uint32_t RB = (nR + DEC_WAVES - 1u) / DEC_WAVES;
+    const uint32_t r0 = min(nR, wave * RB), r1 = min(nR, r0 + RB);
+    const uint32_t rowStep = MODEL == 1 ? nC : MODEL == 2 ? nC - 2u : nC - 1u;
+    auto rowAt = [&](uint32_t r) -> uint32_t {                    // (as if column 0 had a byte of its own; may be "-1" for row 0)
+        if (MODEL == 1) return r * nC - 1u;
+        if (MODEL == 2) return 2u * nR - 1u + r * (nC - 2u) - 2u;
+        return r ? nC + nR - 2u + (r - 1u) * (nC - 1u) - 1u : 0u - 1u;
+    };
+    // the four bytes at rowAt + j0 .. + 3 as one word: a4 = rowAt + j0 + 4 (so that it is never negative)
+    auto fetch = [&](uint32_t a4) -> uint32_t {
+        const uint32_t wi = a4 >> 2;
+        return __builtin_amdgcn_alignbyte(m32w[wi], m32w[wi - 1u], a4 & 3u);
+    };
+    // row 0 of Differencing / Triangle starts at byte "-1": lane 0's first word does not exist (its byte would be column 0)
+    auto fetchRow0 = [&]() -> uint32_t { return __builtin_amdgcn_alignbyte(m32w[lane], lane ? m32w[lane - 1u] : 0u, 3u); };
+    const bool peel = MODEL != 2 && r0 == 0u && r1 > 0u;         // (wave-uniform: wave 0)
+    const uint32_t keep0 = lane == 0u ? 0u : 0xFFFFFFFFu;        // lane 0: the residuals of column 0 (Linear: and 1) count as zero
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;              // Triangle: SUM over the rows so far of the row prefixes
+    if (MODEL == 3) {
+        // ---- pre-pass: T[b][j] = SUM(rows r of block b) SUM(m = 1..j) res(r,m); the last block's is not needed
+        if (wave + 1u < (uint32_t)DEC_WAVES && r1 > r0) {
+            uint32_t ev = 0, od = 0;                              // bytes + 128 of columns j0, j0 + 2 / j0 + 1, j0 + 3 as 16-bit fields
+            uint32_t r = r0;
+            if (peel) {
+                const uint32_t y = fetchRow0() ^ 0x80808080u;
+                ev = y & 0x00FF00FFu;
+                od = (y >> 8) & 0x00FF00FFu;
+                r = 1u;
+            }
+            uint32_t a4 = rowAt(r) + jf + 4u;
+            for (; r < r1; r++) {
+                const uint32_t y = fetch(a4) ^ 0x80808080u;
+                ev += y & 0x00FF00FFu;
+                od += (y >> 8) & 0x00FF00FFu;
+                a4 += rowStep;
+            }
+            const uint32_t bias = 128u * (r1 - r0);
+            const uint32_t c0 = ((ev & 0xFFFFu) - bias) & keep0, c1 = (od & 0xFFFFu) - bias, c2 = (ev >> 16) - bias, c3 = (od >> 16) - bias;
+            const uint32_t p1 = c0 + c1, p2 = p1 + c2, p3 = p2 + c3;
+            const uint32_t ex = gf_wave_incl_scan(p3) - p3;
+            if (j0 < TS) {
+                uint32_t *Tw = T + wave * TS + j0;
+                Tw[0] = ex + c0; Tw[1] = ex + p1; Tw[2] = ex + p2; Tw[3] = ex + p3;
+            }
+        }
+    }
+    __syncthreads();                                              // C(r), d1(r), T are in place
+    if (MODEL == 3 && j0 < TS) {
+        for (uint32_t w = 0; w < wave; w++) {
+            const uint32_t *Tw = T + w * TS + j0;
+            acc0 += Tw[0]; acc1 += Tw[1]; acc2 += Tw[2]; acc3 += Tw[3];
+        }
+    }
+    // ---- the rows
+    const uint32_t nFull = nC >> 2, rem = nC & 3u;               // lanes that store four cells; cells of the lane behind them
+    const bool full = lane < nFull, part = lane == nFull && rem != 0u;
+    struct Quad { uint32_t q0, q1, q2, q3; };
+    auto sums = [&](uint32_t x, uint32_t left, uint32_t d1) -> Quad {
+        const uint32_t v0 = sx(x) & keep0, v1 = MODEL == 2 ? sx(x >> 8) & keep0 : sx(x >> 8), v2 = sx(x >> 16), v3 = (uint32_t)((int32_t)x >> 24);
+        const uint32_t p1 = v0 + v1, p2 = p1 + v2, p3 = p2 + v3;
+        const uint32_t ex = gf_wave_incl_scan(p3) - p3;
+        Quad q;
+        if (MODEL == 2) {
+            // the second prefix sum: within the lane, then over the lanes (a lane before adds its own and four times what lay before it)
+            const uint32_t g1 = v0 + p1, g2 = g1 + p2, g3 = g2 + p3;
+            const uint32_t t = g3 + 4u * ex;
+            const uint32_t gx = gf_wave_incl_scan(t) - t;
+            const uint32_t b = left + j0 * d1 + gx + ex;
+            q.q0 = b + v0;
+            q.q1 = b + d1 + ex + g1;
+            q.q2 = b + 2u * (d1 + ex) + g2;
+            q.q3 = b + 3u * (d1 + ex) + g3;
+        } else if (MODEL == 3) {
+            acc0 += ex + v0; acc1 += ex + p1; acc2 += ex + p2; acc3 += ex + p3;
+            q.q0 = acc0 + left; q.q1 = acc1 + left; q.q2 = acc2 + left; q.q3 = acc3 + left;
+        } else {
+            const uint32_t b = left + ex;
+            q.q0 = b + v0; q.q1 = b + p1; q.q2 = b + p2; q.q3 = b + p3;
+        }
+        return q;
+    };
+    auto put = [&](uint32_t r, const Quad &q) {
+        uint32_t *dst = o + r * nC + j0;
+        if (full) {
+            GfU4 v;
+            v.x = q.q0; v.y = q.q1; v.z = q.q2; v.w = q.q3;
+            *reinterpret_cast<GfU4 *>(dst) = v;
+        }
+        if (part) {
+            dst[0] = q.q0;
+            if (rem >= 2u) dst[1] = q.q1;
+            if (rem == 3u) dst[2] = q.q2;
+        }
+    };
+    uint32_t r = r0;
+    if (peel) {
+        put(0u, sums(fetchRow0(), col0[0], 0u));
+        r = 1u;
+    }
+    if (r < r1) {
+        // two rows per turn -- their scans are independent chains: one fills the wait states the DPP steps of the other need -- and
+        // the words of the next two are asked for before these are summed (behind the block's last row: that row again)
+        const uint32_t last = r1 - 1u;
+        uint32_t a4 = rowAt(r) + jf + 4u, rB = min(r + 1u, last);
+        uint32_t a4B = a4 + (rB - r) * rowStep;
+        uint32_t xA = fetch(a4), leftA = col0[r], dA = MODEL == 2 ? d1s[r] : 0u;
+        uint32_t xB = fetch(a4B), leftB = col0[rB], dB = MODEL == 2 ? d1s[rB] : 0u;
+        for (; r < r1; r += 2u) {
+            const uint32_t x0 = xA, l0 = leftA, e0 = dA, x1 = xB, l1 = leftB, e1 = dB;
+            const uint32_t nA = min(r + 2u, last), nB = min(r + 3u, last);
+            a4 += (nA - r) * rowStep;
+            a4B = a4 + (nB - nA) * rowStep;
+            xA = fetch(a4);
+            leftA = col0[nA];
+            xB = fetch(a4B);
+            leftB = col0[nB];
+            if (MODEL == 2) { dA = d1s[nA]; dB = d1s[nB]; }
+            const Quad qa = sums(x0, l0, e0);
+            const Quad qb = sums(x1, l1, e1);                     // (of the last row once more where the block has no row r + 1)
+            put(r, qa);
+            if (r + 1u < r1) put(r + 1u, qb);
+        }
+    }
+    __syncthreads();
+}
+
+template <class M32Ptr>
+__device__ __forceinline__ void m32_bytes_to_tile(DecShared &S, M32Ptr m32, const int model, const uint32_t seed, const uint32_t nR,
+                                                  const uint32_t nC, uint32_t *__restrict__ o)
+{
+    if (model == 3) m32_bytes_rows<3>(S, m32, seed, nR, nC, o);
+    else if (model == 1) m32_bytes_rows<1>(S, m32, seed, nR, nC, o);
+    else m32_bytes_rows<2>(S, m32, seed, nR, nC, o);
+}
+
 // The Huffman text of a tile whose serialised tree is INCOMPLETE (DecShared::skipLen), decoded the way the reference walks
 // it (HuffmanDecoder.decode :179-185 over the node table of decodeTree :87-120): a step onto a child that was never read
 // finds 0 in the table, which is the root's own slot, so the walk starts over at the root WITHOUT a symbol.  The missing
@@ -2055,7 +2251,8 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             const uint32_t slot = block_excl_scan(isShort ? 1u : 0u, S.waveSum, &nShort);
             if (isShort) S.shortLeaf[slot & 63u] = (uint8_t)tid;
             if (tid == 0) {
-                const uint32_t maxLen = rec[3];
+                const uint32_t maxLen = rec[3] & 0xffu;
+                S.symKinds = rec[3] & ~0xffu;
                 S.uniformSym = (int32_t)rec[4];
                 S.skipLen = rec[5];
                 S.skipLo = rec[6];
@@ -2206,6 +2403,15 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 return (int32_t)GF_K_SKIP;
             } else {
                 // ---------------- phases 2 + 3 fused: M32 bytes -> values, one store per cell ----------------
+                if constexpr (FAST && decltype(inLds)::value) {
+                    // a tree of one-byte values only (no introducer, no null code among its leaves): the byte path
+                    if (!(GF_UNI(S.symKinds) & (GF_TREE_HAS_INTRODUCER | GF_TREE_HAS_NULL)) && byte_path_eligible(model, nR, nC, a.ldsM32Bytes)) {
+                        fused = true;
+                        GF_DPHASE_LIMIT(4, return (int32_t)GF_K_OK);
+                        m32_bytes_to_tile(S, m32, model, seed, nR, nC, o);
+                        return (int32_t)GF_K_OK;
+                    }
+                }
                 if constexpr (decltype(inLds)::value) {
                     if (FAST || (plan.ring && model >= 1 && model <= 3)) {
                         fused = true;
@@ -2452,8 +2658,15 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     uint32_t maxLen = 1;
     uint32_t skipLen = 0;
     unsigned long long skipPath = 0;
+    // which kinds of M32 bytes the text can hold at all (GF_TREE_HAS_*): a tree without the introducers 0x7f / 0x81 codes
+    // one-byte values only, so byte j of the Huffman output IS stream element j (CodecM32.java:327-356)
+    uint32_t symKinds = 0;
+    auto kindOf = [](uint32_t sym) -> uint32_t {
+        return (sym == 0x7fu || sym == 0x81u) ? GF_TREE_HAS_INTRODUCER : sym == 0x80u ? GF_TREE_HAS_NULL : 0u;
+    };
     if (rootBit == 1) {
         uniformSym = (int32_t)take(8);
+        symKinds = kindOf((uint32_t)uniformSym);
     } else {
         uint64_t c = 0;
         uint32_t L = 1;
@@ -2482,6 +2695,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             codes[leaves] = __brevll(c) >> (64u - L);
             lens[leaves] = (uint8_t)L;
             syms[leaves] = (uint8_t)(r9 >> 1);
+            symKinds |= kindOf(r9 >> 1);
             maxLen = max(maxLen, L);
             leaves++;
             const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;
@@ -2499,7 +2713,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     rec[0] = (uint32_t)st;
     rec[1] = nLeaves;
     rec[2] = bp;
-    rec[3] = maxLen;
+    rec[3] = maxLen | symKinds;
     rec[4] = (uint32_t)uniformSym;
     rec[5] = skipLen;
     rec[6] = (uint32_t)skipPath;
