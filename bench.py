@@ -46,11 +46,17 @@ WORKLOADS = {
     # "a variant with 5 % INT4_NULL_CODE ocean-mask blocks to exercise a6" (PredictorModelDifferencingWithNulls)
     "etopo1_nulls": (120, 150, 12960, 144, "ETOPO1-shaped grid as etopo1 with an ocean mask: 5 % of its 16x16 blocks are null "
                                            "(nearly every tile takes PredictorModelDifferencingWithNulls)"),
+    # "neighbouring-cell differences mostly within +-126 with a tail into 2-3 byte codes" -- the rough surface
+    # (provinces of mountains / plains / stripes, cliff and scree blocks: gf_synth_dem_style_dev): each predictor wins a share
+    # of the tiles, 4-5 % of the row differences need two M32 bytes, 0.5 % three
+    "etopo1_rough": (120, 150, 12960, 144, "ETOPO1-shaped grid as etopo1, rough surface: every predictor wins a share of the tiles, "
+                                           "multi-byte M32 values in four tiles of five"),
     "float256": (256, 256, 4096, 64, "4096 tiles of 256x256 float32 (DEM x 0.1f), CodecFloat byte-plane stage"),
     "float256_lsop": (256, 256, 4096, 64, "4096 tiles of 256x256 float32 (DEM x 0.1f) stored as int-coded floats "
                                           "(scale 10, GvrsElementSpecificationIntCodedFloat), LSOP12"),
 }
 MASK_PER_MILLE = {"etopo1_nulls": 50}
+STYLE = {"etopo1_rough": 1}   # GF_DEM_STYLE_ROUGH
 STRONG = {"gebco_full"}       # workloads whose tile count is the whole job's (divided over the GPUs); the others are per GPU
 FP64_PEAK_TFLOPS = 78.6       # MI355X vector FP64 (the roof k_lsop_predict's normal equations are priced against)
 
@@ -345,6 +351,58 @@ def _entropy(vals, n_rows, n_cols):
             "null_cell_share": round(float(null.mean()), 4)}
 
 
+def _m32_stats(vals, preds, n_rows, n_cols):
+    """What the batch asks of the codec beyond the easy case: which predictor won how many tiles (CodecHuffman.java:100-110) and
+    how many M32 bytes the row differences of a sample of tiles need (CodecM32.java:105-111: 1 byte up to 126, 2 up to 254, 3 up
+    to 16,638)."""
+    preds = np.asarray(preds)
+    winners = {str(m): round(float((preds == m).mean()), 4) for m in (1, 2, 3, 4) if (preds == m).any()}
+    t = np.asarray(vals).reshape(-1, n_rows, n_cols)
+    t = t[:: max(1, len(t) // 256)][:256].astype(np.int64)
+    null = t == -2 ** 31
+    d = np.abs((t[:, :, 1:] - t[:, :, :-1])[~(null[:, :, 1:] | null[:, :, :-1])])
+    n = max(1, d.size)
+    return {"winners": winners,
+            "row_difference_m32_bytes": {"1": round(float((d <= 126).sum()) / n, 4), "2": round(float(((d > 126) & (d <= 254)).sum()) / n, 4),
+                                         "3+": round(float((d > 254).sum()) / n, 4), "of": "256 sampled tiles"}}
+
+
+def _rough_record(args, ctx, batch, n_rows, n_cols, n_tiles, tiles_per_row, seed, headline_ms, headline_c):
+    """The same grid as the ROUGH surface (--workload etopo1_rough), timed beside the headline on the same batch buffers: the
+    headline's surface is the codec's easiest case (Triangle wins every tile, every M32 value is one byte).  encode / decode in
+    ms per batch (HIP events, 2 warm-up + 10 timed steps), winners, M32 byte shares, and the time per PACKED byte against the
+    headline's (a rougher surface packs to more bytes; what is left beyond that ratio is what the harder cases cost)."""
+    from gridfour_amd import GpuTimer
+    batch.synth_dem(seed, tiles_per_row, tile0=0, style=STYLE["etopo1_rough"])
+    ctx.synchronize()
+    reps = 10
+    te, td = [GpuTimer(ctx) for _ in range(reps)], [GpuTimer(ctx) for _ in range(reps)]
+    for _ in range(2):
+        batch.encode(codec_index=0)
+        batch.decode()
+    for i in range(reps):
+        te[i].start()
+        batch.encode(codec_index=0)
+        te[i].stop()
+        td[i].start()
+        batch.decode()
+        td[i].stop()
+    ctx.synchronize()
+    enc, dec = float(np.mean([t.elapsed_ms() for t in te])), float(np.mean([t.elapsed_ms() for t in td]))
+    ok, packed, vals = _verify_shard(args, batch, n_rows, n_cols, n_tiles, with_oracle=True)
+    cells = n_rows * n_cols
+    c = packed / float(n_tiles * cells)
+    raw_mb = n_tiles * cells * 4 / 1e6
+    rec = {"workload": "etopo1_rough", "encode_ms": round(enc, 4), "decode_ms": round(dec, 4), "MBps": round(raw_mb / ((enc + dec) * 1e-3), 1),
+           "bit_exact": bool(ok), "bytes_per_cell": round(c, 4)}
+    rec.update(_m32_stats(vals, batch.get_predictors(), n_rows, n_cols))
+    he, hd = headline_ms
+    rec["vs_headline"] = {"encode_ms_ratio": round(enc / he, 3), "decode_ms_ratio": round(dec / hd, 3), "packed_bytes_ratio": round(c / headline_c, 3),
+                          "encode_per_packed_byte": round((enc / he) / (c / headline_c), 3),
+                          "decode_per_packed_byte": round((dec / hd) / (c / headline_c), 3)}
+    return rec
+
+
 def _lsop_fp64_roofline(ctx, batch, n_rows, n_cols, n_tiles, reps):
     """k_lsop_predict against the FP64 roof: the normal equations of LsOptimalPredictor12.computeCoefficients
     (:335-342) are 91 multiply-adds + 13 adds = 195 FP64 flop per interior cell.  The kernel is launched on its own
@@ -572,12 +630,13 @@ def main():
     else:
         ctxs = [gridfour_amd.GvrsHipContext(local_rank)]
     stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
-    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "etopo1_nulls": 2, "gebco_shard": 3, "gebco_full": 3, "float256_lsop": 5}[args.workload]
+    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "etopo1_nulls": 2, "etopo1_rough": 2, "gebco_shard": 3, "gebco_full": 3, "float256_lsop": 5}[args.workload]
     batches = []
     for g, ctx in enumerate(ctxs):
         b = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
         # shard s owns the contiguous tile range starting at s * n_tiles of the global grid (weak scaling)
-        b.synth_dem(seed, tiles_per_row, tile0=(g if single_multi else rank) * n_tiles, mask_per_mille=MASK_PER_MILLE.get(args.workload, 0))
+        b.synth_dem(seed, tiles_per_row, tile0=(g if single_multi else rank) * n_tiles, mask_per_mille=MASK_PER_MILLE.get(args.workload, 0),
+                    style=STYLE.get(args.workload, 0))
         ctx.synchronize()
         if args.workload == "float256_lsop":
             # config 5(ii): the float tiles of config 5(i) (DEM x 0.1f) as the reference stores them in an int-coded-float
@@ -712,11 +771,17 @@ def main():
             dist.all_gather_object(gathered, devices[0])
             devices = gathered
 
-    cpu_baseline, host_path = None, None
+    cpu_baseline, host_path, rough, data_stats = None, None, None, None
+    if rank == 0 and vals0 is not None:
+        data_stats = _m32_stats(vals0, batches[0].get_predictors(), n_rows, n_cols)
     if rank == 0 and total_shards == 1 and not args.no_verify:
         cpu_baseline = _cpu_baseline(args, vals0, n_rows, n_cols, n_tiles)
         if args.codec == "huffman" and args.cpu_sample_tiles != 0:
             host_path = _host_path(ctxs[0].handle, vals0, n_rows, n_cols)
+        if args.codec == "huffman" and args.workload == "etopo1" and args.cpu_sample_tiles != 0:
+            # (last: it refills the batch's buffers with the rough surface)
+            rough = _rough_record(args, ctxs[0], batches[0], n_rows, n_cols, n_tiles, tiles_per_row, seed,
+                                  (float(np.max(enc_ms)), float(np.max(dec_ms))), c_per_cell)
 
     if rank != 0:
         if launcher:
@@ -774,6 +839,10 @@ def main():
         "cpu_baseline": cpu_baseline,
         "host_path": host_path,
     }
+    if data_stats:
+        out["config"]["data"] = data_stats
+    if rough:
+        out["rough"] = rough
     out["roofline_issue"] = _issue_roofline(args.workload, dom_name, n_tiles, dom_ms)
     if args.codec == "lsop" and vals0 is not None and args.cpu_sample_tiles != 0:
         out["default_container"] = _lsop_default_container(ctxs[0].handle, vals0, n_rows, n_cols, 2048)

@@ -98,6 +98,7 @@ SIGNATURES = {
     "gf_float_decode_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
     "gf_synth_dem_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_size_t, _vp]),
     "gf_synth_dem_masked_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_size_t, C.c_int, _vp]),
+    "gf_synth_dem_style_dev": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_size_t, C.c_int, C.c_int, _vp]),
     "gf_dev_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "gf_dev_free": (C.c_int, [_vp, _vp]),
     "gf_dev_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),

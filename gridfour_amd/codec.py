@@ -310,7 +310,12 @@ class DeviceTileBatch:
             self.coefs = DeviceBuffer(ctx, nt * 64)
             self.scratch_status = DeviceBuffer(ctx, nt * 4)
 
-    def synth_dem(self, seed, tiles_per_row, tile0=0, stream=None, mask_per_mille=0):
+    def synth_dem(self, seed, tiles_per_row, tile0=0, stream=None, mask_per_mille=0, style=0):
+        if style:
+            check(lib().gf_synth_dem_style_dev(self.ctx.handle, stream, seed & (2 ** 64 - 1), self.n_rows, self.n_cols,
+                                               tiles_per_row, tile0, self.n_tiles, mask_per_mille, style, self.values.ptr),
+                  "gf_synth_dem_style_dev")
+            return
         if mask_per_mille:
             check(lib().gf_synth_dem_masked_dev(self.ctx.handle, stream, seed & (2 ** 64 - 1), self.n_rows, self.n_cols,
                                                 tiles_per_row, tile0, self.n_tiles, mask_per_mille, self.values.ptr),

@@ -429,6 +429,12 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     } else {
         a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
+        if (a.retryFlag) {
+            // a second run of the fast kernel with LDS for two M32 bytes per cell, for the tiles that outgrow the usual 1.125
+            const size_t cells = (size_t)nRows * (size_t)nCols;
+            const size_t roomy = std::min<size_t>(98304, (2 * cells + 1024 + 31) & ~(size_t)31);
+            a.ldsM32Roomy = roomy > a.ldsM32Bytes ? (uint32_t)roomy : 0u;
+        }
         // Occupancy is set by LDS (M32 stream + start bitmap + tables per workgroup), handed out in 1,280-byte steps, and the kernel
         // gains from every wave a CU can hold (tools/occupancy_sweep.sh).  Two builds of the same source: 256 threads (two Huffman
         // cursors per thread in lockstep, the leaner one per wave) and 512 threads (one cursor per thread, 64 VGPRs, up to four
@@ -644,6 +650,16 @@ gf_status gf_synth_dem_masked_dev(gf_context *c, void *stream, uint64_t seed, in
     return GF_OK;
 }
 
+gf_status gf_synth_dem_style_dev(gf_context *c, void *stream, uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                                 int64_t tile0, size_t nTiles, int maskPerMille, int style, int32_t *dValues)
+{
+    if (!c || nRows < 1 || nCols < 1 || tilesPerRow < 1 || !dValues || maskPerMille < 0 || maskPerMille > 1000) return GF_ERR_ARG;
+    if (style != GF_DEM_STYLE_CLASSIC && style != GF_DEM_STYLE_ROUGH) return GF_ERR_ARG;
+    GF_HIP(hipSetDevice(c->device));
+    GF_HIP(gf_launch_synth_dem(seed, nRows, nCols, tilesPerRow, tile0, nTiles, dValues,
+                               stream ? (hipStream_t)stream : c->stream, maskPerMille, style));
+    return GF_OK;
+}
 
 // ------------------------------------------------------------------ CodecFloat
 

@@ -110,6 +110,72 @@ __device__ int32_t dem_value(uint64_t seed, int64_t gx, int64_t gy)
     return (int32_t)sum;
 }
 
+// The rough surface (style 1, round 4; SURVEY.md 8d asks for "a tail into 2-3 byte codes", which the classic surface does not
+// have): provinces of 1024 x 1024 cells -- mountains (the classic surface), plains (a sixteenth of the largest octave's relief
+// under jitter of -6..6: PredictorModelDifferencing wins), stripes (every row samples the classic surface 37 rows further on:
+// PredictorModelLinear wins) -- and, on hashed 16 x 16 blocks, cliffs (one more octave: lattice spacing 4, amplitude 520) and
+// scree (white noise of -150..150): row differences that need two and three M32 bytes (CodecM32.java:270-311).  Same integer
+// recipe as the test-side generator; the statistics are in its comment and in the bench line.
+constexpr int DEM_PROVINCE_SHIFT = 10;
+constexpr int64_t DEM_CLIFF_AMP = 520;
+constexpr uint32_t DEM_SCREE_AMP = 150;
+__device__ __forceinline__ int64_t dem_octaves(uint64_t seed, int64_t gx, int64_t gy, int first, int last)
+{
+    int64_t sum = 0;
+    for (int o = first; o < last; o++) {
+        const int sh = 8 - o;
+        const int64_t s = (int64_t)1 << sh;
+        const int64_t i = gx >> sh, j = gy >> sh;
+        const int64_t fx = gx & (s - 1), fy = gy & (s - 1);
+        const int64_t l00 = dem_lattice(seed, o, i, j), l10 = dem_lattice(seed, o, i + 1, j);
+        const int64_t l01 = dem_lattice(seed, o, i, j + 1), l11 = dem_lattice(seed, o, i + 1, j + 1);
+        const int64_t top = l00 * (s - fx) + l10 * fx;
+        const int64_t bot = l01 * (s - fx) + l11 * fx;
+        sum += (top * (s - fy) + bot * fy) >> (2 * sh);
+    }
+    return sum;
+}
+__device__ int32_t dem_value_rough(uint64_t seed, int64_t gx, int64_t gy)
+{
+    const uint64_t hp = splitmix64(seed ^ 0x5500000000000000ULL ^ ((((uint64_t)gy >> DEM_PROVINCE_SHIFT) & 0xFFFFFFFULL) << 28) ^
+                                   (((uint64_t)gx >> DEM_PROVINCE_SHIFT) & 0xFFFFFFFULL));
+    const uint32_t k = (uint32_t)((hp >> 33) % 100u);
+    const int kind = k < 50u ? 0 : k < 72u ? 1 : 2;                  // mountains, plains, stripes
+    const uint64_t hj = splitmix64(seed ^ 0x7700000000000000ULL ^ (((uint64_t)gy & 0xFFFFFFFULL) << 28) ^ ((uint64_t)gx & 0xFFFFFFFULL));
+    int64_t sum;
+    uint32_t cliffShare, screeShare;                                 // of 64
+    if (kind == 0) {
+        sum = dem_octaves(seed, gx, gy, 0, 6) + (int64_t)((hj >> 40) % 5) - 2;
+        cliffShare = 12; screeShare = 8;
+    } else if (kind == 1) {
+        sum = (dem_octaves(seed, gx, gy, 0, 1) >> 4) + (int64_t)((hj >> 40) % 13) - 6;
+        cliffShare = 0; screeShare = 0;
+    } else {
+        sum = dem_octaves(seed, gx, gy * 37, 0, 6);
+        cliffShare = 4; screeShare = 0;
+    }
+    const uint64_t hb = splitmix64(seed ^ 0x6600000000000000ULL ^ ((((uint64_t)gy >> 4) & 0xFFFFFFFULL) << 28) ^
+                                   (((uint64_t)gx >> 4) & 0xFFFFFFFULL));
+    const uint32_t pick = (uint32_t)((hb >> 33) & 63u);
+    if (pick < cliffShare) {
+        const int64_t i = gx >> 2, j = gy >> 2, fx = gx & 3, fy = gy & 3;
+        int64_t l[4];
+        for (int q = 0; q < 4; q++) {
+            const uint64_t h = splitmix64(seed ^ 0x4400000000000000ULL ^ ((((uint64_t)(j + (q >> 1))) & 0xFFFFFFFULL) << 28) ^
+                                          (((uint64_t)(i + (q & 1))) & 0xFFFFFFFULL));
+            l[q] = (int64_t)((((h >> 32) & 0xFFFF) * (uint64_t)(2 * DEM_CLIFF_AMP)) >> 16) - DEM_CLIFF_AMP;
+        }
+        const int64_t top = l[0] * (4 - fx) + l[1] * fx, bot = l[2] * (4 - fx) + l[3] * fx;
+        sum += (top * (4 - fy) + bot * fy) >> 4;
+    } else if (pick < cliffShare + screeShare) {
+        sum += (int64_t)((hj >> 20) % (2u * DEM_SCREE_AMP + 1u)) - (int64_t)DEM_SCREE_AMP;
+    }
+    sum -= 2000;
+    if (sum < -11000) sum = -11000;
+    if (sum > 8848) sum = 8848;
+    return (int32_t)sum;
+}
+
 // ocean mask of the nulls workload: 16 x 16 blocks of the grid, maskPerMille / 1000 of them null
 __device__ __forceinline__ bool dem_masked(uint64_t seed, int64_t gx, int64_t gy, int maskPerMille)
 {
@@ -119,7 +185,7 @@ __device__ __forceinline__ bool dem_masked(uint64_t seed, int64_t gx, int64_t gy
 }
 
 __global__ __launch_bounds__(256) void k_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
-                                                   int64_t tile0, size_t nTiles, int maskPerMille, int32_t *__restrict__ values)
+                                                   int64_t tile0, size_t nTiles, int maskPerMille, int style, int32_t *__restrict__ values)
 {
     const size_t nCells = (size_t)nRows * (size_t)nCols;
     const size_t total = nTiles * nCells;
@@ -130,7 +196,8 @@ __global__ __launch_bounds__(256) void k_synth_dem(uint64_t seed, int nRows, int
         const int64_t tile = tile0 + (int64_t)t;
         const int64_t tr = tile / tilesPerRow, tc = tile % tilesPerRow;
         const int64_t gx = tc * nCols + c, gy = tr * nRows + r;
-        values[g] = maskPerMille > 0 && dem_masked(seed, gx, gy, maskPerMille) ? (int32_t)0x80000000u : dem_value(seed, gx, gy);
+        values[g] = maskPerMille > 0 && dem_masked(seed, gx, gy, maskPerMille) ? (int32_t)0x80000000u
+                    : style == 1 ? dem_value_rough(seed, gx, gy) : dem_value(seed, gx, gy);
     }
 }
 
@@ -149,10 +216,10 @@ hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStr
 }
 
 hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow, int64_t tile0,
-                               size_t nTiles, int32_t *values, hipStream_t stream, int maskPerMille)
+                               size_t nTiles, int32_t *values, hipStream_t stream, int maskPerMille, int style)
 {
     if (nTiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_synth_dem, dim3(4096), dim3(256), 0, stream, seed, nRows, nCols, tilesPerRow, tile0, nTiles,
-                       maskPerMille, values);
+                       maskPerMille, style, values);
     return hipGetLastError();
 }

@@ -118,6 +118,11 @@ struct DecShared {
 
 #include "gvrs_decode_common.h"
 
+// A first-level entry with bit 31 set stands for codes longer than the window: bits 0-15 = the prefix's second-level table (its
+// number among the tile's; may lie beyond the tables there is room for), bits 16-23 = the first leaf with that prefix.  A
+// second-level entry is (length << 8) | symbol, or LUT2_SEARCH | first leaf with that (longer) prefix: the code is too long for the
+// table and is looked up among the leaves from there (0xFFFF: never filled -- damaged input --, the whole leaf table).
+constexpr uint32_t LUT_SUB_MASK = 0xffffu, LUT_FIRST_SHIFT = 16u, LUT2_SEARCH = 0x8000u;
 // lookup entry of one symbol
 __device__ __forceinline__ uint32_t lut_single(uint32_t sym, uint32_t len) { return sym | (len << 16) | (len << 22); }   // len <= 63
 
@@ -174,15 +179,18 @@ struct HuffCursorT {
     // Returns a single-symbol entry.
     __device__ __forceinline__ uint32_t resolve_long(uint32_t e, uint32_t w32v) const
     {
-        const uint32_t l2 = S->l2bits, sub = e & 0x7fffffffu;
-        uint32_t e16 = sub < ((uint32_t)L2_ENTRIES >> l2) ? lut2[(sub << l2) | ((w32v >> LUT_BITS) & ((1u << l2) - 1u))] : 0xFFFFu;
-        if (e16 == 0xFFFFu) {
-            // 64 bits of text for the leaf-table search (rare)
+        const uint32_t l2 = S->l2bits, sub = e & LUT_SUB_MASK;
+        uint32_t e16 = sub < ((uint32_t)L2_ENTRIES >> l2) ? lut2[(sub << l2) | ((w32v >> LUT_BITS) & ((1u << l2) - 1u))]
+                                                           : (uint32_t)(LUT2_SEARCH | ((e >> LUT_FIRST_SHIFT) & 0xffu));
+        if (e16 & LUT2_SEARCH) {
+            // 64 bits of text for the leaf-table search (rare), from the first leaf that shares the code's known prefix
             const uint64_t lo = ((uint64_t)w1 << 32) | w0;
             uint64_t w = lo >> sh;
             if (sh) w |= (uint64_t)w2 << (64u - sh);
             const uint32_t n = S->nLeaves;
-            for (uint32_t i = 0; i < n; i++) {
+            const uint32_t first = e16 == 0xFFFFu ? 0u : e16 & 0xffu;
+            e16 = 0xFFFFu;
+            for (uint32_t i = first; i < n; i++) {
                 const uint32_t cl = S->leafLen[i];
                 const uint64_t mask = cl >= 64 ? ~0ull : ((1ull << cl) - 1ull);
                 if (cl > LUT_BITS && (w & mask) == S->leafCode[i]) {
@@ -486,15 +494,21 @@ struct FastHuff {
 __device__ __forceinline__ uint32_t fh_resolve(const FastHuff &H, uint32_t e, uint32_t w, uint32_t x0, uint32_t x1, uint32_t x2,
                                                uint32_t sh)
 {
-    const uint32_t sub = e & 0x7fffffffu;
-    uint32_t e16 = 0xFFFFu;
+    const uint32_t sub = e & LUT_SUB_MASK;
+    uint32_t e16 = LUT2_SEARCH | ((e >> LUT_FIRST_SHIFT) & 0xffu);
     if (sub < H.nSub) e16 = H.lut2[(sub << H.l2bits) | ((w >> LUT_BITS) & ((1u << H.l2bits) - 1u))];
-    if (e16 == 0xFFFFu) {
+    if (e16 & LUT2_SEARCH) {
+        // the leaf table, from the first leaf that shares the code's known prefix (the leaves are in pre-order: those that share a
+        // prefix lie side by side).  Round 4: the search used to start at leaf 0 and reads the path bits from the tile's record in
+        // global memory -- a tile of flat ground with a few hundred rare symbols (codes of 19 bits and more) spent five million
+        // cycles here, and the launch waited for it.
         const uint64_t lo = ((uint64_t)x1 << 32) | x0;
         uint64_t t = lo >> sh;
         if (sh) t |= (uint64_t)x2 << (64u - sh);
         const uint32_t n = H.S->nLeaves;
-        for (uint32_t i = 0; i < n; i++) {
+        const uint32_t first = e16 == 0xFFFFu ? 0u : e16 & 0xffu;
+        e16 = 0xFFFFu;
+        for (uint32_t i = first; i < n; i++) {
             const uint32_t cl = H.S->leafLen[i];
             const uint64_t mask = cl >= 64 ? ~0ull : ((1ull << cl) - 1ull);
             if (cl > LUT_BITS && (t & mask) == H.leafCodeG[i]) {
@@ -941,7 +955,7 @@ __device__ void parse_tree_wave(DecShared &S, uint32_t relBit, uint32_t absBit, 
                     // a branch at depth LUT_BITS on this path: codes below it continue into a second-level table,
                     // indexed by the first LUT_BITS bits of the path (first step in bit 0)
                     const uint32_t prefix = (uint32_t)((c << z) >> (L + z - LUT_BITS));
-                    if (writer) S.lut[__brev(prefix) >> (32 - LUT_BITS)] = 0x80000000u | nSub;
+                    if (writer) S.lut[__brev(prefix) >> (32 - LUT_BITS)] = 0x80000000u | (leaves << LUT_FIRST_SHIFT) | nSub;   // (leaves: the next leaf's index)
                     nSub++;
                 }
                 c <<= z;                                             // z <= 63 here
@@ -1044,13 +1058,22 @@ __device__ __forceinline__ void build_lut(DecShared &S, Lut2Ptr lut2)
             const uint32_t cl = S.leafLen[tid];
             if (cl > LUT_BITS && cl <= LUT_BITS + l2) {
                 const uint64_t code = S.leafCode[tid];
-                const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & 0x7fffffffu;
+                const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & LUT_SUB_MASK;
                 if (subIdx < nSub) {
                     uint16_t *sub = &lut2[subIdx << l2];
                     const uint16_t e = (uint16_t)((cl << 8) | S.leafSym[tid]);
                     for (uint32_t x = (uint32_t)(code >> LUT_BITS); x < (1u << l2); x += 1u << (cl - LUT_BITS))
                         sub[x] = e;
                 }
+            } else if (cl > LUT_BITS + l2) {
+                // too long for the second level too: the first leaf of those that share its LUT_BITS + l2 bits (they lie side by
+                // side) leaves its index in their slot, where the search starts
+                const uint64_t code = S.leafCode[tid];
+                const uint32_t subIdx = S.lut[(uint32_t)code & ((1u << LUT_BITS) - 1u)] & LUT_SUB_MASK;
+                const uint64_t pmask = (1ull << (LUT_BITS + l2)) - 1ull;
+                const bool first = tid == 0 || S.leafLen[tid - 1] <= LUT_BITS + l2 || ((S.leafCode[tid - 1] ^ code) & pmask) != 0ull;
+                if (subIdx < nSub && first)
+                    lut2[(subIdx << l2) | ((uint32_t)(code >> LUT_BITS) & ((1u << l2) - 1u))] = (uint16_t)(LUT2_SEARCH | (uint32_t)tid);
             }
         }
     }
@@ -1082,7 +1105,8 @@ __device__ __forceinline__ void m32_mark_starts(DecShared &S, M32Ptr m32, uint32
     cur.base = 0;
     cur.d0 = cur.d1 = cur.d2 = 0;
     const uint32_t *m32w = reinterpret_cast<const uint32_t *>(m32);
-    if (tid == 0) { S.chainEnd = 0; S.dense = 0; }
+    if (tid == 0) { S.chainEnd = 0; S.dense = 0; S.nRedo[0] = 0; }
+    constexpr uint32_t OPEN_CAP = MAXQ;                 // open words are listed in S.qs (free between the Huffman passes and here)
     __syncthreads();
     // Local resolution, 32 bytes of the stream (one bitmap word) per thread, by bit operations on masks -- no walk over the bytes.
     // I: bytes that may be an introducer (0x7f / 0x81), H: bytes with the continuation bit.  A true introducer at p makes p+1 a
@@ -1130,10 +1154,24 @@ __device__ __forceinline__ void m32_mark_starts(DecShared &S, M32Ptr m32, uint32
             if (w < bmWords) {
                 unsigned long long I64 = ((unsigned long long)bm[w] << 32) | (w ? bm[w - 1u] : 0u);
                 const unsigned long long H64 = ((unsigned long long)wb[w] << 32) | (w ? wb[w - 1u] : 0u);
-                const unsigned long long U = I64 | (I64 << 1) | (I64 << 2) | (I64 << 3) | (I64 << 4);   // bit m: a candidate in m-4..m
-                // bit j: no candidate in j-5..j-1; positions 0..4 of the window do not see all of their five (the word before the
-                // first one is empty: byte 0 of the stream is an anchor)
-                const unsigned long long anchors = ~(U << 1) & ~0x1Full & 0x1FFFFFFFFull;               // up to my first byte (bit 32)
+                // Anchors (round 4): the bytes that NO candidate of the window could cover even if every one of them were a true
+                // introducer -- a byte inside a value lies behind that value's introducer with nothing but continuation bytes in
+                // between, so a byte no candidate reaches that way starts a value.  Positions 0..4 of the window do not see all of
+                // the five bytes before them and do not count (the word before the first one is empty: byte 0 of the stream is an
+                // anchor).  (Round 3 asked for five bytes without any candidate in front of an anchor: a run of three-byte values --
+                // the border residuals of a tile whose rows have little to do with each other -- has none for hundreds of bytes,
+                // and every tile of the rough workload had words left open.)
+                unsigned long long reach;
+                {
+                    unsigned long long c = I64 << 1;
+                    reach = c;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        c = (c & H64) << 1;
+                        reach |= c;
+                    }
+                }
+                const unsigned long long anchors = ~reach & ~0x1Full & 0x1FFFFFFFFull;                  // up to my first byte (bit 32)
                 bool settled = false;
                 unsigned long long Sx = 0;
                 if (anchors) {
@@ -1152,12 +1190,73 @@ __device__ __forceinline__ void m32_mark_starts(DecShared &S, M32Ptr m32, uint32
                         T = Tn;
                     }
                 }
-                if (!settled) S.dense = 1;
                 const uint32_t left = nM32 - 32u * w, valid = left >= 32u ? 0xFFFFFFFFu : (1u << left) - 1u;
                 starts = (uint32_t)(Sx >> 32) & valid;
+                if (!settled) {
+                    // round 4: the word is left OPEN (no start marked) and listed; the words around it that did settle are
+                    // final, and an open word is walked from the end of its left neighbour's last value below.  (The whole
+                    // tile used to fall back to the chain resolution for one such word: a steep slope next to scree in the
+                    // rough workload cost the tile ten times its usual time.)
+                    starts = 0;
+                    const uint32_t slot = atomicAdd(&S.nRedo[0], 1u);
+                    if (slot < OPEN_CAP) S.qs[slot] = w;
+                }
             }
             __syncthreads();                            // every mask of this turn has been read
             if (w < bmWords) bm[w] = starts;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t nOpen = S.nRedo[0];
+        if (nOpen > OPEN_CAP || 8u * nOpen > bmWords + 56u || ((bmWords + 31u) >> 5) > (uint32_t)MAXQ) {
+            if (tid == 0) S.dense = 1;                  // dense in multi-byte values all over: the chain resolution
+        } else if (nOpen) {
+            // A value is at most six bytes, so every 32-byte word holds a start: an open word whose left neighbour is final
+            // begins where that neighbour's last value ends, and is walked from there, a lane per word.  Runs of open words
+            // take a round per word of the run.
+            uint32_t *openBits = S.qe;                  // bit w: word w is still open
+            for (uint32_t i = tid; i < (bmWords + 31u) >> 5; i += DEC_THREADS) openBits[i] = 0;
+            __syncthreads();
+            for (uint32_t e = tid; e < nOpen; e += DEC_THREADS) atomicOr(&openBits[S.qs[e] >> 5], 1u << (S.qs[e] & 31u));
+            __syncthreads();
+            for (;;) {
+                int progress = 0;
+                uint32_t doneW = 0xFFFFFFFFu, doneMask = 0;
+                for (uint32_t e = tid; e < nOpen; e += DEC_THREADS) {   // (nOpen <= DEC_THREADS as a rule: one word per thread)
+                    const uint32_t w = S.qs[e];
+                    if (!((openBits[w >> 5] >> (w & 31u)) & 1u)) continue;
+                    if (w > 0u && ((openBits[(w - 1u) >> 5] >> ((w - 1u) & 31u)) & 1u)) continue;   // its neighbour first
+                    M32Cursor c = cur;
+                    uint32_t pos = 32u * w;
+                    const uint32_t before = w > 0u ? bm[w - 1u] : 0u;
+                    if (before) {
+                        c.seek(32u * (w - 1u) + 31u - (uint32_t)__builtin_clz(before));
+                        c.next();
+                        pos = max(pos, c.pos);
+                    }
+                    const uint32_t limit = min(nM32, 32u * w + 32u);
+                    uint32_t mask = 0;
+                    if (pos < limit) {
+                        c.seek(pos);
+                        while (c.pos < limit) {
+                            mask |= 1u << (c.pos & 31u);
+                            c.next();
+                        }
+                    }
+                    doneW = w;
+                    doneMask = mask;
+                    progress = 1;
+                    break;                                              // one word per thread and round
+                }
+                const int any = __syncthreads_or(progress);             // every neighbour's state has been read
+                if (doneW != 0xFFFFFFFFu) {
+                    bm[doneW] = doneMask;
+                    atomicAnd(&openBits[doneW >> 5], ~(1u << (doneW & 31u)));
+                }
+                __syncthreads();
+                if (!any) break;
+            }
         }
     }
     __syncthreads();
@@ -2167,13 +2266,19 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
     const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
     if constexpr (MODE == DEC_GENERAL) {
-        if (a.retryFlag && *a.retryFlag == 0u) return;               // the fast kernel decoded every tile
+        if (a.retryFlag && a.retryFlag[a.ldsM32Roomy ? 1 : 0] == 0u) return;   // the fast kernel decoded every tile
+    }
+    if constexpr (MODE == DEC_FAST) {
+        if (a.retryPass && a.retryFlag[0] == 0u) return;             // second run: nothing was left behind
     }
 
     GF_FOR_TILES(t, a.nTiles, MODE == DEC_FAST) {                     // the fast kernel: one tile per workgroup, no loop (it never
                                                                       // touches the per-workgroup workspace)
         if constexpr (MODE == DEC_GENERAL) {
             if (a.retryFlag && a.status[t] != GF_K_RETRY) continue;
+        }
+        if constexpr (MODE == DEC_FAST) {
+            if (a.retryPass && a.status[t] != GF_K_RETRY) continue;
         }
         const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
         const uint32_t len = a.lengths[t];
@@ -2210,7 +2315,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         if constexpr (FAST) {
             if (early == GF_K_OK && (nM32 > a.ldsM32Bytes || !plan.ring)) {
                 early = GF_K_RETRY;
-                if (tid == 0) atomicOr(a.retryFlag, 1u);
+                if (tid == 0) atomicOr(a.retryFlag + (a.retryPass ? 1 : 0), 1u);
             }
         }
         if (early != GF_K_OK) {
@@ -2246,7 +2351,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 opens = ((uint32_t)S.leafCode[tid - 1] & ((1u << LUT_BITS) - 1u)) != prefix;
             uint32_t nSub, nShort;
             const uint32_t subIdx = block_excl_scan(opens ? 1u : 0u, S.waveSum, &nSub);
-            if (opens) S.lut[prefix] = 0x80000000u | subIdx;
+            if (opens) S.lut[prefix] = 0x80000000u | ((uint32_t)tid << LUT_FIRST_SHIFT) | subIdx;
             const bool isShort = mine && clen <= 5u;
             const uint32_t slot = block_excl_scan(isShort ? 1u : 0u, S.waveSum, &nShort);
             if (isShort) S.shortLeaf[slot & 63u] = (uint8_t)tid;
@@ -2281,7 +2386,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             if (S.maxLen > 32u || S.skipLen != 0u || (pkWords + FAST_TEXT_PAD) * 4u > a.ldsM32Bytes) {
                 if (tid == 0) {
                     a.status[t] = GF_K_RETRY;
-                    atomicOr(a.retryFlag, 1u);
+                    atomicOr(a.retryFlag + (a.retryPass ? 1 : 0), 1u);
                 }
                 __syncthreads();
                 continue;
@@ -2792,9 +2897,18 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
     if (a.retryFlag) {
         // CodecHuffman batches: the fast kernel first; the general one picks up what that one marked (and returns at once
         // when nothing is marked)
-        if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST>, dyn, optF)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(a.retryFlag, 0, 4, stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, a);
+        const size_t dynRoomy = a.ldsM32Roomy ? decodeDynLds(a.ldsM32Roomy, a.ldsTextBytes) : 0;
+        if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST>, dyn > dynRoomy ? dyn : dynRoomy, optF)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(a.retryFlag, 0, 8, stream)) != hipSuccess) return e;
+        GfDecodeArgs f = a;
+        f.retryPass = 0;
+        hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
+        if (a.ldsM32Roomy) {
+            // the tiles that outgrew their LDS once more, with room (the workgroups of the others leave at once)
+            f.ldsM32Bytes = a.ldsM32Roomy;
+            f.retryPass = 1;
+            hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dynRoomy, stream, f);
+        }
     }
     hipLaunchKernelGGL(k_huffman_decode<DEC_GENERAL>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();

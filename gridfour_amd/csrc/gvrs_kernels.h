@@ -108,9 +108,14 @@ struct GfDecodeArgs {
     uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
     int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
     const uint32_t *trees;     // non-null: the Huffman trees were parsed by k_huffman_parse_trees (GF_TREE_REC_WORDS per tile)
-    uint32_t *retryFlag;       // non-null (CodecHuffman batches with tree records): one device word; the fast kernel runs first
-                               // and ORs 1 into it for every tile it leaves to the general kernel (status GF_K_RETRY inside
-                               // the launch only)
+    uint32_t *retryFlag;       // non-null (CodecHuffman batches with tree records): two device words; the fast kernel runs first
+                               // and ORs 1 into word 0 for every tile it leaves behind (status GF_K_RETRY inside the launch
+                               // only); with ldsM32Roomy the fast kernel runs a second time for those tiles and ORs into word 1
+                               // what it still cannot take; the general kernel looks at the last word written
+    uint32_t ldsM32Roomy;      // 0, or the M32 capacity of the fast kernel's second run (round 4): tiles whose M32 stream or
+                               // packing outgrows ldsM32Bytes (dense in multi-byte values) get a workgroup with more LDS
+                               // instead of the general kernel and its workspace in global memory
+    int retryPass;             // set by the launcher: 1 in the fast kernel's second run
     uint32_t *analysis;        // non-null: CodecHuffman.analyze mode -- per tile GF_ANALYSIS_WORDS words (predictor, nM32,
                                // bits in tree, packing bytes - 10, 256-bin histogram of the M32 bytes); no values are written
     uint32_t *pairCounts;      // analyze mode, may be null: GF_PAIR_TABLES x 65536 counters, [predictor][prior << 8 | value] of
@@ -189,7 +194,7 @@ hipError_t gf_launch_compact(size_t nTiles, const uint8_t *slots, size_t slotStr
                              const uint32_t *lengths, uint64_t *offsets, uint8_t *blob,
                              size_t blobCap, hipStream_t stream, const int32_t *status = nullptr);
 hipError_t gf_launch_synth_dem(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
-                               int64_t tile0, size_t nTiles, int32_t *values, hipStream_t stream, int maskPerMille = 0);
+                               int64_t tile0, size_t nTiles, int32_t *values, hipStream_t stream, int maskPerMille = 0, int style = 0);
 
 // CodecFloat byte planes (gvrs_float.hip); plane buffer of a tile = ceil(n/8) + 4n bytes at planeStride
 hipError_t gf_launch_float_planes_encode(const uint32_t *raw, uint8_t *planes, size_t planeStride, size_t nTiles, int nRows,

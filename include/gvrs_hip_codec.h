@@ -475,6 +475,15 @@ gf_status gf_synth_dem_dev(gf_context *ctx, void *stream, uint64_t seed, int n_r
 gf_status gf_synth_dem_masked_dev(gf_context *ctx, void *stream, uint64_t seed, int n_rows, int n_cols,
                                   int64_t tiles_per_row, int64_t tile0, size_t n_tiles, int mask_per_mille,
                                   int32_t *d_values);
+/* the same grid as another kind of surface.  GF_DEM_STYLE_ROUGH: provinces of mountains / plains / stripes so that each of
+ * PredictorModelDifferencing / Linear / Triangle wins a share of the tiles (compress/CodecHuffman.java:100-110), and cliff and
+ * scree blocks whose residuals need two and three M32 bytes (compress/CodecM32.java:270-311) -- the data SURVEY.md section 8d
+ * describes ("mostly within +-126 with a tail into 2-3 byte codes"); GF_DEM_STYLE_CLASSIC is gf_synth_dem_masked_dev.        */
+#define GF_DEM_STYLE_CLASSIC 0
+#define GF_DEM_STYLE_ROUGH 1
+gf_status gf_synth_dem_style_dev(gf_context *ctx, void *stream, uint64_t seed, int n_rows, int n_cols,
+                                 int64_t tiles_per_row, int64_t tile0, size_t n_tiles, int mask_per_mille, int style,
+                                 int32_t *d_values);
 
 /* ---- thin device-memory helpers so that non-HIP hosts (JNI, ctypes) can
  *      stage data without linking the HIP runtime themselves --------------- */

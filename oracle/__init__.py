@@ -78,6 +78,8 @@ def lib():
         L.gvo_dem_fill_tiles.restype = None
         L.gvo_dem_fill_tiles_masked.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, i32p]
         L.gvo_dem_fill_tiles_masked.restype = None
+        L.gvo_dem_fill_tiles_style.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i32p]
+        L.gvo_dem_fill_tiles_style.restype = None
         f32p = C.POINTER(C.c_float)
         L.gvo_canon_encode.argtypes = [u8p, C.c_size_t, szp, i32p, C.c_size_t, u8p]
         L.gvo_canon_decode.argtypes = [u8p, C.c_size_t, szp, i32p, C.c_size_t, szp]
@@ -336,10 +338,17 @@ def huffman_roundtrip_threads(n_threads, codec_index, n_rows, n_cols, tiles):
 DEM_SEED = 0x9E3779B97F4A7C15
 
 
-def dem_tiles(seed, n_rows, n_cols, tiles_per_row, tile0, n_tiles, mask_per_mille=0):
-    """mask_per_mille > 0: the nulls workload -- that share of the grid's 16 x 16 blocks holds the null code (ocean mask)."""
+DEM_STYLE_ROUGH = 1
+
+
+def dem_tiles(seed, n_rows, n_cols, tiles_per_row, tile0, n_tiles, mask_per_mille=0, style=0):
+    """mask_per_mille > 0: the nulls workload -- that share of the grid's 16 x 16 blocks holds the null code (ocean mask).
+    style 1: the rough surface (provinces of mountains / plains / stripes, cliff blocks: gvrs_oracle.c)."""
     out = np.zeros((n_tiles, n_rows * n_cols), np.int32)
-    if mask_per_mille:
+    if style:
+        lib().gvo_dem_fill_tiles_style(seed & (2 ** 64 - 1), n_rows, n_cols, tiles_per_row, tile0, n_tiles, mask_per_mille, style,
+                                       _p(out, C.c_int32))
+    elif mask_per_mille:
         lib().gvo_dem_fill_tiles_masked(seed & (2 ** 64 - 1), n_rows, n_cols, tiles_per_row, tile0, n_tiles, mask_per_mille,
                                         _p(out, C.c_int32))
     else:

@@ -1184,6 +1184,107 @@ int gvo_dem_masked(uint64_t seed, int64_t gx, int64_t gy, int maskPerMille)
     return (int)((h >> 33) % 1000u) < maskPerMille;
 }
 
+/* The ROUGH surface (style 1; round 4, SURVEY.md section 8d: "neighbouring-cell differences mostly within +-126 with a tail into
+ * 2-3 byte codes").  The classic surface above is one kind of terrain everywhere: the Triangle predictor wins
+ * every tile and no residual needs a second M32 byte.  Here the grid is cut into PROVINCES of 1024 x 1024 cells, each of one kind:
+ *   mountains (about half)   the classic surface
+ *   plains                   a sixteenth of the largest octave's relief under jitter of -6..6: noise dominates, and first
+ *                            differences (PredictorModelDifferencing) carry the least of it
+ *   stripes                  every grid row samples the classic surface 37 rows further on, without jitter: smooth along a row,
+ *                            unrelated from row to row (a push-broom sensor with an offset per line) -- the second difference along
+ *                            the row (PredictorModelLinear) is what predicts well
+ * and on hashed 16 x 16 blocks of the grid there is steeper ground still: CLIFF blocks (12 of 64 mountain blocks, 4 of 64 in the
+ * stripes, none in the plains) add an octave of lattice spacing 4 and amplitude 520 -- slopes beyond +-126 per cell (two M32 bytes,
+ * CodecM32.java:270-311) and, at its steepest and along the block's edges, beyond +-254 (three); SCREE blocks (another 8 of 64 in
+ * the mountains) add white noise of -150..150 per cell.  Measured on the ETOPO1-shaped grid (tools/rough_stats.py, 200 tiles):
+ * 4.5 % of the row differences need two M32 bytes, 0.65 % three; Differencing / Linear / Triangle win 19 / 42 / 39 % of the tiles;
+ * 82 % of the tiles hold at least one multi-byte value. */
+#define DEM_PROVINCE_SHIFT 10
+#define DEM_CLIFF_AMP 520
+#define DEM_SCREE_AMP 150
+static inline int dem_province(uint64_t seed, int64_t gx, int64_t gy)
+{
+    uint64_t h = gvo_splitmix64(seed ^ 0x5500000000000000ULL ^
+                                ((((uint64_t)gy >> DEM_PROVINCE_SHIFT) & 0xFFFFFFFULL) << 28) ^ (((uint64_t)gx >> DEM_PROVINCE_SHIFT) & 0xFFFFFFFULL));
+    uint32_t k = (uint32_t)((h >> 33) % 100u);
+    return k < 50u ? 0 : k < 72u ? 1 : 2;                /* mountains, plains, stripes */
+}
+
+static int64_t dem_octaves(uint64_t seed, int64_t gx, int64_t gy, int first, int last)
+{
+    int64_t sum = 0;
+    for (int o = first; o < last; o++) {
+        int sh = 8 - o;
+        int64_t s = (int64_t)1 << sh;
+        int64_t i = gx >> sh, j = gy >> sh;
+        int64_t fx = gx & (s - 1), fy = gy & (s - 1);
+        int64_t l00 = dem_lattice(seed, o, i, j), l10 = dem_lattice(seed, o, i + 1, j);
+        int64_t l01 = dem_lattice(seed, o, i, j + 1), l11 = dem_lattice(seed, o, i + 1, j + 1);
+        int64_t top = l00 * (s - fx) + l10 * fx;
+        int64_t bot = l01 * (s - fx) + l11 * fx;
+        sum += (top * (s - fy) + bot * fy) >> (2 * sh);
+    }
+    return sum;
+}
+
+int32_t gvo_dem_value_style(uint64_t seed, int64_t gx, int64_t gy, int style)
+{
+    if (style != 1) return gvo_dem_value(seed, gx, gy);
+    const int kind = dem_province(seed, gx, gy);
+    uint64_t hj = gvo_splitmix64(seed ^ 0x7700000000000000ULL ^
+                                 (((uint64_t)gy & 0xFFFFFFFULL) << 28) ^ ((uint64_t)gx & 0xFFFFFFFULL));
+    int64_t sum;
+    uint32_t cliffShare, screeShare;                     /* of 64 */
+    if (kind == 0) {
+        sum = dem_octaves(seed, gx, gy, 0, 6) + (int64_t)((hj >> 40) % 5) - 2;
+        cliffShare = 12; screeShare = 8;
+    } else if (kind == 1) {
+        sum = (dem_octaves(seed, gx, gy, 0, 1) >> 4) + (int64_t)((hj >> 40) % 13) - 6;
+        cliffShare = 0; screeShare = 0;
+    } else {
+        sum = dem_octaves(seed, gx, gy * 37, 0, 6);
+        cliffShare = 4; screeShare = 0;
+    }
+    uint64_t hb = gvo_splitmix64(seed ^ 0x6600000000000000ULL ^
+                                 ((((uint64_t)gy >> 4) & 0xFFFFFFFULL) << 28) ^ (((uint64_t)gx >> 4) & 0xFFFFFFFULL));
+    if ((uint32_t)((hb >> 33) & 63u) < cliffShare) {
+        /* one more octave, bilinear like the others: lattice spacing 4, amplitude DEM_CLIFF_AMP */
+        int64_t i = gx >> 2, j = gy >> 2, fx = gx & 3, fy = gy & 3;
+        int64_t l[4];
+        for (int q = 0; q < 4; q++) {
+            uint64_t h = gvo_splitmix64(seed ^ 0x4400000000000000ULL ^
+                                        ((((uint64_t)(j + (q >> 1))) & 0xFFFFFFFULL) << 28) ^ (((uint64_t)(i + (q & 1))) & 0xFFFFFFFULL));
+            l[q] = (int64_t)((((h >> 32) & 0xFFFF) * (uint64_t)(2 * DEM_CLIFF_AMP)) >> 16) - DEM_CLIFF_AMP;
+        }
+        int64_t top = l[0] * (4 - fx) + l[1] * fx, bot = l[2] * (4 - fx) + l[3] * fx;
+        sum += (top * (4 - fy) + bot * fy) >> 4;
+    } else if ((uint32_t)((hb >> 33) & 63u) < cliffShare + screeShare) {
+        /* scree: white noise of -DEM_SCREE_AMP .. DEM_SCREE_AMP per cell */
+        sum += (int64_t)((hj >> 20) % (2u * DEM_SCREE_AMP + 1u)) - DEM_SCREE_AMP;
+    }
+    sum -= 2000;
+    if (sum < -11000) sum = -11000;
+    if (sum > 8848) sum = 8848;
+    return (int32_t)sum;
+}
+
+void gvo_dem_fill_tiles_style(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                              int64_t tile0, int64_t nTiles, int maskPerMille, int style, int32_t *values)
+{
+    size_t nCells = (size_t)nRows * (size_t)nCols;
+    for (int64_t t = 0; t < nTiles; t++) {
+        int64_t tile = tile0 + t;
+        int64_t tr = tile / tilesPerRow, tc = tile % tilesPerRow;
+        int32_t *v = values + (size_t)t * nCells;
+        for (int r = 0; r < nRows; r++) {
+            for (int c = 0; c < nCols; c++) {
+                int64_t gx = tc * nCols + c, gy = tr * nRows + r;
+                v[(size_t)r * nCols + c] = gvo_dem_masked(seed, gx, gy, maskPerMille) ? (int32_t)0x80000000u : gvo_dem_value_style(seed, gx, gy, style);
+            }
+        }
+    }
+}
+
 void gvo_dem_fill_tiles_masked(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                                int64_t tile0, int64_t nTiles, int maskPerMille, int32_t *values)
 {

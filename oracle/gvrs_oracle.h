@@ -160,6 +160,9 @@ uint64_t gvo_splitmix64(uint64_t x);
 int32_t gvo_dem_value(uint64_t seed, int64_t gx, int64_t gy);
 /* fills nTiles tiles (tile t = tile row t / tilesPerRow, col t % tilesPerRow
  * of a grid cut into nRows x nCols tiles), starting at tile index tile0.     */
+int32_t gvo_dem_value_style(uint64_t seed, int64_t gx, int64_t gy, int style);   /* style 1: the rough surface (provinces, cliffs) */
+void gvo_dem_fill_tiles_style(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
+                              int64_t tile0, int64_t nTiles, int maskPerMille, int style, int32_t *values);
 void gvo_dem_fill_tiles(uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                         int64_t tile0, int64_t nTiles, int32_t *values);
 /* the same with an ocean mask: 16 x 16 blocks of GF null codes, maskPerMille / 1000 of the blocks */

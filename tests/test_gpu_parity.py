@@ -173,6 +173,45 @@ def test_synth_dem_masked_matches_oracle(codec):
     b.free()
 
 
+def test_synth_dem_rough_matches_oracle(codec):
+    """The rough surface (a tail into 2-3 byte M32 codes; bench.py --workload etopo1_rough): generator == oracle
+    across province borders, every predictor wins tiles of the sample, multi-byte values are there, and the batch path gives the
+    oracle's bytes for every tile (the decoder's byte path and its general stage side by side)."""
+    import struct
+    from gridfour_amd import DeviceTileBatch
+    seed, tpr = oracle.DEM_SEED + 2, 144
+    picks = [0, 5, 6, 7, 8, 13, 14, 1000, 1001, 1008, 2100, 4000, 6143, 6144, 9000, 12000, 12959]
+    got, ref = [], []
+    b = DeviceTileBatch(codec.ctx, 120, 150, 1)
+    for t in picks:
+        b.synth_dem(seed, tpr, tile0=t, style=oracle.DEM_STYLE_ROUGH)
+        codec.ctx.synchronize()
+        got.append(b.get_values()[0].copy())
+        ref.append(oracle.dem_tiles(seed, 120, 150, tpr, t, 1, style=oracle.DEM_STYLE_ROUGH)[0])
+    b.free()
+    assert np.array_equal(np.stack(got), np.stack(ref))
+    # a contiguous stretch of the grid through the batch path
+    n = 96
+    b = DeviceTileBatch(codec.ctx, 120, 150, n)
+    b.synth_dem(seed, tpr, tile0=1000, style=oracle.DEM_STYLE_ROUGH)
+    codec.ctx.synchronize()
+    vals = b.get_values()
+    assert np.array_equal(vals, oracle.dem_tiles(seed, 120, 150, tpr, 1000, n, style=oracle.DEM_STYLE_ROUGH))
+    b.encode(codec_index=0)
+    b.decode()
+    codec.ctx.synchronize()
+    assert (b.get_enc_status() == 0).all() and (b.get_dec_status() == 0).all()
+    assert np.array_equal(b.get_decoded(), vals)
+    preds = b.get_predictors()
+    wide = 0
+    for t in range(n):
+        want, used = oracle.codec_huffman_encode(0, 120, 150, vals[t])
+        assert preds[t] == used and b.get_packing(t) == want, t
+        wide += struct.unpack("<I", want[6:10])[0] != 120 * 150 - 1
+    assert 0 < wide < n                                             # tiles with and without multi-byte M32 values
+    b.free()
+
+
 def test_batch_dem_roundtrip_and_sampled_parity(codec):
     """Config-2 shape at reduced count: 256 tiles of 200x200, all three predictors + Huffman."""
     from gridfour_amd import DeviceTileBatch

@@ -19,7 +19,7 @@ def main():
     ctx = gridfour_amd.GvrsHipContext(0)
     cells = n_rows * n_cols
     b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * cells + 1024 + 15) // 16 * 16)
-    b.synth_dem(0x9E3779B97F4A7C15 + 2, 144)
+    b.synth_dem(0x9E3779B97F4A7C15 + 2, 144, style=int(os.environ.get("GF_DEM_STYLE", "0")))     # GF_DEM_STYLE=1: the rough surface
     L = lib()
     L.gf_internal_set_decode_debug.argtypes = [C.c_void_p]
     dbg = DeviceBuffer(ctx, 16 * 4 * nt).fill(0)
@@ -52,7 +52,18 @@ def main():
     if True:
         print("  predictors chosen:", {int(k): int(v) for k, v in zip(*np.unique(pred, return_counts=True))})
     tot = (st[:, 10] - st[:, 0]) & 0xFFFFFFFF
-    print("  total per tile median %d  p90 %d" % (np.median(tot), np.percentile(tot, 90)))
+    print("  total per tile median %d  p90 %d  p99 %d  max %d  mean %d" % (np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), tot.mean()))
+    lengths = b.get_lengths()
+    for t in np.argsort(tot)[::-1][:6]:                          # the slowest tiles, stamp by stamp
+        hdr = b.get_packing(int(t), 10)
+        print("  slow tile %5d: predictor %d, packing %d bytes, nM32 %d, stamps %s, sync rounds %d" % (
+            t, pred[t], lengths[t], int.from_bytes(hdr[6:10], "little"), [int(x) for x in rel[t, 1:11]], st[t, 11]))
+    # (tiles a second run of the kernel redid carry that run's stamps)
+    for m in (1, 2, 3, 4):
+        sel = pred == m
+        if sel.any():
+            print("  predictor %d (%d tiles): mean cycles to LUT %d, sync %d, write %d, values %d, end %d" % (
+                m, sel.sum(), rel[sel, 3].mean(), rel[sel, 4].mean(), rel[sel, 5].mean(), rel[sel, 8].mean(), rel[sel, 10].mean()))
 
 
 if __name__ == "__main__":

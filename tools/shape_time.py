@@ -9,7 +9,7 @@ nr, nc, nt = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 codec = sys.argv[4] if len(sys.argv) > 4 else "huffman"
 ctx = gridfour_amd.GvrsHipContext(0)
 b = DeviceTileBatch(ctx, nr, nc, nt, slot_stride=(2 * nr * nc + 1024 + 15) // 16 * 16, codec=codec)
-b.synth_dem(0x9E3779B97F4A7C15 + 2, 144)
+b.synth_dem(0x9E3779B97F4A7C15 + 2, 144, style=int(os.environ.get("GF_DEM_STYLE", "0")))
 t = GpuTimer(ctx)
 def timeit(fn, reps=7):
     fn(); ctx.synchronize()
