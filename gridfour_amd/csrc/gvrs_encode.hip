@@ -321,7 +321,7 @@ struct PackStateOk {
     PackState ps;
     bool ok;
 };
-template <int MODEL>
+template <int MODEL, bool PLAIN>
 __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                        const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                        PackState ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
@@ -342,8 +342,11 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
     const uint32_t cStep = (64u * CPT) % nC;
     for (uint32_t base = segBegin; base < segEnd; base += 64u * CPT) {
         const uint32_t i0 = base + lane * CPT;
+        // PLAIN (round 4): the record says that every value of the stream is one plain M32 byte (k_huffman_encode looked at the
+        // winner's symbols): the byte is the residual's low eight bits, there are no continuation bytes to look for and nothing
+        // of a residual to keep across the scan
         uint64_t cl[CPT];
-        uint32_t xs[CPT];
+        uint32_t xs[PLAIN ? 1 : CPT];
         uint32_t myBits = 0, multi = 0;
         if (i0 < segEnd) {
             Cells8 Q;
@@ -351,21 +354,21 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
             uint32_t c = c0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                bool emit, single;
+                bool emit, single = true;
                 const uint32_t x = flat_residual<MODEL>(Q, j, i0 + j, c, nC, nCells, seed, &emit);
-                const uint32_t b0 = m32_first_byte(x, &single);
+                const uint32_t b0 = PLAIN ? (x & 0xffu) : m32_first_byte(x, &single);
                 const uint64_t e = emit ? tab[b0] : 0ull;
                 cl[j] = e;
-                xs[j] = x;
+                if (!PLAIN) xs[j] = x;
                 myBits += (uint32_t)(e >> 56);
-                if (emit && !single) multi |= 1u << j;
+                if (!PLAIN && emit && !single) multi |= 1u << j;
                 if (++c == nC) c = 0;
             }
-            if (multi) {                                              // continuation bytes (rare)
+            if (!PLAIN && multi) {                                    // continuation bytes (rare)
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     if ((multi >> j) & 1u) {
-                        const uint32_t x = xs[j];
+                        const uint32_t x = xs[PLAIN ? 0 : j];
                         const int n = gf_m32_len(x);
                         for (int k = 1; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
                     }
@@ -373,7 +376,9 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < CPT; j++) { cl[j] = 0; xs[j] = 0; }
+            for (int j = 0; j < CPT; j++) cl[j] = 0;
+#pragma unroll
+            for (int j = 0; j < (PLAIN ? 1 : CPT); j++) xs[j] = 0;
         }
         c0 += cStep;
         if (c0 >= nC) c0 -= nC;
@@ -388,7 +393,7 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
         const uint32_t n01 = GF_LN(0) + GF_LN(1), n45 = GF_LN(4) + GF_LN(5);
         const uint32_t n0 = n01 + GF_LN(2) + GF_LN(3), n1 = n45 + GF_LN(6) + GF_LN(7);
         static_assert(CPT == 8, "the register path joins eight codes");
-        if (multi == 0u && n0 <= 32u && n1 <= 32u) {
+        if ((PLAIN || multi == 0u) && n0 <= 32u && n1 <= 32u) {
             GF_JOIN8_OR(wwin, bits + incl - myBits, GF_CD, GF_LN, n01, n45, n0);
 #undef GF_LN
 #undef GF_CD
@@ -398,8 +403,8 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
                 sink.put(cl[j] & 0x00ffffffffffffffull, (uint32_t)(cl[j] >> 56));
-                if ((multi >> j) & 1u) {
-                    const uint32_t x = xs[j];
+                if (!PLAIN && ((multi >> j) & 1u)) {
+                    const uint32_t x = xs[PLAIN ? 0 : j];
                     const int n = gf_m32_len(x);
                     for (int k = 1; k < n; k++) {
                         const uint64_t e = tab[gf_m32_byte(x, n, k)];
@@ -479,40 +484,81 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                         if (i0 + j < nCells) myFlags |= Q.cur[j] == GF_NULL_CODE ? 1u : 2u;
                     continue;
                 }
+                // The residuals of the three predictors for the thread's eight cells first (the seed cell and the padding behind
+                // the tile count as residual 0 in every histogram; bin 0 is corrected after the reduction), then the histograms.
+                // Round 4: where every lane of the wave is inside the tile (no seed cell, no first row, no padding), holds no null
+                // cell and all of its 24 residuals are plain one-byte values (-126..126: the M32 byte is the residual's low byte,
+                // CodecM32.java:257-283) -- every turn of a terrain tile but its first and last --, the turn is 24 additions to the
+                // histograms and nothing else: no null / introducer / sign selects per residual, no "is there more" test per cell.
+                uint32_t D1[CPT], D2[CPT], D3[CPT];
+                const bool inside = i0 >= nC + 2u && i0 + (CPT - 1) < nCells;
+                uint32_t widest = 0;                                 // max over the residuals of (d + 126) as unsigned: <= 252 = plain
+                int32_t lowest = 0x7fffffff;                         // min over the cells: Integer.MIN_VALUE = a null cell
+                if (__all(inside)) {
 #pragma unroll
-                for (int j = 0; j < CPT; j++) {
-                    const uint32_t idx = i0 + j;
-                    const uint32_t v = Q.cur[j];
-                    const bool real = idx < nCells;
-                    myFlags |= real ? ((v == GF_NULL_CODE) ? 1u : 2u) : 0u;
-                    const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
-                    const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
-                    const uint32_t N = Q.up[j];
-                    const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
-                    // the seed cell and the padding behind the tile count as residual 0 in every
-                    // histogram; bin 0 is corrected after the reduction
-                    const bool counted = real && idx > 0;
-                    const uint32_t d = v - (c > 0 ? W : N);
-                    const uint32_t d1 = counted ? d : 0u;
-                    const uint32_t d2 = counted ? (c >= 2 ? v - (2u * W - WW) : d) : 0u;
-                    const uint32_t d3 = counted ? ((idx >= nC && c > 0) ? v - (W + N - NW) : d) : 0u;
-                    // the first M32 byte of the three residuals without a branch; the continuation bytes of values that have any
-                    // behind ONE branch per cell (three, one per predictor, cost the scalar unit more than the cell cost the SIMDs)
-                    bool s1, s2, s3 = true;
-                    atomicAdd(h0 + m32_first_byte(d1, &s1) * HIST_R, 1u);
-                    atomicAdd(h1 + m32_first_byte(d2, &s2) * HIST_R, 1u);
-                    if (triOk) atomicAdd(h2 + m32_first_byte(d3, &s3) * HIST_R, 1u);
-                    if (!(s1 && s2 && s3)) {
-                        auto rest = [&](uint32_t *h, uint32_t x) -> uint32_t {
-                            const uint32_t n = (uint32_t)gf_m32_len(x);
-                            for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
-                            return n;
-                        };
-                        if (!s1) maxN1 = max(maxN1, rest(h0, d1));
-                        if (!s2) maxN2 = max(maxN2, rest(h1, d2));
-                        if (!s3) maxN3 = max(maxN3, rest(h2, d3));
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t v = Q.cur[j];
+                        const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+                        const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
+                        const uint32_t N = Q.up[j];
+                        const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+                        const uint32_t d = v - (c > 0 ? W : N);
+                        D1[j] = d;
+                        D2[j] = c >= 2 ? v - (2u * W - WW) : d;
+                        D3[j] = c > 0 ? v - (W + N - NW) : d;
+                        widest = max(widest, max(D1[j] + 126u, max(D2[j] + 126u, D3[j] + 126u)));
+                        lowest = min(lowest, (int32_t)v);
+                        if (++c == nC) c = 0;
                     }
-                    if (++c == nC) c = 0;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t idx = i0 + j;
+                        const uint32_t v = Q.cur[j];
+                        const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+                        const uint32_t WW = j > 1 ? Q.cur[j - 2] : (j == 1 ? Q.wm1 : Q.wm2);
+                        const uint32_t N = Q.up[j];
+                        const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+                        const bool counted = idx < nCells && idx > 0;
+                        const uint32_t d = v - (c > 0 ? W : N);
+                        D1[j] = counted ? d : 0u;
+                        D2[j] = counted ? (c >= 2 ? v - (2u * W - WW) : d) : 0u;
+                        D3[j] = counted ? ((idx >= nC && c > 0) ? v - (W + N - NW) : d) : 0u;
+                        if (++c == nC) c = 0;
+                    }
+                    widest = 0xFFFFFFFFu;                            // (the turns at the tile's ends take the general histogram code)
+                }
+                if (__all(widest <= 252u && lowest != (int32_t)0x80000000)) {
+                    myFlags |= 2u;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        atomicAdd(h0 + (D1[j] & 0xffu) * HIST_R, 1u);
+                        atomicAdd(h1 + (D2[j] & 0xffu) * HIST_R, 1u);
+                        if (triOk) atomicAdd(h2 + (D3[j] & 0xffu) * HIST_R, 1u);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t v = Q.cur[j];
+                        myFlags |= i0 + j < nCells ? ((v == GF_NULL_CODE) ? 1u : 2u) : 0u;
+                        const uint32_t d1 = D1[j], d2 = D2[j], d3 = D3[j];
+                        // the first M32 byte of the three residuals without a branch; the continuation bytes of values that have any
+                        // behind ONE branch per cell (three, one per predictor, cost the scalar unit more than the cell cost the SIMDs)
+                        bool s1, s2, s3 = true;
+                        atomicAdd(h0 + m32_first_byte(d1, &s1) * HIST_R, 1u);
+                        atomicAdd(h1 + m32_first_byte(d2, &s2) * HIST_R, 1u);
+                        if (triOk) atomicAdd(h2 + m32_first_byte(d3, &s3) * HIST_R, 1u);
+                        if (!(s1 && s2 && s3)) {
+                            auto rest = [&](uint32_t *h, uint32_t x) -> uint32_t {
+                                const uint32_t n = (uint32_t)gf_m32_len(x);
+                                for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
+                                return n;
+                            };
+                            if (!s1) maxN1 = max(maxN1, rest(h0, d1));
+                            if (!s2) maxN2 = max(maxN2, rest(h1, d2));
+                            if (!s3) maxN3 = max(maxN3, rest(h2, d3));
+                        }
+                    }
                 }
                 c0 += cStep;
                 if (c0 >= nC) c0 -= nC;
@@ -815,8 +861,10 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
             __builtin_amdgcn_wave_barrier();
             unsigned long long textBits = 0;
             uint32_t maxLen = 0;
+            bool nullByte = false;                                // the byte 0x80 is among the symbols
             if (n == 1) {
                 // uniform special case, HuffmanEncoder.java:147-157: 8 zero bits, a 1 bit, the symbol
+                nullByte = T.sym[0] == 0x80u;
                 if (lane == 0) {
                     const uint32_t rec = 1u | ((uint32_t)T.sym[0] << 1);     // 9 bits at bit 88
                     atomicOr(&img[2], rec << 24);
@@ -829,6 +877,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                     uint32_t pos;
                     const int len = gf_huff_leaf_code(T, i, &code, &pos);
                     const uint32_t sym = T.sym[i];
+                    nullByte = nullByte || sym == 0x80u;
                     P.tab[p][sym] = ((uint64_t)len << 56) | code;
                     textBits += (unsigned long long)T.cnt[i] * (unsigned)len;
                     maxLen = max(maxLen, (uint32_t)len);
@@ -848,6 +897,12 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 P.treeEndBit[p] = 80u + treeBits;
                 P.totalBits[p] = 80ull + treeBits + textBits;
                 P.maxLen[p] = maxLen;
+            }
+            {
+                // a stream of plain bytes -- every value one M32 byte (-126..126), none of them the null code: the packer then takes a
+                // residual's low byte for its M32 form (k_huffman_pack, PLAIN)
+                const bool anyNullByte = __any(nullByte) != 0;
+                if (lane == 0) P.plain[p] = (!anyNullByte && P.maxN[p] == 1u) ? 1u : 0u;
             }
         }
         __syncthreads();
@@ -900,6 +955,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 rec[3] = P.maxN[best];
                 rec[4] = P.maxLen[best];
                 rec[5] = (uint32_t)min(P.totalBits[best] - P.treeEndBit[best], (uint64_t)0xFFFFFFFFu);   // bits of the text
+                rec[7] = P.plain[best];
             }
             for (int i = tid; i < GF_IMG_WORDS; i += ENC_THREADS) rec[8 + i] = P.img[best][i];
             const uint32_t *tw = reinterpret_cast<const uint32_t *>(P.tab[best]);
@@ -913,7 +969,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 // the flat scan of a tile through the wave-private windows, in as many cell ranges as its bit count asks for (a wave's
 // share of a range must fit its quarter of the window); false: a range did not fit after all -- the tile is left to
 // k_huffman_pack_rare, which packs it again from its first bit
-template <int MODEL>
+template <int MODEL, bool PLAIN>
 __device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                                  const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                                  PackState &ps, uint32_t slotWords, uint32_t textBits)
@@ -923,7 +979,7 @@ __device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ ti
     const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / capBits + 1u);
     const uint32_t per = (((nCells + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);
     for (uint32_t b = 0; b < nCells; b += per) {
-        const PackStateOk r = pack_flat_waves<MODEL>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
+        const PackStateOk r = pack_flat_waves<MODEL, PLAIN>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
         if (!r.ok) return false;
         ps = r.ps;
     }
@@ -988,18 +1044,22 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
                     ps = pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
                 }
             } else {
+                const bool plain = rec[7] != 0u && model != 4;                // (the same word in every thread)
                 if (!fast) {
                     done = false;
                 } else if (model == 1) {
-                    done = pack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                    done = plain ? pack_flat_ranges<1, true>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits)
+                                 : pack_flat_ranges<1, false>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
                 } else if (model == 2) {
                     ps = pack_head<2>(tile, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
-                    done = pack_flat_ranges<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                    done = plain ? pack_flat_ranges<2, true>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits)
+                                 : pack_flat_ranges<2, false>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
                 } else if (model == 3) {
                     ps = pack_head<3>(tile, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
-                    done = pack_flat_ranges<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                    done = plain ? pack_flat_ranges<3, true>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits)
+                                 : pack_flat_ranges<3, false>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
                 } else {
-                    done = pack_flat_ranges<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                    done = pack_flat_ranges<4, false>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
                 }
             }
         }

@@ -33,6 +33,7 @@ struct EncPersist {
     unsigned long long sumStart;                // nulls predictor seed
     uint32_t nStart;
     uint32_t lbBytes[3];                        // fast kernel: lower bound of a predictor's packing (header + tree + entropy of its text)
+    uint32_t plain[3];                          // the predictor's stream is plain bytes: every value one M32 byte, none the null code
 };
 
 
