@@ -76,6 +76,16 @@ def parse_args():
     return ap.parse_args()
 
 
+def _replay_is_current(rec):
+    """A replayed PMC file belongs to THESE kernels only if it carries the digest of the kernel sources it was measured on
+    (gridfour_amd.build.csrc_digest, written by tools/pmc_hbm.sh / pmc_issue.sh) and that digest is the tree's."""
+    try:
+        from gridfour_amd.build import csrc_digest
+        return bool(rec.get("csrc_digest")) and rec.get("csrc_digest") == csrc_digest()
+    except Exception:
+        return False
+
+
 def _pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_hbm.sh writes
     profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 corrections applied).
@@ -90,6 +100,9 @@ def _pmc_traffic(workload, kernel):
         return None, None
     if rec.get("workload") != workload:
         return None, None
+    if not _replay_is_current(rec):
+        # the kernels changed since tools/pmc_hbm.sh ran: no bytes are better than another kernel's bytes
+        return None, "STALE: profiles/hbm_traffic.json was measured on other kernel sources (csrc digest differs); rerun tools/pmc_hbm.sh"
 
     def base(name):
         name = name.split("(")[0].strip()
@@ -118,17 +131,36 @@ def _pmc_traffic(workload, kernel):
     return total, "profiles/hbm_traffic.json@%s" % (commit or "unversioned")
 
 
-CLOCK_HZ = 2.4e9              # MI355X_MICROARCH.md: max engine clock; 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9              # MI355X_MICROARCH.md: max engine clock; 256 CUs x 4 SIMDs, ONE scalar unit per CU
+
+
+def _issue_rates():
+    """Measured issue costs (tools/issue_rate.hip on an MI355X, committed under profiles/): cycles per vector wave-instruction
+    and SIMD -- the cheapest kind (VOP2 add) and the VOP3 / compare-select kind these kernels are mostly made of --, cycles per
+    scalar-side wave-instruction (SALU or branch) and CU, all with eight waves per SIMD feeding the port."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    rates = {"valu_fast": 2.8, "valu_vop3": 4.26, "scalar": 1.0, "source": "defaults (profiles/r04_v1/issue_rate.json not readable)"}
+    try:
+        rec = json.load(open(os.path.join(here, "profiles", "r04_v1", "issue_rate.json")))
+        by = {k["kind"]: k["rates"][-1] for k in rec["kinds"]}
+        rates = {"valu_fast": by["v_add_u32 x8 independent"]["cycles_per_vector_instr_per_simd"],
+                 "valu_vop3": by["v_alignbit / v_bfe_u32 / v_lshl_or_b32 / v_mad_u32_u24"]["cycles_per_vector_instr_per_simd"],
+                 "scalar": by["s_add_u32 x8 independent"]["cycles_per_scalar_instr_per_cu"],
+                 "source": "profiles/r04_v1/issue_rate.json (tools/issue_rate.hip, 8 waves per SIMD)"}
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+    return rates
 
 
 def _issue_roofline(workload, kernel, n_tiles, launch_ms):
-    """Second bound next to the HBM one: the instruction-issue floor of the dominant kernel.  Wave-instructions per tile (VALU + SALU,
-    rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of the SHIPPING library, tools/pmc_issue.sh -> profiles/issue_counts.json,
-    replayed here like the HBM traffic: counters cannot be collected inside the timed process) x tiles / (256 CUs x 4 SIMDs x
-    clock): the time the launch would take if every SIMD issued one of these instructions per cycle and nothing ever waited.
-    tools/valu_rate.hip measures what a SIMD really sustains on this instruction mix (profiles/r03_*/valu_rate.txt: 2.6 cycles
-    per integer add / xor, 3.6-3.8 per compare + select pair member at two or more waves): that, not one per cycle, is the wall
-    the decode kernel runs at 60-70 % of."""
+    """Second bound next to the HBM one: the instruction-issue floors of the dominant kernel, one per issue port.  Wave-instructions
+    per tile (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_BRANCH of the SHIPPING library, tools/pmc_issue.sh ->
+    profiles/issue_counts.json, replayed like the HBM traffic and refused when the kernel sources changed since) priced with the
+    MEASURED issue costs of tools/issue_rate.hip:
+      vector  VALU x c_v / 4 SIMDs per CU          c_v = 2.8 cycles (VOP2 add) ... 4.3 (VOP3, compare + select) per SIMD
+      scalar  (SALU + branch) x c_s / 1 unit per CU  c_s = 1.0 cycle
+    floor = the larger of the two at the CHEAPEST vector cost; `binding` names it.  (Round 3 priced VALU + SALU at one per cycle
+    over four SIMDs: the scalar unit exists once per CU, a vector instruction costs a SIMD 2.8-4.3 cycles.)"""
     here = os.path.dirname(os.path.abspath(__file__))
     try:
         rec = json.load(open(os.path.join(here, "profiles", "issue_counts.json")))
@@ -136,21 +168,31 @@ def _issue_roofline(workload, kernel, n_tiles, launch_ms):
         return None
     if rec.get("workload") != workload:
         return None
-    valu = salu = 0.0
+    if not _replay_is_current(rec):
+        return {"bound": "issue", "stale": True, "note": "profiles/issue_counts.json was measured on other kernel sources (csrc digest differs); "
+                                                          "rerun tools/pmc_issue.sh"}
+    valu = salu = branch = 0.0
     found = []
     for part in kernel.split("+"):
         for name, d in rec.get("kernels", {}).items():
             if name.split("<")[0].strip() == part:
                 valu += d.get("insts_valu", 0.0)
                 salu += d.get("insts_salu", 0.0)
+                branch += d.get("insts_branch", 0.0)
                 found.append(name)
     if not found:
         return None
-    floor_ms = (valu + salu) * n_tiles / (256 * 4 * CLOCK_HZ) * 1e3
+    r = _issue_rates()
+    per_cu = n_tiles / 256.0 / CLOCK_HZ * 1e3                     # tiles per CU -> ms per cycle-per-tile
+    v_lo, v_hi = valu * r["valu_fast"] / 4.0 * per_cu, valu * r["valu_vop3"] / 4.0 * per_cu
+    sc = (salu + branch) * r["scalar"] * per_cu
+    floor_ms = max(v_lo, sc)
     return {"bound": "issue", "kernel": "+".join(found), "valu_per_tile": round(valu, 1), "salu_per_tile": round(salu, 1),
-            "floor_ms": round(floor_ms, 4), "avg_launch_ms": round(launch_ms, 4), "frac_of_issue_floor": round(floor_ms / launch_ms, 4),
-            "assumes": "one VALU or SALU wave-instruction per cycle and SIMD, 256 CUs x 4 SIMDs at 2.4 GHz",
-            "counts_replayed_from": "profiles/issue_counts.json@%s" % (rec.get("commit") or "unversioned")}
+            "branch_per_tile": round(branch, 1),
+            "vector_floor_ms": [round(v_lo, 4), round(v_hi, 4)], "scalar_floor_ms": round(sc, 4),
+            "binding": "scalar unit" if sc >= v_lo else "vector issue", "floor_ms": round(floor_ms, 4),
+            "avg_launch_ms": round(launch_ms, 4), "frac_of_issue_floor": round(floor_ms / launch_ms, 4),
+            "rates": r, "counts_replayed_from": "profiles/issue_counts.json@%s" % (rec.get("commit") or "unversioned")}
 
 
 def run_float(args, ctxs, rank, world, dist, torch, single_multi=False):
@@ -454,6 +496,21 @@ def _effective_cores():
     return n
 
 
+def _probe_java():
+    """BASELINE.md section 3: the reference Java codec is timed beside the GPU only where a JDK AND a Gridfour jar exist on the box;
+    the probe's answer is recorded either way (this image has neither: the C port stands in, kind "port")."""
+    import glob
+    import shutil
+    java = shutil.which("java")
+    if not java:
+        return "not found (no `java` on PATH)"
+    jars = [p for pat in ("/usr/share/java/*ridfour*.jar", os.path.expanduser("~/.m2/repository/org/gridfour/**/*.jar"),
+                          os.path.join(ROOT, "*ridfour*.jar")) for p in glob.glob(pat, recursive=True)]
+    if not jars:
+        return "java at %s, no Gridfour jar: not timed" % java
+    return "java at %s, jar %s: present but no timing harness is wired up (report this)" % (java, jars[0])
+
+
 def _cpu_baseline(args, vals, n_rows, n_cols, n_tiles):
     """The oracle ("port": C restatement of the Java algorithm) on the host's cores, bounded sample of the same workload:
     one thread (the `value`: the north star's single-thread reference) and every core (native threads inside the oracle)."""
@@ -486,7 +543,8 @@ def _cpu_baseline(args, vals, n_rows, n_cols, n_tiles):
     mb = sub.nbytes / 1e6
     res = {"value": round(mb / (c2 - c0), 2), "unit": "MB/s", "cores": 1, "kind": "port",
            "sample": "first %d tiles of the same workload (%.0f MB), oracle C restatement of the Java algorithm, 1 thread; "
-                     "encode %.1f MB/s, decode %.1f MB/s" % (ns, mb, mb / (c1 - c0), mb / (c2 - c1))}
+                     "encode %.1f MB/s, decode %.1f MB/s" % (ns, mb, mb / (c1 - c0), mb / (c2 - c1)),
+           "reference_java": _probe_java()}
     if args.codec == "huffman":
         nthr = _effective_cores()
         enc_s, dec_s = oracle.huffman_roundtrip_threads(nthr, 0, n_rows, n_cols, sub)
@@ -771,6 +829,13 @@ def main():
             dist.all_gather_object(gathered, devices[0])
             devices = gathered
 
+    # every shard's own averages (N > 1: a slow device shows in the record, not only in the max)
+    per_shard = [{"shard": g if single_multi else rank, "encode_ms": round(float(e), 4), "decode_ms": round(float(d), 4)}
+                 for g, (e, d) in enumerate(zip(enc_ms, dec_ms))]
+    if launcher:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_shard[0])
+        per_shard = gathered
     cpu_baseline, host_path, rough, data_stats = None, None, None, None
     if rank == 0 and vals0 is not None:
         data_stats = _m32_stats(vals0, batches[0].get_predictors(), n_rows, n_cols)
@@ -828,11 +893,12 @@ def main():
         "devices": devices,
         "encode_ms": round(enc_avg, 4),
         "decode_ms": round(dec_avg, 4),
+        "per_shard_ms": per_shard,
         "encode_MBps": round(raw_mb / (enc_avg * 1e-3), 1),
         "decode_MBps": round(raw_mb / (dec_avg * 1e-3), 1),
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "traffic_replayed_from": traffic_from,
+                     "traffic_replayed_from": traffic_from, "traffic_stale": bool(traffic is None and traffic_from and traffic_from.startswith("STALE")),
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "avg_launch_ms": round(dom_ms, 4),
                      "roundtrip_frac": round((2 * alg_bytes) / ((enc_avg + dec_avg) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},

@@ -48,6 +48,18 @@ def _deps():
     return deps
 
 
+def csrc_digest():
+    """Short digest of the kernel sources (csrc/*.hip, *.h): what a replayed PMC measurement (profiles/hbm_traffic.json,
+    issue_counts.json) records, so that bench.py can tell a measurement of these kernels from one of an earlier state."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build(lib=LIB):
     if not os.path.exists(lib):
         return True

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <memory>
 #include <cmath>
@@ -181,7 +183,8 @@ const char *gf_status_string(int s)
 
 const char *gf_last_error(void) { return g_lastError.c_str(); }
 // (library-internal: gvrs_multi.hip hands the text of a failing shard's thread to the thread that called gf_*_multi)
-void gf_internal_set_last_error(const char *text) { g_lastError = text ? text : ""; }
+// (an internal hook of gvrs_multi.hip, not part of the ABI: hidden from the library's exports)
+__attribute__((visibility("hidden"))) void gf_internal_set_last_error(const char *text) { g_lastError = text ? text : ""; }
 
 int gf_device_count(void)
 {
@@ -1922,19 +1925,39 @@ static gf_status deflateEncodeBatchHost(gf_context *c, int codecIndex, int nRows
         });
     };
     // chunk k's zlib runs on the host's threads while this thread drives the GPU stage of chunk k + 1
-    std::thread worker;
+    // (joined by a guard: an exception on this thread -- a vector that cannot grow -- must not meet a joinable std::thread, which
+    // would end the process; one on the worker thread is caught there and becomes a status)
+    struct Joined {
+        std::thread t;
+        ~Joined() { if (t.joinable()) t.join(); }
+    } worker;
+    std::atomic<int> workerStatus{GF_OK};
     gf_status result = GF_OK;
     int cur = 0;
-    for (size_t t0 = 0; t0 < nTiles && result == GF_OK; t0 += chunk) {
-        const size_t n = std::min(chunk, nTiles - t0);
-        result = gpuStage(stage[cur], t0, n);
-        if (worker.joinable()) worker.join();
-        if (result != GF_OK) break;
-        Stage *g = &stage[cur];
-        worker = std::thread([&, g]() { zlibStage(*g); });
-        cur ^= 1;
+    try {
+        for (size_t t0 = 0; t0 < nTiles && result == GF_OK; t0 += chunk) {
+            const size_t n = std::min(chunk, nTiles - t0);
+            result = gpuStage(stage[cur], t0, n);
+            if (worker.t.joinable()) worker.t.join();
+            if (result != GF_OK) break;
+            Stage *g = &stage[cur];
+            worker.t = std::thread([&, g]() {
+                try {
+                    zlibStage(*g);
+                } catch (const std::bad_alloc &) {
+                    workerStatus = GF_ERR_HIP;
+                }
+            });
+            cur ^= 1;
+        }
+    } catch (const std::bad_alloc &) {
+        result = GF_ERR_HIP;
     }
-    if (worker.joinable()) worker.join();
+    if (worker.t.joinable()) worker.t.join();
+    if (result == GF_OK && workerStatus != GF_OK) {
+        g_lastError = "out of host memory in the Deflate stage";
+        result = (gf_status)workerStatus.load();
+    }
     return result;
 }
 

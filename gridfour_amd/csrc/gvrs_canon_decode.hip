@@ -103,7 +103,10 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
         // Triangle tiles of the one-subsequence-per-thread build: the staged residuals become the tile in one go (cd_fused_triangle)
         // (the stage behind the sync arrays: what this packing leaves of the text buffer, then the bytes behind it)
         uint8_t *const stageB = reinterpret_cast<uint8_t *>(cdLdsText + (textInLds ? needWords : 0u));
-        const uint32_t stageCap = stageCapA + (capWords - (textInLds ? needWords : 0u)) * 4u + a.ldsStageBytes;
+        // (less the last word of part B where there is one: cd_fused_triangle reads the stage two words at a time, and the
+        // word behind the last byte it may ask for has to lie inside the workgroup's LDS as well)
+        const uint32_t stageBytesB = (capWords - (textInLds ? needWords : 0u)) * 4u + a.ldsStageBytes;
+        const uint32_t stageCap = stageCapA + (stageBytesB >= 4u ? stageBytesB - 4u : 0u);
 #ifdef GF_DIAG
         const bool fuse = cd_fuse_eligible(model, nR, nC, stageCap) && !(a.phaseLimit & 0x300);
         const CdCellSink sink{o, GfCellMap::make(model, nR, nC), nStream, !(a.phaseLimit & 0x100),

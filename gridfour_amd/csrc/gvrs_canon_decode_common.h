@@ -403,9 +403,9 @@ __device__ __forceinline__ void cd_fused_triangle(CanonDec &S, const CdCellSink 
     const uint32_t j0 = 4u * lane;                                // the lane's columns: j0 .. j0 + 3
     // the staged bytes of stream elements p0 + j0 .. + 3 (p0 wave-uniform); markers where the stage does not hold the four in
     // one piece (res() sorts those out)
-    // (the second word of a read may lie one word behind the stage: behind part A that is more of CanonDec, behind part B the end
-    // of the workgroup's LDS, where a read returns zero -- either way none of its bytes is used: the four bytes asked for end
-    // inside the stage)
+    // (the second word of a read may lie one word behind the stage -- none of its bytes is used: the four bytes asked for end
+    // inside the stage --: behind part A that is more of CanonDec, behind part B the word the callers keep out of the stage's
+    // capacity for this, so every read stays inside the workgroup's LDS)
     auto fetch4 = [&](uint32_t p0) -> uint32_t {
         const uint32_t pEnd = p0 + 4u * 63u + 3u;                 // the last byte any lane asks for
         uint32_t x;

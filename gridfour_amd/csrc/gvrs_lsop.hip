@@ -1087,9 +1087,10 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct(G
 
 
 // The same wavefront as ONE pipeline down the tile (round 3) instead of a fill and a drain per band of 64 rows: lane l takes rows
-// 2 + l, 2 + 64 + l, ... one after the other, and starts the next one P = max(nC, 192) steps (rounded up to a round) after the
-// last -- as soon as lane 63 is three columns into the row above it.  A band costs P steps instead of 189 + nC: 501 instead of
-// 648 for the 120 x 150 tiles of the ETOPO1-shaped batch, 1,213 instead of 1,780 for 256 x 256.  Everything a step does is the band
+// 2 + l, 2 + 64 + l, ... one after the other, and starts the next one P = max(nC, 208) steps (rounded up to a round) after the
+// last: lane 63 starts 189 steps into a period, lane 0 reads eight columns ahead in the row buffers and two more are kept between
+// them (189 + 2 + 8 = 199 <= P, i.e. 208 as a multiple of the 16-step round).  A band costs P steps instead of 189 + nC: 517
+// instead of 648 for the 120 x 150 tiles of the ETOPO1-shaped batch, 1,213 instead of 1,780 for 256 x 256.  Everything a step does is the band
 // kernel's; what changes is bookkeeping: a lane's column wraps at P (its row index goes up by 64), the per-row constants of the
 // next rows are worked out by the whole wave when lane 0 starts a row and taken over by a lane when it gets there, lane 0 alone
 // re-arms its windows from the two row buffers, and the staging pieces tell rows apart by whether a step lies before or behind a
@@ -1113,6 +1114,7 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_p
     const uint32_t nPh = (nR - 2u + 63u) / 64u;                              // rows per lane
     // steps between a lane's rows: lane 63 starts its row 189 steps into a period, and lane 0 reads column c + 2 of that row for
     // the eight steps of a group at once, from the row buffers: 189 + 2 + 8 <= P
+    static_assert(189 + 2 + 8 <= 208, "the period's floor: lane 63's start, the row buffers' safety distance, lane 0's read-ahead");
     const uint32_t P = ((max(nC, 208u) + ROUND - 1u) / ROUND) * ROUND;
     const uint32_t nLast = nR - 2u - 64u * (nPh - 1u);
     const uint32_t sEnd = (nPh - 1u) * P + 3u * (nLast - 1u) + nC - 1u;       // the last step that produces a value

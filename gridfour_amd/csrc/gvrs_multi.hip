@@ -22,7 +22,7 @@
 #include "../../include/gvrs_hip_codec.h"
 
 // gf_last_error() is per thread: the text of a failing shard's thread is handed to the thread that called gf_*_multi (gvrs_api.hip)
-extern "C" void gf_internal_set_last_error(const char *text);
+extern "C" __attribute__((visibility("hidden"))) void gf_internal_set_last_error(const char *text);
 
 struct gf_multi {
     std::vector<gf_context *> ctx;
@@ -110,8 +110,10 @@ typedef std::function<gf_status(gf_context *, int, int, int, size_t, const int32
     EncodeHostFn;
 typedef std::function<gf_status(gf_context *, int, int, size_t, const uint8_t *, const uint64_t *, int32_t *, int32_t *)> DecodeHostFn;
 
+// perTileGuess: bytes of staging per tile for the first attempt (0: half of the raw cells, what integer packings stay far below;
+// CodecFloat packs to 3-4 bytes per cell and LSOP12 has a bound of its own -- sized too small, every shard was encoded twice)
 gf_status encodeMulti(const EncodeHostFn &fn, gf_multi *m, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
-                      uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *predictors, int32_t *status)
+                      uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *predictors, int32_t *status, size_t perTileGuess = 0)
 {
     if (!m || nRows < 1 || nCols < 1 || (!values && nTiles) || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     const int G = (int)m->ctx.size();
@@ -133,7 +135,7 @@ gf_status encodeMulti(const EncodeHostFn &fn, gf_multi *m, int codecIndex, int n
             p.off.assign(n + 1, 0);
             if (n == 0) return;
             // a shard's packings rarely exceed half of its raw cells; grow once if they do
-            size_t cap = n * (stride / 2) + 4096;
+            size_t cap = n * (perTileGuess ? perTileGuess : stride / 2) + 4096;
             for (int attempt = 0; attempt < 2; attempt++) {
                 if (m->partCap[g] < cap) {
                     free(m->part[g]);
@@ -151,6 +153,12 @@ gf_status encodeMulti(const EncodeHostFn &fn, gf_multi *m, int codecIndex, int n
                 cap = (size_t)p.off[n] + 64;
             }
             if (p.st != GF_OK) p.err = gf_last_error();
+            if (p.st == GF_ERR_CAPACITY) {
+                // still too small after the shard's own regrow: not the caller's "your blob is too small" (offsets[n] means nothing
+                // to the caller here)
+                p.st = GF_ERR_HIP;
+                p.err = "gf_multi: a shard's staging buffer was too small twice";
+            }
         });
     }
     for (auto &t : th) t.join();
@@ -262,7 +270,8 @@ gf_status gf_lsop12_encode_batch_i32_multi(gf_multi *m, int codecIndex, int nRow
                                              uint64_t *off, uint8_t *ty, int32_t *st) {
         return gf_lsop12_encode_batch_i32(c, ci, nr, nc, n, v, deflateEnabled, b, cap, off, ty, st);
     };
-    return encodeMulti(fn, m, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, types, status);
+    return encodeMulti(fn, m, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, types, status,
+                       gf_lsop12_max_packing(nRows, nCols) / 2 + 64);
 }
 
 gf_status gf_lsop12_decode_batch_i32_multi(gf_multi *m, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
@@ -279,8 +288,9 @@ gf_status gf_float_encode_batch_f32_multi(gf_multi *m, int codecIndex, int nRows
                                         uint64_t *off, uint8_t *, int32_t *) {
         return gf_float_encode_batch_f32(c, ci, nr, nc, n, reinterpret_cast<const float *>(v), zlibLevel, b, cap, off);
     };
+    // (a CodecFloat packing: five planes of a byte per cell or less, deflated; sign bits and framing on top)
     return encodeMulti(fn, m, codecIndex, nRows, nCols, nTiles, reinterpret_cast<const int32_t *>(values), blob, blobCap, offsets,
-                       nullptr, nullptr);
+                       nullptr, nullptr, 5 * (size_t)nRows * (size_t)nCols + 4096);
 }
 
 gf_status gf_float_decode_batch_f32_multi(gf_multi *m, int nRows, int nCols, size_t nTiles, const uint8_t *blob,

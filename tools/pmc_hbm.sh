@@ -11,6 +11,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 done
 python3 - <<PY
+import sys; sys.path.insert(0, '.')
 import csv, glob, collections, json, re
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -22,7 +23,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, v in acc.items():
             res[k][c] = v[-1]          # last (warm) dispatch
 import os
-out = {"workload": "$WL", "commit": os.environ.get("GF_COMMIT", ""), "unit": "bytes per launch", "correction": "FETCH_SIZE KB x1024 x2 (gfx950 half-count), WRITE_SIZE KB x1024", "kernels": {}}
+out = {"workload": "$WL", "commit": os.environ.get("GF_COMMIT", ""), "csrc_digest": __import__("gridfour_amd.build", fromlist=["x"]).csrc_digest(), "unit": "bytes per launch", "correction": "FETCH_SIZE KB x1024 x2 (gfx950 half-count), WRITE_SIZE KB x1024", "kernels": {}}
 for k, d in res.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         out["kernels"][k] = {"fetch_size_kb_raw": d["FETCH_SIZE"], "write_size_kb_raw": d["WRITE_SIZE"],

@@ -12,6 +12,7 @@ for k in $CODECS; do
   done
 done
 python3 - <<PY
+import sys; sys.path.insert(0, '.')
 import csv, glob, collections, json, os, re
 nt = {"etopo1": 12960, "dem1024": 1024}["$WL"]
 res = collections.defaultdict(dict)
@@ -23,7 +24,7 @@ for f in glob.glob("gpurun_out/pmcissue/**/*counter_collection.csv", recursive=T
     for k, d in acc.items():
         for c, v in d.items():
             res[k][c.replace("SQ_", "").lower()] = round(v[-1] / nt, 2)          # last (warm) dispatch, per tile
-out = {"workload": "$WL", "tiles": nt, "commit": os.environ.get("GF_COMMIT", ""), "unit": "wave-instructions (cycle counters: quad-cycles) per tile, summed over the tile's waves",
+out = {"workload": "$WL", "tiles": nt, "commit": os.environ.get("GF_COMMIT", ""), "csrc_digest": __import__("gridfour_amd.build", fromlist=["x"]).csrc_digest(), "unit": "wave-instructions (cycle counters: quad-cycles) per tile, summed over the tile's waves",
        "kernels": {k: d for k, d in sorted(res.items()) if d.get("insts_valu", 0) > 1}}
 json.dump(out, open("$OUT", "w"), indent=1)
 print(json.dumps(out, indent=1))
