@@ -99,8 +99,10 @@ struct gf_context {
     DevBuf dM32, dM32Len, dM32Models, dSeeds;   // CodecDeflate staging
     DevBuf dInflate, dInflOut, dInflMeta;       // GPU inflate: stream descriptors, inflated bytes, produced / status
     struct gf_host_pipe *pipe = nullptr;        // pipelined staging of the host-memory batch entry points (created on first use)
+    struct gf_single *single = nullptr;         // one tile per call: page-locked buffers and replayed graphs (created on first use)
 };
 void gf_host_pipe_destroy(struct gf_host_pipe *p);
+void gf_single_destroy(struct gf_single *s);
 
 struct gf_timer {
     gf_context *ctx;
@@ -228,6 +230,8 @@ void gf_context_destroy(gf_context *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    gf_single_destroy(c->single);
+    c->single = nullptr;
     c->workspace.release();
     c->trees.release();
     c->flags.release();
@@ -306,6 +310,9 @@ enum { KIND_HUFFMAN = 0, KIND_CANON = 1, KIND_RAW_M32 = 2, KIND_DEFLATE = 3, KIN
 static gf_status floatDecodeDev(gf_context *c, hipStream_t st, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob, size_t blobBytes,
                                 const uint64_t *dOffsets, const uint32_t *dLengths, float *dValues, int32_t *dStatus);
 
+// set around the device entry points by the one-tile-per-call path (singleEncode / singleDecode): GfEncodeArgs::lean, GfDecodeArgs::lean
+static thread_local int g_lean = 0;
+
 static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codecIndex, int nRows, int nCols,
                                 size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
                                 uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus, int predictorMask)
@@ -338,6 +345,7 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
             if (s != GF_OK) return s;
         }
         a.packRecs = (uint32_t *)c->packRecs.p;
+        a.lean = g_lean;
     }
     if (kind == KIND_CANON) GF_HIP(gf_launch_canon_encode(a, stream ? (hipStream_t)stream : c->stream));
     else GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
@@ -381,6 +389,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     a.pairCounts = pairCounts;
     a.trees = nullptr;
     a.retryFlag = nullptr;
+    a.lean = g_lean;
     if (kind == KIND_HUFFMAN) {
         // tree pre-pass: one lane per tile walks the serialised tree; the decode kernel starts from the leaf records
         const size_t need = nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16;
@@ -1440,6 +1449,217 @@ static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, 
     return decodeBatchHostG(kind, c, nRows, nCols, nTiles, blob, offsets, nullptr, nullptr, nullptr, values, status);
 }
 
+// ------------------------------------------------------------------ one tile per call (BASELINE config 1)
+// What a stock Gridfour application reaches without a patched GvrsFile: CodecMaster hands a codec ONE tile per call
+// (gvrs/CodecMaster.java:150-169, RasterTileCache.java:418-421).  Through the batch machinery that was 180-190 us per tile on an
+// MI355X (three stream slots, five asynchronous copies, events, a dozen API calls) against 10-20 us of kernels.  Here (round 4):
+// per context a page-locked input and output buffer and, per (direction, codec, tile shape, codec index), ONE hipGraph recorded
+// from the same device entry points the batches use -- host-to-device copy of the input, the kernels; the outputs (packing,
+// length, status / cells, status) are written by the kernels straight into the page-locked output buffer -- replayed with one
+// launch and waited for by polling the stream.  The first call of a kind takes the batch path (it loads the code objects and
+// sets the kernels' LDS attributes, which a capture must not do) and records the graph for the next.
+struct gf_single_graph {
+    int dir, kind, nRows, nCols, codecIndex;
+    size_t copyBytes;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+struct gf_single {
+    void *hIn = nullptr, *hOut = nullptr;
+    size_t hInBytes = 0, hOutBytes = 0;
+    DevBuf dIn;
+    std::vector<gf_single_graph> graphs;
+    std::vector<std::pair<int, std::pair<int, int>>> warmed;     // (dir * 8 + kind, shape) that ran once through the batch path
+};
+void gf_single_destroy(gf_single *sg)
+{
+    if (!sg) return;
+    for (auto &g : sg->graphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
+    if (sg->hIn) (void)hipHostFree(sg->hIn);
+    if (sg->hOut) (void)hipHostFree(sg->hOut);
+    sg->dIn.release();
+    delete sg;
+}
+static gf_status singleEnsure(gf_context *c, size_t inBytes, size_t outBytes)
+{
+    if (!c->single) c->single = new (std::nothrow) gf_single;
+    gf_single *sg = c->single;
+    if (!sg) return GF_ERR_HIP;
+    if (sg->hInBytes < inBytes || sg->hOutBytes < outBytes || sg->dIn.bytes < inBytes) {
+        // the graphs hold the old addresses
+        GF_HIP(hipStreamSynchronize(c->stream));
+        for (auto &g : sg->graphs) {
+            (void)hipGraphExecDestroy(g.exec);
+            (void)hipGraphDestroy(g.graph);
+        }
+        sg->graphs.clear();
+        if (sg->hInBytes < inBytes) {
+            if (sg->hIn) (void)hipHostFree(sg->hIn);
+            sg->hIn = nullptr;
+            sg->hInBytes = 0;
+            GF_HIP(hipHostMalloc(&sg->hIn, roundUp(inBytes, 4096), hipHostMallocDefault));
+            sg->hInBytes = roundUp(inBytes, 4096);
+        }
+        if (sg->hOutBytes < outBytes) {
+            if (sg->hOut) (void)hipHostFree(sg->hOut);
+            sg->hOut = nullptr;
+            sg->hOutBytes = 0;
+            GF_HIP(hipHostMalloc(&sg->hOut, roundUp(outBytes, 4096), hipHostMallocDefault));
+            sg->hOutBytes = roundUp(outBytes, 4096);
+        }
+        const gf_status s = sg->dIn.ensure(inBytes);
+        if (s != GF_OK) return s;
+    }
+    return GF_OK;
+}
+static bool singleWarmed(gf_single *sg, int key, int nRows, int nCols)
+{
+    for (auto &w : sg->warmed)
+        if (w.first == key && w.second.first == nRows && w.second.second == nCols) return true;
+    sg->warmed.push_back({key, {nRows, nCols}});
+    return false;
+}
+// waits for the stream without the interrupt path of hipStreamSynchronize (tens of microseconds on its own)
+static gf_status singleWait(hipStream_t st)
+{
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return GF_OK;
+        if (e != hipErrorNotReady) {
+            g_lastError = hipGetErrorString(e);
+            return GF_ERR_HIP;
+        }
+    }
+}
+
+static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                const int32_t *dValues, uint8_t *dOut, size_t slotStride, uint32_t *dLengths, uint8_t *dPredictors,
+                                int32_t *dStatus, int predictorMask);
+
+// returns GF_ERR_UNSUPPORTED where the caller should take the batch path instead (first call of a kind, a packing beyond the slot)
+static gf_status singleEncode(int kind, gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, uint8_t *out,
+                              size_t outCap, size_t *outLen, int32_t *tileStatus)
+{
+    if (!c || nRows < 1 || nCols < 1 || !values || !outLen) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    if (cells * 4 > ((size_t)8 << 20)) return GF_ERR_UNSUPPORTED;            // (large tiles: the batch path's copies are not what they wait for)
+    GF_HIP(hipSetDevice(c->device));
+    const size_t stride = gf_huffman_default_stride(nRows, nCols);
+    gf_status s = singleEnsure(c, std::max(cells * 4, stride + 16), std::max(stride + 64, cells * 4 + 64));
+    if (s != GF_OK) return s;
+    gf_single *sg = c->single;
+    if (!singleWarmed(sg, kind, nRows, nCols)) return GF_ERR_UNSUPPORTED;
+    gf_single_graph *g = nullptr;
+    for (auto &x : sg->graphs)
+        if (x.dir == 0 && x.kind == kind && x.nRows == nRows && x.nCols == nCols && x.codecIndex == codecIndex) g = &x;
+    uint8_t *hOut = (uint8_t *)sg->hOut;
+    uint32_t *hLen = (uint32_t *)(hOut + stride);
+    int32_t *hSt = (int32_t *)(hOut + stride + 4);
+    if (!g) {
+        if ((s = gf_context_reserve(c, nRows, nCols, 1)) != GF_OK) return s;
+        gf_single_graph ng{0, kind, nRows, nCols, codecIndex, cells * 4, nullptr, nullptr};
+        GF_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(sg->dIn.p, sg->hIn, cells * 4, hipMemcpyHostToDevice, c->stream);
+        g_lean = 1;
+        s = e == hipSuccess ? encodeBatchDev(kind, c, c->stream, codecIndex, nRows, nCols, 1, (const int32_t *)sg->dIn.p, hOut, stride, hLen,
+                                             nullptr, hSt, GF_PM_ALL)
+                            : GF_ERR_HIP;
+        g_lean = 0;
+        const hipError_t e2 = hipStreamEndCapture(c->stream, &ng.graph);
+        if (s != GF_OK || e2 != hipSuccess || !ng.graph) {
+            if (ng.graph) (void)hipGraphDestroy(ng.graph);
+            (void)hipGetLastError();
+            return GF_ERR_UNSUPPORTED;
+        }
+        if (hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(ng.graph);
+            (void)hipGetLastError();
+            return GF_ERR_UNSUPPORTED;
+        }
+        sg->graphs.push_back(ng);
+        g = &sg->graphs.back();
+    }
+    memcpy(sg->hIn, values, cells * 4);
+    GF_HIP(hipGraphLaunch(g->exec, c->stream));
+    if ((s = singleWait(c->stream)) != GF_OK) return s;
+    const int32_t st = *hSt;
+    const size_t len = *hLen;
+    if (st == GF_OVERFLOW || st == GF_K_LEAN_RETRY) return GF_ERR_UNSUPPORTED;   // longer than the slot, or a kernel this launch left out: the batch path
+    *tileStatus = st;
+    *outLen = st == GF_OK ? len : 0;
+    if (st == GF_OK) {
+        if (len > outCap) return GF_ERR_CAPACITY;
+        memcpy(out, hOut, len);
+    }
+    return GF_OK;
+}
+
+static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const uint8_t *dBlob,
+                                size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths, int32_t *dValues,
+                                int32_t *dStatus, uint32_t *analysis, uint32_t *pairCounts);
+
+static gf_status singleDecode(int kind, gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values,
+                              int32_t *tileStatus)
+{
+    if (!c || nRows < 1 || nCols < 1 || !packing || !values) return GF_ERR_ARG;
+    const size_t cells = (size_t)nRows * (size_t)nCols;
+    if (cells * 4 > ((size_t)8 << 20)) return GF_ERR_UNSUPPORTED;
+    GF_HIP(hipSetDevice(c->device));
+    const size_t stride = gf_huffman_default_stride(nRows, nCols);
+    if (len + 16 > stride) return GF_ERR_UNSUPPORTED;                         // (an unusually long packing: the batch path)
+    gf_status s = singleEnsure(c, std::max(cells * 4, stride + 16), std::max(stride + 64, cells * 4 + 64));
+    if (s != GF_OK) return s;
+    gf_single *sg = c->single;
+    if (!singleWarmed(sg, 8 + kind, nRows, nCols)) return GF_ERR_UNSUPPORTED;
+    // the copy moves [length, 12 spare bytes, packing]: sized in powers of two so that a few graphs serve every length
+    size_t copyBytes = 4096;
+    while (copyBytes < len + 16 + 8) copyBytes <<= 1;                         // (+ 8: the kernels read whole words behind the last byte)
+    copyBytes = std::min(copyBytes, roundUp(stride + 16, 16));
+    gf_single_graph *g = nullptr;
+    for (auto &x : sg->graphs)
+        if (x.dir == 1 && x.kind == kind && x.nRows == nRows && x.nCols == nCols && x.copyBytes == copyBytes) g = &x;
+    uint8_t *hIn = (uint8_t *)sg->hIn, *hOut = (uint8_t *)sg->hOut;
+    int32_t *hSt = (int32_t *)(hOut + cells * 4);
+    if (!g) {
+        if ((s = gf_context_reserve(c, nRows, nCols, 1)) != GF_OK) return s;
+        gf_single_graph ng{1, kind, nRows, nCols, 0, copyBytes, nullptr, nullptr};
+        uint8_t *dIn = (uint8_t *)sg->dIn.p;
+        GF_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(dIn, hIn, copyBytes, hipMemcpyHostToDevice, c->stream);
+        g_lean = 1;
+        s = e == hipSuccess ? decodeBatchDev(kind, c, c->stream, nRows, nCols, 1, dIn + 16, copyBytes - 16, nullptr, copyBytes - 16,
+                                             (const uint32_t *)dIn, (int32_t *)hOut, hSt, nullptr, nullptr)
+                            : GF_ERR_HIP;
+        g_lean = 0;
+        const hipError_t e2 = hipStreamEndCapture(c->stream, &ng.graph);
+        if (s != GF_OK || e2 != hipSuccess || !ng.graph) {
+            if (ng.graph) (void)hipGraphDestroy(ng.graph);
+            (void)hipGetLastError();
+            return GF_ERR_UNSUPPORTED;
+        }
+        if (hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(ng.graph);
+            (void)hipGetLastError();
+            return GF_ERR_UNSUPPORTED;
+        }
+        sg->graphs.push_back(ng);
+        g = &sg->graphs.back();
+    }
+    const uint32_t len32 = (uint32_t)len;
+    memcpy(hIn, &len32, 4);
+    memcpy(hIn + 16, packing, len);
+    memset(hIn + 16 + len, 0, std::min<size_t>(8, copyBytes - 16 - len));
+    GF_HIP(hipGraphLaunch(g->exec, c->stream));
+    if ((s = singleWait(c->stream)) != GF_OK) return s;
+    if (*hSt == GF_K_LEAN_RETRY) return GF_ERR_UNSUPPORTED;                   // a tile the fast kernel leaves to the others: the batch path
+    *tileStatus = *hSt;
+    if (*hSt == GF_OK) memcpy(values, hOut, cells * 4);
+    return GF_OK;
+}
+
 extern "C" {
 
 gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles,
@@ -1474,7 +1694,10 @@ gf_status gf_canon_encode_i32(gf_context *c, int codecIndex, int nRows, int nCol
     if (!outLen) return GF_ERR_ARG;
     uint64_t offsets[2] = {0, 0};
     int32_t st = 0;
-    gf_status s = gf_canon_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, out, outCap, offsets, nullptr, &st);
+    gf_status s = singleEncode(KIND_CANON, c, codecIndex, nRows, nCols, values, out, outCap, outLen, &st);
+    if (s == GF_OK) return (gf_status)st;
+    if (s != GF_ERR_UNSUPPORTED) return s;
+    s = gf_canon_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, out, outCap, offsets, nullptr, &st);
     *outLen = (size_t)offsets[1];
     if (s != GF_OK) return s;
     return (gf_status)st;
@@ -1484,7 +1707,10 @@ gf_status gf_canon_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t
 {
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
-    gf_status s = gf_canon_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
+    gf_status s = singleDecode(KIND_CANON, c, nRows, nCols, packing, len, values, &st);
+    if (s == GF_OK) return (gf_status)st;
+    if (s != GF_ERR_UNSUPPORTED) return s;
+    s = gf_canon_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
     if (s != GF_OK) return s;
     return (gf_status)st;
 }
@@ -1495,7 +1721,10 @@ gf_status gf_huffman_encode_i32(gf_context *c, int codecIndex, int nRows, int nC
     if (!outLen) return GF_ERR_ARG;
     uint64_t offsets[2] = {0, 0};
     int32_t st = 0;
-    gf_status s = gf_huffman_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, out, outCap, offsets, nullptr, &st);
+    gf_status s = singleEncode(KIND_HUFFMAN, c, codecIndex, nRows, nCols, values, out, outCap, outLen, &st);
+    if (s == GF_OK) return (gf_status)st;
+    if (s != GF_ERR_UNSUPPORTED) return s;
+    s = gf_huffman_encode_batch_i32(c, codecIndex, nRows, nCols, 1, values, out, outCap, offsets, nullptr, &st);
     *outLen = (size_t)offsets[1];
     if (s != GF_OK) return s;
     return (gf_status)st;
@@ -1506,7 +1735,10 @@ gf_status gf_huffman_decode_i32(gf_context *c, int nRows, int nCols, const uint8
 {
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
-    gf_status s = gf_huffman_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
+    gf_status s = singleDecode(KIND_HUFFMAN, c, nRows, nCols, packing, len, values, &st);
+    if (s == GF_OK) return (gf_status)st;
+    if (s != GF_ERR_UNSUPPORTED) return s;
+    s = gf_huffman_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
     if (s != GF_OK) return s;
     return (gf_status)st;
 }

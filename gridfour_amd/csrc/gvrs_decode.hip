@@ -2716,12 +2716,32 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
                                                             const uint32_t *__restrict__ lengths, uint32_t *__restrict__ trees,
                                                             size_t nTiles)
 {
-    if (threadIdx.x >= perWave) return;
-    const size_t t = (size_t)blockIdx.x * perWave + threadIdx.x;
+    if (perWave != 1u && threadIdx.x >= perWave) return;
+    const size_t t = perWave == 1u ? (size_t)blockIdx.x : (size_t)blockIdx.x * perWave + threadIdx.x;
     if (t >= nTiles) return;
     const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
     const uint32_t len = lengths[t];
     uint32_t *rec = trees + t * GF_TREE_REC_WORDS;
+    // A wave per tile (small batches, one tile per call): the walk below is one lane's, and every refill of its bit buffer used to
+    // be a load of its own from global memory -- some thirty dependent round trips, 30 us for the one tile of a call (round 4).
+    // The wave's 64 lanes fetch the words the walk can ask for (the packing's bytes 10 .. 521) at once; the walk reads lanes.
+    uint32_t stage0 = 0, stage1 = 0;
+    if (perWave == 1u) {
+        if (len >= 10 && off + len <= blobBytes) {
+            const uint8_t *__restrict__ pk0 = blob + off;
+            const uint32_t vis = min(len, (uint32_t)(HEAD_WORDS * 4));
+            auto word = [&](uint32_t i) -> uint32_t {
+                if (i + 4u <= vis) return reinterpret_cast<const PackedWord *>(pk0 + i)->v;
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < 4; k++)
+                    if (i + k < vis) w |= (uint32_t)pk0[i + k] << (8u * k);
+                return w;
+            };
+            stage0 = word(10u + 4u * threadIdx.x);
+            stage1 = word(10u + 256u + 4u * threadIdx.x);
+        }
+        if (threadIdx.x >= 1u) return;
+    }
     unsigned long long *codes = reinterpret_cast<unsigned long long *>(rec + 8);
     uint8_t *lens = reinterpret_cast<uint8_t *>(rec + 8 + 512), *syms = lens + 256;
     if (len < 10 || off + len > blobBytes) {                 // the decode kernel rejects the tile before looking here
@@ -2734,6 +2754,15 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     // (staging a tile's serialised tree in LDS first -- all loads in flight, the walk reading from there -- was tried in rounds
     // 2 and 3 and changes nothing: 0.08 ms either way, the walk is bound by its dependent instruction chain at one wave per CU)
     auto ld32 = [&](uint32_t i) -> uint32_t {                // bytes i .. i+3 of the packing, little-endian
+        if (perWave == 1u) {                                 // (i = 10 + 4 k: the staged word k)
+            const uint32_t k = (i - 10u) >> 2;
+            if (k >= 128u) return 0u;                        // beyond the staged head (= beyond `visible`)
+            // (both registers are read at the lane and the pick is made afterwards: a select between them BEFORE the read would be
+            // evaluated in lane 0 alone, the only one still running)
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)stage0, (int)(k & 63u));
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)stage1, (int)(k & 63u));
+            return k < 64u ? lo : hi;
+        }
         if (i + 4u <= visible) return reinterpret_cast<const PackedWord *>(pk + i)->v;
         uint32_t w = 0;
         for (uint32_t k = 0; k < 4; k++)
@@ -2899,9 +2928,14 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         // when nothing is marked)
         const size_t dynRoomy = a.ldsM32Roomy ? decodeDynLds(a.ldsM32Roomy, a.ldsTextBytes) : 0;
         if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST>, dyn > dynRoomy ? dyn : dynRoomy, optF)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(a.retryFlag, 0, 8, stream)) != hipSuccess) return e;
         GfDecodeArgs f = a;
         f.retryPass = 0;
+        if (a.lean) {
+            // the one-tile-per-call path: the fast kernel alone (a tile it leaves behind keeps GF_K_RETRY; the caller sees to it)
+            hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
+            return hipGetLastError();
+        }
+        if ((e = hipMemsetAsync(a.retryFlag, 0, 8, stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
         if (a.ldsM32Roomy) {
             // the tiles that outgrew their LDS once more, with room (the workgroups of the others leave at once)

@@ -1068,6 +1068,7 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
             if (tid == 0) {
                 rec[6] = done ? 0u : 1u;
                 if (!done && a.retryFlag) atomicAdd(a.retryFlag + 1, 1u);  // (word 1: tiles left to k_huffman_pack_rare)
+                if (!done && a.lean) a.status[t] = GF_K_RETRY;              // (no k_huffman_pack_rare behind this launch: the caller's business)
             }
         }
         if (done) {
@@ -1267,20 +1268,24 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (!a.packRecs) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
     const size_t nCells = (size_t)a.nRows * (size_t)a.nCols;
-    if (a.retryFlag) {                                                    // word 0: tiles for k_huffman_encode<false>, word 1: for k_huffman_pack_rare
+    if (a.retryFlag && !a.lean) {                                         // word 0: tiles for k_huffman_encode<false>, word 1: for k_huffman_pack_rare
         const hipError_t e = hipMemsetAsync(a.retryFlag, 0, 8, stream);
         if (e != hipSuccess) return e;
     }
     if (a.retryFlag && 6ull * nCells < (1ull << 23)) {
         hipLaunchKernelGGL(k_huffman_encode<true>, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
+#ifdef GF_ENC_NULLS_RETRY
+        // (only this experiment build's fast kernel leaves tiles behind: the shipping one takes every tile of up to 2^23 / 6 cells, and
+        // the general kernel's launch -- 4-5 us to find nothing to do -- went in round 4)
         hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid < 2048 ? grid : 2048), dim3(ENC_THREADS), 0, stream, a);
+#endif
     } else {
         GfEncodeArgs g = a;
         g.retryFlag = nullptr;
         hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid), dim3(ENC_THREADS), 0, stream, g);
     }
     hipLaunchKernelGGL(k_huffman_pack, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
-    hipLaunchKernelGGL(k_huffman_pack_rare, dim3(grid < 1024 ? grid : 1024), dim3(ENC_THREADS), 0, stream, a);
+    if (!a.lean) hipLaunchKernelGGL(k_huffman_pack_rare, dim3(grid < 1024 ? grid : 1024), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

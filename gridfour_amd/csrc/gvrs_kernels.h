@@ -86,7 +86,11 @@ struct GfEncodeArgs {
     uint32_t *packRecs;        // non-null (CodecHuffman only): k_huffman_encode stops after the selection and leaves per tile
                                // GF_PACK_REC_WORDS words (model, tree end bit, seed, maxN, maxLen, tree image, code table)
                                // for k_huffman_pack, which writes the packing
+    int lean;                  // 1 (the one-tile-per-call path): only the kernels a tile usually needs are launched; a tile that
+                               // needs another one (k_huffman_pack_rare) is reported with the internal status GF_K_LEAN_RETRY and
+                               // the caller takes the batch path for it
 };
+#define GF_K_LEAN_RETRY 0x7fff0002              /* (= GF_K_RETRY of the kernels: the fast kernels' own mark travels the same way) */
 constexpr int GF_PACK_REC_WORDS = 8 + 88 + 512;
 
 struct GfDecodeArgs {
@@ -116,6 +120,8 @@ struct GfDecodeArgs {
                                // packing outgrows ldsM32Bytes (dense in multi-byte values) get a workgroup with more LDS
                                // instead of the general kernel and its workspace in global memory
     int retryPass;             // set by the launcher: 1 in the fast kernel's second run
+    int lean;                  // 1 (the one-tile-per-call path): the fast kernel alone; what it leaves behind keeps the status
+                               // GF_K_LEAN_RETRY and the caller takes the batch path for it
     uint32_t *analysis;        // non-null: CodecHuffman.analyze mode -- per tile GF_ANALYSIS_WORDS words (predictor, nM32,
                                // bits in tree, packing bytes - 10, 256-bin histogram of the M32 bytes); no values are written
     uint32_t *pairCounts;      // analyze mode, may be null: GF_PAIR_TABLES x 65536 counters, [predictor][prior << 8 | value] of
