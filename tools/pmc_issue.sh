@@ -14,7 +14,7 @@ done
 python3 - <<PY
 import sys; sys.path.insert(0, '.')
 import csv, glob, collections, json, os, re
-nt = {"etopo1": 12960, "dem1024": 1024}["$WL"]
+nt = {"etopo1": 12960, "etopo1_rough": 12960, "dem1024": 1024}["$WL"]
 res = collections.defaultdict(dict)
 for f in glob.glob("gpurun_out/pmcissue/**/*counter_collection.csv", recursive=True):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))

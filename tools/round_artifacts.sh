@@ -18,9 +18,14 @@ cp $OUT/issue_counts.json profiles/issue_counts.json 2>/dev/null
 bash tools/pmc_why.sh $OUT both > $OUT/pmc_why.log 2>&1
 bash tools/pmc_phases_dec.sh > $OUT/pmc_phases_dec.txt 2>&1
 bash tools/pmc_phases_canon.sh > $OUT/pmc_phases_canon.txt 2>&1
-[ -x tools/bin/valu_rate ] && tools/bin/valu_rate > $OUT/valu_rate.txt 2>&1
+[ -x tools/bin/issue_rate ] && tools/bin/issue_rate > $OUT/issue_rate.json 2>&1
+[ -x tools/bin/single_tile_latency ] && tools/bin/single_tile_latency > $OUT/single_tile_latency.json 2>&1
+GF_COMMIT=$GF_COMMIT bash tools/pmc_issue.sh $OUT/issue_counts_rough.json etopo1_rough "huffman" > $OUT/pmc_issue_rough.txt 2>&1
 timeout 600 python3 bench.py 2>/dev/null | tail -1 > $OUT/bench.json
 timeout 600 python3 bench.py --workload etopo1_nulls --cpu-sample-tiles 0 2>/dev/null | tail -1 > $OUT/bench_etopo1_nulls.json
+timeout 600 python3 bench.py --workload etopo1_rough --cpu-sample-tiles 0 2>/dev/null | tail -1 > $OUT/bench_etopo1_rough.json
+rm -rf $OUT/profr; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profr -- python3 bench.py --workload etopo1_rough --cpu-sample-tiles 0 > /dev/null 2>> $OUT/rocprof.log
+f=$(find $OUT/profr -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_etopo1_rough.csv; rm -rf $OUT/profr
 timeout 900 python3 tools/codec_master_rate.py 2>/dev/null | tail -1 > $OUT/codec_master_rate.json
 timeout 900 python3 tools/host_path_rate.py etopo1 2>/dev/null | tail -1 > $OUT/host_path_etopo1.json
 timeout 900 python3 tools/host_path_rate.py etopo1 2 2>/dev/null | tail -1 > $OUT/host_path_etopo1_multi2.json

@@ -19,11 +19,11 @@ def main():
     which, el, dl, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     wl = sys.argv[5] if len(sys.argv) > 5 else "etopo1"
     codec = sys.argv[6] if len(sys.argv) > 6 else "huffman"
-    n_rows, n_cols, nt, tpr = {"etopo1": (120, 150, 12960, 144), "dem1024": (200, 200, 1024, 32)}[wl]
+    n_rows, n_cols, nt, tpr = {"etopo1": (120, 150, 12960, 144), "etopo1_rough": (120, 150, 12960, 144), "dem1024": (200, 200, 1024, 32)}[wl]
     ctx = gridfour_amd.GvrsHipContext(0)
     cells = n_rows * n_cols
     b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * cells + 1024 + 15) // 16 * 16, codec=codec)
-    b.synth_dem(0x9E3779B97F4A7C15 + 2, tpr)
+    b.synth_dem(0x9E3779B97F4A7C15 + 2, tpr, style=1 if wl == "etopo1_rough" else 0)
     L = lib()
     diag = bool(os.environ.get("GVRS_HIP_DIAG"))
     if diag:
