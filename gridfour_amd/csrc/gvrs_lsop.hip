@@ -112,6 +112,7 @@ __device__ constexpr PairTab PAIRS = make_pairs();
 
 struct LsopShared {
     double G[104];
+    int32_t C32[1024];         // lsop_gram_mfma: the 32 x 32 digit Gram matrix
     float u[12];
     uint32_t maxAbs;
     int32_t status;
@@ -236,6 +237,97 @@ __device__ __forceinline__ void lsop_gram_rows(const int32_t *__restrict__ v, in
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
         if (lane == 0) G[W * 26 + q] = a;
+    }
+}
+
+// The same sums on the MATRIX pipe (round 4).  The normal equations are the Gram matrix Z^T Z of Z = (cells x 14) with
+// z0..z12 and a column of ones (LsOptimalPredictor12.java:335-342): the one dense contraction of this code base.
+// Under the exactness guard every z is an integer of |z| <= 32,639, i.e. two balanced base-256 digits  z = 256 hi + lo,
+// lo = (int8) z, hi = (z + 128) >> 8, both in -128..127, and
+//   SUM z_i z_j = 65536 SUM hi_i hi_j + 256 (SUM hi_i lo_j + SUM lo_i hi_j) + SUM lo_i lo_j :
+// the 27 digit columns (13 lo, 13 hi, the ones) are one int8 operand of v_mfma_i32_32x32x32_i8 -- THE SAME register quadruple as
+// A and as B: lane l holds column l & 31 for the sixteen cells 16 (l >> 5) .. + 15 of a group of 32 cells of a tile row, which is
+// A[i][k] and B[k][i] at once -- and 32 cells are 27 x 27 x 32 exact integer multiply-adds in ONE instruction of 32 cycles, with
+// int32 accumulators (128 x 128 x cells < 2^31 for cells < 2^17) that are recombined in int64 and converted to double once: the same
+// values, bit for bit, as the scan-order FP64 sums (all of which are exact integers below 2^53 under the guard).  The rows pass
+// through the four-row LDS ring of lsop_gram_rows; the groups of a tile are dealt round-robin to the four waves, which add
+// their 32 x 32 accumulators up in LDS.  (FP64 FMA form: 26 fused multiply-adds per wave and 64 cells on each of the four
+// SIMDs; v_mfma_f64_16x16x4_f64 has the vector rate on gfx950 and lost.)
+typedef int LsV4i __attribute__((ext_vector_type(4)));
+typedef int LsV16i __attribute__((ext_vector_type(16)));
+constexpr uint32_t LSOP_MFMA_MAX_ABS = 32639u;             // (z + 128) >> 8 <= 127
+__device__ __forceinline__ void lsop_gram_mfma(const int32_t *__restrict__ v, int32_t *ring, int32_t *C32, uint32_t nR, uint32_t nC,
+                                               double *G, int tid)
+{
+    const int lane = tid & 63;
+    const uint32_t wave = gf_wave_id();
+    const uint32_t col = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
+    // what this lane's column is: digit `shift` of z_zi (13: the ones, 14: nothing)
+    const uint32_t zi = col < 13u ? col : col < 26u ? col - 13u : col == 26u ? 13u : 14u;
+    const uint32_t bias = (col >= 13u && col < 26u) ? 128u : 0u, shift = (col >= 13u && col < 26u) ? 8u : 0u;
+    // z_i = v(r + dr, c + dc) (lsop_z_offset)
+    int dr = 0, dc = 0;
+    switch (zi) {
+    case 1: dc = -1; break;
+    case 2: dr = -1; dc = -1; break;
+    case 3: dr = -1; break;
+    case 4: dr = -1; dc = 1; break;
+    case 5: dr = -1; dc = 2; break;
+    case 6: dc = -2; break;
+    case 7: dr = -1; dc = -2; break;
+    case 8: dr = -2; dc = -2; break;
+    case 9: dr = -2; dc = -1; break;
+    case 10: dr = -2; break;
+    case 11: dr = -2; dc = 1; break;
+    case 12: dr = -2; dc = 2; break;
+    default: break;
+    }
+    LsV16i acc = {};
+    for (uint32_t i = (uint32_t)tid; i < 1024u; i += 256u) C32[i] = 0;
+    for (uint32_t i = (uint32_t)tid; i < 3u * nC; i += 256u) ring[i] = v[i];          // rows 0..2 -> slots 0..2
+    __syncthreads();
+    const uint32_t wI = nC - 4u, nGroups = (wI + 31u) >> 5;
+    uint32_t turn = 0;                                                                // groups so far, over the rows: dealt to the waves
+    for (uint32_t r = 2; r < nR; r++) {
+        const bool more = r + 1u < nR && (uint32_t)tid < nC;
+        const int32_t pre = more ? v[(size_t)(r + 1u) * nC + (uint32_t)tid] : 0;
+        const int32_t *row = ring + ((r + (uint32_t)dr) & 3u) * nC;                    // the ring row this lane's z lives in
+        for (uint32_t g = 0; g < nGroups; g++, turn++) {
+            if ((turn & 3u) != wave) continue;                                        // (wave-uniform)
+            const uint32_t c0 = 2u + 32u * g + 16u * h;                               // the lane's first cell of the group
+            const uint32_t nValid = c0 < nC - 2u ? min(16u, nC - 2u - c0) : 0u;       // cells of the row among its sixteen
+            LsV4i x;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; b++) {
+                    const uint32_t j = 4u * q + b;
+                    uint32_t d = 0;
+                    if (j < nValid && zi < 14u) {
+                        const uint32_t val = zi == 13u ? 1u : (uint32_t)row[(int32_t)(c0 + j) + dc];
+                        d = ((val + bias) >> shift) & 0xffu;
+                    }
+                    w |= d << (8u * b);
+                }
+                x[q] = (int)w;
+            }
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, x, acc, 0, 0, 0);
+        }
+        if (more) ring[((r + 1u) & 3u) * nC + (uint32_t)tid] = pre;     // the slot of row r - 3
+        __syncthreads();
+    }
+    // the four waves' accumulators into one 32 x 32 matrix (result register q of lane l: row (q & 3) + 8 (q >> 2) + 4 (l >> 5), column l & 31)
+#pragma unroll
+    for (uint32_t q = 0; q < 16u; q++) atomicAdd(&C32[((q & 3u) + 8u * (q >> 2) + 4u * h) * 32u + col], acc[q]);
+    __syncthreads();
+    if (tid < 104) {
+        const int i = PAIRS.i[tid], j = PAIRS.j[tid];
+        long long sum;
+        if (j == 13) sum = 256ll * C32[(13 + i) * 32 + 26] + C32[i * 32 + 26];           // the plain sums: against the ones
+        else
+            sum = 65536ll * C32[(13 + i) * 32 + 13 + j] + 256ll * ((long long)C32[(13 + i) * 32 + j] + C32[i * 32 + 13 + j]) + C32[i * 32 + j];
+        G[tid] = (double)sum;
     }
 }
 
@@ -368,7 +460,9 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT_WGS) void k_lsop_predict(GfLso
             // Exact sums: lanes split the cells, the four waves split the 104 accumulators (26 each), FMA.
             // (v_mfma_f64_16x16x4_f64 was measured here: 64-cycle issue for 1024 MACs of which 416 are needed --
             //  6.7 ms against 3.7 ms for this form; FP64 MFMA has the vector rate on gfx950, so padding loses.)
-            if (nC <= LSOP_RING_MAXC) {
+            if (nC <= LSOP_RING_MAXC && S.maxAbs <= LSOP_MFMA_MAX_ABS && nInt < (1u << 17)) {
+                lsop_gram_mfma(v, lsopRing, S.C32, nR, nC, S.G, tid);
+            } else if (nC <= LSOP_RING_MAXC) {
                 const int w = (int)GF_UNI(wave);                    // (a scalar: each wave runs ONE of the four loops)
                 if (w == 0) lsop_gram_rows<0>(v, lsopRing, nR, nC, S.G, tid);
                 else if (w == 1) lsop_gram_rows<1>(v, lsopRing, nR, nC, S.G, tid);
