@@ -282,6 +282,11 @@ __device__ __forceinline__ void lsop_gram_mfma(const int32_t *__restrict__ v, in
     case 12: dr = -2; dc = 2; break;
     default: break;
     }
+    // Sixteen cells of a column become four operand words: the digit is byte 0 of v (lo) or byte 1 of v + 128 (hi), picked out of
+    // two values at a time by v_perm_b32 with a per-lane selector; the ones column and the five idle columns are constants.
+    const uint32_t selPair = 0x0c0c0000u | ((4u + (shift >> 3)) << 8) | (shift >> 3);     // byte s of the 2nd source, byte s of the 1st
+    const uint32_t constWord = zi == 13u ? 0x01010101u : 0u;
+    const bool isConst = zi >= 13u;
     LsV16i acc = {};
     for (uint32_t i = (uint32_t)tid; i < 1024u; i += 256u) C32[i] = 0;
     for (uint32_t i = (uint32_t)tid; i < 3u * nC; i += 256u) ring[i] = v[i];          // rows 0..2 -> slots 0..2
@@ -291,26 +296,28 @@ __device__ __forceinline__ void lsop_gram_mfma(const int32_t *__restrict__ v, in
     for (uint32_t r = 2; r < nR; r++) {
         const bool more = r + 1u < nR && (uint32_t)tid < nC;
         const int32_t pre = more ? v[(size_t)(r + 1u) * nC + (uint32_t)tid] : 0;
-        const int32_t *row = ring + ((r + (uint32_t)dr) & 3u) * nC;                    // the ring row this lane's z lives in
+        const int32_t *row = ring + ((r + (uint32_t)dr) & 3u) * nC + dc;               // the ring row this lane's z lives in, shifted
         for (uint32_t g = 0; g < nGroups; g++, turn++) {
             if ((turn & 3u) != wave) continue;                                        // (wave-uniform)
             const uint32_t c0 = 2u + 32u * g + 16u * h;                               // the lane's first cell of the group
-            const uint32_t nValid = c0 < nC - 2u ? min(16u, nC - 2u - c0) : 0u;       // cells of the row among its sixteen
+            const int32_t *src = row + c0;                                            // (the ring has room behind its last row for the
+                                                                                      //  reads of a row's last group: their bytes are masked)
             LsV4i x;
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) {
-                uint32_t w = 0;
+                const uint32_t t0 = (uint32_t)src[4u * q] + bias, t1 = (uint32_t)src[4u * q + 1u] + bias;
+                const uint32_t t2 = (uint32_t)src[4u * q + 2u] + bias, t3 = (uint32_t)src[4u * q + 3u] + bias;
+                const uint32_t p01 = __builtin_amdgcn_perm(t1, t0, selPair), p23 = __builtin_amdgcn_perm(t3, t2, selPair);
+                const uint32_t w = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                x[q] = (int)(isConst ? constWord : w);
+            }
+            if (g + 1u == nGroups) {                                                  // (wave-uniform) the row's last group: cells behind it
+                const uint32_t nValid = c0 < nC - 2u ? min(16u, nC - 2u - c0) : 0u;
 #pragma unroll
-                for (uint32_t b = 0; b < 4u; b++) {
-                    const uint32_t j = 4u * q + b;
-                    uint32_t d = 0;
-                    if (j < nValid && zi < 14u) {
-                        const uint32_t val = zi == 13u ? 1u : (uint32_t)row[(int32_t)(c0 + j) + dc];
-                        d = ((val + bias) >> shift) & 0xffu;
-                    }
-                    w |= d << (8u * b);
+                for (uint32_t q = 0; q < 4u; q++) {
+                    const uint32_t have = nValid > 4u * q ? min(4u, nValid - 4u * q) : 0u;
+                    x[q] &= (int)(have >= 4u ? 0xFFFFFFFFu : (1u << (8u * have)) - 1u);
                 }
-                x[q] = (int)w;
             }
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, x, acc, 0, 0, 0);
         }
@@ -1445,7 +1452,8 @@ hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, siz
 {
     if (nTiles == 0) return hipSuccess;
     GfLsopPredictArgs a{values, residuals, resStride, coefs, status, nTiles, nRows, nCols};
-    const size_t dyn = (size_t)nCols <= LSOP_RING_MAXC ? (size_t)4 * (size_t)nCols * 4 : 0;
+    const size_t dyn = (size_t)nCols <= LSOP_RING_MAXC ? ((size_t)4 * (size_t)nCols + 40) * 4 : 0;   // (+ 40 ints: lsop_gram_mfma reads a
+                                                                                                        // row's last group of sixteen past its end)
     hipLaunchKernelGGL(k_lsop_predict, gf_tile_grid(nTiles), dim3(256), dyn, stream, a);
     return hipGetLastError();
 }
