@@ -114,6 +114,7 @@ struct DecShared {
     // decode loop :179-185 finds 0 in such a child slot, lands on the root again and goes on without a symbol.
     uint32_t skipLen, skipLo, skipHi;
     uint32_t symKinds;                         // GF_TREE_HAS_* of the tree record (fast kernel only)
+    uint32_t poolOverflow;                     // fast_sync_pass with a symbol pool: a subsequence had more symbols than its share holds
 };
 
 #include "gvrs_decode_common.h"
@@ -566,9 +567,15 @@ constexpr int NCUR = MAXQ / DEC_THREADS;           // cursors per thread: subseq
 // end: the first code at or behind a border belongs to the other side) and where the first code is longer than the window.
 // With 32 waves on a CU the two dependent LDS round trips per step are covered by the other waves; what the kernel is short of
 // is issue slots (PMC, profiles/r03_*: VALU 60 %, scalar unit 70 % busy), and the step is 28 instructions instead of 42.
+//
+// With a symbol POOL (round 4) the pass is the only decode of the text: behind its warm-up a subsequence is decoded through the
+// two-symbol table and its symbols go, four to a word, to its share of the pool -- poolWords words per subsequence, word-major, in global
+// memory (the tile's own output area, which nothing needs before the rows are written) --; when the counts are known the symbols
+// are moved to their places in the M32 buffer (pool_to_m32) and the write pass, a second decode of every bit, is not run.
 template <int OWNER>
 __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *cnt16, const uint32_t *txt, uint32_t sh0, uint32_t start,
-                               uint32_t end, uint32_t unit, uint32_t Q, uint32_t warm, uint32_t *dbg)
+                               uint32_t end, uint32_t unit, uint32_t Q, uint32_t warm, uint32_t *dbg, uint32_t *pool = nullptr,
+                               const uint32_t poolWords = 0)
 {
     const uint32_t tid = threadIdx.x;
     uint16_t *list = reinterpret_cast<uint16_t *>(S.qdirty);      // subsequences to redo (the flags themselves are not used here)
@@ -578,7 +585,7 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *c
 #else
     (void)dbg;
 #endif
-    if (tid == 0) { S.nRedo[0] = 0; S.nRedo[1] = 0; }
+    if (tid == 0) { S.nRedo[0] = 0; S.nRedo[1] = 0; S.poolOverflow = 0; }
     // one round: cursor i of this thread decodes subsequence qv[i] (>= Q: none)
     auto runRound = [&](const bool first, const uint32_t (&qv)[NCUR]) {
         bool d[NCUR];
@@ -639,7 +646,58 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *c
         while (anyBefore(bA)) step(bA, std::false_type{});
 #pragma unroll
         for (int i = 0; i < NCUR; i++) sPos[i] = a[i] - sh0;                    // the first code at or beyond the boundary
-        while (anyBefore(limA)) step(limA, std::true_type{});
+        if (!pool) {
+            while (anyBefore(limA)) step(limA, std::true_type{});
+        } else {
+            // the subsequence itself, symbols kept: one or two codes per step (the second one only if it STARTS before the
+            // border: the same rule as above, so positions and counts are the same), bytes gathered in a register pair and
+            // stored a word at a time
+            // (the word being filled is stored after EVERY step, complete or not -- a later store of the same word only adds bytes --
+            // so there is no "word full?" branch and no epilogue; word-major addresses: the lanes of a wave are at about the same
+            // word, their stores fall into a line or two)
+            uint32_t lo[NCUR];
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) lo[i] = 0;
+            const uint32_t lastWord = poolWords - 1u;
+            while (anyBefore(limA)) {
+                uint32_t x[NCUR], e[NCUR], anyLong = 0;
+#pragma unroll
+                for (int i = 0; i < NCUR; i++) {
+                    const uint32_t wi = a[i] >> 5;
+                    x[i] = __builtin_amdgcn_alignbit(txt[wi + 1u], txt[wi], a[i]);
+                    e[i] = S.lut[x[i] & ((1u << LUT_BITS) - 1u)];
+                    anyLong |= e[i];
+                }
+                if (__any((anyLong & 0x80000000u) != 0u)) {
+#pragma unroll
+                    for (int i = 0; i < NCUR; i++)
+                        if (e[i] & 0x80000000u) {
+                            const uint32_t wi = a[i] >> 5;
+                            e[i] = fh_resolve(H, e[i], x[i], txt[wi], txt[wi + 1u], txt[wi + 2u], a[i] & 31u);
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < NCUR; i++) {
+                    const bool live = a[i] < limA[i];
+                    const uint32_t a1 = (e[i] >> 16) & 63u, t2 = e[i] >> 22;
+                    const bool two = t2 != a1 && a[i] + a1 < limA[i];
+                    const uint32_t k = live ? (two ? 2u : 1u) : 0u;
+                    const uint32_t syms = live ? (two ? e[i] & 0xffffu : e[i] & 0xffu) : 0u;
+                    const uint32_t at = cnt[i] & 3u;
+                    lo[i] |= syms << (8u * at);                                 // (a second byte behind byte 3 drops out: it opens the next word)
+                    if (d[i]) pool[min(cnt[i] >> 2, lastWord) * Q + qv[i]] = lo[i];
+                    lo[i] = at + k >= 4u ? (at == 3u ? syms >> 8 : 0u) : lo[i];
+                    cnt[i] += k;
+                    a[i] += live ? (two ? t2 : a1) : 0u;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NCUR; i++) {
+                // (the word a second byte may have opened in the very last step)
+                if (d[i] && (cnt[i] & 3u)) pool[min(cnt[i] >> 2, lastWord) * Q + qv[i]] = lo[i];
+                if (d[i] && cnt[i] > 4u * poolWords) S.poolOverflow = 1u;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NCUR; i++)
             if (d[i]) { S.qs[qv[i]] = sPos[i]; S.qe[qv[i]] = a[i] - sh0; S.qn[qv[i]] = cnt[i]; }
@@ -749,11 +807,59 @@ __device__ __forceinline__ void rcur_advance(RCur &c, uint32_t len)             
 // 64 bits of a leaf search in r0..r2 without shifting in a word that was never loaded
 constexpr uint32_t RCUR_BUDGET = 256u - 31u - 96u;
 
+// The pool's symbols to their places: S.qn holds the exclusive prefix of the subsequences' counts, so subsequence q's symbols are bytes
+// [qn[q], qn[q + 1]) of the M32 stream (what lies beyond nM32 is not wanted).  A thread reads its share of the pool eight words at
+// a time; up to three head bytes bring it to a word boundary of the stream, then whole words go out (the pool's words re-aligned by
+// v_alignbyte), then up to three tail bytes -- the words at either end are shared with the neighbouring subsequences.  What is not
+// wanted goes to a spare word behind the stream (no branch per store).
+__device__ __forceinline__ void pool_to_m32(DecShared &S, const uint32_t *pool, uint32_t poolWords, uint32_t Q, uint32_t nM32, uint8_t *m32,
+                                            uint32_t spare)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t *m32w = reinterpret_cast<uint32_t *>(m32);
+#pragma unroll
+    for (int i = 0; i < NCUR; i++) {
+        const uint32_t q = tid + (uint32_t)i * DEC_THREADS;
+        uint32_t base = 0, n = 0;
+        if (q < Q) {
+            base = S.qn[q];
+            n = (q + 1u < Q ? S.qn[q + 1u] : S.chainTotal) - base;
+            n = base < nM32 ? min(n, nM32 - base) : 0u;
+        }
+        const uint32_t *src = pool + (q < Q ? q : 0u);               // word w of subsequence q: pool[w Q + q]
+        const uint32_t h = min(n, (0u - base) & 3u);             // head bytes
+        const uint32_t nb = (n - h) >> 2, r = (n - h) & 3u;       // whole words, tail bytes
+        const uint32_t w0 = (base + h) >> 2;                      // the stream word the first whole word goes to
+        uint32_t tailWord = 0, first = 0;
+        for (uint32_t c = 0; c < poolWords; c += 8u) {
+            if (!__any(4u * c < n)) break;
+            uint32_t w[9];
+#pragma unroll
+            for (uint32_t j = 0; j < 9u; j++) w[j] = c + j < poolWords ? src[(c + j) * Q] : 0u;
+            if (c == 0u) first = w[0];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) {
+                const uint32_t k = c + j;                         // the k-th whole word: pool bytes h + 4 k ..
+                const uint32_t out = __builtin_amdgcn_alignbyte(w[j + 1u], w[j], h);
+                m32w[k < nb ? w0 + k : spare >> 2] = out;
+                tailWord = k == nb ? out : tailWord;
+            }
+        }
+        // head: pool bytes 0 .. h - 1 to stream bytes base ..; tail: the first r bytes of tailWord behind the whole words
+#pragma unroll
+        for (uint32_t j = 0; j < 3u; j++) {
+            m32[j < h ? base + j : spare] = (uint8_t)(first >> (8u * j));
+            m32[j < r ? base + h + 4u * nb + j : spare] = (uint8_t)(tailWord >> (8u * j));
+        }
+    }
+}
+
 template <int OWNER>
 __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict__ base32, uint32_t nW, uint32_t sh0,
                                        uint32_t *txt, uint32_t pkWords, const uint16_t *lut2, const unsigned long long *leafCodeG,
                                        uint32_t textStart, uint32_t endBit, uint32_t nM32, uint8_t *m32, uint32_t *dbg,
-                                       const uint32_t warmBits, const int diagLimit = 0)
+                                       const uint32_t warmBits, const int diagLimit = 0, uint32_t *pool = nullptr, uint32_t poolBytes = 0,
+                                       uint32_t spareByte = 0)
 {
     const uint32_t tid = threadIdx.x;
     int32_t status = GF_K_OK;
@@ -783,7 +889,11 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
 #ifdef GF_DIAG
     if (diagLimit == 7) return GF_K_SKIP;                                        // (count table built, text staged)
 #endif
-    fast_sync_pass<OWNER>(S, H, cnt16, txt, sh0, textStart, endBit, unit, Q, warmBits, dbg);
+    // the symbol pool: the share of a subsequence is what the tile's output area gives each of the Q, at most 128 symbols (more
+    // than a 160-bit subsequence of terrain holds three times over); below 64 the two passes below
+    uint32_t poolWords = pool ? min(32u, (poolBytes / Q) >> 2) : 0u;
+    if (poolWords < 16u) poolWords = 0;
+    fast_sync_pass<OWNER>(S, H, cnt16, txt, sh0, textStart, endBit, unit, Q, warmBits, dbg, poolWords ? pool : nullptr, poolWords);
 #ifdef GF_DIAG
     if (diagLimit == 8) return GF_K_SKIP;                                        // (+ synchronisation pass)
     if (dbg && tid == 0) dbg[-7] = (uint32_t)__builtin_amdgcn_s_memtime();      // stamp 4
@@ -791,6 +901,15 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
     (void)dbg;
 #endif
     if (S.chainTotal < nM32) status = GF_K_ERR_BOUNDS;                   // ran out of bits
+    if (poolWords && !S.poolOverflow) {
+        // (fast_sync_pass ended with a barrier: every reader of the LDS text is done, the pool is written)
+        pool_to_m32(S, pool, poolWords, Q, nM32, m32, spareByte);
+        // the last code the stream needs may run past the end of the packing: only the text's very last code can, and it is the
+        // nM32-th exactly when the text holds no more than that
+        if (status == GF_K_OK && S.chainTotal == nM32 && S.qe[Q - 1u] > endBit) status = GF_K_ERR_BOUNDS;
+        __syncthreads();
+        return status;
+    }
     if (tid == 0) S.chainEnd = 0;
     __syncthreads();                                                     // every reader of the LDS text is done
     {
@@ -2454,9 +2573,17 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                                                            sh0, reinterpret_cast<uint32_t *>(ldsDyn), pkWords, lut2,
                                                            reinterpret_cast<const unsigned long long *>(a.trees + t * GF_TREE_REC_WORDS + 8),
 #ifdef GF_DIAG
-                                                           textStart, endBit, nM32, m32, dbg, warmBits, a.phaseLimit & 0xff);
+                                                           textStart, endBit, nM32, m32, dbg, warmBits, a.phaseLimit & 0xff,
 #else
-                                                           textStart, endBit, nM32, m32, dbg, warmBits);
+                                                           textStart, endBit, nM32, m32, dbg, warmBits, 0,
+#endif
+                                                           // the symbol pool of the single-decode form: the tile's own output area (not
+                                                           // in the one-tile-per-call path, whose output lies in host memory); the spare
+                                                           // byte: in the second-level table's area behind the stream, dead by then
+#ifdef GF_DEC_NO_POOL                                      // (experiment builds: tools/ab.sh)
+                                                           nullptr, 0u, 0u);
+#else
+                                                           a.lean ? nullptr : o, nCells * 4u, a.ldsM32Bytes + 4u);
 #endif
                 } else if (pkWords * 4u <= a.ldsTextBytes) {
                     // stage the packing in LDS: one coalesced pass, then every symbol waits on LDS only
