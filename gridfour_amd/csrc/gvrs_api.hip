@@ -446,6 +446,9 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
             const size_t cells = (size_t)nRows * (size_t)nCols;
             const size_t roomy = std::min<size_t>(98304, (2 * cells + 1024 + 31) & ~(size_t)31);
             a.ldsM32Roomy = roomy > a.ldsM32Bytes ? (uint32_t)roomy : 0u;
+#ifdef GF_DEC_NO_ROOMY                                              // (experiment builds)
+            a.ldsM32Roomy = 0u;
+#endif
         }
         // Occupancy is set by LDS (M32 stream + start bitmap + tables per workgroup), handed out in 1,280-byte steps, and the kernel
         // gains from every wave a CU can hold (tools/occupancy_sweep.sh).  Two builds of the same source: 256 threads (two Huffman

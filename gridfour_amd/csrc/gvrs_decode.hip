@@ -654,11 +654,12 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *c
             // stored a word at a time
             // (the word being filled is stored after EVERY step, complete or not -- a later store of the same word only adds bytes --
             // so there is no "word full?" branch and no epilogue; word-major addresses: the lanes of a wave are at about the same
-            // word, their stores fall into a line or two)
+            // word, their stores fall into a line or two; a cursor that has filled its share, or overrun it, stores to the
+            // dump row behind the pool: an idle step of a cursor with exactly 4 poolWords symbols must not touch its last word)
             uint32_t lo[NCUR];
 #pragma unroll
             for (int i = 0; i < NCUR; i++) lo[i] = 0;
-            const uint32_t lastWord = poolWords - 1u;
+            const uint32_t dumpRow = poolWords;
             while (anyBefore(limA)) {
                 uint32_t x[NCUR], e[NCUR], anyLong = 0;
 #pragma unroll
@@ -685,7 +686,7 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *c
                     const uint32_t syms = live ? (two ? e[i] & 0xffffu : e[i] & 0xffu) : 0u;
                     const uint32_t at = cnt[i] & 3u;
                     lo[i] |= syms << (8u * at);                                 // (a second byte behind byte 3 drops out: it opens the next word)
-                    if (d[i]) pool[min(cnt[i] >> 2, lastWord) * Q + qv[i]] = lo[i];
+                    if (d[i]) pool[min(cnt[i] >> 2, dumpRow) * Q + qv[i]] = lo[i];
                     lo[i] = at + k >= 4u ? (at == 3u ? syms >> 8 : 0u) : lo[i];
                     cnt[i] += k;
                     a[i] += live ? (two ? t2 : a1) : 0u;
@@ -694,7 +695,7 @@ __device__ void fast_sync_pass(DecShared &S, const FastHuff H, const uint16_t *c
 #pragma unroll
             for (int i = 0; i < NCUR; i++) {
                 // (the word a second byte may have opened in the very last step)
-                if (d[i] && (cnt[i] & 3u)) pool[min(cnt[i] >> 2, lastWord) * Q + qv[i]] = lo[i];
+                if (d[i] && (cnt[i] & 3u)) pool[min(cnt[i] >> 2, dumpRow) * Q + qv[i]] = lo[i];
                 if (d[i] && cnt[i] > 4u * poolWords) S.poolOverflow = 1u;
             }
         }
@@ -891,8 +892,9 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
 #endif
     // the symbol pool: the share of a subsequence is what the tile's output area gives each of the Q, at most 128 symbols (more
     // than a 160-bit subsequence of terrain holds three times over); below 64 the two passes below
-    uint32_t poolWords = pool ? min(32u, (poolBytes / Q) >> 2) : 0u;
-    if (poolWords < 16u) poolWords = 0;
+    // (one row of the area is the dump row of fast_sync_pass)
+    uint32_t poolWords = pool ? min(33u, (poolBytes / Q) >> 2) : 0u;
+    poolWords = poolWords < 17u ? 0u : poolWords - 1u;
     fast_sync_pass<OWNER>(S, H, cnt16, txt, sh0, textStart, endBit, unit, Q, warmBits, dbg, poolWords ? pool : nullptr, poolWords);
 #ifdef GF_DIAG
     if (diagLimit == 8) return GF_K_SKIP;                                        // (+ synchronisation pass)
@@ -901,7 +903,11 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
     (void)dbg;
 #endif
     if (S.chainTotal < nM32) status = GF_K_ERR_BOUNDS;                   // ran out of bits
+#ifdef GF_DEC_POOL_FORCE_OVERFLOW                                        // (experiment builds: the fall-back behind a pool that overflowed)
+    if (false) {
+#else
     if (poolWords && !S.poolOverflow) {
+#endif
         // (fast_sync_pass ended with a barrier: every reader of the LDS text is done, the pool is written)
         pool_to_m32(S, pool, poolWords, Q, nM32, m32, spareByte);
         // the last code the stream needs may run past the end of the packing: only the text's very last code can, and it is the

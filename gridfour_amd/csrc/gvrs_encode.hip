@@ -139,6 +139,24 @@ __device__ __forceinline__ void wave_huff_rounds(Tree &T, uint32_t (&K)[4], int 
 #define GF_STAMP(i) do { } while (0)
 #endif
 
+// The continuation bytes of a wide M32 value (CodecM32.java:283-311) without the general form's loop and switch for the lengths
+// terrain has: two bytes -- |x| - 127 as one byte --, three -- |x| - 255 as two 7-bit groups.  Returns the byte count n; b1 / b2 are
+// set for n <= 3, longer values go through gf_m32_byte.
+__device__ __forceinline__ uint32_t m32_wide_bytes(uint32_t x, uint32_t *b1, uint32_t *b2)
+{
+    const uint32_t mag = (int32_t)x < 0 ? 0u - x : x;
+    if (mag <= 254u) { *b1 = mag - 127u; *b2 = 0; return 2u; }
+    if (mag <= 16638u) {
+        const uint32_t d = mag - 255u;
+        *b1 = 0x80u | (d >> 7);
+        *b2 = d & 0x7fu;
+        return 3u;
+    }
+    *b1 = 0;
+    *b2 = 0;
+    return (uint32_t)gf_m32_len(x);
+}
+
 // stream elements [sBegin, sEnd) of `model`, any residual size: the general (slow) packer
 // (The packers are real calls: the pack state travels by value and comes back as the result -- a reference parameter of
 // a function that is not inlined is a stack object, i.e. scratch memory.)
@@ -369,8 +387,13 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
                 for (int j = 0; j < CPT; j++) {
                     if ((multi >> j) & 1u) {
                         const uint32_t x = xs[PLAIN ? 0 : j];
-                        const int n = gf_m32_len(x);
-                        for (int k = 1; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
+                        uint32_t b1, b2;
+                        const uint32_t n = m32_wide_bytes(x, &b1, &b2);
+                        if (n <= 3u) {
+                            myBits += (uint32_t)(tab[b1] >> 56) + (n == 3u ? (uint32_t)(tab[b2] >> 56) : 0u);
+                        } else {
+                            for (uint32_t k = 1; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, (int)n, (int)k)] >> 56);
+                        }
                     }
                 }
             }
@@ -405,10 +428,20 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
                 sink.put(cl[j] & 0x00ffffffffffffffull, (uint32_t)(cl[j] >> 56));
                 if (!PLAIN && ((multi >> j) & 1u)) {
                     const uint32_t x = xs[PLAIN ? 0 : j];
-                    const int n = gf_m32_len(x);
-                    for (int k = 1; k < n; k++) {
-                        const uint64_t e = tab[gf_m32_byte(x, n, k)];
-                        sink.put(e & 0x00ffffffffffffffull, (uint32_t)(e >> 56));
+                    uint32_t b1, b2;
+                    const uint32_t n = m32_wide_bytes(x, &b1, &b2);
+                    if (n <= 3u) {
+                        const uint64_t e1 = tab[b1];
+                        sink.put(e1 & 0x00ffffffffffffffull, (uint32_t)(e1 >> 56));
+                        if (n == 3u) {
+                            const uint64_t e2 = tab[b2];
+                            sink.put(e2 & 0x00ffffffffffffffull, (uint32_t)(e2 >> 56));
+                        }
+                    } else {
+                        for (uint32_t k = 1; k < n; k++) {
+                            const uint64_t e = tab[gf_m32_byte(x, (int)n, (int)k)];
+                            sink.put(e & 0x00ffffffffffffffull, (uint32_t)(e >> 56));
+                        }
                     }
                 }
             }
@@ -549,7 +582,22 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                         atomicAdd(h1 + m32_first_byte(d2, &s2) * HIST_R, 1u);
                         if (triOk) atomicAdd(h2 + m32_first_byte(d3, &s3) * HIST_R, 1u);
                         if (!(s1 && s2 && s3)) {
+                            // the continuation bytes of a wide value (CodecM32.java:283-311).  Two and three bytes -- what terrain has
+                            // -- without a loop: |x| - 127 as one byte, |x| - 255 as two 7-bit groups; longer ones (rare) by the
+                            // general form.  (Round 4: the general form alone, a loop per value around a switch per byte, made phase A
+                            // of the rough batch 3.7 times the plain one.)
                             auto rest = [&](uint32_t *h, uint32_t x) -> uint32_t {
+                                const uint32_t mag = (int32_t)x < 0 ? 0u - x : x;
+                                if (mag <= 254u) {
+                                    atomicAdd(h + (mag - 127u) * HIST_R, 1u);
+                                    return 2u;
+                                }
+                                if (mag <= 16638u) {
+                                    const uint32_t d = mag - 255u;
+                                    atomicAdd(h + (0x80u | (d >> 7)) * HIST_R, 1u);
+                                    atomicAdd(h + (d & 0x7fu) * HIST_R, 1u);
+                                    return 3u;
+                                }
                                 const uint32_t n = (uint32_t)gf_m32_len(x);
                                 for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
                                 return n;

@@ -108,3 +108,67 @@ def test_encode_then_decode_of_gentle_batches(codec):
             assert packs[t] == ref and preds[t] == used, t
         vals, st = codec.decode_batch(n_rows, n_cols, packs)
         assert (st == 0).all() and np.array_equal(vals, tiles)
+
+
+@pytest.mark.parametrize("shape", [(120, 150), (200, 200), (40, 50)], ids=lambda s: "%dx%d" % s)
+def test_streams_between_one_and_two_bytes_per_cell(codec, shape):
+    """Tiles whose M32 stream outgrows the fast kernel's usual LDS buffer (1.125 bytes per cell) but not its second run's
+    (two bytes per cell): half of the residuals need two or three M32 bytes.  They share the batch with tiles that fit and with
+    tiles that need the general kernel's workspace (three bytes per value)."""
+    import struct
+    n_rows, n_cols = shape
+    rng = np.random.default_rng(n_rows * 7 + n_cols)
+    tiles = [rng.integers(-200, 201, n_rows * n_cols).astype(np.int32),          # ~1.5 bytes per value
+             rng.integers(-90, 91, n_rows * n_cols).astype(np.int32),            # ~1.2
+             gentle_tiles(n_rows, n_cols, 4)[0],                                 # 1.0: the byte path
+             rng.integers(-20000, 20001, n_rows * n_cols).astype(np.int32),      # 3 and more: the general kernel
+             (rng.integers(-200, 201, n_rows * n_cols).cumsum() % 5000).astype(np.int32)]
+    packs = []
+    for v in tiles:
+        ref, _ = oracle.codec_huffman_encode(0, n_rows, n_cols, v)
+        packs.append(ref)
+    ratios = [struct.unpack("<I", p[6:10])[0] / (n_rows * n_cols) for p in packs]
+    assert 1.125 < ratios[0] < 2.0 and ratios[3] > 2.0, ratios
+    vals, st = codec.decode_batch(n_rows, n_cols, packs)
+    assert (st == 0).all(), st
+    assert np.array_equal(vals, np.stack(tiles))
+    got, preds, status = codec.encode_batch(0, n_rows, n_cols, np.stack(tiles))
+    assert list(got) == packs
+
+
+@pytest.mark.parametrize("shape", [(120, 150), (200, 200), (256, 256), (400, 400), (90, 1000)], ids=lambda s: "%dx%d" % s)
+def test_subsequences_that_fill_their_share_of_the_symbol_pool(codec, shape):
+    """One-bit and two-bit codes: a 128-bit subsequence of the Huffman text holds exactly 128 symbols, which is exactly the share
+    of the symbol pool a subsequence has (gvrs_decode.hip: fast_sync_pass); at 160 bits and more it overruns the share and the
+    tile takes the two-pass form."""
+    n_rows, n_cols = shape
+    rng = np.random.default_rng(n_rows * 11 + n_cols)
+    tiles = []
+    for n_sym in (2, 3, 4):
+        steps = rng.integers(0, n_sym, (n_rows, n_cols))
+        steps[:, 0] = 0
+        tiles.append(steps.cumsum(axis=1).astype(np.int32).ravel())
+    packs = [oracle.codec_huffman_encode(0, n_rows, n_cols, v)[0] for v in tiles]
+    vals, st = codec.decode_batch(n_rows, n_cols, packs)
+    assert (st == 0).all(), st
+    for t, v in enumerate(tiles):
+        bad = np.nonzero(vals[t] != v)[0]
+        assert bad.size == 0, (t, bad.size, int(bad[0]))
+
+
+def test_saved_soak_case_full_share_in_the_second_run(codec):
+    """tools/soak.py, seed 40041003 case 1023 (228 x 276, six tiles): tile 2 (DifferencingWithNulls, 1.5 M32 bytes per cell) is
+    decoded by the fast kernel's second run, and one subsequence of its text holds exactly as many symbols as its share of the
+    pool while its neighbours in the wave are still decoding (the first form of the pool let the idle steps of such a cursor
+    clear the last word of its share)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak", "soak_40041003_case1023.npz"))
+    tiles, n_rows, n_cols = d["tiles"], int(d["shape"][0]), int(d["shape"][1])
+    packs = [oracle.codec_huffman_encode(0, n_rows, n_cols, v)[0] for v in tiles]
+    got, _, status = codec.encode_batch(0, n_rows, n_cols, tiles)
+    assert (np.asarray(status) == 0).all() and list(got) == packs
+    vals, st = codec.decode_batch(n_rows, n_cols, packs)
+    assert (st == 0).all(), st
+    assert np.array_equal(vals, tiles)
+    for t, p in enumerate(packs):
+        assert np.array_equal(codec.decode(n_rows, n_cols, p), tiles[t]), t

@@ -19,7 +19,7 @@ def main():
     ctx = gridfour_amd.GvrsHipContext(0)
     cells = n_rows * n_cols
     b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * cells + 1024 + 15) // 16 * 16)
-    b.synth_dem(0x9E3779B97F4A7C15 + 2, 144)
+    b.synth_dem(0x9E3779B97F4A7C15 + 2, 144, style=int(os.environ.get("GF_DEM_STYLE", "0")))
     L = lib()
     L.gf_internal_encode_debug_words.restype = C.c_size_t
     L.gf_internal_set_encode_debug.argtypes = [C.c_void_p]
