@@ -468,6 +468,9 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
 #ifdef GF_DEC_LDS_PAD_ENV
         if (const char *e = getenv("GF_DEC_FORCE_THREADS")) threads = atoi(e);   // experiment builds only (tools/occupancy_sweep.sh)
 #endif
+        // one tile per call: the workgroup is alone on the chip and every phase is a latency chain -- the widest build (120x150:
+        // 89 -> 82 us per call against the 512-thread build, 111 with 256 threads)
+        if (a.lean) threads = 1024;
         if (threads == 1024) GF_HIP(gf_launch_huffman_decode_t1024(a, stream ? (hipStream_t)stream : c->stream, grid));
         else if (threads == 512) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
         else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));

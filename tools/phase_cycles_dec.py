@@ -14,7 +14,7 @@ from gridfour_amd import DeviceBuffer, DeviceTileBatch, lib  # noqa: E402
 
 
 def main():
-    nt = 12960
+    nt = int(os.environ.get("GF_NT", "12960"))                   # GF_NT=1: a workgroup alone on the chip (the one-tile call)
     n_rows, n_cols = 120, 150
     ctx = gridfour_amd.GvrsHipContext(0)
     cells = n_rows * n_cols
