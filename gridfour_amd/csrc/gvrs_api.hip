@@ -398,10 +398,11 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
             gf_status s = c->trees.ensure(need);
             if (s != GF_OK) return s;
         }
-        GF_HIP(gf_launch_huffman_parse_trees(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
-                                             stream ? (hipStream_t)stream : c->stream));
-        a.trees = (const uint32_t *)c->trees.p;
         if (!analysis) a.retryFlag = (uint32_t *)c->flags.p;
+        GF_HIP(gf_launch_huffman_parse_trees(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
+                                             stream ? (hipStream_t)stream : c->stream, a.retryFlag));
+        a.trees = (const uint32_t *)c->trees.p;
+        a.flagsCleared = a.retryFlag ? 1 : 0;
     }
     if (kind == KIND_CANON) {
         // the same for the canonical decoder's code lengths

@@ -2398,7 +2398,9 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
     }
 
     GF_FOR_TILES(t, a.nTiles, MODE == DEC_FAST) {                     // the fast kernel: one tile per workgroup, no loop (it never
-                                                                      // touches the per-workgroup workspace)
+                                                                      // touches the per-workgroup workspace; a second run that walks
+                                                                      // the tiles with a small grid was measured in round 4: the
+                                                                      // loop costs the first run 5 % at 120x150 and 25 % at 200x200)
         if constexpr (MODE == DEC_GENERAL) {
             if (a.retryFlag && a.status[t] != GF_K_RETRY) continue;
         }
@@ -2847,33 +2849,85 @@ template <unsigned perWave>                                 // lanes of a wave t
 __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__restrict__ blob, size_t blobBytes,
                                                             const uint64_t *__restrict__ offsets, size_t slotStride,
                                                             const uint32_t *__restrict__ lengths, uint32_t *__restrict__ trees,
-                                                            size_t nTiles)
+                                                            size_t nTiles, uint32_t *__restrict__ clearFlags)
 {
-    if (perWave != 1u && threadIdx.x >= perWave) return;
+    static_assert(perWave == 1u || perWave == 64u, "a wave walks one tree or sixty-four");
+    const uint32_t lane = threadIdx.x;
+    // the decode kernels' two retry words (GfDecodeArgs::retryFlag), cleared here instead of by a launch of their own
+    if (clearFlags && blockIdx.x == 0 && lane < 2u) clearFlags[lane] = 0u;
     const size_t t = perWave == 1u ? (size_t)blockIdx.x : (size_t)blockIdx.x * perWave + threadIdx.x;
-    if (t >= nTiles) return;
-    const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
-    const uint32_t len = lengths[t];
-    uint32_t *rec = trees + t * GF_TREE_REC_WORDS;
-    // A wave per tile (small batches, one tile per call): the walk below is one lane's, and every refill of its bit buffer used to
-    // be a load of its own from global memory -- some thirty dependent round trips, 30 us for the one tile of a call (round 4).
-    // The wave's 64 lanes fetch the words the walk can ask for (the packing's bytes 10 .. 521) at once; the walk reads lanes.
+    const bool inBatch = t < nTiles;                          // (the last wave's spare lanes help with the staging below)
+    const uint64_t off = !inBatch ? 0ull : offsets ? offsets[t] : (uint64_t)t * slotStride;
+    const uint32_t len = inBatch ? lengths[t] : 0u;
+    const bool readable = inBatch && len >= 10 && off + len <= blobBytes;
+    uint32_t *rec = trees + (inBatch ? t : 0) * GF_TREE_REC_WORDS;
+    // The words a walk can ask for -- bytes 10 .. of the packing, zero from its end and from the end of the head (HEAD_WORDS) on --
+    // are fetched before the walk, all loads in flight at once.  A wave per tile (small batches, one tile per call; round 4): the 64
+    // lanes fetch the tile's words, the walk reads lanes (every refill of its bit buffer used to be a load of its own, some thirty
+    // dependent round trips, 30 us for the one tile of a call).  Sixty-four tiles per wave: the wave fetches tile after tile, a
+    // lane a word (coalesced), into a table in LDS that the lanes then read down their own column.
+    constexpr uint32_t STAGE_WORDS = (HEAD_WORDS * 4 - 10 + 3) / 4;             // 86
+    __shared__ uint32_t stage[perWave == 64u ? (STAGE_WORDS + 1) * 64 : 1];
+    // word k of a packing at pk0 with `vis` visible bytes: never a byte beyond them is touched (the load is moved back to end with
+    // the last visible byte and its bytes are shifted into place)
+    // (in three steps, so that the loads of a turn are all in flight together: where to read -- a word that is not visible is read at
+    // byte 0 of the packing and dropped --, the loads, the bytes into place.  The compiler moves a load whose value is used under
+    // a condition into a branch of its own and waits for it there: the empty asm below uses the loaded words unconditionally.)
+    auto staged_at = [](uint32_t vis, uint32_t k) -> uint32_t {
+        const uint32_t i = 10u + 4u * k;
+        return i < vis ? min(i, vis - 4u) : 0u;               // vis >= 10
+    };
+    auto staged_fix = [](uint32_t w, uint32_t vis, uint32_t k) -> uint32_t {
+        const uint32_t i = 10u + 4u * k;
+        return i < vis ? w >> (8u * (i - min(i, vis - 4u))) : 0u;           // (a shift of three bytes at most)
+    };
     uint32_t stage0 = 0, stage1 = 0;
+    if (blobBytes < 10) {                                    // no packing fits (and the staging below reads the blob's first bytes)
+        if (inBatch && (perWave == 64u || lane == 0u)) rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
+        return;
+    }
     if (perWave == 1u) {
-        if (len >= 10 && off + len <= blobBytes) {
-            const uint8_t *__restrict__ pk0 = blob + off;
+        if (readable) {
             const uint32_t vis = min(len, (uint32_t)(HEAD_WORDS * 4));
-            auto word = [&](uint32_t i) -> uint32_t {
-                if (i + 4u <= vis) return reinterpret_cast<const PackedWord *>(pk0 + i)->v;
-                uint32_t w = 0;
-                for (uint32_t k = 0; k < 4; k++)
-                    if (i + k < vis) w |= (uint32_t)pk0[i + k] << (8u * k);
-                return w;
-            };
-            stage0 = word(10u + 4u * threadIdx.x);
-            stage1 = word(10u + 256u + 4u * threadIdx.x);
+            const uint8_t *__restrict__ pk0 = blob + off;
+            stage0 = reinterpret_cast<const PackedWord *>(pk0 + staged_at(vis, lane))->v;
+            stage1 = reinterpret_cast<const PackedWord *>(pk0 + staged_at(vis, 64u + lane))->v;
+            asm volatile("" : "+v"(stage0), "+v"(stage1));
+            stage0 = staged_fix(stage0, vis, lane);
+            stage1 = staged_fix(stage1, vis, 64u + lane);
         }
-        if (threadIdx.x >= 1u) return;
+        if (lane >= 1u) return;
+    } else {
+        const uint32_t visMine = readable ? min(len, (uint32_t)(HEAD_WORDS * 4)) : 0u;
+        // (thirty-two tiles a turn: sixty-four loads in flight, then their stores -- a turn per tile waited for every load on its own)
+        constexpr uint32_t TURN = 32;
+        for (uint32_t j0 = 0; j0 < 64u; j0 += TURN) {
+            uint32_t w0[TURN], w1[TURN], visJ[TURN];
+#pragma unroll
+            for (uint32_t u = 0; u < TURN; u++) {
+                const uint32_t j = j0 + u;
+                const uint32_t vis = (uint32_t)__builtin_amdgcn_readlane((int)visMine, (int)j);
+                const uint64_t offJ = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)j) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)j);
+                const uint8_t *__restrict__ pkJ = blob + (vis ? offJ : 0ull);      // (a tile that cannot be read: the blob's first bytes, dropped)
+                visJ[u] = vis;
+                w0[u] = reinterpret_cast<const PackedWord *>(pkJ + staged_at(vis, lane))->v;
+                w1[u] = reinterpret_cast<const PackedWord *>(pkJ + staged_at(vis, 64u + lane))->v;   // (words 86 .. 127: beyond the head)
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < TURN; u += 8u)
+                asm volatile("" : "+v"(w0[u]), "+v"(w0[u + 1]), "+v"(w0[u + 2]), "+v"(w0[u + 3]), "+v"(w0[u + 4]), "+v"(w0[u + 5]),
+                                  "+v"(w0[u + 6]), "+v"(w0[u + 7]), "+v"(w1[u]), "+v"(w1[u + 1]), "+v"(w1[u + 2]), "+v"(w1[u + 3]),
+                                  "+v"(w1[u + 4]), "+v"(w1[u + 5]), "+v"(w1[u + 6]), "+v"(w1[u + 7]));
+#pragma unroll
+            for (uint32_t u = 0; u < TURN; u++) {
+                stage[lane * 64u + j0 + u] = staged_fix(w0[u], visJ[u], lane);
+                if (lane < STAGE_WORDS - 64u) stage[(64u + lane) * 64u + j0 + u] = staged_fix(w1[u], visJ[u], 64u + lane);
+            }
+        }
+        stage[STAGE_WORDS * 64u + lane] = 0u;                  // the row of zeros behind the head
+        __syncthreads();
+        if (!inBatch) return;
     }
     unsigned long long *codes = reinterpret_cast<unsigned long long *>(rec + 8);
     uint8_t *lens = reinterpret_cast<uint8_t *>(rec + 8 + 512), *syms = lens + 256;
@@ -2884,8 +2938,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     const uint8_t *__restrict__ pk = blob + off;
     // the walk sees what parse_tree_wave sees: the packing's bytes, zero beyond its end and beyond the staged head
     const uint32_t visible = min(len, (uint32_t)(HEAD_WORDS * 4));
-    // (staging a tile's serialised tree in LDS first -- all loads in flight, the walk reading from there -- was tried in rounds
-    // 2 and 3 and changes nothing: 0.08 ms either way, the walk is bound by its dependent instruction chain at one wave per CU)
+    // (the exact walk, for the trees the fast one below turns down, reads the packing itself)
     auto ld32 = [&](uint32_t i) -> uint32_t {                // bytes i .. i+3 of the packing, little-endian
         if (perWave == 1u) {                                 // (i = 10 + 4 k: the staged word k)
             const uint32_t k = (i - 10u) >> 2;
@@ -2902,7 +2955,15 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             if (i + k < visible) w |= (uint32_t)pk[i + k] << (8u * k);
         return w;
     };
-    uint64_t buf = ((uint64_t)ld32(14) << 32) | ld32(10);    // packing bit 80 = byte 10
+    auto fetch = [&](uint32_t k) -> uint32_t {               // staged word k = ld32(10 + 4 k)
+        if (perWave == 1u) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)stage0, (int)(k & 63u));
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)stage1, (int)(k & 63u));
+            return k < 64u ? lo : (k < 128u ? hi : 0u);
+        }
+        return stage[min(k, STAGE_WORDS) * 64u + lane];
+    };
+    uint64_t buf = ((uint64_t)fetch(1) << 32) | fetch(0);    // packing bit 80 = byte 10
     uint32_t have = 64, next = 18, bp = 80;
     auto refill = [&]() {
         if (have <= 32) {
@@ -2931,7 +2992,72 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     auto kindOf = [](uint32_t sym) -> uint32_t {
         return (sym == 0x7fu || sym == 0x81u) ? GF_TREE_HAS_INTRODUCER : sym == 0x80u ? GF_TREE_HAS_NULL : 0u;
     };
-    if (rootBit == 1) {
+    // The walk of a WELL-FORMED tree first (round 4): the steps of the exact walk below with nothing in them that only a damaged
+    // packing needs (no record counts, one depth test), written without a branch -- a turn takes the run of branch records at the
+    // cursor and the leaf behind it, both under predicates; the next word of the packing comes from the staged table a turn before
+    // it is used; the loop ends when no lane of the wave has a leaf left.  About 95 instructions per leaf against 185 of the exact
+    // form (the pre-pass is one wave per SIMD and bound by exactly that chain): 0.090 -> 0.049 ms per 12,960 tiles.  It accepts a tree
+    // only if its last leaf closes it and none before does; anything else (a tree that closes early, stays open, grows deeper than
+    // a code register) is walked again by the exact form, which owns every status and the incomplete-tree record.
+    bool walked = false;
+    {
+        uint64_t fbuf = buf, c = 0;
+        uint32_t fhave = have, nextW = (next - 10u) >> 2, fbp = bp, L = 1, leaves = 0, fmax = 1, fkinds = 0;
+        uint32_t pre = fetch(nextW);
+        const uint32_t depthCap = min(nLeaves, (uint32_t)MAX_DEPTH);
+        bool closed = false, bad = rootBit != 0u;
+        for (;;) {
+            const bool live = leaves < nLeaves && !bad && !closed;
+            if (!__any(live)) break;
+            const bool top = fhave <= 32u;
+            fbuf |= top ? (uint64_t)pre << (fhave & 63u) : 0ull;
+            fhave += top ? 32u : 0u;
+            nextW += top ? 1u : 0u;
+            pre = fetch(nextW);
+            uint32_t z = fbuf ? (uint32_t)__builtin_ctzll(fbuf) : 64u;
+            z = live ? min(min(z, fhave), 63u) : 0u;           // (a run of 64 goes on in the next turn)
+            c <<= z;
+            L += z;
+            fbuf >>= z;
+            fhave -= z;
+            fbp += z;
+            bad = bad || L - 1u > depthCap;
+            // the leaf behind the run, if its nine bits are in the buffer (else the next turn tops it up and finds a run of none)
+            const bool leaf = live && !bad && fhave >= 9u && ((uint32_t)fbuf & 1u) != 0u;
+            const uint32_t sym = ((uint32_t)fbuf >> 1) & 0xffu;
+            if (leaf) {
+                codes[leaves] = __brevll(c) >> (64u - L);
+                lens[leaves] = (uint8_t)L;
+                syms[leaves] = (uint8_t)sym;
+            }
+            const uint32_t adv = leaf ? 9u : 0u;
+            fbuf >>= adv;
+            fhave -= adv;
+            fbp += adv;
+            const uint32_t kd = sym - 0x7fu;                   // 0x7f, 0x81: an introducer; 0x80: the null code
+            fkinds |= (leaf && kd < 3u) ? ((kd & 1u) ? GF_TREE_HAS_NULL : GF_TREE_HAS_INTRODUCER) : 0u;
+            fmax = leaf ? max(fmax, L) : fmax;
+            leaves += leaf ? 1u : 0u;
+            const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;      // trailing ones
+            const bool closes = leaf && t1 >= L;
+            closed = closed || closes;
+            const bool up = leaf && !closes;
+            c = up ? (c >> (t1 & 63u)) | 1ull : c;
+            L -= up ? t1 : 0u;
+        }
+#ifdef GF_PT_FORCE_EXACT                                            // (test builds: every tree through the exact walk)
+        if (false) {
+#else
+        if (!bad && closed && leaves == nLeaves) {
+#endif
+            walked = true;
+            bp = fbp;
+            maxLen = fmax;
+            symKinds = fkinds;
+        }
+    }
+    if (walked) {
+    } else if (rootBit == 1) {
         uniformSym = (int32_t)take(8);
         symKinds = kindOf((uint32_t)uniformSym);
     } else {
@@ -3068,7 +3194,7 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
             hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
             return hipGetLastError();
         }
-        if ((e = hipMemsetAsync(a.retryFlag, 0, 8, stream)) != hipSuccess) return e;
+        if (!a.flagsCleared && (e = hipMemsetAsync(a.retryFlag, 0, 8, stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
         if (a.ldsM32Roomy) {
             // the tiles that outgrew their LDS once more, with room (the workgroups of the others leave at once)
@@ -3094,15 +3220,15 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
 }
 
 hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
-                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream)
+                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream, uint32_t *clearFlags)
 {
     if (nTiles == 0) return hipSuccess;
     if (gf_prepass_tiles_per_wave(nTiles) == 1u)
         hipLaunchKernelGGL(k_huffman_parse_trees<1>, dim3((unsigned)nTiles), dim3(64), 0, stream, blob, blobBytes, offsets, slotStride,
-                           lengths, trees, nTiles);
+                           lengths, trees, nTiles, clearFlags);
     else
         hipLaunchKernelGGL(k_huffman_parse_trees<64>, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
-                           slotStride, lengths, trees, nTiles);
+                           slotStride, lengths, trees, nTiles, clearFlags);
     return hipGetLastError();
 }
 #endif  // GF_DEC_VARIANT

@@ -120,6 +120,7 @@ struct GfDecodeArgs {
                                // packing outgrows ldsM32Bytes (dense in multi-byte values) get a workgroup with more LDS
                                // instead of the general kernel and its workspace in global memory
     int retryPass;             // set by the launcher: 1 in the fast kernel's second run
+    int flagsCleared;          // 1: the tree pre-pass zeroed retryFlag (gf_launch_huffman_parse_trees), no memset in front of the kernels
     int lean;                  // 1 (the one-tile-per-call path): the fast kernel alone; what it leaves behind keeps the status
                                // GF_K_LEAN_RETRY and the caller takes the batch path for it
     uint32_t *analysis;        // non-null: CodecHuffman.analyze mode -- per tile GF_ANALYSIS_WORDS words (predictor, nM32,
@@ -133,7 +134,8 @@ constexpr int GF_PAIR_TABLES = 5;               // one 65536-bin table of byte p
 // single-symbol value or -1, 3 spare), then 256 x (path bits uint64), 256 x code length, 256 x symbol
 constexpr int GF_TREE_REC_WORDS = 8 + 512 + 64 + 64;
 hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
-                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream);
+                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream,
+                                         uint32_t *clearFlags = nullptr);     // clearFlags: GfDecodeArgs::retryFlag, zeroed by the pre-pass
 
 // LSOP12 containers whose entropy stage is CodecM32 bytes: type 0 (legacy Huffman of the two M32 streams) and, with
 // rawM32 = 1, type 1 after the host inflated it (gvrs_decode.hip: k_lsop_unpack_m32)
