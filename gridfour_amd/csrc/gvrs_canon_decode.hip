@@ -172,12 +172,58 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
         __threadfence_block();
     }
     const size_t t = t0 + lane;
-    if (lane >= perWave || t >= nTiles) return;
-    const uint64_t off = offsets ? offsets[t] : (uint64_t)t * slotStride;
-    const uint32_t len = lengths[t];
+    const bool inBatch = lane < perWave && t < nTiles;
+    const uint64_t off = !inBatch ? 0ull : offsets ? offsets[t] : (uint64_t)t * slotStride;
+    const uint32_t len = inBatch ? lengths[t] : 0u;
+    const bool readable = inBatch && len >= 7 && off + len <= blobBytes;
+    // Sixty-four tiles per wave (round 4, as k_huffman_parse_trees): the head of every packing -- the code lengths are its first few
+    // hundred bytes -- goes to LDS first, the wave fetching tile after tile, a lane a word (coalesced, 32 tiles' loads in flight at
+    // once), and a lane's walk reads down its own column: a peek was a dependent load from global memory per token, inside a
+    // branch the compiler waits in (0.143 ms per 12,960 tiles).  A walk that leaves the staged head reads the packing itself.
+    constexpr uint32_t STAGE_WORDS = 128;                    // 512 bytes
+    __shared__ uint32_t stage[perWave == 64u ? STAGE_WORDS * 64 : 1];
+    if (perWave == 64u) {
+        const uint32_t visMine = readable ? min(len, STAGE_WORDS * 4u) : 0u;
+        // word k = bytes 4k .. 4k+3 of the packing, zero from its end on; never a byte beyond the packing is touched (the load is moved
+        // back to end with the last byte and shifted into place; a word that is not visible is read at byte 0 and dropped; the
+        // empty asm keeps the compiler from moving each load into a branch of its own)
+        auto staged_at = [](uint32_t vis, uint32_t k) -> uint32_t { return 4u * k < vis ? min(4u * k, vis - 4u) : 0u; };   // vis >= 7
+        auto staged_fix = [](uint32_t w, uint32_t vis, uint32_t k) -> uint32_t {
+            return 4u * k < vis ? w >> (8u * (4u * k - min(4u * k, vis - 4u))) : 0u;
+        };
+        constexpr uint32_t TURN = 32;
+        if (blobBytes >= 7) {
+            for (uint32_t j0 = 0; j0 < 64u; j0 += TURN) {
+                uint32_t w0[TURN], w1[TURN], visJ[TURN];
+#pragma unroll
+                for (uint32_t u = 0; u < TURN; u++) {
+                    const uint32_t j = j0 + u;
+                    const uint32_t vis = (uint32_t)__builtin_amdgcn_readlane((int)visMine, (int)j);
+                    const uint64_t offJ = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), (int)j) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, (int)j);
+                    const uint8_t *__restrict__ pkJ = blob + (vis ? offJ : 0ull);
+                    visJ[u] = vis;
+                    w0[u] = reinterpret_cast<const CdPackedWord *>(pkJ + staged_at(vis, lane))->v;
+                    w1[u] = reinterpret_cast<const CdPackedWord *>(pkJ + staged_at(vis, 64u + lane))->v;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < TURN; u += 8u)
+                    asm volatile("" : "+v"(w0[u]), "+v"(w0[u + 1]), "+v"(w0[u + 2]), "+v"(w0[u + 3]), "+v"(w0[u + 4]), "+v"(w0[u + 5]),
+                                      "+v"(w0[u + 6]), "+v"(w0[u + 7]), "+v"(w1[u]), "+v"(w1[u + 1]), "+v"(w1[u + 2]), "+v"(w1[u + 3]),
+                                      "+v"(w1[u + 4]), "+v"(w1[u + 5]), "+v"(w1[u + 6]), "+v"(w1[u + 7]));
+#pragma unroll
+                for (uint32_t u = 0; u < TURN; u++) {
+                    stage[lane * 64u + j0 + u] = staged_fix(w0[u], visJ[u], lane);
+                    stage[(64u + lane) * 64u + j0 + u] = staged_fix(w1[u], visJ[u], 64u + lane);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!inBatch) return;
     uint32_t *rec = recs + t * GF_CANON_REC_WORDS;
     uint8_t *outLen = reinterpret_cast<uint8_t *>(rec + 8);
-    if (len < 7 || off + len > blobBytes) {                   // no stream: the decode kernel does not look here
+    if (!readable) {                                          // no stream: the decode kernel does not look here
         rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
         return;
     }
@@ -195,6 +241,10 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
         startBit = hdr * 8u;
     }
     auto peek = [&](uint32_t pos) -> uint32_t {               // 32 bits of the packing from bit pos, zero beyond its end
+        if (perWave == 64u && (pos >> 5) + 1u < STAGE_WORDS) {
+            const uint32_t wi = pos >> 5;
+            return __builtin_amdgcn_alignbit(stage[(wi + 1u) * 64u + lane], stage[wi * 64u + lane], pos & 31u);
+        }
         const uint32_t b = pos >> 3;
         uint64_t w;
         if (b + 8u <= len) {
