@@ -135,8 +135,16 @@ __device__ __forceinline__ void wave_huff_rounds(Tree &T, uint32_t (&K)[4], int 
             (a.debug + t * (size_t)GF_ENC_DEBUG_WORDS + GF_ENC_DEBUG_WORDS - 16)[i] =    \
                 (uint32_t)__builtin_amdgcn_s_memtime();                                   \
     } while (0)
+// (inside phase B a tree is built by the wave of its predictor: the stamp is that wave's, the last one to pass wins)
+#define GF_STAMP_WAVE(i)                                                                  \
+    do {                                                                                  \
+        if (a.debug && lane == 0)                                                         \
+            (a.debug + t * (size_t)GF_ENC_DEBUG_WORDS + GF_ENC_DEBUG_WORDS - 16)[i] =    \
+                (uint32_t)__builtin_amdgcn_s_memtime();                                   \
+    } while (0)
 #else
 #define GF_STAMP(i) do { } while (0)
+#define GF_STAMP_WAVE(i) do { } while (0)
 #endif
 
 // The continuation bytes of a wide M32 value (CodecM32.java:283-311) without the general form's loop and switch for the lengths
@@ -846,7 +854,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                     }
                 }
                 if (lane == 0) T.n = n;
-                GF_STAMP(3);
+                GF_STAMP_WAVE(3);
                 // B2  tree by data-parallel rounds
                 wave_huff_rounds(T, key, n, lane);
             } else if constexpr (!FAST) {
@@ -895,7 +903,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) nM32 += gf_lane_xor(nM32, d);
             __builtin_amdgcn_wave_barrier();
-            GF_STAMP(4);
+            GF_STAMP_WAVE(4);
             // B3  header image, codes, serialised tree, exact bit totals
             uint32_t *img = P.img[p];
             if (lane == 0) {
