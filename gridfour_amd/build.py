@@ -84,6 +84,9 @@ def _compile_all(lib, extra, verbose):
         # ... and the canonical decoder with 512-thread workgroups
         obj = os.path.join(tmp, "gvrs_canon_decode_t512.o")
         jobs.append(([hipcc] + FLAGS + extra + ["-DGF_CD_THREADS=512", "-DGF_CD_VARIANT", "-c", os.path.join(CSRC, "gvrs_canon_decode.hip"), "-o", obj], obj))
+        # ... and the legacy encoder's two usual kernels with 1024-thread workgroups, for the one-tile-per-call path
+        obj = os.path.join(tmp, "gvrs_encode_t1024.o")
+        jobs.append(([hipcc] + FLAGS + extra + ["-DGF_ENC_THREADS=1024", "-DGF_ENC_VARIANT", "-c", os.path.join(CSRC, "gvrs_encode.hip"), "-o", obj], obj))
         # a few compiles at a time: the translation units are independent
         width = max(1, min(4, (os.cpu_count() or 2) // 2))
         running = []

@@ -348,6 +348,8 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
         a.lean = g_lean;
     }
     if (kind == KIND_CANON) GF_HIP(gf_launch_canon_encode(a, stream ? (hipStream_t)stream : c->stream));
+    else if (a.lean && a.retryFlag && 6ull * (size_t)nRows * (size_t)nCols < (1ull << 23))   // one tile per call: the 1024-thread build
+        GF_HIP(gf_launch_huffman_encode_lean_t1024(a, stream ? (hipStream_t)stream : c->stream));
     else GF_HIP(gf_launch_huffman_encode(a, stream ? (hipStream_t)stream : c->stream));
     return GF_OK;
 }

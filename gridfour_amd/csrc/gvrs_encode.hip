@@ -471,7 +471,7 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
 #ifndef GF_ENC_PACK_WGS
 #define GF_ENC_PACK_WGS 8        // sweep: 8 -> 1.137 ms (15 spilled registers: 0.65 GB of scratch traffic), 5 -> 1.208 ms, no spills
 #endif
-constexpr int ENC_AB_WGS = 6, ENC_PACK_WGS = GF_ENC_PACK_WGS;
+constexpr int ENC_AB_WGS = ENC_THREADS == 256 ? 6 : 1, ENC_PACK_WGS = ENC_THREADS == 256 ? GF_ENC_PACK_WGS : 1;
 
 constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel leaves this tile to the general one
 
@@ -1144,6 +1144,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
     huffman_pack_tiles<false>(a, P, win);
 }
 
+#ifndef GF_ENC_VARIANT
 __global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_pack_rare(GfEncodeArgs a)
 {
     __shared__ PackShared P;
@@ -1316,8 +1317,25 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_m32_streams(GfM32Args a)
     }
 }
 
+#endif  // GF_ENC_VARIANT
+
 }  // namespace
 
+#ifdef GF_ENC_VARIANT
+// The one-tile-per-call build (-DGF_ENC_THREADS=1024 -DGF_ENC_VARIANT, round 4): a workgroup alone on the chip is a chain of
+// latencies -- phase A a round trip to memory per turn, the packer likewise --, and sixteen waves take a 120x150 tile in three turns
+// instead of nine (84 -> 76 us per call).  Only the two kernels a tile usually needs; what they leave behind keeps GF_K_RETRY
+// (GfEncodeArgs::lean).
+hipError_t gf_launch_huffman_encode_lean_t1024(const GfEncodeArgs &a, hipStream_t stream)
+{
+    if (a.nTiles == 0) return hipSuccess;
+    const size_t nCells = (size_t)a.nRows * (size_t)a.nCols;
+    if (!a.packRecs || !a.retryFlag || !a.lean || 6ull * nCells >= (1ull << 23)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_huffman_encode<true>, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_huffman_pack, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+#else
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
 {
     if (a.nTiles == 0) return hipSuccess;
@@ -1351,3 +1369,4 @@ hipError_t gf_launch_m32_streams(const GfM32Args &a, hipStream_t stream)
     hipLaunchKernelGGL(k_m32_streams, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
+#endif  // GF_ENC_VARIANT

@@ -4,7 +4,9 @@
 
 #include "huff_build.h"
 
+#ifndef GF_ENC_THREADS                  // (-DGF_ENC_THREADS=1024 -DGF_ENC_VARIANT: the one-tile-per-call build of gvrs_encode.hip)
 #define GF_ENC_THREADS 256
+#endif
 #define GF_ENC_WAVES (GF_ENC_THREADS / 64)
 #define GF_IMG_WORDS 84                 // 80 header bits + 8 + 2559 tree bits -> 83 words
 

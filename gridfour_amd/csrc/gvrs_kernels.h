@@ -166,6 +166,7 @@ struct GfLsopM32Args {
 hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream, unsigned grid);
 
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
+hipError_t gf_launch_huffman_encode_lean_t1024(const GfEncodeArgs &a, hipStream_t stream);   // 1024-thread workgroups, GfEncodeArgs::lean only
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 hipError_t gf_launch_huffman_decode_t512(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);   // 512-thread workgroups
 hipError_t gf_launch_huffman_decode_t1024(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);  // 1024-thread workgroups

@@ -364,3 +364,24 @@ def test_one_tile_per_call_replays(codec):
         with pytest.raises(IOError):
             codec.decode(n_rows, n_cols, bytes(bad))
         assert np.array_equal(codec.decode(n_rows, n_cols, good), tiles[1])
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (9, 8), (16, 16), (40, 50), (64, 253), (17, 300), (120, 150), (200, 200), (256, 256),
+                                   (1100, 8), (7, 129), (300, 400)], ids=lambda s: "%dx%d" % s)
+def test_one_tile_per_call_shapes(codec, shape):
+    """The one-tile call runs builds of its own (1024-thread workgroups: k_huffman_encode / k_huffman_pack of gvrs_encode.hip with
+    sixteen waves, the 1024-thread decoder): tile shapes from 2 x 2 to 300 x 400, every data kind, through the replayed graph
+    (second call of a shape on) against the oracle's bytes."""
+    n_rows, n_cols = shape
+    tiles = [make_tile(k, n_rows, n_cols, seed=11) for k in KINDS]
+    tiles.append(add_nulls(make_tile("smooth", n_rows, n_cols, seed=3), n_rows, n_cols, 0.05))
+    rng = np.random.default_rng(n_rows * 1000 + n_cols)
+    tiles.append(rng.integers(-300, 301, n_rows * n_cols).astype(np.int32))           # two- and three-byte M32 values
+    tiles.append((rng.integers(-2, 3, n_rows * n_cols).cumsum() % 251).astype(np.int32))
+    for rep in range(2):
+        for ci, v in enumerate(tiles):
+            ref, _ = oracle.codec_huffman_encode(ci & 3, n_rows, n_cols, v)
+            got = codec.encode(ci & 3, n_rows, n_cols, v)
+            assert got == ref, (rep, ci)
+            if ref is not None:
+                assert np.array_equal(codec.decode(n_rows, n_cols, got), v), (rep, ci)
