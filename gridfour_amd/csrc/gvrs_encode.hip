@@ -79,8 +79,58 @@ __device__ __forceinline__ uint32_t m32_first_byte(uint32_t x, bool *single)
 // round -- then re-sorts.  tie: leaf = 256 + sorted index, branch k = 254 - k, so that newer
 // branches precede older ones and leaves of equal count (:175-193).  ~15 rounds instead of
 // ~150 dependent merges.  Writes T.parent / T.left / T.nl.  Needs total count < 2^23.
+// A round's P new nodes and the nodes it left, both in ascending order, merged by RANK (round 4): a node that stays moves down by
+// the 2 P places of the pairs and up by the number of new nodes below it, a new node goes behind the old and the new ones below it;
+// every key is written to its place in `scr` (LDS, 64 NR words) and read back in order.  The keys are distinct (count, then a tie
+// field no two nodes share), so this is the permutation a sort of the keys makes.  For a round of at most eight pairs -- ten of the
+// fifteen rounds of a terrain tile's tree -- it is 30 to 130 instructions where the bitonic network over 64 NR keys is 100 to 580.
+// (It buys nothing where the wave that builds the tree is alone with its latencies -- the one-kernel form --, and a third of
+// k_huffman_trees, whose waves are all busy.)
+template <int NR>
+__device__ __forceinline__ void wave_huff_merge_few(uint32_t (&K)[4], uint32_t P, uint32_t Lold, int lane, uint32_t *scr)
+{
+    // the new keys are elements 0, 2, .. 14 (P <= 8): lanes of K[0].  Equal sums make a LATER pair's node the smaller key -- its tie
+    // field counts down --, so a new node counts the new nodes below it as well.
+    uint32_t below[NR], newRank = 0, newBelow = 0;
+    const bool isNew = (uint32_t)lane < 2u * P && !(lane & 1);
+    bool old[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const uint32_t e = (uint32_t)(r * 64 + lane);
+        below[r] = 0;
+        old[r] = e >= 2u * P && e < Lold;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; i++) {
+        if (i < P) {                                               // wave-uniform
+            const uint32_t Ni = (uint32_t)__builtin_amdgcn_readlane((int)K[0], (int)(2u * i));
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                below[r] += (old[r] && Ni < K[r]) ? 1u : 0u;
+                cnt += (uint32_t)__popcll(__ballot(old[r] && K[r] < Ni));
+            }
+            newBelow += (isNew && Ni < K[0]) ? 1u : 0u;
+            newRank = (uint32_t)lane == 2u * i ? cnt : newRank;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const uint32_t e = (uint32_t)(r * 64 + lane);
+        if (old[r]) scr[e - 2u * P + below[r]] = K[r];
+    }
+    if (isNew) scr[newRank + newBelow] = K[0];
+    const uint32_t Lnew = Lold - P;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const uint32_t e = (uint32_t)(r * 64 + lane);
+        K[r] = e < Lnew ? scr[e] : 0xFFFFFFFFu;
+    }
+}
+
+// scr: 256 words of LDS of the wave's own that nothing else needs during the rounds, or null (every round a sort)
 template <class Tree>
-__device__ __forceinline__ void wave_huff_rounds(Tree &T, uint32_t (&K)[4], int n, int lane)
+__device__ __forceinline__ void wave_huff_rounds(Tree &T, uint32_t (&K)[4], int n, int lane, uint32_t *scr = nullptr)
 {
     uint32_t L = (uint32_t)n, kbase = 0;
     const uint32_t un = (uint32_t)n;
@@ -119,7 +169,11 @@ __device__ __forceinline__ void wave_huff_rounds(Tree &T, uint32_t (&K)[4], int 
         kbase += P;
         const uint32_t Lold = L;
         L -= P;
-        if (Lold > 128) wave_bitonic_sort<4>(K, lane);
+        if (scr && P <= 8u) {
+            if (Lold > 128) wave_huff_merge_few<4>(K, P, Lold, lane, scr);
+            else if (Lold > 64) wave_huff_merge_few<2>(K, P, Lold, lane, scr);
+            else wave_huff_merge_few<1>(K, P, Lold, lane, scr);
+        } else if (Lold > 128) wave_bitonic_sort<4>(K, lane);
         else if (Lold > 64) wave_bitonic_sort<2>(K, lane);
         else wave_bitonic_sort<1>(K, lane);
     }
@@ -480,11 +534,31 @@ constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel lea
 // a second histogram pass) is marked GF_K_RETRY and left to the general instantiation, which with a.retryFlag touches only
 // marked tiles and returns at once when there are none.  The general body is twice the size of the fast one and carries the
 // register pressure of the rare paths into every tile's allocation.
-template <bool FAST>
-__global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
+// PART 0: phases A and B and the selection in one kernel (the general kernel, the one-tile-per-call build, the diagnostic flavour).
+// PART 1 (round 4, CodecHuffman batches): phase A alone -- the histograms and what else the trees need go to GfEncodeArgs::encStats,
+// and k_huffman_trees takes it from there with ONE WAVE PER TILE.  In the one-kernel form the tree of a tile is built by one wave
+// (sort, tree rounds, codes: a chain of dependent steps, 42 % of a tile's time) while the workgroup's other three hold their wave
+// slots idle: a CU had fewer than three such chains in flight; the tree kernel keeps seventeen.
+// (what phase A keeps of EncPersist: the part-1 kernel carries no code tables and no tree images -- 12.4 instead of 19.6 KB of LDS
+// per workgroup, eight workgroups = all 32 wave slots of a CU)
+struct EncPersistA {
+    uint32_t maxN[3];
+    uint32_t nM32[3];
+    int32_t model[3];
+    uint32_t seed;
+    uint32_t flags;
+    unsigned long long sumStart;
+    uint32_t nStart;
+};
+union EncScratchA {
+    uint32_t histR[3][256 * HIST_R];
+};
+
+template <bool FAST, int PART = 0>
+__global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
-    __shared__ EncPersist P;
-    __shared__ EncScratchT<FAST> S;
+    __shared__ std::conditional_t<PART == 1, EncPersistA, EncPersist> P;
+    __shared__ std::conditional_t<PART == 1, EncScratchA, EncScratchT<FAST>> S;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
@@ -639,6 +713,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 a.lengths[t] = 0;
                 a.status[t] = GF_K_DECLINED;
                 if (a.predictors) a.predictors[t] = 0;
+                if (PART == 1) (a.encStats + t * (size_t)GF_ENC_STAT_WORDS)[7] = 0u;     // nothing for k_huffman_trees
             }
             __syncthreads();
             continue;
@@ -648,6 +723,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
                 a.lengths[t] = 0;
                 a.status[t] = GF_K_ERR_BOUNDS;
                 if (a.predictors) a.predictors[t] = 0;
+                if (PART == 1) (a.encStats + t * (size_t)GF_ENC_STAT_WORDS)[7] = 0u;
             }
             __syncthreads();
             continue;
@@ -764,8 +840,20 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
 #pragma unroll
             for (int k = 0; k < HIST_R; k++) s += h[k];
             if ((i & 255) == 0 && s >= forcedZeros) s -= forcedZeros;
-            enc_hist(P, i >> 8)[i & 255] = s;
+            if constexpr (PART == 1) (a.encStats + t * (size_t)GF_ENC_STAT_WORDS + 16)[i] = s;
+            else enc_hist(P, i >> 8)[i & 255] = s;
         }
+        if constexpr (PART == 1) {
+            __syncthreads();                     // the models, the seed and the longest values are in place
+            if (tid < 3) {
+                uint32_t *stat = a.encStats + t * (size_t)GF_ENC_STAT_WORDS;
+                stat[tid] = (uint32_t)P.model[tid];
+                stat[4 + tid] = P.maxN[tid];
+                if (tid == 0) { stat[3] = P.seed; stat[7] = 1u; }
+            }
+            __syncthreads();
+            continue;
+        } else {
         for (int i = tid; i < 3 * IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
         __syncthreads();                         // histR dead from here: S.tree may be written
 
@@ -1018,9 +1106,234 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_AB_WGS) void k_huffman_encode(GfEn
             for (int i = tid; i < 512; i += ENC_THREADS) rec[8 + 88 + i] = tw[i];
             __syncthreads();
         }
+        }                                        // PART != 1
     }
 }
 
+
+#ifndef GF_ENC_VARIANT
+// ------------------------------------------------------------------------------------------------
+// k_huffman_trees: phase B and the selection of k_huffman_encode, ONE WAVE PER TILE (round 4; see k_huffman_encode, PART 1).
+// The same steps in the same order: a lower bound of every candidate's packing from its histogram, the tree of the candidate with
+// the smallest bound, then the others' only if their bound does not already lose against its exact size (CodecHuffman.java:100-119;
+// the earlier predictor wins ties); the shortest packing's record for k_huffman_pack.  The histograms are read from the statistics
+// record as they are needed (four bins per lane); of the code tables and tree images only the best so far and the one being built
+// are kept, and one tree's arrays serve every candidate: 8.6 KB of LDS per wave, seventeen waves per CU.
+// ------------------------------------------------------------------------------------------------
+// (a tree's links without the leaves' counts and symbols, which stay in the registers of the lanes that sorted them)
+struct TreeLinks {
+    uint16_t parent[511];
+    uint16_t left[255];
+    uint16_t nl[511];
+    int n;
+};
+struct TreesShared {
+    uint64_t tab[256];                  // the candidate's code table (scratch of the sort and the rounds before it is written)
+    uint32_t img[IMG_WORDS];
+    TreeLinks T;
+};
+static_assert(sizeof(TreesShared) <= 5120, "k_huffman_trees: 32 waves per CU need 5,120 bytes of LDS or less per wave");
+
+__global__ __launch_bounds__(64) void k_huffman_trees(GfEncodeArgs a)
+{
+    __shared__ TreesShared S;
+    const int lane = threadIdx.x;
+    GF_FOR_TILES(t, a.nTiles, true) {
+        const uint32_t *__restrict__ stat = a.encStats + t * (size_t)GF_ENC_STAT_WORDS;
+        if (stat[7] == 0u) continue;                                     // declined or refused by k_huffman_encode
+        int model[3];
+        uint32_t maxN[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) { model[p] = (int)stat[p]; maxN[p] = stat[4 + p]; }
+        const uint32_t seed = stat[3];
+        // lower bounds (see k_huffman_encode, phase B)
+        uint32_t lbBytes[3] = {0, 0, 0};
+        int firstP = -1;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            if (model[p] == 0) continue;                                  // wave-uniform
+            double sumCLogC = 0.0;
+            uint32_t n = 0, N = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t cnt = stat[16 + p * 256 + r * 64 + lane];
+                n += cnt != 0;
+                N += cnt;
+                if (cnt > 1) sumCLogC += (double)cnt * (double)__log2f((float)cnt);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                n += gf_lane_xor(n, d);
+                N += gf_lane_xor(N, d);
+                sumCLogC += __shfl_xor(sumCLogC, d, 64);
+            }
+            double text = n > 1 ? (double)N * (double)__log2f((float)N) - sumCLogC : 0.0;
+            text -= 64.0 + (double)N * (1.0 / 4096.0);
+            const double bits = 80.0 + (n == 1 ? 17.0 : 8.0 + 10.0 * (double)n - 1.0) + (text > 0.0 ? text : 0.0);
+            // (every lane holds the same sums; lane 0's value as in the one-kernel form)
+            lbBytes[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits * 0.125));
+            if (firstP < 0 || lbBytes[p] < lbBytes[firstP]) firstP = p;
+        }
+        // the candidates: firstP, then the others in predictor order; the best so far lies in the tile's record
+        uint32_t *rec = a.packRecs + t * (size_t)GF_PACK_REC_WORDS;
+        int best = -1;
+        uint64_t bestBytes = ~0ull, firstBytes = 0;
+        uint32_t bTreeEnd = 0, bMaxLen = 0, bPlain = 0;
+        uint64_t bTotalBits = 0;
+        for (int k = 0; k < 3 && firstP >= 0; k++) {
+            // k = 0: firstP; k = 1, 2: the other two in order
+            int p = firstP;
+            if (k > 0) {
+                p = k - 1;
+                if (p >= firstP) p++;
+                if (model[p] == 0) continue;
+                const bool lost = p < firstP ? (uint64_t)lbBytes[p] > firstBytes : (uint64_t)lbBytes[p] >= firstBytes;
+                if (lost) continue;
+            }
+            TreeLinks &T = S.T;
+            uint64_t *tab = S.tab;
+            uint32_t *img = S.img;
+            for (int i = lane; i < IMG_WORDS; i += 64) img[i] = 0;
+            int n = 0;
+            uint32_t nM32 = 0;
+            // B1  sort the used symbols by (count asc, symbol asc)
+            uint32_t key[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t cnt = stat[16 + p * 256 + r * 64 + lane];
+                key[r] = cnt ? ((cnt << 8) | (uint32_t)(r * 64 + lane)) : 0xFFFFFFFFu;
+                n += __popcll(__ballot(cnt != 0));
+                nM32 += cnt;
+            }
+            uint32_t *scr = reinterpret_cast<uint32_t *>(tab);            // (the code table is written in B3)
+            if (n <= 128) {
+                // the used bins moved together first (terrain uses 70 to 100 of the 256): a network over 128 keys instead of 256
+                uint32_t at = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned long long m = __ballot(key[r] != 0xFFFFFFFFu);
+                    if (key[r] != 0xFFFFFFFFu) scr[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key[r];
+                    at += (uint32_t)__popcll(m);
+                }
+                key[0] = lane < n ? scr[lane] : 0xFFFFFFFFu;
+                key[1] = 64 + lane < n ? scr[64 + lane] : 0xFFFFFFFFu;
+                key[2] = 0xFFFFFFFFu;
+                key[3] = 0xFFFFFFFFu;
+                wave_bitonic_sort<2>(key, lane);
+            } else {
+                wave_bitonic_sort<4>(key, lane);
+            }
+            // leaf e = r * 64 + lane of the sorted order: its count and symbol stay with this lane
+            uint32_t leafCnt[4], leafSym[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int e = r * 64 + lane;
+                leafCnt[r] = key[r] >> 8;
+                leafSym[r] = key[r] & 0xffu;
+                if (e < n) {
+                    T.nl[e] = 1;
+                    key[r] = ((key[r] >> 8) << 9) | (uint32_t)(256 + e);
+                } else {
+                    key[r] = 0xFFFFFFFFu;
+                }
+            }
+            if (lane == 0) T.n = n;
+            // B2  tree by data-parallel rounds (small rounds merged by rank through the same scratch)
+            wave_huff_rounds(T, key, n, lane, scr);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) nM32 += gf_lane_xor(nM32, d);
+            __builtin_amdgcn_wave_barrier();
+            // B3  header image, codes, serialised tree, exact bit totals
+            if (lane == 0) {
+                // header, CodecHuffman.java:121-130 (LSB-first bit store == little-endian bytes)
+                img[0] = ((uint32_t)a.codecIndex & 0xffu) | ((uint32_t)model[p] << 8) | (seed << 16);
+                img[1] = (seed >> 16) | (nM32 << 16);
+                img[2] = (nM32 >> 16) | ((n > 1 ? (uint32_t)(n - 1) : 0u) << 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long textBits = 0;
+            uint32_t maxLen = 0;
+            bool nullByte = false;                                // the byte 0x80 is among the symbols
+            if (n == 1) {
+                // uniform special case, HuffmanEncoder.java:147-157: 8 zero bits, a 1 bit, the symbol
+                const uint32_t sym0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leafSym[0]);
+                nullByte = sym0 == 0x80u;
+                if (lane == 0) {
+                    const uint32_t r9 = 1u | (sym0 << 1);                     // 9 bits at bit 88
+                    atomicOr(&img[2], r9 << 24);
+                    atomicOr(&img[3], r9 >> 8);
+                    tab[sym0] = 0;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = r * 64 + lane;
+                    if (i < n) {
+                        uint64_t code;
+                        uint32_t pos;
+                        const int len = gf_huff_leaf_code(T, i, &code, &pos);
+                        const uint32_t sym = leafSym[r];
+                        nullByte = nullByte || sym == 0x80u;
+                        tab[sym] = ((uint64_t)len << 56) | code;
+                        textBits += (unsigned long long)leafCnt[r] * (unsigned)len;
+                        maxLen = max(maxLen, (uint32_t)len);
+                        const uint32_t bit = 88u + pos;                       // record: 1, then 8 symbol bits
+                        const uint64_t r9 = (uint64_t)(1u | (sym << 1)) << (bit & 31u);
+                        atomicOr(&img[bit >> 5], (uint32_t)r9);
+                        if (r9 >> 32) atomicOr(&img[(bit >> 5) + 1], (uint32_t)(r9 >> 32));
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                textBits += __shfl_xor(textBits, d, 64);
+                maxLen = max(maxLen, gf_lane_xor(maxLen, d));
+            }
+            const uint32_t treeBits = n == 1 ? 17u : (8u + 10u * (uint32_t)n - 1u);
+            const uint64_t totalBits = 80ull + treeBits + textBits;
+            const uint64_t bytes = (totalBits + 7) >> 3;
+            const bool anyNullByte = __any(nullByte) != 0;
+            if (k == 0) firstBytes = bytes;
+            __builtin_amdgcn_wave_barrier();
+            // strictly shorter wins, the earlier predictor wins a tie (CodecHuffman.java:107; the candidates do not come in order)
+            if (best < 0 || bytes < bestBytes || (bytes == bestBytes && p < best)) {
+                best = p;
+                bestBytes = bytes;
+                bTreeEnd = 80u + treeBits;
+                bTotalBits = totalBits;
+                bMaxLen = maxLen;
+                bPlain = (!anyNullByte && maxN[p] == 1u) ? 1u : 0u;
+                // its tree image and code table to the record (the code table holds what the scratch left where no symbol lies:
+                // the packer looks up symbols of the tile only)
+                for (int i = lane; i < GF_IMG_WORDS; i += 64) rec[8 + i] = img[i];
+                const uint32_t *tw = reinterpret_cast<const uint32_t *>(tab);
+                for (int i = lane; i < 512; i += 64) rec[8 + 88 + i] = tw[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (best < 0) {
+            if (lane == 0) {
+                a.lengths[t] = 0;
+                a.status[t] = GF_K_DECLINED;
+                if (a.predictors) a.predictors[t] = 0;
+            }
+            continue;
+        }
+        if (lane == 0) {
+            a.lengths[t] = (uint32_t)min(bestBytes, (uint64_t)0xffffffffu);
+            a.status[t] = bestBytes > a.slotStride ? GF_K_OVERFLOW : GF_K_OK;
+            if (a.predictors) a.predictors[t] = (uint8_t)model[best];
+            rec[0] = (uint32_t)model[best];
+            rec[1] = bTreeEnd;
+            rec[2] = seed;
+            rec[3] = maxN[best];
+            rec[4] = bMaxLen;
+            rec[5] = (uint32_t)min(bTotalBits - bTreeEnd, (uint64_t)0xFFFFFFFFu);   // bits of the text
+            rec[7] = bPlain;
+        }
+    }
+}
+#endif  // GF_ENC_VARIANT
 
 // the flat scan of a tile through the wave-private windows, in as many cell ranges as its bit count asks for (a wave's
 // share of a range must fit its quarter of the window); false: a range did not fit after all -- the tile is left to
@@ -1347,6 +1660,13 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     if (a.retryFlag && 6ull * nCells < (1ull << 23)) {
+#ifndef GF_DIAG
+        if (a.encStats && !a.lean) {
+            // the histograms, then the trees with a wave per tile (the diagnostic flavour keeps the one-kernel form its stamps describe)
+            hipLaunchKernelGGL((k_huffman_encode<true, 1>), gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
+            hipLaunchKernelGGL(k_huffman_trees, gf_tile_grid(a.nTiles), dim3(64), 0, stream, a);
+        } else
+#endif
         hipLaunchKernelGGL(k_huffman_encode<true>, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
 #ifdef GF_ENC_NULLS_RETRY
         // (only this experiment build's fast kernel leaves tiles behind: the shipping one takes every tile of up to 2^23 / 6 cells, and

@@ -89,7 +89,10 @@ struct GfEncodeArgs {
     int lean;                  // 1 (the one-tile-per-call path): only the kernels a tile usually needs are launched; a tile that
                                // needs another one (k_huffman_pack_rare) is reported with the internal status GF_K_LEAN_RETRY and
                                // the caller takes the batch path for it
+    uint32_t *encStats;        // non-null (CodecHuffman batches): the encoder runs as k_huffman_encode (histograms only) +
+                               // k_huffman_trees (one wave per tile); GF_ENC_STAT_WORDS words per tile between them
 };
+constexpr int GF_ENC_STAT_WORDS = 16 + 3 * 256;   // models, seed, longest value per predictor, a "has work" mark; the three histograms
 #define GF_K_LEAN_RETRY 0x7fff0002              /* (= GF_K_RETRY of the kernels: the fast kernels' own mark travels the same way) */
 constexpr int GF_PACK_REC_WORDS = 8 + 88 + 512;
 
