@@ -550,15 +550,19 @@ struct EncPersistA {
     unsigned long long sumStart;
     uint32_t nStart;
 };
+#ifndef GF_ENC_HIST_R_A
+#define GF_ENC_HIST_R_A 4        // histogram replicas of the part-1 kernel (sweep: see DESIGN.md)
+#endif
 union EncScratchA {
-    uint32_t histR[3][256 * HIST_R];
+    uint32_t histR[3][256 * GF_ENC_HIST_R_A];
 };
 
 template <bool FAST, int PART = 0>
-__global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
+__global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_ENC_HIST_R_A <= 4 ? 8 : ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
     __shared__ std::conditional_t<PART == 1, EncPersistA, EncPersist> P;
     __shared__ std::conditional_t<PART == 1, EncScratchA, EncScratchT<FAST>> S;
+    constexpr int HR = PART == 1 ? GF_ENC_HIST_R_A : HIST_R;              // histogram replicas
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
@@ -574,13 +578,13 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : 
 
         GF_STAMP(0);
         // ---------------- phase A: null scan + three histograms ----------------
-        for (int i = tid; i < 3 * 256 * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
+        for (int i = tid; i < 3 * 256 * HR; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
         if (tid == 0) { P.flags = 0; P.sumStart = 0; P.nStart = 0; }
         if (tid < 3) { P.maxN[tid] = 1; P.model[tid] = 0; P.nM32[tid] = 0; }
         __syncthreads();
 
         const bool triOk = nR >= 2 && nC >= 2;
-        const uint32_t rep = (uint32_t)lane & (HIST_R - 1);
+        const uint32_t rep = (uint32_t)lane & (HR - 1);
         uint32_t myFlags = 0, maxN1 = 1, maxN2 = 1, maxN3 = 1;
         {
             uint32_t *const h0 = &S.histR[0][rep], *const h1 = &S.histR[1][rep], *const h2 = &S.histR[2][rep];
@@ -647,9 +651,9 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : 
                     myFlags |= 2u;
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
-                        atomicAdd(h0 + (D1[j] & 0xffu) * HIST_R, 1u);
-                        atomicAdd(h1 + (D2[j] & 0xffu) * HIST_R, 1u);
-                        if (triOk) atomicAdd(h2 + (D3[j] & 0xffu) * HIST_R, 1u);
+                        atomicAdd(h0 + (D1[j] & 0xffu) * HR, 1u);
+                        atomicAdd(h1 + (D2[j] & 0xffu) * HR, 1u);
+                        if (triOk) atomicAdd(h2 + (D3[j] & 0xffu) * HR, 1u);
                     }
                 } else {
 #pragma unroll
@@ -660,9 +664,9 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : 
                         // the first M32 byte of the three residuals without a branch; the continuation bytes of values that have any
                         // behind ONE branch per cell (three, one per predictor, cost the scalar unit more than the cell cost the SIMDs)
                         bool s1, s2, s3 = true;
-                        atomicAdd(h0 + m32_first_byte(d1, &s1) * HIST_R, 1u);
-                        atomicAdd(h1 + m32_first_byte(d2, &s2) * HIST_R, 1u);
-                        if (triOk) atomicAdd(h2 + m32_first_byte(d3, &s3) * HIST_R, 1u);
+                        atomicAdd(h0 + m32_first_byte(d1, &s1) * HR, 1u);
+                        atomicAdd(h1 + m32_first_byte(d2, &s2) * HR, 1u);
+                        if (triOk) atomicAdd(h2 + m32_first_byte(d3, &s3) * HR, 1u);
                         if (!(s1 && s2 && s3)) {
                             // the continuation bytes of a wide value (CodecM32.java:283-311).  Two and three bytes -- what terrain has
                             // -- without a loop: |x| - 127 as one byte, |x| - 255 as two 7-bit groups; longer ones (rare) by the
@@ -671,17 +675,17 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : 
                             auto rest = [&](uint32_t *h, uint32_t x) -> uint32_t {
                                 const uint32_t mag = (int32_t)x < 0 ? 0u - x : x;
                                 if (mag <= 254u) {
-                                    atomicAdd(h + (mag - 127u) * HIST_R, 1u);
+                                    atomicAdd(h + (mag - 127u) * HR, 1u);
                                     return 2u;
                                 }
                                 if (mag <= 16638u) {
                                     const uint32_t d = mag - 255u;
-                                    atomicAdd(h + (0x80u | (d >> 7)) * HIST_R, 1u);
-                                    atomicAdd(h + (d & 0x7fu) * HIST_R, 1u);
+                                    atomicAdd(h + (0x80u | (d >> 7)) * HR, 1u);
+                                    atomicAdd(h + (d & 0x7fu) * HR, 1u);
                                     return 3u;
                                 }
                                 const uint32_t n = (uint32_t)gf_m32_len(x);
-                                for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
+                                for (uint32_t k = 1; k < n; k++) atomicAdd(h + gf_m32_byte(x, (int)n, (int)k) * HR, 1u);
                                 return n;
                             };
                             if (!s1) maxN1 = max(maxN1, rest(h0, d1));
@@ -748,17 +752,17 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : 
             // mean of exactly their values (:79-96).  So one pass over the tile (eight cells per thread as in phase A) sums the
             // start cells and counts everything else -- null cells as the byte 0x80 -- and a second one adds the start cells.
             forcedZeros = 0;
-            for (int i = tid; i < 3 * 256 * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
+            for (int i = tid; i < 3 * 256 * HR; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
             __syncthreads();
             uint32_t *const h0 = &S.histR[0][rep];
             auto addHist0 = [&](uint32_t x) -> uint32_t {
                 bool single;
                 const uint32_t b0 = m32_first_byte(x, &single);
-                atomicAdd(h0 + b0 * HIST_R, 1u);
+                atomicAdd(h0 + b0 * HR, 1u);
                 uint32_t n = 1;
                 if (!single) {
                     n = (uint32_t)gf_m32_len(x);
-                    for (uint32_t k = 1; k < n; k++) atomicAdd(h0 + gf_m32_byte(x, (int)n, (int)k) * HIST_R, 1u);
+                    for (uint32_t k = 1; k < n; k++) atomicAdd(h0 + gf_m32_byte(x, (int)n, (int)k) * HR, 1u);
                 }
                 return n;
             };
@@ -835,10 +839,10 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 ? 8 : 
 
         // reduce the replicas
         for (int i = tid; i < 3 * 256; i += ENC_THREADS) {
-            const uint32_t *h = &S.histR[0][0] + (size_t)i * HIST_R;
+            const uint32_t *h = &S.histR[0][0] + (size_t)i * HR;
             uint32_t s = 0;
 #pragma unroll
-            for (int k = 0; k < HIST_R; k++) s += h[k];
+            for (int k = 0; k < HR; k++) s += h[k];
             if ((i & 255) == 0 && s >= forcedZeros) s -= forcedZeros;
             if constexpr (PART == 1) (a.encStats + t * (size_t)GF_ENC_STAT_WORDS + 16)[i] = s;
             else enc_hist(P, i >> 8)[i & 255] = s;
