@@ -557,8 +557,11 @@ union EncScratchA {
     uint32_t histR[3][256 * GF_ENC_HIST_R_A];
 };
 
+#ifndef GF_ENC_A_WGS
+#define GF_ENC_A_WGS 7           // workgroups per CU the part-1 kernel is compiled for: 72 VGPRs, no scratch (8: 64 VGPRs and 28 bytes of scratch per lane; measured 0.689 / 0.714 / 0.705 ms per encode with 7 / 8 / 6)
+#endif
 template <bool FAST, int PART = 0>
-__global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_ENC_HIST_R_A <= 4 ? 8 : ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
+__global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_ENC_HIST_R_A <= 4 ? GF_ENC_A_WGS : ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
     __shared__ std::conditional_t<PART == 1, EncPersistA, EncPersist> P;
     __shared__ std::conditional_t<PART == 1, EncScratchA, EncScratchT<FAST>> S;
@@ -613,7 +616,37 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                 const bool inside = i0 >= nC + 2u && i0 + (CPT - 1) < nCells;
                 uint32_t widest = 0;                                 // max over the residuals of (d + 126) as unsigned: <= 252 = plain
                 int32_t lowest = 0x7fffffff;                         // min over the cells: Integer.MIN_VALUE = a null cell
-                if (__all(inside)) {
+                if (__all(inside) && nC >= (uint32_t)CPT) {
+                    // (round 4: phase A is bound by vector issue -- 290 instructions per wave and turn.  The three residuals from
+                    // two raw differences, v - W along the row and N - NW along the row above: Linear's is the difference of two
+                    // neighbouring raw differences, Triangle's the difference of the two rows'.  At most one of the eight cells
+                    // starts a row (nC >= 8): k is its place, and "first / second cell of a row" is a compare of two constants'
+                    // worth instead of a column counter per cell.)
+                    const uint32_t toEnd = nC - c;
+                    const uint32_t k = c == 0u ? 0u : (toEnd < (uint32_t)CPT ? toEnd : (uint32_t)CPT);
+                    const bool second0 = c == 1u;
+                    int32_t hi = -0x7fffffff - 1, lo = 0x7fffffff;
+                    uint32_t rlPrev = Q.wm1 - Q.wm2;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        const uint32_t v = Q.cur[j];
+                        const uint32_t W = j > 0 ? Q.cur[j - 1] : Q.wm1;
+                        const uint32_t N = Q.up[j];
+                        const uint32_t NW = j > 0 ? Q.up[j - 1] : Q.upm1;
+                        const uint32_t rl = v - W, ru = N - NW;
+                        const bool first = (uint32_t)j == k;
+                        const bool second = (uint32_t)j == k + 1u || (j == 0 && second0);
+                        const uint32_t d = first ? v - N : rl;
+                        D1[j] = d;
+                        D2[j] = (first || second) ? d : rl - rlPrev;
+                        D3[j] = first ? d : rl - ru;
+                        rlPrev = rl;
+                        hi = max(hi, max((int32_t)D1[j], max((int32_t)D2[j], (int32_t)D3[j])));
+                        lo = min(lo, min((int32_t)D1[j], min((int32_t)D2[j], (int32_t)D3[j])));
+                        lowest = min(lowest, (int32_t)v);
+                    }
+                    widest = (hi <= 126 && lo >= -126) ? 0u : 0xFFFFFFFFu;
+                } else if (__all(inside)) {
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
                         const uint32_t v = Q.cur[j];
