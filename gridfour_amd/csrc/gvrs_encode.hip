@@ -538,9 +538,9 @@ constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel lea
 // PART 1 (round 4, CodecHuffman batches): phase A alone -- the histograms and what else the trees need go to GfEncodeArgs::encStats,
 // and k_huffman_trees takes it from there with ONE WAVE PER TILE.  In the one-kernel form the tree of a tile is built by one wave
 // (sort, tree rounds, codes: a chain of dependent steps, 42 % of a tile's time) while the workgroup's other three hold their wave
-// slots idle: a CU had fewer than three such chains in flight; the tree kernel keeps seventeen.
-// (what phase A keeps of EncPersist: the part-1 kernel carries no code tables and no tree images -- 12.4 instead of 19.6 KB of LDS
-// per workgroup, eight workgroups = all 32 wave slots of a CU)
+// slots idle: a CU had fewer than three such chains in flight; the tree kernel keeps thirty-two.
+// EncPersistA: what phase A keeps of EncPersist -- the part-1 kernel carries no code tables and no tree images, 12.4 instead of
+// 19.6 KB of LDS per workgroup.
 struct EncPersistA {
     uint32_t maxN[3];
     uint32_t nM32[3];
