@@ -2411,6 +2411,30 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         const uint32_t len = a.lengths[t];
         uint32_t *o = reinterpret_cast<uint32_t *>(a.values) + t * (size_t)nCells;
         const uint8_t *__restrict__ pk = a.blob + off;
+        // The fast kernel's leaf records (round 4): where they lie depends on the tile's index alone, so they are asked for HERE, with
+        // the packing's offset and length, and arrive while the header is read -- the tile's start was four dependent round trips
+        // to memory (offset / length, header, record scalars, leaf arrays), now two.
+#ifdef GF_DEC_NO_PREFETCH                                          // (experiment builds: tools/ab.sh)
+        constexpr bool PRE = false;
+#else
+        constexpr bool PRE = FAST;
+#endif
+        unsigned long long preCode = 0;
+        uint32_t preLen = 0, preSym = 0, preRec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // (and the header's twelve bytes, before the packing's length is known, where the blob has that many behind the offset)
+        uint32_t preHead = 0;
+        const bool headEarly = PRE && off + 12u <= a.blobBytes;
+        if constexpr (PRE) {
+            if (headEarly && tid < 12) preHead = pk[tid];
+            const uint32_t *recP = a.trees + t * GF_TREE_REC_WORDS;
+#pragma unroll
+            for (int i = 0; i < 8; i++) preRec[i] = recP[i];              // (the same words in every thread: scalar loads)
+            if (tid < 256) {
+                preCode = reinterpret_cast<const unsigned long long *>(recP + 8)[tid];
+                preLen = reinterpret_cast<const uint8_t *>(recP + 8 + 512)[tid];
+                preSym = reinterpret_cast<const uint8_t *>(recP + 8 + 512 + 64)[tid];
+            }
+        }
 
         if (len < 10 || off + len > a.blobBytes) {       // BitInputStore would run out / AIOOBE on the header
             if (tid == 0) a.status[t] = GF_K_ERR_BOUNDS;
@@ -2424,7 +2448,20 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             uint8_t *hb = reinterpret_cast<uint8_t *>(S.head);
             const uint32_t nh = min(len, (uint32_t)(HEAD_WORDS * 4));
             constexpr uint32_t nHead = FAST ? 12u : (uint32_t)(HEAD_WORDS * 4);      // the fast kernel needs the 10 header bytes only
-            for (uint32_t i = tid; i < nHead; i += DEC_THREADS) hb[i] = i < nh ? pk[i] : 0;
+            if (headEarly) {
+                asm volatile("" : "+v"(preHead));
+                if (tid < 12) hb[tid] = (uint32_t)tid < nh ? (uint8_t)preHead : (uint8_t)0;
+            } else {
+                for (uint32_t i = tid; i < nHead; i += DEC_THREADS) hb[i] = i < nh ? pk[i] : 0;
+            }
+        }
+        if constexpr (PRE) {
+            // (the compiler would move the record loads down to where their values are used -- behind the header's barrier)
+            uint32_t lo = (uint32_t)preCode, hi = (uint32_t)(preCode >> 32);
+            asm volatile("" : "+v"(lo), "+v"(hi), "+v"(preLen), "+v"(preSym));
+            asm volatile("" : "+v"(preRec[0]), "+v"(preRec[1]), "+v"(preRec[2]), "+v"(preRec[3]), "+v"(preRec[4]), "+v"(preRec[5]),
+                              "+v"(preRec[6]), "+v"(preRec[7]));
+            preCode = ((unsigned long long)hi << 32) | lo;
         }
         __syncthreads();
         const uint8_t *hb = reinterpret_cast<const uint8_t *>(S.head);
@@ -2459,16 +2496,18 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             // whose codes continue in a second-level table (one per distinct LUT_BITS-bit prefix among the longer codes,
             // numbered in pre-order) and list the short leaves -- in parallel, a leaf per thread
             const uint32_t *rec = a.trees + t * GF_TREE_REC_WORDS;
-            const uint32_t nLeaves = rec[1];
-            const bool mine = (uint32_t)tid < nLeaves && rec[0] == (uint32_t)GF_K_OK && (int32_t)rec[4] < 0;
+            // (the fast kernel has words 0..7 already: R)
+            auto R = [&](int i) -> uint32_t { return PRE ? preRec[i] : rec[i]; };
+            const uint32_t nLeaves = R(1);
+            const bool mine = (uint32_t)tid < nLeaves && R(0) == (uint32_t)GF_K_OK && (int32_t)R(4) < 0;
             unsigned long long code = 0;
             uint32_t clen = 0;
             if (mine) {
-                code = reinterpret_cast<const unsigned long long *>(rec + 8)[tid];
-                clen = reinterpret_cast<const uint8_t *>(rec + 8 + 512)[tid];
+                code = PRE ? preCode : reinterpret_cast<const unsigned long long *>(rec + 8)[tid];
+                clen = PRE ? preLen : reinterpret_cast<const uint8_t *>(rec + 8 + 512)[tid];
                 S.leafCode[tid] = code;
                 S.leafLen[tid] = (uint8_t)clen;
-                S.leafSym[tid] = reinterpret_cast<const uint8_t *>(rec + 8 + 512 + 64)[tid];
+                S.leafSym[tid] = (uint8_t)(PRE ? preSym : reinterpret_cast<const uint8_t *>(rec + 8 + 512 + 64)[tid]);
             }
             __syncthreads();
             const uint32_t prefix = (uint32_t)code & ((1u << LUT_BITS) - 1u);
@@ -2483,14 +2522,14 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             const uint32_t slot = block_excl_scan(isShort ? 1u : 0u, S.waveSum, &nShort);
             if (isShort) S.shortLeaf[slot & 63u] = (uint8_t)tid;
             if (tid == 0) {
-                const uint32_t maxLen = rec[3] & 0xffu;
-                S.symKinds = rec[3] & ~0xffu;
-                S.uniformSym = (int32_t)rec[4];
-                S.skipLen = rec[5];
-                S.skipLo = rec[6];
-                S.skipHi = rec[7];
-                S.textStart = rec[2];
-                S.parseStatus = (int32_t)rec[0];
+                const uint32_t maxLen = R(3) & 0xffu;
+                S.symKinds = R(3) & ~0xffu;
+                S.uniformSym = (int32_t)R(4);
+                S.skipLen = R(5);
+                S.skipLo = R(6);
+                S.skipHi = R(7);
+                S.textStart = R(2);
+                S.parseStatus = (int32_t)R(0);
                 S.nLeaves = nLeaves;
                 S.nShort = nShort;
                 const uint32_t l2 = maxLen > LUT_BITS ? min((uint32_t)L2_MAX_BITS, maxLen - LUT_BITS) : 1u;
