@@ -283,7 +283,7 @@ gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
     const unsigned grid = gf_huffman_decode_grid(nTiles);
     gf_status s = c->trees.ensure(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16);
     if (s != GF_OK) return s;
-    if ((s = c->packRecs.ensure(nTiles * std::max((size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS, gf_canon_pack_rec_words()) * 4 + 16)) != GF_OK) return s;
+    if ((s = c->packRecs.ensure(nTiles * std::max((size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS, gf_canon_pack_rec_words() + gf_canon_stat_words()) * 4 + 16)) != GF_OK) return s;
     return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
 }
 
@@ -339,7 +339,7 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
     a.retryFlag = kind == KIND_HUFFMAN ? (uint32_t *)c->flags.p + 4 : nullptr;      // (word 0 belongs to the decoder)
     {
         // (CodecHuffman: the selection records, and behind them the statistics k_huffman_encode hands to k_huffman_trees)
-        const size_t need = nTiles * (kind == KIND_CANON ? gf_canon_pack_rec_words() : (size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS) * 4 + 16;
+        const size_t need = nTiles * (kind == KIND_CANON ? gf_canon_pack_rec_words() + gf_canon_stat_words() : (size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS) * 4 + 16;
         if (c->packRecs.bytes < need) {
             GF_HIP(hipSetDevice(c->device));               // not capture-safe: gf_context_reserve sizes this too
             gf_status s = c->packRecs.ensure(need);
@@ -347,7 +347,7 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
         }
         a.packRecs = (uint32_t *)c->packRecs.p;
         a.lean = g_lean;
-        a.encStats = kind == KIND_CANON ? nullptr : a.packRecs + nTiles * (size_t)GF_PACK_REC_WORDS;
+        a.encStats = a.packRecs + nTiles * (kind == KIND_CANON ? gf_canon_pack_rec_words() : (size_t)GF_PACK_REC_WORDS);
     }
     if (kind == KIND_CANON) GF_HIP(gf_launch_canon_encode(a, stream ? (hipStream_t)stream : c->stream));
     else if (a.lean && a.retryFlag && 6ull * (size_t)nRows * (size_t)nCols < (1ull << 23))   // one tile per call: the 1024-thread build

@@ -30,6 +30,7 @@ namespace {
 // per-tile record between k_canon_encode (phases A, B, selection) and k_canon_pack (phase C): model, seed, image bits, longest
 // code, largest escape kind, 3 spare, then the serialised code tables and the winner's code table (GfEncodeArgs::packRecs)
 constexpr int CN_PACK_REC_WORDS = 8 + CN_IMG_WORDS + CN_HIST;
+constexpr int CN_STAT_WORDS = 16 + 3 * CN_HIST;      // k_canon_encode (part 1) -> k_canon_trees: models, seed, quirk counts, escape kinds, the three histograms
 
 struct CanonPersist {
     uint32_t hist[3][CN_HIST];
@@ -309,10 +310,32 @@ __device__ __forceinline__ void cpack_flat_ranges(const uint32_t *__restrict__ t
 #endif
 constexpr int CN_AB_WGS = GF_CN_AB_WGS, CN_PACK_WGS = GF_CN_PACK_WGS;
 
-__global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncodeArgs a)
+// PART 0: phases A and B and the selection in one kernel.  PART 1 (round 4, as the legacy encoder's): phase A alone, the histograms
+// to GfEncodeArgs::encStats; k_canon_trees builds the code tables with a wave per tile.  In the one-kernel form cn_build -- sort,
+// tree rounds, depths, run-length tokens, the meta tree, the image: a long chain of dependent steps -- ran on one wave per candidate
+// while the workgroup's other waves held their slots idle.
+struct CanonPersistA {
+    uint32_t maxKind[3];
+    uint32_t nGap[3];
+    int32_t model[3];
+    uint32_t seed;
+    uint32_t flags;
+    unsigned long long sumStart;
+    uint32_t nStart;
+    uint32_t pmLock;
+};
+union CanonUnionA {
+    uint32_t histR[3][CN_HIST * HIST_R];
+};
+#ifndef GF_CN_A_WGS
+#define GF_CN_A_WGS 7
+#endif
+
+template <int PART = 0>
+__global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) void k_canon_encode(GfEncodeArgs a)
 {
-    __shared__ CanonPersist P;
-    __shared__ CanonUnion S;
+    __shared__ std::conditional_t<PART == 1, CanonPersistA, CanonPersist> P;
+    __shared__ std::conditional_t<PART == 1, CanonUnionA, CanonUnion> S;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
@@ -412,6 +435,7 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
                 a.lengths[t] = n;
                 a.status[t] = early;
                 if (a.predictors) a.predictors[t] = 0;
+                if (PART == 1) (a.encStats + t * (size_t)CN_STAT_WORDS)[7] = 0u;          // nothing for k_canon_trees
             }
             __syncthreads();
             continue;
@@ -478,8 +502,21 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
             if (s == 128 && sum >= forcedZeros) sum -= forcedZeros;
             if (s == CN_EOT) sum = 1;
             if (s >= CN_SYMS) sum = 0;
-            P.hist[p][s] = sum;
+            if constexpr (PART == 1) (a.encStats + t * (size_t)CN_STAT_WORDS + 16)[i] = sum;
+            else P.hist[p][s] = sum;
         }
+        if constexpr (PART == 1) {
+            __syncthreads();                     // the models, the seed, the quirk counts and the escape kinds are in place
+            if (tid < 3) {
+                uint32_t *stat = a.encStats + t * (size_t)CN_STAT_WORDS;
+                stat[tid] = (uint32_t)P.model[tid];
+                stat[4 + tid] = P.nGap[tid];
+                stat[8 + tid] = P.maxKind[tid];
+                if (tid == 0) { stat[3] = P.seed; stat[7] = 1u; }
+            }
+            __syncthreads();
+            continue;
+        } else {
         for (int i = tid; i < 3 * CN_IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
         __syncthreads();                         // histR dead from here: S.tree may be written
 
@@ -586,6 +623,123 @@ __global__ __launch_bounds__(ENC_THREADS, CN_AB_WGS) void k_canon_encode(GfEncod
             for (int i = tid; i < CN_HIST; i += ENC_THREADS) rec[8 + CN_IMG_WORDS + i] = P.tab[best][i];
             __syncthreads();
         }
+        }                                        // PART != 1
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_canon_trees: phase B and the selection of k_canon_encode with ONE WAVE PER TILE (round 4), four tiles to a workgroup, which
+// share the package-merge scratch under its lock as the candidates' waves of the one-kernel form do.  Same steps in the same order:
+// lower bounds and pruning where no value lies in the -8333608 quirk, cn_build per candidate (its histogram read from the statistics
+// record), strictly shortest wins, the earlier predictor wins a tie; the best candidate so far lies in the tile's record.
+// ------------------------------------------------------------------------------------------------
+struct CanonTreesShared {
+    CanonScratch tree[4];
+    uint32_t tab[4][CN_HIST];
+    uint32_t img[4][CN_IMG_WORDS];
+    CanonPM pm;
+    uint32_t pmLock;
+};
+
+__global__ __launch_bounds__(256, 5) void k_canon_trees(GfEncodeArgs a)
+{
+    __shared__ CanonTreesShared S;
+    const int tid = threadIdx.x, lane = tid & 63, w = (int)gf_wave_id();
+    if (tid == 0) S.pmLock = 0;
+    __syncthreads();
+    const size_t t = ((size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x) * 4u + (size_t)w;
+    if (t >= a.nTiles) return;
+    const uint32_t *__restrict__ stat = a.encStats + t * (size_t)CN_STAT_WORDS;
+    if (stat[7] == 0u) return;                                           // declined, uniform or refused by k_canon_encode
+    int model[3];
+    uint32_t nGap[3], maxKind[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) { model[p] = (int)stat[p]; nGap[p] = stat[4 + p]; maxKind[p] = stat[8 + p]; }
+    const uint32_t seed = stat[3];
+    const bool prune = nGap[0] == 0u && nGap[1] == 0u && nGap[2] == 0u;
+    uint32_t lbBytes[3] = {0, 0, 0};
+    int firstP = -1;
+    if (prune) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            if (model[p] == 0) continue;
+            const uint32_t *hist = stat + 16 + p * CN_HIST;
+            double sumCLogC = 0.0;
+            uint32_t N = 0;
+            for (int e = lane; e < CN_SYMS; e += 64) {
+                const uint32_t cnt = hist[e];
+                N += cnt;
+                if (cnt > 1) sumCLogC += (double)cnt * (double)__log2f((float)cnt);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                N += gf_lane_xor(N, d);
+                sumCLogC += __shfl_xor(sumCLogC, d, 64);
+            }
+            double text = (double)N * (double)__log2f((float)N) - sumCLogC;
+            text -= 64.0 + (double)N * (1.0 / 4096.0);
+            const double bits = 48.0 + (text > 0.0 ? text : 0.0) + 2.0 * (double)hist[CN_ESC2] + 8.0 * (double)hist[CN_ESC1];
+            lbBytes[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits * 0.125));
+            if (firstP < 0 || lbBytes[p] < lbBytes[firstP]) firstP = p;
+        }
+    }
+    uint32_t *rec = a.packRecs + t * (size_t)CN_PACK_REC_WORDS;
+    int best = -1;
+    uint64_t bestBytes = ~0ull, firstBytes = 0;
+    uint32_t bImgBits = 0, bMaxLen = 0;
+    unsigned long long bTotalBits = 0;
+    for (int k = 0; k < 3; k++) {
+        // with pruning: the candidate of the smallest bound first, then the others in order; without: all three in order
+        int p = k;
+        if (prune) {
+            if (firstP < 0) break;
+            p = firstP;
+            if (k > 0) {
+                p = k - 1;
+                if (p >= firstP) p++;
+            }
+        }
+        if (model[p] == 0) continue;
+        if (prune && k > 0) {
+            const bool lost = p < firstP ? (uint64_t)lbBytes[p] > firstBytes : (uint64_t)lbBytes[p] >= firstBytes;
+            if (lost) continue;
+        }
+        for (int i = lane; i < CN_IMG_WORDS; i += 64) S.img[w][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const CanonBuilt B = cn_build(S.tree[w], S.pm, &S.pmLock, stat + 16 + p * CN_HIST, nGap[p], S.tab[w], S.img[w], lane);
+        const unsigned long long totalBits = 48ull + B.imgBits + B.textBits;
+        const uint64_t bytes = (totalBits + 7) >> 3;
+        if (prune && k == 0) firstBytes = bytes;
+        __builtin_amdgcn_wave_barrier();
+        if (best < 0 || bytes < bestBytes || (bytes == bestBytes && p < best)) {
+            best = p;
+            bestBytes = bytes;
+            bImgBits = B.imgBits;
+            bMaxLen = B.maxLen;
+            bTotalBits = totalBits;
+            for (int i = lane; i < CN_IMG_WORDS; i += 64) rec[8 + i] = S.img[w][i];
+            for (int i = lane; i < CN_HIST; i += 64) rec[8 + CN_IMG_WORDS + i] = S.tab[w][i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (best < 0) {
+        if (lane == 0) {
+            a.lengths[t] = 0;
+            a.status[t] = GF_K_DECLINED;
+            if (a.predictors) a.predictors[t] = 0;
+        }
+        return;
+    }
+    if (lane == 0) {
+        a.lengths[t] = (uint32_t)min(bestBytes, (uint64_t)0xffffffffu);
+        a.status[t] = bestBytes > a.slotStride ? GF_K_OVERFLOW : GF_K_OK;
+        if (a.predictors) a.predictors[t] = (uint8_t)model[best];
+        rec[0] = (uint32_t)model[best];
+        rec[1] = seed;
+        rec[2] = bImgBits;
+        rec[3] = bMaxLen;
+        rec[4] = maxKind[best];
+        rec[5] = (uint32_t)min(bTotalBits - 48ull - bImgBits, (unsigned long long)0xFFFFFFFFu);   // text bits
     }
 }
 
@@ -686,9 +840,16 @@ hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (a.nTiles == 0) return hipSuccess;
     const dim3 grid = gf_tile_grid(a.nTiles);
     if (!a.packRecs) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_canon_encode, grid, dim3(ENC_THREADS), 0, stream, a);
+    if (a.encStats) {
+        // the histograms, then the code tables with a wave per tile (four tiles to a workgroup)
+        hipLaunchKernelGGL(k_canon_encode<1>, grid, dim3(ENC_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(k_canon_trees, gf_tile_grid((a.nTiles + 3) / 4), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(k_canon_encode<0>, grid, dim3(ENC_THREADS), 0, stream, a);
+    }
     hipLaunchKernelGGL(k_canon_pack, grid, dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 
 size_t gf_canon_pack_rec_words() { return (size_t)CN_PACK_REC_WORDS; }
+size_t gf_canon_stat_words() { return (size_t)CN_STAT_WORDS; }

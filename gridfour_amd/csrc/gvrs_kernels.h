@@ -189,6 +189,7 @@ hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, 
 
 // CodecCanonHuffman (gvrs_canon_encode.hip / gvrs_canon_decode.hip); same argument blocks as the legacy codec
 hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
+size_t gf_canon_stat_words();          // words per tile of GfEncodeArgs::encStats for the canonical encoder
 size_t gf_canon_pack_rec_words();      // words per tile of GfEncodeArgs::packRecs for the canonical encoder
 hipError_t gf_launch_canon_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
 uint32_t gf_canon_decode_lds_text(int nRows, int nCols);
