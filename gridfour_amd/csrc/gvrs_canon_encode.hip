@@ -633,21 +633,25 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
 // lower bounds and pruning where no value lies in the -8333608 quirk, cn_build per candidate (its histogram read from the statistics
 // record), strictly shortest wins, the earlier predictor wins a tie; the best candidate so far lies in the tile's record.
 // ------------------------------------------------------------------------------------------------
+#ifndef GF_CN_TREES_WAVES
+#define GF_CN_TREES_WAVES 4      // tiles (= waves) per workgroup: 28.6 KB of LDS and five workgroups per CU at four
+#endif
+constexpr int CN_TW = GF_CN_TREES_WAVES;
 struct CanonTreesShared {
-    CanonScratch tree[4];
-    uint32_t tab[4][CN_HIST];
-    uint32_t img[4][CN_IMG_WORDS];
+    CanonScratch tree[CN_TW];
+    uint32_t tab[CN_TW][CN_HIST];
+    uint32_t img[CN_TW][CN_IMG_WORDS];
     CanonPM pm;
     uint32_t pmLock;
 };
 
-__global__ __launch_bounds__(256, 5) void k_canon_trees(GfEncodeArgs a)
+__global__ __launch_bounds__(64 * CN_TW, CN_TW == 4 ? 5 : CN_TW == 2 ? 9 : 3) void k_canon_trees(GfEncodeArgs a)
 {
     __shared__ CanonTreesShared S;
     const int tid = threadIdx.x, lane = tid & 63, w = (int)gf_wave_id();
     if (tid == 0) S.pmLock = 0;
     __syncthreads();
-    const size_t t = ((size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x) * 4u + (size_t)w;
+    const size_t t = ((size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x) * (size_t)CN_TW + (size_t)w;
     if (t >= a.nTiles) return;
     const uint32_t *__restrict__ stat = a.encStats + t * (size_t)CN_STAT_WORDS;
     if (stat[7] == 0u) return;                                           // declined, uniform or refused by k_canon_encode
@@ -843,7 +847,7 @@ hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (a.encStats) {
         // the histograms, then the code tables with a wave per tile (four tiles to a workgroup)
         hipLaunchKernelGGL(k_canon_encode<1>, grid, dim3(ENC_THREADS), 0, stream, a);
-        hipLaunchKernelGGL(k_canon_trees, gf_tile_grid((a.nTiles + 3) / 4), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_canon_trees, gf_tile_grid((a.nTiles + CN_TW - 1) / CN_TW), dim3(64 * CN_TW), 0, stream, a);
     } else {
         hipLaunchKernelGGL(k_canon_encode<0>, grid, dim3(ENC_THREADS), 0, stream, a);
     }
