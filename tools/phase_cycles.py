@@ -36,7 +36,8 @@ def main():
     d = np.diff(st, axis=1) & 0xFFFFFFFF
     names = ["A hist pass", "A->reduce (nulls/replicas)", "B1 sort", "B2 merge", "B3 codes",
              "(k_huffman_encode -> k_huffman_pack: not a phase)", "C pack (k_huffman_pack: window init, pack)"]
-    print("tiles", nt, "median / p90 cycles per phase (s_memtime ticks, 100 MHz? see total)")
+    print("tiles", nt, "median / p90 ticks per phase (s_memtime).  The diagnostic flavour runs the ONE-KERNEL encoder (phases A and B in\n"
+          "k_huffman_encode); the shipping batches run part 1 + k_huffman_trees + k_huffman_pack (gvrs_encode.hip)")
     for i, nme in enumerate(names):
         print("  %-28s median %9d  p90 %9d  max %9d" % (nme, np.median(d[:, i]), np.percentile(d[:, i], 90), d[:, i].max()))
     tot = ((st[:, 5] - st[:, 0]) & 0xFFFFFFFF) + ((st[:, 7] - st[:, 6]) & 0xFFFFFFFF)
