@@ -1383,11 +1383,20 @@ __device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ ti
     const uint32_t capBits = WAVE_WIN_BITS;
     const uint64_t want = ((uint64_t)textBits + (textBits >> 2)) / ENC_WAVES;           // a wave's share, with 25 % slack
     const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / capBits + 1u);
-    const uint32_t per = (((nCells + nRanges - 1) / nRanges) + (CPT * ENC_WAVES) - 1) / (CPT * ENC_WAVES) * (CPT * ENC_WAVES);
-    for (uint32_t b = 0; b < nCells; b += per) {
+    constexpr uint32_t UNIT = CPT * ENC_WAVES;
+    uint32_t per = (((nCells + nRanges - 1) / nRanges) + UNIT - 1) / UNIT * UNIT;
+    // A range whose bits are spread unevenly over the waves' shares (a cliff in one quarter of it) overruns a window although the
+    // range as a whole would fit: nothing was written then, and the range is packed again in two halves (round 4; such tiles -- most
+    // of a rough surface's -- used to go to k_huffman_pack_rare, 0.2 ms per launch of the rough batch).
+    for (uint32_t b = 0; b < nCells;) {
         const PackStateOk r = pack_flat_waves<MODEL, PLAIN>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
-        if (!r.ok) return false;
-        ps = r.ps;
+        if (r.ok) {
+            ps = r.ps;
+            b += per;
+        } else {
+            if (per <= 8u * UNIT) return false;
+            per = (per / 2u + UNIT - 1u) / UNIT * UNIT;
+        }
     }
     return true;
 }
