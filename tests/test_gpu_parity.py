@@ -385,3 +385,35 @@ def test_one_tile_per_call_shapes(codec, shape):
             assert got == ref, (rep, ci)
             if ref is not None:
                 assert np.array_equal(codec.decode(n_rows, n_cols, got), v), (rep, ci)
+
+
+@pytest.mark.parametrize("shape", [(120, 150), (200, 200), (64, 256), (300, 40)], ids=lambda s: "%dx%d" % s)
+def test_packer_on_tiles_with_their_bits_in_one_corner(codec, shape):
+    """k_huffman_pack deals a range of cells to its waves in equal shares, each with a window of its own: a tile whose long codes
+    sit in one part of it (rough ground in one quarter, the rest flat) overruns a share's window although the range would fit.
+    Such a range is packed again in halves (pack_flat_ranges); what still does not fit goes to k_huffman_pack_rare.  The bytes
+    are the oracle's either way."""
+    n_rows, n_cols = shape
+    cells = n_rows * n_cols
+    rng = np.random.default_rng(n_rows * 31 + n_cols)
+    tiles = []
+    for part in range(4):                                   # the noisy quarter first, second, third, last
+        v = np.full(cells, 1000, np.int64)
+        a, b = part * cells // 4, (part + 1) * cells // 4
+        v[a:b] += rng.integers(-20000, 20001, b - a)
+        tiles.append(v.astype(np.int32))
+    v = np.full(cells, -7, np.int64)                        # a noisy stripe of two rows in the middle, values of three and four bytes
+    a = (n_rows // 2) * n_cols
+    v[a:a + 2 * n_cols] += rng.integers(-3000000, 3000001, 2 * n_cols)
+    tiles.append(v.astype(np.int32))
+    v = rng.integers(-2, 3, cells).cumsum()                 # gentle everywhere but the last eighth
+    v[-cells // 8:] += rng.integers(-500, 501, cells // 8)
+    tiles.append(v.astype(np.int32))
+    tiles = np.stack(tiles)
+    packs, preds, status = codec.encode_batch(2, n_rows, n_cols, tiles)
+    assert (np.asarray(status) == 0).all()
+    for t, v in enumerate(tiles):
+        ref, used = oracle.codec_huffman_encode(2, n_rows, n_cols, v)
+        assert packs[t] == ref and preds[t] == used, t
+    vals, st = codec.decode_batch(n_rows, n_cols, packs)
+    assert (st == 0).all() and np.array_equal(vals, tiles)
