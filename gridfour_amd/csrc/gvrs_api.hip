@@ -63,12 +63,19 @@ bool offsetsValid(const uint64_t *offsets, size_t nTiles)
     return true;
 }
 
+// Counts the device buffers that moved (process-wide; a move is rare: buffers only grow).  A recorded hipGraph holds the
+// addresses it was captured with: the one-tile graphs (gf_single) remember the count they were recorded at and are dropped when
+// it has changed -- a batch that grew the context's tree / selection records between two replays used to leave them pointing
+// at freed memory.
+static std::atomic<uint64_t> g_devBufMoves{0};
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
     gf_status ensure(size_t need)
     {
         if (need <= bytes) return GF_OK;
+        g_devBufMoves.fetch_add(1, std::memory_order_relaxed);
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         need = roundUp(need + need / 8, 1 << 20);
         GF_HIP(hipMalloc(&p, need));
@@ -77,7 +84,10 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) {
+            g_devBufMoves.fetch_add(1, std::memory_order_relaxed);
+            (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
     }
@@ -98,11 +108,18 @@ struct gf_context {
     DevBuf dResiduals, dCoefs, dStatus2;   // LSOP staging
     DevBuf dM32, dM32Len, dM32Models, dSeeds;   // CodecDeflate staging
     DevBuf dInflate, dInflOut, dInflMeta;       // GPU inflate: stream descriptors, inflated bytes, produced / status
+    // Every entry point that takes the context holds this lock for its duration (GF_CTX_LOCK): the reference calls ONE decoder
+    // instance from several threads (gvrs/RasterTileCache.java:418-421, TileDecompressionAssistant.java:68-73), and a context's
+    // scratch buffers, staging slots and recorded graphs are one set.  Recursive: entry points call each other.
+    std::recursive_mutex mu;
     struct gf_host_pipe *pipe = nullptr;        // pipelined staging of the host-memory batch entry points (created on first use)
     struct gf_single *single = nullptr;         // one tile per call: page-locked buffers and replayed graphs (created on first use)
 };
 void gf_host_pipe_destroy(struct gf_host_pipe *p);
 void gf_single_destroy(struct gf_single *s);
+#define GF_CTX_LOCK(c)                                       \
+    std::unique_lock<std::recursive_mutex> gfCtxLock_;       \
+    if (c) gfCtxLock_ = std::unique_lock<std::recursive_mutex>((c)->mu)
 
 struct gf_timer {
     gf_context *ctx;
@@ -263,6 +280,7 @@ void *gf_context_stream(gf_context *c) { return c ? (void *)c->stream : nullptr;
 
 gf_status gf_context_synchronize(gf_context *c)
 {
+    GF_CTX_LOCK(c);
     if (!c) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     GF_HIP(hipStreamSynchronize(c->stream));
@@ -278,6 +296,7 @@ static size_t decodeWorkspaceStride(int nRows, int nCols)
 
 gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     const unsigned grid = gf_huffman_decode_grid(nTiles);
@@ -606,6 +625,7 @@ gf_status gf_huffman_encode_batch_i32_dev(gf_context *c, void *stream, int codec
                                           uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus,
                                           int predictorMask)
 {
+    GF_CTX_LOCK(c);
     return encodeBatchDev(KIND_HUFFMAN, c, stream, codecIndex, nRows, nCols, nTiles, dValues, dOut, slotStride, dLengths,
                           dPredictors, dStatus, predictorMask);
 }
@@ -615,6 +635,7 @@ gf_status gf_huffman_decode_batch_i32_dev(gf_context *c, void *stream, int nRows
                                           size_t slotStride, const uint32_t *dLengths, int32_t *dValues,
                                           int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     return decodeBatchDev(KIND_HUFFMAN, c, stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths,
                           dValues, dStatus);
 }
@@ -623,6 +644,7 @@ gf_status gf_canon_encode_batch_i32_dev(gf_context *c, void *stream, int codecIn
                                         size_t nTiles, const int32_t *dValues, uint8_t *dOut, size_t slotStride,
                                         uint32_t *dLengths, uint8_t *dPredictors, int32_t *dStatus, int predictorMask)
 {
+    GF_CTX_LOCK(c);
     return encodeBatchDev(KIND_CANON, c, stream, codecIndex, nRows, nCols, nTiles, dValues, dOut, slotStride, dLengths,
                           dPredictors, dStatus, predictorMask);
 }
@@ -631,6 +653,7 @@ gf_status gf_canon_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, 
                                         const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets,
                                         size_t slotStride, const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     return decodeBatchDev(KIND_CANON, c, stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths,
                           dValues, dStatus);
 }
@@ -645,6 +668,7 @@ size_t gf_canon_max_packing(int nRows, int nCols)
 gf_status gf_compact_dev(gf_context *c, void *stream, size_t nTiles, const uint8_t *dSlots, size_t slotStride,
                          const uint32_t *dLengths, uint64_t *dOffsets, uint8_t *dBlob, size_t blobCap)
 {
+    GF_CTX_LOCK(c);
     if (!c || !dSlots || !dLengths || !dOffsets || !dBlob) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (((uintptr_t)dSlots & 15) != 0 || slotStride % 16 != 0) return GF_ERR_ARG;
@@ -656,6 +680,7 @@ gf_status gf_compact_dev(gf_context *c, void *stream, size_t nTiles, const uint8
 gf_status gf_synth_dem_dev(gf_context *c, void *stream, uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                            int64_t tile0, size_t nTiles, int32_t *dValues)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || tilesPerRow < 1 || !dValues) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(gf_launch_synth_dem(seed, nRows, nCols, tilesPerRow, tile0, nTiles, dValues,
@@ -666,6 +691,7 @@ gf_status gf_synth_dem_dev(gf_context *c, void *stream, uint64_t seed, int nRows
 gf_status gf_synth_dem_masked_dev(gf_context *c, void *stream, uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                                   int64_t tile0, size_t nTiles, int maskPerMille, int32_t *dValues)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || tilesPerRow < 1 || !dValues || maskPerMille < 0 || maskPerMille > 1000) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     GF_HIP(gf_launch_synth_dem(seed, nRows, nCols, tilesPerRow, tile0, nTiles, dValues,
@@ -676,6 +702,7 @@ gf_status gf_synth_dem_masked_dev(gf_context *c, void *stream, uint64_t seed, in
 gf_status gf_synth_dem_style_dev(gf_context *c, void *stream, uint64_t seed, int nRows, int nCols, int64_t tilesPerRow,
                                  int64_t tile0, size_t nTiles, int maskPerMille, int style, int32_t *dValues)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || tilesPerRow < 1 || !dValues || maskPerMille < 0 || maskPerMille > 1000) return GF_ERR_ARG;
     if (style != GF_DEM_STYLE_CLASSIC && style != GF_DEM_STYLE_ROUGH) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
@@ -695,6 +722,7 @@ size_t gf_float_planes_bytes(int nRows, int nCols)
 gf_status gf_float_planes_encode_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const float *dValues,
                                      uint8_t *dPlanes, size_t planeStride)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dPlanes || planeStride < gf_float_planes_bytes(nRows, nCols)) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(gf_launch_float_planes_encode((const uint32_t *)dValues, dPlanes, planeStride, nTiles, nRows, nCols,
@@ -705,6 +733,7 @@ gf_status gf_float_planes_encode_dev(gf_context *c, void *stream, int nRows, int
 gf_status gf_float_planes_decode_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const uint8_t *dPlanes,
                                      size_t planeStride, float *dValues)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dPlanes || planeStride < gf_float_planes_bytes(nRows, nCols)) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(gf_launch_float_planes_decode(dPlanes, (uint32_t *)dValues, planeStride, nTiles, nRows, nCols,
@@ -754,6 +783,7 @@ static bool zDeflateUpTo(const uint8_t *in, size_t n, int level, size_t limit, s
 gf_status gf_float_encode_batch_f32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles, const float *values,
                                     int zlibLevel, uint8_t *blob, size_t blobCap, uint64_t *offsets)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     const size_t n = (size_t)nRows * (size_t)nCols, nSign = (n + 7) / 8;
@@ -807,6 +837,7 @@ static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, 
 gf_status gf_float_decode_batch_f32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                     const uint64_t *offsets, float *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (status) return decodeBatchHost(KIND_FLOAT, c, nRows, nCols, nTiles, blob, offsets, (int32_t *)values, status);
     std::vector<int32_t> st(nTiles, GF_OK);
     const gf_status s = decodeBatchHost(KIND_FLOAT, c, nRows, nCols, nTiles, blob, offsets, (int32_t *)values, st.data());
@@ -820,6 +851,7 @@ gf_status gf_float_decode_batch_f32_dev(gf_context *c, void *stream, int nRows, 
                                         size_t blobBytes, const uint64_t *dOffsets, const uint32_t *dLengths, float *dValues,
                                         int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !dBlob || !dOffsets || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     return floatDecodeDev(c, stream ? (hipStream_t)stream : c->stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, dLengths, dValues, dStatus);
@@ -828,6 +860,7 @@ gf_status gf_float_decode_batch_f32_dev(gf_context *c, void *stream, int nRows, 
 gf_status gf_float_encode_f32(gf_context *c, int codecIndex, int nRows, int nCols, const float *values, int zlibLevel,
                               uint8_t *out, size_t outCap, size_t *outLen)
 {
+    GF_CTX_LOCK(c);
     if (!outLen) return GF_ERR_ARG;
     uint64_t offsets[2] = {0, 0};
     const gf_status s = gf_float_encode_batch_f32(c, codecIndex, nRows, nCols, 1, values, zlibLevel, out, outCap, offsets);
@@ -837,6 +870,7 @@ gf_status gf_float_encode_f32(gf_context *c, int codecIndex, int nRows, int nCol
 
 gf_status gf_float_decode_f32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, float *values)
 {
+    GF_CTX_LOCK(c);
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
     const gf_status s = gf_float_decode_batch_f32(c, nRows, nCols, 1, packing, offsets, values, &st);
@@ -853,6 +887,7 @@ gf_status gf_inflate_batch_dev(gf_context *c, void *stream, size_t nStreams, con
                                const uint32_t *inLengths, uint8_t *dOut, const uint64_t *outOffsets, const uint32_t *outCaps,
                                uint32_t *dProduced, int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || (nStreams && (!dIn || !inOffsets || !inLengths || !dOut || !outOffsets || !outCaps || !dProduced || !dStatus)))
         return GF_ERR_ARG;
     if (nStreams == 0) return GF_OK;
@@ -900,6 +935,7 @@ gf_status gf_host_free(void *p)
 
 gf_status gf_dev_malloc(gf_context *c, size_t bytes, void **p)
 {
+    GF_CTX_LOCK(c);
     if (!c || !p) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     GF_HIP(hipMalloc(p, bytes ? bytes : 16));
@@ -908,6 +944,7 @@ gf_status gf_dev_malloc(gf_context *c, size_t bytes, void **p)
 
 gf_status gf_dev_free(gf_context *c, void *p)
 {
+    GF_CTX_LOCK(c);
     if (!c) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     GF_HIP(hipFree(p));
@@ -916,6 +953,7 @@ gf_status gf_dev_free(gf_context *c, void *p)
 
 gf_status gf_dev_memset(gf_context *c, void *p, int value, size_t bytes)
 {
+    GF_CTX_LOCK(c);
     if (!c) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(hipMemsetAsync(p, value, bytes, c->stream));
@@ -925,6 +963,7 @@ gf_status gf_dev_memset(gf_context *c, void *p, int value, size_t bytes)
 
 gf_status gf_dev_upload(gf_context *c, void *d, const void *h, size_t bytes)
 {
+    GF_CTX_LOCK(c);
     if (!c) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
@@ -934,6 +973,7 @@ gf_status gf_dev_upload(gf_context *c, void *d, const void *h, size_t bytes)
 
 gf_status gf_dev_download(gf_context *c, void *h, const void *d, size_t bytes)
 {
+    GF_CTX_LOCK(c);
     if (!c) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     GF_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -945,6 +985,7 @@ gf_status gf_dev_download(gf_context *c, void *h, const void *d, size_t bytes)
 
 gf_status gf_timer_create(gf_context *c, gf_timer **out)
 {
+    GF_CTX_LOCK(c);
     if (!c || !out) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     gf_timer *t = new (std::nothrow) gf_timer();
@@ -1467,8 +1508,10 @@ static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, 
 // per context a page-locked input and output buffer and, per (direction, codec, tile shape, codec index), ONE hipGraph recorded
 // from the same device entry points the batches use -- host-to-device copy of the input, the kernels; the outputs (packing,
 // length, status / cells, status) are written by the kernels straight into the page-locked output buffer -- replayed with one
-// launch and waited for by polling the stream.  The first call of a kind takes the batch path (it loads the code objects and
-// sets the kernels' LDS attributes, which a capture must not do) and records the graph for the next.
+// launch and waited for by polling the stream.  The first call of a kind takes the batch path; the second runs the lean sequence
+// once outside a capture (code objects of the 1,024-thread builds, the kernels' LDS attributes: what a capture must not do) and
+// records the graph.  A capture that fails is remembered (the batch path from then on); graphs are recorded again when a device
+// buffer they hold has moved (g_devBufMoves).
 struct gf_single_graph {
     int dir, kind, nRows, nCols, codecIndex;
     size_t copyBytes;
@@ -1480,15 +1523,43 @@ struct gf_single {
     size_t hInBytes = 0, hOutBytes = 0;
     DevBuf dIn;
     std::vector<gf_single_graph> graphs;
+    uint64_t moves = 0;                                          // g_devBufMoves when the graphs were recorded
     std::vector<std::pair<int, std::pair<int, int>>> warmed;     // (dir * 8 + kind, shape) that ran once through the batch path
+    std::vector<std::pair<int, std::pair<int, int>>> refused;    // ... whose capture failed: the batch path from then on
 };
-void gf_single_destroy(gf_single *sg)
+static void singleDropGraphs(gf_single *sg)
 {
-    if (!sg) return;
     for (auto &g : sg->graphs) {
         (void)hipGraphExecDestroy(g.exec);
         (void)hipGraphDestroy(g.graph);
     }
+    sg->graphs.clear();
+}
+// The graphs hold device addresses of the context's buffers (tree / selection records, flags, workspace, dIn): when any device
+// buffer of the process has moved since they were recorded, they are recorded again.
+static gf_status singleCheckMoves(gf_context *c, gf_single *sg)
+{
+    const uint64_t now = g_devBufMoves.load(std::memory_order_relaxed);
+    if (sg->moves == now || sg->graphs.empty()) {
+        sg->moves = now;
+        return GF_OK;
+    }
+    GF_HIP(hipStreamSynchronize(c->stream));
+    singleDropGraphs(sg);
+    sg->moves = now;
+    return GF_OK;
+}
+static bool singleRefused(gf_single *sg, int key, int nRows, int nCols, bool add = false)
+{
+    for (auto &w : sg->refused)
+        if (w.first == key && w.second.first == nRows && w.second.second == nCols) return true;
+    if (add) sg->refused.push_back({key, {nRows, nCols}});
+    return false;
+}
+void gf_single_destroy(gf_single *sg)
+{
+    if (!sg) return;
+    singleDropGraphs(sg);
     if (sg->hIn) (void)hipHostFree(sg->hIn);
     if (sg->hOut) (void)hipHostFree(sg->hOut);
     sg->dIn.release();
@@ -1502,11 +1573,7 @@ static gf_status singleEnsure(gf_context *c, size_t inBytes, size_t outBytes)
     if (sg->hInBytes < inBytes || sg->hOutBytes < outBytes || sg->dIn.bytes < inBytes) {
         // the graphs hold the old addresses
         GF_HIP(hipStreamSynchronize(c->stream));
-        for (auto &g : sg->graphs) {
-            (void)hipGraphExecDestroy(g.exec);
-            (void)hipGraphDestroy(g.graph);
-        }
-        sg->graphs.clear();
+        singleDropGraphs(sg);
         if (sg->hInBytes < inBytes) {
             if (sg->hIn) (void)hipHostFree(sg->hIn);
             sg->hIn = nullptr;
@@ -1562,7 +1629,9 @@ static gf_status singleEncode(int kind, gf_context *c, int codecIndex, int nRows
     gf_status s = singleEnsure(c, std::max(cells * 4, stride + 16), std::max(stride + 64, cells * 4 + 64));
     if (s != GF_OK) return s;
     gf_single *sg = c->single;
+    if (singleRefused(sg, kind, nRows, nCols)) return GF_ERR_UNSUPPORTED;
     if (!singleWarmed(sg, kind, nRows, nCols)) return GF_ERR_UNSUPPORTED;
+    if ((s = singleCheckMoves(c, sg)) != GF_OK) return s;
     gf_single_graph *g = nullptr;
     for (auto &x : sg->graphs)
         if (x.dir == 0 && x.kind == kind && x.nRows == nRows && x.nCols == nCols && x.codecIndex == codecIndex) g = &x;
@@ -1571,23 +1640,33 @@ static gf_status singleEncode(int kind, gf_context *c, int codecIndex, int nRows
     int32_t *hSt = (int32_t *)(hOut + stride + 4);
     if (!g) {
         if ((s = gf_context_reserve(c, nRows, nCols, 1)) != GF_OK) return s;
+        const uint64_t movesBefore = g_devBufMoves.load(std::memory_order_relaxed);
+        if (movesBefore != sg->moves) {                                       // (the reservation moved a buffer the other graphs hold)
+            if ((s = singleCheckMoves(c, sg)) != GF_OK) return s;
+        }
+        memcpy(sg->hIn, values, cells * 4);
+        auto sequence = [&]() -> gf_status {
+            if (hipMemcpyAsync(sg->dIn.p, sg->hIn, cells * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return GF_ERR_HIP;
+            g_lean = 1;
+            const gf_status r = encodeBatchDev(kind, c, c->stream, codecIndex, nRows, nCols, 1, (const int32_t *)sg->dIn.p, hOut, stride,
+                                               hLen, nullptr, hSt, GF_PM_ALL);
+            g_lean = 0;
+            return r;
+        };
+        // once outside a capture: the lean launches use builds of the kernels (1,024 threads) that the batch path of this shape may
+        // never have touched -- their code objects are loaded and their LDS attributes set here, not inside the capture
+        if ((s = sequence()) != GF_OK) return s;
+        GF_HIP(hipStreamSynchronize(c->stream));
         gf_single_graph ng{0, kind, nRows, nCols, codecIndex, cells * 4, nullptr, nullptr};
         GF_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(sg->dIn.p, sg->hIn, cells * 4, hipMemcpyHostToDevice, c->stream);
-        g_lean = 1;
-        s = e == hipSuccess ? encodeBatchDev(kind, c, c->stream, codecIndex, nRows, nCols, 1, (const int32_t *)sg->dIn.p, hOut, stride, hLen,
-                                             nullptr, hSt, GF_PM_ALL)
-                            : GF_ERR_HIP;
-        g_lean = 0;
+        s = sequence();
         const hipError_t e2 = hipStreamEndCapture(c->stream, &ng.graph);
-        if (s != GF_OK || e2 != hipSuccess || !ng.graph) {
+        const bool moved = g_devBufMoves.load(std::memory_order_relaxed) != movesBefore;   // (a capture must not allocate; if it did, its addresses are void)
+        if (s != GF_OK || e2 != hipSuccess || !ng.graph || moved ||
+            hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
             if (ng.graph) (void)hipGraphDestroy(ng.graph);
             (void)hipGetLastError();
-            return GF_ERR_UNSUPPORTED;
-        }
-        if (hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
-            (void)hipGraphDestroy(ng.graph);
-            (void)hipGetLastError();
+            if (!moved) singleRefused(sg, kind, nRows, nCols, true);          // every later call of this kind: the batch path, directly
             return GF_ERR_UNSUPPORTED;
         }
         sg->graphs.push_back(ng);
@@ -1624,7 +1703,9 @@ static gf_status singleDecode(int kind, gf_context *c, int nRows, int nCols, con
     gf_status s = singleEnsure(c, std::max(cells * 4, stride + 16), std::max(stride + 64, cells * 4 + 64));
     if (s != GF_OK) return s;
     gf_single *sg = c->single;
+    if (singleRefused(sg, 8 + kind, nRows, nCols)) return GF_ERR_UNSUPPORTED;
     if (!singleWarmed(sg, 8 + kind, nRows, nCols)) return GF_ERR_UNSUPPORTED;
+    if ((s = singleCheckMoves(c, sg)) != GF_OK) return s;
     // the copy moves [length, 12 spare bytes, packing]: sized in powers of two so that a few graphs serve every length
     size_t copyBytes = 4096;
     while (copyBytes < len + 16 + 8) copyBytes <<= 1;                         // (+ 8: the kernels read whole words behind the last byte)
@@ -1634,35 +1715,46 @@ static gf_status singleDecode(int kind, gf_context *c, int nRows, int nCols, con
         if (x.dir == 1 && x.kind == kind && x.nRows == nRows && x.nCols == nCols && x.copyBytes == copyBytes) g = &x;
     uint8_t *hIn = (uint8_t *)sg->hIn, *hOut = (uint8_t *)sg->hOut;
     int32_t *hSt = (int32_t *)(hOut + cells * 4);
+    const uint32_t len32 = (uint32_t)len;
+    auto fillInput = [&]() {
+        memcpy(hIn, &len32, 4);
+        memcpy(hIn + 16, packing, len);
+        memset(hIn + 16 + len, 0, std::min<size_t>(8, copyBytes - 16 - len));
+    };
     if (!g) {
         if ((s = gf_context_reserve(c, nRows, nCols, 1)) != GF_OK) return s;
-        gf_single_graph ng{1, kind, nRows, nCols, 0, copyBytes, nullptr, nullptr};
+        const uint64_t movesBefore = g_devBufMoves.load(std::memory_order_relaxed);
+        if (movesBefore != sg->moves) {
+            if ((s = singleCheckMoves(c, sg)) != GF_OK) return s;
+        }
         uint8_t *dIn = (uint8_t *)sg->dIn.p;
+        fillInput();
+        auto sequence = [&]() -> gf_status {
+            if (hipMemcpyAsync(dIn, hIn, copyBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return GF_ERR_HIP;
+            g_lean = 1;
+            const gf_status r = decodeBatchDev(kind, c, c->stream, nRows, nCols, 1, dIn + 16, copyBytes - 16, nullptr, copyBytes - 16,
+                                               (const uint32_t *)dIn, (int32_t *)hOut, hSt, nullptr, nullptr);
+            g_lean = 0;
+            return r;
+        };
+        if ((s = sequence()) != GF_OK) return s;                              // (outside a capture first: see singleEncode)
+        GF_HIP(hipStreamSynchronize(c->stream));
+        gf_single_graph ng{1, kind, nRows, nCols, 0, copyBytes, nullptr, nullptr};
         GF_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(dIn, hIn, copyBytes, hipMemcpyHostToDevice, c->stream);
-        g_lean = 1;
-        s = e == hipSuccess ? decodeBatchDev(kind, c, c->stream, nRows, nCols, 1, dIn + 16, copyBytes - 16, nullptr, copyBytes - 16,
-                                             (const uint32_t *)dIn, (int32_t *)hOut, hSt, nullptr, nullptr)
-                            : GF_ERR_HIP;
-        g_lean = 0;
+        s = sequence();
         const hipError_t e2 = hipStreamEndCapture(c->stream, &ng.graph);
-        if (s != GF_OK || e2 != hipSuccess || !ng.graph) {
+        const bool moved = g_devBufMoves.load(std::memory_order_relaxed) != movesBefore;
+        if (s != GF_OK || e2 != hipSuccess || !ng.graph || moved ||
+            hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
             if (ng.graph) (void)hipGraphDestroy(ng.graph);
             (void)hipGetLastError();
-            return GF_ERR_UNSUPPORTED;
-        }
-        if (hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
-            (void)hipGraphDestroy(ng.graph);
-            (void)hipGetLastError();
+            if (!moved) singleRefused(sg, 8 + kind, nRows, nCols, true);
             return GF_ERR_UNSUPPORTED;
         }
         sg->graphs.push_back(ng);
         g = &sg->graphs.back();
     }
-    const uint32_t len32 = (uint32_t)len;
-    memcpy(hIn, &len32, 4);
-    memcpy(hIn + 16, packing, len);
-    memset(hIn + 16 + len, 0, std::min<size_t>(8, copyBytes - 16 - len));
+    fillInput();
     GF_HIP(hipGraphLaunch(g->exec, c->stream));
     if ((s = singleWait(c->stream)) != GF_OK) return s;
     if (*hSt == GF_K_LEAN_RETRY) return GF_ERR_UNSUPPORTED;                   // a tile the fast kernel leaves to the others: the batch path
@@ -1677,12 +1769,14 @@ gf_status gf_huffman_encode_batch_i32(gf_context *c, int codecIndex, int nRows, 
                                       const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
                                       uint8_t *predictors, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     return encodeBatchHost(KIND_HUFFMAN, c, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, predictors, status);
 }
 
 gf_status gf_huffman_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                       const uint64_t *offsets, int32_t *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     return decodeBatchHost(KIND_HUFFMAN, c, nRows, nCols, nTiles, blob, offsets, values, status);
 }
 
@@ -1690,18 +1784,21 @@ gf_status gf_canon_encode_batch_i32(gf_context *c, int codecIndex, int nRows, in
                                     const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
                                     uint8_t *predictors, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     return encodeBatchHost(KIND_CANON, c, codecIndex, nRows, nCols, nTiles, values, blob, blobCap, offsets, predictors, status);
 }
 
 gf_status gf_canon_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                     const uint64_t *offsets, int32_t *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     return decodeBatchHost(KIND_CANON, c, nRows, nCols, nTiles, blob, offsets, values, status);
 }
 
 gf_status gf_canon_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, uint8_t *out,
                               size_t outCap, size_t *outLen)
 {
+    GF_CTX_LOCK(c);
     if (!outLen) return GF_ERR_ARG;
     uint64_t offsets[2] = {0, 0};
     int32_t st = 0;
@@ -1716,6 +1813,7 @@ gf_status gf_canon_encode_i32(gf_context *c, int codecIndex, int nRows, int nCol
 
 gf_status gf_canon_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values)
 {
+    GF_CTX_LOCK(c);
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
     gf_status s = singleDecode(KIND_CANON, c, nRows, nCols, packing, len, values, &st);
@@ -1729,6 +1827,7 @@ gf_status gf_canon_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t
 gf_status gf_huffman_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values,
                                 uint8_t *out, size_t outCap, size_t *outLen)
 {
+    GF_CTX_LOCK(c);
     if (!outLen) return GF_ERR_ARG;
     uint64_t offsets[2] = {0, 0};
     int32_t st = 0;
@@ -1744,6 +1843,7 @@ gf_status gf_huffman_encode_i32(gf_context *c, int codecIndex, int nRows, int nC
 gf_status gf_huffman_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len,
                                 int32_t *values)
 {
+    GF_CTX_LOCK(c);
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
     gf_status s = singleDecode(KIND_HUFFMAN, c, nRows, nCols, packing, len, values, &st);
@@ -1773,6 +1873,7 @@ size_t gf_lsop12_max_packing(int nRows, int nCols)
 gf_status gf_lsop12_predict_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const int32_t *dValues,
                                 int32_t *dResiduals, size_t resStride, uint32_t *dCoefs, int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || !dValues || !dResiduals || !dCoefs || !dStatus || nRows < 1 || nCols < 1) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
@@ -1790,6 +1891,7 @@ gf_status gf_lsop12_reconstruct_dev(gf_context *c, void *stream, int nRows, int 
                                     const int32_t *dResiduals, size_t resStride, const uint32_t *dCoefs,
                                     const int32_t *dInStatus, int32_t *dValues, int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || !dValues || !dResiduals || !dCoefs || !dStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (nRows < 6 || nCols < 6 || resStride < gf_lsop12_residual_count(nRows, nCols)) return GF_ERR_ARG;
@@ -1803,6 +1905,7 @@ gf_status gf_lsop12_encode_batch_i32_dev(gf_context *c, void *stream, int codecI
                                          int32_t *dStatus, int32_t *dResiduals, size_t resStride, uint32_t *dCoefs,
                                          int32_t *dScratchStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || !dValues || !dOut || !dLengths || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (slotStride % 16 != 0 || ((uintptr_t)dOut & 15) != 0 || slotStride < 64) return GF_ERR_ARG;
@@ -1828,6 +1931,7 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
                                          const uint32_t *dLengths, int32_t *dValues, int32_t *dStatus, int32_t *dResiduals,
                                          size_t resStride, uint32_t *dCoefs, int32_t *dScratchStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || !dBlob || !dLengths || !dValues || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if (((uintptr_t)dBlob & 3) != 0) return GF_ERR_ARG;
@@ -1881,6 +1985,7 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
                                      int deflateEnabled, uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *types,
                                      int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     if (nRows < 6 || nCols < 6) {
@@ -1970,6 +2075,7 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
 gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                      const uint64_t *offsets, int32_t *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
     if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     GF_HIP(hipSetDevice(c->device));
@@ -2013,6 +2119,7 @@ gf_status gf_lsop12_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t
 gf_status gf_lsop12_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, int deflateEnabled,
                                uint8_t *out, size_t outCap, size_t *outLen)
 {
+    GF_CTX_LOCK(c);
     if (!outLen) return GF_ERR_ARG;
     uint64_t offsets[2] = {0, 0};
     int32_t st = 0;
@@ -2025,6 +2132,7 @@ gf_status gf_lsop12_encode_i32(gf_context *c, int codecIndex, int nRows, int nCo
 
 gf_status gf_lsop12_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values)
 {
+    GF_CTX_LOCK(c);
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
     gf_status s = gf_lsop12_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
@@ -2047,6 +2155,7 @@ gf_status gf_m32_encode_batch_i32_dev(gf_context *c, void *stream, int nRows, in
                                       uint8_t *dStreams, size_t subStride, uint32_t *dLengths, uint8_t *dModels,
                                       uint32_t *dSeeds, int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !dValues || !dStreams || !dLengths || !dModels || !dSeeds || !dStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
     if ((size_t)nRows * (size_t)nCols >= (1ull << 28)) return GF_ERR_UNSUPPORTED;
@@ -2070,6 +2179,7 @@ gf_status gf_m32_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, in
                                       size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
                                       int32_t *dValues, int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     return decodeBatchDev(KIND_RAW_M32, c, stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths,
                           dValues, dStatus);
 }
@@ -2238,6 +2348,7 @@ static gf_status deflateEncodeBatchHost(gf_context *c, int codecIndex, int nRows
 gf_status gf_deflate_encode_batch_i32(gf_context *c, int codecIndex, int nRows, int nCols, size_t nTiles, const int32_t *values,
                                       uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *predictors, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     std::vector<std::vector<uint8_t>> packs;
     std::vector<uint8_t> chosen;
@@ -2263,6 +2374,7 @@ gf_status gf_deflate_encode_batch_i32(gf_context *c, int codecIndex, int nRows, 
 gf_status gf_deflate_decode_batch_i32(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                       const uint64_t *offsets, int32_t *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     return decodeBatchHost(KIND_DEFLATE, c, nRows, nCols, nTiles, blob, offsets, values, status);
 }
 
@@ -2270,6 +2382,7 @@ gf_status gf_deflate_decode_batch_i32_dev(gf_context *c, void *stream, int nRows
                                           size_t blobBytes, const uint64_t *dOffsets, size_t slotStride, const uint32_t *dLengths,
                                           int32_t *dValues, int32_t *dStatus)
 {
+    GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !dBlob || !dLengths || !dValues || !dStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     return deflateDecodeDev(c, stream ? (hipStream_t)stream : c->stream, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride,
@@ -2279,6 +2392,7 @@ gf_status gf_deflate_decode_batch_i32_dev(gf_context *c, void *stream, int nRows
 gf_status gf_deflate_encode_i32(gf_context *c, int codecIndex, int nRows, int nCols, const int32_t *values, uint8_t *out,
                                 size_t outCap, size_t *outLen)
 {
+    GF_CTX_LOCK(c);
     if (!outLen) return GF_ERR_ARG;
     uint64_t offsets[2] = {0, 0};
     int32_t st = 0;
@@ -2290,6 +2404,7 @@ gf_status gf_deflate_encode_i32(gf_context *c, int codecIndex, int nRows, int nC
 
 gf_status gf_deflate_decode_i32(gf_context *c, int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values)
 {
+    GF_CTX_LOCK(c);
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t st = 0;
     gf_status s = gf_deflate_decode_batch_i32(c, nRows, nCols, 1, packing, offsets, values, &st);
@@ -2307,6 +2422,7 @@ gf_status gf_codec_master_encode_batch_i32(gf_context *c, const int *codecs, int
                                            const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
                                            uint8_t *codecUsed, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!c || !codecs || nCodecs < 1 || nCodecs > 255 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     const size_t cells = (size_t)nRows * (size_t)nCols;
     for (int k = 0; k < nCodecs; k++)
@@ -2458,6 +2574,7 @@ static gf_status codecMasterDecodeScattered(gf_context *c, const int *codecs, in
 gf_status gf_codec_master_decode_batch_i32(gf_context *c, const int *codecs, int nCodecs, int nRows, int nCols, size_t nTiles,
                                            const uint8_t *blob, const uint64_t *offsets, int32_t *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!c || !codecs || nCodecs < 1 || !blob || !offsets || !values) return GF_ERR_ARG;
     if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     std::vector<int32_t> st(nTiles, GF_ERR_FORMAT);
@@ -2480,6 +2597,7 @@ gf_status gf_tile_payload_encode_batch_i32(gf_context *c, const int *codecs, int
                                            const int32_t *values, uint8_t *blob, size_t blobCap, uint64_t *offsets,
                                            uint8_t *codecUsed)
 {
+    GF_CTX_LOCK(c);
     if (!c || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
     const size_t cells = (size_t)nRows * (size_t)nCols, rawBytes = cells * 4;
     std::vector<uint8_t> packs(nTiles * (rawBytes + 1024) + 64);
@@ -2520,6 +2638,7 @@ gf_status gf_tile_payload_encode_batch_i32(gf_context *c, const int *codecs, int
 gf_status gf_tile_payload_decode_batch_i32(gf_context *c, const int *codecs, int nCodecs, int nRows, int nCols, size_t nTiles,
                                            const uint8_t *blob, const uint64_t *offsets, int32_t *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!c || !blob || !offsets || !values) return GF_ERR_ARG;
     if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     const size_t cells = (size_t)nRows * (size_t)nCols, rawBytes = cells * 4;
@@ -2561,6 +2680,8 @@ static std::once_flag crc32cOnce;
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) as util/GridfourCRC32C.java:330-338 applies it.  The host's crc32
 // instruction (SSE 4.2: eight bytes per step) where there is one, the byte-at-a-time table otherwise (round 3: the table loop
 // alone, ~1 byte per cycle over every record of a batch).
+#if defined(__x86_64__)
+#define GF_HOST_HAS_CRC32_INSN 1
 __attribute__((target("sse4.2"))) static uint32_t crc32cHw(const uint8_t *data, size_t n)
 {
     uint64_t crc = 0xffffffffu;
@@ -2573,11 +2694,14 @@ __attribute__((target("sse4.2"))) static uint32_t crc32cHw(const uint8_t *data, 
     while (n--) crc = __builtin_ia32_crc32qi((uint32_t)crc, *data++);
     return (uint32_t)crc ^ 0xffffffffu;
 }
+#endif
 
 uint32_t gf_crc32c(const uint8_t *data, size_t n)
 {
+#ifdef GF_HOST_HAS_CRC32_INSN
     static const bool hw = __builtin_cpu_supports("sse4.2");
     if (hw) return crc32cHw(data, n);
+#endif
     std::call_once(crc32cOnce, []() {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t x = i;
@@ -2611,6 +2735,7 @@ gf_status gf_tile_record_encode_batch(gf_context *c, const int *codecs, int nCod
                                       int nCols, size_t nTiles, const int32_t *tileIndices, const void *values,
                                       int checksumEnabled, uint8_t *blob, size_t blobCap, uint64_t *offsets, uint8_t *codecUsed)
 {
+    GF_CTX_LOCK(c);
     if (!c || !values || !offsets || !tileIndices || (!blob && blobCap)) return GF_ERR_ARG;
     if (elemType != GF_ELEM_INT && elemType != GF_ELEM_SHORT) return GF_ERR_ARG;
     if (nRows < 1 || nCols < 1) return GF_ERR_ARG;
@@ -2678,6 +2803,7 @@ gf_status gf_tile_record_decode_batch(gf_context *c, const int *codecs, int nCod
                                       size_t nTiles, const uint8_t *blob, const uint64_t *offsets, int verifyChecksum,
                                       int32_t *tileIndices, void *values, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!c || !blob || !offsets || !values) return GF_ERR_ARG;
     if (!offsetsValid(offsets, nTiles)) return GF_ERR_ARG;    // a bad array must not become an out-of-bounds read
     if (elemType != GF_ELEM_INT && elemType != GF_ELEM_SHORT) return GF_ERR_ARG;
@@ -2834,12 +2960,14 @@ static gf_status analyzeBatch(gf_context *c, int nRows, int nCols, size_t nTiles
 gf_status gf_huffman_analyze_batch(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob, const uint64_t *offsets,
                                    gf_codec_stats *stats, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     return analyzeBatch(c, nRows, nCols, nTiles, blob, offsets, stats, nullptr, status);
 }
 
 gf_status gf_huffman_analyze_batch_h2(gf_context *c, int nRows, int nCols, size_t nTiles, const uint8_t *blob,
                                       const uint64_t *offsets, gf_codec_stats *stats, int64_t *pairCounts, int32_t *status)
 {
+    GF_CTX_LOCK(c);
     if (!pairCounts) return GF_ERR_ARG;
     return analyzeBatch(c, nRows, nCols, nTiles, blob, offsets, stats, pairCounts, status);
 }

@@ -2935,7 +2935,8 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             stage0 = staged_fix(stage0, vis, lane);
             stage1 = staged_fix(stage1, vis, 64u + lane);
         }
-        if (lane >= 1u) return;
+        // (the wave stays whole: the walk below reads the staged words out of the other lanes' registers, which is only defined
+        // while those lanes are active.  Everything the walk computes is wave-uniform -- scalar code --; lane 0 alone stores.)
     } else {
         const uint32_t visMine = readable ? min(len, (uint32_t)(HEAD_WORDS * 4)) : 0u;
         // (thirty-two tiles a turn: sixty-four loads in flight, then their stores -- a turn per tile waited for every load on its own)
@@ -2970,8 +2971,9 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     }
     unsigned long long *codes = reinterpret_cast<unsigned long long *>(rec + 8);
     uint8_t *lens = reinterpret_cast<uint8_t *>(rec + 8 + 512), *syms = lens + 256;
+    const bool writer = perWave == 64u || lane == 0u;        // a wave per tile: every lane walks, lane 0 stores
     if (len < 10 || off + len > blobBytes) {                 // the decode kernel rejects the tile before looking here
-        rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
+        if (writer) rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
         return;
     }
     const uint8_t *__restrict__ pk = blob + off;
@@ -2982,8 +2984,8 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
         if (perWave == 1u) {                                 // (i = 10 + 4 k: the staged word k)
             const uint32_t k = (i - 10u) >> 2;
             if (k >= 128u) return 0u;                        // beyond the staged head (= beyond `visible`)
-            // (both registers are read at the lane and the pick is made afterwards: a select between them BEFORE the read would be
-            // evaluated in lane 0 alone, the only one still running)
+            // (both registers are read at the lane and the pick is made afterwards: a select between them BEFORE the read would
+            // pick per lane, not per word)
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)stage0, (int)(k & 63u));
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)stage1, (int)(k & 63u));
             return k < 64u ? lo : hi;
@@ -3064,7 +3066,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             // the leaf behind the run, if its nine bits are in the buffer (else the next turn tops it up and finds a run of none)
             const bool leaf = live && !bad && fhave >= 9u && ((uint32_t)fbuf & 1u) != 0u;
             const uint32_t sym = ((uint32_t)fbuf >> 1) & 0xffu;
-            if (leaf) {
+            if (leaf && writer) {
                 codes[leaves] = __brevll(c) >> (64u - L);
                 lens[leaves] = (uint8_t)L;
                 syms[leaves] = (uint8_t)sym;
@@ -3124,9 +3126,11 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             if (records + 1u > 2u * nLeaves - 1u) { st = GF_K_ERR_BOUNDS; break; }
             const uint32_t r9 = take(9);
             records++;
-            codes[leaves] = __brevll(c) >> (64u - L);
-            lens[leaves] = (uint8_t)L;
-            syms[leaves] = (uint8_t)(r9 >> 1);
+            if (writer) {
+                codes[leaves] = __brevll(c) >> (64u - L);
+                lens[leaves] = (uint8_t)L;
+                syms[leaves] = (uint8_t)(r9 >> 1);
+            }
             symKinds |= kindOf(r9 >> 1);
             maxLen = max(maxLen, L);
             leaves++;
@@ -3142,6 +3146,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
         }
     }
     if (st == GF_K_OK && bp > len * 8u) st = GF_K_ERR_BOUNDS;
+    if (!writer) return;
     rec[0] = (uint32_t)st;
     rec[1] = nLeaves;
     rec[2] = bp;

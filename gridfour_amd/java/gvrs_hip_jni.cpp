@@ -2,7 +2,7 @@
 // directory) and the C ABI of libgvrs_hip.so (include/gvrs_hip_codec.h).
 //
 // Not compiled in the build image (no JDK, no jni.h).  Build on a host with a JDK:
-//   g++ -O2 -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I<repo>/include \
+//   g++ -O2 -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I<repo>/include
 //       gvrs_hip_jni.cpp -L<repo>/gridfour_amd/lib -lgvrs_hip -o libgvrs_hip_jni.so
 // One gf_context per adapter instance; CodecHolder creates one instance per codec
 // (gvrs/CodecHolder.java:208-234) and the decoder may be called from two threads

@@ -71,8 +71,15 @@ const char *gf_last_error(void);
 int gf_device_count(void);
 
 /* One context per (process, device): owns a stream and the scratch workspace.
- * Calls on one context are serialised by the caller; different contexts are
- * independent (this is how tile batches shard over the GPUs of a node).      */
+ * A context may be called from several threads at once, as the reference calls
+ * one codec instance from its tile cache and its decompression assistant
+ * (gvrs/RasterTileCache.java:418-421, TileDecompressionAssistant.java:68-73):
+ * every entry point that takes a context holds the context's lock for its
+ * duration, so such calls run one after the other.  The *_dev entry points
+ * return while their kernels are still queued on the context's stream; a
+ * caller that hands them another stream orders that stream itself.  Different
+ * contexts are independent (this is how tile batches shard over the GPUs of a
+ * node).                                                                      */
 gf_status gf_context_create(int device, gf_context **ctx);
 void gf_context_destroy(gf_context *ctx);
 /* pre-allocates the workspace (decode: M32 spill per resident workgroup, per-tile records of the tree / code-length

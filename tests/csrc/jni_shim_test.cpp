@@ -1,0 +1,239 @@
+// jni_shim_test.cpp -- TEST INFRASTRUCTURE: calls the Java_* functions of gridfour_amd/java/gvrs_hip_jni.cpp the way a JVM would,
+// over the stand-in JNIEnv of tests/csrc/jni_mock/jni.h (the image has no JDK).  The shim is compiled into this program as it is.
+//
+//   jni_shim_test                 -> without a GPU: "no-device", exit code 10 (createNative must raise IllegalStateException)
+//   jni_shim_test <nRows> <nCols> -> with a GPU: every native method once; prints "ok" and the CodecHuffman packing of a fixed
+//                                    tile as hex (the caller compares it with the oracle's bytes)
+#include "../../gridfour_amd/java/gvrs_hip_jni.cpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+namespace {
+
+int failures = 0;
+#define CHECK(cond, what)                                                  \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            printf("FAIL %s:%d %s\n", __FILE__, __LINE__, what);           \
+            failures++;                                                    \
+        }                                                                  \
+    } while (0)
+
+std::vector<int32_t> tileOf(int nRows, int nCols, int salt)
+{
+    std::vector<int32_t> v((size_t)nRows * nCols);
+    for (size_t i = 0; i < v.size(); i++) {
+        const long r = (long)(i / nCols), c = (long)(i % nCols);
+        v[i] = (int32_t)(((long)i * 7919 + salt * 31) % 211 - 100 + r * 3 + ((c * c + salt) % 17));
+    }
+    return v;
+}
+jintArray intsIn(JNIEnv *env, const std::vector<int32_t> &v)
+{
+    jintArray a = env->NewIntArray((jsize)v.size());
+    env->SetIntArrayRegion(a, 0, (jsize)v.size(), (const jint *)v.data());
+    return a;
+}
+std::vector<int32_t> intsOut(jintArray a)
+{
+    std::vector<int32_t> v((size_t)a->length);
+    memcpy(v.data(), a->bytes.data(), v.size() * 4);
+    return v;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    JNIEnv env;
+    jlong h = Java_org_gridfour_hip_CodecHuffmanHip_createNative(&env, nullptr, 0);
+    if (!h) {
+        // no device: the adapter's constructor sees IllegalStateException
+        if (env.pendingClass == "java/lang/IllegalStateException") {
+            printf("no-device %s\n", env.pendingMessage.c_str());
+            return 10;
+        }
+        printf("FAIL createNative returned 0 without an exception\n");
+        return 1;
+    }
+    const int nRows = argc > 2 ? atoi(argv[1]) : 33, nCols = argc > 2 ? atoi(argv[2]) : 65;
+    const std::vector<int32_t> tile = tileOf(nRows, nCols, 0);
+
+    // ---- CodecHuffmanHip.encodeNative / decodeNative
+    jbyteArray pk = Java_org_gridfour_hip_CodecHuffmanHip_encodeNative(&env, nullptr, h, 4, nRows, nCols, intsIn(&env, tile));
+    CHECK(pk && !env.ExceptionCheck(), "encodeNative");
+    if (!pk) return 1;
+    jintArray back = Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(&env, nullptr, h, nRows, nCols, pk);
+    CHECK(back && !env.ExceptionCheck() && intsOut(back) == tile, "decodeNative round trip");
+    // a damaged packing is the reference's IOException, and null comes back
+    {
+        jbyteArray bad = env.NewByteArray(pk->length);
+        bad->bytes = pk->bytes;
+        for (int i = 10; i < 40 && i < bad->length; i++) bad->bytes[(size_t)i] = 0;   // the tree image
+        jintArray r = Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(&env, nullptr, h, nRows, nCols, bad);
+        CHECK(!r && env.pendingClass == "java/io/IOException", "damaged packing -> IOException");
+        env.ExceptionClear();
+    }
+    // a closed adapter (handle 0) is IllegalStateException, not a crash
+    {
+        jintArray r = Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(&env, nullptr, 0, nRows, nCols, pk);
+        CHECK(!r && env.pendingClass == "java/lang/IllegalStateException", "handle 0 -> IllegalStateException");
+        env.ExceptionClear();
+    }
+
+    // ---- HipCodecNative.encode / decode, every kind: 0 CodecHuffman, 1 CodecCanonHuffman, 2 / 3 LSOP12, 4 CodecDeflate
+    for (int kind = 0; kind <= 4; kind++) {
+        jbyteArray p = Java_org_gridfour_hip_HipCodecNative_encode(&env, nullptr, h, kind, 1, nRows, nCols, intsIn(&env, tile));
+        CHECK(p && !env.ExceptionCheck(), "HipCodecNative.encode");
+        if (!p) { env.ExceptionClear(); continue; }
+        if (kind == 0) CHECK(p->length == pk->length && memcmp(p->bytes.data() + 1, pk->bytes.data() + 1, (size_t)pk->length - 1) == 0,
+                             "kind 0 = CodecHuffman's bytes (but for the codec index)");
+        jintArray r = Java_org_gridfour_hip_HipCodecNative_decode(&env, nullptr, h, kind, nRows, nCols, p);
+        CHECK(r && !env.ExceptionCheck() && intsOut(r) == tile, "HipCodecNative.decode round trip");
+        env.ExceptionClear();
+    }
+    // one column: CodecHuffman's predictors index column 1 (ArrayIndexOutOfBoundsException in the reference)
+    {
+        const std::vector<int32_t> thin = tileOf(9, 1, 3);
+        jbyteArray p = Java_org_gridfour_hip_HipCodecNative_encode(&env, nullptr, h, 0, 0, 9, 1, intsIn(&env, thin));
+        CHECK(!p && env.pendingClass == "java/lang/ArrayIndexOutOfBoundsException", "one column -> ArrayIndexOutOfBoundsException");
+        env.ExceptionClear();
+    }
+
+    // ---- floats
+    {
+        std::vector<float> f(tile.size());
+        for (size_t i = 0; i < f.size(); i++) f[i] = (float)tile[i] * 0.25f;
+        jfloatArray fa = env.NewFloatArray((jsize)f.size());
+        env.SetFloatArrayRegion(fa, 0, (jsize)f.size(), f.data());
+        jbyteArray p = Java_org_gridfour_hip_HipCodecNative_encodeFloats(&env, nullptr, h, 2, nRows, nCols, fa, 6);
+        CHECK(p && !env.ExceptionCheck(), "encodeFloats");
+        if (p) {
+            jfloatArray r = Java_org_gridfour_hip_HipCodecNative_decodeFloats(&env, nullptr, h, nRows, nCols, p);
+            CHECK(r && r->length == (jsize)f.size() && memcmp(r->bytes.data(), f.data(), f.size() * 4) == 0, "decodeFloats round trip");
+        }
+        jfloatArray tooShort = env.NewFloatArray(3);
+        jbyteArray q = Java_org_gridfour_hip_HipCodecNative_encodeFloats(&env, nullptr, h, 2, nRows, nCols, tooShort, 6);
+        CHECK(!q && env.pendingClass == "java/lang/ArrayIndexOutOfBoundsException", "short float[] -> ArrayIndexOutOfBoundsException");
+        env.ExceptionClear();
+    }
+
+    // ---- tile records of the default codec list, and back
+    {
+        const int nTiles = 5;
+        std::vector<int32_t> cells, idx;
+        for (int t = 0; t < nTiles; t++) {
+            const std::vector<int32_t> v = tileOf(nRows, nCols, t + 1);
+            cells.insert(cells.end(), v.begin(), v.end());
+            idx.push_back(7 * t + 2);
+        }
+        const std::vector<int32_t> kinds = {GF_CODEC_HUFFMAN, GF_CODEC_DEFLATE};
+        jlongArray offs = env.NewLongArray(nTiles + 1);
+        jbyteArray recs = Java_org_gridfour_hip_HipCodecNative_tileRecords(&env, nullptr, h, intsIn(&env, kinds), GF_ELEM_INT, -32768, nRows,
+                                                                           nCols, intsIn(&env, idx), intsIn(&env, cells), JNI_TRUE, offs);
+        CHECK(recs && !env.ExceptionCheck(), "tileRecords");
+        if (recs) {
+            jintArray gotIdx = env.NewIntArray(nTiles), gotCells = env.NewIntArray((jsize)cells.size()), st = env.NewIntArray(nTiles);
+            Java_org_gridfour_hip_HipCodecNative_tilesFromRecords(&env, nullptr, h, intsIn(&env, kinds), GF_ELEM_INT, nRows, nCols, recs, offs,
+                                                                  JNI_TRUE, gotIdx, gotCells, st);
+            CHECK(!env.ExceptionCheck() && intsOut(gotIdx) == idx && intsOut(gotCells) == cells, "tilesFromRecords round trip");
+            for (int32_t s : intsOut(st)) CHECK(s == 0, "record status");
+            // offsets that run past the record bytes: IllegalArgumentException before anything is read
+            jlongArray wrong = env.NewLongArray(nTiles + 1);
+            wrong->bytes = offs->bytes;
+            ((int64_t *)wrong->bytes.data())[nTiles] += 1000;
+            Java_org_gridfour_hip_HipCodecNative_tilesFromRecords(&env, nullptr, h, intsIn(&env, kinds), GF_ELEM_INT, nRows, nCols, recs, wrong,
+                                                                  JNI_TRUE, gotIdx, gotCells, st);
+            CHECK(env.pendingClass == "java/lang/IllegalArgumentException", "offsets past the records -> IllegalArgumentException");
+            env.ExceptionClear();
+        }
+        env.ExceptionClear();
+    }
+
+    // ---- read-ahead
+    {
+        const std::vector<int32_t> kinds = {GF_CODEC_HUFFMAN};
+        jlong ra = Java_org_gridfour_hip_HipCodecNative_readaheadCreate(&env, nullptr, 0, intsIn(&env, kinds), nRows, nCols, 8);
+        CHECK(ra && !env.ExceptionCheck(), "readaheadCreate");
+        if (ra) {
+            // payload of a tile: what CodecMaster hands out = the packing itself for a compressed tile; its first byte is the
+            // codec's index in the list (CodecMaster.java:150-169): 0 here
+            jbyteArray pk0 = Java_org_gridfour_hip_CodecHuffmanHip_encodeNative(&env, nullptr, h, 0, nRows, nCols, intsIn(&env, tile));
+            CHECK(pk0 && !env.ExceptionCheck(), "encodeNative, codec index 0");
+            for (int t = 0; t < 3 && pk0; t++) Java_org_gridfour_hip_HipCodecNative_readaheadSubmit(&env, nullptr, ra, 100 + t, pk0);
+            jintArray indices = env.NewIntArray(8), cellsOut = env.NewIntArray((jsize)(8 * tile.size())), st = env.NewIntArray(8);
+            int got = 0;
+            for (int turn = 0; turn < 3 && got < 3; turn++) {
+                const jint n = Java_org_gridfour_hip_HipCodecNative_readaheadTake(&env, nullptr, ra, 100 + got, indices, cellsOut, st);
+                CHECK(!env.ExceptionCheck(), "readaheadTake");
+                for (jint i = 0; i < n; i++) {
+                    CHECK(((int32_t *)st->bytes.data())[i] == 0, "read-ahead tile status");
+                    CHECK(memcmp(cellsOut->bytes.data() + (size_t)i * tile.size() * 4, tile.data(), tile.size() * 4) == 0, "read-ahead tile cells");
+                }
+                got += n;
+            }
+            CHECK(got == 3, "read-ahead handed over three tiles");
+            CHECK(Java_org_gridfour_hip_HipCodecNative_readaheadPending(&env, nullptr, ra) == 0, "nothing pending");
+            jintArray small = env.NewIntArray(4);
+            Java_org_gridfour_hip_HipCodecNative_readaheadTake(&env, nullptr, ra, -1, indices, small, st);
+            CHECK(env.pendingClass == "java/lang/IllegalArgumentException", "short cells[] -> IllegalArgumentException");
+            env.ExceptionClear();
+            Java_org_gridfour_hip_HipCodecNative_readaheadDestroy(&env, nullptr, ra);
+        }
+        env.ExceptionClear();
+    }
+
+    // ---- several GPUs from one JVM (here: the one device, twice)
+    {
+        const std::vector<int32_t> devs = {0, 0};
+        jlong m = Java_org_gridfour_hip_HipCodecNative_multiCreate(&env, nullptr, intsIn(&env, devs));
+        CHECK(m && !env.ExceptionCheck(), "multiCreate");
+        if (m) {
+            const int nTiles = 6;
+            std::vector<int32_t> cells;
+            for (int t = 0; t < nTiles; t++) {
+                const std::vector<int32_t> v = tileOf(nRows, nCols, 20 + t);
+                cells.insert(cells.end(), v.begin(), v.end());
+            }
+            jlongArray offs = env.NewLongArray(nTiles + 1);
+            jbyteArray preds = env.NewByteArray(nTiles);
+            jintArray st = env.NewIntArray(nTiles);
+            jbyteArray blob = Java_org_gridfour_hip_HipCodecNative_multiHuffmanEncode(&env, nullptr, m, 0, nRows, nCols, intsIn(&env, cells), offs,
+                                                                                      preds, st);
+            CHECK(blob && !env.ExceptionCheck(), "multiHuffmanEncode");
+            if (blob) {
+                jintArray out = env.NewIntArray((jsize)cells.size());
+                Java_org_gridfour_hip_HipCodecNative_multiHuffmanDecode(&env, nullptr, m, nRows, nCols, blob, offs, out, st);
+                CHECK(!env.ExceptionCheck() && intsOut(out) == cells, "multiHuffmanDecode round trip");
+            }
+            Java_org_gridfour_hip_HipCodecNative_multiDestroy(&env, nullptr, m);
+        }
+        env.ExceptionClear();
+    }
+
+    // ---- ONE adapter instance, its decoder called from two threads (gvrs/TileDecompressionAssistant.java:68-73): a JNIEnv per thread
+    {
+        int bad[2] = {0, 0};
+        auto work = [&](int who) {
+            JNIEnv mine;
+            for (int k = 0; k < 40; k++) {
+                jintArray r = Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(&mine, nullptr, h, nRows, nCols, pk);
+                if (!r || mine.ExceptionCheck() || intsOut(r) != tile) bad[who]++;
+            }
+        };
+        std::thread a(work, 0), b(work, 1);
+        a.join();
+        b.join();
+        CHECK(bad[0] == 0 && bad[1] == 0, "two threads on one adapter");
+    }
+
+    CHECK(env.outOfBounds == 0, "a region call outside its array");
+    Java_org_gridfour_hip_CodecHuffmanHip_destroyNative(&env, nullptr, h);
+    if (failures) return 1;
+    printf("ok %d", (int)pk->length);
+    for (jsize i = 0; i < pk->length; i++) printf(" %02x", pk->bytes[(size_t)i]);
+    printf("\n");
+    return 0;
+}
