@@ -112,6 +112,7 @@ struct gf_context {
     // instance from several threads (gvrs/RasterTileCache.java:418-421, TileDecompressionAssistant.java:68-73), and a context's
     // scratch buffers, staging slots and recorded graphs are one set.  Recursive: entry points call each other.
     std::recursive_mutex mu;
+    GfSideStream side{nullptr, nullptr, nullptr};   // second stream + fork / join events: the fast decode kernel's roomy run (gvrs_kernels.h)
     struct gf_host_pipe *pipe = nullptr;        // pipelined staging of the host-memory batch entry points (created on first use)
     struct gf_single *single = nullptr;         // one tile per call: page-locked buffers and replayed graphs (created on first use)
 };
@@ -238,6 +239,23 @@ gf_status gf_context_create(int device, gf_context **out)
         delete c;
         return s;
     }
+    // (words 2 and 3 -- count and cursor of the roomy decode run's tile list -- start at zero; the kernels leave them so)
+    if (hipMemset(c->flags.p, 0, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        c->flags.release();
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return GF_ERR_HIP;
+    }
+    // (the side stream is an optimisation: without it the roomy run follows the first one on the caller's stream)
+    if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+        if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
+        c->side = GfSideStream{nullptr, nullptr, nullptr};
+    }
     *out = c;
     return GF_OK;
 }
@@ -272,6 +290,12 @@ void gf_context_destroy(gf_context *c)
     c->dInflOut.release();
     c->dInflMeta.release();
     gf_host_pipe_destroy(c->pipe);
+    if (c->side.stream) {
+        (void)hipStreamSynchronize(c->side.stream);
+        (void)hipEventDestroy(c->side.fork);
+        (void)hipEventDestroy(c->side.join);
+        (void)hipStreamDestroy(c->side.stream);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -300,7 +324,7 @@ gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
     if (!c || nRows < 1 || nCols < 1) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     const unsigned grid = gf_huffman_decode_grid(nTiles);
-    gf_status s = c->trees.ensure(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16);
+    gf_status s = c->trees.ensure(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16 + nTiles * 4);
     if (s != GF_OK) return s;
     if ((s = c->packRecs.ensure(nTiles * std::max((size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS, gf_canon_pack_rec_words() + gf_canon_stat_words()) * 4 + 16)) != GF_OK) return s;
     return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
@@ -415,15 +439,30 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     a.lean = g_lean;
     if (kind == KIND_HUFFMAN) {
         // tree pre-pass: one lane per tile walks the serialised tree; the decode kernel starts from the leaf records
-        const size_t need = nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16;
+        const size_t need = nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16 + nTiles * 4;      // (+ the roomy run's tile list)
         if (c->trees.bytes < need) {
             GF_HIP(hipSetDevice(c->device));               // not capture-safe either: gf_context_reserve sizes this too
             gf_status s = c->trees.ensure(need);
             if (s != GF_OK) return s;
         }
+        uint32_t *roomyList = (uint32_t *)c->trees.p + nTiles * (size_t)GF_TREE_REC_WORDS + 4;
         if (!analysis) a.retryFlag = (uint32_t *)c->flags.p;
+        uint32_t fastBytes = 0, roomyBytes = 0;
+        if (a.retryFlag && !a.lean) {
+            // the fast kernel runs twice: the usual LDS budget (1.125 M32 bytes per cell) and, for the tiles that outgrow it, two bytes
+            // per cell; the pre-pass sorts the tiles
+            const size_t cells = (size_t)nRows * (size_t)nCols;
+            fastBytes = gf_huffman_decode_lds_m32(nRows, nCols);
+            const size_t roomy = std::min<size_t>(98304, (2 * cells + 1024 + 31) & ~(size_t)31);
+            roomyBytes = roomy > fastBytes ? (uint32_t)roomy : 0u;
+#ifdef GF_DEC_NO_ROOMY                                              // (experiment builds)
+            roomyBytes = 0u;
+#endif
+        }
+        a.ldsM32Roomy = roomyBytes;
         GF_HIP(gf_launch_huffman_parse_trees(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
-                                             stream ? (hipStream_t)stream : c->stream, a.retryFlag));
+                                             stream ? (hipStream_t)stream : c->stream, a.retryFlag, fastBytes, roomyBytes, roomyList));
+        a.roomyList = roomyList;
         a.trees = (const uint32_t *)c->trees.p;
         a.flagsCleared = a.retryFlag ? 1 : 0;
     }
@@ -465,15 +504,6 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     } else {
         a.ldsM32Bytes = gf_huffman_decode_lds_m32(nRows, nCols);
         a.ldsTextBytes = gf_huffman_decode_lds_text(nRows, nCols);
-        if (a.retryFlag) {
-            // a second run of the fast kernel with LDS for two M32 bytes per cell, for the tiles that outgrow the usual 1.125
-            const size_t cells = (size_t)nRows * (size_t)nCols;
-            const size_t roomy = std::min<size_t>(98304, (2 * cells + 1024 + 31) & ~(size_t)31);
-            a.ldsM32Roomy = roomy > a.ldsM32Bytes ? (uint32_t)roomy : 0u;
-#ifdef GF_DEC_NO_ROOMY                                              // (experiment builds)
-            a.ldsM32Roomy = 0u;
-#endif
-        }
         // Occupancy is set by LDS (M32 stream + start bitmap + tables per workgroup), handed out in 1,280-byte steps, and the kernel
         // gains from every wave a CU can hold (tools/occupancy_sweep.sh).  Two builds of the same source: 256 threads (two Huffman
         // cursors per thread in lockstep, the leaner one per wave) and 512 threads (one cursor per thread, 64 VGPRs, up to four
@@ -495,9 +525,13 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         // one tile per call: the workgroup is alone on the chip and every phase is a latency chain -- the widest build (120x150:
         // 89 -> 82 us per call against the 512-thread build, 111 with 256 threads)
         if (a.lean) threads = 1024;
-        if (threads == 1024) GF_HIP(gf_launch_huffman_decode_t1024(a, stream ? (hipStream_t)stream : c->stream, grid));
-        else if (threads == 512) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid));
-        else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid));
+        const GfSideStream *side = c->side.stream ? &c->side : nullptr;
+#ifdef GF_DEC_ROOMY_BEHIND                                          // (experiment builds: the roomy run behind the first, as in round 4)
+        side = nullptr;
+#endif
+        if (threads == 1024) GF_HIP(gf_launch_huffman_decode_t1024(a, stream ? (hipStream_t)stream : c->stream, grid, side));
+        else if (threads == 512) GF_HIP(gf_launch_huffman_decode_t512(a, stream ? (hipStream_t)stream : c->stream, grid, side));
+        else GF_HIP(gf_launch_huffman_decode(a, stream ? (hipStream_t)stream : c->stream, grid, side));
     }
     return GF_OK;
 }

@@ -2376,36 +2376,53 @@ constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel lea
 //   DEC_ANALYZE  CodecHuffman.analyze: statistics instead of values.
 // The general body is several times the size of the fast one; run for every tile it kept the instruction cache of a CU
 // (shared by the workgroups of different phases) missing.
-enum { DEC_GENERAL = 0, DEC_ANALYZE = 1, DEC_FAST = 2 };
+//   DEC_FAST_ROOMY  (round 5) the fast body once more for the tiles the pre-pass marked GF_TREE_ROOMY (M32 stream or packing
+//                beyond the usual LDS buffer: tiles dense in multi-byte values), launched with LDS for two bytes per cell BESIDE
+//                the fast run, on the other stream.  A few persistent workgroups that draw their tiles from the pre-pass's list
+//                (GfDecodeArgs::roomyList, an atomic cursor): a tile-indexed grid would need a 55 KB hole in some CU's LDS for
+//                every one of its thousands of workgroups, empty or not, while the fast run refills every 40 KB hole at once --
+//                measured, such a run crawled beside the fast one and ended after it.  An instantiation of its own: the loop
+//                around the body costs the one-tile-per-workgroup form 5-25 % (round 4).
+enum { DEC_GENERAL = 0, DEC_ANALYZE = 1, DEC_FAST = 2, DEC_FAST_ROOMY = 3 };
 
 template <int MODE>
-__global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GENERAL) void k_huffman_decode(GfDecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GENERAL) void k_huffman_decode(GfDecodeArgs a)
 {
     __shared__ DecShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
     constexpr bool ANALYZE = MODE == DEC_ANALYZE;
-    constexpr bool FAST = MODE == DEC_FAST;
+    constexpr bool ROOMY = MODE == DEC_FAST_ROOMY;
+    constexpr bool FAST = MODE == DEC_FAST || ROOMY;
+    constexpr int OWNER = MODE;                                       // (the Huffman passes: one copy per kernel, so that each inlines its own)
 
     const int tid = threadIdx.x, wave = (int)gf_wave_id();
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(a.blob);
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
     if constexpr (MODE == DEC_GENERAL) {
+        // (the last kernel of a CodecHuffman batch: the roomy list's count and cursor are zero again for the next pre-pass)
+        if (a.retryFlag && a.ldsM32Roomy && blockIdx.x == 0 && tid == 0) { a.retryFlag[2] = 0u; a.retryFlag[3] = 0u; }
         if (a.retryFlag && a.retryFlag[a.ldsM32Roomy ? 1 : 0] == 0u) return;   // the fast kernel decoded every tile
     }
-    if constexpr (MODE == DEC_FAST) {
-        if (a.retryPass && a.retryFlag[0] == 0u) return;             // second run: nothing was left behind
-    }
+    // the roomy run's tiles: entry i of the pre-pass's list, i drawn from the cursor (all threads call; ~0 = the list is exhausted)
+    // (the draw travels through a word of S that is free between tiles -- a __shared__ word of its own would be LDS of EVERY
+    // instantiation, and the 512-thread build's 120x150 workgroup sits exactly on its 40 KB step: four workgroups per CU, or three)
+    auto roomy_next = [&]() -> size_t {
+        __syncthreads();                                             // (the tile before is finished: S and the dynamic LDS are free)
+        if (tid == 0) S.carry = atomicAdd(a.retryFlag + 3, 1u);
+        __syncthreads();
+        const uint32_t i = S.carry;
+        return i < min(a.retryFlag[2], (uint32_t)a.nTiles) ? (size_t)a.roomyList[i] : ~(size_t)0;
+    };
 
-    GF_FOR_TILES(t, a.nTiles, MODE == DEC_FAST) {                     // the fast kernel: one tile per workgroup, no loop (it never
+    for (size_t t = ROOMY ? roomy_next() : (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x; t < a.nTiles;
+         t = ROOMY ? roomy_next() : MODE == DEC_FAST ? ~(size_t)0 : t + gridDim.x) {
+                                                                      // the fast kernel: one tile per workgroup, no loop (it never
                                                                       // touches the per-workgroup workspace; a second run that walks
                                                                       // the tiles with a small grid was measured in round 4: the
                                                                       // loop costs the first run 5 % at 120x150 and 25 % at 200x200)
         if constexpr (MODE == DEC_GENERAL) {
             if (a.retryFlag && a.status[t] != GF_K_RETRY) continue;
-        }
-        if constexpr (MODE == DEC_FAST) {
-            if (a.retryPass && a.status[t] != GF_K_RETRY) continue;
         }
         const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
         const uint32_t len = a.lengths[t];
@@ -2477,9 +2494,17 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         else if (nM32 < nStream) early = GF_K_ERR_BOUNDS;               // M32 reads run off codeM32s
         const FusedPlan plan = fused_plan(nR, nC, model);
         if constexpr (FAST) {
+            // (first run: a tile of the roomy run is not touched -- not even its status, which the other run writes meanwhile;
+            // the one-tile-per-call path has no second run: the tile keeps GF_K_RETRY and the caller sees to it)
+            const uint32_t rec0 = PRE ? preRec[0] : (a.trees + t * GF_TREE_REC_WORDS)[0];
+            const uint32_t rec3 = PRE ? preRec[3] : (a.trees + t * GF_TREE_REC_WORDS)[3];
+            if (!ROOMY && a.ldsM32Roomy && !a.lean && rec0 == (uint32_t)GF_K_OK && (rec3 & GF_TREE_ROOMY)) {
+                __syncthreads();
+                continue;
+            }
             if (early == GF_K_OK && (nM32 > a.ldsM32Bytes || !plan.ring)) {
                 early = GF_K_RETRY;
-                if (tid == 0) atomicOr(a.retryFlag + (a.retryPass ? 1 : 0), 1u);
+                if (tid == 0) atomicOr(a.retryFlag + (a.ldsM32Roomy ? 1 : 0), 1u);
             }
         }
         if (early != GF_K_OK) {
@@ -2552,7 +2577,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             if (S.maxLen > 32u || S.skipLen != 0u || (pkWords + FAST_TEXT_PAD) * 4u > a.ldsM32Bytes) {
                 if (tid == 0) {
                     a.status[t] = GF_K_RETRY;
-                    atomicOr(a.retryFlag + (a.retryPass ? 1 : 0), 1u);
+                    atomicOr(a.retryFlag + (a.ldsM32Roomy ? 1 : 0), 1u);
                 }
                 __syncthreads();
                 continue;
@@ -2616,7 +2641,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 const uint32_t sh0 = (uint32_t)(off * 8ull) & 31u;
                 const uint32_t pkWords = (sh0 + endBit + 31u) >> 5;          // words that hold the packing
                 if constexpr (FAST) {
-                    tileStatus = huffman_to_m32_fast<MODE>(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
+                    tileStatus = huffman_to_m32_fast<OWNER>(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
                                                            sh0, reinterpret_cast<uint32_t *>(ldsDyn), pkWords, lut2,
                                                            reinterpret_cast<const unsigned long long *>(a.trees + t * GF_TREE_REC_WORDS + 8),
 #ifdef GF_DIAG
@@ -2644,7 +2669,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                     cur.sh0 = sh0;
                     cur.S = &S;
                     cur.lut2 = lut2;
-                    tileStatus = huffman_to_m32<MODE>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                    tileStatus = huffman_to_m32<OWNER>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
                 } else {
                     HuffCursorT<const uint32_t *> cur;
                     cur.base32 = w32 + baseWord;
@@ -2652,7 +2677,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE == 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                     cur.sh0 = sh0;
                     cur.S = &S;
                     cur.lut2 = lut2;
-                    tileStatus = huffman_to_m32<MODE>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
+                    tileStatus = huffman_to_m32<OWNER>(S, cur, textStart, endBit, nM32, m32, dbg, warmBits);
                 }
             }
             if (tileStatus != GF_K_OK) return tileStatus;
@@ -2888,7 +2913,8 @@ template <unsigned perWave>                                 // lanes of a wave t
 __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__restrict__ blob, size_t blobBytes,
                                                             const uint64_t *__restrict__ offsets, size_t slotStride,
                                                             const uint32_t *__restrict__ lengths, uint32_t *__restrict__ trees,
-                                                            size_t nTiles, uint32_t *__restrict__ clearFlags)
+                                                            size_t nTiles, uint32_t *__restrict__ clearFlags, uint32_t fastBytes,
+                                                            uint32_t roomyBytes, uint32_t *__restrict__ roomyList)
 {
     static_assert(perWave == 1u || perWave == 64u, "a wave walks one tree or sixty-four");
     const uint32_t lane = threadIdx.x;
@@ -3147,10 +3173,23 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     }
     if (st == GF_K_OK && bp > len * 8u) st = GF_K_ERR_BOUNDS;
     if (!writer) return;
+    // Which run of the fast decode kernel takes the tile (round 5): what that kernel needs in its M32 buffer is the stream (nM32
+    // bytes: bytes 6..9 of the header, CodecHuffman.java:122-124) and, during the Huffman pass, the packing's words plus padding.
+    // A tile that outgrows the usual buffer and fits the roomy one is marked here, before either run starts.
+    uint32_t roomy = 0;
+    if (roomyBytes > fastBytes && st == GF_K_OK && roomyList && clearFlags) {
+        const uint32_t nM32 = reinterpret_cast<const PackedWord *>(pk + 6)->v;           // (len >= 10)
+        const uint32_t pkWords = (((uint32_t)(off * 8ull) & 31u) + len * 8u + 31u) >> 5;
+        const uint64_t need = max((uint64_t)nM32, ((uint64_t)pkWords + FAST_TEXT_PAD) * 4u);
+        roomy = (need > fastBytes && need <= roomyBytes) ? GF_TREE_ROOMY : 0u;
+        // ... and listed for the roomy run's workgroups (clearFlags[2]: the count, zero when the pre-pass starts: the general
+        // decode kernel of the batch before left it so)
+        if (roomy) roomyList[atomicAdd(clearFlags + 2, 1u)] = (uint32_t)t;
+    }
     rec[0] = (uint32_t)st;
     rec[1] = nLeaves;
     rec[2] = bp;
-    rec[3] = maxLen | symKinds;
+    rec[3] = maxLen | symKinds | roomy;
     rec[4] = (uint32_t)uniformSym;
     rec[5] = skipLen;
     rec[6] = (uint32_t)skipPath;
@@ -3214,7 +3253,7 @@ size_t gf_huffman_decode_lds_per_wg(const GfDecodeArgs &a)
     return sizeof(DecShared) + decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
 }
 
-hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid)
+hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid, const GfSideStream *side)
 {
     if (a.nTiles == 0) return hipSuccess;
     const size_t dyn = decodeDynLds(a.ldsM32Bytes, a.ldsTextBytes);
@@ -3230,21 +3269,45 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         // CodecHuffman batches: the fast kernel first; the general one picks up what that one marked (and returns at once
         // when nothing is marked)
         const size_t dynRoomy = a.ldsM32Roomy ? decodeDynLds(a.ldsM32Roomy, a.ldsTextBytes) : 0;
-        if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST>, dyn > dynRoomy ? dyn : dynRoomy, optF)) != hipSuccess) return e;
+        if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST>, dyn, optF)) != hipSuccess) return e;
         GfDecodeArgs f = a;
-        f.retryPass = 0;
         if (a.lean) {
             // the one-tile-per-call path: the fast kernel alone (a tile it leaves behind keeps GF_K_RETRY; the caller sees to it)
             hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
             return hipGetLastError();
         }
         if (!a.flagsCleared && (e = hipMemsetAsync(a.retryFlag, 0, 8, stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
+        // The roomy run -- the tiles the pre-pass marked GF_TREE_ROOMY, with LDS for two M32 bytes per cell; the workgroups of
+        // the other tiles leave at once -- BESIDE the first run (round 5): it is a few hundred tiles of a rough batch at two
+        // workgroups per CU, a chain of latencies that took 0.33 ms behind the first run's 1.2.  The roomy run stays on the
+        // caller's stream, directly behind the pre-pass, and the FIRST run goes to the context's side stream: the roomy workgroups
+        // must reach the CUs first -- once four workgroups of the first run hold a CU's LDS (4 x 40 KB), a 55 KB workgroup finds
+        // no room until two of them end together, i.e. until the first run drains (measured: the other order gained 0.06 ms of
+        // the 0.33).
+        // (a small batch -- BASELINE config 2: 1,024 tiles, 0.18 ms per decode -- loses more to the two hand-overs between the
+        // streams, ~10 us each, than the roomy run could hide: 0.183 -> 0.201 ms measured; there the runs follow one another)
+        const bool beside = a.ldsM32Roomy && side && side->stream && a.nTiles >= 4096;
+        GfDecodeArgs r = f;
+        r.ldsM32Bytes = a.ldsM32Roomy;
+        // (persistent workgroups: as many as the chip holds of them -- LDS in 1,280-byte steps, 256 CUs -- and never more than tiles)
+        static GfDynLdsOptIn optR;
+        unsigned roomyGrid = 1;
         if (a.ldsM32Roomy) {
-            // the tiles that outgrew their LDS once more, with room (the workgroups of the others leave at once)
-            f.ldsM32Bytes = a.ldsM32Roomy;
-            f.retryPass = 1;
-            hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dynRoomy, stream, f);
+            if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST_ROOMY>, dynRoomy, optR)) != hipSuccess) return e;
+            const size_t step = 1280, per = (sizeof(DecShared) + dynRoomy + 64 + step - 1) / step * step;
+            const size_t perCu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / per, 2048 / DEC_THREADS));
+            roomyGrid = (unsigned)std::min<size_t>(a.nTiles, perCu * 256);
+        }
+        if (beside) {
+            if ((e = hipEventRecord(side->fork, stream)) != hipSuccess) return e;            // (behind the pre-pass)
+            if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_huffman_decode<DEC_FAST_ROOMY>, dim3(roomyGrid), dim3(DEC_THREADS), dynRoomy, stream, r);
+            hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, side->stream, f);
+            if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(stream, side->join, 0)) != hipSuccess) return e;
+        } else {
+            if (a.ldsM32Roomy) hipLaunchKernelGGL(k_huffman_decode<DEC_FAST_ROOMY>, dim3(roomyGrid), dim3(DEC_THREADS), dynRoomy, stream, r);
+            hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
         }
     }
     hipLaunchKernelGGL(k_huffman_decode<DEC_GENERAL>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
@@ -3264,15 +3327,16 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
 }
 
 hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
-                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream, uint32_t *clearFlags)
+                                         const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream, uint32_t *clearFlags,
+                                         uint32_t fastBytes, uint32_t roomyBytes, uint32_t *roomyList)
 {
     if (nTiles == 0) return hipSuccess;
     if (gf_prepass_tiles_per_wave(nTiles) == 1u)
         hipLaunchKernelGGL(k_huffman_parse_trees<1>, dim3((unsigned)nTiles), dim3(64), 0, stream, blob, blobBytes, offsets, slotStride,
-                           lengths, trees, nTiles, clearFlags);
+                           lengths, trees, nTiles, clearFlags, fastBytes, roomyBytes, roomyList);
     else
         hipLaunchKernelGGL(k_huffman_parse_trees<64>, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
-                           slotStride, lengths, trees, nTiles, clearFlags);
+                           slotStride, lengths, trees, nTiles, clearFlags, fastBytes, roomyBytes, roomyList);
     return hipGetLastError();
 }
 #endif  // GF_DEC_VARIANT

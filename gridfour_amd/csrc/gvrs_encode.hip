@@ -427,7 +427,7 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
         // of a residual to keep across the scan
         uint64_t cl[CPT];
         uint32_t xs[PLAIN ? 1 : CPT];
-        uint32_t myBits = 0, multi = 0;
+        uint32_t myBits = 0, multi = 0, hard = 0;
         if (i0 < segEnd) {
             Cells8 Q;
             load_cells8(tile, nC, nCells, i0, Q);
@@ -444,16 +444,31 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
                 if (!PLAIN && emit && !single) multi |= 1u << j;
                 if (++c == nC) c = 0;
             }
-            if (!PLAIN && multi) {                                    // continuation bytes (rare)
+            if (!PLAIN && multi) {                                    // continuation bytes
+                // (round 5) a value of two or three bytes -- what rough terrain has -- becomes ONE code here: the codes of its bytes
+                // joined in stream order, at most 56 bits, in the cell's (code, length) pair; the emission below then sees eight
+                // codes whatever their origin.  Longer values, or joins beyond 56 bits, stay `hard`: first byte in the pair, the
+                // rest through the bit sink.
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     if ((multi >> j) & 1u) {
                         const uint32_t x = xs[PLAIN ? 0 : j];
                         uint32_t b1, b2;
                         const uint32_t n = m32_wide_bytes(x, &b1, &b2);
+                        const uint32_t l0 = (uint32_t)(cl[j] >> 56);
                         if (n <= 3u) {
-                            myBits += (uint32_t)(tab[b1] >> 56) + (n == 3u ? (uint32_t)(tab[b2] >> 56) : 0u);
+                            const uint64_t e1 = tab[b1], e2 = n == 3u ? tab[b2] : 0ull;
+                            const uint32_t l1 = (uint32_t)(e1 >> 56), l2 = (uint32_t)(e2 >> 56), lt = l0 + l1 + l2;
+                            myBits += l1 + l2;
+                            if (lt <= 56u) {
+                                const uint64_t c = (cl[j] & 0x00ffffffffffffffull) | ((e1 & 0x00ffffffffffffffull) << l0) |
+                                                   ((e2 & 0x00ffffffffffffffull) << (l0 + l1));
+                                cl[j] = c | ((uint64_t)lt << 56);
+                            } else {
+                                hard |= 1u << j;
+                            }
                         } else {
+                            hard |= 1u << j;
                             for (uint32_t k = 1; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, (int)n, (int)k)] >> 56);
                         }
                     }
@@ -472,23 +487,41 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (bits + total > capBits) { fits = false; break; }         // wave-uniform
         // the usual lane -- eight one-byte values whose codes make two groups of four of at most 32 bits each -- joins its codes
-        // in registers (GF_JOIN8_OR, gvrs_encode_common.h); the others go through the bit sink
+        // in registers (GF_JOIN8_OR, gvrs_encode_common.h).  Round 5: a lane with longer codes -- a rare symbol, a joined
+        // multi-byte value -- joins them in PAIRS of at most 64 bits and ORs every pair into the window as three words
+        // (GF_JOIN2_OR64): on rough terrain some lane of nearly every wave is such a lane, and through the bit sink (a branch or
+        // two per code, the whole wave waiting) it made the packer 2.2 times the smooth batch's.  What is left to the sink: values
+        // of four bytes and more, joins beyond 56 bits, a pair beyond 64.
 #define GF_LN(j) ((uint32_t)(cl[j] >> 56))
 #define GF_CD(j) ((uint32_t)cl[j])
         const uint32_t n01 = GF_LN(0) + GF_LN(1), n45 = GF_LN(4) + GF_LN(5);
-        const uint32_t n0 = n01 + GF_LN(2) + GF_LN(3), n1 = n45 + GF_LN(6) + GF_LN(7);
+        const uint32_t n23 = GF_LN(2) + GF_LN(3), n67 = GF_LN(6) + GF_LN(7);
+        const uint32_t n0 = n01 + n23, n1 = n45 + n67;
         static_assert(CPT == 8, "the register path joins eight codes");
         if ((PLAIN || multi == 0u) && n0 <= 32u && n1 <= 32u) {
             GF_JOIN8_OR(wwin, bits + incl - myBits, GF_CD, GF_LN, n01, n45, n0);
 #undef GF_LN
 #undef GF_CD
+#ifdef GF_PACK_NO_PAIRS                                             // (experiment builds: tools/ab.sh)
+        } else if (false) {
+#else
+        } else if (hard == 0u && max(max(n01, n23), max(n45, n67)) <= 64u) {
+#endif
+            uint32_t pos = bits + incl - myBits;
+#pragma unroll
+            for (int q = 0; q < CPT; q += 2) {
+                const uint32_t la = (uint32_t)(cl[q] >> 56), lb = (uint32_t)(cl[q + 1] >> 56);
+                const uint64_t ca = cl[q] & 0x00ffffffffffffffull, cb = cl[q + 1] & 0x00ffffffffffffffull;
+                GF_JOIN2_OR64(wwin, pos, ca, la, cb, lb);
+                pos += la + lb;
+            }
         } else if (myBits) {
             BitSink sink;
             sink.init(wwin, bits + incl - myBits);
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
                 sink.put(cl[j] & 0x00ffffffffffffffull, (uint32_t)(cl[j] >> 56));
-                if (!PLAIN && ((multi >> j) & 1u)) {
+                if (!PLAIN && ((hard >> j) & 1u)) {
                     const uint32_t x = xs[PLAIN ? 0 : j];
                     uint32_t b1, b2;
                     const uint32_t n = m32_wide_bytes(x, &b1, &b2);

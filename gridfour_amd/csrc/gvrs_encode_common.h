@@ -198,6 +198,19 @@ struct BitSink {
         atomicOr(&(wwin)[w_ + 2u], o_ ? hi_ >> ro_ : 0u);                                                           \
     } while (0)
 
+// Two (code, length) pairs of at most 64 bits together (either may be empty), joined in a 64-bit register and ORed into a zeroed
+// bit window at bit position pbit as three words.  A shift count of 64 or 32 only ever meets a guarded operand.
+#define GF_JOIN2_OR64(wwin, pbit, ca, la, cb, lb)                                                                   \
+    do {                                                                                                            \
+        const uint64_t p_ = (ca) | ((la) < 64u ? (cb) << (la) : 0ull);                                              \
+        const uint32_t w_ = (pbit) >> 5, o_ = (pbit) & 31u;                                                         \
+        const uint64_t lo_ = p_ << o_;                                                                              \
+        const uint32_t hi_ = o_ ? (uint32_t)(p_ >> (64u - o_)) : 0u;                                                \
+        atomicOr(&(wwin)[w_], (uint32_t)lo_);                                                                       \
+        atomicOr(&(wwin)[w_ + 1u], (uint32_t)(lo_ >> 32));                                                          \
+        atomicOr(&(wwin)[w_ + 2u], hi_);                                                                            \
+    } while (0)
+
 // residual and emit mask of cell j of a Cells8 block for one model (flat-scan form)
 template <int MODEL>
 __device__ __forceinline__ uint32_t flat_residual(const Cells8 &Q, int j, uint32_t idx, uint32_t c, uint32_t nC,

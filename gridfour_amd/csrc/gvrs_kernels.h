@@ -115,14 +115,15 @@ struct GfDecodeArgs {
     uint32_t *debug;           // diagnostic: 16 cycle stamps per tile, normally null
     int rawM32;                // 1: the container holds the M32 bytes themselves behind the 10-byte header (CodecDeflate after inflate)
     const uint32_t *trees;     // non-null: the Huffman trees were parsed by k_huffman_parse_trees (GF_TREE_REC_WORDS per tile)
-    uint32_t *retryFlag;       // non-null (CodecHuffman batches with tree records): two device words; the fast kernel runs first
-                               // and ORs 1 into word 0 for every tile it leaves behind (status GF_K_RETRY inside the launch
-                               // only); with ldsM32Roomy the fast kernel runs a second time for those tiles and ORs into word 1
-                               // what it still cannot take; the general kernel looks at the last word written
+    uint32_t *retryFlag;       // non-null (CodecHuffman batches with tree records): two device words; the fast kernel ORs 1 into
+                               // word (ldsM32Roomy ? 1 : 0) for every tile it leaves to the general kernel (status GF_K_RETRY
+                               // inside the launch only), which looks at that word.  With ldsM32Roomy the fast kernel runs twice,
+                               // each run taking the tiles the pre-pass gave it (GF_TREE_ROOMY in the tile's tree record)
     uint32_t ldsM32Roomy;      // 0, or the M32 capacity of the fast kernel's second run (round 4): tiles whose M32 stream or
                                // packing outgrows ldsM32Bytes (dense in multi-byte values) get a workgroup with more LDS
                                // instead of the general kernel and its workspace in global memory
-    int retryPass;             // set by the launcher: 1 in the fast kernel's second run
+    const uint32_t *roomyList; // the tiles of the roomy run, listed by the pre-pass; retryFlag[2] = their count, retryFlag[3] = the
+                               // cursor the run's workgroups draw from (both zeroed again by the general kernel, the batch's last)
     int flagsCleared;          // 1: the tree pre-pass zeroed retryFlag (gf_launch_huffman_parse_trees), no memset in front of the kernels
     int lean;                  // 1 (the one-tile-per-call path): the fast kernel alone; what it leaves behind keeps the status
                                // GF_K_LEAN_RETRY and the caller takes the batch path for it
@@ -136,9 +137,22 @@ constexpr int GF_PAIR_TABLES = 5;               // one 65536-bin table of byte p
 // per-tile record of the tree pre-pass: 8 header words (status, leaves, bit position of the first code, longest code,
 // single-symbol value or -1, 3 spare), then 256 x (path bits uint64), 256 x code length, 256 x symbol
 constexpr int GF_TREE_REC_WORDS = 8 + 512 + 64 + 64;
+// fastBytes / roomyBytes (round 5): GfDecodeArgs::ldsM32Bytes / ldsM32Roomy of the decode launch that follows -- the pre-pass marks
+// the tiles whose M32 stream or packing outgrows the first but fits the second (GF_TREE_ROOMY in word 3 of the tile's record) and
+// lists them (roomyList; count in clearFlags[2]), so that the fast kernel's two runs know their tiles BEFORE either starts and
+// can run side by side (GfSideStream)
 hipError_t gf_launch_huffman_parse_trees(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                          const uint32_t *lengths, uint32_t *trees, size_t nTiles, hipStream_t stream,
-                                         uint32_t *clearFlags = nullptr);     // clearFlags: GfDecodeArgs::retryFlag, zeroed by the pre-pass
+                                         uint32_t *clearFlags = nullptr,      // clearFlags: GfDecodeArgs::retryFlag, words 0 and 1 zeroed by the pre-pass
+                                         uint32_t fastBytes = 0, uint32_t roomyBytes = 0, uint32_t *roomyList = nullptr);
+constexpr uint32_t GF_TREE_ROOMY = 0x400u;          // word 3 of a tree record (beside GF_TREE_HAS_*): the tile belongs to the roomy run
+// A second stream of the context with the two events that fork it off the caller's stream and join it again: the fast decode
+// kernel's roomy run (some per cent of the tiles of rough terrain, none of smooth terrain) runs there, beside the first run
+// instead of behind it.  Event record / wait only: safe inside a stream capture (the side stream joins the capture and leaves it).
+struct GfSideStream {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
 
 // LSOP12 containers whose entropy stage is CodecM32 bytes: type 0 (legacy Huffman of the two M32 streams) and, with
 // rawM32 = 1, type 1 after the host inflated it (gvrs_decode.hip: k_lsop_unpack_m32)
@@ -170,9 +184,9 @@ hipError_t gf_launch_lsop_unpack_m32(const GfLsopM32Args &a, hipStream_t stream,
 
 hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream);
 hipError_t gf_launch_huffman_encode_lean_t1024(const GfEncodeArgs &a, hipStream_t stream);   // 1024-thread workgroups, GfEncodeArgs::lean only
-hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);
-hipError_t gf_launch_huffman_decode_t512(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);   // 512-thread workgroups
-hipError_t gf_launch_huffman_decode_t1024(const GfDecodeArgs &a, hipStream_t stream, unsigned grid);  // 1024-thread workgroups
+hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid, const GfSideStream *side = nullptr);
+hipError_t gf_launch_huffman_decode_t512(const GfDecodeArgs &a, hipStream_t stream, unsigned grid, const GfSideStream *side = nullptr);   // 512-thread workgroups
+hipError_t gf_launch_huffman_decode_t1024(const GfDecodeArgs &a, hipStream_t stream, unsigned grid, const GfSideStream *side = nullptr);  // 1024-thread workgroups
 size_t gf_huffman_decode_lds_per_wg(const GfDecodeArgs &a);           // LDS bytes per workgroup, 256-thread build
 size_t gf_huffman_decode_lds_per_wg_t512(const GfDecodeArgs &a);      // ... 512-thread build
 size_t gf_huffman_decode_lds_per_wg_t1024(const GfDecodeArgs &a);     // ... 1024-thread build
