@@ -139,14 +139,22 @@ def _issue_rates():
     and SIMD -- the cheapest kind (VOP2 add) and the VOP3 / compare-select kind these kernels are mostly made of --, cycles per
     scalar-side wave-instruction (SALU or branch) and CU, all with eight waves per SIMD feeding the port."""
     here = os.path.dirname(os.path.abspath(__file__))
-    rates = {"valu_fast": 2.8, "valu_vop3": 4.26, "scalar": 1.0, "source": "defaults (profiles/r04_v1/issue_rate.json not readable)"}
+    import glob
+    rates = {"valu_fast": 2.8, "valu_vop3": 4.26, "scalar": 1.0, "source": "defaults (no profiles/r*/issue_rate.json readable)"}
+    # the newest measurement under profiles/ (directories are named r<round>_v<n>: the last one by round and number)
+    def order(path):
+        name = os.path.basename(os.path.dirname(path))
+        nums = [int(x) for x in __import__("re").findall(r"\d+", name)] or [0]
+        return nums
+    found = sorted(glob.glob(os.path.join(here, "profiles", "r*", "issue_rate.json")), key=order)
+    src = found[-1] if found else os.path.join(here, "profiles", "r04_v1", "issue_rate.json")
     try:
-        rec = json.load(open(os.path.join(here, "profiles", "r04_v1", "issue_rate.json")))
+        rec = json.load(open(src))
         by = {k["kind"]: k["rates"][-1] for k in rec["kinds"]}
         rates = {"valu_fast": by["v_add_u32 x8 independent"]["cycles_per_vector_instr_per_simd"],
                  "valu_vop3": by["v_alignbit / v_bfe_u32 / v_lshl_or_b32 / v_mad_u32_u24"]["cycles_per_vector_instr_per_simd"],
                  "scalar": by["s_add_u32 x8 independent"]["cycles_per_scalar_instr_per_cu"],
-                 "source": "profiles/r04_v1/issue_rate.json (tools/issue_rate.hip, 8 waves per SIMD)"}
+                 "source": "%s (tools/issue_rate.hip, 8 waves per SIMD)" % os.path.relpath(src, here)}
     except (OSError, ValueError, KeyError, IndexError):
         pass
     return rates
@@ -497,18 +505,64 @@ def _effective_cores():
 
 
 def _probe_java():
-    """BASELINE.md section 3: the reference Java codec is timed beside the GPU only where a JDK AND a Gridfour jar exist on the box;
-    the probe's answer is recorded either way (this image has neither: the C port stands in, kind "port")."""
+    """where is a JVM and a Gridfour jar?  Returns (java, jar, note); java / jar are None when missing (this
+    image and the GPU boxes so far hold neither: the C port stands in, kind "port")."""
     import glob
     import shutil
     java = shutil.which("java")
     if not java:
-        return "not found (no `java` on PATH)"
-    jars = [p for pat in ("/usr/share/java/*ridfour*.jar", os.path.expanduser("~/.m2/repository/org/gridfour/**/*.jar"),
-                          os.path.join(ROOT, "*ridfour*.jar")) for p in glob.glob(pat, recursive=True)]
+        return None, None, "not found (no `java` on PATH)"
+    pats = [os.environ.get("GRIDFOUR_JAR", ""), "/usr/share/java/*ridfour*.jar",
+            os.path.expanduser("~/.m2/repository/org/gridfour/**/*ridfour*ore*.jar"),
+            os.path.expanduser("~/.m2/repository/org/gridfour/**/*.jar"), os.path.join(ROOT, "*ridfour*.jar")]
+    jars = [p for pat in pats if pat for p in glob.glob(pat, recursive=True)]
     if not jars:
-        return "java at %s, no Gridfour jar: not timed" % java
-    return "java at %s, jar %s: present but no timing harness is wired up (report this)" % (java, jars[0])
+        return java, None, "java at %s, no Gridfour jar (GRIDFOUR_JAR, /usr/share/java, ~/.m2, repo root): not timed" % java
+    return java, jars[0], "java at %s, jar %s" % (java, jars[0])
+
+
+def _java_reference(args, sub, n_rows, n_cols, gpu_packings=None):
+    """The reference Java codec itself on the sample (tools/JavaCodecTimer.java: one thread, 20 warm-up passes, best of five), where
+    a JVM and a Gridfour jar exist; else the probe's answer as a string.  With gpu_packings (tile of the sample -> its packing's
+    bytes or None) the Java packings are compared with the GPU's byte for byte."""
+    import subprocess
+    import tempfile
+    java, jar, note = _probe_java()
+    if not java or not jar:
+        return note
+    codec = {"huffman": "huffman", "canon": "canon", "lsop": "lsop"}.get(args.codec)
+    if codec is None:
+        return note + ": no Java timing for codec %s" % args.codec
+    ns = min(sub.shape[0], 2048)
+    with tempfile.TemporaryDirectory() as tmp:
+        raw, out = os.path.join(tmp, "tiles.raw"), os.path.join(tmp, "packings.out")
+        np.ascontiguousarray(sub[:ns]).astype("<i4").tofile(raw)
+        cmd = [java, "-Xmx4g", "-cp", jar, os.path.join(ROOT, "tools", "JavaCodecTimer.java"), raw, str(n_rows), str(n_cols),
+               str(ns), codec, out]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        except (OSError, subprocess.TimeoutExpired) as e:
+            return note + ": harness did not run (%s)" % e
+        if r.returncode != 0:
+            return note + ": harness failed rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])
+        try:
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            return note + ": harness output not understood: %s" % r.stdout[-200:]
+        rec["harness"] = "tools/JavaCodecTimer.java, first %d tiles of the sample" % ns
+        rec["where"] = note
+        if gpu_packings is not None:
+            import struct
+            blob = open(out, "rb").read()
+            pos, same = 0, 0
+            for t in range(ns):
+                (n,) = struct.unpack_from("<i", blob, pos)
+                pos += 4
+                jp = None if n < 0 else blob[pos:pos + n]
+                pos += max(n, 0)
+                same += int(jp == gpu_packings(t))
+            rec["gpu_packings_identical_to_java"] = "%d of %d" % (same, ns)
+        return rec
 
 
 def _cpu_baseline(args, vals, n_rows, n_cols, n_tiles):
@@ -544,7 +598,7 @@ def _cpu_baseline(args, vals, n_rows, n_cols, n_tiles):
     res = {"value": round(mb / (c2 - c0), 2), "unit": "MB/s", "cores": 1, "kind": "port",
            "sample": "first %d tiles of the same workload (%.0f MB), oracle C restatement of the Java algorithm, 1 thread; "
                      "encode %.1f MB/s, decode %.1f MB/s" % (ns, mb, mb / (c1 - c0), mb / (c2 - c1)),
-           "reference_java": _probe_java()}
+           "reference_java": _java_reference(args, sub, n_rows, n_cols, getattr(args, "_gpu_packings", None))}
     if args.codec == "huffman":
         nthr = _effective_cores()
         enc_s, dec_s = oracle.huffman_roundtrip_threads(nthr, 0, n_rows, n_cols, sub)
@@ -840,6 +894,9 @@ def main():
     if rank == 0 and vals0 is not None:
         data_stats = _m32_stats(vals0, batches[0].get_predictors(), n_rows, n_cols)
     if rank == 0 and total_shards == 1 and not args.no_verify:
+        # (the GPU's packing of sample tile t, for the byte-for-byte comparison with the reference Java codec where one exists)
+        lens0, st0 = batches[0].get_lengths(), batches[0].get_enc_status()
+        args._gpu_packings = lambda t: batches[0].get_packing(t, int(lens0[t])) if st0[t] == 0 else None
         cpu_baseline = _cpu_baseline(args, vals0, n_rows, n_cols, n_tiles)
         if args.codec == "huffman" and args.cpu_sample_tiles != 0:
             host_path = _host_path(ctxs[0].handle, vals0, n_rows, n_cols)

@@ -11,6 +11,7 @@ from . import build as _build
 OK, DECLINED, OVERFLOW = 0, 1, 2
 ERR_FORMAT, ERR_BOUNDS, ERR_CAPACITY, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 PM_ALL = 0xF
+LSOP_DEFLATE, LSOP_VALUE_CHECKSUM = 1, 2          # LsEncoder12.setDeflateEnabled / setValueChecksumEnabled (include/gvrs_hip_codec.h)
 
 _u8p = C.POINTER(C.c_uint8)
 _i32p = C.POINTER(C.c_int32)
@@ -57,6 +58,8 @@ SIGNATURES = {
     "gf_lsop12_reconstruct_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
     "gf_lsop12_encode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, C.c_size_t,
                                                  _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "gf_lsop12_encode_batch_i32_dev_ex": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t,
+                                                    _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "gf_lsop12_decode_batch_i32_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, C.c_size_t, _vp,
                                                  C.c_size_t, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "gf_lsop12_encode_batch_i32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t,

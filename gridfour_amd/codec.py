@@ -324,13 +324,13 @@ class DeviceTileBatch:
         check(lib().gf_synth_dem_dev(self.ctx.handle, stream, seed & (2 ** 64 - 1), self.n_rows, self.n_cols,
                                      tiles_per_row, tile0, self.n_tiles, self.values.ptr), "gf_synth_dem_dev")
 
-    def encode(self, codec_index=0, predictor_mask=_lib.PM_ALL, stream=None):
+    def encode(self, codec_index=0, predictor_mask=_lib.PM_ALL, stream=None, lsop_flags=0):
         if self.codec == "lsop":
-            check(lib().gf_lsop12_encode_batch_i32_dev(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols,
-                                                       self.n_tiles, self.values.ptr, self.slots.ptr, self.stride,
-                                                       self.lengths.ptr, self.enc_status.ptr, self.residuals.ptr,
-                                                       self.res_stride, self.coefs.ptr, self.scratch_status.ptr),
-                  "gf_lsop12_encode_batch_i32_dev")
+            check(lib().gf_lsop12_encode_batch_i32_dev_ex(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols,
+                                                          self.n_tiles, self.values.ptr, lsop_flags, self.slots.ptr, self.stride,
+                                                          self.lengths.ptr, self.enc_status.ptr, self.residuals.ptr,
+                                                          self.res_stride, self.coefs.ptr, self.scratch_status.ptr),
+                  "gf_lsop12_encode_batch_i32_dev_ex")
             return
         fn = getattr(lib(), "gf_%s_encode_batch_i32_dev" % self.codec)
         check(fn(self.ctx.handle, stream, codec_index, self.n_rows, self.n_cols, self.n_tiles, self.values.ptr,
@@ -481,12 +481,16 @@ class LsCodecHip:
     """Drop-in for org.gridfour.lsop.LsEncoder12 + LsDecoder12 (codec id "LSOP12", LsCodecUtility.java:53),
     computed on the MI355X; the Deflate alternative container uses the host's zlib as the reference uses the JDK's."""
 
-    def __init__(self, context=None, device=0, deflate_enabled=True):
+    def __init__(self, context=None, device=0, deflate_enabled=True, value_checksum_enabled=False):
         self.ctx = context if context is not None else GvrsHipContext(device)
         self.deflate_enabled = bool(deflate_enabled)           # LsEncoder12.setDeflateEnabled, default true
+        self.value_checksum_enabled = bool(value_checksum_enabled)   # LsEncoder12.setValueChecksumEnabled, default false
 
     def setDeflateEnabled(self, enabled):
         self.deflate_enabled = bool(enabled)
+
+    def setValueChecksumEnabled(self, enabled):
+        self.value_checksum_enabled = bool(enabled)            # LsEncoder12.java:117-119
 
     # ---- ICompressionEncoder ----
     def encode(self, codecIndex, nRows, nCols, values):
@@ -527,7 +531,9 @@ class LsCodecHip:
         types = np.zeros(nt, np.uint8)
         status = np.zeros(nt, np.int32)
         check(lib().gf_lsop12_encode_batch_i32(self.ctx.handle, codecIndex, nRows, nCols, nt, _ptr(v),
-                                               int(self.deflate_enabled), _ptr(blob), cap, _ptr(offsets), _ptr(types),
+                                               (_lib.LSOP_DEFLATE if self.deflate_enabled else 0) |
+                                               (_lib.LSOP_VALUE_CHECKSUM if self.value_checksum_enabled else 0),
+                                               _ptr(blob), cap, _ptr(offsets), _ptr(types),
                                                _ptr(status)), "gf_lsop12_encode_batch_i32")
         packs = [bytes(blob[int(offsets[t]):int(offsets[t + 1])]) if status[t] == _lib.OK else None for t in range(nt)]
         return packs, types, status

@@ -1899,9 +1899,10 @@ size_t gf_lsop12_residual_count(int nRows, int nCols)
 
 size_t gf_lsop12_max_packing(int nRows, int nCols)
 {
-    // 55 header bytes + two canonical-Huffman streams (tables < 750 bytes each, at most 84 bits per value + end-of-text)
+    // 55 header bytes (59 with the value checksum) + two canonical-Huffman streams (tables < 750 bytes each, at most 84 bits per
+    // value + end-of-text)
     const size_t n = gf_lsop12_residual_count(nRows, nCols);
-    return roundUp(55 + 2 * 768 + (n * 84 + 2 * 15 + 7) / 8 + 16, 16);
+    return roundUp(59 + 2 * 768 + (n * 84 + 2 * 15 + 7) / 8 + 16, 16);
 }
 
 gf_status gf_lsop12_predict_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles, const int32_t *dValues,
@@ -1939,6 +1940,17 @@ gf_status gf_lsop12_encode_batch_i32_dev(gf_context *c, void *stream, int codecI
                                          int32_t *dStatus, int32_t *dResiduals, size_t resStride, uint32_t *dCoefs,
                                          int32_t *dScratchStatus)
 {
+    return gf_lsop12_encode_batch_i32_dev_ex(c, stream, codecIndex, nRows, nCols, nTiles, dValues, 0, dOut, slotStride, dLengths, dStatus,
+                                             dResiduals, resStride, dCoefs, dScratchStatus);
+}
+
+// ... with LsEncoder12's switches (flags: GF_LSOP_VALUE_CHECKSUM = setValueChecksumEnabled, lsop/LsEncoder12.java:117-119; the
+// Deflate alternative needs the host's zlib and is not a device-resident operation)
+gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *c, void *stream, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                            const int32_t *dValues, int flags, uint8_t *dOut, size_t slotStride, uint32_t *dLengths,
+                                            int32_t *dStatus, int32_t *dResiduals, size_t resStride, uint32_t *dCoefs,
+                                            int32_t *dScratchStatus)
+{
     GF_CTX_LOCK(c);
     if (!c || !dValues || !dOut || !dLengths || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
@@ -1955,8 +1967,11 @@ gf_status gf_lsop12_encode_batch_i32_dev(gf_context *c, void *stream, int codecI
     if (s != GF_OK) return s;
     const uint32_t n0 = (uint32_t)(4 * nRows + 2 * nCols - 9), n1 = (uint32_t)((nRows - 2) * (nCols - 4));
     if (4ull * ((uint64_t)n1 + 1) >= (1ull << 22)) return GF_ERR_UNSUPPORTED;       // 22-bit counts in the tree keys
+    const int valueChecksum = (flags & GF_LSOP_VALUE_CHECKSUM) ? 1 : 0;
+    if (valueChecksum)
+        GF_HIP(gf_launch_lsop_value_crc(dValues, (size_t)nRows * (size_t)nCols, nTiles, dScratchStatus, dCoefs, st));
     GF_HIP(gf_launch_canon_pack2(dResiduals, resStride, dCoefs, dScratchStatus, dOut, slotStride, dLengths, dStatus, nTiles,
-                                 n0, n1, codecIndex, st));
+                                 n0, n1, codecIndex, st, valueChecksum));
     return GF_OK;
 }
 
@@ -2040,10 +2055,15 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
     if ((s = c->dResiduals.ensure(nTiles * resStride * 4 + 16)) != GF_OK) return s;
     if ((s = c->dCoefs.ensure(nTiles * 64 + 16)) != GF_OK) return s;
     GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
-    s = gf_lsop12_encode_batch_i32_dev(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
-                                       (uint8_t *)c->dSlots.p, stride, (uint32_t *)c->dLengths.p, (int32_t *)c->dStatus.p,
-                                       (int32_t *)c->dResiduals.p, resStride, (uint32_t *)c->dCoefs.p,
-                                       (int32_t *)c->dStatus2.p);
+    // deflateEnabled carries LsEncoder12's two switches: GF_LSOP_DEFLATE (setDeflateEnabled; any odd value, as before) and
+    // GF_LSOP_VALUE_CHECKSUM (setValueChecksumEnabled)
+    const bool valueChecksum = (deflateEnabled & GF_LSOP_VALUE_CHECKSUM) != 0;
+    deflateEnabled &= GF_LSOP_DEFLATE;
+    const size_t hdrCanon = valueChecksum ? 59 : 55, hdrDeflate = valueChecksum ? 67 : 63;
+    s = gf_lsop12_encode_batch_i32_dev_ex(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
+                                          valueChecksum ? GF_LSOP_VALUE_CHECKSUM : 0, (uint8_t *)c->dSlots.p, stride,
+                                          (uint32_t *)c->dLengths.p, (int32_t *)c->dStatus.p, (int32_t *)c->dResiduals.p, resStride,
+                                          (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p);
     if (s != GF_OK) return s;
     std::vector<uint32_t> lengths(nTiles);
     std::vector<int32_t> st(nTiles);
@@ -2065,7 +2085,7 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
     if (deflateEnabled) {
         parallelFor(nTiles, [&](size_t t) {
             if (st[t] != GF_OK) return;
-            const size_t canonLength = lengths[t] - 55;
+            const size_t canonLength = lengths[t] - hdrCanon;
             const int32_t *r = res.data() + t * resStride;
             std::vector<uint8_t> mInt, mInit, zInt, zInit;
             const size_t nMX = m32Pack(r + nInit, nInt, mInt);
@@ -2075,15 +2095,16 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
             if (!zDeflate(mInit.data(), nMI, 6, zInit)) return;
             if (zInit.empty() || zInit.size() + zInt.size() >= canonLength || zInit.size() > nMI + 128) return;   // :194-196
             std::vector<uint8_t> &p = alt[t];
-            p.resize(63 + zInit.size() + zInt.size());
+            p.resize(hdrDeflate + zInit.size() + zInt.size());
             p[0] = (uint8_t)codecIndex;
-            p[1] = 0x41;                                     // COMPRESSION_TYPE_DEFLATE | REVISION_FLAG
+            p[1] = valueChecksum ? 0xC1 : 0x41;              // COMPRESSION_TYPE_DEFLATE | REVISION_FLAG (| VALUE_CHECKSUM_INCLUDED)
             p[2] = 12;
             for (int k = 0; k < 13; k++) putLE32(&p[3 + 4 * k], coefs[t * 16 + k]);
             putLE32(&p[55], (uint32_t)nMI);
             putLE32(&p[59], (uint32_t)nMX);
-            memcpy(&p[63], zInit.data(), zInit.size());
-            memcpy(&p[63 + zInit.size()], zInt.data(), zInt.size());
+            if (valueChecksum) putLE32(&p[63], coefs[t * 16 + 13]);   // LsHeader.packHeader :259-261
+            memcpy(&p[hdrDeflate], zInit.data(), zInit.size());
+            memcpy(&p[hdrDeflate + zInit.size()], zInt.data(), zInt.size());
         });
     }
     uint64_t total = 0;

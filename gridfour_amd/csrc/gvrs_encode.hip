@@ -604,6 +604,10 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     if constexpr (!FAST) {
         if (a.retryFlag && *a.retryFlag == 0u) return;               // the fast kernel finished every tile
+    } else {
+        // (round 5) the count of tiles the packer leaves to k_huffman_pack_rare starts at zero: cleared here, a kernel boundary
+        // before the packer adds to it, instead of by a memset node in front of every encode (4 us that found nothing to do)
+        if (a.retryFlag && !a.lean && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.retryFlag[1] = 0u;
     }
 
     GF_FOR_TILES(t, a.nTiles, FAST) {                                     // the fast kernel: one tile per workgroup, no loop
@@ -1734,7 +1738,13 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (!a.packRecs) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(a.nTiles < 65536 * 16 ? a.nTiles : 65536 * 16);
     const size_t nCells = (size_t)a.nRows * (size_t)a.nCols;
-    if (a.retryFlag && !a.lean) {                                         // word 0: tiles for k_huffman_encode<false>, word 1: for k_huffman_pack_rare
+    // word 0: tiles for k_huffman_encode<false> (experiment builds only), word 1: for k_huffman_pack_rare -- zeroed by the fast
+    // kernel's first workgroup, or here where that kernel does not run or sets word 0 itself
+#ifndef GF_ENC_NULLS_RETRY
+    if (a.retryFlag && !a.lean && 6ull * nCells >= (1ull << 23)) {
+#else
+    if (a.retryFlag && !a.lean) {
+#endif
         const hipError_t e = hipMemsetAsync(a.retryFlag, 0, 8, stream);
         if (e != hipSuccess) return e;
     }

@@ -699,6 +699,68 @@ __device__ void p2_append_bits(const uint32_t *img, uint32_t nbits, uint32_t *wi
     window_flush(win, out32, ps);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_lsop_value_crc: LsHeader.computeChecksum (lsop/LsHeader.java:391-406) -- the CRC-32C (util/GridfourCRC32C.java:160-185) of a
+// tile's values as little-endian bytes, i.e. of the tile as it lies in memory -- for LsEncoder12.setValueChecksumEnabled
+// (:117-119, default off).  One wave per tile: lane l takes the l-th of 64 equal runs of cells byte by byte through the
+// polynomial's table (in LDS, made by the workgroup), and the runs' checksums are joined by the CRC's linearity:
+//   crc(A || B) = crc(A) * x^(8 |B|)  xor  crc(B)    in GF(2)[x] modulo the (reflected) polynomial,
+// so the tile's checksum is the XOR over the lanes of crc(run) * x^(8 bytes behind the run).  The multiplications are 32 steps
+// of shift-and-conditional-xor each, the powers by square and multiply.  Word 13 of the tile's coefficient record receives it.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t CRC32C_POLY = 0x82F63B78u;
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)        // a * b mod P, operands and result bit-reflected
+{
+    uint32_t p = 0;
+#pragma unroll 1
+    for (uint32_t m = 0x80000000u; m; m >>= 1) {
+        p ^= (a & m) ? b : 0u;
+        b = (b & 1u) ? (b >> 1) ^ CRC32C_POLY : b >> 1;
+    }
+    return p;
+}
+__device__ __forceinline__ uint32_t crc_xpow8n(uint32_t nBytes)               // x^(8 nBytes) mod P
+{
+    uint32_t p = 0x80000000u, sq = 0x00800000u;                               // x^0; x^8
+#pragma unroll 1
+    for (uint32_t n = nBytes; n; n >>= 1) {
+        if (n & 1u) p = crc_mulmod(sq, p);
+        sq = crc_mulmod(sq, sq);
+    }
+    return p;
+}
+__global__ __launch_bounds__(256) void k_lsop_value_crc(const int32_t *__restrict__ values, uint32_t nCells, size_t nTiles,
+                                                        const int32_t *__restrict__ inStatus, uint32_t *__restrict__ coefs)
+{
+    __shared__ uint32_t table[256];
+    {
+        uint32_t c = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC32C_POLY : 0u);
+        table[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t t = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (t >= nTiles || (inStatus && inStatus[t] != GF_K_OK)) return;
+    const uint32_t *__restrict__ v = reinterpret_cast<const uint32_t *>(values) + t * (size_t)nCells;
+    const uint32_t per = (nCells + 63u) / 64u, begin = min(nCells, lane * per), end = min(nCells, begin + per);
+    uint32_t crc = 0xffffffffu;
+    for (uint32_t i = begin; i < end; i++) {
+        uint32_t w = v[i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            crc = table[(crc ^ w) & 0xffu] ^ (crc >> 8);
+            w >>= 8;
+        }
+    }
+    crc ^= 0xffffffffu;                                                       // the run's own checksum (an empty run: 0)
+    uint32_t part = crc_mulmod(crc_xpow8n((nCells - end) * 4u), crc);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part ^= gf_lane_xor(part, o);
+    if (lane == 0) coefs[t * 16 + 13] = part;
+}
+
 struct GfPack2Args {
     const int32_t *residuals;  // per tile resStride ints: stream 0 (n0), stream 1 (n1)
     size_t resStride;
@@ -711,9 +773,10 @@ struct GfPack2Args {
     size_t nTiles;
     uint32_t n0, n1;
     int codecIndex;
+    int valueChecksum;         // LsEncoder12.setValueChecksumEnabled: word 13 of the coefficient record goes behind the header
 };
 
-constexpr uint32_t LSOP_HEADER_BYTES = 55;     // LsHeader.packHeader :219-222 for the canonical container: 7 + 12*4
+constexpr uint32_t LSOP_HEADER_BYTES = 55;     // LsHeader.packHeader :219-222 for the canonical container: 7 + 12*4 (+ 4: the checksum)
 
 __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(GfPack2Args a)
 {
@@ -780,8 +843,8 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
         }
         __syncthreads();
 
-        const unsigned long long totalBits =
-            8ull * LSOP_HEADER_BYTES + P.imgBits[0] + P.textBits[0] + P.imgBits[1] + P.textBits[1];
+        const uint32_t headerBytes = LSOP_HEADER_BYTES + (a.valueChecksum ? 4u : 0u);
+        const unsigned long long totalBits = 8ull * headerBytes + P.imgBits[0] + P.textBits[0] + P.imgBits[1] + P.textBits[1];
         const unsigned long long bytes = (totalBits + 7) >> 3;
         if (tid == 0) {
             a.lengths[t] = (uint32_t)min(bytes, 0xffffffffull);
@@ -794,9 +857,10 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
         __syncthreads();
         if (tid < 14) {
             const uint32_t *cf = a.coefs + t * 16;
-            // byte stream: [codec][0x42][12] then 13 little-endian words (seed, coefficients) from byte 3 on
-            if (tid == 0) atomicOr(&S.win[0], ((uint32_t)a.codecIndex & 0xffu) | (0x42u << 8) | (12u << 16));
-            if (tid < 13) {
+            // byte stream: [codec][0x42, 0xC2 with the value checksum][12] then 13 little-endian words (seed, coefficients) from
+            // byte 3 on, and the checksum as a 14th (LsHeader.packHeader :245-262)
+            if (tid == 0) atomicOr(&S.win[0], ((uint32_t)a.codecIndex & 0xffu) | ((a.valueChecksum ? 0xC2u : 0x42u) << 8) | (12u << 16));
+            if (tid < 13 || a.valueChecksum) {
                 const uint32_t w = cf[tid];
                 atomicOr(&S.win[tid], w << 24);
                 atomicOr(&S.win[tid + 1], w >> 8);
@@ -804,7 +868,7 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
         }
         __syncthreads();
         PackState ps;
-        ps.bitBase = 8u * LSOP_HEADER_BYTES;
+        ps.bitBase = 8u * headerBytes;
         ps.wordBase = 0;
         window_flush(S.win, out32, ps);
         for (int sidx = 0; sidx < 2; sidx++) {
@@ -1460,11 +1524,21 @@ hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, siz
 
 hipError_t gf_launch_canon_pack2(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
                                  uint8_t *out, size_t slotStride, uint32_t *lengths, int32_t *status, size_t nTiles,
-                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream)
+                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream, int valueChecksum)
 {
     if (nTiles == 0) return hipSuccess;
-    GfPack2Args a{residuals, resStride, coefs, inStatus, out, slotStride, lengths, status, nTiles, n0, n1, codecIndex};
+    GfPack2Args a{residuals, resStride, coefs, inStatus, out, slotStride, lengths, status, nTiles, n0, n1, codecIndex, valueChecksum};
     hipLaunchKernelGGL(k_canon_pack2, gf_tile_grid(nTiles), dim3(ENC_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gf_launch_lsop_value_crc(const int32_t *values, size_t nCells, size_t nTiles, const int32_t *inStatus, uint32_t *coefs,
+                                    hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    if (nCells >= (1ull << 30)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lsop_value_crc, dim3((unsigned)((nTiles + 3) / 4)), dim3(256), 0, stream, values, (uint32_t)nCells, nTiles,
+                       inStatus, coefs);
     return hipGetLastError();
 }
 

@@ -277,13 +277,14 @@ public:
     LsCodecHip(const LsCodecHip &) = delete;
     LsCodecHip &operator=(const LsCodecHip &) = delete;
     void setDeflateEnabled(bool enabled) { deflate_ = enabled; }         // LsEncoder12.java:94-96
+    void setValueChecksumEnabled(bool enabled) { checksum_ = enabled; }  // LsEncoder12.java:117-119
 
     std::optional<std::vector<uint8_t>> encode(int codecIndex, int nRows, int nCols, const std::vector<int32_t> &values) override
     {
         if ((size_t)nRows * (size_t)nCols != values.size()) throw std::invalid_argument("values.length != nRows*nCols");
         std::vector<uint8_t> out(gf_lsop12_max_packing(nRows, nCols) + 64);
         size_t n = 0;
-        const gf_status s = gf_lsop12_encode_i32(ctx_, codecIndex, nRows, nCols, values.data(), deflate_ ? 1 : 0, out.data(),
+        const gf_status s = gf_lsop12_encode_i32(ctx_, codecIndex, nRows, nCols, values.data(), (deflate_ ? GF_LSOP_DEFLATE : 0) | (checksum_ ? GF_LSOP_VALUE_CHECKSUM : 0), out.data(),
                                                  out.size(), &n);
         if (s == GF_DECLINED) return std::nullopt;                       // LsEncoder12.java:124-127
         if (s < 0) throw std::runtime_error(std::string("gf_lsop12_encode_i32: ") + gf_status_string(s));
@@ -309,6 +310,7 @@ public:
 private:
     gf_context *ctx_ = nullptr;
     bool deflate_;
+    bool checksum_ = false;
 };
 
 /** Drop-in for org.gridfour.compress.CodecDeflate (CodecDeflate.java:108-228): predictor + CodecM32 on the GPU,

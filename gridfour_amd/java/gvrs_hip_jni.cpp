@@ -144,7 +144,7 @@ JNIEXPORT jintArray JNICALL Java_org_gridfour_hip_CodecHuffmanHip_decodeNative(J
 
 // ---- org.gridfour.hip.HipCodecNative: the same two calls for every integer codec of the library ----
 // kind 0 = CodecHuffman, 1 = CodecCanonHuffman, 2 = LSOP12 (Deflate alternative disabled), 3 = LSOP12 (reference default),
-// 4 = CodecDeflate
+// 4 = CodecDeflate, 5 / 6 = LSOP12 as 2 / 3 with the value checksum in the header (LsEncoder12.setValueChecksumEnabled)
 JNIEXPORT jlong JNICALL Java_org_gridfour_hip_HipCodecNative_create(JNIEnv *env, jclass cls, jint device)
 {
     return Java_org_gridfour_hip_CodecHuffmanHip_createNative(env, cls, device);
@@ -173,7 +173,9 @@ JNIEXPORT jbyteArray JNICALL Java_org_gridfour_hip_HipCodecNative_encode(JNIEnv 
         if (kind == 0) s = gf_huffman_encode_i32(h->ctx, codecIndex, nRows, nCols, v, (uint8_t *)out, cap, &n);
         else if (kind == 1) s = gf_canon_encode_i32(h->ctx, codecIndex, nRows, nCols, v, (uint8_t *)out, cap, &n);
         else if (kind == 4) s = gf_deflate_encode_i32(h->ctx, codecIndex, nRows, nCols, v, (uint8_t *)out, cap, &n);
-        else s = gf_lsop12_encode_i32(h->ctx, codecIndex, nRows, nCols, v, kind == 3, (uint8_t *)out, cap, &n);
+        else s = gf_lsop12_encode_i32(h->ctx, codecIndex, nRows, nCols, v,
+                                      ((kind == 3 || kind == 6) ? GF_LSOP_DEFLATE : 0) | (kind >= 5 ? GF_LSOP_VALUE_CHECKSUM : 0),
+                                      (uint8_t *)out, cap, &n);
     }
     jbyteArray result = nullptr;
     if (s == GF_OK) {

@@ -20,7 +20,9 @@ import org.gridfour.lsop.LsDecoder12;
 
 public class LsCodecHip implements ICompressionEncoder, ICompressionDecoder {
 
-  private static final int KIND = Boolean.parseBoolean(System.getProperty("gridfour.hip.lsop.deflate", "true")) ? 3 : 2;
+  /** LsEncoder12's two switches (setDeflateEnabled, default on; setValueChecksumEnabled, default off); system properties preset them */
+  private boolean deflateEnabled = Boolean.parseBoolean(System.getProperty("gridfour.hip.lsop.deflate", "true"));
+  private boolean valueChecksumEnabled = Boolean.parseBoolean(System.getProperty("gridfour.hip.lsop.checksum", "false"));
   private final long handle = HipCodecNative.create(Integer.getInteger("gridfour.hip.device", 0));
   /** analysis statistics are host-side bookkeeping: delegate to the stock implementation */
   private final LsDecoder12 statsDelegate = new LsDecoder12();
@@ -28,14 +30,29 @@ public class LsCodecHip implements ICompressionEncoder, ICompressionDecoder {
   public LsCodecHip() {
   }
 
+  /** as LsEncoder12.setDeflateEnabled (lsop/LsEncoder12.java:92-94) */
+  public void setDeflateEnabled(boolean deflateEnabled) {
+    this.deflateEnabled = deflateEnabled;
+  }
+
+  /** as LsEncoder12.setValueChecksumEnabled (lsop/LsEncoder12.java:117-119) */
+  public void setValueChecksumEnabled(boolean valueChecksumEnabled) {
+    this.valueChecksumEnabled = valueChecksumEnabled;
+  }
+
+  /** the native kind: 2 / 3 = LSOP12 without / with the Deflate alternative, 5 / 6 = the same with the value checksum */
+  private int kind() {
+    return (deflateEnabled ? 3 : 2) + (valueChecksumEnabled ? 3 : 0);
+  }
+
   @Override
   public byte[] encode(int codecIndex, int nRows, int nCols, int[] values) {
-    return HipCodecNative.encode(handle, KIND, codecIndex, nRows, nCols, values);
+    return HipCodecNative.encode(handle, kind(), codecIndex, nRows, nCols, values);
   }
 
   @Override
   public int[] decode(int nRows, int nColumns, byte[] packing) throws IOException {
-    return HipCodecNative.decode(handle, KIND, nRows, nColumns, packing);
+    return HipCodecNative.decode(handle, kind(), nRows, nColumns, packing);
   }
 
   @Override

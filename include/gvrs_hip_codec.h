@@ -321,6 +321,14 @@ gf_status gf_deflate_decode_i32(gf_context *ctx, int n_rows, int n_cols, const u
  * until it has run once for the shape).                                                                             */
 size_t gf_lsop12_residual_count(int n_rows, int n_cols);
 size_t gf_lsop12_max_packing(int n_rows, int n_cols);
+/* LsEncoder12's two switches, as bits of the `deflate_enabled` / `flags` argument of the encode entry points:
+ *   GF_LSOP_DEFLATE         setDeflateEnabled (lsop/LsEncoder12.java:92-94, default on; 1, as the argument always meant)
+ *   GF_LSOP_VALUE_CHECKSUM  setValueChecksumEnabled (:117-119, default off): LsHeader.computeChecksum (LsHeader.java:391-406), the
+ *                           CRC-32C of the tile's values as little-endian bytes, computed on the device, goes behind the
+ *                           header's last field and bit 7 of byte 1 is set (LsHeader.packHeader :245-262).  The decoders skip
+ *                           it, as the reference's decoder only prints a mismatch (LsDecoder12.java:153-158).                */
+#define GF_LSOP_DEFLATE 1
+#define GF_LSOP_VALUE_CHECKSUM 2
 /* LsOptimalPredictor12.encode: tile -> coefficients + residual streams (d_status: GF_OK / GF_DECLINED per tile) */
 gf_status gf_lsop12_predict_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
                                 const int32_t *d_values, int32_t *d_residuals, size_t res_stride, uint32_t *d_coefs,
@@ -335,6 +343,11 @@ gf_status gf_lsop12_encode_batch_i32_dev(gf_context *ctx, void *stream, int code
                                          size_t n_tiles, const int32_t *d_values, uint8_t *d_out, size_t slot_stride,
                                          uint32_t *d_lengths, int32_t *d_status, int32_t *d_residuals, size_t res_stride,
                                          uint32_t *d_coefs, int32_t *d_scratch_status);
+/* ... with flags (GF_LSOP_VALUE_CHECKSUM; the Deflate alternative is a host-side operation) */
+gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *ctx, void *stream, int codec_index, int n_rows, int n_cols,
+                                            size_t n_tiles, const int32_t *d_values, int flags, uint8_t *d_out,
+                                            size_t slot_stride, uint32_t *d_lengths, int32_t *d_status, int32_t *d_residuals,
+                                            size_t res_stride, uint32_t *d_coefs, int32_t *d_scratch_status);
 gf_status gf_lsop12_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
                                          const uint8_t *d_blob, size_t blob_bytes, const uint64_t *d_offsets,
                                          size_t slot_stride, const uint32_t *d_lengths, int32_t *d_values,

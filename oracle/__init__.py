@@ -96,6 +96,11 @@ def lib():
         L.gvo_lsop12_encode.argtypes = [C.c_int, C.c_int, C.c_int, i32p, C.c_int, u8p, C.c_size_t, szp, ip]
         L.gvo_lsop12_decode.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, i32p]
         L.gvo_lsop12_encode_legacy_huffman.argtypes = [C.c_int, C.c_int, C.c_int, i32p, u8p, C.c_size_t, szp]
+        L.gvo_lsop12_encode_ex.argtypes = [C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, u8p, C.c_size_t, szp, ip]
+        L.gvo_crc32c.argtypes = [u8p, C.c_size_t]
+        L.gvo_crc32c.restype = C.c_uint32
+        L.gvo_lsop_value_checksum.argtypes = [C.c_int, C.c_int, i32p]
+        L.gvo_lsop_value_checksum.restype = C.c_uint32
         L.gvo_lsop12_bound.argtypes = [C.c_size_t]
         L.gvo_lsop12_bound.restype = C.c_size_t
         L.gvo_batch_lsop12_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, i32p, C.c_int, u8p, C.c_size_t,
@@ -478,15 +483,27 @@ def lsop12_residuals(n_rows, n_cols, values):
     return seed.value, u, init, inter
 
 
-def lsop12_encode(codec_index, n_rows, n_cols, values, deflate_enabled=True):
-    """LsEncoder12.encode: (packing | None, container type)."""
+def crc32c(data):
+    """util/GridfourCRC32C: update(data), getValue()."""
+    b = _u8(data)
+    return int(lib().gvo_crc32c(_p(b, C.c_uint8), b.size))
+
+
+def lsop_value_checksum(n_rows, n_cols, values):
+    """LsHeader.computeChecksum."""
+    v = _i32(values).ravel()
+    return int(lib().gvo_lsop_value_checksum(n_rows, n_cols, _p(v, C.c_int32)))
+
+
+def lsop12_encode(codec_index, n_rows, n_cols, values, deflate_enabled=True, value_checksum=False):
+    """LsEncoder12.encode: (packing | None, container type).  value_checksum: setValueChecksumEnabled."""
     v = _i32(values).ravel()
     cap = int(lib().gvo_lsop12_bound(v.size))
     out = np.zeros(cap, np.uint8)
     n = C.c_size_t(0)
     typ = C.c_int(0)
-    rc = lib().gvo_lsop12_encode(codec_index, n_rows, n_cols, _p(v, C.c_int32), int(deflate_enabled), _p(out, C.c_uint8),
-                                 cap, C.byref(n), C.byref(typ))
+    rc = lib().gvo_lsop12_encode_ex(codec_index, n_rows, n_cols, _p(v, C.c_int32), int(deflate_enabled), int(value_checksum),
+                                    _p(out, C.c_uint8), cap, C.byref(n), C.byref(typ))
     if rc == DECLINED:
         return None, 0
     if rc != OK:

@@ -132,6 +132,12 @@ int gvo_lsop12_residuals(int nRows, int nCols, const int32_t *values, int32_t *s
                          int32_t *initInt, int32_t *interiorInt);
 int gvo_lsop12_encode(int codecIndex, int nRows, int nCols, const int32_t *values, int deflateEnabled,
                       uint8_t *out, size_t outCap, size_t *outLen, int *containerType);
+/* ... with LsEncoder12.setValueChecksumEnabled :117-119 */
+int gvo_lsop12_encode_ex(int codecIndex, int nRows, int nCols, const int32_t *values, int deflateEnabled, int checksumEnabled,
+                         uint8_t *out, size_t outCap, size_t *outLen, int *containerType);
+/* util/GridfourCRC32C.java:160-185; LsHeader.computeChecksum :391-406 */
+uint32_t gvo_crc32c(const uint8_t *b, size_t n);
+uint32_t gvo_lsop_value_checksum(int nRows, int nCols, const int32_t *values);
 int gvo_lsop12_decode(int nRows, int nCols, const uint8_t *packing, size_t len, int32_t *values);
 int gvo_lsop12_encode_legacy_huffman(int codecIndex, int nRows, int nCols, const int32_t *values,
                                      uint8_t *out, size_t outCap, size_t *outLen);

@@ -172,17 +172,57 @@ static size_t m32_pack(const int32_t *x, size_t n, uint8_t *out)
 static void put_i32(uint8_t *p, uint32_t x) { p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24); }
 static uint32_t get_i32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-/* LsHeader.packHeader :210-265 (value checksum never enabled: LsEncoder12.java:80 default) */
+/* util/GridfourCRC32C.java:160-167 (update: table-driven, reflected Castagnoli polynomial; the table :81-146 is the one this
+ * loop generates) over a whole buffer, :183-185 getValue. */
+uint32_t gvo_crc32c(const uint8_t *b, size_t n)
+{
+    static uint32_t table[256];
+    static int ready = 0;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0x82F63B78u : 0u);
+            table[i] = c;
+        }
+        ready = 1;
+    }
+    uint32_t crc = 0;
+    crc ^= 0xffffffffu;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ b[i]) & 0xffu] ^ (crc >> 8);
+    crc ^= 0xffffffffu;
+    return crc;
+}
+
+/* LsHeader.computeChecksum :391-406: CRC-32C of the values as little-endian bytes */
+uint32_t gvo_lsop_value_checksum(int nRows, int nCols, const int32_t *values)
+{
+    const size_t n = (size_t)nRows * (size_t)nCols;
+    uint8_t *b = malloc(n * 4 + 1);
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t v = (uint32_t)values[i];
+        b[k++] = (uint8_t)(v & 0xff);
+        b[k++] = (uint8_t)((v >> 8) & 0xff);
+        b[k++] = (uint8_t)((v >> 16) & 0xff);
+        b[k++] = (uint8_t)((v >> 24) & 0xff);
+    }
+    const uint32_t c = gvo_crc32c(b, k);
+    free(b);
+    return c;
+}
+
+/* LsHeader.packHeader :210-265; checksumIncluded: LsEncoder12.setValueChecksumEnabled :117-119 (default off, :80) */
 static size_t pack_header(uint8_t *out, int codecIndex, int32_t seed, const float *u, uint32_t nInit, uint32_t nInterior,
-                          int type)
+                          int type, int checksumIncluded, uint32_t checksum)
 {
     out[0] = (uint8_t)codecIndex;
-    out[1] = (uint8_t)(type | 0x40);
+    out[1] = (uint8_t)(type | 0x40 | (checksumIncluded ? 0x80 : 0));
     out[2] = 12;
     put_i32(out + 3, (uint32_t)seed);
     size_t o = 7;
     for (int i = 0; i < 12; i++) { uint32_t b; memcpy(&b, &u[i], 4); put_i32(out + o, b); o += 4; }
     if (type != 2) { put_i32(out + o, nInit); o += 4; put_i32(out + o, nInterior); o += 4; }
+    if (checksumIncluded) { put_i32(out + o, checksum); o += 4; }
     return o;
 }
 
@@ -205,6 +245,14 @@ size_t gvo_lsop12_bound(size_t nCells) { return 64 + gvo_codec_canon_bound(nCell
 int gvo_lsop12_encode(int codecIndex, int nRows, int nCols, const int32_t *values, int deflateEnabled, uint8_t *out,
                       size_t outCap, size_t *outLen, int *containerType)
 {
+    return gvo_lsop12_encode_ex(codecIndex, nRows, nCols, values, deflateEnabled, 0, out, outCap, outLen, containerType);
+}
+
+/* ... with LsEncoder12.setValueChecksumEnabled (:117-119): the checksum is computed from the raw values (:127-131) and goes
+ * into either header (:136-146, :202-211) */
+int gvo_lsop12_encode_ex(int codecIndex, int nRows, int nCols, const int32_t *values, int deflateEnabled, int checksumEnabled,
+                         uint8_t *out, size_t outCap, size_t *outLen, int *containerType)
+{
     if (nRows < 6 || nCols < 6) return GVO_DECLINED;
     const size_t nInit = (size_t)nRows * 4 + (size_t)nCols * 2 - 9, nInt = (size_t)(nRows - 2) * (size_t)(nCols - 4);
     const size_t nCells = (size_t)nRows * (size_t)nCols;
@@ -212,11 +260,12 @@ int gvo_lsop12_encode(int codecIndex, int nRows, int nCols, const int32_t *value
     float u[12];
     int32_t seed;
     int rc = gvo_lsop12_residuals(nRows, nCols, values, &seed, u, initInt, interior);
+    const uint32_t checksum = checksumEnabled && rc == GVO_OK ? gvo_lsop_value_checksum(nRows, nCols, values) : 0u;
     uint8_t *canon = NULL, *mInit = NULL, *mInt = NULL, *zInit = NULL, *zInt = NULL;
     if (rc == GVO_OK) {
         const size_t cap = gvo_lsop12_bound(nCells);
         canon = calloc(cap, 1);
-        size_t hdr = pack_header(canon, codecIndex, seed, u, 0, 0, 2);
+        size_t hdr = pack_header(canon, codecIndex, seed, u, 0, 0, 2, checksumEnabled, checksum);
         size_t bitPos = hdr * 8;
         rc = gvo_canon_encode(canon, cap * 8, &bitPos, initInt, nInit, NULL);
         if (rc == GVO_OK) rc = gvo_canon_encode(canon, cap * 8, &bitPos, interior, nInt, NULL);  /* same bit store :152-153 */
@@ -231,8 +280,8 @@ int gvo_lsop12_encode(int codecIndex, int nRows, int nCols, const int32_t *value
             if (!(insideN <= 0 || insideN >= canonLength)) {
                 zdeflate6(mInit, nMI, zInit, nMI + 128, &initN);
                 if (!(initN <= 0 || initN + insideN >= canonLength)) {
-                    uint8_t h[64];
-                    size_t hl = pack_header(h, codecIndex, seed, u, (uint32_t)nMI, (uint32_t)nMX, 1);
+                    uint8_t h[80];
+                    size_t hl = pack_header(h, codecIndex, seed, u, (uint32_t)nMI, (uint32_t)nMX, 1, checksumEnabled, checksum);
                     total = hl + initN + insideN;
                     if (total <= outCap) {
                         memcpy(out, h, hl);

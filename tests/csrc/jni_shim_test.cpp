@@ -83,13 +83,15 @@ int main(int argc, char **argv)
         env.ExceptionClear();
     }
 
-    // ---- HipCodecNative.encode / decode, every kind: 0 CodecHuffman, 1 CodecCanonHuffman, 2 / 3 LSOP12, 4 CodecDeflate
-    for (int kind = 0; kind <= 4; kind++) {
+    // ---- HipCodecNative.encode / decode, every kind: 0 CodecHuffman, 1 CodecCanonHuffman, 2 / 3 LSOP12, 4 CodecDeflate, 5 / 6 LSOP12 + checksum
+    for (int kind = 0; kind <= 6; kind++) {
         jbyteArray p = Java_org_gridfour_hip_HipCodecNative_encode(&env, nullptr, h, kind, 1, nRows, nCols, intsIn(&env, tile));
         CHECK(p && !env.ExceptionCheck(), "HipCodecNative.encode");
         if (!p) { env.ExceptionClear(); continue; }
         if (kind == 0) CHECK(p->length == pk->length && memcmp(p->bytes.data() + 1, pk->bytes.data() + 1, (size_t)pk->length - 1) == 0,
                              "kind 0 = CodecHuffman's bytes (but for the codec index)");
+        if (kind >= 5) CHECK((p->bytes[1] & 0x80) != 0, "kinds 5 / 6: the value checksum's flag in the LSOP header");
+        if (kind == 2 || kind == 3) CHECK((p->bytes[1] & 0x80) == 0, "kinds 2 / 3: no value checksum");
         jintArray r = Java_org_gridfour_hip_HipCodecNative_decode(&env, nullptr, h, kind, nRows, nCols, p);
         CHECK(r && !env.ExceptionCheck() && intsOut(r) == tile, "HipCodecNative.decode round trip");
         env.ExceptionClear();

@@ -379,3 +379,61 @@ def test_every_single_bit_flip_of_a_deflate_container_matches_the_oracle(codec):
             assert st[k] == 0 and np.array_equal(vals[k], want), (where, int(st[k]))
             n_ok += 1
     assert n_ok > 0 and n_err > 0
+
+
+# ---- LsEncoder12.setValueChecksumEnabled (lsop/LsEncoder12.java:117-119, LsHeader.computeChecksum :391-406) ----
+@pytest.mark.parametrize("shape", [(6, 6), (24, 40), (101, 101), (120, 150), (37, 203)], ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("deflate", [False, True], ids=["canon", "deflate"])
+def test_value_checksum_containers(shape, deflate):
+    """Both containers with the value checksum: byte-equal to the oracle (whose CRC-32C is pinned by the reference's own tile
+    records, tests/test_oracle_lsop.py), decodable by the library and by the oracle."""
+    import gridfour_amd
+    codec = gridfour_amd.LsCodecHip(deflate_enabled=deflate)
+    codec.setValueChecksumEnabled(True)
+    nr, nc = shape
+    rng = np.random.default_rng(nr * 1000 + nc)
+    tiles = np.stack([_terrain(nr, nc, k).ravel() for k in range(3)] +
+                     [rng.integers(-2**31, 2**31 - 1, nr * nc, dtype=np.int64).astype(np.int32),      # every byte value in the CRC
+                      make_tile("noise16", nr, nc)])
+    packs, types, status = codec.encode_batch(1, nr, nc, tiles)
+    good, idx = [], []
+    for t, v in enumerate(tiles):
+        ref, typ = oracle.lsop12_encode(1, nr, nc, v, deflate, value_checksum=True)
+        if ref is None:
+            assert packs[t] is None and status[t] == 1
+            continue
+        assert status[t] == 0 and types[t] == typ, (t, status[t], types[t], typ)
+        assert packs[t][1] & 0x80
+        hdr = 55 if typ == 2 else 63
+        assert struct.unpack_from("<I", packs[t], hdr)[0] == oracle.lsop_value_checksum(nr, nc, v), t
+        assert packs[t] == ref, (t, len(packs[t]), len(ref))
+        good.append(packs[t])
+        idx.append(t)
+    vals, st = codec.decode_batch(nr, nc, good)
+    assert (st == 0).all() and np.array_equal(vals, tiles[idx])
+    # the same tiles without the switch: the four bytes and the flag are the whole difference
+    codec.setValueChecksumEnabled(False)
+    plain, types2, _ = codec.encode_batch(1, nr, nc, tiles[idx])
+    for k, t in enumerate(idx):
+        hdr = 55 if types[t] == 2 else 63
+        assert types2[k] == types[t] and len(good[k]) == len(plain[k]) + 4
+        assert good[k][hdr + 4:] == plain[k][hdr:] and good[k][2:hdr] == plain[k][2:hdr]
+
+
+def test_value_checksum_device_resident_batch():
+    import gridfour_amd
+    ctx = gridfour_amd.GvrsHipContext(0)
+    nr, nc, nt = 120, 150, 300
+    b = gridfour_amd.DeviceTileBatch(ctx, nr, nc, nt, codec="lsop")
+    b.synth_dem(0x9E3779B97F4A7C15 + 19, 32)
+    b.encode(codec_index=2, lsop_flags=gridfour_amd._lib.LSOP_VALUE_CHECKSUM)
+    b.decode()
+    ctx.synchronize()
+    assert np.all(b.get_enc_status() == 0) and np.all(b.get_dec_status() == 0)
+    vals = b.get_values()
+    assert np.array_equal(b.get_decoded(), vals)
+    lengths = b.get_lengths()
+    for t in range(0, nt, 37):
+        ref, _ = oracle.lsop12_encode(2, nr, nc, vals[t], False, value_checksum=True)
+        assert b.get_packing(t, int(lengths[t])) == ref, t
+    b.free()

@@ -85,3 +85,43 @@ def test_lsop_large_values_roundtrip():
     packing, typ = oracle.lsop12_encode(1, 12, 13, v, True)
     if packing is not None:
         assert np.array_equal(oracle.lsop12_decode(12, 13, packing), v.ravel())
+
+
+# ---- value checksum (LsEncoder12.setValueChecksumEnabled :117-119, LsHeader.computeChecksum :391-406) ----
+def test_crc32c_pinned_by_the_reference_sample_records(golden_dir):
+    """util/GridfourCRC32C as the oracle restates it, against checksums the REFERENCE wrote: the last four bytes of every tile
+    record of the sample files are the CRC-32C of the record before them (RecordManager.writeTile)."""
+    import os
+    import struct
+    from gvrs_walk import walk_records
+    checked = 0
+    for name in ("Sample05_IntComp.gvrs", "Sample04_ShortComp.gvrs", "Sample01_IntNoComp.gvrs", "Sample00_ShortNoComp.gvrs"):
+        with open(os.path.join(golden_dir, "ref_samples", name), "rb") as f:
+            data = f.read()
+        for pos, size, rtype, _ in walk_records(data):
+            if rtype != 2:
+                continue
+            rec = data[pos:pos + size]
+            assert struct.unpack_from("<I", rec, size - 4)[0] == oracle.crc32c(rec[:size - 4]), (name, pos)
+            checked += 1
+    assert checked == 16
+    assert oracle.crc32c(b"123456789") == 0xE3069283          # the polynomial's published check value
+
+
+@pytest.mark.parametrize("deflate", [False, True])
+def test_value_checksum_header(deflate):
+    """With the checksum enabled the packing is the one without it plus four bytes behind the header's last field, bit 7 of
+    byte 1 set (LsHeader.packHeader :245-262); the decoder skips them (LsDecoder12 prints a mismatch, nothing else)."""
+    import struct
+    nr, nc = 24, 40
+    v = oracle.dem_tiles(oracle.DEM_SEED + 5, nr, nc, 16, 0, 1)[0]
+    plain, typ = oracle.lsop12_encode(3, nr, nc, v, deflate)
+    summed, typ2 = oracle.lsop12_encode(3, nr, nc, v, deflate, value_checksum=True)
+    assert typ == typ2
+    hdr = 55 if typ == 2 else 63
+    assert len(summed) == len(plain) + 4
+    assert summed[1] == plain[1] | 0x80 and summed[0] == plain[0] and summed[2:hdr] == plain[2:hdr]
+    assert struct.unpack_from("<I", summed, hdr)[0] == oracle.lsop_value_checksum(nr, nc, v)
+    assert oracle.lsop_value_checksum(nr, nc, v) == oracle.crc32c(v.astype("<i4").tobytes())
+    assert summed[hdr + 4:] == plain[hdr:]
+    assert np.array_equal(oracle.lsop12_decode(nr, nc, summed), v)
