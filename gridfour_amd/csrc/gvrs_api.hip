@@ -1944,6 +1944,7 @@ gf_status gf_lsop12_encode_batch_i32_dev(gf_context *c, void *stream, int codecI
                                              dResiduals, resStride, dCoefs, dScratchStatus);
 }
 
+constexpr int GF_LSOP_INTERNAL_INT32_RESIDUALS = 0x100;   // (not in the header: gf_lsop12_encode_batch_i32's Deflate stage reads d_residuals)
 // ... with LsEncoder12's switches (flags: GF_LSOP_VALUE_CHECKSUM = setValueChecksumEnabled, lsop/LsEncoder12.java:117-119; the
 // Deflate alternative needs the host's zlib and is not a device-resident operation)
 gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *c, void *stream, int codecIndex, int nRows, int nCols, size_t nTiles,
@@ -1963,15 +1964,30 @@ gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *c, void *stream, int cod
         }
         return GF_OK;
     }
-    gf_status s = gf_lsop12_predict_dev(c, stream, nRows, nCols, nTiles, dValues, dResiduals, resStride, dCoefs, dScratchStatus);
-    if (s != GF_OK) return s;
+    // Terrain-sized tiles (round 5): the first kernel keeps the tile in LDS as halfwords, writes the residuals as int16 and counts
+    // the histograms on the way (k_lsop_predict16; records in the context's selection-record buffer, which gf_context_reserve
+    // sizes) -- unless the caller wants the int32 residuals themselves (GF_LSOP_INTERNAL_INT32_RESIDUALS: the host's Deflate stage)
+    const bool fast16 = gf_lsop_predict16_eligible(nRows, nCols) && !(flags & GF_LSOP_INTERNAL_INT32_RESIDUALS) && resStride >= gf_lsop12_residual_count(nRows, nCols);
+    uint32_t *hist16 = nullptr;
+    gf_status s;
+    if (fast16) {
+        const size_t need = nTiles * gf_lsop_hist_rec_words() * 4 + 16;
+        if (c->packRecs.bytes < need) {                    // not capture-safe: gf_context_reserve sizes this too
+            if ((s = c->packRecs.ensure(need)) != GF_OK) return s;
+        }
+        hist16 = (uint32_t *)c->packRecs.p;
+        GF_HIP(gf_launch_lsop_predict16(dValues, dResiduals, resStride, dCoefs, dScratchStatus, hist16, nTiles, nRows, nCols, st));
+    } else {
+        s = gf_lsop12_predict_dev(c, stream, nRows, nCols, nTiles, dValues, dResiduals, resStride, dCoefs, dScratchStatus);
+        if (s != GF_OK) return s;
+    }
     const uint32_t n0 = (uint32_t)(4 * nRows + 2 * nCols - 9), n1 = (uint32_t)((nRows - 2) * (nCols - 4));
     if (4ull * ((uint64_t)n1 + 1) >= (1ull << 22)) return GF_ERR_UNSUPPORTED;       // 22-bit counts in the tree keys
     const int valueChecksum = (flags & GF_LSOP_VALUE_CHECKSUM) ? 1 : 0;
     if (valueChecksum)
-        GF_HIP(gf_launch_lsop_value_crc(dValues, (size_t)nRows * (size_t)nCols, nTiles, dScratchStatus, dCoefs, st));
+        GF_HIP(gf_launch_lsop_value_crc(dValues, (size_t)nRows * (size_t)nCols, nTiles, nullptr, dCoefs, st));
     GF_HIP(gf_launch_canon_pack2(dResiduals, resStride, dCoefs, dScratchStatus, dOut, slotStride, dLengths, dStatus, nTiles,
-                                 n0, n1, codecIndex, st, valueChecksum));
+                                 n0, n1, codecIndex, st, valueChecksum, hist16));
     return GF_OK;
 }
 
@@ -2061,7 +2077,8 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
     deflateEnabled &= GF_LSOP_DEFLATE;
     const size_t hdrCanon = valueChecksum ? 59 : 55, hdrDeflate = valueChecksum ? 67 : 63;
     s = gf_lsop12_encode_batch_i32_dev_ex(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
-                                          valueChecksum ? GF_LSOP_VALUE_CHECKSUM : 0, (uint8_t *)c->dSlots.p, stride,
+                                          (valueChecksum ? GF_LSOP_VALUE_CHECKSUM : 0) | (deflateEnabled ? GF_LSOP_INTERNAL_INT32_RESIDUALS : 0),
+                                          (uint8_t *)c->dSlots.p, stride,
                                           (uint32_t *)c->dLengths.p, (int32_t *)c->dStatus.p, (int32_t *)c->dResiduals.p, resStride,
                                           (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p);
     if (s != GF_OK) return s;

@@ -19,6 +19,10 @@ struct __attribute__((packed, aligned(4))) GfU4 {
     uint32_t x, y, z, w;
 };
 
+struct __attribute__((packed, aligned(4))) GfU2 {
+    uint32_t x, y;
+};
+
 // ---- CodecM32 (compress/CodecM32.java:257-311) -------------------------
 // Number of M32 bytes of a residual (1..6).  Thresholds :105-111.
 GF_HD int gf_m32_len(uint32_t x)

@@ -235,7 +235,15 @@ hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, siz
                                   int32_t *status, size_t nTiles, int nRows, int nCols, hipStream_t stream);
 hipError_t gf_launch_canon_pack2(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
                                  uint8_t *out, size_t slotStride, uint32_t *lengths, int32_t *status, size_t nTiles,
-                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream, int valueChecksum = 0);
+                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream, int valueChecksum = 0,
+                                 const uint32_t *hist16 = nullptr);
+// the encoder's first kernel with the tile held in LDS as halfwords (round 5): residuals as int16 in the same per-tile regions of
+// `residuals`, histogram records (gf_lsop_hist_rec_words() words per tile) for gf_launch_canon_pack2's hist16; status receives
+// internal codes that only gf_launch_canon_pack2 understands
+bool gf_lsop_predict16_eligible(int nRows, int nCols);
+size_t gf_lsop_hist_rec_words();
+hipError_t gf_launch_lsop_predict16(const int32_t *values, int32_t *residuals, size_t resStride, uint32_t *coefs, int32_t *status,
+                                    uint32_t *hist, size_t nTiles, int nRows, int nCols, hipStream_t stream);
 // LsHeader.computeChecksum for a batch: word 13 of every tile's coefficient record (16 words) receives the CRC-32C of its values
 hipError_t gf_launch_lsop_value_crc(const int32_t *values, size_t nCells, size_t nTiles, const int32_t *inStatus, uint32_t *coefs,
                                     hipStream_t stream);

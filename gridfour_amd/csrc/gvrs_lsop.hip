@@ -55,6 +55,20 @@ __device__ __forceinline__ int32_t lsop_round_sat(float p)
     return r;
 }
 
+// The same value from single-precision steps only (round 5; FP64 instructions issue at a quarter of the rate and the interior
+// stream rounds once per cell): floor(p) is exact, and so is p - floor(p) -- for |p| >= 1 the two lie within a factor of two of
+// each other (Sterbenz); for 0 <= p < 1 it is p itself; for -1 < p < 0 it is p + 1, which rounds only where p is so small that
+// both the rounded and the true value are far above one half -- hence floor(p + 0.5) = floor(p) + [p - floor(p) >= 0.5] with no
+// rounding anywhere.  v_cvt_i32_f32 saturates and turns NaN into 0 (an infinite p: inf - inf = NaN fails the compare).
+__device__ __forceinline__ int32_t lsop_round_f32(float p)
+{
+    const float fl = floorf(p);
+    const float up = (p - fl) >= 0.5f ? fl + 1.0f : fl;       // (fl + 1 is exact below 2^24; beyond that p is an integer and p - fl = 0)
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(up));
+    return r;
+}
+
 // u1*z1 + ... + u12*z12 in float32, left to right (LsOptimalPredictor12.java:254-267)
 __device__ __forceinline__ float lsop_predict12(const float *u, const int32_t *v, uint32_t idx, uint32_t nC)
 {
@@ -349,7 +363,8 @@ __device__ __forceinline__ double lsop_bcast(double x, int k)           // value
 // inner loop  s += LU[i][k] * LUcolj[k]  runs over k in the same order here, for all rows in lockstep (row i stops at
 // k = min(i, j)); the column value of row k is final exactly when step k needs it.  Every multiply and add is
 // rounded separately, as in Java.  Writes S.u / S.status.
-__device__ __forceinline__ void lsop_lu_solve_wave(LsopShared &S, int lane)
+template <class Shared>                                // LsopShared / LsopShared16: G, u, status
+__device__ __forceinline__ void lsop_lu_solve_wave(Shared &S, int lane)
 {
     auto Cij = [&](int i, int j) -> double {              // c[i][j], symmetric (:345-349)
         if (i > j) { const int q = i; i = j; j = q; }
@@ -418,7 +433,9 @@ struct GfLsopPredictArgs {
     int32_t *status;
     size_t nTiles;
     int nRows, nCols;
+    int retryOnly;             // 1: behind k_lsop_predict16 -- only the tiles that kernel marked GF_K_LSOP_RETRY
 };
+constexpr int GF_K_LSOP_RETRY_ = 0x7fff0011;     // (= GF_K_LSOP_RETRY below)
 
 #ifndef GF_LSOP_PREDICT_WGS
 #define GF_LSOP_PREDICT_WGS 4
@@ -435,6 +452,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT_WGS) void k_lsop_predict(GfLso
     const uint32_t nInit = lsop_n_init(nR, nC), nInt = lsop_n_interior(nR, nC);
 
     GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
+        if (a.retryOnly && a.status[t] != GF_K_LSOP_RETRY_) continue;
         const int32_t *__restrict__ v = a.values + t * (size_t)nCells;
         int32_t *__restrict__ res = a.residuals + t * a.resStride;
         if (tid == 0) { S.maxAbs = 0; S.status = GF_K_OK; }
@@ -544,6 +562,388 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT_WGS) void k_lsop_predict(GfLso
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_lsop_predict16 (round 5): the encoder's first kernel for terrain-sized tiles, with the tile ON THE CHIP.
+//
+// k_lsop_predict reads a tile three and a half times (the scan for max |v|, the rows through its LDS ring for the normal
+// equations, thirteen scattered loads per cell for the interior residuals: 2.9 GB of HBM reads for 0.93 GB of tiles) and hands
+// the residuals to k_canon_pack2 as int32 (0.94 GB written, read back twice for the histograms and for the text).  Here:
+//   * the tile is read ONCE, coalesced, and kept in LDS as its two base-256 digit planes -- every tile the matrix-pipe form of
+//     the normal equations takes (|v| <= 32,639) is two bytes per cell: 36 KB for 120 x 150 --; the max scan, the initialiser
+//     residuals, the Gram matrix and the interior residuals all read LDS;
+//   * the residuals go out as int16 (half the bytes, read once: see below), and
+//   * the two histograms of CanonicalHuffman.countSymbols (:352-418) are counted here, while the residuals are in registers,
+//     and handed over as a 2 KB record per tile: k_canon_pack2 starts at the code tables and reads the residuals once.
+// A tile this kernel cannot take (|v| beyond the matrix-pipe guard, a residual beyond a halfword) is marked GF_K_LSOP_RETRY
+// and goes through k_lsop_predict and the int32 form of k_canon_pack2, which run behind it and touch only such tiles.
+// Same sums, same coefficients, same residuals: every operand of the normal equations is exact (see lsop_gram_mfma), the
+// prediction is LsOptimalPredictor12's float32 sum in its order (:254-267).
+// ------------------------------------------------------------------------------------------------
+#ifndef GF_LSOP_PREDICT16_WGS
+#define GF_LSOP_PREDICT16_WGS 4
+#endif
+constexpr int GF_K_LSOP16 = 0x7fff0010;          // internal: predicted by k_lsop_predict16 (residuals int16, histogram record written)
+constexpr int GF_K_LSOP_RETRY = GF_K_LSOP_RETRY_; // internal: left to k_lsop_predict
+#ifndef GF_LSOP_HR16
+#define GF_LSOP_HR16 2
+#endif
+constexpr int LSOP_HR16 = GF_LSOP_HR16;          // replicas of the interior's histogram in k_lsop_predict16
+constexpr int LSOP_HIST_REC_WORDS = 2 * CN_HIST + 8;   // per tile: the two histograms, then maxKind[2], nGap[2], 4 spare
+
+struct LsopShared16 {
+    double G[104];
+    union {
+        int32_t C32[27 * 32];                    // lsop_gram_mfma16: the digit Gram matrix, the 27 rows that hold digits
+        struct {                                 // ... and afterwards the residual histograms
+            uint32_t hist0[CN_HIST];
+            uint32_t hist1[CN_HIST * LSOP_HR16];
+        };
+    };
+    float u[12];
+    uint32_t maxAbs, maxRes;
+    uint32_t maxKind[2];
+    int32_t status;
+};
+
+struct GfLsopPredict16Args {
+    const int32_t *values;
+    int16_t *residuals;        // per tile resStride halfwords: [initialisers | interior]
+    size_t resStride;
+    uint32_t *coefs;           // per tile 16 words: seed, 12 float bit patterns, 3 spare
+    int32_t *status;           // GF_K_LSOP16 / GF_K_DECLINED / GF_K_LSOP_RETRY
+    uint32_t *hist;            // per tile LSOP_HIST_REC_WORDS
+    size_t nTiles;
+    int nRows, nCols;
+};
+
+// halfword layout of a tile's residuals between k_lsop_predict16 and k_canon_pack2<true>: initialisers at 0, the interior on the
+// next 16-byte boundary
+__device__ __forceinline__ uint32_t lsop_interior_offset16(uint32_t nInit) { return (nInit + 7u) & ~7u; }
+
+// The tile in LDS as its two balanced base-256 DIGIT PLANES (a byte per cell each): lo = (int8) v, hi = (v + 128) >> 8,
+// v = 256 hi + lo -- the digits the matrix pipe multiplies (lsop_gram_mfma).  Kept as halfwords, every cell's digits were picked
+// apart again for each of the 26 operand columns it belongs to: 16 reads, 16 adds and 12 byte permutes per MFMA, 1.58 of the
+// kernel's 2.3 ms; from a plane a lane's sixteen cells are sixteen consecutive BYTES: five words and four v_alignbyte.
+struct LsopPlanes {
+    const int8_t *lo, *hi;
+};
+__device__ __forceinline__ int32_t lsop_plane_value(const LsopPlanes &P, uint32_t idx) { return ((int32_t)P.hi[idx] << 8) + (int32_t)P.lo[idx]; }
+
+// the prediction of lsop_predict12 from the planes
+__device__ __forceinline__ float lsop_predict12_p(const float *u, const LsopPlanes &P, uint32_t idx, uint32_t nC)
+{
+    auto V = [&](uint32_t i) -> float { return (float)lsop_plane_value(P, i); };
+    float p = u[0] * V(idx - 1);
+    p = p + u[1] * V(idx - nC - 1);
+    p = p + u[2] * V(idx - nC);
+    p = p + u[3] * V(idx - nC + 1);
+    p = p + u[4] * V(idx - nC + 2);
+    p = p + u[5] * V(idx - 2);
+    p = p + u[6] * V(idx - nC - 2);
+    p = p + u[7] * V(idx - 2 * nC - 2);
+    p = p + u[8] * V(idx - 2 * nC - 1);
+    p = p + u[9] * V(idx - 2 * nC);
+    p = p + u[10] * V(idx - 2 * nC + 1);
+    p = p + u[11] * V(idx - 2 * nC + 2);
+    return p;
+}
+
+// lsop_gram_mfma with the whole tile in LDS as digit planes: no ring, no barrier per row -- the groups of 32 cells of all rows are
+// dealt round-robin to the four waves.  Operand layout and the recombination are lsop_gram_mfma's: lane l holds column l & 31
+// (13 lo digits, 13 hi digits, the ones, five idle) for the sixteen cells 16 (l >> 5) .. + 15 of the group.
+__device__ __forceinline__ void lsop_gram_mfma16(const LsopPlanes &P, int32_t *C32, uint32_t nR, uint32_t nC, double *G, int tid)
+{
+    const int lane = tid & 63;
+    const uint32_t wave = gf_wave_id();
+    const uint32_t col = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
+    const uint32_t zi = col < 13u ? col : col < 26u ? col - 13u : col == 26u ? 13u : 14u;
+    int dr = 0, dc = 0;
+    switch (zi) {
+    case 1: dc = -1; break;
+    case 2: dr = -1; dc = -1; break;
+    case 3: dr = -1; break;
+    case 4: dr = -1; dc = 1; break;
+    case 5: dr = -1; dc = 2; break;
+    case 6: dc = -2; break;
+    case 7: dr = -1; dc = -2; break;
+    case 8: dr = -2; dc = -2; break;
+    case 9: dr = -2; dc = -1; break;
+    case 10: dr = -2; break;
+    case 11: dr = -2; dc = 1; break;
+    case 12: dr = -2; dc = 2; break;
+    default: break;
+    }
+    const int8_t *plane = (col >= 13u && col < 26u) ? P.hi : P.lo;                    // (the constant columns read the lo plane and drop it)
+    const uint32_t constWord = zi == 13u ? 0x01010101u : 0u;
+    const bool isConst = zi >= 13u;
+    LsV16i acc = {};
+    for (uint32_t i = (uint32_t)tid; i < 27u * 32u; i += 256u) C32[i] = 0;
+    __syncthreads();
+    const uint32_t wI = nC - 4u, nGroups = (wI + 31u) >> 5, nTurns = (nR - 2u) * nGroups;
+    uint32_t r = 2u, g = wave;                                                        // turn = (r - 2) nGroups + g
+    while (g >= nGroups) { g -= nGroups; r++; }
+    for (uint32_t turn = wave; turn < nTurns; turn += 4u) {
+        const uint32_t c0 = 2u + 32u * g + 16u * h;                                   // the lane's first cell of the group
+        const uint32_t byteAt = (uint32_t)((int)(r * nC) + dr * (int)nC + dc) + c0;   // ... in its plane
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(plane + (byteAt & ~3u));
+        const uint32_t sh = byteAt & 3u;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+        LsV4i x;
+        x[0] = (int)(isConst ? constWord : __builtin_amdgcn_alignbyte(w1, w0, sh));
+        x[1] = (int)(isConst ? constWord : __builtin_amdgcn_alignbyte(w2, w1, sh));
+        x[2] = (int)(isConst ? constWord : __builtin_amdgcn_alignbyte(w3, w2, sh));
+        x[3] = (int)(isConst ? constWord : __builtin_amdgcn_alignbyte(w4, w3, sh));
+        if (g + 1u == nGroups) {                                                      // (wave-uniform) the row's last group
+            const uint32_t nValid = c0 < nC - 2u ? min(16u, nC - 2u - c0) : 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) {
+                const uint32_t have = nValid > 4u * q ? min(4u, nValid - 4u * q) : 0u;
+                x[q] &= (int)(have >= 4u ? 0xFFFFFFFFu : (1u << (8u * have)) - 1u);
+            }
+        }
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, x, acc, 0, 0, 0);
+        g += 4u;
+        while (g >= nGroups) { g -= nGroups; r++; }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 16u; q++) {
+        const uint32_t row = (q & 3u) + 8u * (q >> 2) + 4u * h;
+        if (row < 27u) atomicAdd(&C32[row * 32u + col], acc[q]);
+    }
+    __syncthreads();
+    if (tid < 104) {
+        const int i = PAIRS.i[tid], j = PAIRS.j[tid];
+        long long sum;
+        if (j == 13) sum = 256ll * C32[(13 + i) * 32 + 26] + C32[i * 32 + 26];
+        else
+            sum = 65536ll * C32[(13 + i) * 32 + 13 + j] + 256ll * ((long long)C32[(13 + i) * 32 + j] + C32[i * 32 + 13 + j]) + C32[i * 32 + j];
+        G[tid] = (double)sum;
+    }
+}
+
+// OUT32: the same kernel behind gf_lsop12_predict_dev -- residuals as int32 in the public layout ([initialisers | interior], resStride
+// ints per tile), no histograms, status GF_K_OK; only the tiles the matrix pipe cannot take are left to k_lsop_predict.
+template <bool OUT32>
+__global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(GfLsopPredict16Args a)
+{
+    __shared__ LsopShared16 S;
+    extern __shared__ __attribute__((aligned(16))) int8_t lsopPlanes[];    // the tile's two digit planes, a byte per cell each (+ 64
+                                                                           // behind either: the reads of a row's last group, masked)
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    const uint32_t nInit = lsop_n_init(nR, nC), nInt = lsop_n_interior(nR, nC);
+    const uint32_t planeStride = (nCells + 64u + 15u) & ~15u;
+    int8_t *const loP = lsopPlanes, *const hiP = lsopPlanes + planeStride;
+    const LsopPlanes PL{loP, hiP};
+    auto V = [&](uint32_t idx) -> uint32_t { return (uint32_t)lsop_plane_value(PL, idx); };
+
+    GF_FOR_WG_TILE(t, a.nTiles) {
+        const int32_t *__restrict__ v = a.values + t * (size_t)nCells;
+        int16_t *__restrict__ res = a.residuals + t * a.resStride;                    // (OUT32: resStride counts halfwords here too)
+        int32_t *__restrict__ res32 = reinterpret_cast<int32_t *>(res);
+        if (tid == 0) { S.maxAbs = 0; S.maxRes = 0; S.status = GF_K_OK; S.maxKind[0] = 0; S.maxKind[1] = 0; }
+        __syncthreads();
+
+        // the tile, once: HBM -> halfwords in LDS, max |v| on the way (four cells per thread and turn where the tile starts on a
+        // 16-byte boundary)
+        uint32_t m = 0;
+        if ((nCells & 3u) == 0u) {
+            const GfU4 *v4 = reinterpret_cast<const GfU4 *>(v);
+            uint32_t *lo32 = reinterpret_cast<uint32_t *>(loP), *hi32 = reinterpret_cast<uint32_t *>(hiP);
+            for (uint32_t i = tid; i < (nCells >> 2); i += 256u) {
+                const GfU4 q = v4[i];
+                auto mag = [](uint32_t x) -> uint32_t { return (int32_t)x < 0 ? 0u - x : x; };
+                m = max(max(m, mag(q.x)), max(max(mag(q.y), mag(q.z)), mag(q.w)));
+                // byte 0 of the four cells; byte 1 of the four cells + 128
+                lo32[i] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(q.w, q.z, 0x0c0c0400u), __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0400u), 0x05040100u);
+                const uint32_t hx = q.x + 128u, hy = q.y + 128u, hz = q.z + 128u, hw = q.w + 128u;
+                hi32[i] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(hw, hz, 0x0c0c0501u), __builtin_amdgcn_perm(hy, hx, 0x0c0c0501u), 0x05040100u);
+            }
+        } else {
+            for (uint32_t i = tid; i < nCells; i += 256u) {
+                const int32_t x = v[i];
+                m = max(m, x < 0 ? 0u - (uint32_t)x : (uint32_t)x);
+                loP[i] = (int8_t)x;
+                hiP[i] = (int8_t)((x + 128) >> 8);
+            }
+        }
+        if (tid < 64) { loP[nCells + (uint32_t)tid] = 0; hiP[nCells + (uint32_t)tid] = 0; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, gf_lane_xor(m, o));
+        if (lane == 0) atomicMax(&S.maxAbs, m);
+        __syncthreads();
+        if (S.maxAbs > LSOP_MFMA_MAX_ABS) {                               // (what a halfword and the matrix pipe's digits hold)
+            if (tid == 0) a.status[t] = GF_K_LSOP_RETRY;
+            __syncthreads();
+            continue;
+        }
+
+        // normal equations (:335-342) on the matrix pipe, 13 x 13 system (:353-378) by wave 0
+        lsop_gram_mfma16(PL, S.C32, nR, nC, S.G, tid);
+        __syncthreads();
+        if (wave == 0) lsop_lu_solve_wave(S, lane);
+        __syncthreads();
+
+        if (S.status != GF_K_OK) {
+            if (tid == 0) a.status[t] = S.status;
+            __syncthreads();
+            continue;
+        }
+        float u[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) u[i] = S.u[i];
+        if (tid < 16) a.coefs[t * 16 + tid] = tid == 0 ? (uint32_t)v[0] : tid <= 12 ? __float_as_uint(S.u[tid - 1]) : 0u;
+        for (int i = tid; i < CN_HIST * (1 + LSOP_HR16); i += 256) S.hist0[i] = 0;          // (C32 is done with; hist1 follows hist0)
+        __syncthreads();
+
+        // a residual into its stream's histogram as CanonicalHuffman.countSymbols classifies it (:352-418; a halfword has kinds 0-4)
+        // (the interior's histogram in LSOP_HR16 replicas, replica-major -- a tile's residuals crowd a dozen bins around zero,
+        // and lanes that add to the same word take turns --; the few hundred initialisers in one)
+        const uint32_t rep = (uint32_t)lane & (LSOP_HR16 - 1);
+        uint32_t mk0 = 0, mk1 = 0, maxRes = 0;
+        auto count = [&](uint32_t *hist, uint32_t x, uint32_t &mk, bool replicated) {
+            uint32_t *h = hist + (replicated ? rep * CN_HIST : 0u);
+            if (x + 128u < 256u) { atomicAdd(h + (x + 128u), 1u); return; }
+            uint32_t kind;
+            const uint32_t target = cn_classify_count(x, &kind);
+            atomicAdd(h + target, 1u);
+            if (kind >= 1u && kind <= 3u) atomicAdd(h + CN_ESC2, kind);
+            else if (kind >= 4u && kind <= 6u) atomicAdd(h + CN_ESC1, kind - 3u);
+            mk = max(mk, kind == 7u ? 0u : kind);
+        };
+        auto magOf = [](uint32_t x) -> uint32_t { return (int32_t)x < 0 ? ~x : x; };   // x fits a halfword iff magOf(x) <= 32767
+
+        // initialiser stream (:143-209)
+        for (uint32_t k = tid; k < nInit; k += 256) {
+            uint32_t kind;
+            const uint32_t idx = lsop_init_cell(k, nR, nC, &kind);
+            const uint32_t x = V(idx);
+            uint32_t r;
+            if (kind == 0) r = x - V(idx - 1);
+            else if (kind == 1) r = x - V(idx - nC);
+            else r = x - (V(idx - 1) + V(idx - nC) - V(idx - nC - 1));
+            if constexpr (OUT32) res32[k] = (int32_t)r;
+            else {
+                res[k] = (int16_t)r;
+                maxRes = max(maxRes, magOf(r));
+                count(S.hist0, r, mk0, false);
+            }
+        }
+
+        // interior stream (:248-272): EIGHT neighbouring elements per thread and turn -- inside a row (all but the one item in 19
+        // that straddles a row's end) their 104 neighbours are 34 distinct cells: ten of the row, twelve of each row above, read
+        // and converted once --, one 16-byte store (the interior starts on a 16-byte boundary of the halfword layout)
+        {
+            GfU4 *__restrict__ ri128 = reinterpret_cast<GfU4 *>(res + lsop_interior_offset16(nInit));
+            const uint32_t wI = nC - 4u;
+            const uint32_t magicW = (uint32_t)(((1ull << 32) + wI - 1u) / wI);          // e / wI = umulhi(e, magicW) for e wI < 2^32
+            auto residualOf = [&](uint32_t e) -> uint32_t {
+                const uint32_t r = __umulhi(e, magicW), c = e - r * wI;
+                const uint32_t idx = (r + 2u) * nC + c + 2u;
+                return V(idx) - (uint32_t)lsop_round_f32(lsop_predict12_p(u, PL, idx, nC));
+            };
+            constexpr int IT = 8;                                                        // elements per item
+            const uint32_t nItems = (nInt + IT - 1u) / IT;
+            for (uint32_t k = (uint32_t)tid; k < nItems; k += 256u) {
+                const uint32_t e = (uint32_t)IT * k;
+                const uint32_t r = __umulhi(e, magicW), c = e - r * wI;
+                uint32_t x[IT];
+                if (c + (IT - 1u) < wI) {                                                // (then e + IT - 1 < nInt as well)
+                    const uint32_t i0 = (r + 2u) * nC + c, i1 = i0 - nC, i2 = i1 - nC;   // column c = the first cell's column - 2
+                    float a[IT + 2], b[IT + 4], d[IT + 4];
+                    int32_t own[IT];
+#pragma unroll
+                    for (int q = 0; q < IT + 2; q++) {
+                        const int32_t val = lsop_plane_value(PL, i0 + (uint32_t)q);
+                        a[q] = (float)val;
+                        if (q >= 2) own[q - 2] = val;
+                    }
+#pragma unroll
+                    for (int q = 0; q < IT + 4; q++) { b[q] = (float)lsop_plane_value(PL, i1 + (uint32_t)q); d[q] = (float)lsop_plane_value(PL, i2 + (uint32_t)q); }
+#pragma unroll
+                    for (int q = 0; q < IT; q++) {
+                        // the cell at column c + 2 + q: z1 = W, z2 = NW, z3 = N, z4 = NE, z5 = NEE, z6 = WW, z7 = NWW, z8..z12 = the row two above
+                        float pr = u[0] * a[q + 1];
+                        pr = pr + u[1] * b[q + 1];
+                        pr = pr + u[2] * b[q + 2];
+                        pr = pr + u[3] * b[q + 3];
+                        pr = pr + u[4] * b[q + 4];
+                        pr = pr + u[5] * a[q];
+                        pr = pr + u[6] * b[q];
+                        pr = pr + u[7] * d[q];
+                        pr = pr + u[8] * d[q + 1];
+                        pr = pr + u[9] * d[q + 2];
+                        pr = pr + u[10] * d[q + 3];
+                        pr = pr + u[11] * d[q + 4];
+                        x[q] = (uint32_t)own[q] - (uint32_t)lsop_round_f32(pr);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < IT; q++) x[q] = e + (uint32_t)q < nInt ? residualOf(e + (uint32_t)q) : 0u;
+                }
+                if constexpr (OUT32) {
+                    int32_t *ro = res32 + nInit + e;
+                    if (e + (uint32_t)IT <= nInt) {
+                        GfU4 w0, w1;
+                        w0.x = x[0]; w0.y = x[1]; w0.z = x[2]; w0.w = x[3];
+                        w1.x = x[4]; w1.y = x[5]; w1.z = x[6]; w1.w = x[7];
+                        *reinterpret_cast<GfU4 *>(ro) = w0;
+                        *reinterpret_cast<GfU4 *>(ro + 4) = w1;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < IT; q++)
+                            if (e + (uint32_t)q < nInt) ro[q] = (int32_t)x[q];
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int q = 0; q < IT; q++) {
+                    if (e + (uint32_t)q < nInt) {
+                        maxRes = max(maxRes, magOf(x[q]));
+                        count(S.hist1, x[q], mk1, true);
+                    }
+                }
+                GfU4 w;
+                w.x = (x[0] & 0xffffu) | (x[1] << 16);
+                w.y = (x[2] & 0xffffu) | (x[3] << 16);
+                w.z = (x[4] & 0xffffu) | (x[5] << 16);
+                w.w = (x[6] & 0xffffu) | (x[7] << 16);
+                ri128[k] = w;                                                            // (the region has room for the padding halfwords)
+            }
+        }
+        if constexpr (OUT32) {
+            if (tid == 0) a.status[t] = GF_K_OK;
+            __syncthreads();
+            continue;
+        }
+        if (mk0) atomicMax(&S.maxKind[0], mk0);
+        if (mk1) atomicMax(&S.maxKind[1], mk1);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) maxRes = max(maxRes, gf_lane_xor(maxRes, o));
+        if (lane == 0) atomicMax(&S.maxRes, maxRes);
+        __syncthreads();
+
+        // the record for k_canon_pack2: the histograms as its own first pass leaves them (end-of-text counted once, nothing
+        // beyond the alphabet), the largest escape kind per stream, no values in the -8333608 gap (a halfword holds none)
+        uint32_t *rec = a.hist + t * (size_t)LSOP_HIST_REC_WORDS;
+        for (int i = tid; i < 2 * CN_HIST; i += 256) {
+            const int p = i / CN_HIST, sym = i - p * CN_HIST;
+            uint32_t sum = 0;
+            if (p == 0) sum = S.hist0[sym];
+            else {
+#pragma unroll
+                for (int k = 0; k < LSOP_HR16; k++) sum += S.hist1[k * CN_HIST + sym];
+            }
+            if (sym == CN_EOT) sum = 1;
+            if (sym >= CN_SYMS) sum = 0;
+            rec[i] = sum;
+        }
+        if (tid < 8) rec[2 * CN_HIST + tid] = tid < 2 ? S.maxKind[tid] : 0u;
+        if (tid == 0) a.status[t] = S.maxRes > 32767u ? GF_K_LSOP_RETRY : GF_K_LSOP16;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_canon_pack2: header + two canonical-Huffman streams in one bit store
 // ------------------------------------------------------------------------------------------------
 
@@ -580,7 +980,8 @@ __device__ __forceinline__ uint32_t p2_elem_max_bits(uint32_t maxLen, uint32_t m
 // text of one stream held as an int array
 // elements [begin, end) of a residual array through wave-private bit windows (gvrs_encode_common.h: wave_windows_*), eight
 // consecutive elements per lane; false = a wave's share did not fit its window, nothing was written
-__device__ bool p2_pack_array_waves(const int32_t *__restrict__ arr, uint32_t begin, uint32_t end, const uint32_t *tab,
+template <class T>                                     // int32_t, or int16_t behind k_lsop_predict16
+__device__ bool p2_pack_array_waves(const T *__restrict__ arr, uint32_t begin, uint32_t end, const uint32_t *tab,
                                     uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps,
                                     uint32_t slotWords)
 {
@@ -596,7 +997,7 @@ __device__ bool p2_pack_array_waves(const int32_t *__restrict__ arr, uint32_t be
         uint32_t cl[CPT], xs[CPT];
         uint32_t myBits = 0, wide = 0;
 #pragma unroll
-        for (int j = 0; j < CPT; j++) xs[j] = i0 + j < segEnd ? (uint32_t)arr[i0 + j] : 0u;
+        for (int j = 0; j < CPT; j++) xs[j] = i0 + j < segEnd ? (uint32_t)(int32_t)arr[i0 + j] : 0u;
 #pragma unroll
         for (int j = 0; j < CPT; j++) {
             const bool emit = i0 + j < segEnd;
@@ -641,7 +1042,8 @@ __device__ bool p2_pack_array_waves(const int32_t *__restrict__ arr, uint32_t be
     return wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
 }
 
-__device__ void p2_pack_array(const int32_t *__restrict__ arr, uint32_t n, const uint32_t *tab, uint32_t elemMaxBits,
+template <class T>
+__device__ void p2_pack_array(const T *__restrict__ arr, uint32_t n, const uint32_t *tab, uint32_t elemMaxBits,
                               uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps)
 {
     const uint32_t tid = threadIdx.x;
@@ -661,7 +1063,7 @@ __device__ void p2_pack_array(const int32_t *__restrict__ arr, uint32_t n, const
             xs[e] = 0;
             const uint32_t s = s0 + e;
             if (e < E && tid < active && s < cEnd) {
-                xs[e] = (uint32_t)arr[s];
+                xs[e] = (uint32_t)(int32_t)arr[s];
                 myBits += cn_value_bits(tab, xs[e]);
             }
         }
@@ -774,39 +1176,53 @@ struct GfPack2Args {
     uint32_t n0, n1;
     int codecIndex;
     int valueChecksum;         // LsEncoder12.setValueChecksumEnabled: word 13 of the coefficient record goes behind the header
+    const uint32_t *hist;      // R16: the histogram records of k_lsop_predict16 (LSOP_HIST_REC_WORDS per tile)
 };
 
 constexpr uint32_t LSOP_HEADER_BYTES = 55;     // LsHeader.packHeader :219-222 for the canonical container: 7 + 12*4 (+ 4: the checksum)
 
+// R16 (round 5): the tiles k_lsop_predict16 took -- residuals as halfwords, the histograms already counted (a.hist): the kernel
+// starts at the code tables and reads the residuals once.  The int32 instantiation takes every other tile (predicted by
+// k_lsop_predict: inStatus GF_K_OK; or declined) and leaves the halfword tiles alone.
+template <bool R16>
 __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(GfPack2Args a)
 {
     __shared__ Pack2Persist P;
     __shared__ Pack2Union S;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)gf_wave_id();
+    using ResT = std::conditional_t<R16, int16_t, int32_t>;
 
     GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
-        if (a.inStatus[t] != GF_K_OK) {
-            if (tid == 0) { a.lengths[t] = 0; a.status[t] = a.inStatus[t]; }
+        const int32_t inStatus = a.inStatus[t];
+        if (R16 ? inStatus != GF_K_LSOP16 : inStatus == GF_K_LSOP16) continue;            // the other instantiation's tile
+        if (inStatus != (R16 ? GF_K_LSOP16 : GF_K_OK)) {
+            if (tid == 0) { a.lengths[t] = 0; a.status[t] = inStatus; }
             __syncthreads();
             continue;
         }
-        const int32_t *__restrict__ res = a.residuals + t * a.resStride;
+        const ResT *__restrict__ res = reinterpret_cast<const ResT *>(a.residuals) + t * (R16 ? 2 * a.resStride : a.resStride);
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
 
-        for (int i = tid; i < 2 * CN_HIST * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
         if (tid < 2) { P.maxKind[tid] = 0; P.nGap[tid] = 0; }
         if (tid == 0) P.pmLock = 0;
+        if constexpr (R16) {
+            const uint32_t *rec = a.hist + t * (size_t)LSOP_HIST_REC_WORDS;
+            __syncthreads();
+            for (int i = tid; i < 2 * CN_HIST; i += ENC_THREADS) (&P.hist[0][0])[i] = rec[i];
+            if (tid < 2) P.maxKind[tid] = rec[2 * CN_HIST + tid];
+        } else {
+        for (int i = tid; i < 2 * CN_HIST * HIST_R; i += ENC_THREADS) (&S.histR[0][0])[i] = 0;
         __syncthreads();
         const uint32_t rep = (uint32_t)lane & (HIST_R - 1);
         for (int sidx = 0; sidx < 2; sidx++) {
-            const int32_t *arr = sidx == 0 ? res : res + a.n0;
+            const ResT *arr = sidx == 0 ? res : res + a.n0;
             const uint32_t n = sidx == 0 ? a.n0 : a.n1;
             uint32_t *h = &S.histR[sidx][rep];
             uint32_t mk = 0, gaps = 0;
             for (uint32_t i0 = tid; i0 < n; i0 += 4u * ENC_THREADS) {       // four independent loads in flight
                 uint32_t xv[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) xv[k] = i0 + k * ENC_THREADS < n ? (uint32_t)arr[i0 + k * ENC_THREADS] : 0u;
+                for (int k = 0; k < 4; k++) xv[k] = i0 + k * ENC_THREADS < n ? (uint32_t)(int32_t)arr[i0 + k * ENC_THREADS] : 0u;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (i0 + k * ENC_THREADS >= n) break;
@@ -834,6 +1250,7 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
             if (s == CN_EOT) sum = 1;
             if (s >= CN_SYMS) sum = 0;
             P.hist[p][s] = sum;
+        }
         }
         for (int i = tid; i < 2 * CN_IMG_WORDS; i += ENC_THREADS) (&P.img[0][0])[i] = 0;
         __syncthreads();
@@ -872,7 +1289,7 @@ __global__ __launch_bounds__(ENC_THREADS, GF_LSOP_PACK2_WGS) void k_canon_pack2(
         ps.wordBase = 0;
         window_flush(S.win, out32, ps);
         for (int sidx = 0; sidx < 2; sidx++) {
-            const int32_t *arr = sidx == 0 ? res : res + a.n0;
+            const ResT *arr = sidx == 0 ? res : res + (R16 ? lsop_interior_offset16(a.n0) : a.n0);
             const uint32_t n = sidx == 0 ? a.n0 : a.n1;
             p2_append_bits(P.img[sidx], P.imgBits[sidx], S.win, out32, ps);
             const uint32_t emb = max(1u, p2_elem_max_bits(P.maxLen[sidx], P.maxKind[sidx]));
@@ -1515,7 +1932,19 @@ hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, siz
                                   int32_t *status, size_t nTiles, int nRows, int nCols, hipStream_t stream)
 {
     if (nTiles == 0) return hipSuccess;
-    GfLsopPredictArgs a{values, residuals, resStride, coefs, status, nTiles, nRows, nCols};
+    if (gf_lsop_predict16_eligible(nRows, nCols)) {
+        // terrain-sized tiles: the tile in LDS as digit planes (k_lsop_predict16<true>), k_lsop_predict behind it for what it leaves
+        GfLsopPredict16Args p{values, reinterpret_cast<int16_t *>(residuals), 2 * resStride, coefs, status, nullptr, nTiles, nRows, nCols};
+        const size_t dyn16 = 2 * (((size_t)nRows * (size_t)nCols + 64 + 15) & ~(size_t)15);
+        static GfDynLdsOptIn opt32;
+        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_predict16<true>, dyn16, opt32);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_lsop_predict16<true>, gf_tile_grid(nTiles), dim3(256), dyn16, stream, p);
+        GfLsopPredictArgs b{values, residuals, resStride, coefs, status, nTiles, nRows, nCols, 1};
+        hipLaunchKernelGGL(k_lsop_predict, gf_tile_grid(nTiles), dim3(256), ((size_t)4 * (size_t)nCols + 40) * 4, stream, b);
+        return hipGetLastError();
+    }
+    GfLsopPredictArgs a{values, residuals, resStride, coefs, status, nTiles, nRows, nCols, 0};
     const size_t dyn = (size_t)nCols <= LSOP_RING_MAXC ? ((size_t)4 * (size_t)nCols + 40) * 4 : 0;   // (+ 40 ints: lsop_gram_mfma reads a
                                                                                                         // row's last group of sixteen past its end)
     hipLaunchKernelGGL(k_lsop_predict, gf_tile_grid(nTiles), dim3(256), dyn, stream, a);
@@ -1524,11 +1953,40 @@ hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, siz
 
 hipError_t gf_launch_canon_pack2(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
                                  uint8_t *out, size_t slotStride, uint32_t *lengths, int32_t *status, size_t nTiles,
-                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream, int valueChecksum)
+                                 uint32_t n0, uint32_t n1, int codecIndex, hipStream_t stream, int valueChecksum, const uint32_t *hist16)
 {
     if (nTiles == 0) return hipSuccess;
-    GfPack2Args a{residuals, resStride, coefs, inStatus, out, slotStride, lengths, status, nTiles, n0, n1, codecIndex, valueChecksum};
-    hipLaunchKernelGGL(k_canon_pack2, gf_tile_grid(nTiles), dim3(ENC_THREADS), 0, stream, a);
+    GfPack2Args a{residuals, resStride, coefs, inStatus, out, slotStride, lengths, status, nTiles, n0, n1, codecIndex, valueChecksum, hist16};
+    // hist16: k_lsop_predict16 ran first -- its tiles through the halfword instantiation, what it left to k_lsop_predict through the other
+    if (hist16) hipLaunchKernelGGL(k_canon_pack2<true>, gf_tile_grid(nTiles), dim3(ENC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k_canon_pack2<false>, gf_tile_grid(nTiles), dim3(ENC_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+// the tile sizes k_lsop_predict16 takes: the halfword tile and its static LDS in a third of a CU's 160 KB, rows the matrix-pipe
+// form accepts, interiors whose int32 digit sums cannot overflow
+bool gf_lsop_predict16_eligible(int nRows, int nCols)
+{
+    const size_t nCells = (size_t)nRows * (size_t)nCols, nInt = (size_t)(nRows - 2) * (size_t)(nCols - 4);
+    return nRows >= 6 && nCols >= 6 && (size_t)nCols <= LSOP_RING_MAXC && nInt < (1u << 17) &&
+           2 * ((nCells + 64 + 15) & ~(size_t)15) + sizeof(LsopShared16) <= 53 * 1024;
+}
+size_t gf_lsop_hist_rec_words() { return LSOP_HIST_REC_WORDS; }
+
+// k_lsop_predict16, then k_lsop_predict for the tiles it marked GF_K_LSOP_RETRY (none on terrain)
+hipError_t gf_launch_lsop_predict16(const int32_t *values, int32_t *residuals, size_t resStride, uint32_t *coefs, int32_t *status,
+                                    uint32_t *hist, size_t nTiles, int nRows, int nCols, hipStream_t stream)
+{
+    if (nTiles == 0) return hipSuccess;
+    GfLsopPredict16Args a{values, reinterpret_cast<int16_t *>(residuals), 2 * resStride, coefs, status, hist, nTiles, nRows, nCols};
+    const size_t dyn = 2 * (((size_t)nRows * (size_t)nCols + 64 + 15) & ~(size_t)15);      // the two digit planes
+    static GfDynLdsOptIn opt;
+    const hipError_t e = gf_opt_in_dyn_lds(k_lsop_predict16<false>, dyn, opt);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lsop_predict16<false>, gf_tile_grid(nTiles), dim3(256), dyn, stream, a);
+    GfLsopPredictArgs b{values, residuals, resStride, coefs, status, nTiles, nRows, nCols, 1};
+    const size_t dynB = (size_t)nCols <= LSOP_RING_MAXC ? ((size_t)4 * (size_t)nCols + 40) * 4 : 0;
+    hipLaunchKernelGGL(k_lsop_predict, gf_tile_grid(nTiles), dim3(256), dynB, stream, b);
     return hipGetLastError();
 }
 

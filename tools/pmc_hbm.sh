@@ -21,7 +21,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row["Counter_Name"] == c:
                 acc[re.sub(r"\(anonymous namespace\)::", "", row["Kernel_Name"]).split("(")[0]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
-            res[k][c] = max(v[-2:])    # the last (warm) call; the fast decode kernel runs twice per call, its second run empty on terrain
+            res[k][c] = v[-1]          # the last (warm) call: every kernel runs once per call (round 5: the fast decode kernel's
+                                       # second run is an instantiation of its own)
 import os
 out = {"workload": "$WL", "commit": os.environ.get("GF_COMMIT", ""), "csrc_digest": __import__("gridfour_amd.build", fromlist=["x"]).csrc_digest(), "unit": "bytes per launch", "correction": "FETCH_SIZE KB x1024 x2 (gfx950 half-count), WRITE_SIZE KB x1024", "kernels": {}}
 for k, d in res.items():

@@ -13,7 +13,7 @@ for f in glob.glob("gpurun_out/pmcp/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
         if "k_huffman_decode<2>" in row["Kernel_Name"].replace("(anonymous namespace)::", ""): acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    print("dec limit=$3", {c.replace("SQ_", ""): "%.5g" % (max(v[-2:]) / 12960) for c, v in acc.items()})
+    print("dec limit=$3", {c.replace("SQ_", ""): "%.5g" % (v[-1] / 12960) for c, v in acc.items()})
 PY
 done
 done

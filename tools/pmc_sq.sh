@@ -17,7 +17,7 @@ for f in glob.glob("gpurun_out/pmcsq_$i/**/*counter_collection.csv", recursive=T
         if ("encode" in k or "pack" in k) if "$WHICH" == "enc" else ("decode" in k):
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, d in acc.items():
-        print(k, {c.replace("SQ_", ""): "%.5g" % (max(v[-2:]) / 12960) for c, v in d.items()})
+        print(k, {c.replace("SQ_", ""): "%.5g" % (v[-1] / 12960) for c, v in d.items()})
 PY
 rm -rf gpurun_out/pmcsq_$i
 done
