@@ -446,6 +446,15 @@ def _rough_record(args, ctx, batch, n_rows, n_cols, n_tiles, tiles_per_row, seed
     rec = {"workload": "etopo1_rough", "encode_ms": round(enc, 4), "decode_ms": round(dec, 4), "MBps": round(raw_mb / ((enc + dec) * 1e-3), 1),
            "bit_exact": bool(ok), "bytes_per_cell": round(c, 4)}
     rec.update(_m32_stats(vals, batch.get_predictors(), n_rows, n_cols))
+    # its own roofline block, as the headline's: algorithmic bytes per launch (4 + c per cell) over the slower direction's time
+    algo = (4.0 + c) * n_tiles * cells
+    dom_ms, dom = (enc, "encode") if enc >= dec else (dec, "decode")
+    ach = algo / (dom_ms * 1e-3) / 1e9
+    rec["roofline"] = {"bound": "hbm", "direction": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(dom_ms, 4),
+                       "traffic": None,
+                       "note": "HIP events around the whole direction (its three / four kernels) on the context's stream; PMC traffic "
+                               "is measured for the headline surface only (profiles/hbm_traffic.json)"}
     he, hd = headline_ms
     rec["vs_headline"] = {"encode_ms_ratio": round(enc / he, 3), "decode_ms_ratio": round(dec / hd, 3), "packed_bytes_ratio": round(c / headline_c, 3),
                           "encode_per_packed_byte": round((enc / he) / (c / headline_c), 3),
