@@ -213,11 +213,12 @@ def test_synth_dem_rough_matches_oracle(codec):
 
 
 def test_batch_dem_roundtrip_and_sampled_parity(codec):
-    """Config-2 shape at reduced count: 256 tiles of 200x200, all three predictors + Huffman."""
+    """BASELINE config 2 as bench.py --workload dem1024 runs it: 1,024 tiles of 200x200, all three predictors + Huffman
+    (round trip on every tile, every 17th tile byte for byte against the oracle)."""
     from gridfour_amd import DeviceTileBatch
-    n_rows, n_cols, nt = 200, 200, 256
+    n_rows, n_cols, nt = 200, 200, 1024
     b = DeviceTileBatch(codec.ctx, n_rows, n_cols, nt)
-    b.synth_dem(oracle.DEM_SEED + 1, 16)
+    b.synth_dem(oracle.DEM_SEED + 1, 32)
     b.encode(codec_index=0)
     b.decode()
     codec.ctx.synchronize()

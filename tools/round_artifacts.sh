@@ -69,4 +69,8 @@ PY
   done
   rm -rf $OUT/calib
 fi
+# round 5: the rough batch's phase stamps, and whether the fast decode kernel's two runs overlap (start / end per dispatch)
+GF_DEM_STYLE=1 timeout 300 python3 tools/phase_cycles_dec.py > $OUT/phase_cycles_dec_rough.txt 2>&1
+rm -rf $OUT/trace; GF_DEM_STYLE=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/shape_time.py 120 150 12960 > /dev/null 2>> $OUT/rocprof.log
+f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/overlap_trace.py $f > $OUT/decode_overlap_rough.txt 2>&1; rm -rf $OUT/trace
 head -c 600 $OUT/bench.json; echo; head -5 $OUT/kernel_stats.csv
