@@ -113,6 +113,7 @@ struct gf_context {
     // scratch buffers, staging slots and recorded graphs are one set.  Recursive: entry points call each other.
     std::recursive_mutex mu;
     GfSideStream side{nullptr, nullptr, nullptr};   // second stream + fork / join events: the fast decode kernel's roomy run (gvrs_kernels.h)
+    uint32_t *hRoomySeen = nullptr;                 // page-locked word: GfDecodeArgs::roomySeenHost
     struct gf_host_pipe *pipe = nullptr;        // pipelined staging of the host-memory batch entry points (created on first use)
     struct gf_single *single = nullptr;         // one tile per call: page-locked buffers and replayed graphs (created on first use)
 };
@@ -247,6 +248,8 @@ gf_status gf_context_create(int device, gf_context **out)
         delete c;
         return GF_ERR_HIP;
     }
+    if (hipHostMalloc((void **)&c->hRoomySeen, 64, hipHostMallocDefault) == hipSuccess) *c->hRoomySeen = 0u;
+    else { (void)hipGetLastError(); c->hRoomySeen = nullptr; }
     // (the side stream is an optimisation: without it the roomy run follows the first one on the caller's stream)
     if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
@@ -290,6 +293,7 @@ void gf_context_destroy(gf_context *c)
     c->dInflOut.release();
     c->dInflMeta.release();
     gf_host_pipe_destroy(c->pipe);
+    if (c->hRoomySeen) (void)hipHostFree(c->hRoomySeen);
     if (c->side.stream) {
         (void)hipStreamSynchronize(c->side.stream);
         (void)hipEventDestroy(c->side.fork);
@@ -463,6 +467,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         GF_HIP(gf_launch_huffman_parse_trees(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles,
                                              stream ? (hipStream_t)stream : c->stream, a.retryFlag, fastBytes, roomyBytes, roomyList));
         a.roomyList = roomyList;
+        a.roomySeenHost = c->hRoomySeen;
         a.trees = (const uint32_t *)c->trees.p;
         a.flagsCleared = a.retryFlag ? 1 : 0;
     }

@@ -2401,7 +2401,11 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
     const uint64_t nWords = (a.blobBytes + 3) >> 2;
     if constexpr (MODE == DEC_GENERAL) {
         // (the last kernel of a CodecHuffman batch: the roomy list's count and cursor are zero again for the next pre-pass)
-        if (a.retryFlag && a.ldsM32Roomy && blockIdx.x == 0 && tid == 0) { a.retryFlag[2] = 0u; a.retryFlag[3] = 0u; }
+        if (a.retryFlag && a.ldsM32Roomy && blockIdx.x == 0 && tid == 0) {
+            if (a.roomySeenHost) *a.roomySeenHost = 1u + a.retryFlag[2];
+            a.retryFlag[2] = 0u;
+            a.retryFlag[3] = 0u;
+        }
         if (a.retryFlag && a.retryFlag[a.ldsM32Roomy ? 1 : 0] == 0u) return;   // the fast kernel decoded every tile
     }
     // the roomy run's tiles: entry i of the pre-pass's list, i drawn from the cursor (all threads call; ~0 = the list is exhausted)
@@ -3286,7 +3290,12 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         // the 0.33).
         // (a small batch -- BASELINE config 2: 1,024 tiles, 0.18 ms per decode -- loses more to the two hand-overs between the
         // streams, ~10 us each, than the roomy run could hide: 0.183 -> 0.201 ms measured; there the runs follow one another)
-        const bool beside = a.ldsM32Roomy && side && side->stream && a.nTiles >= 4096;
+        // ... and a batch whose predecessors on this context listed no tile for the roomy run (smooth terrain: the run is 7 us of empty
+        // workgroups) keeps everything on one stream: the hand-overs were 15-20 us of its 0.70 ms.  The hint (roomySeenHost: 1 + the
+        // count of the last batch whose general kernel has finished, 0 before the first) may be a batch or two old; either order of
+        // the runs is correct for any data.
+        const bool roomyLikely = !a.roomySeenHost || *(volatile const uint32_t *)a.roomySeenHost != 1u;
+        const bool beside = a.ldsM32Roomy && side && side->stream && a.nTiles >= 4096 && roomyLikely;
         GfDecodeArgs r = f;
         r.ldsM32Bytes = a.ldsM32Roomy;
         // (persistent workgroups: as many as the chip holds of them -- LDS in 1,280-byte steps, 256 CUs -- and never more than tiles)

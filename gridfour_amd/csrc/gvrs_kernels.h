@@ -124,6 +124,8 @@ struct GfDecodeArgs {
                                // instead of the general kernel and its workspace in global memory
     const uint32_t *roomyList; // the tiles of the roomy run, listed by the pre-pass; retryFlag[2] = their count, retryFlag[3] = the
                                // cursor the run's workgroups draw from (both zeroed again by the general kernel, the batch's last)
+    uint32_t *roomySeenHost;   // may be null: a word of page-locked host memory that receives 1 + that count from the general kernel --
+                               // the host's hint for the NEXT batch (does the roomy run have work, i.e. is it worth a second stream?)
     int flagsCleared;          // 1: the tree pre-pass zeroed retryFlag (gf_launch_huffman_parse_trees), no memset in front of the kernels
     int lean;                  // 1 (the one-tile-per-call path): the fast kernel alone; what it leaves behind keeps the status
                                // GF_K_LEAN_RETRY and the caller takes the batch path for it
