@@ -83,6 +83,7 @@ def main():
                 ("canon", gridfour_amd.CodecCanonHuffmanHip(context=ctx), oracle.codec_canon_encode, oracle.codec_canon_decode),
                 ("deflate", gridfour_amd.CodecDeflateHip(context=ctx), oracle.codec_deflate_encode, oracle.codec_deflate_decode)]
         lsop = gridfour_amd.LsCodecHip(context=ctx, deflate_enabled=True)
+        lsop_nd = gridfour_amd.LsCodecHip(context=ctx, deflate_enabled=False)
         fl = gridfour_amd.CodecFloatHip(context=ctx, level=6)
     t0 = time.time()
     n_cases = n_tiles = 0
@@ -200,6 +201,29 @@ def main():
                         raise AssertionError((tag, "lsop decode", t, int(st[k]), "header", good[k][:3].hex(), "oracle ok",
                                               bool(np.array_equal(ref, tiles[t])), "bad cells", bad[:10].tolist(), len(bad),
                                               "got", vals[k][bad[:5]].tolist(), "want", ref[bad[:5]].tolist()))
+        if nr * nc <= 40000 and not replay:
+            # round 5: the canonical container alone -- the device-resident form of the encoder (k_lsop_predict16: tile in LDS as digit
+            # planes, int16 residuals; falls back per tile to the int32 kernels) -- with and without the value checksum
+            cs = bool(n_cases & 1)
+            lsop_nd.setValueChecksumEnabled(cs)
+            packs, types, status = lsop_nd.encode_batch(5, nr, nc, tiles)
+            good = []
+            for t, v in enumerate(tiles):
+                ref, typ = oracle.lsop12_encode(5, nr, nc, v, False, value_checksum=cs)
+                if ref is None:
+                    assert packs[t] is None and status[t] == 1, (tag, "lsop canonical", t, status[t])
+                else:
+                    assert status[t] == 0 and types[t] == typ and packs[t] == ref, (tag, "lsop canonical", t, status[t], types[t], typ, cs)
+                    good.append((t, ref))
+            if good:
+                vals, st = lsop_nd.decode_batch(nr, nc, [g[1] for g in good])
+                for k, (t, ref) in enumerate(good):
+                    try:
+                        want = oracle.lsop12_decode(nr, nc, ref)
+                    except IOError:
+                        assert st[k] != 0, (tag, "lsop canonical: undecodable stream accepted", t)
+                        continue
+                    assert st[k] == 0 and np.array_equal(vals[k], want), (tag, "lsop canonical decode", t, int(st[k]))
         if nr * nc <= 70000:
             f = (tiles[:2].astype(np.float32) * np.float32(0.37)).reshape(-1, nr * nc)
             f[0, ::7] = np.nan
