@@ -86,14 +86,14 @@ def _replay_is_current(rec):
         return False
 
 
-def _pmc_traffic(workload, kernel):
+def _pmc_traffic(workload, kernel, filename="hbm_traffic.json"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_hbm.sh writes
     profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 corrections applied).
     PMC collection cannot run inside the timed process, so the per-launch figure measured for this same
     workload is REPLAYED from that file -- the returned provenance says from which commit of it; None when no
     measurement for the workload is committed.  Kernel names match exactly (template arguments stripped)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "profiles", "hbm_traffic.json")
+    path = os.path.join(here, "profiles", filename)
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
@@ -102,7 +102,7 @@ def _pmc_traffic(workload, kernel):
         return None, None
     if not _replay_is_current(rec):
         # the kernels changed since tools/pmc_hbm.sh ran: no bytes are better than another kernel's bytes
-        return None, "STALE: profiles/hbm_traffic.json was measured on other kernel sources (csrc digest differs); rerun tools/pmc_hbm.sh"
+        return None, "STALE: profiles/%s was measured on other kernel sources (csrc digest differs); rerun tools/pmc_hbm.sh" % filename
 
     def base(name):
         name = name.split("(")[0].strip()
@@ -124,11 +124,11 @@ def _pmc_traffic(workload, kernel):
     if not commit:
         try:
             import subprocess
-            commit = subprocess.run(["git", "-C", here, "log", "-n", "1", "--format=%h", "--", "profiles/hbm_traffic.json"],
+            commit = subprocess.run(["git", "-C", here, "log", "-n", "1", "--format=%h", "--", "profiles/" + filename],
                                     capture_output=True, text=True, timeout=10).stdout.strip() or None
         except Exception:
             commit = None
-    return total, "profiles/hbm_traffic.json@%s" % (commit or "unversioned")
+    return total, "profiles/%s@%s" % (filename, commit or "unversioned")
 
 
 CLOCK_HZ = 2.4e9              # MI355X_MICROARCH.md: max engine clock; 256 CUs x 4 SIMDs, ONE scalar unit per CU
@@ -453,8 +453,11 @@ def _rough_record(args, ctx, batch, n_rows, n_cols, n_tiles, tiles_per_row, seed
     rec["roofline"] = {"bound": "hbm", "direction": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(dom_ms, 4),
                        "traffic": None,
-                       "note": "HIP events around the whole direction (its three / four kernels) on the context's stream; PMC traffic "
-                               "is measured for the headline surface only (profiles/hbm_traffic.json)"}
+                       "note": "HIP events around the whole direction (its three / four kernels) on the context's stream"}
+    names = "k_huffman_encode+k_huffman_trees+k_huffman_pack+k_huffman_pack_rare" if dom == "encode" else "k_huffman_parse_trees+k_huffman_decode"
+    traffic, src = _pmc_traffic("etopo1_rough", names, "hbm_traffic_rough.json")
+    rec["roofline"]["traffic"] = traffic
+    rec["roofline"]["traffic_replayed_from"] = src
     he, hd = headline_ms
     rec["vs_headline"] = {"encode_ms_ratio": round(enc / he, 3), "decode_ms_ratio": round(dec / hd, 3), "packed_bytes_ratio": round(c / headline_c, 3),
                           "encode_per_packed_byte": round((enc / he) / (c / headline_c), 3),

@@ -73,4 +73,11 @@ fi
 GF_DEM_STYLE=1 timeout 300 python3 tools/phase_cycles_dec.py > $OUT/phase_cycles_dec_rough.txt 2>&1
 rm -rf $OUT/trace; GF_DEM_STYLE=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/shape_time.py 120 150 12960 > /dev/null 2>> $OUT/rocprof.log
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/overlap_trace.py $f > $OUT/decode_overlap_rough.txt 2>&1; rm -rf $OUT/trace
+# ... HBM traffic of the rough batch (bench.py's rough.roofline.traffic replays it) and the device-side timeline of a one-tile call
+GF_COMMIT=$GF_COMMIT bash tools/pmc_hbm.sh $OUT/hbm_rough etopo1_rough huffman > $OUT/pmc_hbm_rough.txt 2>&1
+cp $OUT/hbm_rough/hbm_traffic.json $OUT/hbm_traffic_rough.json 2>/dev/null && cp $OUT/hbm_traffic_rough.json profiles/hbm_traffic_rough.json; rm -rf $OUT/hbm_rough
+if [ -x tools/bin/single_tile_latency ]; then
+  rm -rf $OUT/tr; rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- tools/bin/single_tile_latency > /dev/null 2>> $OUT/rocprof.log
+  f=$(find $OUT/tr -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/single_tile_timeline.py $f > $OUT/single_tile_timeline.txt 2>&1; rm -rf $OUT/tr
+fi
 head -c 600 $OUT/bench.json; echo; head -5 $OUT/kernel_stats.csv
