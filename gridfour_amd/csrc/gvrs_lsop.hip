@@ -650,6 +650,7 @@ __device__ __forceinline__ float lsop_predict12_p(const float *u, const LsopPlan
 // lsop_gram_mfma with the whole tile in LDS as digit planes: no ring, no barrier per row -- the groups of 32 cells of all rows are
 // dealt round-robin to the four waves.  Operand layout and the recombination are lsop_gram_mfma's: lane l holds column l & 31
 // (13 lo digits, 13 hi digits, the ones, five idle) for the sixteen cells 16 (l >> 5) .. + 15 of the group.
+template <int THREADS>
 __device__ __forceinline__ void lsop_gram_mfma16(const LsopPlanes &P, int32_t *C32, uint32_t nR, uint32_t nC, double *G, int tid)
 {
     const int lane = tid & 63;
@@ -676,12 +677,12 @@ __device__ __forceinline__ void lsop_gram_mfma16(const LsopPlanes &P, int32_t *C
     const uint32_t constWord = zi == 13u ? 0x01010101u : 0u;
     const bool isConst = zi >= 13u;
     LsV16i acc = {};
-    for (uint32_t i = (uint32_t)tid; i < 27u * 32u; i += 256u) C32[i] = 0;
+    for (uint32_t i = (uint32_t)tid; i < 27u * 32u; i += (uint32_t)THREADS) C32[i] = 0;
     __syncthreads();
     const uint32_t wI = nC - 4u, nGroups = (wI + 31u) >> 5, nTurns = (nR - 2u) * nGroups;
     uint32_t r = 2u, g = wave;                                                        // turn = (r - 2) nGroups + g
     while (g >= nGroups) { g -= nGroups; r++; }
-    for (uint32_t turn = wave; turn < nTurns; turn += 4u) {
+    for (uint32_t turn = wave; turn < nTurns; turn += (uint32_t)(THREADS / 64)) {
         const uint32_t c0 = 2u + 32u * g + 16u * h;                                   // the lane's first cell of the group
         const uint32_t byteAt = (uint32_t)((int)(r * nC) + dr * (int)nC + dc) + c0;   // ... in its plane
         const uint32_t *w = reinterpret_cast<const uint32_t *>(plane + (byteAt & ~3u));
@@ -701,7 +702,7 @@ __device__ __forceinline__ void lsop_gram_mfma16(const LsopPlanes &P, int32_t *C
             }
         }
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(x, x, acc, 0, 0, 0);
-        g += 4u;
+        g += (uint32_t)(THREADS / 64);
         while (g >= nGroups) { g -= nGroups; r++; }
     }
 #pragma unroll
@@ -722,8 +723,10 @@ __device__ __forceinline__ void lsop_gram_mfma16(const LsopPlanes &P, int32_t *C
 
 // OUT32: the same kernel behind gf_lsop12_predict_dev -- residuals as int32 in the public layout ([initialisers | interior], resStride
 // ints per tile), no histograms, status GF_K_OK; only the tiles the matrix pipe cannot take are left to k_lsop_predict.
-template <bool OUT32>
-__global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(GfLsopPredict16Args a)
+// THREADS: 256 (tiles of up to ~26 K cells: four workgroups per CU) or 1,024 (larger tiles -- BASELINE config 5's 256 x 256: the planes are
+// 128 KB, one workgroup of sixteen waves per CU, the same sixteen waves a CU holds of the small form).
+template <bool OUT32, int THREADS>
+__global__ __launch_bounds__(THREADS, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(GfLsopPredict16Args a)
 {
     __shared__ LsopShared16 S;
     extern __shared__ __attribute__((aligned(16))) int8_t lsopPlanes[];    // the tile's two digit planes, a byte per cell each (+ 64
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(G
         if ((nCells & 3u) == 0u) {
             const GfU4 *v4 = reinterpret_cast<const GfU4 *>(v);
             uint32_t *lo32 = reinterpret_cast<uint32_t *>(loP), *hi32 = reinterpret_cast<uint32_t *>(hiP);
-            for (uint32_t i = tid; i < (nCells >> 2); i += 256u) {
+            for (uint32_t i = tid; i < (nCells >> 2); i += (uint32_t)THREADS) {
                 const GfU4 q = v4[i];
                 auto mag = [](uint32_t x) -> uint32_t { return (int32_t)x < 0 ? 0u - x : x; };
                 m = max(max(m, mag(q.x)), max(max(mag(q.y), mag(q.z)), mag(q.w)));
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(G
                 hi32[i] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(hw, hz, 0x0c0c0501u), __builtin_amdgcn_perm(hy, hx, 0x0c0c0501u), 0x05040100u);
             }
         } else {
-            for (uint32_t i = tid; i < nCells; i += 256u) {
+            for (uint32_t i = tid; i < nCells; i += (uint32_t)THREADS) {
                 const int32_t x = v[i];
                 m = max(m, x < 0 ? 0u - (uint32_t)x : (uint32_t)x);
                 loP[i] = (int8_t)x;
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(G
         }
 
         // normal equations (:335-342) on the matrix pipe, 13 x 13 system (:353-378) by wave 0
-        lsop_gram_mfma16(PL, S.C32, nR, nC, S.G, tid);
+        lsop_gram_mfma16<THREADS>(PL, S.C32, nR, nC, S.G, tid);
         __syncthreads();
         if (wave == 0) lsop_lu_solve_wave(S, lane);
         __syncthreads();
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(G
 #pragma unroll
         for (int i = 0; i < 12; i++) u[i] = S.u[i];
         if (tid < 16) a.coefs[t * 16 + tid] = tid == 0 ? (uint32_t)v[0] : tid <= 12 ? __float_as_uint(S.u[tid - 1]) : 0u;
-        for (int i = tid; i < CN_HIST * (1 + LSOP_HR16); i += 256) S.hist0[i] = 0;          // (C32 is done with; hist1 follows hist0)
+        for (int i = tid; i < CN_HIST * (1 + LSOP_HR16); i += THREADS) S.hist0[i] = 0;          // (C32 is done with; hist1 follows hist0)
         __syncthreads();
 
         // a residual into its stream's histogram as CanonicalHuffman.countSymbols classifies it (:352-418; a halfword has kinds 0-4)
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(G
         auto magOf = [](uint32_t x) -> uint32_t { return (int32_t)x < 0 ? ~x : x; };   // x fits a halfword iff magOf(x) <= 32767
 
         // initialiser stream (:143-209)
-        for (uint32_t k = tid; k < nInit; k += 256) {
+        for (uint32_t k = tid; k < nInit; k += THREADS) {
             uint32_t kind;
             const uint32_t idx = lsop_init_cell(k, nR, nC, &kind);
             const uint32_t x = V(idx);
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(G
             };
             constexpr int IT = 8;                                                        // elements per item
             const uint32_t nItems = (nInt + IT - 1u) / IT;
-            for (uint32_t k = (uint32_t)tid; k < nItems; k += 256u) {
+            for (uint32_t k = (uint32_t)tid; k < nItems; k += (uint32_t)THREADS) {
                 const uint32_t e = (uint32_t)IT * k;
                 const uint32_t r = __umulhi(e, magicW), c = e - r * wI;
                 uint32_t x[IT];
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(256, GF_LSOP_PREDICT16_WGS) void k_lsop_predict16(G
         // the record for k_canon_pack2: the histograms as its own first pass leaves them (end-of-text counted once, nothing
         // beyond the alphabet), the largest escape kind per stream, no values in the -8333608 gap (a halfword holds none)
         uint32_t *rec = a.hist + t * (size_t)LSOP_HIST_REC_WORDS;
-        for (int i = tid; i < 2 * CN_HIST; i += 256) {
+        for (int i = tid; i < 2 * CN_HIST; i += THREADS) {
             const int p = i / CN_HIST, sym = i - p * CN_HIST;
             uint32_t sum = 0;
             if (p == 0) sum = S.hist0[sym];
@@ -1928,6 +1931,8 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_p
 // launchers
 // ------------------------------------------------------------------------------------------------
 
+static int gf_lsop_predict16_threads(int nRows, int nCols);
+
 hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, size_t resStride, uint32_t *coefs,
                                   int32_t *status, size_t nTiles, int nRows, int nCols, hipStream_t stream)
 {
@@ -1937,9 +1942,16 @@ hipError_t gf_launch_lsop_predict(const int32_t *values, int32_t *residuals, siz
         GfLsopPredict16Args p{values, reinterpret_cast<int16_t *>(residuals), 2 * resStride, coefs, status, nullptr, nTiles, nRows, nCols};
         const size_t dyn16 = 2 * (((size_t)nRows * (size_t)nCols + 64 + 15) & ~(size_t)15);
         static GfDynLdsOptIn opt32;
-        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_predict16<true>, dyn16, opt32);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_lsop_predict16<true>, gf_tile_grid(nTiles), dim3(256), dyn16, stream, p);
+        if (gf_lsop_predict16_threads(nRows, nCols) == 1024) {
+            static GfDynLdsOptIn opt32w;
+            const hipError_t e = gf_opt_in_dyn_lds((k_lsop_predict16<true, 1024>), dyn16, opt32w);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_lsop_predict16<true, 1024>), gf_tile_grid(nTiles), dim3(1024), dyn16, stream, p);
+        } else {
+            const hipError_t e = gf_opt_in_dyn_lds((k_lsop_predict16<true, 256>), dyn16, opt32);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_lsop_predict16<true, 256>), gf_tile_grid(nTiles), dim3(256), dyn16, stream, p);
+        }
         GfLsopPredictArgs b{values, residuals, resStride, coefs, status, nTiles, nRows, nCols, 1};
         hipLaunchKernelGGL(k_lsop_predict, gf_tile_grid(nTiles), dim3(256), ((size_t)4 * (size_t)nCols + 40) * 4, stream, b);
         return hipGetLastError();
@@ -1965,11 +1977,17 @@ hipError_t gf_launch_canon_pack2(const int32_t *residuals, size_t resStride, con
 
 // the tile sizes k_lsop_predict16 takes: the halfword tile and its static LDS in a third of a CU's 160 KB, rows the matrix-pipe
 // form accepts, interiors whose int32 digit sums cannot overflow
+// 256 threads while three workgroups or more fit a CU's LDS, 1,024 (one workgroup per CU) for the larger tiles the LDS still holds
+static int gf_lsop_predict16_threads(int nRows, int nCols)
+{
+    const size_t nCells = (size_t)nRows * (size_t)nCols;
+    return 2 * ((nCells + 64 + 15) & ~(size_t)15) + sizeof(LsopShared16) <= 53 * 1024 ? 256 : 1024;
+}
 bool gf_lsop_predict16_eligible(int nRows, int nCols)
 {
     const size_t nCells = (size_t)nRows * (size_t)nCols, nInt = (size_t)(nRows - 2) * (size_t)(nCols - 4);
     return nRows >= 6 && nCols >= 6 && (size_t)nCols <= LSOP_RING_MAXC && nInt < (1u << 17) &&
-           2 * ((nCells + 64 + 15) & ~(size_t)15) + sizeof(LsopShared16) <= 53 * 1024;
+           2 * ((nCells + 64 + 15) & ~(size_t)15) + sizeof(LsopShared16) <= 150 * 1024;
 }
 size_t gf_lsop_hist_rec_words() { return LSOP_HIST_REC_WORDS; }
 
@@ -1981,9 +1999,16 @@ hipError_t gf_launch_lsop_predict16(const int32_t *values, int32_t *residuals, s
     GfLsopPredict16Args a{values, reinterpret_cast<int16_t *>(residuals), 2 * resStride, coefs, status, hist, nTiles, nRows, nCols};
     const size_t dyn = 2 * (((size_t)nRows * (size_t)nCols + 64 + 15) & ~(size_t)15);      // the two digit planes
     static GfDynLdsOptIn opt;
-    const hipError_t e = gf_opt_in_dyn_lds(k_lsop_predict16<false>, dyn, opt);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lsop_predict16<false>, gf_tile_grid(nTiles), dim3(256), dyn, stream, a);
+    if (gf_lsop_predict16_threads(nRows, nCols) == 1024) {
+        static GfDynLdsOptIn optW;
+        const hipError_t e = gf_opt_in_dyn_lds((k_lsop_predict16<false, 1024>), dyn, optW);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_lsop_predict16<false, 1024>), gf_tile_grid(nTiles), dim3(1024), dyn, stream, a);
+    } else {
+        const hipError_t e = gf_opt_in_dyn_lds((k_lsop_predict16<false, 256>), dyn, opt);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_lsop_predict16<false, 256>), gf_tile_grid(nTiles), dim3(256), dyn, stream, a);
+    }
     GfLsopPredictArgs b{values, residuals, resStride, coefs, status, nTiles, nRows, nCols, 1};
     const size_t dynB = (size_t)nCols <= LSOP_RING_MAXC ? ((size_t)4 * (size_t)nCols + 40) * 4 : 0;
     hipLaunchKernelGGL(k_lsop_predict, gf_tile_grid(nTiles), dim3(256), dynB, stream, b);
