@@ -3071,7 +3071,68 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     // only if its last leaf closes it and none before does; anything else (a tree that closes early, stays open, grows deeper than
     // a code register) is walked again by the exact form, which owns every status and the incomplete-tree record.
     bool walked = false;
-    {
+    // A wave per tile (one tile per call, small batches; round 5): everything the walk computes is wave-uniform, i.e. scalar code, and
+    // the predicated turn above all serves sixty-four DIFFERENT trees per instruction -- for one tree it was 95 dependent scalar
+    // instructions per leaf, 25 us of a one-tile decode call's 66 on the device (profiles/r05_v3/single_tile_timeline.txt).  Here the same
+    // steps with plain branches; the leaf records collect in LDS and leave together, a lane a leaf.  Same acceptance rule.
+    __shared__ uint32_t leafLds[perWave == 1u ? 3 * 256 : 1];
+    if constexpr (perWave == 1u) {
+        uint64_t fbuf = buf, c = 0;
+        uint32_t fhave = have, nextW = (next - 10u) >> 2, fbp = bp, L = 1, leaves = 0, fmax = 1, fkinds = 0;
+        const uint32_t depthCap = min(nLeaves, (uint32_t)MAX_DEPTH);
+        bool closed = false, bad = rootBit != 0u;
+        while (leaves < nLeaves && !bad && !closed) {
+            if (fhave <= 32u) {
+                fbuf |= (uint64_t)fetch(nextW) << fhave;
+                fhave += 32u;
+                nextW++;
+            }
+            uint32_t z = fbuf ? (uint32_t)__builtin_ctzll(fbuf) : 64u;
+            z = min(min(z, fhave), 63u);
+            c <<= z;
+            L += z;
+            fbuf >>= z;
+            fhave -= z;
+            fbp += z;
+            if (L - 1u > depthCap) { bad = true; break; }
+            if (fhave >= 9u && ((uint32_t)fbuf & 1u)) {
+                const uint32_t sym = ((uint32_t)fbuf >> 1) & 0xffu;
+                const uint64_t code = __brevll(c) >> (64u - L);
+                if (lane == 0u) {
+                    leafLds[leaves] = (uint32_t)code;
+                    leafLds[256u + leaves] = (uint32_t)(code >> 32);
+                    leafLds[512u + leaves] = L | (sym << 8);
+                }
+                fbuf >>= 9;
+                fhave -= 9u;
+                fbp += 9u;
+                fkinds |= kindOf(sym);
+                fmax = max(fmax, L);
+                leaves++;
+                const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;
+                if (t1 >= L) closed = true;
+                else {
+                    c = (c >> t1) | 1ull;
+                    L -= t1;
+                }
+            }
+        }
+#ifndef GF_PT_FORCE_EXACT                                           // (test builds: every tree through the exact walk)
+        if (!bad && closed && leaves == nLeaves) {
+            walked = true;
+            bp = fbp;
+            maxLen = fmax;
+            symKinds = fkinds;
+            __syncthreads();                                        // (one wave: the records are in LDS)
+            for (uint32_t i = lane; i < nLeaves; i += 64u) {
+                codes[i] = ((unsigned long long)leafLds[256u + i] << 32) | leafLds[i];
+                const uint32_t ls = leafLds[512u + i];
+                lens[i] = (uint8_t)ls;
+                syms[i] = (uint8_t)(ls >> 8);
+            }
+        }
+#endif
+    } else {
         uint64_t fbuf = buf, c = 0;
         uint32_t fhave = have, nextW = (next - 10u) >> 2, fbp = bp, L = 1, leaves = 0, fmax = 1, fkinds = 0;
         uint32_t pre = fetch(nextW);
