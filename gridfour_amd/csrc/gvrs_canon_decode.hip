@@ -171,11 +171,25 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
         for (size_t i = lane; i < n; i += 64) r0[i] = 0;
         __threadfence_block();
     }
-    const size_t t = t0 + lane;
-    const bool inBatch = lane < perWave && t < nTiles;
+    // (a wave per tile, round 5: every lane walks the one tile -- the walk is wave-uniform, i.e. scalar code, and reads the packing's
+    // head out of the other lanes' registers, which is only defined while they are active --, lane 0 stores)
+    const size_t t = perWave == 1u ? t0 : t0 + lane;
+    const bool inBatch = t < nTiles;
+    const bool writer = perWave == 64u || lane == 0u;
     const uint64_t off = !inBatch ? 0ull : offsets ? offsets[t] : (uint64_t)t * slotStride;
     const uint32_t len = inBatch ? lengths[t] : 0u;
     const bool readable = inBatch && len >= 7 && off + len <= blobBytes;
+    uint32_t head0 = 0, head1 = 0;                          // perWave == 1: words lane and 64 + lane of the packing (zero beyond its end)
+    if (perWave == 1u && readable && blobBytes >= 7) {
+        const uint32_t vis = min(len, 512u);
+        const uint8_t *__restrict__ pk0 = blob + off;
+        const uint32_t a0 = 4u * lane < vis ? min(4u * lane, vis - 4u) : 0u, a1 = 4u * (64u + lane) < vis ? min(4u * (64u + lane), vis - 4u) : 0u;
+        head0 = reinterpret_cast<const CdPackedWord *>(pk0 + a0)->v;
+        head1 = reinterpret_cast<const CdPackedWord *>(pk0 + a1)->v;
+        asm volatile("" : "+v"(head0), "+v"(head1));
+        head0 = 4u * lane < vis ? head0 >> (8u * (4u * lane - a0)) : 0u;
+        head1 = 4u * (64u + lane) < vis ? head1 >> (8u * (4u * (64u + lane) - a1)) : 0u;
+    }
     // Sixty-four tiles per wave (round 4, as k_huffman_parse_trees): the head of every packing -- the code lengths are its first few
     // hundred bytes -- goes to LDS first, the wave fetching tile after tile, a lane a word (coalesced, 32 tiles' loads in flight at
     // once), and a lane's walk reads down its own column: a peek was a dependent load from global memory per token, inside a
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
     uint32_t *rec = recs + t * GF_CANON_REC_WORDS;
     uint8_t *outLen = reinterpret_cast<uint8_t *>(rec + 8);
     if (!readable) {                                          // no stream: the decode kernel does not look here
-        rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
+        if (writer) rec[0] = (uint32_t)GF_K_ERR_BOUNDS;
         return;
     }
     const uint8_t *__restrict__ pk = blob + off;
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
     if (lsopContainer) {
         const uint32_t hdr = 55u + ((pk[1] & 0x80) ? 4u : 0u);
         if (!(pk[1] & 0x40) || (pk[1] & 0x0f) != 2 || pk[2] != 12 || len < hdr) {
-            rec[0] = (uint32_t)GF_K_ERR_UNSUPPORTED;
+            if (writer) rec[0] = (uint32_t)GF_K_ERR_UNSUPPORTED;
             return;
         }
         startBit = hdr * 8u;
@@ -244,6 +258,12 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
         if (perWave == 64u && (pos >> 5) + 1u < STAGE_WORDS) {
             const uint32_t wi = pos >> 5;
             return __builtin_amdgcn_alignbit(stage[(wi + 1u) * 64u + lane], stage[wi * 64u + lane], pos & 31u);
+        }
+        if (perWave == 1u && (pos >> 5) + 1u < 128u) {        // (pos is wave-uniform: the words out of the lanes that fetched them)
+            const uint32_t wi = pos >> 5, wj = wi + 1u;
+            const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)head0, (int)(wi & 63u)), lo1 = (uint32_t)__builtin_amdgcn_readlane((int)head1, (int)(wi & 63u));
+            const uint32_t hi0 = (uint32_t)__builtin_amdgcn_readlane((int)head0, (int)(wj & 63u)), hi1 = (uint32_t)__builtin_amdgcn_readlane((int)head1, (int)(wj & 63u));
+            return __builtin_amdgcn_alignbit(wj < 64u ? hi0 : hi1, wi < 64u ? lo0 : lo1, pos & 31u);
         }
         const uint32_t b = pos >> 3;
         uint64_t w;
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
             const bool take = found && fits;
             const uint32_t val = isLit ? sym : (sym == 16u ? prior : 0u);         // symbol 19 (meta end-of-text): no store
             const uint32_t nStore = (take && val) ? n : 0u;
-            if (nStore) {
+            if (nStore && writer) {
                 outLen[i] = (uint8_t)val;
                 for (uint32_t j = 1; j < nStore; j++) outLen[i + j] = (uint8_t)val;
             }
@@ -384,6 +404,7 @@ __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__res
         }
         if (bad) st = GF_K_ERR_BOUNDS;
     }
+    if (!writer) return;
     rec[0] = (uint32_t)st;
     rec[1] = pos;
     rec[2] = nonZero;
