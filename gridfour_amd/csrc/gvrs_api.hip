@@ -473,15 +473,44 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
     }
     if (kind == KIND_CANON) {
         // the same for the canonical decoder's code lengths
-        const size_t need = nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16;
+        // The canonical run of the fast legacy kernel first (round 5): a packing whose code has no escape, null or spare symbol is a
+        // prefix-coded byte string like any other, and that kernel decodes it once (symbol pool, byte path) where k_canon_decode
+        // decodes it twice.  For tile shapes its byte path takes; what it leaves (GF_K_RETRY) k_canon_decode picks up.
+        const size_t cells = (size_t)nRows * (size_t)nCols;
+        const uint32_t fastM32 = gf_huffman_decode_lds_m32(nRows, nCols);
+        bool viaFast = !a.lean && !analysis && nRows >= 2 && nCols >= 4 && nCols <= 256 && cells + 8 <= fastM32;
+#ifdef GF_CANON_NO_FAST_RUN                                       // (experiment builds: tools/ab.sh)
+        viaFast = false;
+#endif
+        if (viaFast) a.retryFlag = (uint32_t *)c->flags.p;
+        const size_t need = nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16 + (viaFast ? 4096 : 0);
         if (c->trees.bytes < need) {
             GF_HIP(hipSetDevice(c->device));
             gf_status s = c->trees.ensure(need);
             if (s != GF_OK) return s;
         }
         GF_HIP(gf_launch_canon_parse_lengths(dBlob, blobBytes, dOffsets, slotStride, dLengths, (uint32_t *)c->trees.p, nTiles, 0,
-                                             stream ? (hipStream_t)stream : c->stream));
+                                             stream ? (hipStream_t)stream : c->stream, a.retryFlag));
         a.trees = (const uint32_t *)c->trees.p;
+        if (viaFast) {
+            GfDecodeArgs f = a;
+            f.ldsM32Bytes = fastM32;
+            f.ldsTextBytes = 0;
+            f.ldsM32Roomy = 0;
+            auto wgsPerCu = [](size_t lds, size_t cap) {
+                const size_t step = 1280, n = (160 * 1024) / ((lds + step - 1) / step * step);
+                return n < cap ? n : cap;
+            };
+            // (the build as for a CodecHuffman batch below)
+            const size_t waves256 = 4 * wgsPerCu(gf_huffman_decode_lds_per_wg(f), 8), waves512 = 8 * wgsPerCu(gf_huffman_decode_lds_per_wg_t512(f), 4),
+                         waves1024 = 16 * wgsPerCu(gf_huffman_decode_lds_per_wg_t1024(f), 2);
+            int threads = 2 * waves512 >= 3 * waves256 ? 512 : 256;
+            if (threads == 512 && waves1024 >= 2 * waves512) threads = 1024;
+            hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+            if (threads == 1024) GF_HIP(gf_launch_huffman_decode_canon_t1024(f, st));
+            else if (threads == 512) GF_HIP(gf_launch_huffman_decode_canon_t512(f, st));
+            else GF_HIP(gf_launch_huffman_decode_canon(f, st));
+        }
     }
     if (kind == KIND_CANON) {
         // two builds as for the legacy decoder below: 256 threads (up to five workgroups per CU) or 512 (four = 32 waves)

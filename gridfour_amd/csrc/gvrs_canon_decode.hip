@@ -61,7 +61,12 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_THREADS == 256 ? 4 : 8) void k_can
                   "qs .. qx form one stretch of LDS");
     static_assert(offsetof(CanonDec, qc) == offsetof(CanonDec, qe) + sizeof(S.qe), "qe and qc form one stretch of LDS");
 
+    // behind the canonical run of the fast legacy kernel (round 5; DEC_FAST_CANON in gvrs_decode.hip, a.retryFlag non-null): only the tiles
+    // that run marked, and nothing at all when it marked none
+    if (a.retryFlag && a.retryFlag[0] == 0u) return;
+
     GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
+        if (a.retryFlag && a.status[t] != (int32_t)GF_K_LEAN_RETRY) continue;
         const uint64_t off = a.offsets ? a.offsets[t] : (uint64_t)t * a.slotStride;
         const uint32_t len = a.lengths[t];
         uint32_t *o = reinterpret_cast<uint32_t *>(a.values) + t * (size_t)nCells;
@@ -159,10 +164,12 @@ template <unsigned perWave>                                 // as k_huffman_pars
 __global__ __launch_bounds__(64) void k_canon_parse_lengths(const uint8_t *__restrict__ blob, size_t blobBytes,
                                                             const uint64_t *__restrict__ offsets, size_t slotStride,
                                                             const uint32_t *__restrict__ lengths, uint32_t *__restrict__ recs,
-                                                            size_t nTiles, int lsopContainer)
+                                                            size_t nTiles, int lsopContainer, uint32_t *__restrict__ clearFlags)
 {
     __shared__ uint8_t sMetaLen[CN_META * 64], sOrder[CN_META * 64], sLut[128 * 64];   // per-lane columns
     const uint32_t lane = threadIdx.x;
+    // (the retry words of the decode kernels that follow, cleared here instead of by a launch of their own)
+    if (clearFlags && blockIdx.x == 0 && lane < 2u) clearFlags[lane] = 0u;
     const size_t t0 = (size_t)blockIdx.x * perWave;          // perWave lanes walk a tile each: gf_prepass_tiles_per_wave
     // records start out zero: only non-zero lengths are stored below
     {
@@ -468,15 +475,15 @@ size_t gf_canon_decode_lds_per_wg(const GfDecodeArgs &a) { return sizeof(CanonDe
 #ifndef GF_CD_VARIANT
 hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                          const uint32_t *lengths, uint32_t *recs, size_t nTiles, int lsopContainer,
-                                         hipStream_t stream)
+                                         hipStream_t stream, uint32_t *clearFlags)
 {
     if (nTiles == 0) return hipSuccess;
     if (gf_prepass_tiles_per_wave(nTiles) == 1u)
         hipLaunchKernelGGL(k_canon_parse_lengths<1>, dim3((unsigned)nTiles), dim3(64), 0, stream, blob, blobBytes, offsets, slotStride,
-                           lengths, recs, nTiles, lsopContainer);
+                           lengths, recs, nTiles, lsopContainer, clearFlags);
     else
         hipLaunchKernelGGL(k_canon_parse_lengths<64>, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), 0, stream, blob, blobBytes, offsets,
-                           slotStride, lengths, recs, nTiles, lsopContainer);
+                           slotStride, lengths, recs, nTiles, lsopContainer, clearFlags);
     return hipGetLastError();
 }
 #endif  // GF_CD_VARIANT

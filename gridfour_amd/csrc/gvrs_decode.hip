@@ -54,6 +54,7 @@ constexpr int GF_K_SKIP = 0x7fff0001;           // internal: a diagnostic phase 
 #define GF_DEC_CAT(a, b) GF_DEC_CAT2(a, b)
 #define gf_launch_huffman_decode GF_DEC_CAT(gf_launch_huffman_decode_t, GF_DEC_THREADS)
 #define gf_huffman_decode_lds_per_wg GF_DEC_CAT(gf_huffman_decode_lds_per_wg_t, GF_DEC_THREADS)
+#define gf_launch_huffman_decode_canon GF_DEC_CAT(gf_launch_huffman_decode_canon_t, GF_DEC_THREADS)
 #endif
 constexpr int DEC_THREADS = GF_DEC_THREADS;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
@@ -2383,7 +2384,14 @@ constexpr int GF_K_RETRY = 0x7fff0002;          // internal: the fast kernel lea
 //                every one of its thousands of workgroups, empty or not, while the fast run refills every 40 KB hole at once --
 //                measured, such a run crawled beside the fast one and ended after it.  An instantiation of its own: the loop
 //                around the body costs the one-tile-per-workgroup form 5-25 % (round 4).
-enum { DEC_GENERAL = 0, DEC_ANALYZE = 1, DEC_FAST = 2, DEC_FAST_ROOMY = 3 };
+//   DEC_FAST_CANON  (round 5) the fast body for CodecCanonHuffman packings (CodecCanonHuffman.java:163-195) whose code has no
+//                escape, null or spare symbol: such a text is a prefix-coded string of the bytes value + 128 and an end-of-text
+//                symbol (CanonicalHuffman.java:441-519), i.e. what the fast body decodes anyway -- one decode of the text into the
+//                symbol pool, the byte path behind it -- once the 260 code lengths of the pre-pass (k_canon_parse_lengths) have been
+//                turned into leaf records (canonical order IS pre-order).  The end-of-text symbol takes a byte value no symbol of the
+//                tile uses, is asked for as value number nStream + 1 and looked for among the others afterwards.  A tile this run cannot
+//                take, or finds anything unusual in, is left to k_canon_decode (GF_K_RETRY), which owns every status.
+enum { DEC_GENERAL = 0, DEC_ANALYZE = 1, DEC_FAST = 2, DEC_FAST_ROOMY = 3, DEC_FAST_CANON = 4 };
 
 template <int MODE>
 __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GENERAL) void k_huffman_decode(GfDecodeArgs a)
@@ -2392,7 +2400,8 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsDyn[];
     constexpr bool ANALYZE = MODE == DEC_ANALYZE;
     constexpr bool ROOMY = MODE == DEC_FAST_ROOMY;
-    constexpr bool FAST = MODE == DEC_FAST || ROOMY;
+    constexpr bool CANON = MODE == DEC_FAST_CANON;
+    constexpr bool FAST = MODE == DEC_FAST || ROOMY || CANON;
     constexpr int OWNER = MODE;                                       // (the Huffman passes: one copy per kernel, so that each inlines its own)
 
     const int tid = threadIdx.x, wave = (int)gf_wave_id();
@@ -2420,7 +2429,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
     };
 
     for (size_t t = ROOMY ? roomy_next() : (size_t)blockIdx.x + (size_t)blockIdx.y * gridDim.x; t < a.nTiles;
-         t = ROOMY ? roomy_next() : MODE == DEC_FAST ? ~(size_t)0 : t + gridDim.x) {
+         t = ROOMY ? roomy_next() : (MODE == DEC_FAST || CANON) ? ~(size_t)0 : t + gridDim.x) {
                                                                       // the fast kernel: one tile per workgroup, no loop (it never
                                                                       // touches the per-workgroup workspace; a second run that walks
                                                                       // the tiles with a small grid was measured in round 4: the
@@ -2436,7 +2445,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         // the packing's offset and length, and arrive while the header is read -- the tile's start was four dependent round trips
         // to memory (offset / length, header, record scalars, leaf arrays), now two.
 #ifdef GF_DEC_NO_PREFETCH                                          // (experiment builds: tools/ab.sh)
-        constexpr bool PRE = false;
+        constexpr bool PRE = CANON;
 #else
         constexpr bool PRE = FAST;
 #endif
@@ -2445,7 +2454,16 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         // (and the header's twelve bytes, before the packing's length is known, where the blob has that many behind the offset)
         uint32_t preHead = 0;
         const bool headEarly = PRE && off + 12u <= a.blobBytes;
-        if constexpr (PRE) {
+        if constexpr (PRE && CANON) {
+            // (the pre-pass's record of a canonical packing: status, bit position of the text, then the 260 (+1) code lengths, a byte each;
+            // thread s takes the length of symbol s, the first sixteen threads those of 256 .. 271 as well)
+            if (headEarly && tid < 12) preHead = pk[tid];
+            const uint32_t *recP = a.trees + t * GF_CANON_REC_WORDS;
+            preRec[0] = recP[0];
+            preRec[1] = recP[1];
+            if (tid < 256) preLen = reinterpret_cast<const uint8_t *>(recP + 8)[tid];
+            if (tid < 16) preSym = reinterpret_cast<const uint8_t *>(recP + 8)[256 + tid];
+        } else if constexpr (PRE) {
             if (headEarly && tid < 12) preHead = pk[tid];
             const uint32_t *recP = a.trees + t * GF_TREE_REC_WORDS;
 #pragma unroll
@@ -2457,6 +2475,20 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             }
         }
 
+        // (the canonical run: whatever it does not decode itself goes to k_canon_decode, which owns the statuses)
+        auto canon_leave = [&]() {
+            if (tid == 0) {
+                a.status[t] = GF_K_RETRY;
+                atomicOr(a.retryFlag, 1u);
+            }
+            __syncthreads();
+        };
+        if constexpr (CANON) {
+            if (len < 12 || off + len > a.blobBytes) {
+                canon_leave();
+                continue;
+            }
+        }
         if (len < 10 || off + len > a.blobBytes) {       // BitInputStore would run out / AIOOBE on the header
             if (tid == 0) a.status[t] = GF_K_ERR_BOUNDS;
             __syncthreads();
@@ -2486,10 +2518,18 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         }
         __syncthreads();
         const uint8_t *hb = reinterpret_cast<const uint8_t *>(S.head);
-        const int model = hb[1];
+        const int model = CANON ? (int)(int8_t)hb[1] : (int)hb[1];
         const uint32_t seed = (uint32_t)hb[2] | ((uint32_t)hb[3] << 8) | ((uint32_t)hb[4] << 16) | ((uint32_t)hb[5] << 24);
-        const uint32_t nM32 = (uint32_t)hb[6] | ((uint32_t)hb[7] << 8) | ((uint32_t)hb[8] << 16) | ((uint32_t)hb[9] << 24);
+        if constexpr (CANON) {
+            // (CodecCanonHuffman's header is six bytes; the predictors of the byte path only, on a shape it takes, behind a readable table)
+            if (model < 1 || model > 3 || !byte_path_eligible(model, nR, nC, a.ldsM32Bytes) || preRec[0] != (uint32_t)GF_K_OK) {
+                canon_leave();
+                continue;
+            }
+        }
         const uint32_t nStream = gf_stream_len(model, nR, nC);
+        // (the canonical text: the stream's values and the end-of-text symbol behind them)
+        const uint32_t nM32 = CANON ? nStream + 1u : (uint32_t)hb[6] | ((uint32_t)hb[7] << 8) | ((uint32_t)hb[8] << 16) | ((uint32_t)hb[9] << 24);
         int32_t early = GF_K_OK;
         if (model < 1 || model > 4) early = GF_K_ERR_FORMAT;            // CodecHuffman.java:155-169
         else if ((int32_t)nM32 < 0) early = GF_K_ERR_BOUNDS;            // NegativeArraySizeException
@@ -2497,7 +2537,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         else if ((model == 2 && nC < 2)) early = GF_K_ERR_BOUNDS;       // PredictorModelLinear.java:80 output[1]
         else if (nM32 < nStream) early = GF_K_ERR_BOUNDS;               // M32 reads run off codeM32s
         const FusedPlan plan = fused_plan(nR, nC, model);
-        if constexpr (FAST) {
+        if constexpr (FAST && !CANON) {
             // (first run: a tile of the roomy run is not touched -- not even its status, which the other run writes meanwhile;
             // the one-tile-per-call path has no second run: the tile keeps GF_K_RETRY and the caller sees to it)
             const uint32_t rec0 = PRE ? preRec[0] : (a.trees + t * GF_TREE_REC_WORDS)[0];
@@ -2509,6 +2549,12 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             if (early == GF_K_OK && (nM32 > a.ldsM32Bytes || !plan.ring)) {
                 early = GF_K_RETRY;
                 if (tid == 0) atomicOr(a.retryFlag + (a.ldsM32Roomy ? 1 : 0), 1u);
+            }
+        }
+        if constexpr (CANON) {
+            if (early != GF_K_OK || nM32 > a.ldsM32Bytes) {
+                canon_leave();
+                continue;
             }
         }
         if (early != GF_K_OK) {
@@ -2527,11 +2573,101 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             const uint32_t *rec = a.trees + t * GF_TREE_REC_WORDS;
             // (the fast kernel has words 0..7 already: R)
             auto R = [&](int i) -> uint32_t { return PRE ? preRec[i] : rec[i]; };
-            const uint32_t nLeaves = R(1);
-            const bool mine = (uint32_t)tid < nLeaves && R(0) == (uint32_t)GF_K_OK && (int32_t)R(4) < 0;
+            uint32_t nLeaves = R(1);
+            bool mine = (uint32_t)tid < nLeaves && R(0) == (uint32_t)GF_K_OK && (int32_t)R(4) < 0;
             unsigned long long code = 0;
             uint32_t clen = 0;
-            if (mine) {
+            uint32_t canonMaxLen = 0;
+            if constexpr (CANON) {
+                // Leaf records from the 260 code lengths (CanonHuffTreeDecoder.java:68-95: symbols sorted by length, then symbol;
+                // consecutive codes, shifted when the length grows), by the whole workgroup: a symbol's place is the number of
+                // symbols with a shorter code plus those of its own length before it -- ballots inside the wave, a table of
+                // per-wave counts across them.  The end-of-text symbol (259) is the last of its length.  Scratch: the M32 buffer.
+                uint32_t *cw = reinterpret_cast<uint32_t *>(ldsDyn);   // [4][16] counts of the four waves of symbols; 64..67 first
+                                                                       // unused byte per wave; 80..95 lengths of 256..271; 96 / 112:
+                                                                       // first code / first place of a length; 128..191 places taken
+                                                                       // by the waves before; 192: longest code
+                const uint32_t lane = (uint32_t)tid & 63u;
+                const uint32_t L = tid < 256 ? preLen : 0u;
+                uint32_t within = 0;
+                if (tid < 256) {                                       // (whole waves)
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+                    for (uint32_t l = 1; l <= 15u; l++) {
+                        const unsigned long long m = __ballot(L == l);
+                        within = L == l ? (uint32_t)__popcll(m & lt) : within;
+                        if (lane == 0u) cw[(uint32_t)wave * 16u + l] = (uint32_t)__popcll(m);
+                    }
+                    const unsigned long long m0 = __ballot(L == 0u);
+                    if (lane == 0u) {
+                        cw[(uint32_t)wave * 16u] = 0u;
+                        cw[64u + (uint32_t)wave] = m0 ? (uint32_t)wave * 64u + (uint32_t)__builtin_ctzll(m0) : 0xFFFFu;
+                    }
+                }
+                if (tid < 16) cw[80 + tid] = preSym;
+                __syncthreads();
+                if (tid < 64) {
+                    const uint32_t l = lane & 15u;
+                    const uint32_t c0 = cw[l], c1 = cw[16u + l], c2 = cw[32u + l], c3 = cw[48u + l];
+                    const uint32_t Le = cw[83];
+                    const uint32_t esc = cw[80] | cw[81] | cw[82] | cw[84];            // null, the two escapes, the spare symbol 260
+                    const uint32_t tot = (lane >= 1u && lane < 16u) ? c0 + c1 + c2 + c3 + (l == Le ? 1u : 0u) : 0u;
+                    const uint32_t incl = gf_wave_incl_scan(tot);
+                    uint32_t first = 0, kraft = 0;
+#pragma unroll
+                    for (uint32_t j = 1; j <= 15u; j++) {
+                        const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)j);
+                        first += j < l ? tj << (l - j) : 0u;
+                        kraft += tj << (15u - j);
+                    }
+                    if (lane < 16u) {
+                        cw[96u + l] = first;
+                        cw[112u + l] = incl - tot;
+                        cw[128u + l] = 0u;
+                        cw[144u + l] = c0;
+                        cw[160u + l] = c0 + c1;
+                        cw[176u + l] = c0 + c1 + c2;
+                    }
+                    const uint32_t nL = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+                    const uint32_t unused = min(min(cw[64], cw[65]), min(cw[66], cw[67]));
+                    const unsigned long long used = __ballot(tot != 0u);
+                    const uint32_t mx = used ? 63u - (uint32_t)__builtin_clzll(used) : 0u;
+                    const bool ok = esc == 0u && Le >= 1u && Le <= 15u && nL >= 2u && nL <= 256u && kraft == (1u << 15) && unused != 0xFFFFu;
+                    // the end-of-text symbol's leaf: behind the plain symbols of its length
+                    const uint32_t totE = (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)(Le & 15u));
+                    const uint32_t offE = (uint32_t)__builtin_amdgcn_readlane((int)(incl - tot), (int)(Le & 15u));
+                    const uint32_t firstE = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)(Le & 15u));
+                    if (lane == 0u) {
+                        S.parseStatus = ok ? GF_K_OK : GF_K_RETRY;
+                        S.nLeaves = nL;
+                        S.skipLo = (unused ^ 0x80u) & 0xffu;                           // the byte that stands for the end of the text
+                        cw[192] = mx;
+                        if (ok) {
+                            const uint32_t rk = offE + totE - 1u, cd = firstE + totE - 1u;
+                            S.leafCode[rk] = (unsigned long long)(__brev(cd) >> (32u - Le));
+                            S.leafLen[rk] = (uint8_t)Le;
+                            S.leafSym[rk] = (uint8_t)(unused ^ 0x80u);
+                        }
+                    }
+                }
+                __syncthreads();
+                const bool okAll = S.parseStatus == GF_K_OK;
+                if (tid < 256 && L != 0u && okAll) {
+                    const uint32_t rk = cw[112u + L] + cw[128u + (uint32_t)wave * 16u + L] + within;
+                    const uint32_t cd = cw[96u + L] + (rk - cw[112u + L]);
+                    S.leafCode[rk] = (unsigned long long)(__brev(cd) >> (32u - L));    // first bit of the stream in bit 0
+                    S.leafLen[rk] = (uint8_t)L;
+                    S.leafSym[rk] = (uint8_t)((uint32_t)tid ^ 0x80u);                  // symbol s is the value s - 128, as a byte
+                }
+                canonMaxLen = cw[192];
+                __syncthreads();
+                nLeaves = okAll ? S.nLeaves : 0u;
+                mine = (uint32_t)tid < nLeaves;
+                if (mine) {
+                    code = S.leafCode[tid];
+                    clen = S.leafLen[tid];
+                }
+            } else if (mine) {
                 code = PRE ? preCode : reinterpret_cast<const unsigned long long *>(rec + 8)[tid];
                 clen = PRE ? preLen : reinterpret_cast<const uint8_t *>(rec + 8 + 512)[tid];
                 S.leafCode[tid] = code;
@@ -2551,17 +2687,27 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             const uint32_t slot = block_excl_scan(isShort ? 1u : 0u, S.waveSum, &nShort);
             if (isShort) S.shortLeaf[slot & 63u] = (uint8_t)tid;
             if (tid == 0) {
-                const uint32_t maxLen = R(3) & 0xffu;
-                S.symKinds = R(3) & ~0xffu;
-                S.uniformSym = (int32_t)R(4);
-                S.skipLen = R(5);
-                S.skipLo = R(6);
-                S.skipHi = R(7);
-                S.textStart = R(2);
-                S.parseStatus = (int32_t)R(0);
-                S.nLeaves = nLeaves;
-                S.nShort = nShort;
+                const uint32_t maxLen = CANON ? canonMaxLen : R(3) & 0xffu;
                 const uint32_t l2 = maxLen > LUT_BITS ? min((uint32_t)L2_MAX_BITS, maxLen - LUT_BITS) : 1u;
+                if constexpr (CANON) {
+                    // (S.parseStatus, S.nLeaves and S.skipLo -- the end-of-text byte -- are set above)
+                    S.symKinds = 0u;
+                    S.uniformSym = -1;
+                    S.skipLen = 0u;
+                    S.textStart = R(1);
+                    // (every long code in a second-level table: the search behind them reads legacy tree records)
+                    if (nSub > ((uint32_t)L2_ENTRIES >> l2)) S.parseStatus = GF_K_RETRY;
+                } else {
+                    S.symKinds = R(3) & ~0xffu;
+                    S.uniformSym = (int32_t)R(4);
+                    S.skipLen = R(5);
+                    S.skipLo = R(6);
+                    S.skipHi = R(7);
+                    S.textStart = R(2);
+                    S.parseStatus = (int32_t)R(0);
+                    S.nLeaves = nLeaves;
+                }
+                S.nShort = nShort;
                 S.l2bits = l2;
                 S.nSub = min(nSub, (uint32_t)L2_ENTRIES >> l2);
                 S.maxLen = maxLen;
@@ -2571,7 +2717,10 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         }
         __syncthreads();
         if (S.parseStatus != GF_K_OK) {
-            if (tid == 0) a.status[t] = S.parseStatus;
+            if (tid == 0) {
+                a.status[t] = S.parseStatus;
+                if constexpr (CANON) atomicOr(a.retryFlag, 1u);
+            }
             __syncthreads();
             continue;
         }
@@ -2647,7 +2796,8 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 if constexpr (FAST) {
                     tileStatus = huffman_to_m32_fast<OWNER>(S, w32 + baseWord, (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord),
                                                            sh0, reinterpret_cast<uint32_t *>(ldsDyn), pkWords, lut2,
-                                                           reinterpret_cast<const unsigned long long *>(a.trees + t * GF_TREE_REC_WORDS + 8),
+                                                           // (the canonical run never searches the leaves: codes of fifteen bits at most)
+                                                           reinterpret_cast<const unsigned long long *>(CANON ? a.trees : a.trees + t * GF_TREE_REC_WORDS + 8),
 #ifdef GF_DIAG
                                                            textStart, endBit, nM32, m32, dbg, warmBits, a.phaseLimit & 0xff,
 #else
@@ -2711,7 +2861,27 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 return (int32_t)GF_K_SKIP;
             } else {
                 // ---------------- phases 2 + 3 fused: M32 bytes -> values, one store per cell ----------------
-                if constexpr (FAST && decltype(inLds)::value) {
+                if constexpr (CANON && decltype(inLds)::value) {
+                    // the text must be nStream values and THEN the end of the text (CanonicalHuffman.java:469-519 stops at that
+                    // symbol wherever it stands, and a longer text overruns the reader's array): its byte -- one no value of this
+                    // tile has -- nowhere before, and right behind them
+                    const uint32_t eb = S.skipLo, eb4 = eb * 0x01010101u;
+                    const uint32_t *mw = reinterpret_cast<const uint32_t *>(m32);
+                    uint32_t bad = 0;
+                    for (uint32_t i = tid; 4u * i < nStream; i += DEC_THREADS) {
+                        const uint32_t v = mw[i] ^ eb4;
+                        uint32_t z = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;   // 0x80 in every byte that is zero
+                        const uint32_t left = nStream - 4u * i;
+                        if (left < 4u) z &= (1u << (8u * left)) - 1u;
+                        bad |= z;
+                    }
+                    if (tid == 0 && m32[nStream] != (uint8_t)eb) bad = 1u;
+                    if (__syncthreads_or((int)(bad != 0u))) return (int32_t)GF_K_RETRY;
+                    fused = true;
+                    m32_bytes_to_tile(S, m32, model, seed, nR, nC, o);
+                    return (int32_t)GF_K_OK;
+                }
+                if constexpr (FAST && !CANON && decltype(inLds)::value) {
                     // a tree of one-byte values only (no introducer, no null code among its leaves): the byte path
                     if (!(GF_UNI(S.symKinds) & (GF_TREE_HAS_INTRODUCER | GF_TREE_HAS_NULL)) && byte_path_eligible(model, nR, nC, a.ldsM32Bytes)) {
                         fused = true;
@@ -2742,6 +2912,12 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         if constexpr (FAST) tileStatus = phases12(std::true_type{});
         else tileStatus = nM32 <= a.ldsM32Bytes ? phases12(std::true_type{}) : phases12(std::false_type{});
         if (tileStatus == (int32_t)GF_K_SKIP) continue;
+        if constexpr (CANON) {
+            if (tileStatus != GF_K_OK) {                 // (a text that ends early, a last code cut off, ...: k_canon_decode says what it is)
+                canon_leave();
+                continue;
+            }
+        }
         if (tileStatus != GF_K_OK) {
             if (tid == 0) a.status[t] = tileStatus;
             __syncthreads();
@@ -3381,6 +3557,20 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         }
     }
     hipLaunchKernelGGL(k_huffman_decode<DEC_GENERAL>, dim3(grid), dim3(DEC_THREADS), dyn, stream, a);
+    return hipGetLastError();
+}
+
+// The canonical run (DEC_FAST_CANON): a.trees = the records of k_canon_parse_lengths, a.retryFlag[0] = zero before the launch and
+// non-zero behind it when some tile is left to k_canon_decode (status GF_K_RETRY).
+hipError_t gf_launch_huffman_decode_canon(const GfDecodeArgs &a, hipStream_t stream)
+{
+    if (a.nTiles == 0) return hipSuccess;
+    if (!a.retryFlag || !a.trees || a.ldsM32Roomy || a.lean) return hipErrorInvalidValue;
+    const size_t dyn = decodeDynLds(a.ldsM32Bytes, 0);
+    static GfDynLdsOptIn opt;
+    const hipError_t e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST_CANON>, dyn, opt);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_huffman_decode<DEC_FAST_CANON>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, a);
     return hipGetLastError();
 }
 

@@ -189,6 +189,11 @@ hipError_t gf_launch_huffman_encode_lean_t1024(const GfEncodeArgs &a, hipStream_
 hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, unsigned grid, const GfSideStream *side = nullptr);
 hipError_t gf_launch_huffman_decode_t512(const GfDecodeArgs &a, hipStream_t stream, unsigned grid, const GfSideStream *side = nullptr);   // 512-thread workgroups
 hipError_t gf_launch_huffman_decode_t1024(const GfDecodeArgs &a, hipStream_t stream, unsigned grid, const GfSideStream *side = nullptr);  // 1024-thread workgroups
+// CodecCanonHuffman packings without escapes through the fast body (DEC_FAST_CANON in gvrs_decode.hip); the tiles it leaves carry
+// GF_K_RETRY and a.retryFlag[0] != 0: k_canon_decode (launched with the same retryFlag) takes those
+hipError_t gf_launch_huffman_decode_canon(const GfDecodeArgs &a, hipStream_t stream);
+hipError_t gf_launch_huffman_decode_canon_t512(const GfDecodeArgs &a, hipStream_t stream);
+hipError_t gf_launch_huffman_decode_canon_t1024(const GfDecodeArgs &a, hipStream_t stream);
 size_t gf_huffman_decode_lds_per_wg(const GfDecodeArgs &a);           // LDS bytes per workgroup, 256-thread build
 size_t gf_huffman_decode_lds_per_wg_t512(const GfDecodeArgs &a);      // ... 512-thread build
 size_t gf_huffman_decode_lds_per_wg_t1024(const GfDecodeArgs &a);     // ... 1024-thread build
@@ -201,7 +206,7 @@ uint32_t gf_huffman_decode_lds_text(int nRows, int nCols);
 constexpr int GF_CANON_REC_WORDS = 8 + 68;
 hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                          const uint32_t *lengths, uint32_t *recs, size_t nTiles, int lsopContainer,
-                                         hipStream_t stream);
+                                         hipStream_t stream, uint32_t *clearFlags = nullptr);   // clearFlags: GfDecodeArgs::retryFlag, zeroed
 
 // CodecCanonHuffman (gvrs_canon_encode.hip / gvrs_canon_decode.hip); same argument blocks as the legacy codec
 hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream);
