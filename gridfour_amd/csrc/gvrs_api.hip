@@ -478,7 +478,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
         // decodes it twice.  For tile shapes its byte path takes; what it leaves (GF_K_RETRY) k_canon_decode picks up.
         const size_t cells = (size_t)nRows * (size_t)nCols;
         const uint32_t fastM32 = gf_huffman_decode_lds_m32(nRows, nCols);
-        bool viaFast = !a.lean && !analysis && nRows >= 2 && nCols >= 4 && nCols <= 256 && cells + 8 <= fastM32;
+        bool viaFast = !analysis && nRows >= 2 && nCols >= 4 && nCols <= 256 && cells + 8 <= fastM32;
 #ifdef GF_CANON_NO_FAST_RUN                                       // (experiment builds: tools/ab.sh)
         viaFast = false;
 #endif
@@ -506,6 +506,7 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
                          waves1024 = 16 * wgsPerCu(gf_huffman_decode_lds_per_wg_t1024(f), 2);
             int threads = 2 * waves512 >= 3 * waves256 ? 512 : 256;
             if (threads == 512 && waves1024 >= 2 * waves512) threads = 1024;
+            if (a.lean) threads = 1024;                           // (one tile per call: the widest build, as below)
             hipStream_t st = stream ? (hipStream_t)stream : c->stream;
             if (threads == 1024) GF_HIP(gf_launch_huffman_decode_canon_t1024(f, st));
             else if (threads == 512) GF_HIP(gf_launch_huffman_decode_canon_t512(f, st));

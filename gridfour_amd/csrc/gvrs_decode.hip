@@ -3565,7 +3565,7 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
 hipError_t gf_launch_huffman_decode_canon(const GfDecodeArgs &a, hipStream_t stream)
 {
     if (a.nTiles == 0) return hipSuccess;
-    if (!a.retryFlag || !a.trees || a.ldsM32Roomy || a.lean) return hipErrorInvalidValue;
+    if (!a.retryFlag || !a.trees || a.ldsM32Roomy) return hipErrorInvalidValue;
     const size_t dyn = decodeDynLds(a.ldsM32Bytes, 0);
     static GfDynLdsOptIn opt;
     const hipError_t e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST_CANON>, dyn, opt);
