@@ -118,6 +118,70 @@ __device__ __forceinline__ void cd_tables(const uint8_t *len, int nSym, uint32_t
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same tables for the 261 text lengths by the WHOLE workgroup (round 5): a symbol's place in the (length, symbol) order is the
+// number of symbols with a shorter code plus those of its own length before it -- fifteen ballots inside each wave of 64 symbols, a
+// table of per-wave counts across them, one wave that adds those up.  (cd_tables<5> on wave 0 was fifteen dependent turns with
+// every other wave of the workgroup waiting: with the fetch of the pre-pass's record 25 K cycles of a tile's 200 K.)
+// len: 320 entries in LDS, zero from the 261st on; scr: 192 words of LDS scratch.  All threads call; ends with a barrier.
+// Returns the number of symbols that have a code.
+__device__ __forceinline__ uint32_t cd_tables_wg(const uint8_t *len, uint32_t *first, uint32_t *count, uint32_t *offset,
+                                                 uint16_t *symByOrder, uint32_t *scr)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    constexpr uint32_t TURNS = (320u + DEC_THREADS - 1u) / DEC_THREADS;      // symbols per thread: 2 with 256 threads, else 1
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t L[TURNS], within[TURNS];
+#pragma unroll
+    for (uint32_t u = 0; u < TURNS; u++) {
+        const uint32_t s = u * DEC_THREADS + tid, vw = s >> 6;               // vw: the wave of 64 symbols this one belongs to (0 .. 4)
+        L[u] = s < 320u ? len[s] : 0u;
+        within[u] = 0;
+        if ((s & ~63u) < 320u) {                                             // (wave-uniform)
+#pragma unroll
+            for (uint32_t l = 1; l <= 15u; l++) {
+                const unsigned long long m = __ballot(L[u] == l);
+                within[u] = L[u] == l ? (uint32_t)__popcll(m & lt) : within[u];
+                if (lane == 0u) scr[vw * 16u + l] = (uint32_t)__popcll(m);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64u) {
+        const uint32_t l = lane & 15u;
+        uint32_t tot = 0;
+        if (lane >= 1u && lane < 16u) {
+#pragma unroll
+            for (uint32_t v = 0; v < 5u; v++) {
+                const uint32_t c = scr[v * 16u + l];
+                scr[80u + v * 16u + l] = tot;                                // places of this length taken by the waves before
+                tot += c;
+            }
+        }
+        const uint32_t incl = gf_wave_incl_scan(tot);
+        uint32_t f = 0;
+#pragma unroll
+        for (uint32_t j = 1; j <= 14u; j++) {                                // first[l] = (first[l - 1] + count[l - 1]) << 1
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)j);
+            f += j < l ? tj << (l - j) : 0u;
+        }
+        if (lane < 16u) {
+            first[l] = lane ? f : 0u;
+            count[l] = tot;
+            offset[l] = lane ? incl - tot : 0u;
+        }
+        if (lane == 15u) scr[160] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < TURNS; u++) {
+        const uint32_t s = u * DEC_THREADS + tid;
+        if (L[u]) symByOrder[offset[L[u]] + scr[80u + (s >> 6) * 16u + L[u]] + within[u]] = (uint16_t)s;
+    }
+    const uint32_t nUsed = scr[160];
+    __syncthreads();
+    return nUsed;
+}
+
 struct CdTok {
     uint32_t sym, bits, raw;     // bits = code + raw bits; sym == 0xFFFF: no such code
 };
@@ -533,19 +597,12 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     if (tid == 0) { S.parseStatus = GF_K_OK; S.runStatus = GF_K_OK; S.qStar = 0xFFFFFFFFu; S.carry = 0; }
     __syncthreads();
     // ---------------- phase 0: code tables ----------------
-    if (wave == 0 && pre) {
+    if (pre) {
         // the code lengths were read by k_canon_parse_lengths (one lane per tile): pre = its record, preBase = the bit
         // position its packing-relative positions are counted from
-        int32_t st = (int32_t)pre[0];
-        uint32_t nUsed = 0;
-        if (st == GF_K_OK) {
-            const uint8_t *pl = reinterpret_cast<const uint8_t *>(pre + 8);
-            for (uint32_t e = (uint32_t)lane; e < 320u; e += 64) S.len[e] = e < 272u ? pl[e] : (uint8_t)0;
-            __builtin_amdgcn_wave_barrier();
-            cd_tables<5>(S.len, CN_SYMS + 1, S.first, S.count, S.offset, S.symByOrder, lane, &nUsed);
-            if (nUsed == 0) st = GF_K_ERR_BOUNDS;
-        }
-        if (lane == 0) { S.parseStatus = st; S.textStart = preBase + pre[1]; }
+        const uint8_t *pl = reinterpret_cast<const uint8_t *>(pre + 8);
+        for (uint32_t e = (uint32_t)tid; e < 320u; e += DEC_THREADS) S.len[e] = e < 272u ? pl[e] : (uint8_t)0;
+        if (tid == 0) { S.parseStatus = (int32_t)pre[0]; S.textStart = preBase + pre[1]; }
     } else if (wave == 0) {
         uint32_t pos = startBit + 1u;                           // reserved bit, CanonicalHuffman.java:451
         int32_t st = GF_K_OK;
@@ -620,13 +677,17 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (st == GF_K_OK) {
-            cd_tables<5>(S.len, CN_SYMS + 1, S.first, S.count, S.offset, S.symByOrder, lane, &nUsed);
-            if (nUsed == 0) st = GF_K_ERR_BOUNDS;
-        }
         if (lane == 0) { S.parseStatus = st; S.textStart = pos; }
     }
     __syncthreads();
+    if (S.parseStatus == GF_K_OK) {
+        // (the lookup table's words are free until the table is built below)
+        const uint32_t nUsed = cd_tables_wg(S.len, S.first, S.count, S.offset, S.symByOrder, S.lut);
+        if (nUsed == 0) {
+            __syncthreads();
+            return GF_K_ERR_BOUNDS;
+        }
+    }
     CD_STAMP(1);                                  // code lengths read
     if (S.parseStatus != GF_K_OK) {
         const int32_t st = S.parseStatus;
