@@ -886,6 +886,7 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     // (a staged sink may lie over the sync arrays: with one subsequence per thread over all four of them -- what phase 2 needs
     // of them goes into registers first)
     const uint32_t eotEnd = S.qx[qStar];
+    const bool plainOnly = GF_UNI((uint32_t)S.len[CN_NULL] | S.len[CN_ESC1] | S.len[CN_ESC2] | S.len[260]) == 0u;
     uint32_t myStart[CD_NCUR];
 #pragma unroll
     for (int j = 0; j < CD_NCUR; j++) myStart[j] = tid + j * DEC_THREADS < Q ? S.qs[tid + j * DEC_THREADS] : 0u;
@@ -907,6 +908,24 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
             const uint32_t bound = Bn == endBit ? 0xFFFFFFF0u : Bn;
             uint32_t k = base[j], a = mine ? (CD_NCUR == 1 ? myStart[j] : S.qs[q]) : 0u, v = 0;
             bool fin = !mine, pend = false, started = q != 0;
+#ifndef GF_CD_NO_PLAIN_LOOP
+            // A code without escapes, null and spare symbol (round 5; wave-uniform: the tile's code lengths say so): every symbol
+            // is a complete value the moment it is read -- nothing pends, two values per lookup where the table pairs them.
+            if (plainOnly) {
+                while (__any(!fin)) {
+                    const uint32_t w = cd_peek(T, a);
+                    const uint32_t e = cd_entry_of(S, w);
+                    const uint32_t sym = cd_e_sym(e), cl = cd_e_len(e);
+                    const bool take = !fin && a < bound && e != 0x7FFFFFFFu && sym < 256u;   // (else: the end-of-text symbol, no code, the border)
+                    const bool takePair = take && cd_e_pair(e) && a + cl < bound;
+                    sink.put(k, sym - 128u, take);
+                    sink.put(k + 1u, cd_e_sym2(e) - 128u, takePair);
+                    k += (take ? 1u : 0u) + (takePair ? 1u : 0u);
+                    a += takePair ? cd_e_len12(e) : take ? cl : 0u;
+                    fin = fin || !take;
+                }
+            }
+#endif
             while (__any(!fin)) {
                 const uint32_t w = cd_peek(T, a);
                 const uint32_t e = cd_entry_of(S, w);
