@@ -215,19 +215,50 @@ __device__ __forceinline__ int cn_code_lengths(CanonScratch &S, CanonPM &M, uint
 {
     uint32_t K[8];
     int n = 0;
+#ifndef GF_CN_NO_COMPACT
+    if constexpr (NREG > 1) {
+        // The symbols in use first, side by side (round 5): a terrain tile uses 60 to 130 of the 260, and the sorting network over the
+        // 512 slots that hold them all is 45 stages of eight registers -- a fifth of cn_build's instructions -- where 128 slots take
+        // 28 stages of two.  (The keys carry their symbol, so where a key stands before the sort does not matter.)
+        uint32_t *tmp = S.cntOf;                            // (filled from the sorted keys below)
+        const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        K[r] = CN_DEAD;
-        if (r < NREG) {
+        for (int r = 0; r < NREG; r++) {
             const int e = r * 64 + lane;
-            const uint32_t c = e < nSym ? cnt[e] : 0u;
-            if (e < nSym) lenOut[e] = 0;
-            // TreeBuilder.java:124-128: count ascending, symbol DESCENDING
-            K[r] = c ? ((c << 9) | (uint32_t)(511 - e)) : CN_DEAD;
-            n += __popcll(__ballot(c != 0));
+            if (r * 64 < nSym) {                            // (wave-uniform)
+                const uint32_t c = e < nSym ? cnt[e] : 0u;
+                if (e < nSym) lenOut[e] = 0;
+                const unsigned long long m = __ballot(c != 0);
+                // TreeBuilder.java:124-128: count ascending, symbol DESCENDING
+                if (c) tmp[n + __popcll(m & lt)] = (c << 9) | (uint32_t)(511 - e);
+                n += __popcll(m);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; r++) K[r] = (r < NREG && r * 64 + lane < n) ? tmp[r * 64 + lane] : CN_DEAD;
+        __builtin_amdgcn_wave_barrier();
+        if (n <= 64) wave_bitonic_sort<1>(K, lane);
+        else if (n <= 128) wave_bitonic_sort<2>(K, lane);
+        else if (NREG <= 4 || n <= 256) wave_bitonic_sort<(NREG < 4 ? NREG : 4)>(K, lane);
+        else wave_bitonic_sort<NREG>(K, lane);
+    } else
+#endif
+    {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            K[r] = CN_DEAD;
+            if (r < NREG) {
+                const int e = r * 64 + lane;
+                const uint32_t c = e < nSym ? cnt[e] : 0u;
+                if (e < nSym) lenOut[e] = 0;
+                // TreeBuilder.java:124-128: count ascending, symbol DESCENDING
+                K[r] = c ? ((c << 9) | (uint32_t)(511 - e)) : CN_DEAD;
+                n += __popcll(__ballot(c != 0));
+            }
+        }
+        wave_bitonic_sort<NREG>(K, lane);
     }
-    wave_bitonic_sort<NREG>(K, lane);
 #pragma unroll
     for (int r = 0; r < NREG; r++) {
         const int e = r * 64 + lane;

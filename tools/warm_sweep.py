@@ -8,7 +8,7 @@ from gridfour_amd import DeviceTileBatch, GpuTimer, lib
 ctx = gridfour_amd.GvrsHipContext(0)
 n_rows, n_cols, nt = 120, 150, 12960
 b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * n_rows * n_cols + 1024 + 15) // 16 * 16)
-b.synth_dem(0x9E3779B97F4A7C15 + 2, 144)
+b.synth_dem(0x9E3779B97F4A7C15 + 2, 144, style=int(os.environ.get("GF_DEM_STYLE", "0")))     # GF_DEM_STYLE=1: the rough surface
 L = lib(); L.gf_internal_set_phase_limits.argtypes = [C.c_int, C.c_int]
 b.encode(); ctx.synchronize()
 vals = b.get_values()
