@@ -552,7 +552,12 @@ __device__ __forceinline__ void build_count_table(DecShared &S, uint16_t *cnt16)
     }
 }
 
+constexpr uint32_t SHORT5_READY = 0xFFFFFFFFu;      // DecShared::nShort: the entries of the codes of up to five bits stand in S.qs[0..31]
 constexpr uint32_t FAST_TEXT_PAD = 8;              // zero words behind the LDS copy of the text
+#ifndef GF_DEC_EARLY_TXT
+#define GF_DEC_EARLY_TXT 6
+#endif
+constexpr int EARLY_TXT = GF_DEC_EARLY_TXT;         // words per thread of the packing that k_huffman_decode<FAST> stages at the top of a tile
 
 constexpr int NCUR = MAXQ / DEC_THREADS;           // cursors per thread: subsequences tid, tid + DEC_THREADS, ...
 
@@ -883,7 +888,8 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
 #ifdef GF_DIAG
     const uint32_t tStage = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
-    for (uint32_t i = tid; i < pkWords + FAST_TEXT_PAD; i += DEC_THREADS) txt[i] = (i < pkWords && i < nW) ? base32[i] : 0u;
+    // (the first EARLY_TXT words per thread are there already: the kernel asked for them at the top of the tile)
+    for (uint32_t i = tid + (uint32_t)EARLY_TXT * DEC_THREADS; i < pkWords + FAST_TEXT_PAD; i += DEC_THREADS) txt[i] = (i < pkWords && i < nW) ? base32[i] : 0u;
     __syncthreads();
 #ifdef GF_DIAG
     if (dbg && tid == 0) dbg[2] = (uint32_t)__builtin_amdgcn_s_memtime() - tStage;
@@ -1158,7 +1164,13 @@ __device__ __forceinline__ void build_lut(DecShared &S, Lut2Ptr lut2)
                 for (uint32_t x = (uint32_t)S.leafCode[tid]; x < (1u << LUT_BITS); x += 1u << cl) S.lut[x] = e;
             }
         }
-        const uint32_t nShort = min(S.nShort, 64u);
+        if (S.nShort == SHORT5_READY) {                       // (leaf records from a pre-pass: the short codes' table is in S.qs)
+            for (uint32_t x = tid; x < (1u << LUT_BITS); x += DEC_THREADS) {
+                const uint32_t e = S.qs[x & 31u];
+                if (e) S.lut[x] = e;
+            }
+        }
+        const uint32_t nShort = S.nShort == SHORT5_READY ? 0u : min(S.nShort, 64u);
         for (uint32_t j = 0; j < nShort; j++) {             // few, large fills: all threads together
             const uint32_t i = S.shortLeaf[j];
             const uint32_t cl = S.leafLen[i];
@@ -2496,6 +2508,28 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
         }
 
         GF_DSTAMP(0);
+        // The packing's text on its way into LDS (round 5): the fast Huffman pass reads it from a copy in the M32 buffer, which is idle
+        // until then -- the first EARLY_TXT words per thread are asked for here, next to the leaf records, and arrive while the
+        // header is read, instead of behind the lookup tables with the whole workgroup waiting for them (huffman_to_m32_fast
+        // stages what is left).  A packing that turns out not to fit its buffer is marked below as before.
+        if constexpr (FAST && EARLY_TXT > 0) {
+            const uint64_t baseWord = (off * 8ull) >> 5;
+            const uint32_t pkWords = (((uint32_t)(off * 8ull) & 31u) + len * 8u + 31u) >> 5;
+            const uint32_t avail = (uint32_t)min((uint64_t)0xffffffffu, nWords - baseWord);
+            const uint32_t cap = min(pkWords + FAST_TEXT_PAD, a.ldsM32Bytes >> 2);
+            uint32_t *txt = reinterpret_cast<uint32_t *>(ldsDyn);
+            uint32_t w[EARLY_TXT > 0 ? EARLY_TXT : 1];
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)EARLY_TXT; j++) {
+                const uint32_t i = (uint32_t)tid + j * DEC_THREADS;
+                w[j] = (i < pkWords && i < avail) ? w32[baseWord + i] : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)EARLY_TXT; j++) {
+                const uint32_t i = (uint32_t)tid + j * DEC_THREADS;
+                if (i < cap) txt[i] = w[j];
+            }
+        }
         // ---------------- phase 0: header + tree ----------------
         {
             uint8_t *hb = reinterpret_cast<uint8_t *>(S.head);
@@ -2576,14 +2610,18 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             uint32_t nLeaves = R(1);
             bool mine = (uint32_t)tid < nLeaves && R(0) == (uint32_t)GF_K_OK && (int32_t)R(4) < 0;
             unsigned long long code = 0;
-            uint32_t clen = 0;
+            uint32_t clen = 0, lsym = 0;
             uint32_t canonMaxLen = 0;
+            // the short codes' table (round 5): the lookup entry of the leaf that owns a pattern of five text bits, 0 where a longer code
+            // starts -- written by the leaves themselves below, read by build_lut (S.qs: free until the Huffman pass)
+            if (tid < 32) S.qs[tid] = 0u;
             if constexpr (CANON) {
                 // Leaf records from the 260 code lengths (CanonHuffTreeDecoder.java:68-95: symbols sorted by length, then symbol;
                 // consecutive codes, shifted when the length grows), by the whole workgroup: a symbol's place is the number of
                 // symbols with a shorter code plus those of its own length before it -- ballots inside the wave, a table of
-                // per-wave counts across them.  The end-of-text symbol (259) is the last of its length.  Scratch: the M32 buffer.
-                uint32_t *cw = reinterpret_cast<uint32_t *>(ldsDyn);   // [4][16] counts of the four waves of symbols; 64..67 first
+                // per-wave counts across them.  The end-of-text symbol (259) is the last of its length.  Scratch: the bitmap area
+                // behind the M32 buffer (the second-level table's place, not built yet; the buffer itself holds the text already).
+                uint32_t *cw = reinterpret_cast<uint32_t *>(ldsDyn + a.ldsM32Bytes);   // [4][16] counts of the four waves of symbols; 64..67 first
                                                                        // unused byte per wave; 80..95 lengths of 256..271; 96 / 112:
                                                                        // first code / first place of a length; 128..191 places taken
                                                                        // by the waves before; 192: longest code
@@ -2666,13 +2704,15 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
                 if (mine) {
                     code = S.leafCode[tid];
                     clen = S.leafLen[tid];
+                    lsym = S.leafSym[tid];
                 }
             } else if (mine) {
                 code = PRE ? preCode : reinterpret_cast<const unsigned long long *>(rec + 8)[tid];
                 clen = PRE ? preLen : reinterpret_cast<const uint8_t *>(rec + 8 + 512)[tid];
+                lsym = (uint8_t)(PRE ? preSym : reinterpret_cast<const uint8_t *>(rec + 8 + 512 + 64)[tid]);
                 S.leafCode[tid] = code;
                 S.leafLen[tid] = (uint8_t)clen;
-                S.leafSym[tid] = (uint8_t)(PRE ? preSym : reinterpret_cast<const uint8_t *>(rec + 8 + 512 + 64)[tid]);
+                S.leafSym[tid] = (uint8_t)lsym;
             }
             __syncthreads();
             const uint32_t prefix = (uint32_t)code & ((1u << LUT_BITS) - 1u);
@@ -2680,12 +2720,17 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             bool opens = deep;
             if (deep && tid > 0 && S.leafLen[tid - 1] > LUT_BITS)
                 opens = ((uint32_t)S.leafCode[tid - 1] & ((1u << LUT_BITS) - 1u)) != prefix;
-            uint32_t nSub, nShort;
+            uint32_t nSub;
             const uint32_t subIdx = block_excl_scan(opens ? 1u : 0u, S.waveSum, &nSub);
             if (opens) S.lut[prefix] = 0x80000000u | ((uint32_t)tid << LUT_FIRST_SHIFT) | subIdx;
-            const bool isShort = mine && clen <= 5u;
-            const uint32_t slot = block_excl_scan(isShort ? 1u : 0u, S.waveSum, &nShort);
-            if (isShort) S.shortLeaf[slot & 63u] = (uint8_t)tid;
+            // a leaf with a code of up to five bits owns 2^(5 - length) of the thirty-two five-bit patterns (a prefix code: no two
+            // leaves claim the same one).  Round 4 listed these leaves -- a second workgroup scan -- and build_lut went through the
+            // list leaf by leaf, four dependent LDS reads per turn with every thread waiting: ten to fifteen turns per terrain tile.
+            if (mine && clen <= 5u) {
+                const uint32_t e = lut_single(lsym, clen);
+                for (uint32_t k = 0; k < (1u << (5u - clen)); k++) S.qs[((uint32_t)code & 31u) | (k << clen)] = e;
+            }
+            constexpr uint32_t nShort = SHORT5_READY;
             if (tid == 0) {
                 const uint32_t maxLen = CANON ? canonMaxLen : R(3) & 0xffu;
                 const uint32_t l2 = maxLen > LUT_BITS ? min((uint32_t)L2_MAX_BITS, maxLen - LUT_BITS) : 1u;
