@@ -482,6 +482,10 @@ static gf_status decodeBatchDev(int kind, gf_context *c, void *stream, int nRows
 #ifdef GF_CANON_NO_FAST_RUN                                       // (experiment builds: tools/ab.sh)
         viaFast = false;
 #endif
+#ifdef GF_DIAG
+        // (the diagnostic build's phase limits and cycle stamps are k_canon_decode's: tools/phase_cycles_canon.py, pmc_phases_canon.sh)
+        if (g_decPhaseLimit || g_decodeDebug) viaFast = false;
+#endif
         if (viaFast) a.retryFlag = (uint32_t *)c->flags.p;
         const size_t need = nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16 + (viaFast ? 4096 : 0);
         if (c->trees.bytes < need) {

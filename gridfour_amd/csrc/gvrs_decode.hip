@@ -552,6 +552,9 @@ __device__ __forceinline__ void build_count_table(DecShared &S, uint16_t *cnt16)
     }
 }
 
+#ifndef GF_DEC_MIN_UNIT
+#define GF_DEC_MIN_UNIT 128                         // bits of a subsequence of the fast Huffman pass, at least
+#endif
 constexpr uint32_t SHORT5_READY = 0xFFFFFFFFu;      // DecShared::nShort: the entries of the codes of up to five bits stand in S.qs[0..31]
 constexpr uint32_t FAST_TEXT_PAD = 8;              // zero words behind the LDS copy of the text
 #ifndef GF_DEC_EARLY_TXT
@@ -872,7 +875,7 @@ __device__ int32_t huffman_to_m32_fast(DecShared &S, const uint32_t *__restrict_
     int32_t status = GF_K_OK;
     const uint32_t textBits = endBit - textStart;
     uint32_t unit = (textBits + MAXQ - 1) / MAXQ;
-    unit = max(128u, (unit + 31u) & ~31u);
+    unit = max((uint32_t)GF_DEC_MIN_UNIT, (unit + 31u) & ~31u);
     const uint32_t Q = max(1u, (textBits + unit - 1) / unit);
     FastHuff H;
     H.S = &S;
