@@ -937,7 +937,7 @@ def main():
     alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
     # the decode side of the two Huffman codecs is a per-tile pre-pass kernel followed by the decode kernel: both are inside
     # the HIP-event bracket and both are named, so that the rocprofv3 averages under profiles/ add up to avg_launch_ms
-    enc_name = {"canon": "k_canon_encode+k_canon_pack", "lsop": "k_lsop_predict16+k_lsop_predict+k_canon_pack2", "huffman": "k_huffman_encode+k_huffman_trees+k_huffman_pack"}[args.codec]
+    enc_name = {"canon": "k_canon_encode+k_canon_trees+k_canon_pack", "lsop": "k_lsop_predict16+k_lsop_predict+k_canon_pack2", "huffman": "k_huffman_encode+k_huffman_trees+k_huffman_pack"}[args.codec]
     dec_name = {"canon": "k_canon_parse_lengths+k_huffman_decode<4>+k_canon_decode", "lsop": "k_canon_parse_lengths+k_lsop_unpack2+k_lsop_unpack_m32+k_lsop_reconstruct+k_lsop_reconstruct_pipe",
                 "huffman": "k_huffman_parse_trees+k_huffman_decode"}[args.codec]
     dom_name, dom_ms = (dec_name, dec_avg) if dec_avg >= enc_avg else (enc_name, enc_avg)
