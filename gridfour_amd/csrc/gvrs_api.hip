@@ -328,7 +328,9 @@ gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
     if (!c || nRows < 1 || nCols < 1) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));
     const unsigned grid = gf_huffman_decode_grid(nTiles);
-    gf_status s = c->trees.ensure(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16 + nTiles * 4);
+    // (the legacy decoder's leaf records + its roomy list; the canonical decoder's length records + the slack of its fast run)
+    gf_status s = c->trees.ensure(std::max(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16 + nTiles * 4,
+                                           nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16 + 4096));
     if (s != GF_OK) return s;
     if ((s = c->packRecs.ensure(nTiles * std::max((size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS, gf_canon_pack_rec_words() + gf_canon_stat_words()) * 4 + 16)) != GF_OK) return s;
     return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
