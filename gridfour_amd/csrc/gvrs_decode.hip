@@ -2089,7 +2089,11 @@ __device__ __forceinline__ int32_t m32_to_tile(DecShared &S, M32Ptr m32, uint32_
             __syncthreads();
             GF_CSTAMP(tcC);
             if (!skipRows) finishRows(it);
+#ifdef GF_DEC_END_BARRIER2
             __syncthreads();
+#endif
+            // (no barrier behind the rows -- round 5: what they read from the ring is overwritten by the NEXT chunk's ring writes,
+            // and those stand behind that chunk's scan barrier, which no wave passes before every wave has finished these rows)
         }
         GF_CSTAMP(tcD);
     }
