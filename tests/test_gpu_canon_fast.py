@@ -172,3 +172,27 @@ def test_device_batch_plain_terrain(codec):
         assert np.all(b.get_enc_status() == 0) and np.all(b.get_dec_status() == 0)
         assert np.array_equal(b.get_decoded(), b.get_values())
     b.free()
+
+
+@pytest.mark.parametrize("model,seed", [(1, 11), (3, 12)])
+def test_random_damage_of_the_code_tables_and_the_text(codec, model, seed):
+    """heavier damage than single bits: runs of random bytes over the serialised code tables (the lengths the fast run turns into leaf
+    records, or leaves to k_canon_decode when they make no complete code) and over the text"""
+    n_rows, n_cols = 24, 36
+    v = _gentle(n_rows, n_cols, 300 + seed, amp=5)
+    good, used = oracle.codec_canon_encode(0, n_rows, n_cols, v, predictor_mask=1 << (model - 1))
+    assert used == model and _is_plain(n_rows, n_cols, good)
+    rng = np.random.default_rng(seed)
+    packs = [good]
+    for k in range(600):
+        x = bytearray(good)
+        if k % 3 == 0:                                        # the head of the stream: the meta lengths and the coded lengths
+            a = int(rng.integers(6, 40))
+        else:
+            a = int(rng.integers(6, len(good) - 1))
+        n = int(rng.integers(1, 9))
+        x[a:a + n] = rng.integers(0, 256, min(n, len(good) - a), dtype=np.uint8).tobytes()
+        packs.append(bytes(x))
+        if k % 50 == 0:                                       # ... and a tail of garbage behind a good packing
+            packs.append(good + rng.integers(0, 256, 5, dtype=np.uint8).tobytes())
+    _decode_and_compare(codec, n_rows, n_cols, packs)
