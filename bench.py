@@ -370,8 +370,9 @@ class _BorrowedContext:
         check(lib().gf_context_reserve(self._h, n_rows, n_cols, n_tiles), "gf_context_reserve")
 
 
-def _verify_shard(args, batch, n_rows, n_cols, n_tiles, with_oracle):
+def _verify_shard(args, batch, n_rows, n_cols, n_tiles, with_oracle, codec=None):
     """Per shard: every status OK and every tile survives the round trip; with_oracle: sampled byte parity as well."""
+    codec = codec or args.codec
     lengths = batch.get_lengths()
     ok = bool((batch.get_enc_status() == 0).all() and (batch.get_dec_status() == 0).all())
     vals = batch.get_values()
@@ -380,11 +381,11 @@ def _verify_shard(args, batch, n_rows, n_cols, n_tiles, with_oracle):
         import oracle
         preds = batch.get_predictors()
         for t in list(range(0, n_tiles, max(1, n_tiles // 64)))[:64]:
-            if args.codec == "lsop":
+            if codec == "lsop":
                 ref, _ = oracle.lsop12_encode(0, n_rows, n_cols, vals[t], False)
                 used = preds[t]
             else:
-                ref, used = (oracle.codec_canon_encode if args.codec == "canon" else oracle.codec_huffman_encode)(
+                ref, used = (oracle.codec_canon_encode if codec == "canon" else oracle.codec_huffman_encode)(
                     0, n_rows, n_cols, vals[t])
             if ref != batch.get_packing(t, int(lengths[t])) or used != preds[t]:
                 ok = False
@@ -470,6 +471,150 @@ def _rough_record(args, ctx, batch, n_rows, n_cols, n_tiles, tiles_per_row, seed
                           "encode_per_packed_byte": round((enc / he) / (c / headline_c), 3),
                           "decode_per_packed_byte": round((dec / hd) / (c / headline_c), 3)}
     return rec
+
+
+ENC_KERNELS = {"canon": "k_canon_encode+k_canon_trees+k_canon_pack", "lsop": "k_lsop_predict16+k_lsop_predict+k_canon_pack2",
+               "huffman": "k_huffman_encode+k_huffman_trees+k_huffman_pack+k_huffman_pack_rare"}
+# the decode side of the two Huffman codecs is a per-tile pre-pass kernel followed by the decode kernel: both are inside the
+# HIP-event bracket and both are named, so that the rocprofv3 averages under profiles/ add up to avg_launch_ms
+DEC_KERNELS = {"canon": "k_canon_parse_lengths+k_huffman_decode<4>+k_canon_decode",
+               "lsop": "k_canon_parse_lengths+k_lsop_unpack2+k_lsop_unpack16+k_lsop_unpack_m32+k_lsop_reconstruct+k_lsop_reconstruct_pipe+k_lsop_reconstruct16",
+               "huffman": "k_huffman_parse_trees+k_huffman_decode"}
+SEEDS = {"dem1024": 1, "etopo1": 2, "etopo1_nulls": 2, "etopo1_rough": 2, "gebco_shard": 3, "gebco_full": 3, "float256_lsop": 5}
+
+
+def _roofline_block(algo_bytes, enc_ms, dec_ms, workload, codec, traffic_file="hbm_traffic.json"):
+    """The `roofline` object of a (workload, codec): the slower direction's algorithmic bytes over its HIP-event time, its replayed
+    PMC traffic (None where profiles/ holds none for this workload) and -- so that "is it bandwidth?" is a number -- the rate at
+    which that traffic moved (traffic_GBps) beside the algorithmic rate (achieved)."""
+    dom_ms, dom, names = (enc_ms, "encode", ENC_KERNELS[codec]) if enc_ms >= dec_ms else (dec_ms, "decode", DEC_KERNELS[codec])
+    ach = algo_bytes / (dom_ms * 1e-3) / 1e9
+    traffic, src = _pmc_traffic(workload, names, traffic_file)
+    return {"bound": "hbm", "direction": dom, "kernel": names, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(dom_ms, 4),
+            "traffic": traffic, "traffic_GBps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None,
+            "traffic_replayed_from": src,
+            "roundtrip_frac": round((2 * algo_bytes) / ((enc_ms + dec_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+
+def _int_sub_record(args, ctx, workload, codec, reps=10):
+    """Another of BASELINE.json's configurations (or another codec on the headline's grid) timed in the same run, beside the headline:
+    its own batch, 2 warm-up + `reps` timed steps between HIP events on the context's stream, every tile's round trip and 64
+    sampled packings against the oracle.  Compact: what the driver's record needs to see that configuration measured."""
+    from gridfour_amd import DeviceTileBatch, GpuTimer
+    n_rows, n_cols, n_tiles, tiles_per_row, _ = WORKLOADS[workload]
+    cells = n_rows * n_cols
+    b = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=((2 * cells + 1024) + 15) // 16 * 16, codec=codec)
+    b.synth_dem(0x9E3779B97F4A7C15 + SEEDS[workload], tiles_per_row, tile0=0, mask_per_mille=MASK_PER_MILLE.get(workload, 0),
+                style=STYLE.get(workload, 0))
+    ctx.synchronize()
+    if workload == "float256_lsop":
+        f = b.get_values().astype(np.float32) * np.float32(0.1)
+        b.values.upload(np.floor((f * np.float32(10.0)).astype(np.float64) + 0.5).astype(np.int32))
+        del f
+    te, td = [GpuTimer(ctx) for _ in range(reps)], [GpuTimer(ctx) for _ in range(reps)]
+    for _ in range(2):
+        b.encode(codec_index=0)
+        b.decode()
+    for i in range(reps):
+        te[i].start()
+        b.encode(codec_index=0)
+        te[i].stop()
+        td[i].start()
+        b.decode()
+        td[i].stop()
+    ctx.synchronize()
+    enc, dec = float(np.mean([t.elapsed_ms() for t in te])), float(np.mean([t.elapsed_ms() for t in td]))
+    ok, packed, _ = _verify_shard(args, b, n_rows, n_cols, n_tiles, with_oracle=True, codec=codec)
+    c = packed / float(n_tiles * cells)
+    raw_mb = n_tiles * cells * 4 / 1e6
+    rec = {"workload": workload, "codec": codec, "tiles": n_tiles, "tile": "%dx%d" % (n_rows, n_cols), "encode_ms": round(enc, 4),
+           "decode_ms": round(dec, 4), "MBps": round(raw_mb / ((enc + dec) * 1e-3), 1), "bit_exact": bool(ok), "bytes_per_cell": round(c, 4),
+           "roofline": _roofline_block((4.0 + c) * n_tiles * cells, enc, dec, workload, codec)}
+    b.free()
+    if codec == "lsop":
+        for x in (b.residuals, b.coefs, b.scratch_status):
+            x.free()
+    return rec
+
+
+def _float_sub_record(ctx, reps=10):
+    """BASELINE config 5(i) beside the headline: CodecFloat's GPU stage (the five byte planes) on 4,096 tiles of 256x256 floats, every
+    tile's round trip checked, sixteen tiles' planes against the oracle's.  The Deflate stage is the host's zlib (run_float times it
+    on a sample with --codec float)."""
+    import oracle
+    from gridfour_amd import DeviceBuffer, DeviceTileBatch, GpuTimer, lib
+    from gridfour_amd._lib import check
+    n_rows, n_cols, n_tiles, tiles_per_row, _ = WORKLOADS["float256"]
+    cells = n_rows * n_cols
+    pstride = (int(lib().gf_float_planes_bytes(n_rows, n_cols)) + 15) // 16 * 16
+    gen = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=16)
+    gen.synth_dem(0x9E3779B97F4A7C15 + 5, tiles_per_row, tile0=0)
+    ctx.synchronize()
+    v = (gen.get_values().astype(np.float32) * np.float32(0.1)).reshape(n_tiles, cells)
+    gen.free()
+    d_in, d_planes, d_out = DeviceBuffer(ctx, v.nbytes), DeviceBuffer(ctx, n_tiles * pstride), DeviceBuffer(ctx, v.nbytes)
+    d_in.upload(v)
+    enc = lambda: check(lib().gf_float_planes_encode_dev(ctx.handle, None, n_rows, n_cols, n_tiles, d_in.ptr, d_planes.ptr, pstride), "enc")
+    dec = lambda: check(lib().gf_float_planes_decode_dev(ctx.handle, None, n_rows, n_cols, n_tiles, d_planes.ptr, pstride, d_out.ptr), "dec")
+    te, td = [GpuTimer(ctx) for _ in range(reps)], [GpuTimer(ctx) for _ in range(reps)]
+    for _ in range(2):
+        enc()
+        dec()
+    for i in range(reps):
+        te[i].start()
+        enc()
+        te[i].stop()
+        td[i].start()
+        dec()
+        td[i].stop()
+    ctx.synchronize()
+    e_ms, d_ms = float(np.mean([t.elapsed_ms() for t in te])), float(np.mean([t.elapsed_ms() for t in td]))
+    back = d_out.download(np.uint32, n_tiles * cells).reshape(n_tiles, cells)
+    ok = bool(np.array_equal(back, v.view(np.uint32)))
+    nb = int(lib().gf_float_planes_bytes(n_rows, n_cols))
+    for t in range(0, n_tiles, n_tiles // 16):
+        pl = d_planes.download(np.uint8, nb, t * pstride)
+        ok = ok and pl.tobytes() == bytes(oracle.float_planes_encode(n_rows, n_cols, v[t].view(np.uint32)))
+    for x in (d_in, d_planes, d_out):
+        x.free()
+    algo = (4.0 + 4.125) * n_tiles * cells
+    dom_ms, dom = (e_ms, "k_float_planes_encode") if e_ms >= d_ms else (d_ms, "k_float_planes_decode")
+    ach = algo / (dom_ms * 1e-3) / 1e9
+    return {"workload": "float256", "codec": "float (plane stage; Deflate on the host's zlib)", "tiles": n_tiles, "tile": "256x256",
+            "encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4), "MBps": round(n_tiles * cells * 4 / 1e6 / ((e_ms + d_ms) * 1e-3), 1),
+            "bit_exact": ok, "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(algo),
+                                          "avg_launch_ms": round(dom_ms, 4), "traffic": None}}
+
+
+def _compact_record(ctx, batch, n_tiles, reps=10):
+    """gf_compact_dev on the headline batch: the timed encode leaves every packing at the start of its slot; SURVEY 8b(4)'s batch
+    result -- offsets + one blob -- is this gather behind it.  Its time is reported beside the headline, not inside it."""
+    from gridfour_amd import DeviceBuffer, GpuTimer, lib
+    from gridfour_amd._lib import check
+    lengths = batch.get_lengths()
+    total = int(lengths.astype(np.int64).sum())
+    d_off, d_blob = DeviceBuffer(ctx, (n_tiles + 1) * 8), DeviceBuffer(ctx, total + 64)
+    run = lambda: check(lib().gf_compact_dev(ctx.handle, None, n_tiles, batch.slots.ptr, batch.stride, batch.lengths.ptr, d_off.ptr,
+                                             d_blob.ptr, total + 64), "gf_compact_dev")
+    tm = [GpuTimer(ctx) for _ in range(reps)]
+    run()
+    for t in tm:
+        t.start()
+        run()
+        t.stop()
+    ctx.synchronize()
+    ms = float(np.mean([t.elapsed_ms() for t in tm]))
+    off = d_off.download(np.uint64, n_tiles + 1)
+    ok = int(off[n_tiles]) == total and bool(np.array_equal(np.diff(off).astype(np.uint32), lengths))
+    blob = d_blob.download(np.uint8, total)
+    for t in range(0, n_tiles, max(1, n_tiles // 32)):
+        ok = ok and blob[int(off[t]):int(off[t + 1])].tobytes() == batch.get_packing(t, int(lengths[t]))
+    d_off.free()
+    d_blob.free()
+    return {"compact_ms": round(ms, 4), "blob_bytes": total, "checked": bool(ok),
+            "note": "gf_compact_dev (exclusive scan of the lengths + gather of the slots into one blob) on the headline batch; outside `value`"}
 
 
 def _lsop_fp64_roofline(ctx, batch, n_rows, n_cols, n_tiles, reps):
@@ -761,7 +906,7 @@ def main():
     else:
         ctxs = [gridfour_amd.GvrsHipContext(local_rank)]
     stride = ((2 * cells + 1024) + 15) // 16 * 16           # DEM packings are far below 2 B/cell
-    seed = 0x9E3779B97F4A7C15 + {"dem1024": 1, "etopo1": 2, "etopo1_nulls": 2, "etopo1_rough": 2, "gebco_shard": 3, "gebco_full": 3, "float256_lsop": 5}[args.workload]
+    seed = 0x9E3779B97F4A7C15 + SEEDS[args.workload]
     batches = []
     for g, ctx in enumerate(ctxs):
         b = DeviceTileBatch(ctx, n_rows, n_cols, n_tiles, slot_stride=stride, codec=args.codec)
@@ -909,7 +1054,7 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, per_shard[0])
         per_shard = gathered
-    cpu_baseline, host_path, rough, data_stats = None, None, None, None
+    cpu_baseline, host_path, rough, data_stats, extra = None, None, None, None, {}
     if rank == 0 and vals0 is not None:
         data_stats = _m32_stats(vals0, batches[0].get_predictors(), n_rows, n_cols)
     if rank == 0 and total_shards == 1 and not args.no_verify:
@@ -920,9 +1065,17 @@ def main():
         if args.codec == "huffman" and args.cpu_sample_tiles != 0:
             host_path = _host_path(ctxs[0].handle, vals0, n_rows, n_cols)
         if args.codec == "huffman" and args.workload == "etopo1" and args.cpu_sample_tiles != 0:
-            # (last: it refills the batch's buffers with the rough surface)
+            # the other configurations north_star names, timed in this same run (each with its own batch, verified like the headline)
+            extra["compact"] = _compact_record(ctxs[0], batches[0], n_tiles)
+            # (it refills the headline batch's buffers with the rough surface)
             rough = _rough_record(args, ctxs[0], batches[0], n_rows, n_cols, n_tiles, tiles_per_row, seed,
                                   (float(np.max(enc_ms)), float(np.max(dec_ms))), c_per_cell)
+            batches[0].free()
+            extra["lsop"] = _int_sub_record(args, ctxs[0], "etopo1", "lsop")
+            extra["canon"] = _int_sub_record(args, ctxs[0], "etopo1", "canon")
+            extra["dem1024"] = _int_sub_record(args, ctxs[0], "dem1024", "huffman")
+            extra["float256_lsop"] = _int_sub_record(args, ctxs[0], "float256_lsop", "lsop", reps=5)
+            extra["float256"] = _float_sub_record(ctxs[0])
 
     if rank != 0:
         if launcher:
@@ -937,9 +1090,7 @@ def main():
     alg_bytes = (4.0 + c_per_cell) * n_tiles * cells
     # the decode side of the two Huffman codecs is a per-tile pre-pass kernel followed by the decode kernel: both are inside
     # the HIP-event bracket and both are named, so that the rocprofv3 averages under profiles/ add up to avg_launch_ms
-    enc_name = {"canon": "k_canon_encode+k_canon_trees+k_canon_pack", "lsop": "k_lsop_predict16+k_lsop_predict+k_canon_pack2", "huffman": "k_huffman_encode+k_huffman_trees+k_huffman_pack"}[args.codec]
-    dec_name = {"canon": "k_canon_parse_lengths+k_huffman_decode<4>+k_canon_decode", "lsop": "k_canon_parse_lengths+k_lsop_unpack2+k_lsop_unpack_m32+k_lsop_reconstruct+k_lsop_reconstruct_pipe",
-                "huffman": "k_huffman_parse_trees+k_huffman_decode"}[args.codec]
+    enc_name, dec_name = ENC_KERNELS[args.codec], DEC_KERNELS[args.codec]
     dom_name, dom_ms = (dec_name, dec_avg) if dec_avg >= enc_avg else (enc_name, enc_avg)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     traffic, traffic_from = _pmc_traffic(args.workload, dom_name)
@@ -974,6 +1125,7 @@ def main():
         "decode_MBps": round(raw_mb / (dec_avg * 1e-3), 1),
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_GBps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None,
                      "traffic_replayed_from": traffic_from, "traffic_stale": bool(traffic is None and traffic_from and traffic_from.startswith("STALE")),
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "avg_launch_ms": round(dom_ms, 4),
@@ -985,6 +1137,7 @@ def main():
         out["config"]["data"] = data_stats
     if rough:
         out["rough"] = rough
+    out.update(extra)
     out["roofline_issue"] = _issue_roofline(args.workload, dom_name, n_tiles, dom_ms)
     if args.codec == "lsop" and vals0 is not None and args.cpu_sample_tiles != 0:
         out["default_container"] = _lsop_default_container(ctxs[0].handle, vals0, n_rows, n_cols, 2048)

@@ -322,6 +322,15 @@ static size_t decodeWorkspaceStride(int nRows, int nCols)
     return roundUp(cap + 2 * ((cap >> 5) + 2) * 4 + 64, 16);
 }
 
+// the encoders' per-tile records between their kernels (selection records, statistics) and, behind them, the legacy encoder's byte
+// plane of raw row differences (GfEncodeArgs::plane): one allocation of the context
+static size_t encPlaneStride(int nRows, int nCols) { return roundUp((size_t)nRows * (size_t)nCols, 16); }
+static size_t encRecordBytes(int nRows, int nCols, size_t nTiles)
+{
+    const size_t recs = nTiles * std::max((size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS, gf_canon_pack_rec_words() + gf_canon_stat_words()) * 4 + 16;
+    return roundUp(recs, 256) + nTiles * encPlaneStride(nRows, nCols) + 256;
+}
+
 gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
 {
     GF_CTX_LOCK(c);
@@ -332,7 +341,7 @@ gf_status gf_context_reserve(gf_context *c, int nRows, int nCols, size_t nTiles)
     gf_status s = c->trees.ensure(std::max(nTiles * (size_t)GF_TREE_REC_WORDS * 4 + 16 + nTiles * 4,
                                            nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16 + 4096));
     if (s != GF_OK) return s;
-    if ((s = c->packRecs.ensure(nTiles * std::max((size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS, gf_canon_pack_rec_words() + gf_canon_stat_words()) * 4 + 16)) != GF_OK) return s;
+    if ((s = c->packRecs.ensure(encRecordBytes(nRows, nCols, nTiles))) != GF_OK) return s;
     return c->workspace.ensure((size_t)grid * decodeWorkspaceStride(nRows, nCols));
 }
 
@@ -389,14 +398,24 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
     {
         // (CodecHuffman: the selection records, and behind them the statistics k_huffman_encode hands to k_huffman_trees)
         const size_t need = nTiles * (kind == KIND_CANON ? gf_canon_pack_rec_words() + gf_canon_stat_words() : (size_t)GF_PACK_REC_WORDS + GF_ENC_STAT_WORDS) * 4 + 16;
-        if (c->packRecs.bytes < need) {
+        const size_t needAll = encRecordBytes(nRows, nCols, nTiles);
+        if (c->packRecs.bytes < needAll) {
             GF_HIP(hipSetDevice(c->device));               // not capture-safe: gf_context_reserve sizes this too
-            gf_status s = c->packRecs.ensure(need);
+            gf_status s = c->packRecs.ensure(needAll);
             if (s != GF_OK) return s;
         }
         a.packRecs = (uint32_t *)c->packRecs.p;
         a.lean = g_lean;
         a.encStats = a.packRecs + nTiles * (kind == KIND_CANON ? gf_canon_pack_rec_words() : (size_t)GF_PACK_REC_WORDS);
+        // (round 6) the byte plane of raw row differences between phase A and the packer (GfEncodeArgs::plane), behind the records
+        a.plane = nullptr;
+        a.planeStride = 0;
+#ifndef GF_ENC_NO_PLANE
+        if (kind == KIND_HUFFMAN && !a.lean) {
+            a.planeStride = encPlaneStride(nRows, nCols);
+            a.plane = (uint8_t *)c->packRecs.p + roundUp(need, 256);
+        }
+#endif
     }
     if (kind == KIND_CANON) GF_HIP(gf_launch_canon_encode(a, stream ? (hipStream_t)stream : c->stream));
     else if (a.lean && a.retryFlag && 6ull * (size_t)nRows * (size_t)nCols < (1ull << 23))   // one tile per call: the 1024-thread build

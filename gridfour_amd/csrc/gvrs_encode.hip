@@ -282,7 +282,9 @@ __device__ PackState pack_generic(int model, const uint32_t *__restrict__ tile, 
 // one element per thread and chunk, INLINED: as a call into pack_generic it cost every tile the callee's register saves --
 // twelve VGPRs per lane stored to and reloaded from scratch, a third of a gigabyte per launch on the bench batch.
 // Requires 256 * elemMaxBits <= window bits (implied by the kernels' `fast` condition).
-template <int MODEL>
+// PLANE (round 6): `tile` is the tile's byte plane of raw row differences (GfEncodeArgs::plane) and every value of the stream one plain
+// byte: the heads of the Linear and the Triangle stream -- first row, first column(s) -- are plane bytes as they stand.
+template <int MODEL, bool PLANE = false>
 __device__ __forceinline__ PackState pack_head(const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
                                                const uint64_t *tab, uint32_t sEnd, uint32_t *win, uint32_t *__restrict__ out32,
                                                uint32_t *waveSum, PackState ps)
@@ -294,10 +296,16 @@ __device__ __forceinline__ PackState pack_head(const uint32_t *__restrict__ tile
         int n = 0;
         if (s < sEnd) {
             const uint32_t idx = gf_stream_cell(MODEL, nR, nC, s);
+            if constexpr (PLANE) {
+                x = (uint32_t)reinterpret_cast<const uint8_t *>(tile)[idx];
+                n = 1;
+                myBits = (uint32_t)(tab[x] >> 56);
+            } else {
             const uint32_t r = idx / nC, c = idx - r * nC;
             x = cell_residual(MODEL, tile, nC, idx, r, c, seed);
             n = gf_m32_len(x);
             for (int k = 0; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
+            }
         }
         uint32_t total;
         const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
@@ -401,7 +409,64 @@ struct PackStateOk {
     PackState ps;
     bool ok;
 };
-template <int MODEL, bool PLAIN>
+
+// (round 6) The low bytes of the residuals of eight consecutive cells i0 .. i0 + 7 (i0 a multiple of 8) of model 1, 2 or 3 from the
+// tile's byte plane of raw row differences p (GfEncodeArgs::plane; every byte is its value exactly and the winner's values are plain
+// bytes, so a residual's low byte is its M32 form): Differencing -- the plane's bytes; Linear -- a byte less its left neighbour
+// (PredictorModelLinear.java:128-141: v - (2 W - WW) = (v - W) - (W - WW)); Triangle -- a byte less the byte above
+// (PredictorModelTriangle.java:130-142: v - (W + N - NW) = (v - W) - (N - NW)).  Four bytes are subtracted at once (no carries
+// between them); cells that the model does not emit in the flat scan (first row, first columns) give bytes nobody looks at.
+// Words up to 12 bytes in front of the plane may be read (never used): the plane of tile 0 has the records' slack in front of it.
+__device__ __forceinline__ uint32_t bytes_sub4(uint32_t x, uint32_t y)
+{
+    constexpr uint32_t H = 0x80808080u;
+    return ((x | H) - (y & ~H)) ^ ((x ^ ~y) & H);
+}
+// (in two steps, so that the packer can ask for a turn's words one turn ahead: five registers instead of the nineteen of a turn's cells)
+struct PlaneWords {
+    uint32_t c0, c1;                    // the eight bytes at i0
+    uint32_t x0, x1, x2;                // Linear: x0 = the word in front of them; Triangle: the three words that hold the bytes above
+};
+template <int MODEL>
+__device__ __forceinline__ PlaneWords plane_load(const uint8_t *__restrict__ p, uint32_t nC, uint32_t i0)
+{
+    PlaneWords w;
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(p + i0);
+    const GfU2 cur = *reinterpret_cast<const GfU2 *>(pw);
+    w.c0 = cur.x;
+    w.c1 = cur.y;
+    w.x0 = w.x1 = w.x2 = 0;
+    if constexpr (MODEL == 2) {
+        w.x0 = pw[-1];
+    } else if constexpr (MODEL == 3) {
+        int32_t o = (int32_t)i0 - (int32_t)nC;
+        if (o < -8) o = -8;                                             // (the first row: nothing of it is emitted here)
+        const uint32_t *uw = reinterpret_cast<const uint32_t *>(p + (o & ~3));
+        w.x0 = uw[0];
+        w.x1 = uw[1];
+        w.x2 = uw[2];
+    }
+    return w;
+}
+template <int MODEL>
+__device__ __forceinline__ void plane_residual_bytes(const PlaneWords &w, uint32_t nC, uint32_t i0, uint32_t (&rb)[2])
+{
+    if constexpr (MODEL == 1) {
+        rb[0] = w.c0;
+        rb[1] = w.c1;
+    } else if constexpr (MODEL == 2) {
+        rb[0] = bytes_sub4(w.c0, __builtin_amdgcn_alignbyte(w.c0, w.x0, 3u));
+        rb[1] = bytes_sub4(w.c1, __builtin_amdgcn_alignbyte(w.c1, w.c0, 3u));
+    } else {
+        int32_t o = (int32_t)i0 - (int32_t)nC;
+        if (o < -8) o = -8;
+        const uint32_t sh = (uint32_t)o & 3u;
+        rb[0] = bytes_sub4(w.c0, __builtin_amdgcn_alignbyte(w.x1, w.x0, sh));
+        rb[1] = bytes_sub4(w.c1, __builtin_amdgcn_alignbyte(w.x2, w.x1, sh));
+    }
+}
+
+template <int MODEL, bool PLAIN, bool PLANE = false>
 __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                        const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                        PackState ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
@@ -420,6 +485,12 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
     bool fits = true;
     uint32_t c0 = (segBegin + lane * CPT) % nC;
     const uint32_t cStep = (64u * CPT) % nC;
+    // PLANE: the words of a turn are asked for a turn ahead (an address behind the wave's share is bent back into the tile: the words
+    // are not used).  The packer's turn is a chain -- plane words, code table, scan, window -- and with the tile's nineteen
+    // registers per lane in place of these five there was no room to keep the next link's loads in flight.
+    [[maybe_unused]] PlaneWords ahead;
+    [[maybe_unused]] const uint32_t lastI0 = (nCells - 1u) & ~(uint32_t)(CPT - 1);
+    if constexpr (PLANE) ahead = plane_load<MODEL>(reinterpret_cast<const uint8_t *>(tile), nC, min(segBegin + lane * CPT, lastI0));
     for (uint32_t base = segBegin; base < segEnd; base += 64u * CPT) {
         const uint32_t i0 = base + lane * CPT;
         // PLAIN (round 4): the record says that every value of the stream is one plain M32 byte (k_huffman_encode looked at the
@@ -428,6 +499,48 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
         uint64_t cl[CPT];
         uint32_t xs[PLAIN ? 1 : CPT];
         uint32_t myBits = 0, multi = 0, hard = 0;
+        if constexpr (PLANE) {
+            static_assert(PLAIN && MODEL >= 1 && MODEL <= 3, "the byte plane serves plain streams of the three predictors");
+            const PlaneWords now = ahead;
+            ahead = plane_load<MODEL>(reinterpret_cast<const uint8_t *>(tile), nC, min(i0 + 64u * CPT, lastI0));
+            if (i0 < segEnd) {
+                uint32_t rb[2];
+                plane_residual_bytes<MODEL>(now, nC, i0, rb);
+                // which of the eight cells the flat scan emits, as a bit mask (nC >= 8: at most one of them starts a row): not the
+                // cells behind the tile; Differencing: not the seed; Linear: not the first two cells of a row; Triangle: not the first
+                // row, not the first cell of a row.  A cell that is not emitted gets the byte 0x80, which no plain stream holds and
+                // whose table entry the packer has emptied: eight table reads without a condition.
+                uint32_t em = 0xffu;
+                const uint32_t left = nCells - i0;
+                if (left < (uint32_t)CPT) em = (1u << left) - 1u;
+                const uint32_t kz = c0 == 0u ? 0u : min(nC - c0, 16u);          // the place of the cell that starts a row (>= 8: none)
+                if constexpr (MODEL == 1) {
+                    if (i0 == 0u) em &= ~1u;
+                } else if constexpr (MODEL == 2) {
+                    em &= ~(3u << kz);
+                    if (c0 == 1u) em &= ~1u;
+                } else {
+                    em &= ~(1u << kz);
+                    if (i0 < nC) em &= ~((1u << min((uint32_t)CPT, nC - i0)) - 1u);
+                }
+                {
+                    const uint32_t y0 = __umul24(em & 15u, 0x00204081u) & 0x01010101u, y1 = __umul24((em >> 4) & 15u, 0x00204081u) & 0x01010101u;
+                    constexpr uint32_t H = 0x80808080u;
+                    const uint32_t m0 = (H - y0) ^ H, m1 = (H - y1) ^ H;       // a byte of ones per emitted cell (no borrow crosses a byte)
+                    rb[0] = (rb[0] & m0) | (0x80808080u & ~m0);
+                    rb[1] = (rb[1] & m1) | (0x80808080u & ~m1);
+                }
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint64_t e = tab[(rb[j >> 2] >> (8 * (j & 3))) & 0xffu];
+                    cl[j] = e;
+                    myBits += (uint32_t)(e >> 56);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) cl[j] = 0;
+            }
+        } else
         if (i0 < segEnd) {
             Cells8 Q;
             load_cells8(tile, nC, nCells, i0, Q);
@@ -593,9 +706,13 @@ union EncScratchA {
 #ifndef GF_ENC_A_WGS
 #define GF_ENC_A_WGS 7           // workgroups per CU the part-1 kernel is compiled for: 72 VGPRs, no scratch (8: 64 VGPRs and 28 bytes of scratch per lane; measured 0.689 / 0.714 / 0.705 ms per encode with 7 / 8 / 6)
 #endif
-template <bool FAST, int PART = 0>
+// PLANE (PART 1 only, round 6): the byte plane of raw row differences is written (GfEncodeArgs::plane is not null).  A template
+// parameter and not a test of the pointer: behind a branch around the store the compiler waits for the store itself (the counter of
+// outstanding memory operations is one for loads and stores and counts in order; at the join it cannot tell which path was taken).
+template <bool FAST, int PART = 0, bool PLANE = false>
 __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_ENC_HIST_R_A <= 4 ? GF_ENC_A_WGS : ENC_AB_WGS) void k_huffman_encode(GfEncodeArgs a)
 {
+    static_assert(!PLANE || PART == 1, "the byte plane belongs to the part-1 kernel");
     __shared__ std::conditional_t<PART == 1, EncPersistA, EncPersist> P;
     __shared__ std::conditional_t<PART == 1, EncScratchA, EncScratchT<FAST>> S;
     constexpr int HR = PART == 1 ? GF_ENC_HIST_R_A : HIST_R;              // histogram replicas
@@ -630,6 +747,11 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
             uint32_t *const h0 = &S.histR[0][rep], *const h1 = &S.histR[1][rep], *const h2 = &S.histR[2][rep];
             uint32_t c0 = ((uint32_t)tid * CPT) % nC;
             const uint32_t cStep = STEP_CELLS % nC;
+#ifdef GF_PLANE_STORE_LATE
+            GfU2 pend;
+            pend.x = pend.y = 0;
+            uint32_t pendI0 = 0xFFFFFFFFu;
+#endif
             for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
                 Cells8 Q;
                 load_cells8(tile, nC, nCells, i0, Q);
@@ -717,6 +839,29 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                     }
                     widest = 0xFFFFFFFFu;                            // (the turns at the tile's ends take the general histogram code)
                 }
+                if constexpr (PLANE) {
+                    // (round 6) the Differencing residual -- the raw row difference, column 0: the difference to the row above -- as one
+                    // byte per cell for the packer (GfEncodeArgs::plane): eight bytes per lane, a wave's store is 512 consecutive bytes.
+                    // The residuals of all three predictors are differences of these (k_huffman_pack, PLANE), as long as every byte IS
+                    // its value: a turn that is not plain looks at its eight values (bit 2 of the flags: the plane does not hold the tile).
+                    const uint32_t p01 = __builtin_amdgcn_perm(D1[1], D1[0], 0x0c0c0400u), p23 = __builtin_amdgcn_perm(D1[3], D1[2], 0x0c0c0400u);
+                    const uint32_t p45 = __builtin_amdgcn_perm(D1[5], D1[4], 0x0c0c0400u), p67 = __builtin_amdgcn_perm(D1[7], D1[6], 0x0c0c0400u);
+                    GfU2 w;
+                    w.x = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    w.y = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
+#if defined(GF_PLANE_STORE_OFF)                                      // (experiment builds, tools/ab.sh: where does the store's time go?)
+                    asm volatile("" ::"v"(w.x), "v"(w.y));
+#elif defined(GF_PLANE_STORE_LATE)
+                    if (pendI0 != 0xFFFFFFFFu) *reinterpret_cast<GfU2 *>(a.plane + t * a.planeStride + pendI0) = pend;
+                    pend = w;
+                    pendI0 = i0;
+#elif defined(GF_PLANE_STORE_NT)
+                    __builtin_nontemporal_store(w.x, reinterpret_cast<uint32_t *>(a.plane + t * a.planeStride + i0));
+                    __builtin_nontemporal_store(w.y, reinterpret_cast<uint32_t *>(a.plane + t * a.planeStride + i0) + 1);
+#else
+                    *reinterpret_cast<GfU2 *>(a.plane + t * a.planeStride + i0) = w;
+#endif
+                }
                 if (__all(widest <= 252u && lowest != (int32_t)0x80000000)) {
                     myFlags |= 2u;
 #pragma unroll
@@ -731,6 +876,7 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                         const uint32_t v = Q.cur[j];
                         myFlags |= i0 + j < nCells ? ((v == GF_NULL_CODE) ? 1u : 2u) : 0u;
                         const uint32_t d1 = D1[j], d2 = D2[j], d3 = D3[j];
+                        if (PLANE && d1 + 128u > 255u) myFlags |= 4u;
                         // the first M32 byte of the three residuals without a branch; the continuation bytes of values that have any
                         // behind ONE branch per cell (three, one per predictor, cost the scalar unit more than the cell cost the SIMDs)
                         bool s1, s2, s3 = true;
@@ -767,6 +913,11 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                 c0 += cStep;
                 if (c0 >= nC) c0 -= nC;
             }
+#ifdef GF_PLANE_STORE_LATE
+            if constexpr (PLANE) {
+                if (pendI0 != 0xFFFFFFFFu) *reinterpret_cast<GfU2 *>(a.plane + t * a.planeStride + pendI0) = pend;
+            }
+#endif
         }
         if (myFlags) atomicOr(&P.flags, myFlags);
         if (maxN1 > 1) atomicMax(&P.maxN[0], maxN1);
@@ -923,7 +1074,11 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                 uint32_t *stat = a.encStats + t * (size_t)GF_ENC_STAT_WORDS;
                 stat[tid] = (uint32_t)P.model[tid];
                 stat[4 + tid] = P.maxN[tid];
-                if (tid == 0) { stat[3] = P.seed; stat[7] = 1u; }
+                if (tid == 0) {
+                    stat[3] = P.seed;
+                    stat[7] = 1u;
+                    stat[8] = (PLANE && !(flags & 5u)) ? 1u : 0u;              // the byte plane holds this tile (no null cell, no wide row difference)
+                }
             }
             __syncthreads();
             continue;
@@ -1403,7 +1558,7 @@ __global__ __launch_bounds__(64) void k_huffman_trees(GfEncodeArgs a)
             rec[3] = maxN[best];
             rec[4] = bMaxLen;
             rec[5] = (uint32_t)min(bTotalBits - bTreeEnd, (uint64_t)0xFFFFFFFFu);   // bits of the text
-            rec[7] = bPlain;
+            rec[7] = bPlain | (stat[8] ? 2u : 0u);                           // bit 1: the byte plane holds the tile (k_huffman_encode, PART 1)
         }
     }
 }
@@ -1412,7 +1567,7 @@ __global__ __launch_bounds__(64) void k_huffman_trees(GfEncodeArgs a)
 // the flat scan of a tile through the wave-private windows, in as many cell ranges as its bit count asks for (a wave's
 // share of a range must fit its quarter of the window); false: a range did not fit after all -- the tile is left to
 // k_huffman_pack_rare, which packs it again from its first bit
-template <int MODEL, bool PLAIN>
+template <int MODEL, bool PLAIN, bool PLANE = false>
 __device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                                  const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                                  PackState &ps, uint32_t slotWords, uint32_t textBits)
@@ -1426,7 +1581,7 @@ __device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ ti
     // range as a whole would fit: nothing was written then, and the range is packed again in two halves (round 4; such tiles -- most
     // of a rough surface's -- used to go to k_huffman_pack_rare, 0.2 ms per launch of the rough batch).
     for (uint32_t b = 0; b < nCells;) {
-        const PackStateOk r = pack_flat_waves<MODEL, PLAIN>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
+        const PackStateOk r = pack_flat_waves<MODEL, PLAIN, PLANE>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
         if (r.ok) {
             ps = r.ps;
             b += per;
@@ -1465,8 +1620,10 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
         const uint32_t imgWords = (treeEnd + 31u) >> 5;
         for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) win[i] = i < (int)imgWords ? rec[8 + i] : 0u;
         {
+            // (0x80 is no symbol of a plain stream -- rec[7] bit 0 --: the plane path gives that byte to the cells it does not emit)
             uint32_t *tw = reinterpret_cast<uint32_t *>(P.tab);
-            for (int i = tid; i < 512; i += ENC_THREADS) tw[i] = rec[8 + 88 + i];
+            const bool emptyNull = !RARE && (rec[7] & 3u) == 3u;
+            for (int i = tid; i < 512; i += ENC_THREADS) tw[i] = (emptyNull && (i >> 1) == 0x80) ? 0u : rec[8 + 88 + i];
         }
         __syncthreads();
 
@@ -1496,9 +1653,21 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
                     ps = pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
                 }
             } else {
-                const bool plain = rec[7] != 0u && model != 4;                // (the same word in every thread)
+                const bool plain = (rec[7] & 1u) != 0u && model != 4;         // (the same word in every thread)
+                // (round 6) a plain stream of a tile whose byte plane phase A has left: the plane instead of the tile -- a byte per cell
+                const uint32_t *__restrict__ plane = reinterpret_cast<const uint32_t *>(a.plane + t * a.planeStride);
                 if (!fast) {
                     done = false;
+                } else if (plain && a.plane && (rec[7] & 2u) && nC >= (uint32_t)CPT) {
+                    if (model == 1) {
+                        done = pack_flat_ranges<1, true, true>(plane, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                    } else if (model == 2) {
+                        ps = pack_head<2, true>(plane, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
+                        done = pack_flat_ranges<2, true, true>(plane, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                    } else {
+                        ps = pack_head<3, true>(plane, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
+                        done = pack_flat_ranges<3, true, true>(plane, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
+                    }
                 } else if (model == 1) {
                     done = plain ? pack_flat_ranges<1, true>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits)
                                  : pack_flat_ranges<1, false>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
@@ -1752,7 +1921,8 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
 #ifndef GF_DIAG
         if (a.encStats && !a.lean) {
             // the histograms, then the trees with a wave per tile (the diagnostic flavour keeps the one-kernel form its stamps describe)
-            hipLaunchKernelGGL((k_huffman_encode<true, 1>), gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
+            if (a.plane) hipLaunchKernelGGL((k_huffman_encode<true, 1, true>), gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
+            else hipLaunchKernelGGL((k_huffman_encode<true, 1>), gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
             hipLaunchKernelGGL(k_huffman_trees, gf_tile_grid(a.nTiles), dim3(64), 0, stream, a);
         } else
 #endif

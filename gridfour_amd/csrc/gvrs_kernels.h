@@ -91,6 +91,11 @@ struct GfEncodeArgs {
                                // the caller takes the batch path for it
     uint32_t *encStats;        // non-null (CodecHuffman batches): the encoder runs as k_huffman_encode (histograms only) +
                                // k_huffman_trees (one wave per tile); GF_ENC_STAT_WORDS words per tile between them
+    uint8_t *plane;            // non-null (CodecHuffman batches with encStats, round 6): phase A leaves every cell's RAW ROW DIFFERENCE
+                               // as one byte -- v - W, column 0: v - N, the seed cell 0 -- at plane + t * planeStride + cell, and marks
+                               // the tile (word 8 of its statistics record) when every one of them is that byte exactly; the packer
+                               // then derives the winner's residuals from the plane (1 byte per cell) instead of reading the tile again
+    size_t planeStride;        // bytes per tile: the cells rounded up to a multiple of 16
 };
 constexpr int GF_ENC_STAT_WORDS = 16 + 3 * 256;   // models, seed, longest value per predictor, a "has work" mark; the three histograms
 #define GF_K_LEAN_RETRY 0x7fff0002              /* (= GF_K_RETRY of the kernels: the fast kernels' own mark travels the same way) */
