@@ -162,7 +162,7 @@ __device__ void cpack_flat(const uint32_t *__restrict__ tile, uint32_t nC, uint3
         uint32_t myBits = 0, wide = 0;
         if (i0 < cellEnd) {
             Cells8 Q;
-            load_cells8(tile, nC, nCells, i0, Q);
+            load_cells8_wave(tile, nC, nCells, i0, Q);
             uint32_t c = c0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
@@ -229,7 +229,7 @@ __device__ bool cpack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC,
         uint32_t myBits = 0, wide = 0;
         if (i0 < segEnd) {
             Cells8 Q;
-            load_cells8(tile, nC, nCells, i0, Q);
+            load_cells8_wave(tile, nC, nCells, i0, Q);
             uint32_t c = c0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
             const uint32_t cStep = STEP_CELLS % nC;
             for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
                 Cells8 Q;
-                load_cells8(tile, nC, nCells, i0, Q);
+                load_cells8_wave(tile, nC, nCells, i0, Q);
                 uint32_t c = c0;
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {

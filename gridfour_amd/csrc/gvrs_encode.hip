@@ -27,6 +27,7 @@
 // bandwidth.
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -282,9 +283,7 @@ __device__ PackState pack_generic(int model, const uint32_t *__restrict__ tile, 
 // one element per thread and chunk, INLINED: as a call into pack_generic it cost every tile the callee's register saves --
 // twelve VGPRs per lane stored to and reloaded from scratch, a third of a gigabyte per launch on the bench batch.
 // Requires 256 * elemMaxBits <= window bits (implied by the kernels' `fast` condition).
-// PLANE (round 6): `tile` is the tile's byte plane of raw row differences (GfEncodeArgs::plane) and every value of the stream one plain
-// byte: the heads of the Linear and the Triangle stream -- first row, first column(s) -- are plane bytes as they stand.
-template <int MODEL, bool PLANE = false>
+template <int MODEL>
 __device__ __forceinline__ PackState pack_head(const uint32_t *__restrict__ tile, uint32_t nR, uint32_t nC, uint32_t seed,
                                                const uint64_t *tab, uint32_t sEnd, uint32_t *win, uint32_t *__restrict__ out32,
                                                uint32_t *waveSum, PackState ps)
@@ -296,16 +295,10 @@ __device__ __forceinline__ PackState pack_head(const uint32_t *__restrict__ tile
         int n = 0;
         if (s < sEnd) {
             const uint32_t idx = gf_stream_cell(MODEL, nR, nC, s);
-            if constexpr (PLANE) {
-                x = (uint32_t)reinterpret_cast<const uint8_t *>(tile)[idx];
-                n = 1;
-                myBits = (uint32_t)(tab[x] >> 56);
-            } else {
             const uint32_t r = idx / nC, c = idx - r * nC;
             x = cell_residual(MODEL, tile, nC, idx, r, c, seed);
             n = gf_m32_len(x);
             for (int k = 0; k < n; k++) myBits += (uint32_t)(tab[gf_m32_byte(x, n, k)] >> 56);
-            }
         }
         uint32_t total;
         const uint32_t excl = block_excl_scan(myBits, waveSum, &total);
@@ -344,7 +337,7 @@ __device__ PackState pack_flat(const uint32_t *__restrict__ tile, uint32_t nC, u
         uint32_t myBits = 0, multi = 0;
         if (i0 < cellEnd) {
             Cells8 Q;
-            load_cells8(tile, nC, nCells, i0, Q);
+            load_cells8_wave(tile, nC, nCells, i0, Q);
             uint32_t c = c0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
@@ -466,7 +459,7 @@ __device__ __forceinline__ void plane_residual_bytes(const PlaneWords &w, uint32
     }
 }
 
-template <int MODEL, bool PLAIN, bool PLANE = false>
+template <int MODEL, bool PLAIN>
 __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                        const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                        PackState ps, uint32_t slotWords, uint32_t cellBegin, uint32_t cellEnd)
@@ -485,12 +478,6 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
     bool fits = true;
     uint32_t c0 = (segBegin + lane * CPT) % nC;
     const uint32_t cStep = (64u * CPT) % nC;
-    // PLANE: the words of a turn are asked for a turn ahead (an address behind the wave's share is bent back into the tile: the words
-    // are not used).  The packer's turn is a chain -- plane words, code table, scan, window -- and with the tile's nineteen
-    // registers per lane in place of these five there was no room to keep the next link's loads in flight.
-    [[maybe_unused]] PlaneWords ahead;
-    [[maybe_unused]] const uint32_t lastI0 = (nCells - 1u) & ~(uint32_t)(CPT - 1);
-    if constexpr (PLANE) ahead = plane_load<MODEL>(reinterpret_cast<const uint8_t *>(tile), nC, min(segBegin + lane * CPT, lastI0));
     for (uint32_t base = segBegin; base < segEnd; base += 64u * CPT) {
         const uint32_t i0 = base + lane * CPT;
         // PLAIN (round 4): the record says that every value of the stream is one plain M32 byte (k_huffman_encode looked at the
@@ -499,51 +486,9 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
         uint64_t cl[CPT];
         uint32_t xs[PLAIN ? 1 : CPT];
         uint32_t myBits = 0, multi = 0, hard = 0;
-        if constexpr (PLANE) {
-            static_assert(PLAIN && MODEL >= 1 && MODEL <= 3, "the byte plane serves plain streams of the three predictors");
-            const PlaneWords now = ahead;
-            ahead = plane_load<MODEL>(reinterpret_cast<const uint8_t *>(tile), nC, min(i0 + 64u * CPT, lastI0));
-            if (i0 < segEnd) {
-                uint32_t rb[2];
-                plane_residual_bytes<MODEL>(now, nC, i0, rb);
-                // which of the eight cells the flat scan emits, as a bit mask (nC >= 8: at most one of them starts a row): not the
-                // cells behind the tile; Differencing: not the seed; Linear: not the first two cells of a row; Triangle: not the first
-                // row, not the first cell of a row.  A cell that is not emitted gets the byte 0x80, which no plain stream holds and
-                // whose table entry the packer has emptied: eight table reads without a condition.
-                uint32_t em = 0xffu;
-                const uint32_t left = nCells - i0;
-                if (left < (uint32_t)CPT) em = (1u << left) - 1u;
-                const uint32_t kz = c0 == 0u ? 0u : min(nC - c0, 16u);          // the place of the cell that starts a row (>= 8: none)
-                if constexpr (MODEL == 1) {
-                    if (i0 == 0u) em &= ~1u;
-                } else if constexpr (MODEL == 2) {
-                    em &= ~(3u << kz);
-                    if (c0 == 1u) em &= ~1u;
-                } else {
-                    em &= ~(1u << kz);
-                    if (i0 < nC) em &= ~((1u << min((uint32_t)CPT, nC - i0)) - 1u);
-                }
-                {
-                    const uint32_t y0 = __umul24(em & 15u, 0x00204081u) & 0x01010101u, y1 = __umul24((em >> 4) & 15u, 0x00204081u) & 0x01010101u;
-                    constexpr uint32_t H = 0x80808080u;
-                    const uint32_t m0 = (H - y0) ^ H, m1 = (H - y1) ^ H;       // a byte of ones per emitted cell (no borrow crosses a byte)
-                    rb[0] = (rb[0] & m0) | (0x80808080u & ~m0);
-                    rb[1] = (rb[1] & m1) | (0x80808080u & ~m1);
-                }
-#pragma unroll
-                for (int j = 0; j < CPT; j++) {
-                    const uint64_t e = tab[(rb[j >> 2] >> (8 * (j & 3))) & 0xffu];
-                    cl[j] = e;
-                    myBits += (uint32_t)(e >> 56);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < CPT; j++) cl[j] = 0;
-            }
-        } else
         if (i0 < segEnd) {
             Cells8 Q;
-            load_cells8(tile, nC, nCells, i0, Q);
+            load_cells8_wave(tile, nC, nCells, i0, Q);
             uint32_t c = c0;
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
@@ -663,6 +608,171 @@ __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32
     return r;
 }
 
+// Eight (code, length) pairs of one-byte values at bit `pos` of a wave's window: the register join, the join in pairs, the bit sink
+// (see pack_flat_waves).
+__device__ __forceinline__ void emit8_codes(uint32_t *wwin, uint32_t pos, const uint64_t (&cl)[CPT], uint32_t myBits)
+{
+#define GF_LN(j) ((uint32_t)(cl[j] >> 56))
+#define GF_CD(j) ((uint32_t)cl[j])
+    const uint32_t n01 = GF_LN(0) + GF_LN(1), n45 = GF_LN(4) + GF_LN(5);
+    const uint32_t n23 = GF_LN(2) + GF_LN(3), n67 = GF_LN(6) + GF_LN(7);
+    const uint32_t n0 = n01 + n23, n1 = n45 + n67;
+    if (n0 <= 32u && n1 <= 32u) {
+        GF_JOIN8_OR(wwin, pos, GF_CD, GF_LN, n01, n45, n0);
+#undef GF_LN
+#undef GF_CD
+    } else if (max(max(n01, n23), max(n45, n67)) <= 64u) {
+#pragma unroll
+        for (int q = 0; q < CPT; q += 2) {
+            const uint32_t la = (uint32_t)(cl[q] >> 56), lb = (uint32_t)(cl[q + 1] >> 56);
+            const uint64_t ca = cl[q] & 0x00ffffffffffffffull, cb = cl[q + 1] & 0x00ffffffffffffffull;
+            GF_JOIN2_OR64(wwin, pos, ca, la, cb, lb);
+            pos += la + lb;
+        }
+    } else if (myBits) {
+        BitSink sink;
+        sink.init(wwin, pos);
+#pragma unroll
+        for (int j = 0; j < CPT; j++) sink.put(cl[j] & 0x00ffffffffffffffull, (uint32_t)(cl[j] >> 56));
+        sink.finish();
+    }
+}
+
+// (round 6) pack_flat_waves for a PLAIN stream from the tile's byte plane of raw row differences (GfEncodeArgs::plane) -- cells
+// [cellBegin, cellEnd) through the wave-private windows -- and, in front of the tile's first range (headElems != 0), the head of a
+// Linear or Triangle stream: first row, first column(s), which are plane bytes as they stand (PredictorModelLinear.java:113-126,
+// PredictorModelTriangle.java:114-127).  Wave 0 takes the head as turns of its own in front of its share of the cells, eight
+// elements per lane like any turn: no pass of the workgroup over the head, no barriers, no flush for it.  A tile's time in the packer
+// was five round trips to memory one behind the other (status; record; two chunks of the head; the first turn's cells) around nine
+// turns of work; here the head's bytes and the first turn's words are asked for together, before the windows are cleared, and every
+// later turn's words a turn ahead (five registers per lane; the tile's nineteen left no room for that).
+template <int MODEL>
+__device__ __forceinline__ uint32_t plane_head_cell(uint32_t s, uint32_t nC)
+{
+    if constexpr (MODEL == 2) {
+        const uint32_t t = s - 1u;
+        return s == 0u ? 1u : (1u + (t >> 1)) * nC + (t & 1u);
+    } else {
+        const uint32_t t = s - (nC - 1u);
+        return s < nC - 1u ? s + 1u : (t + 1u) * nC;
+    }
+}
+template <int MODEL>
+__device__ __forceinline__ void plane_head_bytes(const uint8_t *__restrict__ p, uint32_t nC, uint32_t s0, uint32_t headElems, uint32_t (&hb)[2])
+{
+    uint32_t b[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+        const uint32_t s = s0 + (uint32_t)j;
+        const uint32_t v = p[s < headElems ? plane_head_cell<MODEL>(s, nC) : 0u];
+        b[j] = s < headElems ? v : 0x80u;                                 // (0x80: the byte whose table entry is empty)
+    }
+    hb[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    hb[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+}
+
+template <int MODEL>
+__device__ PackStateOk pack_plane_waves(const uint8_t *__restrict__ plane, uint32_t nC, uint32_t nCells, const uint64_t *tab, uint32_t *win,
+                                        uint32_t *__restrict__ out32, uint32_t *waveSum, PackState ps, uint32_t slotWords,
+                                        uint32_t cellBegin, uint32_t cellEnd, uint32_t headElems)
+{
+    static_assert(MODEL >= 1 && MODEL <= 3, "the byte plane serves the three predictors");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = GF_UNI(tid >> 6);
+    cellEnd = min(cellEnd, nCells);
+    const uint32_t quarter = (((cellEnd - cellBegin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
+    const uint32_t segBegin = min(cellEnd, cellBegin + wave * quarter), segEnd = min(cellEnd, segBegin + quarter);
+    const uint32_t lastI0 = (nCells - 1u) & ~(uint32_t)(CPT - 1);
+    // what memory has to give first: the first turn's words and, on wave 0, the head's bytes
+    PlaneWords ahead = plane_load<MODEL>(plane, nC, min(segBegin + lane * CPT, lastI0));
+    const bool withHead = MODEL != 1 && headElems != 0u && wave == 0u;     // (wave-uniform)
+    uint32_t hb[2] = {0x80808080u, 0x80808080u};
+    if constexpr (MODEL != 1) {
+        if (withHead) plane_head_bytes<MODEL>(plane, nC, lane * CPT, headElems, hb);
+    }
+    const uint32_t carryWord = wave_windows_begin(win, waveSum);
+    uint32_t *wwin = win + wave * WAVE_WIN;
+    const uint32_t capBits = WAVE_WIN_BITS;
+    uint32_t bits = 0;
+    bool fits = true;
+    if constexpr (MODEL != 1) {
+        if (withHead) {
+            for (uint32_t h = 0; h < headElems; h += 64u * CPT) {       // (one turn up to 512 elements: tiles of up to 256 rows)
+                if (h) plane_head_bytes<MODEL>(plane, nC, h + lane * CPT, headElems, hb);
+                uint64_t cl[CPT];
+                uint32_t myBits = 0;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint64_t e = tab[(hb[j >> 2] >> (8 * (j & 3))) & 0xffu];
+                    cl[j] = e;
+                    myBits += (uint32_t)(e >> 56);
+                }
+                const uint32_t incl = gf_wave_incl_scan(myBits);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (bits + total > capBits) { fits = false; break; }     // wave-uniform
+                emit8_codes(wwin, bits + incl - myBits, cl, myBits);
+                bits += total;
+            }
+        }
+    }
+    uint32_t c0 = (segBegin + lane * CPT) % nC;
+    const uint32_t cStep = (64u * CPT) % nC;
+    for (uint32_t base = segBegin; base < segEnd && fits; base += 64u * CPT) {
+        const uint32_t i0 = base + lane * CPT;
+        uint64_t cl[CPT];
+        uint32_t myBits = 0;
+        const PlaneWords now = ahead;
+        ahead = plane_load<MODEL>(plane, nC, min(i0 + 64u * CPT, lastI0));
+        if (i0 < segEnd) {
+            uint32_t rb[2];
+            plane_residual_bytes<MODEL>(now, nC, i0, rb);
+            // which of the eight cells the flat scan emits, as a bit mask (nC >= 8: at most one of them starts a row): not the
+            // cells behind the tile; Differencing: not the seed; Linear: not the first two cells of a row; Triangle: not the first
+            // row, not the first cell of a row.  A cell that is not emitted gets the byte 0x80, which no plain stream holds and
+            // whose table entry the packer has emptied: eight table reads without a condition.
+            uint32_t em = 0xffu;
+            const uint32_t left = nCells - i0;
+            if (left < (uint32_t)CPT) em = (1u << left) - 1u;
+            const uint32_t kz = c0 == 0u ? 0u : min(nC - c0, 16u);              // the place of the cell that starts a row (>= 8: none)
+            if constexpr (MODEL == 1) {
+                if (i0 == 0u) em &= ~1u;
+            } else if constexpr (MODEL == 2) {
+                em &= ~(3u << kz);
+                if (c0 == 1u) em &= ~1u;
+            } else {
+                em &= ~(1u << kz);
+                if (i0 < nC) em &= ~((1u << min((uint32_t)CPT, nC - i0)) - 1u);
+            }
+            {
+                const uint32_t y0 = __umul24(em & 15u, 0x00204081u) & 0x01010101u, y1 = __umul24((em >> 4) & 15u, 0x00204081u) & 0x01010101u;
+                constexpr uint32_t H = 0x80808080u;
+                const uint32_t m0 = (H - y0) ^ H, m1 = (H - y1) ^ H;           // a byte of ones per emitted cell (no borrow crosses a byte)
+                rb[0] = (rb[0] & m0) | (0x80808080u & ~m0);
+                rb[1] = (rb[1] & m1) | (0x80808080u & ~m1);
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const uint64_t e = tab[(rb[j >> 2] >> (8 * (j & 3))) & 0xffu];
+                cl[j] = e;
+                myBits += (uint32_t)(e >> 56);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) cl[j] = 0;
+        }
+        c0 += cStep;
+        if (c0 >= nC) c0 -= nC;
+        const uint32_t incl = gf_wave_incl_scan(myBits);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (bits + total > capBits) { fits = false; break; }             // wave-uniform
+        emit8_codes(wwin, bits + incl - myBits, cl, myBits);
+        bits += total;
+    }
+    PackStateOk r;
+    r.ok = wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
+    r.ps = ps;
+    return r;
+}
+
 // Two kernels per batch: k_huffman_encode (phases A and B and the selection) and k_huffman_pack (phase C).  Fused into
 // one kernel the phases shared one register budget (96 VGPRs at five workgroups per CU, 428 bytes of scratch per lane,
 // the calls into the packers saving and restoring two dozen registers); apart, they run at six workgroups per CU
@@ -747,14 +857,13 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
             uint32_t *const h0 = &S.histR[0][rep], *const h1 = &S.histR[1][rep], *const h2 = &S.histR[2][rep];
             uint32_t c0 = ((uint32_t)tid * CPT) % nC;
             const uint32_t cStep = STEP_CELLS % nC;
-#ifdef GF_PLANE_STORE_LATE
-            GfU2 pend;
-            pend.x = pend.y = 0;
-            uint32_t pendI0 = 0xFFFFFFFFu;
-#endif
             for (uint32_t i0 = (uint32_t)tid * CPT; i0 < nCells; i0 += STEP_CELLS) {
                 Cells8 Q;
+#ifdef GF_ENC_HALO_LOADS                                                 // (experiment builds: the halo words as three loads per lane)
                 load_cells8(tile, nC, nCells, i0, Q);
+#else
+                load_cells8_wave(tile, nC, nCells, i0, Q);
+#endif
                 uint32_t c = c0;
                 // a tile with a null cell takes the nulls predictor alone, with a histogram of its own (below): once a lane of the wave
                 // has seen one, the three histograms of this pass are not needed any more -- only the scan for valid cells goes on
@@ -849,18 +958,7 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                     GfU2 w;
                     w.x = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
                     w.y = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
-#if defined(GF_PLANE_STORE_OFF)                                      // (experiment builds, tools/ab.sh: where does the store's time go?)
-                    asm volatile("" ::"v"(w.x), "v"(w.y));
-#elif defined(GF_PLANE_STORE_LATE)
-                    if (pendI0 != 0xFFFFFFFFu) *reinterpret_cast<GfU2 *>(a.plane + t * a.planeStride + pendI0) = pend;
-                    pend = w;
-                    pendI0 = i0;
-#elif defined(GF_PLANE_STORE_NT)
-                    __builtin_nontemporal_store(w.x, reinterpret_cast<uint32_t *>(a.plane + t * a.planeStride + i0));
-                    __builtin_nontemporal_store(w.y, reinterpret_cast<uint32_t *>(a.plane + t * a.planeStride + i0) + 1);
-#else
                     *reinterpret_cast<GfU2 *>(a.plane + t * a.planeStride + i0) = w;
-#endif
                 }
                 if (__all(widest <= 252u && lowest != (int32_t)0x80000000)) {
                     myFlags |= 2u;
@@ -913,11 +1011,6 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                 c0 += cStep;
                 if (c0 >= nC) c0 -= nC;
             }
-#ifdef GF_PLANE_STORE_LATE
-            if constexpr (PLANE) {
-                if (pendI0 != 0xFFFFFFFFu) *reinterpret_cast<GfU2 *>(a.plane + t * a.planeStride + pendI0) = pend;
-            }
-#endif
         }
         if (myFlags) atomicOr(&P.flags, myFlags);
         if (maxN1 > 1) atomicMax(&P.maxN[0], maxN1);
@@ -1567,7 +1660,7 @@ __global__ __launch_bounds__(64) void k_huffman_trees(GfEncodeArgs a)
 // the flat scan of a tile through the wave-private windows, in as many cell ranges as its bit count asks for (a wave's
 // share of a range must fit its quarter of the window); false: a range did not fit after all -- the tile is left to
 // k_huffman_pack_rare, which packs it again from its first bit
-template <int MODEL, bool PLAIN, bool PLANE = false>
+template <int MODEL, bool PLAIN>
 __device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                                  const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
                                                  PackState &ps, uint32_t slotWords, uint32_t textBits)
@@ -1581,7 +1674,31 @@ __device__ __forceinline__ bool pack_flat_ranges(const uint32_t *__restrict__ ti
     // range as a whole would fit: nothing was written then, and the range is packed again in two halves (round 4; such tiles -- most
     // of a rough surface's -- used to go to k_huffman_pack_rare, 0.2 ms per launch of the rough batch).
     for (uint32_t b = 0; b < nCells;) {
-        const PackStateOk r = pack_flat_waves<MODEL, PLAIN, PLANE>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
+        const PackStateOk r = pack_flat_waves<MODEL, PLAIN>(tile, nC, nCells, seed, tab, win, out32, waveSum, ps, slotWords, b, b + per);
+        if (r.ok) {
+            ps = r.ps;
+            b += per;
+        } else {
+            if (per <= 8u * UNIT) return false;
+            per = (per / 2u + UNIT - 1u) / UNIT * UNIT;
+        }
+    }
+    return true;
+}
+
+// ... and the same for a plain stream from the byte plane: the head of the stream rides in front of the first range
+template <int MODEL>
+__device__ __forceinline__ bool pack_plane_ranges(const uint8_t *__restrict__ plane, uint32_t nC, uint32_t nCells, const uint64_t *tab, uint32_t *win,
+                                                  uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps, uint32_t slotWords,
+                                                  uint32_t textBits, uint32_t headElems)
+{
+    const uint32_t capBits = WAVE_WIN_BITS;
+    const uint64_t want = ((uint64_t)textBits + (textBits >> 2)) / ENC_WAVES;           // a wave's share, with 25 % slack
+    const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / capBits + 1u);
+    constexpr uint32_t UNIT = CPT * ENC_WAVES;
+    uint32_t per = (((nCells + nRanges - 1) / nRanges) + UNIT - 1) / UNIT * UNIT;
+    for (uint32_t b = 0; b < nCells;) {
+        const PackStateOk r = pack_plane_waves<MODEL>(plane, nC, nCells, tab, win, out32, waveSum, ps, slotWords, b, b + per, b == 0u ? headElems : 0u);
         if (r.ok) {
             ps = r.ps;
             b += per;
@@ -1609,23 +1726,45 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
     const int tid = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     GF_FOR_TILES(t, a.nTiles, !RARE) {                                    // the packer: no tile loop (see gvrs_kernels.h)
-        if (a.status[t] != GF_K_OK) continue;                             // declined, overflow: nothing to write
+        // (round 6) everything the tile's record holds is asked for at once, the tile's status with it: as `status, then the record's
+        // scalars, then as many words of the tree image as they say` these were three round trips to memory one behind the other --
+        // 13 K of a tile's 58 K cycles in the packer (tools/phase_cycles_pack.py)
         uint32_t *rec = a.packRecs + t * (size_t)GF_PACK_REC_WORDS;
-        if (RARE && rec[6] != 1u) continue;                               // (the same word in every thread)
+        constexpr int IMG_PER = (GF_IMG_WORDS + ENC_THREADS - 1) / ENC_THREADS, TAB_PER = (512 + ENC_THREADS - 1) / ENC_THREADS;
+        const int32_t tileStatus = a.status[t];
+        uint32_t rv[8], imgv[IMG_PER], tabv[TAB_PER];
+#pragma unroll
+        for (int k = 0; k < 8; k++) rv[k] = rec[k];
+#pragma unroll
+        for (int k = 0; k < IMG_PER; k++) imgv[k] = rec[8 + min(tid + k * ENC_THREADS, GF_IMG_WORDS - 1)];
+#pragma unroll
+        for (int k = 0; k < TAB_PER; k++) tabv[k] = rec[8 + 88 + min(tid + k * ENC_THREADS, 511)];
+        if (tileStatus != GF_K_OK) continue;                              // declined, overflow: nothing to write
+        if (RARE && rv[6] != 1u) continue;                                // (the same word in every thread)
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
         if (!RARE) GF_STAMP(6);
-        const int model = (int)rec[0];
-        const uint32_t treeEnd = rec[1], seed = rec[2], maxN = rec[3], maxLen = rec[4], textBits = rec[5];
+        const int model = (int)rv[0];
+        const uint32_t treeEnd = rv[1], seed = rv[2], maxN = rv[3], maxLen = rv[4], textBits = rv[5], recFlags = rv[7];
         const uint32_t imgWords = (treeEnd + 31u) >> 5;
-        for (int i = tid; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) win[i] = i < (int)imgWords ? rec[8 + i] : 0u;
+        for (int i = tid + IMG_PER * ENC_THREADS; i < WIN_WORDS + WIN_SLACK; i += ENC_THREADS) win[i] = 0u;
+#pragma unroll
+        for (int k = 0; k < IMG_PER; k++) {
+            const int i = tid + k * ENC_THREADS;
+            win[i] = i < (int)imgWords ? imgv[k] : 0u;                    // (IMG_PER * ENC_THREADS <= WIN_WORDS)
+        }
         {
-            // (0x80 is no symbol of a plain stream -- rec[7] bit 0 --: the plane path gives that byte to the cells it does not emit)
+            // (0x80 is no symbol of a plain stream -- bit 0 of the record's flags --: the plane path gives that byte to the cells it does not emit)
             uint32_t *tw = reinterpret_cast<uint32_t *>(P.tab);
-            const bool emptyNull = !RARE && (rec[7] & 3u) == 3u;
-            for (int i = tid; i < 512; i += ENC_THREADS) tw[i] = (emptyNull && (i >> 1) == 0x80) ? 0u : rec[8 + 88 + i];
+            const bool emptyNull = !RARE && (recFlags & 3u) == 3u;
+#pragma unroll
+            for (int k = 0; k < TAB_PER; k++) {
+                const int i = tid + k * ENC_THREADS;
+                if (i < 512) tw[i] = (emptyNull && (i >> 1) == 0x80) ? 0u : tabv[k];
+            }
         }
         __syncthreads();
+        if (!RARE) GF_STAMP(8);
 
         const uint32_t nStream = gf_stream_len(model, nR, nC);
         const uint64_t *tab = P.tab;
@@ -1635,6 +1774,7 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
         ps.bitBase = treeEnd;
         ps.wordBase = 0;
         window_flush(win, out32, ps);            // header + tree image
+        if (!RARE) GF_STAMP(9);
         bool done = true;
         if (nStream > 0 && maxLen > 0) {
             const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
@@ -1653,21 +1793,16 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
                     ps = pack_flat<4>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps);
                 }
             } else {
-                const bool plain = (rec[7] & 1u) != 0u && model != 4;         // (the same word in every thread)
+                const bool plain = (recFlags & 1u) != 0u && model != 4;       // (the same word in every thread)
                 // (round 6) a plain stream of a tile whose byte plane phase A has left: the plane instead of the tile -- a byte per cell
-                const uint32_t *__restrict__ plane = reinterpret_cast<const uint32_t *>(a.plane + t * a.planeStride);
                 if (!fast) {
                     done = false;
-                } else if (plain && a.plane && (rec[7] & 2u) && nC >= (uint32_t)CPT) {
-                    if (model == 1) {
-                        done = pack_flat_ranges<1, true, true>(plane, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
-                    } else if (model == 2) {
-                        ps = pack_head<2, true>(plane, nR, nC, seed, tab, 2u * nR - 1u, win, out32, P.waveSum, ps);
-                        done = pack_flat_ranges<2, true, true>(plane, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
-                    } else {
-                        ps = pack_head<3, true>(plane, nR, nC, seed, tab, nC - 1u + nR - 1u, win, out32, P.waveSum, ps);
-                        done = pack_flat_ranges<3, true, true>(plane, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
-                    }
+                } else if (plain && a.plane && (recFlags & 2u) && nC >= (uint32_t)CPT) {
+                    const uint8_t *__restrict__ plane = a.plane + t * a.planeStride;
+                    if (model == 1) done = pack_plane_ranges<1>(plane, nC, nCells, tab, win, out32, P.waveSum, ps, slotWords, textBits, 0u);
+                    else if (model == 2) done = pack_plane_ranges<2>(plane, nC, nCells, tab, win, out32, P.waveSum, ps, slotWords, textBits, 2u * nR - 1u);
+                    else done = pack_plane_ranges<3>(plane, nC, nCells, tab, win, out32, P.waveSum, ps, slotWords, textBits, nC - 1u + nR - 1u);
+                    GF_STAMP(10);
                 } else if (model == 1) {
                     done = plain ? pack_flat_ranges<1, true>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits)
                                  : pack_flat_ranges<1, false>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, slotWords, textBits);
@@ -1918,14 +2053,17 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     if (a.retryFlag && 6ull * nCells < (1ull << 23)) {
-#ifndef GF_DIAG
+#ifdef GF_DIAG
+        static const bool diagSplit = getenv("GF_DIAG_SPLIT") != nullptr;      // the three-kernel form with the packer's stamps (tools/phase_cycles_pack.py)
+        if (diagSplit && a.encStats && !a.lean) {
+#else
         if (a.encStats && !a.lean) {
+#endif
             // the histograms, then the trees with a wave per tile (the diagnostic flavour keeps the one-kernel form its stamps describe)
             if (a.plane) hipLaunchKernelGGL((k_huffman_encode<true, 1, true>), gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
             else hipLaunchKernelGGL((k_huffman_encode<true, 1>), gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
             hipLaunchKernelGGL(k_huffman_trees, gf_tile_grid(a.nTiles), dim3(64), 0, stream, a);
         } else
-#endif
         hipLaunchKernelGGL(k_huffman_encode<true>, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
 #ifdef GF_ENC_NULLS_RETRY
         // (only this experiment build's fast kernel leaves tiles behind: the shipping one takes every tile of up to 2^23 / 6 cells, and

@@ -102,6 +102,37 @@ __device__ __forceinline__ void load_cells8(const uint32_t *__restrict__ tile, u
     Q.upm1 = upm1;
 }
 
+// The same for a WAVE whose lanes hold consecutive blocks of eight cells (lane l: i0 = i0 of lane 0 + 8 l -- the flat scans).
+// Round 6: the three words in front of a block (W, WW and NW of its first cell) are the last words of the block of the lane before:
+// a DPP move each (wave_shr:1); lane 0 alone loads its three.  As three dword loads per lane -- 64 addresses 32 bytes apart, sixteen
+// cache lines per instruction -- they cost the memory pipeline more than the four 16-byte loads of the block itself
+// (tools/bw_probe.hip: 0.208 -> 0.167 ms for phase A's loads over the bench batch; k_huffman_encode<true, 1> 0.323 -> 0.289 ms).
+// (Lane 0's words through the scalar cache instead: the wait for them is a wait for every LDS operation in flight as well -- one
+// counter --, which cost the rough batch's phase A, whose turns queue more histogram additions, 0.027 ms.)
+__device__ __forceinline__ void load_cells8_wave(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t i0, Cells8 &Q)
+{
+    const bool interior = i0 >= nC + 2 && i0 + (CPT - 1) < nCells;
+    if (__all(interior)) {
+        const GfU4 a = *reinterpret_cast<const GfU4 *>(tile + i0);
+        const GfU4 b = *reinterpret_cast<const GfU4 *>(tile + i0 + 4);
+        const GfU4 c = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC));
+        const GfU4 d = *reinterpret_cast<const GfU4 *>(tile + (i0 - nC) + 4);
+        uint32_t s1 = 0, s2 = 0, s3 = 0;
+        if ((threadIdx.x & 63u) == 0u) {
+            s1 = tile[i0 - 1];
+            s2 = tile[i0 - 2];
+            s3 = tile[i0 - nC - 1];
+        }
+        Q.cur[0] = a.x; Q.cur[1] = a.y; Q.cur[2] = a.z; Q.cur[3] = a.w; Q.cur[4] = b.x; Q.cur[5] = b.y; Q.cur[6] = b.z; Q.cur[7] = b.w;
+        Q.up[0] = c.x; Q.up[1] = c.y; Q.up[2] = c.z; Q.up[3] = c.w; Q.up[4] = d.x; Q.up[5] = d.y; Q.up[6] = d.z; Q.up[7] = d.w;
+        Q.wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s1, (int)b.w, 0x138, 0xf, 0xf, false);      // wave_shr:1; lane 0 keeps its own
+        Q.wm2 = (uint32_t)__builtin_amdgcn_update_dpp((int)s2, (int)b.z, 0x138, 0xf, 0xf, false);
+        Q.upm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s3, (int)d.w, 0x138, 0xf, 0xf, false);
+    } else {
+        load_cells8(tile, nC, nCells, i0, Q);
+    }
+}
+
 // Bitonic sort, ascending, of the 64*NREG 32-bit keys held in k[0..NREG) (element e = r*64 + lane).
 template <int NREG, class Arr>
 __device__ __forceinline__ void wave_bitonic_sort(Arr &k, int lane)
