@@ -1006,9 +1006,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enqueued = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    # host time of the enqueue calls alone (launches are asynchronous: nothing in step() waits for the GPU unless a queue fills up).
+    # What one Python thread needs per step to feed every device of the process; to hold against ms_per_step.
+    host_enqueue_ms = (t_enqueued - t0) / args.steps * 1e3
     enc_ms = [np.mean([t.elapsed_ms() for t in tg]) for tg in t_enc]
     dec_ms = [np.mean([t.elapsed_ms() for t in tg]) for tg in t_dec]
     if launcher:
@@ -1121,6 +1125,7 @@ def main():
         "encode_ms": round(enc_avg, 4),
         "decode_ms": round(dec_avg, 4),
         "per_shard_ms": per_shard,
+        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
         "encode_MBps": round(raw_mb / (enc_avg * 1e-3), 1),
         "decode_MBps": round(raw_mb / (dec_avg * 1e-3), 1),
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,

@@ -757,7 +757,7 @@ struct CanonPackShared {
 __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncodeArgs a)
 {
     __shared__ CanonPackShared P;
-    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+    __shared__ __attribute__((aligned(16))) uint32_t win[WIN_WORDS + WIN_SLACK];
 
     const int tid = threadIdx.x;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;

@@ -962,12 +962,35 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 && ENC_THREADS == 256 && GF_
                 }
                 if (__all(widest <= 252u && lowest != (int32_t)0x80000000)) {
                     myFlags |= 2u;
+#ifdef GF_ENC_HIST_AGG
+                    // (experiment build, round 6: the round-5 review's wave-level aggregation of the hot bins -- the value the first lane
+                    // holds is counted once for all the lanes that hold it when they are sixteen or more; measured in profiles/HISTORY.md)
+                    auto addAgg = [&](uint32_t *h, uint32_t d) {
+                        d &= 0xffu;
+                        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                        const unsigned long long m = __ballot(d == d0);
+                        const uint32_t n = (uint32_t)__popcll(m);
+                        if (n >= 16u) {
+                            if (lane == 0) atomicAdd(h + d0 * HR, n);
+                            if (d != d0) atomicAdd(h + d * HR, 1u);
+                        } else {
+                            atomicAdd(h + d * HR, 1u);
+                        }
+                    };
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        addAgg(h0, D1[j]);
+                        addAgg(h1, D2[j]);
+                        if (triOk) addAgg(h2, D3[j]);
+                    }
+#else
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
                         atomicAdd(h0 + (D1[j] & 0xffu) * HR, 1u);
                         atomicAdd(h1 + (D2[j] & 0xffu) * HR, 1u);
                         if (triOk) atomicAdd(h2 + (D3[j] & 0xffu) * HR, 1u);
                     }
+#endif
                 } else {
 #pragma unroll
                     for (int j = 0; j < CPT; j++) {
@@ -1840,7 +1863,7 @@ __device__ __forceinline__ void huffman_pack_tiles(const GfEncodeArgs &a, PackSh
 __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEncodeArgs a)
 {
     __shared__ PackShared P;
-    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+    __shared__ __attribute__((aligned(16))) uint32_t win[WIN_WORDS + WIN_SLACK];
     huffman_pack_tiles<false>(a, P, win);
 }
 
@@ -1848,7 +1871,7 @@ __global__ __launch_bounds__(ENC_THREADS, ENC_PACK_WGS) void k_huffman_pack(GfEn
 __global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_pack_rare(GfEncodeArgs a)
 {
     __shared__ PackShared P;
-    __shared__ uint32_t win[WIN_WORDS + WIN_SLACK];
+    __shared__ __attribute__((aligned(16))) uint32_t win[WIN_WORDS + WIN_SLACK];
     if (a.retryFlag && a.retryFlag[1] == 0u) return;                      // the packer finished every tile
     huffman_pack_tiles<true>(a, P, win);
 }
@@ -1861,7 +1884,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void k_huffman_pack_rare(GfEncodeAr
 // ------------------------------------------------------------------------------------------------
 struct M32Shared {
     uint64_t tab[256];
-    uint32_t win[WIN_WORDS + WIN_SLACK];
+    alignas(16) uint32_t win[WIN_WORDS + WIN_SLACK];
     uint32_t waveSum[ENC_WAVES];
     uint32_t flags, seed, nStart;
     uint32_t nBytes[3];         // exact M32 bytes of the candidates
@@ -2075,6 +2098,8 @@ hipError_t gf_launch_huffman_encode(const GfEncodeArgs &a, hipStream_t stream)
         g.retryFlag = nullptr;
         hipLaunchKernelGGL(k_huffman_encode<false>, dim3(grid), dim3(ENC_THREADS), 0, stream, g);
     }
+    // (round 6: the packer with a wave or two per tile -- a 64- and a 128-thread build of this file, 4 KB of window per wave -- was
+    // measured: 0.192 / 0.176 ms against 0.176 with four waves on the bench batch, 0.42 / 0.36 against 0.32 on 200x200 tiles)
     hipLaunchKernelGGL(k_huffman_pack, gf_tile_grid(a.nTiles), dim3(ENC_THREADS), 0, stream, a);
     if (!a.lean) hipLaunchKernelGGL(k_huffman_pack_rare, dim3(grid < 1024 ? grid : 1024), dim3(ENC_THREADS), 0, stream, a);
     return hipGetLastError();

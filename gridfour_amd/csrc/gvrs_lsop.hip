@@ -970,7 +970,7 @@ struct Pack2Trees {
 union Pack2Union {
     uint32_t histR[2][CN_HIST * HIST_R];
     Pack2Trees b;
-    uint32_t win[WIN_WORDS + WIN_SLACK];
+    alignas(16) uint32_t win[WIN_WORDS + WIN_SLACK];
 };
 
 __device__ __forceinline__ uint32_t p2_elem_max_bits(uint32_t maxLen, uint32_t maxKind)
