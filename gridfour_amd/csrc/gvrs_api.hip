@@ -602,7 +602,7 @@ static gf_status lsopParseLengths(gf_context *c, hipStream_t st, size_t nTiles, 
 {
     if (!c) return GF_ERR_ARG;
     GF_HIP(hipSetDevice(c->device));                        // launches and copies below go to the context's device
-    const size_t need = nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16;
+    const size_t need = 2 * nTiles * (size_t)GF_CANON_REC_WORDS * 4 + 16;     // (both streams' records: k_lsop_head)
     if (c->trees.bytes < need) {
         GF_HIP(hipSetDevice(c->device));                   // not capture-safe: gf_context_reserve sizes this too
         gf_status s = c->trees.ensure(need);
@@ -2071,7 +2071,13 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
     if (s != GF_OK) return s;
     GF_HIP(gf_launch_lsop_unpack2(dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride, dCoefs,
                                   dScratchStatus, nTiles, nRows, nCols, gf_lsop_unpack_lds_text(nRows, nCols), grid, st,
-                                  (const uint32_t *)c->trees.p));
+                                  (const uint32_t *)c->trees.p, g_decodeDebug,
+                                  // (the serial walk of a lane pays where sixty-four tiles share a wave: large batches)
+#ifdef GF_LSOP_NO_HEAD                                      // (experiment builds: tools/ab_kernels.sh)
+                                  nullptr));
+#else
+                                  gf_prepass_tiles_per_wave(nTiles) == 64u ? (uint32_t *)c->trees.p + nTiles * (size_t)GF_CANON_REC_WORDS : nullptr));
+#endif
     s = lsopUnpackM32Deflate(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride,
                              dCoefs, dScratchStatus);
     if (s != GF_OK) return s;

@@ -988,3 +988,147 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     return GF_K_OK;
 #undef CD_STAMP
 }
+
+struct __attribute__((packed, aligned(1))) CdPackedWord { uint32_t v; };     // a word of a packing at any byte address
+
+// The code lengths of one canonical stream by ONE LANE (LengthEncoder.readEncodedLengths :197-236, CanonHuffTreeDecoder.decodeTree
+// :133-177): the serial walk of k_canon_parse_lengths and k_lsop_head.  peek(pos) = 32 bits of the packing from bit pos; sMetaLen /
+// sOrder / sLut: per-lane columns in LDS (CN_META, CN_META and 128 bytes per lane, element k of lane l at [k * 64 + l]); outLen: the
+// record's 261 lengths, zero beforehand -- only non-zero lengths are stored, by `writer` lanes.  st: the lane's status so far (a lane
+// that has failed before takes no part but stays in the wave's loops).  Same checks and statuses as phase 0 of cd_decode_stream.
+template <class Peek>
+__device__ __forceinline__ int32_t cd_lane_parse_lengths(const Peek &peek, int32_t st, uint32_t startBit, uint32_t endBit, uint32_t lane,
+                                                         uint8_t *sMetaLen, uint8_t *sOrder, uint8_t *sLut, uint8_t *outLen, bool writer,
+                                                         uint32_t *posOut, uint32_t *nonZeroOut)
+{
+    uint32_t pos = startBit + 1u;                             // reserved bit, CanonicalHuffman.java:451
+    // LengthEncoder.readEncodedLengths :197-236: the 20 lengths of the meta alphabet
+    for (uint32_t k = 0; k < (uint32_t)CN_META; k++) sMetaLen[k * 64 + lane] = 0;
+    {
+        uint32_t k = 0, prior = 0;
+        while (k < (uint32_t)CN_META && st == GF_K_OK) {
+            if (pos + 12u > endBit + 32u) { st = GF_K_ERR_BOUNDS; break; }
+            const uint32_t w = peek(pos);
+            const uint32_t idx = w & 31u;
+            pos += 5;
+            if (idx <= 15u) {
+                sMetaLen[k * 64 + lane] = (uint8_t)idx;
+                k++;
+                prior = idx;
+            } else if (idx <= 18u) {
+                const uint32_t nb = idx == 16u ? 2u : idx == 17u ? 3u : 7u;
+                const uint32_t n = ((w >> 5) & ((1u << nb) - 1u)) + (idx == 18u ? 11u : 3u);
+                pos += nb;
+                if (idx != 16u) prior = 0;
+                if (k + n > (uint32_t)CN_META) { st = GF_K_ERR_BOUNDS; break; }
+                for (uint32_t j = 0; j < n; j++) sMetaLen[(k + j) * 64 + lane] = (uint8_t)prior;
+                k += n;
+            }
+            if (pos > endBit) st = GF_K_ERR_BOUNDS;
+        }
+    }
+    // canonical tables of the meta code: symbols per length (8-bit counters packed in two words), symbols ordered by
+    // (length, symbol)
+    unsigned long long cntLo = 0, cntHi = 0;
+    auto cnt8 = [&](uint32_t l) -> uint32_t { return (uint32_t)((l < 8 ? cntLo >> (8u * l) : cntHi >> (8u * (l - 8u))) & 0xffu); };
+    uint32_t nUsed = 0;
+    if (st == GF_K_OK) {
+        for (uint32_t k = 0; k < (uint32_t)CN_META; k++) {
+            const uint32_t l = sMetaLen[k * 64 + lane];
+            if (l) {
+                if (l < 8) cntLo += 1ull << (8u * l); else cntHi += 1ull << (8u * (l - 8u));
+                nUsed++;
+            }
+        }
+        if (nUsed == 0) st = GF_K_ERR_BOUNDS;                 // sortNodes[0] of an empty array
+        // (a counting sort: where each length's symbols start, then the symbols in order -- a scan of the twenty per length was 300
+        // turns)
+        if (st == GF_K_OK) {
+            unsigned long long atLo = 0, atHi = 0;            // first slot of length l, 8-bit fields as cntLo / cntHi
+            uint32_t run = 0;
+            for (uint32_t l = 1; l <= 15; l++) {
+                if (l < 8) atLo |= (unsigned long long)run << (8u * l); else atHi |= (unsigned long long)run << (8u * (l - 8u));
+                run += cnt8(l);
+            }
+            for (uint32_t k = 0; k < (uint32_t)CN_META; k++) {
+                const uint32_t l = sMetaLen[k * 64 + lane];
+                if (l) {
+                    const uint32_t slot = (uint32_t)((l < 8 ? atLo >> (8u * l) : atHi >> (8u * (l - 8u))) & 0xffu);
+                    sOrder[slot * 64 + lane] = (uint8_t)k;
+                    if (l < 8) atLo += 1ull << (8u * l); else atHi += 1ull << (8u * (l - 8u));
+                }
+            }
+        }
+    }
+    // The meta code's first-level table (round 4): the next seven bits of the stream -> (length << 5) | symbol for the codes of up to
+    // seven bits, 0 for the longer ones (which take the canonical search below).  A lane's column of 128 bytes; canonical codes in
+    // order of (length, symbol), first bit of a code = first bit of the stream = bit 0 of the index.
+    // (Only for lengths that make a prefix code, Kraft sum <= 1 -- those a CanonicalHuffman encoder writes.  Damaged lengths that
+    // over-subscribe the code space leave the table empty: the search alone decides what such a stream decodes to.)
+    if (st == GF_K_OK) {
+        for (uint32_t x = 0; x < 128u; x++) sLut[x * 64 + lane] = 0;
+        uint32_t kraft = 0;
+        for (uint32_t l = 1; l <= 15; l++) kraft += cnt8(l) << (15u - l);
+        uint32_t code = 0, slot = 0;
+        for (uint32_t l = 1; l <= 7 && kraft <= (1u << 15); l++) {
+            const uint32_t n = cnt8(l);
+            for (uint32_t d = 0; d < n; d++) {
+                const uint32_t sym = sOrder[(slot + d) * 64 + lane];
+                const uint32_t r = __brev(code + d) >> (32u - l);          // the code as the stream holds it
+                const uint8_t e = (uint8_t)((l << 5) | sym);
+                for (uint32_t x = r; x < 128u; x += 1u << l) sLut[x * 64 + lane] = e;
+            }
+            code = (code + n) << 1;
+            slot += n;
+        }
+    }
+    // CanonHuffTreeDecoder.decodeTree :133-177: the 260 (+1) code lengths
+    // (round 4: one turn per token with its kinds -- a length, a run of the prior length, a run of zeros, the end-of-text symbol --
+    // under predicates instead of branches; the lanes of the wave leave the loop together.  Every way out with an error is
+    // GF_K_ERR_BOUNDS, and nothing is stored in the turn that finds one.)
+    uint32_t nonZero = 0;
+    {
+        uint32_t i = 0, prior = 0;
+        bool bad = false;
+        for (;;) {
+            const bool live = st == GF_K_OK && !bad && i < (uint32_t)CN_SYMS;
+            if (!__any(live)) break;
+            const bool atEnd = pos >= endBit;
+            const uint32_t w = peek(pos);
+            const uint32_t e = sLut[(w & 127u) * 64 + lane];
+            uint32_t cl = e >> 5, sym = e & 31u;
+            if (live && !atEnd && e == 0u) {                  // a code of more than seven bits (or none): the canonical search (cd_search)
+                const uint32_t c = __brev(w);
+                uint32_t code = 0, offs = 0;
+                for (uint32_t l = 1; l <= 15; l++) {
+                    const uint32_t n = cnt8(l);
+                    const uint32_t d = (c >> (32u - l)) - code;
+                    if (d < n) { cl = l; sym = sOrder[(offs + d) * 64 + lane]; break; }
+                    code = (code + n) << 1;
+                    offs += n;
+                }
+            }
+            const bool found = live && !atEnd && cl != 0u;    // (cl == 0: the stream walks into a missing node)
+            const bool isLit = sym <= 15u, isRun = sym - 16u < 3u;
+            const uint32_t nb = sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+            const uint32_t n = isRun ? ((w >> cl) & ((1u << nb) - 1u)) + (sym == 18u ? 11u : 3u) : 1u;
+            const bool fits = !isRun || i + n <= (uint32_t)CN_SYMS + 1u;
+            const bool take = found && fits;
+            const uint32_t val = isLit ? sym : (sym == 16u ? prior : 0u);         // symbol 19 (meta end-of-text): no store
+            const uint32_t nStore = (take && val) ? n : 0u;
+            if (nStore && writer) {
+                outLen[i] = (uint8_t)val;
+                for (uint32_t j = 1; j < nStore; j++) outLen[i + j] = (uint8_t)val;
+            }
+            nonZero += nStore;
+            pos += found ? cl + (isRun ? nb : 0u) : 0u;
+            prior = !take ? prior : isLit ? sym : (sym == 17u || sym == 18u) ? 0u : prior;
+            i += take ? n : 0u;
+            bad = bad || (live && (!take || pos > endBit));
+        }
+        if (bad) st = GF_K_ERR_BOUNDS;
+    }
+    *posOut = pos;
+    *nonZeroOut = nonZero;
+    return st;
+}

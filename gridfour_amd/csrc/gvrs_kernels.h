@@ -265,7 +265,11 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
 hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                   const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
                                   int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
-                                  hipStream_t stream, const uint32_t *pre = nullptr);   // pre: records of the first stream's lengths
+                                  hipStream_t stream, const uint32_t *pre = nullptr,    // pre: records of the first stream's lengths
+                                  uint32_t *debug = nullptr,                            // debug: cycle stamps (diagnostic flavour)
+                                  uint32_t *pre2 = nullptr);    // room for k_lsop_head's records of the second stream (as many as pre): the
+                                                                // serial parts of a tile -- its first stream, the second one's code lengths --
+                                                                // then run a lane per tile in front of k_lsop_unpack2
 
 // zlib streams inflated on the GPU, one wave per stream (gvrs_inflate.hip)
 struct GfInflateStream {
