@@ -63,19 +63,22 @@ bool offsetsValid(const uint64_t *offsets, size_t nTiles)
     return true;
 }
 
-// Counts the device buffers that moved (process-wide; a move is rare: buffers only grow).  A recorded hipGraph holds the
-// addresses it was captured with: the one-tile graphs (gf_single) remember the count they were recorded at and are dropped when
-// it has changed -- a batch that grew the context's tree / selection records between two replays used to leave them pointing
-// at freed memory.
+// Counts the device buffers that moved (a move is rare: buffers only grow).  A recorded hipGraph holds the addresses it was
+// captured with: the one-tile graphs (gf_single) remember the count they were recorded at and are dropped when it has changed --
+// a batch that grew the context's tree / selection records between two replays used to leave them pointing at freed memory.
+// Round 6 (advice): a context's buffers count on the CONTEXT's counter (gf_context::bufMoves) -- with one counter for the process
+// another GPU's shard or another thread's batch made every context drop and re-record its graphs; this one is what is left for
+// buffers that belong to no context.
 static std::atomic<uint64_t> g_devBufMoves{0};
 
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    std::atomic<uint64_t> *moves = &g_devBufMoves;
     gf_status ensure(size_t need)
     {
         if (need <= bytes) return GF_OK;
-        g_devBufMoves.fetch_add(1, std::memory_order_relaxed);
+        moves->fetch_add(1, std::memory_order_relaxed);
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         need = roundUp(need + need / 8, 1 << 20);
         GF_HIP(hipMalloc(&p, need));
@@ -85,7 +88,7 @@ struct DevBuf {
     void release()
     {
         if (p) {
-            g_devBufMoves.fetch_add(1, std::memory_order_relaxed);
+            moves->fetch_add(1, std::memory_order_relaxed);
             (void)hipFree(p);
         }
         p = nullptr;
@@ -108,6 +111,13 @@ struct gf_context {
     DevBuf dResiduals, dCoefs, dStatus2;   // LSOP staging
     DevBuf dM32, dM32Len, dM32Models, dSeeds;   // CodecDeflate staging
     DevBuf dInflate, dInflOut, dInflMeta;       // GPU inflate: stream descriptors, inflated bytes, produced / status
+    std::atomic<uint64_t> bufMoves{0};          // moves of THIS context's device buffers (DevBuf::moves): what its recorded graphs watch
+    gf_context()
+    {
+        for (DevBuf *b : {&workspace, &trees, &flags, &packRecs, &dValues, &dSlots, &dBlob, &dLengths, &dPred, &dStatus, &dOffsets, &dPlanes,
+                          &dResiduals, &dCoefs, &dStatus2, &dM32, &dM32Len, &dM32Models, &dSeeds, &dInflate, &dInflOut, &dInflMeta})
+            b->moves = &bufMoves;
+    }
     // Every entry point that takes the context holds this lock for its duration (GF_CTX_LOCK): the reference calls ONE decoder
     // instance from several threads (gvrs/RasterTileCache.java:418-421, TileDecompressionAssistant.java:68-73), and a context's
     // scratch buffers, staging slots and recorded graphs are one set.  Recursive: entry points call each other.
@@ -1605,7 +1615,7 @@ static gf_status decodeBatchHost(int kind, gf_context *c, int nRows, int nCols, 
 // launch and waited for by polling the stream.  The first call of a kind takes the batch path; the second runs the lean sequence
 // once outside a capture (code objects of the 1,024-thread builds, the kernels' LDS attributes: what a capture must not do) and
 // records the graph.  A capture that fails is remembered (the batch path from then on); graphs are recorded again when a device
-// buffer they hold has moved (g_devBufMoves).
+// buffer they hold has moved (gf_context::bufMoves).
 struct gf_single_graph {
     int dir, kind, nRows, nCols, codecIndex;
     size_t copyBytes;
@@ -1617,7 +1627,7 @@ struct gf_single {
     size_t hInBytes = 0, hOutBytes = 0;
     DevBuf dIn;
     std::vector<gf_single_graph> graphs;
-    uint64_t moves = 0;                                          // g_devBufMoves when the graphs were recorded
+    uint64_t moves = 0;                                          // gf_context::bufMoves when the graphs were recorded
     std::vector<std::pair<int, std::pair<int, int>>> warmed;     // (dir * 8 + kind, shape) that ran once through the batch path
     std::vector<std::pair<int, std::pair<int, int>>> refused;    // ... whose capture failed: the batch path from then on
 };
@@ -1630,10 +1640,10 @@ static void singleDropGraphs(gf_single *sg)
     sg->graphs.clear();
 }
 // The graphs hold device addresses of the context's buffers (tree / selection records, flags, workspace, dIn): when any device
-// buffer of the process has moved since they were recorded, they are recorded again.
+// buffer of the context has moved since they were recorded, they are recorded again.
 static gf_status singleCheckMoves(gf_context *c, gf_single *sg)
 {
-    const uint64_t now = g_devBufMoves.load(std::memory_order_relaxed);
+    const uint64_t now = c->bufMoves.load(std::memory_order_relaxed);
     if (sg->moves == now || sg->graphs.empty()) {
         sg->moves = now;
         return GF_OK;
@@ -1661,7 +1671,10 @@ void gf_single_destroy(gf_single *sg)
 }
 static gf_status singleEnsure(gf_context *c, size_t inBytes, size_t outBytes)
 {
-    if (!c->single) c->single = new (std::nothrow) gf_single;
+    if (!c->single) {
+        c->single = new (std::nothrow) gf_single;
+        if (c->single) c->single->dIn.moves = &c->bufMoves;
+    }
     gf_single *sg = c->single;
     if (!sg) return GF_ERR_HIP;
     if (sg->hInBytes < inBytes || sg->hOutBytes < outBytes || sg->dIn.bytes < inBytes) {
@@ -1734,7 +1747,7 @@ static gf_status singleEncode(int kind, gf_context *c, int codecIndex, int nRows
     int32_t *hSt = (int32_t *)(hOut + stride + 4);
     if (!g) {
         if ((s = gf_context_reserve(c, nRows, nCols, 1)) != GF_OK) return s;
-        const uint64_t movesBefore = g_devBufMoves.load(std::memory_order_relaxed);
+        const uint64_t movesBefore = c->bufMoves.load(std::memory_order_relaxed);
         if (movesBefore != sg->moves) {                                       // (the reservation moved a buffer the other graphs hold)
             if ((s = singleCheckMoves(c, sg)) != GF_OK) return s;
         }
@@ -1755,7 +1768,7 @@ static gf_status singleEncode(int kind, gf_context *c, int codecIndex, int nRows
         GF_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         s = sequence();
         const hipError_t e2 = hipStreamEndCapture(c->stream, &ng.graph);
-        const bool moved = g_devBufMoves.load(std::memory_order_relaxed) != movesBefore;   // (a capture must not allocate; if it did, its addresses are void)
+        const bool moved = c->bufMoves.load(std::memory_order_relaxed) != movesBefore;   // (a capture must not allocate; if it did, its addresses are void)
         if (s != GF_OK || e2 != hipSuccess || !ng.graph || moved ||
             hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
             if (ng.graph) (void)hipGraphDestroy(ng.graph);
@@ -1817,7 +1830,7 @@ static gf_status singleDecode(int kind, gf_context *c, int nRows, int nCols, con
     };
     if (!g) {
         if ((s = gf_context_reserve(c, nRows, nCols, 1)) != GF_OK) return s;
-        const uint64_t movesBefore = g_devBufMoves.load(std::memory_order_relaxed);
+        const uint64_t movesBefore = c->bufMoves.load(std::memory_order_relaxed);
         if (movesBefore != sg->moves) {
             if ((s = singleCheckMoves(c, sg)) != GF_OK) return s;
         }
@@ -1837,7 +1850,7 @@ static gf_status singleDecode(int kind, gf_context *c, int nRows, int nCols, con
         GF_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         s = sequence();
         const hipError_t e2 = hipStreamEndCapture(c->stream, &ng.graph);
-        const bool moved = g_devBufMoves.load(std::memory_order_relaxed) != movesBefore;
+        const bool moved = c->bufMoves.load(std::memory_order_relaxed) != movesBefore;
         if (s != GF_OK || e2 != hipSuccess || !ng.graph || moved ||
             hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) {
             if (ng.graph) (void)hipGraphDestroy(ng.graph);
@@ -2004,13 +2017,36 @@ gf_status gf_lsop12_encode_batch_i32_dev(gf_context *c, void *stream, int codecI
                                              dResiduals, resStride, dCoefs, dScratchStatus);
 }
 
-constexpr int GF_LSOP_INTERNAL_INT32_RESIDUALS = 0x100;   // (not in the header: gf_lsop12_encode_batch_i32's Deflate stage reads d_residuals)
+}  // extern "C"
+
+// (round 6, advice) int32Residuals: the caller reads d_residuals itself (gf_lsop12_encode_batch_i32's Deflate stage) -- a parameter of
+// this internal form, no longer an undocumented bit of the public flags word
+static gf_status lsopEncodeBatchDev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                    const int32_t *dValues, int flags, bool int32Residuals, uint8_t *dOut, size_t slotStride,
+                                    uint32_t *dLengths, int32_t *dStatus, int32_t *dResiduals, size_t resStride, uint32_t *dCoefs,
+                                    int32_t *dScratchStatus);
+
+extern "C" {
+
 // ... with LsEncoder12's switches (flags: GF_LSOP_VALUE_CHECKSUM = setValueChecksumEnabled, lsop/LsEncoder12.java:117-119; the
-// Deflate alternative needs the host's zlib and is not a device-resident operation)
+// Deflate alternative needs the host's zlib and is not a device-resident operation: GF_LSOP_DEFLATE is accepted and means nothing
+// here; any other bit is GF_ERR_ARG)
 gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *c, void *stream, int codecIndex, int nRows, int nCols, size_t nTiles,
                                             const int32_t *dValues, int flags, uint8_t *dOut, size_t slotStride, uint32_t *dLengths,
                                             int32_t *dStatus, int32_t *dResiduals, size_t resStride, uint32_t *dCoefs,
                                             int32_t *dScratchStatus)
+{
+    if (flags & ~(GF_LSOP_DEFLATE | GF_LSOP_VALUE_CHECKSUM)) return GF_ERR_ARG;
+    return lsopEncodeBatchDev(c, stream, codecIndex, nRows, nCols, nTiles, dValues, flags, false, dOut, slotStride, dLengths, dStatus,
+                              dResiduals, resStride, dCoefs, dScratchStatus);
+}
+
+}  // extern "C"
+
+static gf_status lsopEncodeBatchDev(gf_context *c, void *stream, int codecIndex, int nRows, int nCols, size_t nTiles,
+                                    const int32_t *dValues, int flags, bool int32Residuals, uint8_t *dOut, size_t slotStride,
+                                    uint32_t *dLengths, int32_t *dStatus, int32_t *dResiduals, size_t resStride, uint32_t *dCoefs,
+                                    int32_t *dScratchStatus)
 {
     GF_CTX_LOCK(c);
     if (!c || !dValues || !dOut || !dLengths || !dStatus || !dResiduals || !dCoefs || !dScratchStatus) return GF_ERR_ARG;
@@ -2026,8 +2062,8 @@ gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *c, void *stream, int cod
     }
     // Terrain-sized tiles (round 5): the first kernel keeps the tile in LDS as halfwords, writes the residuals as int16 and counts
     // the histograms on the way (k_lsop_predict16; records in the context's selection-record buffer, which gf_context_reserve
-    // sizes) -- unless the caller wants the int32 residuals themselves (GF_LSOP_INTERNAL_INT32_RESIDUALS: the host's Deflate stage)
-    const bool fast16 = gf_lsop_predict16_eligible(nRows, nCols) && !(flags & GF_LSOP_INTERNAL_INT32_RESIDUALS) && resStride >= gf_lsop12_residual_count(nRows, nCols);
+    // sizes) -- unless the caller wants the int32 residuals themselves (int32Residuals: the host's Deflate stage)
+    const bool fast16 = gf_lsop_predict16_eligible(nRows, nCols) && !int32Residuals && resStride >= gf_lsop12_residual_count(nRows, nCols);
     uint32_t *hist16 = nullptr;
     gf_status s;
     if (fast16) {
@@ -2050,6 +2086,8 @@ gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *c, void *stream, int cod
                                  n0, n1, codecIndex, st, valueChecksum, hist16));
     return GF_OK;
 }
+
+extern "C" {
 
 gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows, int nCols, size_t nTiles,
                                          const uint8_t *dBlob, size_t blobBytes, const uint64_t *dOffsets, size_t slotStride,
@@ -2118,6 +2156,7 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
 {
     GF_CTX_LOCK(c);
     if (!c || nRows < 1 || nCols < 1 || !values || !offsets || (!blob && blobCap)) return GF_ERR_ARG;
+    if (deflateEnabled & ~(GF_LSOP_DEFLATE | GF_LSOP_VALUE_CHECKSUM)) return GF_ERR_ARG;      // (a bit mask since round 5: see the header)
     GF_HIP(hipSetDevice(c->device));
     if (nRows < 6 || nCols < 6) {
         for (size_t t = 0; t <= nTiles; t++) offsets[t] = 0;
@@ -2137,16 +2176,15 @@ gf_status gf_lsop12_encode_batch_i32(gf_context *c, int codecIndex, int nRows, i
     if ((s = c->dResiduals.ensure(nTiles * resStride * 4 + 16)) != GF_OK) return s;
     if ((s = c->dCoefs.ensure(nTiles * 64 + 16)) != GF_OK) return s;
     GF_HIP(hipMemcpyAsync(c->dValues.p, values, nTiles * cells * 4, hipMemcpyHostToDevice, c->stream));
-    // deflateEnabled carries LsEncoder12's two switches: GF_LSOP_DEFLATE (setDeflateEnabled; any odd value, as before) and
-    // GF_LSOP_VALUE_CHECKSUM (setValueChecksumEnabled)
+    // deflateEnabled carries LsEncoder12's two switches as bits: GF_LSOP_DEFLATE (setDeflateEnabled) and GF_LSOP_VALUE_CHECKSUM
+    // (setValueChecksumEnabled); any other bit was refused above
     const bool valueChecksum = (deflateEnabled & GF_LSOP_VALUE_CHECKSUM) != 0;
     deflateEnabled &= GF_LSOP_DEFLATE;
     const size_t hdrCanon = valueChecksum ? 59 : 55, hdrDeflate = valueChecksum ? 67 : 63;
-    s = gf_lsop12_encode_batch_i32_dev_ex(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
-                                          (valueChecksum ? GF_LSOP_VALUE_CHECKSUM : 0) | (deflateEnabled ? GF_LSOP_INTERNAL_INT32_RESIDUALS : 0),
-                                          (uint8_t *)c->dSlots.p, stride,
-                                          (uint32_t *)c->dLengths.p, (int32_t *)c->dStatus.p, (int32_t *)c->dResiduals.p, resStride,
-                                          (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p);
+    s = lsopEncodeBatchDev(c, c->stream, codecIndex, nRows, nCols, nTiles, (const int32_t *)c->dValues.p,
+                           valueChecksum ? GF_LSOP_VALUE_CHECKSUM : 0, deflateEnabled != 0, (uint8_t *)c->dSlots.p, stride,
+                           (uint32_t *)c->dLengths.p, (int32_t *)c->dStatus.p, (int32_t *)c->dResiduals.p, resStride,
+                           (uint32_t *)c->dCoefs.p, (int32_t *)c->dStatus2.p);
     if (s != GF_OK) return s;
     std::vector<uint32_t> lengths(nTiles);
     std::vector<int32_t> st(nTiles);

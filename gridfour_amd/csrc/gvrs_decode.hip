@@ -3477,7 +3477,12 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
         roomy = (need > fastBytes && need <= roomyBytes) ? GF_TREE_ROOMY : 0u;
         // ... and listed for the roomy run's workgroups (clearFlags[2]: the count, zero when the pre-pass starts: the general
         // decode kernel of the batch before left it so)
-        if (roomy) roomyList[atomicAdd(clearFlags + 2, 1u)] = (uint32_t)t;
+        // (the list has nTiles entries: a count that a batch which ended early left behind, or another batch of this context on
+        // another stream, must not carry the writer beyond them -- the reader clamps to nTiles as well)
+        if (roomy) {
+            const uint32_t at = atomicAdd(clearFlags + 2, 1u);
+            if (at < nTiles) roomyList[at] = (uint32_t)t;
+        }
     }
     rec[0] = (uint32_t)st;
     rec[1] = nLeaves;
@@ -3593,8 +3598,16 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         if (a.ldsM32Roomy) {
             if ((e = gf_opt_in_dyn_lds(k_huffman_decode<DEC_FAST_ROOMY>, dynRoomy, optR)) != hipSuccess) return e;
             const size_t step = 1280, per = (sizeof(DecShared) + dynRoomy + 64 + step - 1) / step * step;
-            const size_t perCu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / per, 2048 / DEC_THREADS));
-            roomyGrid = (unsigned)std::min<size_t>(a.nTiles, perCu * 256);
+            // (the chip's CUs and a CU's LDS from the device, not from this file: advice of round 5)
+            int dev = 0, cus = 256, ldsPerCu = 160 * 1024;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v > 0) ldsPerCu = v;
+            }
+            (void)hipGetLastError();
+            const size_t perCu = std::max<size_t>(1, std::min<size_t>((size_t)ldsPerCu / per, 2048 / DEC_THREADS));
+            roomyGrid = (unsigned)std::min<size_t>(a.nTiles, perCu * (size_t)cus);
         }
         if (beside) {
             if ((e = hipEventRecord(side->fork, stream)) != hipSuccess) return e;            // (behind the pre-pass)

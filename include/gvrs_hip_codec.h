@@ -329,6 +329,9 @@ size_t gf_lsop12_max_packing(int n_rows, int n_cols);
  *                           it, as the reference's decoder only prints a mismatch (LsDecoder12.java:153-158).                */
 #define GF_LSOP_DEFLATE 1
 #define GF_LSOP_VALUE_CHECKSUM 2
+/* ABI note: `deflate_enabled` was a boolean before the value checksum existed (any non-zero value meant Deflate); it is a bit mask of
+ * the two switches above now -- 2 is "checksum, no Deflate", not "Deflate" -- and any other bit is refused with GF_ERR_ARG by every
+ * encode entry point (the _dev_ex form accepts GF_LSOP_DEFLATE and ignores it: Deflate needs the host's zlib).               */
 /* LsOptimalPredictor12.encode: tile -> coefficients + residual streams (d_status: GF_OK / GF_DECLINED per tile) */
 gf_status gf_lsop12_predict_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
                                 const int32_t *d_values, int32_t *d_residuals, size_t res_stride, uint32_t *d_coefs,
