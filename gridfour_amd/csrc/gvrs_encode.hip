@@ -729,25 +729,35 @@ __device__ PackStateOk pack_plane_waves(const uint8_t *__restrict__ plane, uint3
             // cells behind the tile; Differencing: not the seed; Linear: not the first two cells of a row; Triangle: not the first
             // row, not the first cell of a row.  A cell that is not emitted gets the byte 0x80, which no plain stream holds and
             // whose table entry the packer has emptied: eight table reads without a condition.
-            uint32_t em = 0xffu;
-            const uint32_t left = nCells - i0;
-            if (left < (uint32_t)CPT) em = (1u << left) - 1u;
             const uint32_t kz = c0 == 0u ? 0u : min(nC - c0, 16u);              // the place of the cell that starts a row (>= 8: none)
-            if constexpr (MODEL == 1) {
-                if (i0 == 0u) em &= ~1u;
-            } else if constexpr (MODEL == 2) {
-                em &= ~(3u << kz);
-                if (c0 == 1u) em &= ~1u;
-            } else {
-                em &= ~(1u << kz);
-                if (i0 < nC) em &= ~((1u << min((uint32_t)CPT, nC - i0)) - 1u);
-            }
-            {
+            // (the wave's turn as a whole -- scalars: its first cell and the tile's shape)
+            const bool edgeTurn = base + 64u * CPT > nCells || (MODEL == 3 && base < nC) || (MODEL == 1 && base == 0u);
+            if (edgeTurn) {
+                uint32_t em = 0xffu;
+                const uint32_t left = nCells - i0;
+                if (left < (uint32_t)CPT) em = (1u << left) - 1u;
+                if constexpr (MODEL == 1) {
+                    if (i0 == 0u) em &= ~1u;
+                } else if constexpr (MODEL == 2) {
+                    em &= ~(3u << kz);
+                    if (c0 == 1u) em &= ~1u;
+                } else {
+                    em &= ~(1u << kz);
+                    if (i0 < nC) em &= ~((1u << min((uint32_t)CPT, nC - i0)) - 1u);
+                }
                 const uint32_t y0 = __umul24(em & 15u, 0x00204081u) & 0x01010101u, y1 = __umul24((em >> 4) & 15u, 0x00204081u) & 0x01010101u;
                 constexpr uint32_t H = 0x80808080u;
                 const uint32_t m0 = (H - y0) ^ H, m1 = (H - y1) ^ H;           // a byte of ones per emitted cell (no borrow crosses a byte)
                 rb[0] = (rb[0] & m0) | (0x80808080u & ~m0);
                 rb[1] = (rb[1] & m1) | (0x80808080u & ~m1);
+            } else if constexpr (MODEL != 1) {
+                // a turn inside the tile (all but its first and last): the cells that start a row are all there is to leave out -- a
+                // byte's mask shifted to its place (Linear: two bytes, and the second cell of a row that started in the lane before)
+                unsigned long long m = kz < (uint32_t)CPT ? (MODEL == 2 ? 0xffffull : 0xffull) << (8u * kz) : 0ull;
+                if (MODEL == 2 && c0 == 1u) m |= 0xffull;
+                const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+                rb[0] = (rb[0] & ~m0) | (0x80808080u & m0);
+                rb[1] = (rb[1] & ~m1) | (0x80808080u & m1);
             }
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
