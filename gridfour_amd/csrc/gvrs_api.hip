@@ -421,7 +421,7 @@ static gf_status encodeBatchDev(int kind, gf_context *c, void *stream, int codec
         a.plane = nullptr;
         a.planeStride = 0;
 #ifndef GF_ENC_NO_PLANE
-        if (kind == KIND_HUFFMAN && !a.lean) {
+        if ((kind == KIND_HUFFMAN || kind == KIND_CANON) && !a.lean) {
             a.planeStride = encPlaneStride(nRows, nCols);
             a.plane = (uint8_t *)c->packRecs.p + roundUp(need, 256);
         }

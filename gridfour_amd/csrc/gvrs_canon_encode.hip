@@ -299,6 +299,142 @@ __device__ __forceinline__ void cpack_flat_ranges(const uint32_t *__restrict__ t
     }
 }
 
+// (round 6) cpack_flat_waves for a stream WITHOUT wide values (the winner's largest escape kind is 0: every residual a byte) from the
+// tile's byte plane of raw row differences (GfEncodeArgs::plane; see pack_plane_waves in gvrs_encode.hip): a residual's byte, bit 7
+// flipped, is its symbol (CanonicalHuffman.java:223-231: value + 128); the head of a Linear or Triangle stream rides in front of
+// wave 0's share of the first range; the plane's words are asked for a turn ahead.  A cell the flat scan does not emit takes the
+// table's last, empty entry.
+constexpr uint32_t CN_NO_SYMBOL = CN_HIST - 1;                    // (an index behind the 261 symbols: the packer clears the entry)
+static_assert(CN_HIST - 1 > CN_SYMS, "the canonical table needs a spare entry behind its symbols");
+
+__device__ __forceinline__ void cemit8_codes(uint32_t *wwin, uint32_t pos, const uint32_t (&cl)[CPT], uint32_t myBits)
+{
+#define GF_LN(j) (cl[j] >> 16)
+#define GF_CD(j) (cl[j] & 0xffffu)
+    const uint32_t n01 = GF_LN(0) + GF_LN(1), n45 = GF_LN(4) + GF_LN(5);
+    const uint32_t n0 = n01 + GF_LN(2) + GF_LN(3), n1 = n45 + GF_LN(6) + GF_LN(7);
+    if (n0 <= 32u && n1 <= 32u) {
+        GF_JOIN8_OR(wwin, pos, GF_CD, GF_LN, n01, n45, n0);
+#undef GF_LN
+#undef GF_CD
+    } else if (myBits) {
+        BitSink sink;
+        sink.init(wwin, pos);
+#pragma unroll
+        for (int j = 0; j < CPT; j++) sink.put32(cl[j] & 0xffffu, cl[j] >> 16);
+        sink.finish();
+    }
+}
+
+template <int MODEL>
+__device__ bool cpack_plane_waves(const uint8_t *__restrict__ plane, uint32_t nC, uint32_t nCells, const uint32_t *tab, uint32_t *win,
+                                  uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps, uint32_t slotWords, uint32_t cellBegin,
+                                  uint32_t cellEnd, uint32_t headElems)
+{
+    static_assert(MODEL >= 1 && MODEL <= 3, "the byte plane serves the three predictors");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = gf_wave_id();
+    cellEnd = min(cellEnd, nCells);
+    const uint32_t quarter = (((cellEnd - cellBegin + ENC_WAVES - 1) / ENC_WAVES) + CPT - 1) / CPT * CPT;
+    const uint32_t segBegin = min(cellEnd, cellBegin + wave * quarter), segEnd = min(cellEnd, segBegin + quarter);
+    const uint32_t lastI0 = (nCells - 1u) & ~(uint32_t)(CPT - 1);
+    PlaneWords ahead = plane_load<MODEL>(plane, nC, min(segBegin + lane * CPT, lastI0));
+    const bool withHead = MODEL != 1 && headElems != 0u && wave == 0u;     // (wave-uniform)
+    uint32_t hb[2] = {0u, 0u};
+    if constexpr (MODEL != 1) {
+        if (withHead) plane_head_bytes<MODEL>(plane, nC, lane * CPT, headElems, hb);
+    }
+    const uint32_t carryWord = wave_windows_begin(win, waveSum);
+    uint32_t *wwin = win + wave * WAVE_WIN;
+    uint32_t bits = 0;
+    bool fits = true;
+    if constexpr (MODEL != 1) {
+        if (withHead) {
+            for (uint32_t h = 0; h < headElems; h += 64u * CPT) {
+                if (h) plane_head_bytes<MODEL>(plane, nC, h + lane * CPT, headElems, hb);
+                uint32_t cl[CPT], myBits = 0;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    const uint32_t b = (hb[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    const uint32_t e = tab[h + lane * CPT + (uint32_t)j < headElems ? (b ^ 0x80u) : CN_NO_SYMBOL];
+                    cl[j] = e;
+                    myBits += e >> 16;
+                }
+                const uint32_t incl = gf_wave_incl_scan(myBits);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (bits + total > WAVE_WIN_BITS) { fits = false; break; }
+                cemit8_codes(wwin, bits + incl - myBits, cl, myBits);
+                bits += total;
+            }
+        }
+    }
+    uint32_t c0 = (segBegin + lane * CPT) % nC;
+    const uint32_t cStep = (64u * CPT) % nC;
+    for (uint32_t base = segBegin; base < segEnd && fits; base += 64u * CPT) {
+        const uint32_t i0 = base + lane * CPT;
+        uint32_t cl[CPT], myBits = 0;
+        const PlaneWords now = ahead;
+        ahead = plane_load<MODEL>(plane, nC, min(i0 + 64u * CPT, lastI0));
+        if (i0 < segEnd) {
+            uint32_t rb[2];
+            plane_residual_bytes<MODEL>(now, nC, i0, rb);
+            // the cells of the eight that the flat scan emits (nC >= 8: at most one of them starts a row), as in pack_plane_waves
+            uint32_t em = 0xffu;
+            const uint32_t left = nCells - i0;
+            if (left < (uint32_t)CPT) em = (1u << left) - 1u;
+            const uint32_t kz = c0 == 0u ? 0u : min(nC - c0, 16u);
+            if constexpr (MODEL == 1) {
+                if (i0 == 0u) em &= ~1u;
+            } else if constexpr (MODEL == 2) {
+                em &= ~(3u << kz);
+                if (c0 == 1u) em &= ~1u;
+            } else {
+                em &= ~(1u << kz);
+                if (i0 < nC) em &= ~((1u << min((uint32_t)CPT, nC - i0)) - 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const uint32_t b = (rb[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const uint32_t e = tab[(em >> j) & 1u ? (b ^ 0x80u) : CN_NO_SYMBOL];
+                cl[j] = e;
+                myBits += e >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) cl[j] = 0;
+        }
+        c0 += cStep;
+        if (c0 >= nC) c0 -= nC;
+        const uint32_t incl = gf_wave_incl_scan(myBits);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (bits + total > WAVE_WIN_BITS) { fits = false; break; }   // wave-uniform
+        cemit8_codes(wwin, bits + incl - myBits, cl, myBits);
+        bits += total;
+    }
+    return wave_windows_end(win, waveSum, carryWord, bits, fits, out32, slotWords, ps);
+}
+
+// ... in as many cell ranges as the text's bit count asks for; false: a range did not fit (nothing of it was written, ps stands behind
+// the ranges before it, *resume = its first cell: the caller goes on from there through the tile)
+template <int MODEL>
+__device__ __forceinline__ bool cpack_plane_ranges(const uint8_t *__restrict__ plane, uint32_t nC, uint32_t nCells, const uint32_t *tab,
+                                                   uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum, PackState &ps,
+                                                   uint32_t slotWords, uint32_t textBits, uint32_t headElems, uint32_t *resume)
+{
+    const uint64_t want = ((uint64_t)textBits + (textBits >> 2)) / ENC_WAVES;           // a wave's share, with 25 % slack
+    const uint32_t nRanges = (uint32_t)min((uint64_t)1024, want / WAVE_WIN_BITS + 1u);
+    constexpr uint32_t UNIT = CPT * ENC_WAVES;
+    uint32_t per = (((nCells + nRanges - 1) / nRanges) + UNIT - 1) / UNIT * UNIT;
+    for (uint32_t b = 0; b < nCells;) {
+        if (cpack_plane_waves<MODEL>(plane, nC, nCells, tab, win, out32, waveSum, ps, slotWords, b, b + per, b == 0u ? headElems : 0u)) {
+            b += per;
+        } else {
+            if (per <= 8u * UNIT) { *resume = b; return false; }
+            per = (per / 2u + UNIT - 1u) / UNIT * UNIT;
+        }
+    }
+    return true;
+}
+
 // workgroups per CU: the histogram + table kernel runs six (25.8 KB of LDS since the package-merge scratch is shared; with the
 // two-turn phase B of round 3 the bound has to say so: left at four the compiler took 110 VGPRs, 1.03 against 1.23 ms),
 // the pack kernel runs six (80 VGPRs; eight, at 64 VGPRs, cost 0.3 ms with the wave-private windows)
@@ -331,9 +467,13 @@ union CanonUnionA {
 #define GF_CN_A_WGS 7
 #endif
 
-template <int PART = 0>
+// PLANE (PART 1 only, round 6): the byte plane of raw row differences is written for k_canon_pack (GfEncodeArgs::plane, as
+// k_huffman_encode<true, 1, true> of the legacy codec: the Differencing residual of every cell as one byte; bit 3 of the flags: some
+// row difference is no byte -- the plane does not hold the tile)
+template <int PART = 0, bool PLANE = false>
 __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) void k_canon_encode(GfEncodeArgs a)
 {
+    static_assert(!PLANE || PART == 1, "the byte plane belongs to the part-1 kernel");
     __shared__ std::conditional_t<PART == 1, CanonPersistA, CanonPersist> P;
     __shared__ std::conditional_t<PART == 1, CanonUnionA, CanonUnion> S;
 
@@ -376,6 +516,7 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
                 Cells8 Q;
                 load_cells8_wave(tile, nC, nCells, i0, Q);
                 uint32_t c = c0;
+                [[maybe_unused]] uint32_t rowDiff[CPT];
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     const uint32_t idx = i0 + j;
@@ -395,7 +536,19 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
                     mk1 = max(mk1, addHist(h0, d1, gap1));
                     mk2 = max(mk2, addHist(h1, d2, gap2));
                     if (triOk) mk3 = max(mk3, addHist(h2, d3, gap3));
+                    if constexpr (PLANE) {
+                        rowDiff[j] = d1;
+                        if (d1 + 128u > 255u) myFlags |= 8u;
+                    }
                     if (++c == nC) c = 0;
+                }
+                if constexpr (PLANE) {
+                    const uint32_t p01 = __builtin_amdgcn_perm(rowDiff[1], rowDiff[0], 0x0c0c0400u), p23 = __builtin_amdgcn_perm(rowDiff[3], rowDiff[2], 0x0c0c0400u);
+                    const uint32_t p45 = __builtin_amdgcn_perm(rowDiff[5], rowDiff[4], 0x0c0c0400u), p67 = __builtin_amdgcn_perm(rowDiff[7], rowDiff[6], 0x0c0c0400u);
+                    GfU2 w;
+                    w.x = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    w.y = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
+                    *reinterpret_cast<GfU2 *>(a.plane + t * a.planeStride + i0) = w;
                 }
                 c0 += cStep;
                 if (c0 >= nC) c0 -= nC;
@@ -512,7 +665,11 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
                 stat[tid] = (uint32_t)P.model[tid];
                 stat[4 + tid] = P.nGap[tid];
                 stat[8 + tid] = P.maxKind[tid];
-                if (tid == 0) { stat[3] = P.seed; stat[7] = 1u; }
+                if (tid == 0) {
+                    stat[3] = P.seed;
+                    stat[7] = 1u;
+                    stat[11] = (PLANE && !(flags & 9u)) ? 1u : 0u;       // the byte plane holds this tile (no null cell, every row difference a byte)
+                }
             }
             __syncthreads();
             continue;
@@ -618,6 +775,7 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
                 rec[3] = P.maxLen[best];
                 rec[4] = P.maxKind[best];
                 rec[5] = (uint32_t)min(P.totalBits[best] - 48ull - P.imgBits[best], (unsigned long long)0xFFFFFFFFu);   // text bits
+                rec[6] = 0u;                                                                                             // (no byte plane in the one-kernel form)
             }
             for (int i = tid; i < CN_IMG_WORDS; i += ENC_THREADS) rec[8 + i] = P.img[best][i];
             for (int i = tid; i < CN_HIST; i += ENC_THREADS) rec[8 + CN_IMG_WORDS + i] = P.tab[best][i];
@@ -744,6 +902,7 @@ __global__ __launch_bounds__(64 * CN_TW, CN_TW == 4 ? 5 : CN_TW == 2 ? 9 : 3) vo
         rec[3] = bMaxLen;
         rec[4] = maxKind[best];
         rec[5] = (uint32_t)min(bTotalBits - 48ull - bImgBits, (unsigned long long)0xFFFFFFFFu);   // text bits
+        rec[6] = stat[11];                                                                       // the byte plane holds the tile
     }
 }
 
@@ -763,15 +922,35 @@ __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncod
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
 
     GF_FOR_WG_TILE(t, a.nTiles) {                                         // no tile loop: see gvrs_kernels.h
+        // (round 6) the tile's status and length and everything its record holds are asked for at once (as k_huffman_pack: one behind
+        // the other they were three round trips to memory before the first bit was packed)
+        const uint32_t *rec = a.packRecs + t * (size_t)CN_PACK_REC_WORDS;
+        constexpr int IMG_PER = (CN_IMG_WORDS + ENC_THREADS - 1) / ENC_THREADS, TAB_PER = (CN_HIST + ENC_THREADS - 1) / ENC_THREADS;
+        const int32_t tileStatus = a.status[t];
+        const uint32_t tileLen = a.lengths[t];
+        uint32_t rv[8], imgv[IMG_PER], tabv[TAB_PER];
+#pragma unroll
+        for (int k = 0; k < 8; k++) rv[k] = rec[k];
+#pragma unroll
+        for (int k = 0; k < IMG_PER; k++) imgv[k] = rec[8 + min(tid + k * ENC_THREADS, CN_IMG_WORDS - 1)];
+#pragma unroll
+        for (int k = 0; k < TAB_PER; k++) tabv[k] = rec[8 + CN_IMG_WORDS + min(tid + k * ENC_THREADS, CN_HIST - 1)];
         // declined, overflow: nothing to write; a uniform tile (exactly the 6 header bytes) was written by k_canon_encode
-        if (a.status[t] != GF_K_OK || a.lengths[t] <= 6u) continue;
+        if (tileStatus != GF_K_OK || tileLen <= 6u) continue;
         const uint32_t *__restrict__ tile = reinterpret_cast<const uint32_t *>(a.values) + t * (size_t)nCells;
         uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(a.out + t * a.slotStride);
-        const uint32_t *rec = a.packRecs + t * (size_t)CN_PACK_REC_WORDS;
-        const int model = (int)rec[0];
-        const uint32_t seed = rec[1], imgBits = rec[2], maxLen = rec[3], maxKind = rec[4], textBits = rec[5];
-        for (int i = tid; i < CN_IMG_WORDS; i += ENC_THREADS) P.img[i] = rec[8 + i];
-        for (int i = tid; i < CN_HIST; i += ENC_THREADS) P.tab[i] = rec[8 + CN_IMG_WORDS + i];
+        const int model = (int)rv[0];
+        const uint32_t seed = rv[1], imgBits = rv[2], maxLen = rv[3], maxKind = rv[4], textBits = rv[5];
+        // a stream without wide values of a tile whose byte plane k_canon_encode<1, true> has left: the plane instead of the tile
+        const bool fromPlane = a.plane && rv[6] != 0u && maxKind == 0u && model >= 1 && model <= 3 && nC >= (uint32_t)CPT;
+#pragma unroll
+        for (int k = 0; k < IMG_PER; k++)
+            if (tid + k * ENC_THREADS < CN_IMG_WORDS) P.img[tid + k * ENC_THREADS] = imgv[k];
+#pragma unroll
+        for (int k = 0; k < TAB_PER; k++) {
+            const int i = tid + k * ENC_THREADS;
+            if (i < CN_HIST) P.tab[i] = (fromPlane && i == (int)CN_NO_SYMBOL) ? 0u : tabv[k];
+        }
         __syncthreads();
 
         // header (6 bytes = 48 bits) + code tables image shifted behind it
@@ -802,7 +981,25 @@ __global__ __launch_bounds__(ENC_THREADS, CN_PACK_WGS) void k_canon_pack(GfEncod
         window_flush(win, out32, ps);
         if (nStream > 0) {
             const bool fast = (uint64_t)STEP_CELLS * elemMaxBits <= (uint64_t)(WIN_WORDS - 2) * 32u && nC >= 2;
-            if (!fast) {
+            uint32_t resume = 0;
+            bool done = false;
+            if (fast && fromPlane) {
+                const uint8_t *__restrict__ plane = a.plane + t * a.planeStride;
+                const uint32_t slotWords = (uint32_t)(a.slotStride >> 2);
+                if (model == 1) done = cpack_plane_ranges<1>(plane, nC, nCells, tab, win, out32, P.waveSum, ps, slotWords, textBits, 0u, &resume);
+                else if (model == 2) done = cpack_plane_ranges<2>(plane, nC, nCells, tab, win, out32, P.waveSum, ps, slotWords, textBits, 2u * nR - 1u, &resume);
+                else done = cpack_plane_ranges<3>(plane, nC, nCells, tab, win, out32, P.waveSum, ps, slotWords, textBits, nC - 1u + nR - 1u, &resume);
+                if (!done && resume != 0u) {
+                    // (a range that overran its windows after all: the rest of the cells from the tile, the slow way)
+                    if (model == 1) cpack_flat<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, resume, nCells);
+                    else if (model == 2) cpack_flat<2>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, resume, nCells);
+                    else cpack_flat<3>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, resume, nCells);
+                    done = true;
+                }
+            }
+            if (done) {
+                // (packed from the plane)
+            } else if (!fast) {
                 cpack_generic(model, tile, nR, nC, seed, tab, elemMaxBits, 0u, nStream, win, out32, P.waveSum, ps);
             } else if (model == 1) {
                 cpack_flat_ranges<1>(tile, nC, nCells, seed, tab, win, out32, P.waveSum, ps, (uint32_t)(a.slotStride >> 2), textBits);
@@ -846,7 +1043,8 @@ hipError_t gf_launch_canon_encode(const GfEncodeArgs &a, hipStream_t stream)
     if (!a.packRecs) return hipErrorInvalidValue;
     if (a.encStats) {
         // the histograms, then the code tables with a wave per tile (four tiles to a workgroup)
-        hipLaunchKernelGGL(k_canon_encode<1>, grid, dim3(ENC_THREADS), 0, stream, a);
+        if (a.plane) hipLaunchKernelGGL((k_canon_encode<1, true>), grid, dim3(ENC_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL(k_canon_encode<1>, grid, dim3(ENC_THREADS), 0, stream, a);
         hipLaunchKernelGGL(k_canon_trees, gf_tile_grid((a.nTiles + CN_TW - 1) / CN_TW), dim3(64 * CN_TW), 0, stream, a);
     } else {
         hipLaunchKernelGGL(k_canon_encode<0>, grid, dim3(ENC_THREADS), 0, stream, a);

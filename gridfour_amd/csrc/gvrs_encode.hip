@@ -403,62 +403,6 @@ struct PackStateOk {
     bool ok;
 };
 
-// (round 6) The low bytes of the residuals of eight consecutive cells i0 .. i0 + 7 (i0 a multiple of 8) of model 1, 2 or 3 from the
-// tile's byte plane of raw row differences p (GfEncodeArgs::plane; every byte is its value exactly and the winner's values are plain
-// bytes, so a residual's low byte is its M32 form): Differencing -- the plane's bytes; Linear -- a byte less its left neighbour
-// (PredictorModelLinear.java:128-141: v - (2 W - WW) = (v - W) - (W - WW)); Triangle -- a byte less the byte above
-// (PredictorModelTriangle.java:130-142: v - (W + N - NW) = (v - W) - (N - NW)).  Four bytes are subtracted at once (no carries
-// between them); cells that the model does not emit in the flat scan (first row, first columns) give bytes nobody looks at.
-// Words up to 12 bytes in front of the plane may be read (never used): the plane of tile 0 has the records' slack in front of it.
-__device__ __forceinline__ uint32_t bytes_sub4(uint32_t x, uint32_t y)
-{
-    constexpr uint32_t H = 0x80808080u;
-    return ((x | H) - (y & ~H)) ^ ((x ^ ~y) & H);
-}
-// (in two steps, so that the packer can ask for a turn's words one turn ahead: five registers instead of the nineteen of a turn's cells)
-struct PlaneWords {
-    uint32_t c0, c1;                    // the eight bytes at i0
-    uint32_t x0, x1, x2;                // Linear: x0 = the word in front of them; Triangle: the three words that hold the bytes above
-};
-template <int MODEL>
-__device__ __forceinline__ PlaneWords plane_load(const uint8_t *__restrict__ p, uint32_t nC, uint32_t i0)
-{
-    PlaneWords w;
-    const uint32_t *pw = reinterpret_cast<const uint32_t *>(p + i0);
-    const GfU2 cur = *reinterpret_cast<const GfU2 *>(pw);
-    w.c0 = cur.x;
-    w.c1 = cur.y;
-    w.x0 = w.x1 = w.x2 = 0;
-    if constexpr (MODEL == 2) {
-        w.x0 = pw[-1];
-    } else if constexpr (MODEL == 3) {
-        int32_t o = (int32_t)i0 - (int32_t)nC;
-        if (o < -8) o = -8;                                             // (the first row: nothing of it is emitted here)
-        const uint32_t *uw = reinterpret_cast<const uint32_t *>(p + (o & ~3));
-        w.x0 = uw[0];
-        w.x1 = uw[1];
-        w.x2 = uw[2];
-    }
-    return w;
-}
-template <int MODEL>
-__device__ __forceinline__ void plane_residual_bytes(const PlaneWords &w, uint32_t nC, uint32_t i0, uint32_t (&rb)[2])
-{
-    if constexpr (MODEL == 1) {
-        rb[0] = w.c0;
-        rb[1] = w.c1;
-    } else if constexpr (MODEL == 2) {
-        rb[0] = bytes_sub4(w.c0, __builtin_amdgcn_alignbyte(w.c0, w.x0, 3u));
-        rb[1] = bytes_sub4(w.c1, __builtin_amdgcn_alignbyte(w.c1, w.c0, 3u));
-    } else {
-        int32_t o = (int32_t)i0 - (int32_t)nC;
-        if (o < -8) o = -8;
-        const uint32_t sh = (uint32_t)o & 3u;
-        rb[0] = bytes_sub4(w.c0, __builtin_amdgcn_alignbyte(w.x1, w.x0, sh));
-        rb[1] = bytes_sub4(w.c1, __builtin_amdgcn_alignbyte(w.x2, w.x1, sh));
-    }
-}
-
 template <int MODEL, bool PLAIN>
 __device__ PackStateOk pack_flat_waves(const uint32_t *__restrict__ tile, uint32_t nC, uint32_t nCells, uint32_t seed,
                                        const uint64_t *tab, uint32_t *win, uint32_t *__restrict__ out32, uint32_t *waveSum,
@@ -646,31 +590,6 @@ __device__ __forceinline__ void emit8_codes(uint32_t *wwin, uint32_t pos, const 
 // was five round trips to memory one behind the other (status; record; two chunks of the head; the first turn's cells) around nine
 // turns of work; here the head's bytes and the first turn's words are asked for together, before the windows are cleared, and every
 // later turn's words a turn ahead (five registers per lane; the tile's nineteen left no room for that).
-template <int MODEL>
-__device__ __forceinline__ uint32_t plane_head_cell(uint32_t s, uint32_t nC)
-{
-    if constexpr (MODEL == 2) {
-        const uint32_t t = s - 1u;
-        return s == 0u ? 1u : (1u + (t >> 1)) * nC + (t & 1u);
-    } else {
-        const uint32_t t = s - (nC - 1u);
-        return s < nC - 1u ? s + 1u : (t + 1u) * nC;
-    }
-}
-template <int MODEL>
-__device__ __forceinline__ void plane_head_bytes(const uint8_t *__restrict__ p, uint32_t nC, uint32_t s0, uint32_t headElems, uint32_t (&hb)[2])
-{
-    uint32_t b[CPT];
-#pragma unroll
-    for (int j = 0; j < CPT; j++) {
-        const uint32_t s = s0 + (uint32_t)j;
-        const uint32_t v = p[s < headElems ? plane_head_cell<MODEL>(s, nC) : 0u];
-        b[j] = s < headElems ? v : 0x80u;                                 // (0x80: the byte whose table entry is empty)
-    }
-    hb[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-    hb[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-}
-
 template <int MODEL>
 __device__ PackStateOk pack_plane_waves(const uint8_t *__restrict__ plane, uint32_t nC, uint32_t nCells, const uint64_t *tab, uint32_t *win,
                                         uint32_t *__restrict__ out32, uint32_t *waveSum, PackState ps, uint32_t slotWords,

@@ -12,17 +12,20 @@ from tilegen import make_tile
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def codec():
+@pytest.fixture(scope="module", params=["huffman", "canon"])
+def codec(request):
+    """CodecHuffman and CodecCanonHuffman (k_huffman_pack / k_canon_pack: both pack a narrow stream from the plane)"""
     import gridfour_amd
-    return gridfour_amd.CodecHuffmanHip()
+    c = gridfour_amd.CodecHuffmanHip() if request.param == "huffman" else gridfour_amd.CodecCanonHuffmanHip()
+    c.oracle_encode = oracle.codec_huffman_encode if request.param == "huffman" else oracle.codec_canon_encode
+    return c
 
 
 def _check(codec, nr, nc, tiles, want_models=None):
     tiles = np.ascontiguousarray(np.stack(tiles), np.int32)
     packs, preds, status = codec.encode_batch(1, nr, nc, tiles)
     for t, v in enumerate(tiles):
-        ref, used = oracle.codec_huffman_encode(1, nr, nc, v)
+        ref, used = codec.oracle_encode(1, nr, nc, v)
         assert status[t] == 0 and preds[t] == used, (t, status[t], preds[t], used)
         if packs[t] != ref:
             first = next(i for i in range(min(len(ref), len(packs[t]))) if packs[t][i] != ref[i])
