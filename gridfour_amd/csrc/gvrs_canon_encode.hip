@@ -516,7 +516,11 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
                 Cells8 Q;
                 load_cells8_wave(tile, nC, nCells, i0, Q);
                 uint32_t c = c0;
-                [[maybe_unused]] uint32_t rowDiff[CPT];
+                // (round 6, as the legacy encoder's phase A since round 4) the residuals of the thread's eight cells first; where every
+                // one of the wave's is a byte -- every turn of a terrain tile -- the turn is 24 additions to the histograms and
+                // nothing else: no "is it a byte?" branch per residual, no classification
+                uint32_t D1[CPT], D2[CPT], D3[CPT];
+                uint32_t wide = 0;
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     const uint32_t idx = i0 + j;
@@ -530,18 +534,29 @@ __global__ __launch_bounds__(ENC_THREADS, PART == 1 ? GF_CN_A_WGS : CN_AB_WGS) v
                     // the seed cell and the padding behind the tile count as residual 0; bin 128 is corrected below
                     const bool counted = real && idx > 0;
                     const uint32_t d = v - (c > 0 ? W : N);
-                    const uint32_t d1 = counted ? d : 0u;
-                    const uint32_t d2 = counted ? (c >= 2 ? v - (2u * W - WW) : d) : 0u;
-                    const uint32_t d3 = counted ? ((idx >= nC && c > 0) ? v - (W + N - NW) : d) : 0u;
-                    mk1 = max(mk1, addHist(h0, d1, gap1));
-                    mk2 = max(mk2, addHist(h1, d2, gap2));
-                    if (triOk) mk3 = max(mk3, addHist(h2, d3, gap3));
-                    if constexpr (PLANE) {
-                        rowDiff[j] = d1;
-                        if (d1 + 128u > 255u) myFlags |= 8u;
-                    }
+                    D1[j] = counted ? d : 0u;
+                    D2[j] = counted ? (c >= 2 ? v - (2u * W - WW) : d) : 0u;
+                    D3[j] = (counted && triOk) ? ((idx >= nC && c > 0) ? v - (W + N - NW) : d) : 0u;
+                    wide = max(wide, max(D1[j] + 128u, max(D2[j] + 128u, D3[j] + 128u)));
                     if (++c == nC) c = 0;
                 }
+                if (__all(wide <= 255u)) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        atomicAdd(h0 + (D1[j] + 128u) * HIST_R, 1u);
+                        atomicAdd(h1 + (D2[j] + 128u) * HIST_R, 1u);
+                        if (triOk) atomicAdd(h2 + (D3[j] + 128u) * HIST_R, 1u);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) {
+                        mk1 = max(mk1, addHist(h0, D1[j], gap1));
+                        mk2 = max(mk2, addHist(h1, D2[j], gap2));
+                        if (triOk) mk3 = max(mk3, addHist(h2, D3[j], gap3));
+                        if (PLANE && D1[j] + 128u > 255u) myFlags |= 8u;
+                    }
+                }
+                [[maybe_unused]] uint32_t (&rowDiff)[CPT] = D1;
                 if constexpr (PLANE) {
                     const uint32_t p01 = __builtin_amdgcn_perm(rowDiff[1], rowDiff[0], 0x0c0c0400u), p23 = __builtin_amdgcn_perm(rowDiff[3], rowDiff[2], 0x0c0c0400u);
                     const uint32_t p45 = __builtin_amdgcn_perm(rowDiff[5], rowDiff[4], 0x0c0c0400u), p67 = __builtin_amdgcn_perm(rowDiff[7], rowDiff[6], 0x0c0c0400u);
