@@ -2107,20 +2107,28 @@ gf_status gf_lsop12_decode_batch_i32_dev(gf_context *c, void *stream, int nRows,
     const unsigned grid = gf_huffman_decode_grid(nTiles);
     gf_status s = lsopParseLengths(c, st, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths);
     if (s != GF_OK) return s;
+    // (round 6) interior residuals as byte planes in the reconstruction's order where a tile's values allow (gvrs_kernels.h)
+#ifdef GF_LSOP_NO_PLANES                                    // (experiment builds: tools/ab_kernels.sh)
+    const bool lsopPlanes = false;
+#else
+    const bool lsopPlanes = true;
+#endif
     GF_HIP(gf_launch_lsop_unpack2(dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride, dCoefs,
                                   dScratchStatus, nTiles, nRows, nCols, gf_lsop_unpack_lds_text(nRows, nCols), grid, st,
                                   (const uint32_t *)c->trees.p, g_decodeDebug,
                                   // (the serial walk of a lane pays where sixty-four tiles share a wave: large batches)
 #ifdef GF_LSOP_NO_HEAD                                      // (experiment builds: tools/ab_kernels.sh)
-                                  nullptr));
+                                  nullptr,
 #else
-                                  gf_prepass_tiles_per_wave(nTiles) == 64u ? (uint32_t *)c->trees.p + nTiles * (size_t)GF_CANON_REC_WORDS : nullptr));
+                                  gf_prepass_tiles_per_wave(nTiles) == 64u ? (uint32_t *)c->trees.p + nTiles * (size_t)GF_CANON_REC_WORDS : nullptr,
 #endif
+                                  lsopPlanes));
     s = lsopUnpackM32Deflate(c, st, nRows, nCols, nTiles, dBlob, blobBytes, dOffsets, slotStride, dLengths, dResiduals, resStride,
                              dCoefs, dScratchStatus);
     if (s != GF_OK) return s;
-    return gf_lsop12_reconstruct_dev(c, stream, nRows, nCols, nTiles, dResiduals, resStride, dCoefs, dScratchStatus, dValues,
-                                     dStatus);
+    GF_HIP(gf_launch_lsop_reconstruct(dResiduals, resStride, dCoefs, dScratchStatus, dValues, dStatus, nTiles, nRows, nCols, st,
+                                      lsopPlanes));
+    return GF_OK;
 }
 
 }  // extern "C"

@@ -380,6 +380,8 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
     uint32_t capA, cap;
     uint32_t halfBase;                    // stream position of the half being decoded
     bool fuse;                            // the staged values stay where they are: cd_fused_triangle() turns them into the tile
+    uint32_t *wide = nullptr;             // (round 6) an LDS word that learns whether any value went straight to its cell: a stage
+                                          // without such a value IS the stream (k_lsop_unpack2's byte plane)
     __device__ __forceinline__ uint8_t *slot(uint32_t rel) const { return rel < capA ? stA + rel : stB + (rel - capA); }
     __device__ __forceinline__ void put(uint32_t k, uint32_t v, bool on = true) const
     {
@@ -388,7 +390,10 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
         const bool ok = on && k < nStream && enabled;
         const bool small = v + 127u <= 254u, staged = rel < cap;
         if (ok && staged) *slot(rel) = small ? (uint8_t)v : (uint8_t)0x80;
-        if (ok && !(staged && small)) o[cell(k)] = v;
+        if (ok && !(staged && small)) {
+            o[cell(k)] = v;
+            if (wide) *wide = 1u;
+        }
     }
     __device__ __forceinline__ void expand(uint32_t count) const        // the whole workgroup, between two barriers
     {

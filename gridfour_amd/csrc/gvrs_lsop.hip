@@ -1338,6 +1338,8 @@ struct GfLsopReconArgs {
     int32_t *status;
     size_t nTiles;
     int nRows, nCols;
+    bool planes;               // word GF_LSOP_FMT_WORD of a tile's coefficient record is valid: 1 = its interior residuals are a byte
+                               // plane (k_lsop_reconstruct_plane's tile; the other kernels pass it by)
 };
 
 __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs a)
@@ -1349,6 +1351,7 @@ __global__ __launch_bounds__(256) void k_lsop_reconstruct_global(GfLsopReconArgs
     const uint32_t wI = nC - 4u;
 
     for (size_t t = wid; t < a.nTiles; t += wavesPerGrid) {
+        if (a.planes && a.coefs[t * 16 + GF_LSOP_FMT_WORD] == 1u) continue;
         if (a.inStatus && a.inStatus[t] != GF_K_OK) {
             if (lane == 0) a.status[t] = a.inStatus[t];
             continue;
@@ -1491,6 +1494,7 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct(G
     // (a grid-stride loop, although the launcher gives every tile its own workgroup: without the loop -- GF_FOR_WG_TILE -- the
     // compiler allocates 79 instead of 103 registers and the kernel is slower, 1.28 against 1.18 ms on the bench batch)
     for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if (a.planes && a.coefs[t * 16 + GF_LSOP_FMT_WORD] == 1u) continue;
         if (a.inStatus && a.inStatus[t] != GF_K_OK) {
             if (lane == 0) a.status[t] = a.inStatus[t];
             continue;
@@ -1706,6 +1710,7 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_p
     const uint32_t nRounds = sEnd / ROUND + 1u;
 
     for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        if (a.planes && a.coefs[t * 16 + GF_LSOP_FMT_WORD] == 1u) continue;
         if (a.inStatus && a.inStatus[t] != GF_K_OK) {
             if (lane == 0) a.status[t] = a.inStatus[t];
             continue;
@@ -1925,6 +1930,215 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_p
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_lsop_reconstruct_plane (round 6): the pipeline of k_lsop_reconstruct_pipe for tiles whose interior residuals k_lsop_unpack2 left as
+// a byte plane in pipeline order (gvrs_kernels.h: GfLsopPlaneGeom).  What the old kernel spent per step -- 185 instructions, of which
+// the arithmetic of LsDecoder12.java:311-383 is about fifty -- went into moving data between the order the memory wants (rows) and the
+// order the pipeline wants (a lane a row, three steps apart): sixteen residual pieces in and sixteen value pieces out per round,
+// each with its own (row, column) arithmetic, through an LDS ring.  Here
+//   * a lane's sixteen residuals of a round are one 16-byte load of the plane (a wave: 1 KB in a row), taken apart with v_bfe_i32;
+//   * its sixteen values of a round stay in registers and leave as four 16-byte stores to its own row (a quad that a row's end or
+//     start cuts goes out cell by cell) -- no LDS ring, no transposition;
+//   * the windows hold the neighbours as FLOATS (a value is converted once, when it enters a window, not in each of the twelve
+//     products it takes part in) and the rounding is lsop_round_f32 (single precision, exact: the encoder's);
+//   * a lane's state is not guarded: what a lane computes while it is between two rows (or before its first) is never stored and
+//     reaches only cells of the lane below that are not stored either;
+//   * the rows' constants -- columns 0 and 1, the two tail residuals -- are worked out for the whole tile up front (scans down the
+//     rows) and wait in LDS; lane 0's rows above lie interleaved, so that its sixteen steps are eight 16-byte LDS reads.
+// Bytes: the old kernel read 2.5 GB and wrote 1.5 GB per 12,960 tiles of 120 x 150; this one reads the planes (0.44 GB with their
+// holes) and the initialisers.
+// ------------------------------------------------------------------------------------------------
+#ifndef RECON_PLANE_WAVES
+#define RECON_PLANE_WAVES 4
+#endif
+constexpr uint32_t RP_FRONT = GF_LSOP_PLANE_FRONT;
+
+__global__ __launch_bounds__(64, RECON_PLANE_WAVES) void k_lsop_reconstruct_plane(GfLsopReconArgs a, GfLsopPlaneGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t rpLds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
+    const int32_t P = (int32_t)g.P;
+    uint32_t *const rowsAB = rpLds + 2u * RP_FRONT;                        // [P + 32][2]: {row r - 2, row r - 1} of lane 0's row, by column
+    GfU4 *const cst = reinterpret_cast<GfU4 *>(rpLds + 2u * (RP_FRONT + g.P + 32u));   // [64 (nPh + 1)]: columns 0 and 1, tail residuals of row 2 + i
+    const bool feeds = lane >= 62u;
+
+    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+        const uint32_t *cf = a.coefs + t * 16;
+        if (cf[GF_LSOP_FMT_WORD] != 1u) continue;                           // int32 residuals: the kernels above
+        if (a.inStatus && a.inStatus[t] != GF_K_OK) {
+            if (lane == 0) a.status[t] = a.inStatus[t];
+            continue;
+        }
+        const int32_t *__restrict__ res = a.residuals + t * a.resStride;
+        const uint8_t *__restrict__ plane = reinterpret_cast<const uint8_t *>(res + g.offWords);
+        int32_t *__restrict__ v = a.values + t * (size_t)nCells;
+        const uint32_t seed = cf[0];
+        float u[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) u[i] = __uint_as_float(cf[1 + i]);
+        GfU4 chunk = *reinterpret_cast<const GfU4 *>(plane + lane * 16u);
+
+        // rows 0 and 1 as prefix sums (LsDecoder12.unpackInitializers :186-221): to global memory and to lane 0's row buffers
+        {
+            uint32_t carry = seed;
+            if (lane == 0) { v[0] = (int32_t)seed; rowsAB[0] = seed; }
+            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                if (c < nC) { v[c] = (int32_t)incl; rowsAB[2u * c] = incl; }
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        const uint32_t v10 = seed + (uint32_t)res[nC - 1u];                    // v[1][0]
+        if (lane == 0) { v[nC] = (int32_t)v10; rowsAB[1] = v10; }
+        uint32_t v11 = 0;                                                      // v[1][1]
+        {
+            uint32_t carry = v10 - seed;
+            const uint32_t base = nC - 1u + nR - 1u;
+            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const uint32_t x = c < nC ? (uint32_t)res[base + c - 1] : 0u;
+                const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                const uint32_t val = incl + (c < nC ? rowsAB[2u * c] : 0u);
+                if (c < nC) { v[nC + c] = (int32_t)val; rowsAB[2u * c + 1u] = val; }
+                if (c0 == 1) v11 = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        // columns 0 and 1 of the rows below are running sums down the rows; with the rows' tail residuals into LDS
+        {
+            uint32_t carry0 = v10, carry1 = v11 - v10;
+            const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
+            for (uint32_t pn = 0; pn <= g.nPh; pn++) {
+                const uint32_t r = 2u + 64u * pn + lane;
+                const bool rowValid = r < nR;
+                const uint32_t x0 = rowValid ? (uint32_t)res[base0 + r - 1u] : 0u;
+                const uint32_t x1 = rowValid ? (uint32_t)res[base1 + r - 2u] : 0u;
+                GfU4 k4;
+                k4.z = rowValid ? (uint32_t)res[tailBase + 2u * (r - 2u)] : 0u;
+                k4.w = rowValid ? (uint32_t)res[tailBase + 2u * (r - 2u) + 1u] : 0u;
+                const uint32_t i0 = gf_wave_incl_scan(x0) + carry0;
+                carry0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+                const uint32_t i1 = gf_wave_incl_scan(x1) + carry1;
+                carry1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+                k4.x = i0;
+                k4.y = i1 + i0;
+                cst[64u * pn + lane] = k4;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        float a0f = 0, a1f = 0, a2f = 0, a3f = 0, a4f = 0, b0f = 0, b1f = 0, b2f = 0, b3f = 0, b4f = 0, z1f = 0, z6f = 0;
+        uint32_t a1i = 0, a2i = 0, a3i = 0, a4i = 0, z1i = 0;
+        uint32_t colv0, colv1, t0, t1;
+        {
+            const GfU4 k4 = cst[lane];
+            colv0 = k4.x; colv1 = k4.y; t0 = k4.z; t1 = k4.w;
+        }
+        int32_t cB = -3 * (int32_t)lane;                   // the lane's column at the round's first step (negative: not started)
+        uint32_t ph = 0;                                   // its row: 2 + 64 ph + lane
+        for (uint32_t R = 0; R < g.nBlocks; R++) {
+            // the next round's residuals (the last round asks for its own again)
+            const GfU4 nxt = *reinterpret_cast<const GfU4 *>(plane + ((size_t)min(R + 1u, g.nBlocks - 1u) * 64u + lane) * 16u);
+            // lane 0's rows above, columns c0 + 2 .. c0 + 17 (c0: its column, a multiple of 16; it starts its rows with a round)
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane(cB);
+            if (c0 == 0u) {
+                // ... and columns 0 and 1 into its windows when it starts a row (the lanes below get theirs from the lane above)
+                const GfU4 w = *reinterpret_cast<const GfU4 *>(rowsAB);
+                if (lane == 0) {
+                    b3f = (float)(int32_t)w.x; a3i = w.y; a3f = (float)(int32_t)w.y;
+                    b4f = (float)(int32_t)w.z; a4i = w.w; a4f = (float)(int32_t)w.w;
+                }
+            }
+            uint32_t ra[16], rb[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k += 2) {
+                const GfU4 w = *reinterpret_cast<const GfU4 *>(rowsAB + 2u * (c0 + 2u + k));
+                rb[k] = w.x; ra[k] = w.y; rb[k + 1] = w.z; ra[k + 1] = w.w;
+            }
+            // a lane that starts a row in this round takes over that row's columns 0 and 1; one that has started a row within the
+            // last sixteen steps its tail residuals (the row before's tail lies before its end, a row's own beyond its 30th column)
+            {
+                const bool wrapSoon = cB > P - 16;
+                const GfU4 k4 = cst[64u * (ph + (wrapSoon ? 1u : 0u)) + lane];
+                const bool needCol = wrapSoon || cB == 0, needTail = cB >= 0 && cB < 16;
+                colv0 = needCol ? k4.x : colv0;
+                colv1 = needCol ? k4.y : colv1;
+                t0 = needTail ? k4.z : t0;
+                t1 = needTail ? k4.w : t1;
+            }
+            uint32_t out[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const int32_t cw = cB + (int32_t)k;
+                const int32_t c = cw >= P ? cw - P : cw;
+                const uint32_t na = lsop_from_lane_above(ra[k], z1i);
+                const uint32_t nb = lsop_from_lane_above(rb[k], a2i);
+                a0f = a1f; a1f = a2f; a2f = a3f; a3f = a4f; a4f = (float)(int32_t)na;
+                b0f = b1f; b1f = b2f; b2f = b3f; b3f = b4f; b4f = (float)(int32_t)nb;
+                a1i = a2i; a2i = a3i; a3i = a4i; a4i = na;
+                float p = u[0] * z1f;
+                p = p + u[1] * a1f;
+                p = p + u[2] * a2f;
+                p = p + u[3] * a3f;
+                p = p + u[4] * a4f;
+                p = p + u[5] * z6f;
+                p = p + u[6] * a0f;
+                p = p + u[7] * b0f;
+                p = p + u[8] * b1f;
+                p = p + u[9] * b2f;
+                p = p + u[10] * b3f;
+                p = p + u[11] * b4f;
+                const uint32_t word = k < 4 ? chunk.x : k < 8 ? chunk.y : k < 12 ? chunk.z : chunk.w;
+                const int32_t r8 = (int32_t)(word << (24u - 8u * (k & 3u))) >> 24;
+                const uint32_t interior = (uint32_t)lsop_round_f32(p) + (uint32_t)r8;              // LsDecoder12 :311-351
+                const uint32_t tail = (c == (int32_t)nC - 2 ? t0 : t1) + (z1i + a2i - a1i);       // :353-383
+                const uint32_t border = c == 0 ? colv0 : colv1;
+                const uint32_t val = c < 2 ? border : (c <= (int32_t)nC - 3 ? interior : tail);
+                z6f = z1f;
+                z1f = (float)(int32_t)val;
+                z1i = val;
+                out[k] = val;
+                if (feeds) rowsAB[2 * c + (int32_t)(lane - 62u)] = val;      // (c >= -189: the words in front of the buffers)
+            }
+            // the sixteen values to the lane's row: whole quads where the row covers them, single cells at its ends
+            {
+                const uint32_t r = 2u + 64u * ph + lane;
+                const bool vCur = r < nR, vNext = r + 64u < nR;
+                const uint32_t rowOff = r * nC;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const int32_t cq = cB + 4 * (int32_t)q;
+                    const bool full = vCur && cq >= 0 && cq + 3 < (int32_t)nC;
+                    const bool part = !full && ((vCur && cq + 3 >= 0 && cq < (int32_t)nC) || (vNext && cq + 3 >= P));
+                    if (full) {
+                        GfU4 x;
+                        x.x = out[4 * q]; x.y = out[4 * q + 1]; x.z = out[4 * q + 2]; x.w = out[4 * q + 3];
+                        *reinterpret_cast<GfU4 *>(v + rowOff + (uint32_t)cq) = x;
+                    } else if (part) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            const int32_t cj = cq + (int32_t)j;
+                            const bool wr = cj >= P;
+                            const bool ok = wr ? vNext : (vCur && cj >= 0 && cj < (int32_t)nC);    // (a new row's first fifteen columns: inside it)
+                            const uint32_t at = wr ? rowOff + 64u * nC + (uint32_t)(cj - P) : rowOff + (uint32_t)cj;
+                            if (ok) v[at] = (int32_t)out[4 * q + j];
+                        }
+                    }
+                }
+            }
+            chunk = nxt;
+            cB += 16;
+            if (cB >= P) { cB -= P; ph++; }
+        }
+        if (lane == 0) a.status[t] = GF_K_OK;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -2027,10 +2241,22 @@ hipError_t gf_launch_lsop_value_crc(const int32_t *values, size_t nCells, size_t
 
 hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride, const uint32_t *coefs, const int32_t *inStatus,
                                       int32_t *values, int32_t *status, size_t nTiles, int nRows, int nCols,
-                                      hipStream_t stream)
+                                      hipStream_t stream, bool planes)
 {
     if (nTiles == 0) return hipSuccess;
-    GfLsopReconArgs a{residuals, resStride, coefs, inStatus, values, status, nTiles, nRows, nCols};
+    const GfLsopPlaneGeom g = gf_lsop_plane_geom((uint32_t)nRows, (uint32_t)nCols);
+    const size_t dynP = g.ldsBytes;
+    planes = planes && g.ok;
+    GfLsopReconArgs a{residuals, resStride, coefs, inStatus, values, status, nTiles, nRows, nCols, planes};
+    if (planes) {
+        // the tiles whose interior residuals lie as byte planes (k_lsop_unpack2 says which: terrain, all of them); the kernels
+        // below then find the others
+        static GfDynLdsOptIn optPlane;
+        const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct_plane, dynP, optPlane);
+        if (e != hipSuccess) return e;
+        const unsigned gridP = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
+        hipLaunchKernelGGL(k_lsop_reconstruct_plane, dim3(gridP), dim3(64), dynP, stream, a, g);
+    }
     const size_t dyn = (64 * (2 * RECON_ROUND + 1) + 2 * (size_t)nCols) * 4;      // 64 staging rings + 2 row buffers
     if (dyn <= 96 * 1024) {
         static GfDynLdsOptIn opt;

@@ -37,6 +37,8 @@ struct GfLsopUnpackArgs {
     const uint32_t *pre;       // code-length records of the first stream (k_canon_parse_lengths), or null
     const uint32_t *pre2;      // k_lsop_head's records of the second stream, or null (word 3 != 0: the tile's first stream is done)
     uint32_t *debug;           // diagnostic flavour: 16 cycle stamps per tile (tools/phase_cycles_lsop.py), normally null
+    GfLsopPlaneGeom plane;     // plane.ok: the interior residuals of a tile whose values are all bytes leave as a byte plane in pipeline
+                               // order (gvrs_kernels.h), word GF_LSOP_FMT_WORD of the tile's coefficient record says so
 };
 
 
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
             const uint32_t hdr = 55u + ((pk[1] & 0x80) ? 4u : 0u);         // value checksum, if present, is skipped
             if (len < hdr) early = GF_K_ERR_BOUNDS;
         }
+        if (tid == 0) a.coefs[t * 16 + GF_LSOP_FMT_WORD] = 0u;             // (until the tile's plane is written)
         if (early != GF_K_OK) {
             if (tid == 0) a.status[t] = early;
             __syncthreads();
@@ -367,15 +370,53 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
             // subsequence per thread: dead by then), the token table and the unused end of the text buffer; what does not fit goes straight out
             // ... and the part of the text buffer this packing does not fill (the buffer is sized for 3/4 byte per cell)
             const uint32_t usedWords = textInLds ? min(needWords, capWords) : 0u;
+            const uint32_t stageCap = (uint32_t)(4 * sizeof(S.qe)) + (capWords - usedWords) * 4u + 4096u;
+            // (round 6) a stage that holds the whole stream keeps it (`fuse`): if no value went past it -- S.changed, which the
+            // synchronisation rounds leave zero -- the stage is the stream, and it leaves as a byte plane in the reconstruction's order
+            const bool wantPlane = a.plane.ok && stageCap >= nInt;
             const CdCellSink sink1{reinterpret_cast<uint32_t *>(res + nInit), GfCellMap::make(4, 1u, 2u), nInt, true,
                                    reinterpret_cast<uint8_t *>(S.qs), reinterpret_cast<uint8_t *>(cdLdsText + usedWords),
-                                   (uint32_t)(4 * sizeof(S.qe)), (uint32_t)(4 * sizeof(S.qe)) + (capWords - usedWords) * 4u + 4096u, 0u, false};
+                                   (uint32_t)(4 * sizeof(S.qe)), stageCap, 0u, wantPlane, wantPlane ? &S.changed : nullptr};
             static_assert(CD_NCUR == 1, "the stage over all four sync arrays needs one subsequence per thread");
 #ifdef GF_DIAG
             if (stamps && tid == 0) stamps[8] = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
             st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias, tok)
                            : cd_decode_stream(S, TG, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias);
+            if (wantPlane && st == GF_K_OK) {
+                // (cd_decode_stream ends behind a barrier: the stage and the flag are everybody's)
+                if (S.changed != 0u) sink1.expand(nInt);              // a wide value went to the int32 array: the bytes follow it there
+                else {
+                    // thread = (block parity, lane, quarter of its sixteen steps): consecutive threads write consecutive words.  Lane l's
+                    // column at step s is (s - 3 l) mod P, its row 2 + 64 ((s - 3 l) div P) + l; a word may reach across the end of a
+                    // period (its last cell is then column 2 of the lane's next row at most: P >= nC + 2 or the cells before are the tail)
+                    uint32_t *plane = reinterpret_cast<uint32_t *>(res + a.plane.offWords);
+                    const uint32_t l = ((uint32_t)tid >> 2) & 63u, kq = (uint32_t)tid & 3u, wI = nC - 4u;
+                    constexpr uint32_t BLOCKS_PER_TURN = DEC_THREADS / 256;
+                    int32_t c = (int32_t)(16u * ((uint32_t)tid >> 8) + 4u * kq) - 3 * (int32_t)l;
+                    uint32_t ph = 0;
+                    const int32_t PP = (int32_t)a.plane.P;
+                    for (uint32_t b = (uint32_t)tid >> 8; b < a.plane.nBlocks; b += BLOCKS_PER_TURN) {
+                        const uint32_t r = 2u + 64u * ph + l;
+                        const bool cur = r < nR && c + 3 >= 2 && c <= (int32_t)nC - 3;
+                        const bool next = r + 64u < nR && c + 3 >= PP + 2;           // (the word's last cell is column 2 of the lane's next row)
+                        if (cur || next) {
+                            const uint32_t rowBase = (r - 2u) * wI;
+                            uint32_t w = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int32_t cj = c + j;
+                                if (cur && cj >= 2 && cj <= (int32_t)nC - 3) w |= (uint32_t)*sink1.slot(rowBase + (uint32_t)(cj - 2)) << (8 * j);
+                                if (next && cj >= PP + 2) w |= (uint32_t)*sink1.slot(rowBase + 64u * wI + (uint32_t)(cj - PP - 2)) << (8 * j);
+                            }
+                            plane[(b * 64u + l) * 4u + kq] = w;
+                        }
+                        c += 16 * (int32_t)BLOCKS_PER_TURN;
+                        if (c >= (int32_t)a.plane.P) { c -= (int32_t)a.plane.P; ph++; }
+                    }
+                    if (tid == 0) a.coefs[t * 16 + GF_LSOP_FMT_WORD] = 1u;
+                }
+            }
         }
 #ifdef GF_DIAG
         if (stamps && tid == 0) stamps[14] = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -411,7 +452,7 @@ uint32_t gf_lsop_unpack_lds_text(int nRows, int nCols)
 hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,
                                   const uint32_t *lengths, int32_t *residuals, size_t resStride, uint32_t *coefs,
                                   int32_t *status, size_t nTiles, int nRows, int nCols, uint32_t ldsTextBytes, unsigned grid,
-                                  hipStream_t stream, const uint32_t *pre, uint32_t *debug, uint32_t *pre2)
+                                  hipStream_t stream, const uint32_t *pre, uint32_t *debug, uint32_t *pre2, bool planes)
 {
     if (nTiles == 0) return hipSuccess;
     if (pre && pre2) {
@@ -424,7 +465,7 @@ hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const u
         hipLaunchKernelGGL(k_lsop_head, dim3((unsigned)((nTiles + 63) / 64)), dim3(64), LH_LDS_BYTES, stream, h);
     }
     GfLsopUnpackArgs a{blob, blobBytes, offsets, slotStride, lengths, residuals, resStride, coefs, status, nTiles, nRows, nCols,
-                       ldsTextBytes, pre, pre2, debug};
+                       ldsTextBytes, pre, pre2, debug, planes ? gf_lsop_plane_geom((uint32_t)nRows, (uint32_t)nCols) : GfLsopPlaneGeom{}};
     static GfDynLdsOptIn opt;
     {
         const hipError_t e = gf_opt_in_dyn_lds(k_lsop_unpack2, ldsTextBytes + (sizeof(uint16_t) << CD_LUT_BITS), opt);
