@@ -264,39 +264,43 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
                                       hipStream_t stream, bool planes = false);    // planes: word GF_LSOP_FMT_WORD of a tile's
                                                                                    // coefficient record says where its interior residuals are
 // The interior residuals of a decoded tile as a BYTE PLANE in pipeline order (round 6).  k_lsop_reconstruct_plane walks a tile as
-// k_lsop_reconstruct_pipe does -- lane l takes rows 2 + l, 2 + 64 + l, ..., three steps behind lane l - 1, a new row every P steps --
-// and at step s = 16 b + k a lane wants the residual of ITS cell of that step.  k_lsop_unpack2 therefore leaves the residuals, which
-// it has in LDS as bytes anyway, in exactly that order: byte (b * 64 + l) * 16 + k of the plane belongs to lane l at step 16 b + k
-// (steps at which a lane has no interior cell are holes that nobody writes or looks at), so that a lane's sixteen residuals of a
-// round are ONE 16-byte load, a wave's 1 KB in a row -- where the int32 array cost four bytes per residual in 64-byte row pieces
-// on both sides (profiles/hbm_traffic.json of round 5: 1.28 GB written, 2.52 GB read for 0.93 GB of values).  The plane lies in
-// the tile's residual slot behind the initialisers (which stay int32); a tile with a residual outside -127..127 keeps the int32
-// array and the old kernels (word GF_LSOP_FMT_WORD of its coefficient record: 0 = int32 array, 1 = plane).
+// k_lsop_reconstruct_pipe does, with HALF a wave: lane l (0..31) takes rows 2 + l, 2 + 32 + l, ..., three steps behind lane l - 1, a
+// new row every P steps (two tiles share a wave) -- and at step s = 16 b + k a lane wants the residual of ITS cell of that step.
+// k_lsop_unpack2 therefore leaves the residuals, which it has in LDS as bytes anyway, in exactly that order: byte (b * 32 + l) * 16 + k
+// of the plane belongs to lane l at step 16 b + k (steps at which a lane has no interior cell are holes that nobody writes or looks
+// at), so that a lane's sixteen residuals of a round are ONE 16-byte load, a tile's 512 bytes in a row -- where the int32 array
+// cost four bytes per residual in 64-byte row pieces on both sides (profiles/hbm_traffic.json of round 5: 1.28 GB written, 2.52 GB
+// read for 0.93 GB of values).  The plane lies in the tile's residual slot behind the initialisers (which stay int32); a tile with a
+// residual outside -127..127 keeps the int32 array and the old kernels (word GF_LSOP_FMT_WORD of its coefficient record: 0 = int32
+// array, 1 = plane).
 constexpr uint32_t GF_LSOP_FMT_WORD = 14;
-constexpr uint32_t GF_LSOP_PIPE_MIN_P = 208;       // lane 63 starts 189 steps into a period; lane 0 reads 2 + 16 columns ahead of it
+constexpr uint32_t GF_LSOP_PLANE_LANES = 32;       // lanes per tile
+constexpr uint32_t GF_LSOP_PIPE_MIN_P = 112;       // lane 31 starts 93 steps into a period; lane 0 reads 2 + 16 columns ahead of it
+constexpr uint32_t GF_LSOP_PLANE_FRONT = 96;       // lanes 30 / 31 "write" their columns -93.. before they start: words nobody reads
 struct GfLsopPlaneGeom {
     uint32_t P;            // steps between two rows of a lane (a multiple of 16)
     uint32_t nPh;          // rows per lane
     uint32_t sEnd;         // the last step that produces a value
-    uint32_t nBlocks;      // 16-step blocks: the plane is nBlocks x 64 lanes x 16 bytes
+    uint32_t nBlocks;      // 16-step blocks: the plane is nBlocks x 32 lanes x 16 bytes
     uint32_t offWords;     // where the plane starts in the tile's residual slot (int32 words; a multiple of 4)
-    uint32_t ldsBytes;     // k_lsop_reconstruct_plane's LDS: lane 0's two rows above (interleaved, GF_LSOP_PLANE_FRONT words in front) + the rows' constants
+    uint32_t rowsWords;    // k_lsop_reconstruct_plane's LDS per tile: lane 0's two rows above (interleaved, GF_LSOP_PLANE_FRONT columns in front) ...
+    uint32_t ldsBytes;     // ... for the two tiles of a wave, + the wave's value stage (33 words per lane) and the rows' store descriptors
     bool ok;               // the shape takes the plane path at all
 };
-constexpr uint32_t GF_LSOP_PLANE_FRONT = 192;      // lanes 62 / 63 "write" their columns -186.. before they start: words nobody reads
 __host__ __device__ inline GfLsopPlaneGeom gf_lsop_plane_geom(uint32_t nR, uint32_t nC)
 {
     GfLsopPlaneGeom g{};
     if (nR < 6u || nC < 32u || nC > 4096u || nR > 4096u) return g;      // (narrow tiles: a row's two ends would share a round)
-    const uint32_t nInit = 4u * nR + 2u * nC - 9u, nInt = (nR - 2u) * (nC - 4u);
+    const uint32_t nInit = 4u * nR + 2u * nC - 9u, nInt = (nR - 2u) * (nC - 4u), L = GF_LSOP_PLANE_LANES;
     g.P = ((nC > GF_LSOP_PIPE_MIN_P ? nC : GF_LSOP_PIPE_MIN_P) + 15u) & ~15u;
-    g.nPh = (nR - 2u + 63u) / 64u;
-    const uint32_t nLast = nR - 2u - 64u * (g.nPh - 1u);
+    g.nPh = (nR - 2u + L - 1u) / L;
+    const uint32_t nLast = nR - 2u - L * (g.nPh - 1u);
     g.sEnd = (g.nPh - 1u) * g.P + 3u * (nLast - 1u) + nC - 1u;
     g.nBlocks = g.sEnd / 16u + 1u;
     g.offWords = (nInit + 3u) & ~3u;
-    g.ldsBytes = (2u * (GF_LSOP_PLANE_FRONT + g.P + 32u) + 4u * 64u * (g.nPh + 1u)) * 4u;
-    g.ok = (uint64_t)g.offWords * 4u + (uint64_t)g.nBlocks * 1024u <= ((uint64_t)nInit + nInt) * 4u && g.ldsBytes <= 64u * 1024u;
+    g.rowsWords = 2u * (GF_LSOP_PLANE_FRONT + g.P + 32u);
+    g.ldsBytes = (2u * g.rowsWords + 64u * 33u + 128u) * 4u;
+    g.ok = (uint64_t)g.offWords * 4u + (uint64_t)g.nBlocks * (L * 16u) <= ((uint64_t)nInit + nInt) * 4u && g.ldsBytes <= 64u * 1024u;
     return g;
 }
 hipError_t gf_launch_lsop_unpack2(const uint8_t *blob, size_t blobBytes, const uint64_t *offsets, size_t slotStride,

@@ -1932,201 +1932,248 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_p
 
 
 // ------------------------------------------------------------------------------------------------
-// k_lsop_reconstruct_plane (round 6): the pipeline of k_lsop_reconstruct_pipe for tiles whose interior residuals k_lsop_unpack2 left as
-// a byte plane in pipeline order (gvrs_kernels.h: GfLsopPlaneGeom).  What the old kernel spent per step -- 185 instructions, of which
-// the arithmetic of LsDecoder12.java:311-383 is about fifty -- went into moving data between the order the memory wants (rows) and the
+// k_lsop_reconstruct_plane (round 6): the pipeline of k_lsop_reconstruct_pipe for tiles whose residuals k_lsop_unpack2 left as a byte
+// plane in pipeline order (gvrs_kernels.h: GfLsopPlaneGeom).  What the old kernel spent per step -- 185 instructions, of which the
+// arithmetic of LsDecoder12.java:311-383 is about fifty -- went into moving data between the order the memory wants (rows) and the
 // order the pipeline wants (a lane a row, three steps apart): sixteen residual pieces in and sixteen value pieces out per round,
 // each with its own (row, column) arithmetic, through an LDS ring.  Here
-//   * a lane's sixteen residuals of a round are one 16-byte load of the plane (a wave: 1 KB in a row), taken apart with v_bfe_i32;
-//   * its sixteen values of a round stay in registers and leave as four 16-byte stores to its own row (a quad that a row's end or
-//     start cuts goes out cell by cell) -- no LDS ring, no transposition;
-//   * the windows hold the neighbours as FLOATS (a value is converted once, when it enters a window, not in each of the twelve
-//     products it takes part in) and the rounding is lsop_round_f32 (single precision, exact: the encoder's);
+//   * TWO TILES SHARE A WAVE, thirty-two lanes each: a pipeline of 64 lanes is 189 steps deep, so a lane cannot start a new row
+//     more often than every 208 steps -- on a 150-column tile its lanes idle for a quarter of every period and half of the first
+//     and the last one (517 steps per tile); with 32 lanes a period is max(nC, 112) steps: 693 steps per PAIR of such tiles;
+//   * a lane's sixteen residuals of a round are one 16-byte load of the plane, taken apart with v_bfe_i32 / SDWA;
+//   * EVERY cell of rows 2.. is "something the lane already has + a byte of the plane": an interior cell the rounded prediction +
+//     its residual (:311-351); the two tail cells and column 1 the triangle z1 + a2 - a1 + their residual (:353-383, :204-221);
+//     column 0 the cell above + its residual (:196-202) -- k_lsop_unpack2 puts those four initialisers of a row into the plane's
+//     holes at the row's ends, so there are no per-row constants to work out, keep or hand over;
+//   * the values wait in LDS (a word per lane and step, conflict-free) and leave every SECOND round as a lane's 128 bytes in a row:
+//     eight 16-byte stores to its own row (a quad that a row's end or start cuts goes out cell by cell).  Written four cells at a
+//     time as they came the same kernel took 0.87 ms instead of 0.41 without any store: 262,000 rows are open at once on the chip,
+//     a 128-byte line of each of them a quarter written for thousands of cycles -- the L2 (32 MB in all) wrote 2.7 GB back for 0.93;
+//   * a neighbour is converted to float and multiplied by the coefficients it will meet ONCE, when it enters the window (packed
+//     multiplies with the value on both halves), not in each of the five steps it takes part in; the rounding is the encoder's
+//     lsop_round_f32 (single precision, exact);
 //   * a lane's state is not guarded: what a lane computes while it is between two rows (or before its first) is never stored and
-//     reaches only cells of the lane below that are not stored either;
-//   * the rows' constants -- columns 0 and 1, the two tail residuals -- are worked out for the whole tile up front (scans down the
-//     rows) and wait in LDS; lane 0's rows above lie interleaved, so that its sixteen steps are eight 16-byte LDS reads.
-// Bytes: the old kernel read 2.5 GB and wrote 1.5 GB per 12,960 tiles of 120 x 150; this one reads the planes (0.44 GB with their
-// holes) and the initialisers.
+//     reaches only cells of the lane below that are not stored either; which of a round's sixteen steps is a row's column 0 and
+//     which its column nC - 2 is worked out once per round, not the column per step.
 // ------------------------------------------------------------------------------------------------
 #ifndef RECON_PLANE_WAVES
 #define RECON_PLANE_WAVES 4
 #endif
-constexpr uint32_t RP_FRONT = GF_LSOP_PLANE_FRONT;
+typedef float lsop_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t lsop_lds_u32;
+constexpr uint32_t RP_STAGE_STRIDE = 33;      // words per lane of the value stage: 32 steps + 1 (lanes of a step hit different banks)
 
 __global__ __launch_bounds__(64, RECON_PLANE_WAVES) void k_lsop_reconstruct_plane(GfLsopReconArgs a, GfLsopPlaneGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t rpLds[];
-    const uint32_t lane = threadIdx.x;
+    constexpr uint32_t L = GF_LSOP_PLANE_LANES;
+    const uint32_t lane = threadIdx.x, lam = lane & (L - 1u), half = lane / L;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
     const int32_t P = (int32_t)g.P;
-    uint32_t *const rowsAB = rpLds + 2u * RP_FRONT;                        // [P + 32][2]: {row r - 2, row r - 1} of lane 0's row, by column
-    GfU4 *const cst = reinterpret_cast<GfU4 *>(rpLds + 2u * (RP_FRONT + g.P + 32u));   // [64 (nPh + 1)]: columns 0 and 1, tail residuals of row 2 + i
-    const bool feeds = lane >= 62u;
+    // per tile of the pair: [FRONT + P + 32][2] words {row r - 2, row r - 1} of lane 0's row by column; then the wave's value stage
+    uint32_t *const rowsAB = rpLds + half * g.rowsWords + 2u * GF_LSOP_PLANE_FRONT;
+    lsop_lds_u32 *const stageAll = (lsop_lds_u32 *)(rpLds + 2u * g.rowsWords);
+    lsop_lds_u32 *const stage = stageAll + lane * RP_STAGE_STRIDE;
+    uint32_t *const desc = rpLds + 2u * g.rowsWords + 64u * RP_STAGE_STRIDE;             // [64][2]: see the even rounds
+    const bool head = lam == 0u, feeds = lam >= L - 2u;
+    const uint32_t nRounds = (g.nBlocks + 1u) & ~1u;                        // (an even number: the values leave every second round)
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
-        const uint32_t *cf = a.coefs + t * 16;
-        if (cf[GF_LSOP_FMT_WORD] != 1u) continue;                           // int32 residuals: the kernels above
-        if (a.inStatus && a.inStatus[t] != GF_K_OK) {
-            if (lane == 0) a.status[t] = a.inStatus[t];
-            continue;
-        }
-        const int32_t *__restrict__ res = a.residuals + t * a.resStride;
-        const uint8_t *__restrict__ plane = reinterpret_cast<const uint8_t *>(res + g.offWords);
-        int32_t *__restrict__ v = a.values + t * (size_t)nCells;
-        const uint32_t seed = cf[0];
-        float u[12];
+    for (size_t pair = blockIdx.x; 2 * pair < a.nTiles; pair += gridDim.x) {
+        // ---- the two tiles' rows 0 and 1, a tile after the other by the whole wave ----
+        bool okT[2];
 #pragma unroll
-        for (int i = 0; i < 12; i++) u[i] = __uint_as_float(cf[1 + i]);
-        GfU4 chunk = *reinterpret_cast<const GfU4 *>(plane + lane * 16u);
-
-        // rows 0 and 1 as prefix sums (LsDecoder12.unpackInitializers :186-221): to global memory and to lane 0's row buffers
-        {
-            uint32_t carry = seed;
-            if (lane == 0) { v[0] = (int32_t)seed; rowsAB[0] = seed; }
-            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
-                const uint32_t c = c0 + lane;
-                const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
-                const uint32_t incl = gf_wave_incl_scan(x) + carry;
-                if (c < nC) { v[c] = (int32_t)incl; rowsAB[2u * c] = incl; }
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        for (uint32_t hh = 0; hh < 2; hh++) {
+            const size_t t = 2 * pair + hh;
+            okT[hh] = t < a.nTiles && a.coefs[t * 16 + GF_LSOP_FMT_WORD] == 1u;     // (else: int32 residuals, the kernels above)
+            if (okT[hh] && a.inStatus && a.inStatus[t] != GF_K_OK) {
+                if (lane == 0) a.status[t] = a.inStatus[t];
+                okT[hh] = false;
+            }
+            if (!okT[hh]) continue;
+            const int32_t *__restrict__ res = a.residuals + t * a.resStride;
+            int32_t *__restrict__ v = a.values + t * (size_t)nCells;
+            uint32_t *const rows = rpLds + hh * g.rowsWords + 2u * GF_LSOP_PLANE_FRONT;
+            const uint32_t seed = a.coefs[t * 16];
+            // rows 0 and 1 as prefix sums (LsDecoder12.unpackInitializers :186-221): to global memory and to lane 0's row buffers
+            {
+                uint32_t carry = seed;
+                if (lane == 0) { v[0] = (int32_t)seed; rows[0] = seed; }
+                for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                    const uint32_t c = c0 + lane;
+                    const uint32_t x = c < nC ? (uint32_t)res[c - 1] : 0u;
+                    const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                    if (c < nC) { v[c] = (int32_t)incl; rows[2u * c] = incl; }
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+            }
+            const uint32_t v10 = seed + (uint32_t)res[nC - 1u];                    // v[1][0]
+            if (lane == 0) { v[nC] = (int32_t)v10; rows[1] = v10; }
+            {
+                uint32_t carry = v10 - seed;
+                const uint32_t base = nC - 1u + nR - 1u;
+                for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
+                    const uint32_t c = c0 + lane;
+                    const uint32_t x = c < nC ? (uint32_t)res[base + c - 1] : 0u;
+                    const uint32_t incl = gf_wave_incl_scan(x) + carry;
+                    const uint32_t val = incl + (c < nC ? rows[2u * c] : 0u);
+                    if (c < nC) { v[nC + c] = (int32_t)val; rows[2u * c + 1u] = val; }
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
             }
         }
-        const uint32_t v10 = seed + (uint32_t)res[nC - 1u];                    // v[1][0]
-        if (lane == 0) { v[nC] = (int32_t)v10; rowsAB[1] = v10; }
-        uint32_t v11 = 0;                                                      // v[1][1]
-        {
-            uint32_t carry = v10 - seed;
-            const uint32_t base = nC - 1u + nR - 1u;
-            for (uint32_t c0 = 1; c0 < nC; c0 += 64) {
-                const uint32_t c = c0 + lane;
-                const uint32_t x = c < nC ? (uint32_t)res[base + c - 1] : 0u;
-                const uint32_t incl = gf_wave_incl_scan(x) + carry;
-                const uint32_t val = incl + (c < nC ? rowsAB[2u * c] : 0u);
-                if (c < nC) { v[nC + c] = (int32_t)val; rowsAB[2u * c + 1u] = val; }
-                if (c0 == 1) v11 = (uint32_t)__builtin_amdgcn_readlane((int)val, 0);
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-        }
-        // columns 0 and 1 of the rows below are running sums down the rows; with the rows' tail residuals into LDS
-        {
-            uint32_t carry0 = v10, carry1 = v11 - v10;
-            const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
-            for (uint32_t pn = 0; pn <= g.nPh; pn++) {
-                const uint32_t r = 2u + 64u * pn + lane;
-                const bool rowValid = r < nR;
-                const uint32_t x0 = rowValid ? (uint32_t)res[base0 + r - 1u] : 0u;
-                const uint32_t x1 = rowValid ? (uint32_t)res[base1 + r - 2u] : 0u;
-                GfU4 k4;
-                k4.z = rowValid ? (uint32_t)res[tailBase + 2u * (r - 2u)] : 0u;
-                k4.w = rowValid ? (uint32_t)res[tailBase + 2u * (r - 2u) + 1u] : 0u;
-                const uint32_t i0 = gf_wave_incl_scan(x0) + carry0;
-                carry0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
-                const uint32_t i1 = gf_wave_incl_scan(x1) + carry1;
-                carry1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
-                k4.x = i0;
-                k4.y = i1 + i0;
-                cst[64u * pn + lane] = k4;
-            }
-        }
+        if (!okT[0] && !okT[1]) continue;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
 
-        float a0f = 0, a1f = 0, a2f = 0, a3f = 0, a4f = 0, b0f = 0, b1f = 0, b2f = 0, b3f = 0, b4f = 0, z1f = 0, z6f = 0;
-        uint32_t a1i = 0, a2i = 0, a3i = 0, a4i = 0, z1i = 0;
-        uint32_t colv0, colv1, t0, t1;
+        // ---- per lane: its tile (a half without a tile computes on the other one's and stores nothing) ----
+        const bool tileOk = half == 0u ? okT[0] : okT[1];
+        const size_t tMine = 2 * pair + (tileOk ? half : (okT[0] ? 0u : 1u));
+        const uint8_t *__restrict__ plane = reinterpret_cast<const uint8_t *>(a.residuals + tMine * a.resStride + g.offWords);
+        const uint32_t tileHalf = (uint32_t)(tMine - 2 * pair);
+        int32_t *const vPair = a.values + 2 * pair * (size_t)nCells;
+        lsop_f2 u43, u21, u6_, uBA, u98, u7_, u05;
         {
-            const GfU4 k4 = cst[lane];
-            colv0 = k4.x; colv1 = k4.y; t0 = k4.z; t1 = k4.w;
-        }
-        int32_t cB = -3 * (int32_t)lane;                   // the lane's column at the round's first step (negative: not started)
-        uint32_t ph = 0;                                   // its row: 2 + 64 ph + lane
-        for (uint32_t R = 0; R < g.nBlocks; R++) {
-            // the next round's residuals (the last round asks for its own again)
-            const GfU4 nxt = *reinterpret_cast<const GfU4 *>(plane + ((size_t)min(R + 1u, g.nBlocks - 1u) * 64u + lane) * 16u);
-            // lane 0's rows above, columns c0 + 2 .. c0 + 17 (c0: its column, a multiple of 16; it starts its rows with a round)
-            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane(cB);
-            if (c0 == 0u) {
-                // ... and columns 0 and 1 into its windows when it starts a row (the lanes below get theirs from the lane above)
-                const GfU4 w = *reinterpret_cast<const GfU4 *>(rowsAB);
-                if (lane == 0) {
-                    b3f = (float)(int32_t)w.x; a3i = w.y; a3f = (float)(int32_t)w.y;
-                    b4f = (float)(int32_t)w.z; a4i = w.w; a4f = (float)(int32_t)w.w;
-                }
-            }
-            uint32_t ra[16], rb[16];
+            const uint32_t *cf = a.coefs + tMine * 16;
+            float u[12];
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k += 2) {
-                const GfU4 w = *reinterpret_cast<const GfU4 *>(rowsAB + 2u * (c0 + 2u + k));
-                rb[k] = w.x; ra[k] = w.y; rb[k + 1] = w.z; ra[k + 1] = w.w;
+            for (int i = 0; i < 12; i++) u[i] = __uint_as_float(cf[1 + i]);
+            u43 = lsop_f2{u[4], u[3]}; u21 = lsop_f2{u[2], u[1]}; u6_ = lsop_f2{u[6], 0.0f};
+            uBA = lsop_f2{u[11], u[10]}; u98 = lsop_f2{u[9], u[8]}; u7_ = lsop_f2{u[7], 0.0f};
+            u05 = lsop_f2{u[0], u[5]};
+        }
+        GfU4 chunk = *reinterpret_cast<const GfU4 *>(plane + lam * 16u);
+
+        // products of the neighbours with the coefficients they will meet, by age (0: entered in this step).  Row above: a value is
+        // a4 (u4) when it enters, then a3 (u3), a2 (u2), a1 (u1), a0 (u6); two rows above: b4 (u11) ... b0 (u7)
+        lsop_f2 A43n = {0, 0}, A43o = {0, 0}, A21[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, B43n = {0, 0}, B43o = {0, 0}, B21[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        float A6[5] = {0, 0, 0, 0, 0}, B7[5] = {0, 0, 0, 0, 0};
+        lsop_f2 Z = {0, 0};                                // {u0 z1, u5 z1}: the second one is next step's u5 z6
+        float z6p = 0;
+        uint32_t a1i = 0, a2i = 0, a3i = 0, a4i = 0, z1i = 0;
+        // a neighbour of each of the two rows above enters (wave_shr:1; lanes 0 and 32 take theirs from the row buffers)
+        auto enter = [&](uint32_t raK, uint32_t rbK) {
+            uint32_t na = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z1i, 0x138, 0xf, 0xf, true);      // wave_shr:1
+            uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a2i, 0x138, 0xf, 0xf, true);
+            na = head ? raK : na;
+            nb = head ? rbK : nb;
+            a1i = a2i; a2i = a3i; a3i = a4i; a4i = na;
+            const float xa = (float)(int32_t)na, xb = (float)(int32_t)nb;
+            A43o = A43n; A43n = u43 * lsop_f2{xa, xa};
+            A21[3] = A21[2]; A21[2] = A21[1]; A21[1] = A21[0]; A21[0] = u21 * lsop_f2{xa, xa};
+            A6[4] = A6[3]; A6[3] = A6[2]; A6[2] = A6[1]; A6[1] = A6[0]; A6[0] = u6_.x * xa;
+            B43o = B43n; B43n = uBA * lsop_f2{xb, xb};
+            B21[3] = B21[2]; B21[2] = B21[1]; B21[1] = B21[0]; B21[0] = u98 * lsop_f2{xb, xb};
+            B7[4] = B7[3]; B7[3] = B7[2]; B7[2] = B7[1]; B7[1] = B7[0]; B7[0] = u7_.x * xb;
+        };
+        // lane 0's first row: columns 0 and 1 of rows 1 and 0 enter as they do in the two steps before a later row's start
+        {
+            const GfU4 w = *reinterpret_cast<const GfU4 *>(rowsAB);
+            enter(w.y, w.x);
+            enter(w.w, w.z);
+        }
+        int32_t cB = -3 * (int32_t)lam;                    // the lane's column at the round's first step (negative: not started)
+        uint32_t ph = 0;                                   // its row: 2 + 32 ph + lam
+        asm volatile("" : "+v"(chunk.x), "+v"(chunk.y), "+v"(chunk.z), "+v"(chunk.w));      // (waited for here, not inside the loop: see k == 2)
+        for (uint32_t R = 0; R < nRounds; R++) {
+            // the next round's residuals (the last rounds ask for the last block again)
+            GfU4 nxt = *reinterpret_cast<const GfU4 *>(plane + ((size_t)min(R + 1u, g.nBlocks - 1u) * L + lam) * 16u);
+            // lane 0's column (a multiple of 16: it starts its rows with a round); its rows above at columns c0 + 2 .. c0 + 17 -- in the
+            // round before it starts a row the last two are that row's columns 0 and 1
+            const int32_t c0 = __builtin_amdgcn_readfirstlane(cB);
+            const uint32_t cHi = c0 + 16 == P ? 0u : (uint32_t)(c0 + 16);
+            const bool wrapSoon = cB > P - 16;
+            // the steps of this round at which the lane is in column 0 / in column nC - 2 (anything else: none of the sixteen)
+            const int32_t kB0 = cB <= 1 ? -cB : P - cB, kT0 = (int32_t)nC - 2 - cB;
+            // where lanes 30 / 31 leave their values for lane 0's next row: they begin a row at step 10 / 13 of a round (3 l mod 16)
+            lsop_lds_u32 *feedLo = (lsop_lds_u32 *)(rowsAB + 2 * cB + (int32_t)(lam - (L - 2u)));
+            lsop_lds_u32 *feedHi = wrapSoon ? feedLo - 2 * P : feedLo;
+            lsop_lds_u32 *feedMid = lam == L - 2u ? feedHi : feedLo;
+            const bool odd = (R & 1u) != 0u;
+            lsop_lds_u32 *st = odd ? stage + 16 : stage;
+            asm volatile("" : "+v"(feedLo), "+v"(feedHi), "+v"(feedMid), "+v"(st));    // (a register each per round, the step in the offset field)
+            if (!odd) {
+                // where the lane's 32 values of this round and the next belong: its column now, its row (cells from the pair's first
+                // tile), whether that row and its next one exist -- for the lanes that will store them
+                const uint32_t r = 2u + L * ph + lam;
+                GfU2 d;
+                d.x = (uint32_t)cB;
+                d.y = (tileHalf * nCells + r * nC) | (tileOk && r < nR ? 1u << 30 : 0u) | (tileOk && r + L < nR ? 1u << 31 : 0u);
+                *reinterpret_cast<GfU2 *>(desc + 2u * lane) = d;
             }
-            // a lane that starts a row in this round takes over that row's columns 0 and 1; one that has started a row within the
-            // last sixteen steps its tail residuals (the row before's tail lies before its end, a row's own beyond its 30th column)
-            {
-                const bool wrapSoon = cB > P - 16;
-                const GfU4 k4 = cst[64u * (ph + (wrapSoon ? 1u : 0u)) + lane];
-                const bool needCol = wrapSoon || cB == 0, needTail = cB >= 0 && cB < 16;
-                colv0 = needCol ? k4.x : colv0;
-                colv1 = needCol ? k4.y : colv1;
-                t0 = needTail ? k4.z : t0;
-                t1 = needTail ? k4.w : t1;
-            }
-            uint32_t out[16];
+            uint32_t ra[4], rb[4];
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
-                const int32_t cw = cB + (int32_t)k;
-                const int32_t c = cw >= P ? cw - P : cw;
-                const uint32_t na = lsop_from_lane_above(ra[k], z1i);
-                const uint32_t nb = lsop_from_lane_above(rb[k], a2i);
-                a0f = a1f; a1f = a2f; a2f = a3f; a3f = a4f; a4f = (float)(int32_t)na;
-                b0f = b1f; b1f = b2f; b2f = b3f; b3f = b4f; b4f = (float)(int32_t)nb;
-                a1i = a2i; a2i = a3i; a3i = a4i; a4i = na;
-                float p = u[0] * z1f;
-                p = p + u[1] * a1f;
-                p = p + u[2] * a2f;
-                p = p + u[3] * a3f;
-                p = p + u[4] * a4f;
-                p = p + u[5] * z6f;
-                p = p + u[6] * a0f;
-                p = p + u[7] * b0f;
-                p = p + u[8] * b1f;
-                p = p + u[9] * b2f;
-                p = p + u[10] * b3f;
-                p = p + u[11] * b4f;
+                if ((k & 3u) == 0u) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j += 2) {
+                        const uint32_t col = k + j == 14u ? cHi : (uint32_t)(c0 + 2 + (int32_t)(k + j));
+                        const GfU4 w = *reinterpret_cast<const GfU4 *>(rowsAB + 2 * (int32_t)col);
+                        rb[j] = w.x; ra[j] = w.y; rb[j + 1] = w.z; ra[j + 1] = w.w;
+                    }
+                }
+                enter(ra[k & 3u], rb[k & 3u]);
+                float p = Z.x;                      // u0 z1
+                p = p + A21[3].y;                   // u1 a1
+                p = p + A21[2].x;                   // u2 a2
+                p = p + A43o.y;                     // u3 a3
+                p = p + A43n.x;                     // u4 a4
+                p = p + z6p;                        // u5 z6
+                p = p + A6[4];                      // u6 a0
+                p = p + B7[4];                      // u7 b0
+                p = p + B21[3].y;                   // u8 b1
+                p = p + B21[2].x;                   // u9 b2
+                p = p + B43o.y;                     // u10 b3
+                p = p + B43n.x;                     // u11 b4
                 const uint32_t word = k < 4 ? chunk.x : k < 8 ? chunk.y : k < 12 ? chunk.z : chunk.w;
                 const int32_t r8 = (int32_t)(word << (24u - 8u * (k & 3u))) >> 24;
-                const uint32_t interior = (uint32_t)lsop_round_f32(p) + (uint32_t)r8;              // LsDecoder12 :311-351
-                const uint32_t tail = (c == (int32_t)nC - 2 ? t0 : t1) + (z1i + a2i - a1i);       // :353-383
-                const uint32_t border = c == 0 ? colv0 : colv1;
-                const uint32_t val = c < 2 ? border : (c <= (int32_t)nC - 3 ? interior : tail);
-                z6f = z1f;
-                z1f = (float)(int32_t)val;
+                const bool isB0 = kB0 == (int32_t)k, isB1 = kB0 == (int32_t)k - 1, isT0 = kT0 == (int32_t)k, isT1 = kT0 == (int32_t)k - 1;
+                uint32_t base = (uint32_t)lsop_round_f32(p);                               // LsDecoder12 :311-351
+                if (isB1 || isT0 || isT1) base = z1i + a2i - a1i;                          // :353-383, :204-221
+                if (isB0) base = a2i;                                                      // :196-202
+                const uint32_t val = base + (uint32_t)r8;
+                z6p = Z.y;
+                Z = u05 * lsop_f2{(float)(int32_t)val, (float)(int32_t)val};
                 z1i = val;
-                out[k] = val;
-                if (feeds) rowsAB[2 * c + (int32_t)(lane - 62u)] = val;      // (c >= -189: the words in front of the buffers)
+                st[k] = val;
+                if (feeds) (k < 10 ? feedLo : k < 13 ? feedMid : feedHi)[2 * (int32_t)k] = val;
+                // (the next round's residuals have arrived before this round's stores are issued: loads and stores share a counter,
+                // and a wait for the load behind the stores would be a wait for the stores)
+                if (k == 2u) asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w));
             }
-            // the sixteen values to the lane's row: whole quads where the row covers them, single cells at its ends
-            {
-                const uint32_t r = 2u + 64u * ph + lane;
-                const bool vCur = r < nR, vNext = r + 64u < nR;
-                const uint32_t rowOff = r * nC;
+            if (odd) {
+                // the wave's 64 x 32 values of the two rounds to their rows: EIGHT LANES TAKE A ROW'S 128 BYTES (a store instruction: eight
+                // rows), four cells each -- the memory sees whole lines or two pieces of a line, not sixty-four 16-byte requests per
+                // instruction (that form, a lane storing its own row: 0.84 ms where the kernel without stores takes 0.42: the L2's
+                // request rate, not its bytes).  Whole quads where the row covers them, single cells at its ends
+                const uint32_t q = lane & 7u;
 #pragma unroll
-                for (uint32_t q = 0; q < 4; q++) {
-                    const int32_t cq = cB + 4 * (int32_t)q;
-                    const bool full = vCur && cq >= 0 && cq + 3 < (int32_t)nC;
-                    const bool part = !full && ((vCur && cq + 3 >= 0 && cq < (int32_t)nC) || (vNext && cq + 3 >= P));
-                    if (full) {
+                for (uint32_t i = 0; i < 8; i++) {
+                    const uint32_t rho = 8u * i + (lane >> 3);
+                    const GfU2 d = *reinterpret_cast<const GfU2 *>(desc + 2u * rho);
+                    const int32_t cq = (int32_t)d.x + 4 * (int32_t)q;
+                    const bool vCurQ = (d.y >> 30) & 1u, vNextQ = (d.y >> 31) != 0u;
+                    int32_t *const vrowQ = vPair + (d.y & 0x3fffffffu);
+#ifdef GF_RP_NO_STORES                                      // (experiment builds: what the kernel costs without its stores)
+                    const bool full = false, part = false;
+#else
+                    const bool full = vCurQ && cq >= 0 && cq + 3 < (int32_t)nC;
+                    const bool part = !full && ((vCurQ && cq + 3 >= 0 && cq < (int32_t)nC) || (vNextQ && cq + 3 >= P));
+#endif
+                    if (full || part) {
+                        const lsop_lds_u32 *src = stageAll + rho * RP_STAGE_STRIDE + 4u * q;
                         GfU4 x;
-                        x.x = out[4 * q]; x.y = out[4 * q + 1]; x.z = out[4 * q + 2]; x.w = out[4 * q + 3];
-                        *reinterpret_cast<GfU4 *>(v + rowOff + (uint32_t)cq) = x;
-                    } else if (part) {
+                        x.x = src[0]; x.y = src[1]; x.z = src[2]; x.w = src[3];
+                        if (full) *reinterpret_cast<GfU4 *>(vrowQ + cq) = x;
+                        else {
+                            const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; j++) {
-                            const int32_t cj = cq + (int32_t)j;
-                            const bool wr = cj >= P;
-                            const bool ok = wr ? vNext : (vCur && cj >= 0 && cj < (int32_t)nC);    // (a new row's first fifteen columns: inside it)
-                            const uint32_t at = wr ? rowOff + 64u * nC + (uint32_t)(cj - P) : rowOff + (uint32_t)cj;
-                            if (ok) v[at] = (int32_t)out[4 * q + j];
+                            for (int j = 0; j < 4; j++) {
+                                const int32_t cj = cq + j;
+                                const bool wr = cj >= P;
+                                const bool ok = wr ? vNextQ : (vCurQ && cj >= 0 && cj < (int32_t)nC);   // (a new row's first columns: inside it)
+                                int32_t *const at = wr ? vrowQ + (size_t)L * nC + (cj - P) : vrowQ + cj;
+                                if (ok) *at = (int32_t)xs[j];
+                            }
                         }
                     }
                 }
@@ -2135,7 +2182,7 @@ __global__ __launch_bounds__(64, RECON_PLANE_WAVES) void k_lsop_reconstruct_plan
             cB += 16;
             if (cB >= P) { cB -= P; ph++; }
         }
-        if (lane == 0) a.status[t] = GF_K_OK;
+        if (head && tileOk) a.status[2 * pair + half] = GF_K_OK;
     }
 }
 
@@ -2245,7 +2292,10 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
 {
     if (nTiles == 0) return hipSuccess;
     const GfLsopPlaneGeom g = gf_lsop_plane_geom((uint32_t)nRows, (uint32_t)nCols);
-    const size_t dynP = g.ldsBytes;
+#ifndef GF_RP_LDS_PAD
+#define GF_RP_LDS_PAD 0
+#endif
+    const size_t dynP = g.ldsBytes + GF_RP_LDS_PAD;             // (experiment builds: fewer waves per CU)
     planes = planes && g.ok;
     GfLsopReconArgs a{residuals, resStride, coefs, inStatus, values, status, nTiles, nRows, nCols, planes};
     if (planes) {
@@ -2254,7 +2304,8 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
         static GfDynLdsOptIn optPlane;
         const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct_plane, dynP, optPlane);
         if (e != hipSuccess) return e;
-        const unsigned gridP = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
+        const size_t pairs = (nTiles + 1) / 2;                   // two tiles to a wave
+        const unsigned gridP = (unsigned)(pairs < 65536 * 16 ? pairs : 65536 * 16);
         hipLaunchKernelGGL(k_lsop_reconstruct_plane, dim3(gridP), dim3(64), dynP, stream, a, g);
     }
     const size_t dyn = (64 * (2 * RECON_ROUND + 1) + 2 * (size_t)nCols) * 4;      // 64 staging rings + 2 row buffers

@@ -384,35 +384,54 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
             st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias, tok)
                            : cd_decode_stream(S, TG, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias);
             if (wantPlane && st == GF_K_OK) {
-                // (cd_decode_stream ends behind a barrier: the stage and the flag are everybody's)
+                // (cd_decode_stream ends behind a barrier: the stage and the flag are everybody's.)  The plane also carries the four
+                // initialisers of every row from the third on -- columns 0 and 1, the two tail cells: k_lsop_reconstruct_plane adds a byte
+                // of the plane to something it has in registers for EVERY cell -- so these must be bytes as well
+                const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
+                {
+                    bool wide = false;
+                    for (uint32_t i = (uint32_t)tid; i < 4u * (nR - 2u); i += DEC_THREADS) {
+                        const uint32_t q = i / (nR - 2u), k = i - q * (nR - 2u);
+                        const uint32_t at = q == 0u ? base0 + 1u + k : q == 1u ? base1 + k : tailBase + (q - 2u) * (nR - 2u) + k;
+                        wide = wide || (uint32_t)res[at] + 127u > 254u;
+                    }
+                    if (wide) S.changed = 1u;
+                }
+                __syncthreads();
                 if (S.changed != 0u) sink1.expand(nInt);              // a wide value went to the int32 array: the bytes follow it there
                 else {
-                    // thread = (block parity, lane, quarter of its sixteen steps): consecutive threads write consecutive words.  Lane l's
-                    // column at step s is (s - 3 l) mod P, its row 2 + 64 ((s - 3 l) div P) + l; a word may reach across the end of a
-                    // period (its last cell is then column 2 of the lane's next row at most: P >= nC + 2 or the cells before are the tail)
+                    // thread = (block of a turn, lane, quarter of its sixteen steps): consecutive threads write consecutive words.  Lane l's
+                    // column at step s is (s - 3 l) mod P, its row 2 + 32 ((s - 3 l) div P) + l; a word may reach across the end of a
+                    // period into the lane's next row
+                    constexpr uint32_t L = GF_LSOP_PLANE_LANES, BLOCK_WORDS = L * 4u, BLOCKS_PER_TURN = DEC_THREADS / BLOCK_WORDS;
+                    static_assert(DEC_THREADS % BLOCK_WORDS == 0 && 16u * BLOCKS_PER_TURN < GF_LSOP_PIPE_MIN_P, "a turn moves a lane by less than a period");
                     uint32_t *plane = reinterpret_cast<uint32_t *>(res + a.plane.offWords);
-                    const uint32_t l = ((uint32_t)tid >> 2) & 63u, kq = (uint32_t)tid & 3u, wI = nC - 4u;
-                    constexpr uint32_t BLOCKS_PER_TURN = DEC_THREADS / 256;
-                    int32_t c = (int32_t)(16u * ((uint32_t)tid >> 8) + 4u * kq) - 3 * (int32_t)l;
-                    uint32_t ph = 0;
+                    const uint32_t l = ((uint32_t)tid >> 2) & (L - 1u), kq = (uint32_t)tid & 3u, wI = nC - 4u;
                     const int32_t PP = (int32_t)a.plane.P;
-                    for (uint32_t b = (uint32_t)tid >> 8; b < a.plane.nBlocks; b += BLOCKS_PER_TURN) {
-                        const uint32_t r = 2u + 64u * ph + l;
-                        const bool cur = r < nR && c + 3 >= 2 && c <= (int32_t)nC - 3;
-                        const bool next = r + 64u < nR && c + 3 >= PP + 2;           // (the word's last cell is column 2 of the lane's next row)
+                    int32_t c = (int32_t)(16u * ((uint32_t)tid / BLOCK_WORDS) + 4u * kq) - 3 * (int32_t)l;
+                    uint32_t ph = 0;
+                    // the byte of cell (r, cc): an interior residual from the stage, an initialiser from the residual array
+                    auto cellByte = [&](uint32_t r, int32_t cc) -> uint32_t {
+                        if (cc >= 2 && cc <= (int32_t)nC - 3) return *sink1.slot((r - 2u) * wI + (uint32_t)(cc - 2));
+                        const uint32_t at = cc == 0 ? base0 + r - 1u : cc == 1 ? base1 + r - 2u : tailBase + 2u * (r - 2u) + (uint32_t)(cc - ((int32_t)nC - 2));
+                        return (uint32_t)res[at] & 0xffu;
+                    };
+                    for (uint32_t b = (uint32_t)tid / BLOCK_WORDS; b < a.plane.nBlocks; b += BLOCKS_PER_TURN) {
+                        const uint32_t r = 2u + L * ph + l;
+                        const bool cur = r < nR && c + 3 >= 0 && c < (int32_t)nC;
+                        const bool next = r + L < nR && c + 3 >= PP;
                         if (cur || next) {
-                            const uint32_t rowBase = (r - 2u) * wI;
                             uint32_t w = 0;
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
                                 const int32_t cj = c + j;
-                                if (cur && cj >= 2 && cj <= (int32_t)nC - 3) w |= (uint32_t)*sink1.slot(rowBase + (uint32_t)(cj - 2)) << (8 * j);
-                                if (next && cj >= PP + 2) w |= (uint32_t)*sink1.slot(rowBase + 64u * wI + (uint32_t)(cj - PP - 2)) << (8 * j);
+                                if (cur && cj >= 0 && cj < (int32_t)nC) w |= cellByte(r, cj) << (8 * j);
+                                if (next && cj >= PP) w |= cellByte(r + L, cj - PP) << (8 * j);
                             }
-                            plane[(b * 64u + l) * 4u + kq] = w;
+                            plane[(b * L + l) * 4u + kq] = w;
                         }
                         c += 16 * (int32_t)BLOCKS_PER_TURN;
-                        if (c >= (int32_t)a.plane.P) { c -= (int32_t)a.plane.P; ph++; }
+                        if (c >= PP) { c -= PP; ph++; }
                     }
                     if (tid == 0) a.coefs[t * 16 + GF_LSOP_FMT_WORD] = 1u;
                 }
