@@ -374,6 +374,18 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
             // (round 6) a stage that holds the whole stream keeps it (`fuse`): if no value went past it -- S.changed, which the
             // synchronisation rounds leave zero -- the stage is the stream, and it leaves as a byte plane in the reconstruction's order
             const bool wantPlane = a.plane.ok && stageCap >= nInt;
+            // ... and the four initialisers of every row from the third on, which the plane carries too (below): a thread asks for
+            // its one now -- the first stream is done, by k_lsop_head or behind this workgroup's barriers -- and the second stream's
+            // decode hides the round trip (tiles of more than 130 rows fetch them behind it)
+            const uint32_t nSpec = 4u * (nR - 2u);
+            const bool specEarly = wantPlane && nSpec <= (uint32_t)DEC_THREADS;
+            auto specAt = [&](uint32_t i) -> uint32_t {
+                const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
+                const uint32_t q = i / (nR - 2u), k = i - q * (nR - 2u);
+                return q == 0u ? base0 + 1u + k : q == 1u ? base1 + k : tailBase + (q - 2u) * (nR - 2u) + k;
+            };
+            uint32_t specMine = 0;
+            if (specEarly && (uint32_t)tid < nSpec) specMine = (uint32_t)res[specAt((uint32_t)tid)];
             const CdCellSink sink1{reinterpret_cast<uint32_t *>(res + nInit), GfCellMap::make(4, 1u, 2u), nInt, true,
                                    reinterpret_cast<uint8_t *>(S.qs), reinterpret_cast<uint8_t *>(cdLdsText + usedWords),
                                    (uint32_t)(4 * sizeof(S.qe)), stageCap, 0u, wantPlane, wantPlane ? &S.changed : nullptr};
@@ -387,13 +399,16 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
                 // (cd_decode_stream ends behind a barrier: the stage and the flag are everybody's.)  The plane also carries the four
                 // initialisers of every row from the third on -- columns 0 and 1, the two tail cells: k_lsop_reconstruct_plane adds a byte
                 // of the plane to something it has in registers for EVERY cell -- so these must be bytes as well
-                const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
+                // (they are fetched here, into the lookup table's words -- nothing decodes any more --, before the first word of the plane
+                // is stored: a load behind a store waits for the store, loads and stores share a counter)
+                uint8_t *const spec = reinterpret_cast<uint8_t *>(S.lut);         // [4][nR - 2]: column 0, column 1, the 2 (nR - 2) tail cells
+                static_assert(sizeof(S.lut) >= 4u * 2048u, "the rows' initialisers of a plane tile (nR <= 2048: gf_lsop_plane_geom) fit the lookup table");
                 {
                     bool wide = false;
-                    for (uint32_t i = (uint32_t)tid; i < 4u * (nR - 2u); i += DEC_THREADS) {
-                        const uint32_t q = i / (nR - 2u), k = i - q * (nR - 2u);
-                        const uint32_t at = q == 0u ? base0 + 1u + k : q == 1u ? base1 + k : tailBase + (q - 2u) * (nR - 2u) + k;
-                        wide = wide || (uint32_t)res[at] + 127u > 254u;
+                    for (uint32_t i = (uint32_t)tid; i < nSpec; i += DEC_THREADS) {
+                        const uint32_t x = specEarly ? specMine : (uint32_t)res[specAt(i)];
+                        wide = wide || x + 127u > 254u;
+                        spec[i] = (uint8_t)x;
                     }
                     if (wide) S.changed = 1u;
                 }
@@ -402,7 +417,8 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
                 else {
                     // thread = (block of a turn, lane, quarter of its sixteen steps): consecutive threads write consecutive words.  Lane l's
                     // column at step s is (s - 3 l) mod P, its row 2 + 32 ((s - 3 l) div P) + l; a word may reach across the end of a
-                    // period into the lane's next row
+                    // period into the lane's next row.  (A thread a lane's sixteen bytes -- one 16-byte store, a quarter of the turns --
+                    // was slower: 24 K cycles per tile against 17 K, tools/phase_cycles_lsop.py.)
                     constexpr uint32_t L = GF_LSOP_PLANE_LANES, BLOCK_WORDS = L * 4u, BLOCKS_PER_TURN = DEC_THREADS / BLOCK_WORDS;
                     static_assert(DEC_THREADS % BLOCK_WORDS == 0 && 16u * BLOCKS_PER_TURN < GF_LSOP_PIPE_MIN_P, "a turn moves a lane by less than a period");
                     uint32_t *plane = reinterpret_cast<uint32_t *>(res + a.plane.offWords);
@@ -410,26 +426,42 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
                     const int32_t PP = (int32_t)a.plane.P;
                     int32_t c = (int32_t)(16u * ((uint32_t)tid / BLOCK_WORDS) + 4u * kq) - 3 * (int32_t)l;
                     uint32_t ph = 0;
-                    // the byte of cell (r, cc): an interior residual from the stage, an initialiser from the residual array
+                    // the byte of cell (r, cc): an interior residual from the stage, an initialiser from the table above
                     auto cellByte = [&](uint32_t r, int32_t cc) -> uint32_t {
                         if (cc >= 2 && cc <= (int32_t)nC - 3) return *sink1.slot((r - 2u) * wI + (uint32_t)(cc - 2));
-                        const uint32_t at = cc == 0 ? base0 + r - 1u : cc == 1 ? base1 + r - 2u : tailBase + 2u * (r - 2u) + (uint32_t)(cc - ((int32_t)nC - 2));
-                        return (uint32_t)res[at] & 0xffu;
+                        const uint32_t at = cc == 0 ? r - 2u : cc == 1 ? nR - 2u + r - 2u : 2u * (nR - 2u) + 2u * (r - 2u) + (uint32_t)(cc - ((int32_t)nC - 2));
+                        return spec[at];
                     };
                     for (uint32_t b = (uint32_t)tid / BLOCK_WORDS; b < a.plane.nBlocks; b += BLOCKS_PER_TURN) {
                         const uint32_t r = 2u + L * ph + l;
-                        const bool cur = r < nR && c + 3 >= 0 && c < (int32_t)nC;
-                        const bool next = r + L < nR && c + 3 >= PP;
-                        if (cur || next) {
-                            uint32_t w = 0;
+                        uint32_t w = 0;                               // (a word of holes is written as well: whole lines leave the L2)
+                        if (r < nR && c >= 2 && c + 3 <= (int32_t)nC - 3) {
+                            // four interior cells of one row: four neighbouring bytes of the stage (two words and a funnel shift where
+                            // they lie in one of its two parts and not at its very end)
+                            const uint32_t rel = (r - 2u) * wI + (uint32_t)(c - 2);
+                            const bool inA = rel + 8u <= sink1.capA, inB = rel >= sink1.capA && rel + 8u <= sink1.cap;
+                            if (inA || inB) {
+                                const uint8_t *at = inA ? sink1.stA + rel : sink1.stB + (rel - sink1.capA);
+                                const uint32_t sh = (uint32_t)(uintptr_t)at & 3u;
+                                const uint32_t *p4 = reinterpret_cast<const uint32_t *>(at - sh);
+                                w = __builtin_amdgcn_alignbyte(p4[1], p4[0], sh);
+                            } else {
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const int32_t cj = c + j;
-                                if (cur && cj >= 0 && cj < (int32_t)nC) w |= cellByte(r, cj) << (8 * j);
-                                if (next && cj >= PP) w |= cellByte(r + L, cj - PP) << (8 * j);
+                                for (int j = 0; j < 4; j++) w |= (uint32_t)*sink1.slot(rel + (uint32_t)j) << (8 * j);
                             }
-                            plane[(b * L + l) * 4u + kq] = w;
+                        } else {
+                            const bool cur = r < nR && c + 3 >= 0 && c < (int32_t)nC;
+                            const bool next = r + L < nR && c + 3 >= PP;
+                            if (cur || next) {
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const int32_t cj = c + j;
+                                    if (cur && cj >= 0 && cj < (int32_t)nC) w |= cellByte(r, cj) << (8 * j);
+                                    if (next && cj >= PP) w |= cellByte(r + L, cj - PP) << (8 * j);
+                                }
+                            }
                         }
+                        plane[(b * L + l) * 4u + kq] = w;
                         c += 16 * (int32_t)BLOCKS_PER_TURN;
                         if (c >= PP) { c -= PP; ph++; }
                     }

@@ -24,5 +24,6 @@ hd = [(st[:, i + 1] - st[:, i]) & 0xFFFFFFFF for i in range(1, 5)]
 if np.median(hd[0]) < 10**8:
     print("k_lsop_head (a lane per tile): staging %d, tables %d, initialisers %d, second stream's lengths %d cycles (medians)" % tuple(np.median(x) for x in hd))
 print("between the streams           median %9d" % np.median((st[:, 8] - st[:, 5]) & 0xFFFFFFFF))
+print("plane dump (behind the values)  median %9d" % np.median((st[:, 14] - st[:, 13]) & 0xFFFFFFFF))
 tot = (st[:, 14] - st[:, 0]) & 0xFFFFFFFF
 print("whole tile (behind the text's staging) median %d p90 %d" % (np.median(tot), np.percentile(tot, 90)))
