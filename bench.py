@@ -478,7 +478,7 @@ ENC_KERNELS = {"canon": "k_canon_encode+k_canon_trees+k_canon_pack", "lsop": "k_
 # the decode side of the two Huffman codecs is a per-tile pre-pass kernel followed by the decode kernel: both are inside the
 # HIP-event bracket and both are named, so that the rocprofv3 averages under profiles/ add up to avg_launch_ms
 DEC_KERNELS = {"canon": "k_canon_parse_lengths+k_huffman_decode<4>+k_canon_decode",
-               "lsop": "k_canon_parse_lengths+k_lsop_unpack2+k_lsop_unpack16+k_lsop_unpack_m32+k_lsop_reconstruct+k_lsop_reconstruct_pipe+k_lsop_reconstruct16",
+               "lsop": "k_canon_parse_lengths+k_lsop_head+k_lsop_unpack2+k_lsop_unpack_m32+k_lsop_reconstruct_plane+k_lsop_reconstruct+k_lsop_reconstruct_pipe",
                "huffman": "k_huffman_parse_trees+k_huffman_decode"}
 SEEDS = {"dem1024": 1, "etopo1": 2, "etopo1_nulls": 2, "etopo1_rough": 2, "gebco_shard": 3, "gebco_full": 3, "float256_lsop": 5}
 

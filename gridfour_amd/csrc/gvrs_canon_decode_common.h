@@ -380,20 +380,26 @@ struct CdCellSink {                       // value k of a predictor's stream -> 
     uint32_t capA, cap;
     uint32_t halfBase;                    // stream position of the half being decoded
     bool fuse;                            // the staged values stay where they are: cd_fused_triangle() turns them into the tile
-    uint32_t *wide = nullptr;             // (round 6) an LDS word that learns whether any value went straight to its cell: a stage
-                                          // without such a value IS the stream (k_lsop_unpack2's byte plane)
+    // (round 6) WINDOWS: k_lsop_unpack2's byte plane.  window != 0 asks cd_decode_stream, for a text whose every value is a byte
+    // (a code without escapes and null, as many values as the reader expects), to stage the stream `window` values at a time -- each
+    // subsequence is decoded once per window it reaches into -- and to call its `afterPass(first value, count)` behind each window
+    // instead of writing anything to `o`; *windowed tells the caller which of the two happened
+    uint32_t window = 0;
+    uint32_t *windowed = nullptr;
+    bool windowOn = false;                // (set by cd_decode_stream)
     __device__ __forceinline__ uint8_t *slot(uint32_t rel) const { return rel < capA ? stA + rel : stB + (rel - capA); }
     __device__ __forceinline__ void put(uint32_t k, uint32_t v, bool on = true) const
     {
         // (two flat predicated stores: nested, the conditions cost the scalar unit more than the stores cost the SIMDs)
         const uint32_t rel = k - halfBase;
+        if (windowOn) {
+            if (on && rel < window) *slot(rel) = (uint8_t)v;
+            return;
+        }
         const bool ok = on && k < nStream && enabled;
         const bool small = v + 127u <= 254u, staged = rel < cap;
         if (ok && staged) *slot(rel) = small ? (uint8_t)v : (uint8_t)0x80;
-        if (ok && !(staged && small)) {
-            o[cell(k)] = v;
-            if (wide) *wide = 1u;
-        }
+        if (ok && !(staged && small)) o[cell(k)] = v;
     }
     __device__ __forceinline__ void expand(uint32_t count) const        // the whole workgroup, between two barriers
     {
@@ -585,12 +591,15 @@ __device__ __forceinline__ void cd_fused_triangle(CanonDec &S, const CdCellSink 
 // workgroup: code tables, subsequence synchronisation, then every value k handed to sink(k, value); values the
 // text does not supply up to fillTo are handed over as 0.  More than maxValues values is the reference's
 // ArrayIndexOutOfBounds.  Returns the tile status (same in all threads); *endPos = bit after the end-of-text symbol.
-template <class Text, class Sink>
+struct CdNoAfterPass {
+    __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {}
+};
+template <class Text, class Sink, class AfterPass = CdNoAfterPass>
 __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, uint32_t startBit, uint32_t endBit,
                                                     uint32_t maxValues, uint32_t fillTo, Sink sink, uint32_t *endPos,
                                                     uint32_t *nValuesOut, uint32_t *stamps = nullptr,
                                                     const uint32_t *pre = nullptr, uint32_t preBase = 0, uint16_t *tok = nullptr,
-                                                    int diagLimit = 0)
+                                                    int diagLimit = 0, const AfterPass afterPass = AfterPass())
 {
     // diagLimit (diagnostic build only): return early after the tables (1), the synchronisation pass (2), the value pass (3)
     // tok: 4 KB of LDS for the token table of the synchronisation pass (LDS text only), or null: the cursor walk
@@ -864,13 +873,14 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
     int32_t tileStatus = GF_K_OK;
     if (qStar == 0xFFFFFFFFu || S.qe[qStar] != CD_END_EOT) tileStatus = GF_K_ERR_BOUNDS;   // no end-of-text: read past the data
     // exclusive prefix sum of the counts over the chain
-    uint32_t base[CD_NCUR], firstHalf = 0;              // firstHalf: values of subsequences 0..DEC_THREADS-1 (uniform)
+    uint32_t base[CD_NCUR], myCount[CD_NCUR], firstHalf = 0;              // firstHalf: values of subsequences 0..DEC_THREADS-1 (uniform)
     {
         uint32_t running = 0;
 #pragma unroll
         for (int j = 0; j < CD_NCUR; j++) {
             const uint32_t q = tid + j * DEC_THREADS;
             const uint32_t c = (q < Q && q <= qStar) ? S.qc[q] : 0u;
+            myCount[j] = c;
             uint32_t tot;
             base[j] = running + block_excl_scan(c, S.waveSum, &tot);
             running += tot;
@@ -896,10 +906,17 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
 #pragma unroll
     for (int j = 0; j < CD_NCUR; j++) myStart[j] = tid + j * DEC_THREADS < Q ? S.qs[tid + j * DEC_THREADS] : 0u;
     if (CD_NCUR == 1) __syncthreads();
+    uint32_t nPass = 1;
+    if constexpr (Sink::kStaged) {
+        sink.windowOn = sink.window != 0u && plainOnly && nValues == fillTo;
+        if (sink.windowOn) nPass = (nValues + sink.window - 1u) / sink.window;
+        if (sink.windowed && tid == 0) *sink.windowed = sink.windowOn ? 1u : 0u;
+    }
+    for (uint32_t pass = 0; pass < nPass; pass++)
 #pragma unroll
     for (int j = 0; j < CD_NCUR; j++) {
         const uint32_t q = tid + j * DEC_THREADS;
-        if constexpr (Sink::kStaged) sink.halfBase = j == 0 ? 0u : min(firstHalf, nValues);
+        if constexpr (Sink::kStaged) sink.halfBase = sink.windowOn ? pass * sink.window : j == 0 ? 0u : min(firstHalf, nValues);
         {
             // One TOKEN per turn of a wave-uniform loop, everything by selects (round 3).  A value is PENDING from its symbol on until
             // the next token shows that no escape extends it any further (CanonicalHuffman.java:489-511): a plain symbol or the end
@@ -908,7 +925,11 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
             // value is text[-1]).  Two plain values that share a lookup go out together, the second one becomes the pending one.
             // (The loop used to be three nested per-lane loops -- values, escapes, pairs -- around a register cursor: the scalar
             // unit spent more instructions on their exec masks than the SIMDs on the values: 54 K SALU + 16 K branches per tile.)
-            const bool mine = q < Q && q <= qStar;
+            bool mine = q < Q && q <= qStar;
+            if constexpr (Sink::kStaged) {
+                // (a window's subsequences: those with a value in it)
+                if (sink.windowOn) mine = mine && base[j] < sink.halfBase + sink.window && base[j] + myCount[j] > sink.halfBase;
+            }
             const uint32_t Bq = T0 + q * unit, Bn = min(endBit, Bq + unit);
             const uint32_t bound = Bn == endBit ? 0xFFFFFFF0u : Bn;
             uint32_t k = base[j], a = mine ? (CD_NCUR == 1 ? myStart[j] : S.qs[q]) : 0u, v = 0;
@@ -965,7 +986,8 @@ __device__ __forceinline__ int32_t cd_decode_stream(CanonDec &S, const Text T, u
         }
         if constexpr (Sink::kStaged) {             // this half's small values wait in LDS: out with them, whole lines at a time
             __syncthreads();
-            if (!sink.fuse) sink.expand(j == 0 ? min(firstHalf, nValues) : nValues - min(firstHalf, nValues));
+            if (sink.windowOn) afterPass(sink.halfBase, min(sink.window, nValues - sink.halfBase));
+            else if (!sink.fuse) sink.expand(j == 0 ? min(firstHalf, nValues) : nValues - min(firstHalf, nValues));
             __syncthreads();
         }
     }

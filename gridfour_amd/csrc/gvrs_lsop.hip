@@ -1684,10 +1684,11 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct(G
 // next rows are worked out by the whole wave when lane 0 starts a row and taken over by a lane when it gets there, lane 0 alone
 // re-arms its windows from the two row buffers, and the staging pieces tell rows apart by whether a step lies before or behind a
 // row's start inside the current period.  For tiles of more than one band and at least 16 columns (the launcher decides).
+// (the body: tiles tFirst, tFirst + tStride, ... -- k_lsop_reconstruct_plane's first workgroups run it beside the plane tiles, round 6)
 template <int ROUND>
-__global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_pipe(GfLsopReconArgs a)
+__device__ __forceinline__ void lsop_reconstruct_pipe_tiles(const GfLsopReconArgs &a, uint32_t *const reconLds, const size_t tFirst,
+                                                            const size_t tStride)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t reconLds[];
     constexpr uint32_t RING = 2u * ROUND;
     constexpr uint32_t RS = RING + 1u;
     constexpr uint32_t RPI = 64u / ROUND;
@@ -1709,7 +1710,7 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_p
     const uint32_t sEnd = (nPh - 1u) * P + 3u * (nLast - 1u) + nC - 1u;       // the last step that produces a value
     const uint32_t nRounds = sEnd / ROUND + 1u;
 
-    for (size_t t = blockIdx.x; t < a.nTiles; t += gridDim.x) {
+    for (size_t t = tFirst; t < a.nTiles; t += tStride) {
         if (a.planes && a.coefs[t * 16 + GF_LSOP_FMT_WORD] == 1u) continue;
         if (a.inStatus && a.inStatus[t] != GF_K_OK) {
             if (lane == 0) a.status[t] = a.inStatus[t];
@@ -1931,6 +1932,14 @@ __global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_p
 }
 
 
+template <int ROUND>
+__global__ __launch_bounds__(64, RECON_WAVES_PER_SIMD) void k_lsop_reconstruct_pipe(GfLsopReconArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t reconLds[];
+    lsop_reconstruct_pipe_tiles<ROUND>(a, reconLds, blockIdx.x, gridDim.x);
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // k_lsop_reconstruct_plane (round 6): the pipeline of k_lsop_reconstruct_pipe for tiles whose residuals k_lsop_unpack2 left as a byte
 // plane in pipeline order (gvrs_kernels.h: GfLsopPlaneGeom).  What the old kernel spent per step -- 185 instructions, of which the
@@ -1963,9 +1972,16 @@ typedef float lsop_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint32_t lsop_lds_u32;
 constexpr uint32_t RP_STAGE_STRIDE = 33;      // words per lane of the value stage: 32 steps + 1 (lanes of a step hit different banks)
 
-__global__ __launch_bounds__(64, RECON_PLANE_WAVES) void k_lsop_reconstruct_plane(GfLsopReconArgs a, GfLsopPlaneGeom g)
+__global__ __launch_bounds__(64, RECON_PLANE_WAVES) void k_lsop_reconstruct_plane(GfLsopReconArgs a, GfLsopPlaneGeom g, uint32_t nOld)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t rpLds[];
+    // The first nOld workgroups take the tiles that are NOT planes (a residual beyond a byte: a handful of a terrain batch, if any)
+    // through the old pipeline, beside the plane tiles: in a launch of their own behind this one, three such tiles of 256 x 256 were
+    // 0.46 ms -- one wave's walk down a tile is a chain of 1,200 steps whatever else the chip does
+    if (blockIdx.x < nOld) {
+        lsop_reconstruct_pipe_tiles<RECON_ROUND>(a, rpLds, blockIdx.x, nOld);
+        return;
+    }
     constexpr uint32_t L = GF_LSOP_PLANE_LANES;
     const uint32_t lane = threadIdx.x, lam = lane & (L - 1u), half = lane / L;
     const uint32_t nR = (uint32_t)a.nRows, nC = (uint32_t)a.nCols, nCells = nR * nC;
@@ -1978,7 +1994,7 @@ __global__ __launch_bounds__(64, RECON_PLANE_WAVES) void k_lsop_reconstruct_plan
     const bool head = lam == 0u, feeds = lam >= L - 2u;
     const uint32_t nRounds = (g.nBlocks + 1u) & ~1u;                        // (an even number: the values leave every second round)
 
-    for (size_t pair = blockIdx.x; 2 * pair < a.nTiles; pair += gridDim.x) {
+    for (size_t pair = blockIdx.x - nOld; 2 * pair < a.nTiles; pair += gridDim.x - nOld) {
         // ---- the two tiles' rows 0 and 1, a tile after the other by the whole wave ----
         bool okT[2];
 #pragma unroll
@@ -2295,26 +2311,32 @@ hipError_t gf_launch_lsop_reconstruct(const int32_t *residuals, size_t resStride
 #ifndef GF_RP_LDS_PAD
 #define GF_RP_LDS_PAD 0
 #endif
-    const size_t dynP = g.ldsBytes + GF_RP_LDS_PAD;             // (experiment builds: fewer waves per CU)
     planes = planes && g.ok;
     GfLsopReconArgs a{residuals, resStride, coefs, inStatus, values, status, nTiles, nRows, nCols, planes};
+    const size_t dyn = (64 * (2 * RECON_ROUND + 1) + 2 * (size_t)nCols) * 4;      // 64 staging rings + 2 row buffers
+    const bool pipe = dyn <= 96 * 1024 && nRows > 66 && nCols >= 16;               // more than one band of 64 rows: one pipeline down the tile
     if (planes) {
-        // the tiles whose interior residuals lie as byte planes (k_lsop_unpack2 says which: terrain, all of them); the kernels
-        // below then find the others
+        // the tiles whose interior residuals lie as byte planes (k_lsop_unpack2 says which: terrain, nearly all of them), two to a
+        // wave; the others through the old pipeline by the launch's first workgroups where the shape is that kernel's, else by the
+        // kernels below
+        const size_t dynP = std::max<size_t>(g.ldsBytes + GF_RP_LDS_PAD, pipe ? dyn : 0);      // (GF_RP_LDS_PAD: experiment builds, fewer waves per CU)
         static GfDynLdsOptIn optPlane;
         const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct_plane, dynP, optPlane);
         if (e != hipSuccess) return e;
         const size_t pairs = (nTiles + 1) / 2;                   // two tiles to a wave
-        const unsigned gridP = (unsigned)(pairs < 65536 * 16 ? pairs : 65536 * 16);
-        hipLaunchKernelGGL(k_lsop_reconstruct_plane, dim3(gridP), dim3(64), dynP, stream, a, g);
+        // (a workgroup per tile, as in that kernel's own launch: one that finds a plane tile leaves at once -- a batch may as well
+        // consist of tiles with wide residuals only)
+        const unsigned nOld = pipe ? (unsigned)std::min<size_t>(nTiles, 65536 * 16) : 0u;
+        const unsigned gridP = nOld + (unsigned)(pairs < 65536 * 16 ? pairs : 65536 * 16);
+        hipLaunchKernelGGL(k_lsop_reconstruct_plane, dim3(gridP), dim3(64), dynP, stream, a, g, nOld);
+        if (pipe) return hipGetLastError();
     }
-    const size_t dyn = (64 * (2 * RECON_ROUND + 1) + 2 * (size_t)nCols) * 4;      // 64 staging rings + 2 row buffers
     if (dyn <= 96 * 1024) {
         static GfDynLdsOptIn opt;
         const hipError_t e = gf_opt_in_dyn_lds(k_lsop_reconstruct<RECON_ROUND>, dyn, opt);
         if (e != hipSuccess) return e;
         const unsigned grid = (unsigned)(nTiles < 65536 * 16 ? nTiles : 65536 * 16);
-        if (nRows > 66 && nCols >= 16) {                        // more than one band of 64 rows: one pipeline down the tile
+        if (pipe) {
             static GfDynLdsOptIn optPipe;
             const hipError_t e2 = gf_opt_in_dyn_lds(k_lsop_reconstruct_pipe<RECON_ROUND>, dyn, optPipe);
             if (e2 != hipSuccess) return e2;

@@ -370,75 +370,95 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
             // subsequence per thread: dead by then), the token table and the unused end of the text buffer; what does not fit goes straight out
             // ... and the part of the text buffer this packing does not fill (the buffer is sized for 3/4 byte per cell)
             const uint32_t usedWords = textInLds ? min(needWords, capWords) : 0u;
-            const uint32_t stageCap = (uint32_t)(4 * sizeof(S.qe)) + (capWords - usedWords) * 4u + 4096u;
-            // (round 6) a stage that holds the whole stream keeps it (`fuse`): if no value went past it -- S.changed, which the
-            // synchronisation rounds leave zero -- the stage is the stream, and it leaves as a byte plane in the reconstruction's order
-            const bool wantPlane = a.plane.ok && stageCap >= nInt;
-            // ... and the four initialisers of every row from the third on, which the plane carries too (below): a thread asks for
-            // its one now -- the first stream is done, by k_lsop_head or behind this workgroup's barriers -- and the second stream's
-            // decode hides the round trip (tiles of more than 130 rows fetch them behind it)
-            const uint32_t nSpec = 4u * (nR - 2u);
-            const bool specEarly = wantPlane && nSpec <= (uint32_t)DEC_THREADS;
+            // (round 6) THE BYTE PLANE.  A tile whose second stream holds bytes only (a code without escapes: cd_decode_stream decides)
+            // and whose rows' initialisers -- columns 0 and 1, the two tail cells of every row from the third on -- are bytes as well
+            // leaves as a plane in the reconstruction's pipeline order (gvrs_kernels.h): k_lsop_reconstruct_plane adds a byte of it to
+            // something it has in registers for EVERY cell of those rows.  The initialisers wait in the last bytes of the token
+            // table's words (the stage ends in front of them); the stream is staged a WINDOW of whole rows at a time -- one window
+            // where it fits (terrain tiles of 120 x 150: 17,228 values), three for 256 x 256 --, and behind each window its rows go
+            // to the plane.
+            const uint32_t nSpec = 4u * (nR - 2u), specRoom = a.plane.ok ? (nSpec + 15u) & ~15u : 0u;
+            const uint32_t stageCap = (uint32_t)(4 * sizeof(S.qe)) + (capWords - usedWords) * 4u + 4096u - specRoom;
+            uint8_t *const spec = reinterpret_cast<uint8_t *>(cdLdsText + capWords) + 4096u - specRoom;   // [4][nR - 2]: column 0, column 1, the 2 (nR - 2) tail cells
+            const uint32_t wI = nC - 4u;
+            uint32_t window = 0, specMine = 0;
             auto specAt = [&](uint32_t i) -> uint32_t {
                 const uint32_t base0 = nC - 1u, base1 = 2u * (nC - 1u) + nR - 1u, tailBase = base1 + nR - 2u;
                 const uint32_t q = i / (nR - 2u), k = i - q * (nR - 2u);
                 return q == 0u ? base0 + 1u + k : q == 1u ? base1 + k : tailBase + (q - 2u) * (nR - 2u) + k;
             };
-            uint32_t specMine = 0;
-            if (specEarly && (uint32_t)tid < nSpec) specMine = (uint32_t)res[specAt((uint32_t)tid)];
-            const CdCellSink sink1{reinterpret_cast<uint32_t *>(res + nInit), GfCellMap::make(4, 1u, 2u), nInt, true,
-                                   reinterpret_cast<uint8_t *>(S.qs), reinterpret_cast<uint8_t *>(cdLdsText + usedWords),
-                                   (uint32_t)(4 * sizeof(S.qe)), stageCap, 0u, wantPlane, wantPlane ? &S.changed : nullptr};
-            static_assert(CD_NCUR == 1, "the stage over all four sync arrays needs one subsequence per thread");
-#ifdef GF_DIAG
-            if (stamps && tid == 0) stamps[8] = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
-            st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias, tok)
-                           : cd_decode_stream(S, TG, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias);
-            if (wantPlane && st == GF_K_OK) {
-                // (cd_decode_stream ends behind a barrier: the stage and the flag are everybody's.)  The plane also carries the four
-                // initialisers of every row from the third on -- columns 0 and 1, the two tail cells: k_lsop_reconstruct_plane adds a byte
-                // of the plane to something it has in registers for EVERY cell -- so these must be bytes as well
-                // (they are fetched here, into the lookup table's words -- nothing decodes any more --, before the first word of the plane
-                // is stored: a load behind a store waits for the store, loads and stores share a counter)
-                uint8_t *const spec = reinterpret_cast<uint8_t *>(S.lut);         // [4][nR - 2]: column 0, column 1, the 2 (nR - 2) tail cells
-                static_assert(sizeof(S.lut) >= 4u * 2048u, "the rows' initialisers of a plane tile (nR <= 2048: gf_lsop_plane_geom) fit the lookup table");
-                {
-                    bool wide = false;
-                    for (uint32_t i = (uint32_t)tid; i < nSpec; i += DEC_THREADS) {
-                        const uint32_t x = specEarly ? specMine : (uint32_t)res[specAt(i)];
-                        wide = wide || x + 127u > 254u;
-                        spec[i] = (uint8_t)x;
-                    }
-                    if (wide) S.changed = 1u;
+            if (a.plane.ok) {
+                // (the first stream is done, by k_lsop_head or behind this workgroup's barriers.  The table itself is written behind
+                // the second stream's synchronisation pass, whose token table lies there: a thread keeps its first initialiser)
+                bool wide = false;
+                for (uint32_t i = (uint32_t)tid; i < nSpec; i += DEC_THREADS) {
+                    const uint32_t x = (uint32_t)res[specAt(i)];
+                    wide = wide || x + 128u > 255u;
+                    if (i == (uint32_t)tid) specMine = x;
                 }
-                __syncthreads();
-                if (S.changed != 0u) sink1.expand(nInt);              // a wide value went to the int32 array: the bytes follow it there
-                else {
-                    // thread = (block of a turn, lane, quarter of its sixteen steps): consecutive threads write consecutive words.  Lane l's
-                    // column at step s is (s - 3 l) mod P, its row 2 + 32 ((s - 3 l) div P) + l; a word may reach across the end of a
-                    // period into the lane's next row.  (A thread a lane's sixteen bytes -- one 16-byte store, a quarter of the turns --
-                    // was slower: 24 K cycles per tile against 17 K, tools/phase_cycles_lsop.py.)
-                    constexpr uint32_t L = GF_LSOP_PLANE_LANES, BLOCK_WORDS = L * 4u, BLOCKS_PER_TURN = DEC_THREADS / BLOCK_WORDS;
-                    static_assert(DEC_THREADS % BLOCK_WORDS == 0 && 16u * BLOCKS_PER_TURN < GF_LSOP_PIPE_MIN_P, "a turn moves a lane by less than a period");
-                    uint32_t *plane = reinterpret_cast<uint32_t *>(res + a.plane.offWords);
-                    const uint32_t l = ((uint32_t)tid >> 2) & (L - 1u), kq = (uint32_t)tid & 3u, wI = nC - 4u;
-                    const int32_t PP = (int32_t)a.plane.P;
-                    int32_t c = (int32_t)(16u * ((uint32_t)tid / BLOCK_WORDS) + 4u * kq) - 3 * (int32_t)l;
-                    uint32_t ph = 0;
-                    // the byte of cell (r, cc): an interior residual from the stage, an initialiser from the table above
-                    auto cellByte = [&](uint32_t r, int32_t cc) -> uint32_t {
-                        if (cc >= 2 && cc <= (int32_t)nC - 3) return *sink1.slot((r - 2u) * wI + (uint32_t)(cc - 2));
-                        const uint32_t at = cc == 0 ? r - 2u : cc == 1 ? nR - 2u + r - 2u : 2u * (nR - 2u) + 2u * (r - 2u) + (uint32_t)(cc - ((int32_t)nC - 2));
-                        return spec[at];
-                    };
-                    for (uint32_t b = (uint32_t)tid / BLOCK_WORDS; b < a.plane.nBlocks; b += BLOCKS_PER_TURN) {
-                        const uint32_t r = 2u + L * ph + l;
-                        uint32_t w = 0;                               // (a word of holes is written as well: whole lines leave the L2)
-                        if (r < nR && c >= 2 && c + 3 <= (int32_t)nC - 3) {
-                            // four interior cells of one row: four neighbouring bytes of the stage (two words and a funnel shift where
-                            // they lie in one of its two parts and not at its very end)
-                            const uint32_t rel = (r - 2u) * wI + (uint32_t)(c - 2);
+#ifndef GF_LSOP_WINDOW_DIV
+#define GF_LSOP_WINDOW_DIV 1                                   // (experiment builds: several windows where one would do)
+#endif
+                if (!__syncthreads_or(wide ? 1 : 0)) window = min(nInt, stageCap / GF_LSOP_WINDOW_DIV / wI * wI);
+            }
+            CdCellSink sink1{reinterpret_cast<uint32_t *>(res + nInit), GfCellMap::make(4, 1u, 2u), nInt, true,
+                             reinterpret_cast<uint8_t *>(S.qs), reinterpret_cast<uint8_t *>(cdLdsText + usedWords),
+                             (uint32_t)(4 * sizeof(S.qe)), stageCap, 0u, false};
+            sink1.window = window;
+            sink1.windowed = &S.changed;
+            static_assert(CD_NCUR == 1, "the stage over all four sync arrays needs one subsequence per thread");
+            // the rows of a window to the plane (the whole workgroup, between two barriers): values lo .. lo + count - 1 of the stream =
+            // rows 2 + lo / wI .. of the tile lie in the stage.  thread = (block of a turn, lane, quarter of its sixteen steps):
+            // consecutive threads write consecutive words.  Lane l's column at step s is (s - 3 l) mod P, its row 2 + 32 ((s - 3 l)
+            // div P) + l; a word may reach across the end of a period into the lane's next row, but it holds INTERIOR cells of one row
+            // only (five steps lie between a row's last interior cell and the next row's first): that row's window writes it, a word
+            // without any the window of its first row; a word of holes is written where one window is all (whole lines leave the L2).
+            // (A thread a lane's sixteen bytes -- one 16-byte store, a quarter of the turns -- was slower: 24 K cycles per tile against 17 K.)
+            auto dumpRows = [&](uint32_t lo, uint32_t count) {
+#ifdef GF_DIAG
+                const uint32_t tDump = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+                if (lo == 0u) {                                                           // (before the first word of the plane is stored)
+                    for (uint32_t i = (uint32_t)tid; i < nSpec; i += DEC_THREADS) spec[i] = (uint8_t)(i == (uint32_t)tid ? specMine : (uint32_t)res[specAt(i)]);
+                    __syncthreads();
+                }
+                constexpr uint32_t L = GF_LSOP_PLANE_LANES, BLOCK_WORDS = L * 4u, BLOCKS_PER_TURN = DEC_THREADS / BLOCK_WORDS;
+                static_assert(DEC_THREADS % BLOCK_WORDS == 0 && 16u * BLOCKS_PER_TURN < GF_LSOP_PIPE_MIN_P, "a turn moves a lane by less than a period");
+                const uint32_t rLo = 2u + lo / wI, rHi = rLo + count / wI;                 // the window's rows
+                const bool all = count == nInt;
+                uint32_t *plane = reinterpret_cast<uint32_t *>(res + a.plane.offWords);
+                const uint32_t l = ((uint32_t)tid >> 2) & (L - 1u), kq = (uint32_t)tid & 3u;
+                const int32_t PP = (int32_t)a.plane.P;
+                // (one window of several: a lane's rows inside the window, i.e. the blocks from the period of its first such row to the
+                // period behind its last one -- the words of holes between the rows are then not written at all)
+                uint32_t ph = 0, bFrom = 0, bTo = a.plane.nBlocks;
+                if (!all) {
+                    const uint32_t first = rLo > 2u + l ? (rLo - 2u - l + L - 1u) / L : 0u;      // the lane's first period with a row >= rLo
+                    const uint32_t beyond = rHi > 2u + l ? (rHi - 2u - l + L - 1u) / L : 0u;     // ... with a row >= rHi
+                    ph = first > 0u ? first - 1u : 0u;              // (a word of the period before may reach into the row)
+                    bFrom = (ph * a.plane.P + 3u * l) / 16u;
+                    bTo = min(bTo, (beyond * a.plane.P + 3u * l + 15u) / 16u + 1u);
+                    if (first >= beyond) bTo = 0;
+                }
+                bFrom = bFrom / BLOCKS_PER_TURN * BLOCKS_PER_TURN + (uint32_t)tid / BLOCK_WORDS;
+                int32_t c = (int32_t)(16u * bFrom + 4u * kq) - (int32_t)(3u * l + ph * a.plane.P);
+                if (c < 0 && ph > 0u) { c += PP; ph--; }
+                // the byte of cell (r, cc): an interior residual from the stage, an initialiser from the table above
+                auto cellByte = [&](uint32_t r, int32_t cc) -> uint32_t {
+                    if (cc >= 2 && cc <= (int32_t)nC - 3) return *sink1.slot((r - 2u) * wI + (uint32_t)(cc - 2) - lo);
+                    const uint32_t at = cc == 0 ? r - 2u : cc == 1 ? nR - 2u + r - 2u : 2u * (nR - 2u) + 2u * (r - 2u) + (uint32_t)(cc - ((int32_t)nC - 2));
+                    return spec[at];
+                };
+                for (uint32_t b = bFrom; b < bTo; b += BLOCKS_PER_TURN) {
+                    const uint32_t r = 2u + L * ph + l;
+                    uint32_t w = 0;
+                    bool mine = all;
+                    if (r < nR && c >= 2 && c + 3 <= (int32_t)nC - 3) {
+                        // four interior cells of one row: four neighbouring bytes of the stage (two words and a funnel shift where
+                        // they lie in one of its two parts and not at its very end)
+                        mine = mine || (r >= rLo && r < rHi);
+                        if (mine) {
+                            const uint32_t rel = (r - 2u) * wI + (uint32_t)(c - 2) - lo;
                             const bool inA = rel + 8u <= sink1.capA, inB = rel >= sink1.capA && rel + 8u <= sink1.cap;
                             if (inA || inB) {
                                 const uint8_t *at = inA ? sink1.stA + rel : sink1.stB + (rel - sink1.capA);
@@ -449,25 +469,39 @@ __global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArg
 #pragma unroll
                                 for (int j = 0; j < 4; j++) w |= (uint32_t)*sink1.slot(rel + (uint32_t)j) << (8 * j);
                             }
-                        } else {
-                            const bool cur = r < nR && c + 3 >= 0 && c < (int32_t)nC;
-                            const bool next = r + L < nR && c + 3 >= PP;
-                            if (cur || next) {
+                        }
+                    } else {
+                        const bool cur = r < nR && c + 3 >= 0 && c < (int32_t)nC;
+                        const bool next = r + L < nR && c + 3 >= PP;
+                        if (!all) {
+                            const bool curInt = cur && c + 3 >= 2 && c <= (int32_t)nC - 3, nextInt = next && c + 3 >= PP + 2;
+                            const uint32_t owner = curInt ? r : nextInt ? r + L : cur ? r : next ? r + L : 0u;
+                            mine = owner >= rLo && owner < rHi;
+                        }
+                        if (mine && (cur || next)) {
 #pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    const int32_t cj = c + j;
-                                    if (cur && cj >= 0 && cj < (int32_t)nC) w |= cellByte(r, cj) << (8 * j);
-                                    if (next && cj >= PP) w |= cellByte(r + L, cj - PP) << (8 * j);
-                                }
+                            for (int j = 0; j < 4; j++) {
+                                const int32_t cj = c + j;
+                                if (cur && cj >= 0 && cj < (int32_t)nC) w |= cellByte(r, cj) << (8 * j);
+                                if (next && cj >= PP) w |= cellByte(r + L, cj - PP) << (8 * j);
                             }
                         }
-                        plane[(b * L + l) * 4u + kq] = w;
-                        c += 16 * (int32_t)BLOCKS_PER_TURN;
-                        if (c >= PP) { c -= PP; ph++; }
                     }
-                    if (tid == 0) a.coefs[t * 16 + GF_LSOP_FMT_WORD] = 1u;
+                    if (mine) plane[(b * L + l) * 4u + kq] = w;
+                    c += 16 * (int32_t)BLOCKS_PER_TURN;
+                    if (c >= PP) { c -= PP; ph++; }
                 }
-            }
+#ifdef GF_DIAG
+                if (stamps && tid == 0) stamps[15] = (lo == 0u ? 0u : stamps[15]) + ((uint32_t)__builtin_amdgcn_s_memtime() - tDump);   // wave 0's share
+#endif
+            };
+#ifdef GF_DIAG
+            if (stamps && tid == 0) stamps[8] = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+            st = textInLds ? cd_decode_stream(S, TL, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias, tok, 0, dumpRows)
+                           : cd_decode_stream(S, TG, pos, endBit, nInt, nInt, sink1, &pos, &nv, stamps ? stamps + 8 : nullptr, pre2, bias, nullptr, 0, dumpRows);
+            // (cd_decode_stream ends behind a barrier)
+            if (st == GF_K_OK && window != 0u && S.changed == 1u && tid == 0) a.coefs[t * 16 + GF_LSOP_FMT_WORD] = 1u;
         }
 #ifdef GF_DIAG
         if (stamps && tid == 0) stamps[14] = (uint32_t)__builtin_amdgcn_s_memtime();

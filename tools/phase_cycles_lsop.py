@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gridfour_amd
 from gridfour_amd import DeviceBuffer, DeviceTileBatch, lib
-nt, n_rows, n_cols = 12960, 120, 150
+nt, n_rows, n_cols = (int(sys.argv[3]), int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 3 else (12960, 120, 150)
 ctx = gridfour_amd.GvrsHipContext(0)
 b = DeviceTileBatch(ctx, n_rows, n_cols, nt, slot_stride=(2 * n_rows * n_cols + 1024 + 15) // 16 * 16, codec="lsop")
 b.synth_dem(0x9E3779B97F4A7C15 + 2, 144)
@@ -24,6 +24,6 @@ hd = [(st[:, i + 1] - st[:, i]) & 0xFFFFFFFF for i in range(1, 5)]
 if np.median(hd[0]) < 10**8:
     print("k_lsop_head (a lane per tile): staging %d, tables %d, initialisers %d, second stream's lengths %d cycles (medians)" % tuple(np.median(x) for x in hd))
 print("between the streams           median %9d" % np.median((st[:, 8] - st[:, 5]) & 0xFFFFFFFF))
-print("plane dump (behind the values)  median %9d" % np.median((st[:, 14] - st[:, 13]) & 0xFFFFFFFF))
+print("plane dump (wave 0, inside the value passes)  median %9d" % np.median(st[:, 15]))
 tot = (st[:, 14] - st[:, 0]) & 0xFFFFFFFF
 print("whole tile (behind the text's staging) median %d p90 %d" % (np.median(tot), np.percentile(tot, 90)))
