@@ -351,6 +351,9 @@ gf_status gf_lsop12_encode_batch_i32_dev_ex(gf_context *ctx, void *stream, int c
                                             size_t n_tiles, const int32_t *d_values, int flags, uint8_t *d_out,
                                             size_t slot_stride, uint32_t *d_lengths, int32_t *d_status, int32_t *d_residuals,
                                             size_t res_stride, uint32_t *d_coefs, int32_t *d_scratch_status);
+/* (the work buffers' contents behind a decode are the library's business: a tile's slot of d_residuals holds its initialisers and either
+   its interior residuals as ints or -- tiles whose residuals are all bytes -- a byte plane in the order the reconstruction consumes it; words
+   13 .. 15 of a tile's 16 words of d_coefs are the library's too) */
 gf_status gf_lsop12_decode_batch_i32_dev(gf_context *ctx, void *stream, int n_rows, int n_cols, size_t n_tiles,
                                          const uint8_t *d_blob, size_t blob_bytes, const uint64_t *d_offsets,
                                          size_t slot_stride, const uint32_t *d_lengths, int32_t *d_values,
