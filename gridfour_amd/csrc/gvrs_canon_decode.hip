@@ -351,7 +351,13 @@ hipError_t gf_launch_canon_parse_lengths(const uint8_t *blob, size_t blobBytes, 
                                          hipStream_t stream, uint32_t *clearFlags)
 {
     if (nTiles == 0) return hipSuccess;
-    if (gf_prepass_tiles_per_wave(nTiles) == 1u)
+#ifndef GF_CANON_PREPASS_ONE_LANE_MAX
+#define GF_CANON_PREPASS_ONE_LANE_MAX 3000       // where the code lengths' walk changes from a wave to a lane per tile (round 6, decode ms of
+                                                // CodecCanonHuffman batches of 120 x 150 with a wave / a lane per tile: 1,280 tiles 0.152 / 0.167, 3,000
+                                                // 0.241 / 0.237, 4,096 0.317 / 0.291; 4,096 tiles of 256 x 256: 1.101 / 1.066 -- the tree walk's own
+                                                // threshold, GF_PREPASS_ONE_LANE_MAX, is 4,096)
+#endif
+    if (nTiles <= GF_CANON_PREPASS_ONE_LANE_MAX)
         hipLaunchKernelGGL(k_canon_parse_lengths<1>, dim3((unsigned)nTiles), dim3(64), 0, stream, blob, blobBytes, offsets, slotStride,
                            lengths, recs, nTiles, lsopContainer, clearFlags);
     else

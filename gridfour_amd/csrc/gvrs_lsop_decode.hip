@@ -284,7 +284,10 @@ __global__ __launch_bounds__(64) void k_lsop_head(GfLsopHeadArgs a)
     r2[3] = headDone ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(DEC_THREADS, 8) void k_lsop_unpack2(GfLsopUnpackArgs a)
+#ifndef GF_LSOP_UNPACK_WAVES
+#define GF_LSOP_UNPACK_WAVES 8                                 // (waves per SIMD the register budget is cut for: experiment builds)
+#endif
+__global__ __launch_bounds__(DEC_THREADS, GF_LSOP_UNPACK_WAVES) void k_lsop_unpack2(GfLsopUnpackArgs a)
 {
     __shared__ CanonDec S;
 
