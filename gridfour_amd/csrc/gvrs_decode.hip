@@ -3303,10 +3303,14 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     // the predicated turn above all serves sixty-four DIFFERENT trees per instruction -- for one tree it was 95 dependent scalar
     // instructions per leaf, 25 us of a one-tile decode call's 66 on the device (profiles/r05_v3/single_tile_timeline.txt).  Here the same
     // steps with plain branches; the leaf records collect in LDS and leave together, a lane a leaf.  Same acceptance rule.
-    __shared__ uint32_t leafLds[perWave == 1u ? 3 * 256 : 1];
+    // (round 6: the walk was a hundred scalar instructions per leaf -- 21 us of a one-tile decode call, 37 us of the 165 us of a
+    // 1,024-tile batch, where four such walks share a CU's scalar unit.  What it no longer does per leaf: it does not tell the kinds of
+    // M32 bytes apart (the lanes do that over the finished records), it does not switch the wave's lanes off and on around three LDS
+    // stores (every lane stores the same record, four words in one store), it takes its minima on the scalar unit.)
+    __shared__ __attribute__((aligned(16))) uint32_t leafLds[perWave == 1u ? 4 * 256 : 4];
     if constexpr (perWave == 1u) {
         uint64_t fbuf = buf, c = 0;
-        uint32_t fhave = have, nextW = (next - 10u) >> 2, fbp = bp, L = 1, leaves = 0, fmax = 1, fkinds = 0;
+        uint32_t fhave = have, nextW = (next - 10u) >> 2, fbp = bp, L = 1, leaves = 0, fmax = 1;
         const uint32_t depthCap = min(nLeaves, (uint32_t)MAX_DEPTH);
         bool closed = false, bad = rootBit != 0u;
         while (leaves < nLeaves && !bad && !closed) {
@@ -3316,7 +3320,8 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
                 nextW++;
             }
             uint32_t z = fbuf ? (uint32_t)__builtin_ctzll(fbuf) : 64u;
-            z = min(min(z, fhave), 63u);
+            z = z < fhave ? z : fhave;
+            z = z < 63u ? z : 63u;
             c <<= z;
             L += z;
             fbuf >>= z;
@@ -3326,16 +3331,13 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             if (fhave >= 9u && ((uint32_t)fbuf & 1u)) {
                 const uint32_t sym = ((uint32_t)fbuf >> 1) & 0xffu;
                 const uint64_t code = __brevll(c) >> (64u - L);
-                if (lane == 0u) {
-                    leafLds[leaves] = (uint32_t)code;
-                    leafLds[256u + leaves] = (uint32_t)(code >> 32);
-                    leafLds[512u + leaves] = L | (sym << 8);
-                }
+                GfU4 recW;
+                recW.x = (uint32_t)code; recW.y = (uint32_t)(code >> 32); recW.z = L | (sym << 8); recW.w = 0u;
+                reinterpret_cast<GfU4 *>(leafLds)[leaves] = recW;        // (by every lane: the same words to the same place)
                 fbuf >>= 9;
                 fhave -= 9u;
                 fbp += 9u;
-                fkinds |= kindOf(sym);
-                fmax = max(fmax, L);
+                fmax = fmax > L ? fmax : L;
                 leaves++;
                 const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;
                 if (t1 >= L) closed = true;
@@ -3350,14 +3352,18 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             walked = true;
             bp = fbp;
             maxLen = fmax;
-            symKinds = fkinds;
             __syncthreads();                                        // (one wave: the records are in LDS)
+            bool intro = false, nul = false;
             for (uint32_t i = lane; i < nLeaves; i += 64u) {
-                codes[i] = ((unsigned long long)leafLds[256u + i] << 32) | leafLds[i];
-                const uint32_t ls = leafLds[512u + i];
-                lens[i] = (uint8_t)ls;
-                syms[i] = (uint8_t)(ls >> 8);
+                const GfU4 r4 = reinterpret_cast<const GfU4 *>(leafLds)[i];
+                codes[i] = ((unsigned long long)r4.y << 32) | r4.x;
+                const uint32_t sym = r4.z >> 8;
+                lens[i] = (uint8_t)r4.z;
+                syms[i] = (uint8_t)sym;
+                intro = intro || sym == 0x7fu || sym == 0x81u;
+                nul = nul || sym == 0x80u;
             }
+            symKinds = (__any(intro) ? GF_TREE_HAS_INTRODUCER : 0u) | (__any(nul) ? GF_TREE_HAS_NULL : 0u);
         }
 #endif
     } else {
