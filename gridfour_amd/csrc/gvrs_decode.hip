@@ -2583,7 +2583,7 @@ __global__ __launch_bounds__(DEC_THREADS, MODE >= 2 ? GF_DEC_WGS : GF_DEC_WGS_GE
             // the one-tile-per-call path has no second run: the tile keeps GF_K_RETRY and the caller sees to it)
             const uint32_t rec0 = PRE ? preRec[0] : (a.trees + t * GF_TREE_REC_WORDS)[0];
             const uint32_t rec3 = PRE ? preRec[3] : (a.trees + t * GF_TREE_REC_WORDS)[3];
-            if (!ROOMY && a.ldsM32Roomy && !a.lean && rec0 == (uint32_t)GF_K_OK && (rec3 & GF_TREE_ROOMY)) {
+            if (!ROOMY && a.ldsM32Roomy && !a.noRoomyRun && !a.lean && rec0 == (uint32_t)GF_K_OK && (rec3 & GF_TREE_ROOMY)) {
                 __syncthreads();
                 continue;
             }
@@ -3596,6 +3596,10 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         // the runs is correct for any data.
         const bool roomyLikely = !a.roomySeenHost || *(volatile const uint32_t *)a.roomySeenHost != 1u;
         const bool beside = a.ldsM32Roomy && side && side->stream && a.nTiles >= 4096 && roomyLikely;
+        // (round 6) a SMALL batch whose predecessors listed no tile for the roomy run does without its launch (5 us of BASELINE config
+        // 2's 165): should the pre-pass list a tile after all, the first run tries it, the general kernel takes it, and the next batch knows
+        const bool noRoomy = a.ldsM32Roomy && !roomyLikely && a.nTiles < 4096;
+        f.noRoomyRun = noRoomy ? 1 : 0;
         GfDecodeArgs r = f;
         r.ldsM32Bytes = a.ldsM32Roomy;
         // (persistent workgroups: as many as the chip holds of them -- LDS in 1,280-byte steps, 256 CUs -- and never more than tiles)
@@ -3627,7 +3631,7 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
             if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, side->join, 0)) != hipSuccess) return e;
         } else {
-            if (a.ldsM32Roomy) hipLaunchKernelGGL(k_huffman_decode<DEC_FAST_ROOMY>, dim3(roomyGrid), dim3(DEC_THREADS), dynRoomy, stream, r);
+            if (a.ldsM32Roomy && !noRoomy) hipLaunchKernelGGL(k_huffman_decode<DEC_FAST_ROOMY>, dim3(roomyGrid), dim3(DEC_THREADS), dynRoomy, stream, r);
             hipLaunchKernelGGL(k_huffman_decode<DEC_FAST>, gf_tile_grid(a.nTiles), dim3(DEC_THREADS), dyn, stream, f);
         }
     }

@@ -138,6 +138,8 @@ struct GfDecodeArgs {
                                // bits in tree, packing bytes - 10, 256-bin histogram of the M32 bytes); no values are written
     uint32_t *pairCounts;      // analyze mode, may be null: GF_PAIR_TABLES x 65536 counters, [predictor][prior << 8 | value] of
                                // neighbouring M32 bytes (CodecStats.addCountsForM32 :150-156), added to with atomics
+    int noRoomyRun;            // (set by gf_launch_huffman_decode, round 6) the roomy run is not launched for this batch: the first run
+                               // takes the tiles the pre-pass gave to it as well (what it cannot hold goes to the general kernel)
 };
 constexpr int GF_ANALYSIS_WORDS = 260;
 constexpr int GF_PAIR_TABLES = 5;               // one 65536-bin table of byte pairs per predictor code (CodecStats.sB)

@@ -72,6 +72,32 @@ def test_small_rough_batch_takes_the_one_stream_form():
     b.free()
 
 
+def test_small_batches_do_without_the_roomy_launch_when_none_is_expected():
+    """Round 6: a batch of fewer than 4,096 tiles whose predecessors on the context listed no tile for the roomy run is decoded without
+    that launch -- a rough batch behind smooth ones then has its roomy tiles tried by the first run and taken by the general kernel, and
+    the batch after it gets the roomy run again."""
+    import gridfour_amd
+    ctx = gridfour_amd.GvrsHipContext(0)
+    nr, nc, nt = 120, 150, 1300
+    b = gridfour_amd.DeviceTileBatch(ctx, nr, nc, nt)
+    smooth, rough = 0, oracle.DEM_STYLE_ROUGH
+    seen = 0
+    for k, style in enumerate([smooth, smooth, rough, rough, smooth, smooth, smooth, rough, smooth, rough, rough]):
+        vals = _roundtrip(b, ctx, style, tile0=2000 + 700 * (k % 4), sample=173)
+        if style == rough:
+            seen += _n_roomy(vals, nr, nc, b.get_lengths(), b)
+    assert seen > 0, "the rough surface no longer has tiles for the roomy run"
+    # ... and without a synchronisation between the batches (the hint lags)
+    for style in (smooth, rough, smooth, rough):
+        b.synth_dem(SEED, 144, tile0=2500, style=style)
+        b.encode(codec_index=0)
+        b.decode()
+        b.decode()
+    ctx.synchronize()
+    assert (b.get_dec_status() == 0).all() and np.array_equal(b.get_decoded(), b.get_values())
+    b.free()
+
+
 def test_two_stream_decode_replayed_from_a_graph():
     """fork / join events inside a stream capture: the side stream joins the capture and leaves it"""
     import gridfour_amd
