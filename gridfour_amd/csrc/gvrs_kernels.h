@@ -292,8 +292,9 @@ struct GfLsopPlaneGeom {
 __host__ __device__ inline GfLsopPlaneGeom gf_lsop_plane_geom(uint32_t nR, uint32_t nC)
 {
     GfLsopPlaneGeom g{};
-    if (nR < 6u || nC < 32u || nC > 4096u || nR > 2048u) return g;      // (narrow tiles: a row's two ends would share a round; tall ones:
-                                                                          // k_lsop_unpack2 keeps the rows' initialisers in 8 KB of LDS)
+    if (nR < 6u || nC < 32u || nC > 4096u || nR > 1024u) return g;      // (narrow tiles: a row's two ends would share a round; tall ones:
+                                                                          // k_lsop_unpack2 keeps the rows' 4 (nR - 2) initialisers in the
+                                                                          // 4 KB of its token table)
     const uint32_t nInit = 4u * nR + 2u * nC - 9u, nInt = (nR - 2u) * (nC - 4u), L = GF_LSOP_PLANE_LANES;
     g.P = ((nC > GF_LSOP_PIPE_MIN_P ? nC : GF_LSOP_PIPE_MIN_P) + 15u) & ~15u;
     g.nPh = (nR - 2u + L - 1u) / L;

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(DEC_THREADS, GF_LSOP_UNPACK_WAVES) void k_lsop_unpa
             // table's words (the stage ends in front of them); the stream is staged a WINDOW of whole rows at a time -- one window
             // where it fits (terrain tiles of 120 x 150: 17,228 values), three for 256 x 256 --, and behind each window its rows go
             // to the plane.
-            const uint32_t nSpec = 4u * (nR - 2u), specRoom = a.plane.ok ? (nSpec + 15u) & ~15u : 0u;
+            const uint32_t nSpec = 4u * (nR - 2u), specRoom = a.plane.ok ? (nSpec + 15u) & ~15u : 0u;      // (<= 4,096: gf_lsop_plane_geom)
             const uint32_t stageCap = (uint32_t)(4 * sizeof(S.qe)) + (capWords - usedWords) * 4u + 4096u - specRoom;
             uint8_t *const spec = reinterpret_cast<uint8_t *>(cdLdsText + capWords) + 4096u - specRoom;   // [4][nR - 2]: column 0, column 1, the 2 (nR - 2) tail cells
             const uint32_t wI = nC - 4u;

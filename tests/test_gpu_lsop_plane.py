@@ -52,9 +52,10 @@ def _check(codec, nr, nc, tiles, codec_index=1):
 
 
 # nC < 32: never a plane; 9x40, 20x36: the plane does not fit the residual slot; 256x256: the stage does not hold the stream; the others
-# take the plane path with 1 .. 5 rows per lane, periods of 112 (narrow tiles), nC rounded up, exactly nC (160, 208)
+# take the plane path with 1 .. 5 rows per lane, periods of 112 (narrow tiles), nC rounded up, exactly nC (160, 208); 256x256 and
+# 1000x40 in several windows
 SHAPES = [(40, 31), (9, 40), (20, 36), (34, 32), (35, 33), (66, 47), (67, 112), (40, 113), (98, 160), (120, 150), (131, 64), (50, 208),
-          (34, 250), (256, 256)]
+          (34, 250), (256, 256), (1000, 40), (1030, 40)]    # (the last two: 32 rows per lane and 3,992 initialisers in the table; more than 1,024 rows: no plane)
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%d" % s)
