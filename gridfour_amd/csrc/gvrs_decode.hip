@@ -3597,8 +3597,16 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
         const bool roomyLikely = !a.roomySeenHost || *(volatile const uint32_t *)a.roomySeenHost != 1u;
         const bool beside = a.ldsM32Roomy && side && side->stream && a.nTiles >= 4096 && roomyLikely;
         // (round 6) a SMALL batch whose predecessors listed no tile for the roomy run does without its launch (5 us of BASELINE config
-        // 2's 165): should the pre-pass list a tile after all, the first run tries it, the general kernel takes it, and the next batch knows
-        const bool noRoomy = a.ldsM32Roomy && !roomyLikely && a.nTiles < 4096;
+        // 2's 165): should the pre-pass list a tile after all, the first run tries it, the general kernel takes it, and the next batch
+        // knows.  What a stale hint costs (-DGF_DEC_FORCE_NO_ROOMY on the rough surface): 1,024 tiles of 120 x 150 0.304 -> 0.339 ms,
+        // 1,300 0.350 -> 0.384, 3,000 0.530 -> 0.669 -- hence small batches only.  (For every batch, with a reduced grid for the run
+        // where none is expected: a caller that queues a smooth batch and then rough ones without waiting had each of them draw
+        // its 650 roomy tiles through 64 workgroups -- the default bench line's rough sub-record, 1.37 -> 2.38 ms; taken back.)
+#ifdef GF_DEC_FORCE_NO_ROOMY                                        // (experiment builds)
+        const bool noRoomy = a.ldsM32Roomy && a.nTiles < 4096;
+#else
+        const bool noRoomy = a.ldsM32Roomy && !roomyLikely && a.nTiles < 2048;
+#endif
         f.noRoomyRun = noRoomy ? 1 : 0;
         GfDecodeArgs r = f;
         r.ldsM32Bytes = a.ldsM32Roomy;
@@ -3618,10 +3626,6 @@ hipError_t gf_launch_huffman_decode(const GfDecodeArgs &a, hipStream_t stream, u
             (void)hipGetLastError();
             const size_t perCu = std::max<size_t>(1, std::min<size_t>((size_t)ldsPerCu / per, 2048 / DEC_THREADS));
             roomyGrid = (unsigned)std::min<size_t>(a.nTiles, perCu * (size_t)cus);
-            // (round 6) a batch whose predecessors listed no tile for this run starts a workgroup per four CUs only: the launch of
-            // 512 workgroups of 55 KB that find an empty list was 10 us of a smooth batch's 0.67 ms; should the list not be empty after
-            // all, the few draw its tiles one after the other and the next batch knows
-            if (!roomyLikely) roomyGrid = std::min<unsigned>(roomyGrid, (unsigned)std::max(1, cus / 4));
         }
         if (beside) {
             if ((e = hipEventRecord(side->fork, stream)) != hipSuccess) return e;            // (behind the pre-pass)
