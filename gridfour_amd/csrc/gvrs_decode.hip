@@ -3308,7 +3308,141 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
     // M32 bytes apart (the lanes do that over the finished records), it does not switch the wave's lanes off and on around three LDS
     // stores (every lane stores the same record, four words in one store), it takes its minima on the scalar unit.)
     __shared__ __attribute__((aligned(16))) uint32_t leafLds[perWave == 1u ? 4 * 256 : 4];
+#ifndef GF_PT_NO_SCAN                                               // (experiment builds: the walk alone)
     if constexpr (perWave == 1u) {
+        // THE WALK AS SCANS (round 6).  What is sequential in a serialised tree is less than the walk makes it:
+        //   * where the records start -- a branch is one bit, a leaf nine -- is a transducer with nine states (bits still to skip): a
+        //     lane takes forty bits, works out backwards, for each of the nine states it may be entered in, the state it is left in
+        //     (E[p] = bit p ? E[p + 9] : E[p + 1], nine of them in a register), a scalar chain hands the states from lane to lane
+        //     (two v_readlane and a shift per lane in use), and every lane then walks its own forty bits from its true first record;
+        //   * which leaf is which, and how many branch records stand in front of each, are prefix sums over the lanes;
+        //   * only the code lengths are a recurrence over the LEAVES (a leaf's depth is its predecessor's, minus the ones its path
+        //     ends in, plus the branch records between them): some twenty scalar instructions per leaf where the walk has eighty,
+        //     the records written from registers afterwards, a lane a leaf.
+        // Accepted under the walk's own rule: as many leaves and branch records as a tree of nLeaves leaves has, closed by its last
+        // leaf and not before, no code deeper than a register; anything else goes on to the walk below.
+        const uint32_t T = 10u * nLeaves + 7u;                        // bits of a well-formed tree behind packing bit 80
+        // (batches only: four such waves share a CU's scalar unit there -- 1,024 tiles of 200 x 200: 30.3 -> 26.5 us; alone on the chip the
+        // walk below is the shorter chain -- one tile per call: 69.3 us with it, 70.6-72.6 us with the scans)
+        if (nTiles >= 64u && rootBit == 0u && nLeaves >= 2u && T <= 8u * (visible - 10u)) {
+            uint32_t *tile = leafLds, *gbArr = leafLds + 128, *symArr = leafLds + 384;
+            tile[lane] = stage0;
+            tile[64u + lane] = stage1;
+            __syncthreads();
+            const uint32_t b0 = 9u + 40u * lane, w = b0 >> 5, sh = b0 & 31u;
+            uint64_t cb = (((uint64_t)tile[w + 1u] << 32) | tile[w]) >> sh;
+            if (sh > 16u) cb |= (uint64_t)tile[w + 2u] << (64u - sh);
+            cb &= (1ull << 48) - 1ull;
+            // the state a record walk leaves the lane's forty bits in, for each state it may enter them in
+            // (nine nibbles: E[p + 1] .. E[p + 8] in wLo, E[p + 9] in wHi; 32-bit steps, the forty of them unrolled)
+            uint32_t wLo = 0x76543210u, wHi = 8u;
+            {
+                const uint32_t cbLo = (uint32_t)cb, cbHi = (uint32_t)(cb >> 32);
+#pragma unroll
+                for (int p = 39; p >= 0; p--) {
+                    const bool bit = p >= 32 ? ((cbHi >> (p - 32)) & 1u) != 0u : ((cbLo >> p) & 1u) != 0u;
+                    const uint32_t e = bit ? wHi : wLo & 15u;
+                    wHi = wLo >> 28;
+                    wLo = (wLo << 4) | e;
+                }
+            }
+            const uint32_t nLanes = (T - 9u + 39u) / 40u;             // lanes with bits of the tree
+            uint32_t ent = 0;
+            {
+                uint32_t sState = 0;
+                for (uint32_t l = 0; l < nLanes; l++) {
+                    ent = l == lane ? sState : ent;
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)wLo, (int)l), hi = (uint32_t)__builtin_amdgcn_readlane((int)wHi, (int)l);
+                    sState = sState < 8u ? (lo >> (4u * sState)) & 15u : hi & 15u;
+                }
+            }
+            // the lane's own records: leaves (at most five: nine bits each) with the branch records in front of them in this lane
+            uint32_t nLeaf = 0, nb = 0, nbPack = 0;
+            uint64_t symPack = 0;
+            {
+                uint32_t p = ent;
+                const uint32_t lim = lane < nLanes ? min(40u, T - b0) : 0u;
+                while (__any(p < lim)) {
+                    const bool live = p < lim;
+                    const bool leaf = live && ((cb >> (p & 63u)) & 1ull);
+                    const uint32_t sym = (uint32_t)(cb >> ((p + 1u) & 63u)) & 0xffu;
+                    symPack |= leaf ? (uint64_t)sym << (8u * nLeaf) : 0ull;
+                    nbPack |= leaf ? nb << (6u * nLeaf) : 0u;
+                    nLeaf += leaf ? 1u : 0u;
+                    nb += live && !leaf ? 1u : 0u;
+                    p += leaf ? 9u : live ? 1u : 0u;
+                }
+            }
+            const uint32_t leafIncl = gf_wave_incl_scan(nLeaf), nbIncl = gf_wave_incl_scan(nb);
+            const uint32_t totalLeaves = (uint32_t)__builtin_amdgcn_readlane((int)leafIncl, 63);
+            const uint32_t totalBranches = (uint32_t)__builtin_amdgcn_readlane((int)nbIncl, 63);
+            if (totalLeaves == nLeaves && totalBranches == nLeaves - 2u) {
+                const uint32_t leafBase = leafIncl - nLeaf, nbBase = nbIncl - nb;
+#pragma unroll
+                for (uint32_t j = 0; j < 5; j++)
+                    if (j < nLeaf) {
+                        gbArr[leafBase + j] = nbBase + ((nbPack >> (6u * j)) & 63u);
+                        symArr[leafBase + j] = (uint32_t)(symPack >> (8u * j)) & 0xffu;
+                    }
+                __syncthreads();
+                // the code lengths: a scalar recurrence over the leaves, sixty-four of them at a time (branch runs in a register's lanes)
+                uint32_t cLo[4], cHi[4], lenR[4];
+                uint64_t c = 0;
+                uint32_t L = 1;
+                const uint32_t depthCap = min(nLeaves, (uint32_t)MAX_DEPTH);
+                bool bad = false, closed = false;
+#pragma unroll
+                for (uint32_t blk = 0; blk < 4; blk++) {
+                    cLo[blk] = 0; cHi[blk] = 0; lenR[blk] = 0;
+                    const uint32_t i = 64u * blk + lane;
+                    const uint32_t zMine = i < nLeaves ? gbArr[i] - (i ? gbArr[i - 1u] : 0u) : 0u;
+                    const uint32_t cnt = nLeaves > 64u * blk ? min(64u, nLeaves - 64u * blk) : 0u;
+                    for (uint32_t k = 0; k < cnt && !bad && !closed; k++) {
+                        const uint32_t z = (uint32_t)__builtin_amdgcn_readlane((int)zMine, (int)k);
+                        if (L + z - 1u > depthCap) { bad = true; break; }
+                        c <<= z;
+                        L += z;
+                        cLo[blk] = k == lane ? (uint32_t)c : cLo[blk];
+                        cHi[blk] = k == lane ? (uint32_t)(c >> 32) : cHi[blk];
+                        lenR[blk] = k == lane ? L : lenR[blk];
+                        const uint32_t t1 = ~c ? (uint32_t)__builtin_ctzll(~c) : 64u;
+                        if (t1 >= L) { closed = true; bad = 64u * blk + k + 1u != nLeaves; break; }
+                        c = (c >> t1) | 1ull;
+                        L -= t1;
+                    }
+                }
+#ifndef GF_PT_FORCE_EXACT                                           // (test builds: every tree through the exact walk)
+                if (!bad && closed) {
+                    walked = true;
+                    bp = 80u + T;
+                    uint32_t fmax = 0;
+                    bool intro = false, nul = false;
+#pragma unroll
+                    for (uint32_t blk = 0; blk < 4; blk++) {
+                        const uint32_t i = 64u * blk + lane;
+                        if (i < nLeaves) {
+                            const uint32_t Li = lenR[blk], sym = symArr[i];
+                            codes[i] = __brevll(((unsigned long long)cHi[blk] << 32) | cLo[blk]) >> (64u - Li);
+                            lens[i] = (uint8_t)Li;
+                            syms[i] = (uint8_t)sym;
+                            fmax = max(fmax, Li);
+                            intro = intro || sym == 0x7fu || sym == 0x81u;
+                            nul = nul || sym == 0x80u;
+                        }
+                    }
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) fmax = max(fmax, (uint32_t)__shfl_xor((int)fmax, o));
+                    maxLen = fmax;
+                    symKinds = (__any(intro) ? GF_TREE_HAS_INTRODUCER : 0u) | (__any(nul) ? GF_TREE_HAS_NULL : 0u);
+                }
+#endif
+            }
+            __syncthreads();                                            // (the walk below writes the same LDS words)
+        }
+    }
+#endif
+    if constexpr (perWave == 1u) {
+      if (!walked) {
         uint64_t fbuf = buf, c = 0;
         uint32_t fhave = have, nextW = (next - 10u) >> 2, fbp = bp, L = 1, leaves = 0, fmax = 1;
         const uint32_t depthCap = min(nLeaves, (uint32_t)MAX_DEPTH);
@@ -3366,6 +3500,7 @@ __global__ __launch_bounds__(64) void k_huffman_parse_trees(const uint8_t *__res
             symKinds = (__any(intro) ? GF_TREE_HAS_INTRODUCER : 0u) | (__any(nul) ? GF_TREE_HAS_NULL : 0u);
         }
 #endif
+      }
     } else {
         uint64_t fbuf = buf, c = 0;
         uint32_t fhave = have, nextW = (next - 10u) >> 2, fbp = bp, L = 1, leaves = 0, fmax = 1, fkinds = 0;

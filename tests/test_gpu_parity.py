@@ -310,6 +310,43 @@ def test_tree_tie_breaking_on_device(codec):
         b.free()
 
 
+def test_trees_of_every_shape_in_batches_of_the_wave_per_tile_prepass(codec):
+    """The serialised trees of the tie sets above -- two leaves, 250 equal ones, the deepest ones (depth 15 and 23), random ones -- in
+    batches of 64 .. 300 packings: the size at which a wave parses a tile's tree, with its scans (round 6: record starts by a 9-state
+    transducer, leaf and branch counts by prefix sums, the code lengths by a recurrence over the leaves) in front of the walks.  Each
+    packing decodes to the oracle's cells; a damaged copy of each (a flipped bit inside the serialised tree) to the oracle's verdict."""
+    sets = list(_tie_symbol_sets())
+    rng = np.random.default_rng(99)
+    for data in sets:
+        res = data.astype(np.int64) - 125
+        v = np.concatenate([[1000], 1000 + np.cumsum(res)]).astype(np.int32)
+        n = v.size
+        ref, _ = oracle.codec_huffman_encode(0, 1, n, v, predictor_mask=1)
+        n_leaves = ref[10] + 1
+        tree_bits = 10 * n_leaves + 7 if n_leaves >= 2 else 17
+        packs, damaged = [], []
+        for k in range(int(rng.integers(64, 301))):
+            if k % 3 == 2:
+                b = bytearray(ref)
+                bit = 80 + int(rng.integers(0, tree_bits))
+                b[bit >> 3] ^= 1 << (bit & 7)
+                packs.append(bytes(b))
+                damaged.append(True)
+            else:
+                packs.append(ref)
+                damaged.append(False)
+        vals, st = codec.decode_batch(1, n, packs)
+        for k, pk in enumerate(packs):
+            try:
+                want = oracle.codec_huffman_decode(1, n, pk)
+            except Exception:
+                want = None
+            if want is None:
+                assert st[k] != 0, (len(set(data.tolist())), k)
+            else:
+                assert st[k] == 0 and np.array_equal(vals[k], want), (len(set(data.tolist())), k, int(st[k]), damaged[k])
+
+
 @pytest.mark.parametrize("shape", [(120, 150), (200, 200), (64, 64)], ids=lambda s: "%dx%d" % s)
 def test_bits_crowded_into_part_of_the_tile(codec, shape):
     """The packer deals a tile's cells out to its waves by count, with room for a quarter more bits than the average share: tiles
